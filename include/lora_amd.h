@@ -1,0 +1,180 @@
+/*
+ * lora_amd.h — C-ABI of the MI355X (gfx950) LoRA hot-path kernels.
+ *
+ * The reference (cloneofsimo/lora) has no FFI: its hot path is a sequence of
+ * ATen calls issued from Python.  Each entry point below replaces one such
+ * sequence; the `replaces:` tag names the reference lines (paths relative to
+ * /root/reference).  A reference maintainer binds these with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless the
+ *     parameter name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *     the call never synchronises, allocates or frees (hipGraph-capturable);
+ *   - row-major, contiguous unless a leading dimension `ld*` is given;
+ *   - return value: LORA_AMD_OK or a negative LORA_AMD_E* code; the message of
+ *     the last failure on the calling thread is lora_amd_last_error().
+ */
+#ifndef LORA_AMD_H
+#define LORA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LORA_AMD_ABI_VERSION 1
+
+/* status codes */
+#define LORA_AMD_OK 0
+#define LORA_AMD_EINVAL (-1)   /* bad argument (shape, dtype, alignment, null) */
+#define LORA_AMD_ERANK (-2)    /* rank r outside [1, LORA_AMD_MAX_RANK] */
+#define LORA_AMD_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
+#define LORA_AMD_EWORKSPACE (-4) /* workspace too small */
+
+#define LORA_AMD_MAX_RANK 64
+
+/* element types of activations / frozen weights */
+#define LORA_AMD_F32 0
+#define LORA_AMD_F16 1
+#define LORA_AMD_BF16 2
+
+/* layout of a small (low-rank) factor */
+#define LORA_AMD_FACTOR_RK 0 /* [r, K]  (lora_down.weight, lora.py:44) */
+#define LORA_AMD_FACTOR_KR 1 /* [K, r]  (lora_up.weight,   lora.py:46) */
+
+/* rounding of the merge kernel */
+#define LORA_AMD_ROUND_REFERENCE 0 /* round exactly where collapse_lora does */
+#define LORA_AMD_ROUND_ONCE 1      /* fp32 throughout, one final rounding   */
+
+int lora_amd_abi_version(void);
+const char *lora_amd_last_error(void);
+/* gfx arch string the library was compiled for ("gfx950"). */
+const char *lora_amd_target_arch(void);
+
+/* ------------------------------------------------------------------------
+ * K3  fused merge  W' = W + alpha * (up @ down)
+ * replaces: lora_diffusion/lora.py:646-655 (Linear) and :659-669 (Conv2d,
+ *           both factors flattened from dim 1) — mm + mul + add + new Parameter.
+ *
+ * One descriptor per adapter site; ALL sites are merged by ONE launch.
+ * `rows_per_tile`/`cols_per_tile` are chosen by lora_amd_merge_plan().
+ * ---------------------------------------------------------------------- */
+typedef struct lora_amd_merge_site {
+  const void *w_in;  /* [N, K] frozen weight, w_dtype                        */
+  void *w_out;       /* [N, K] result, w_dtype; may alias w_in (in place)    */
+  const void *up;    /* [N, r] ab_dtype  (lora_up.weight,   flattened)       */
+  const void *down;  /* [r, K] ab_dtype  (lora_down.weight, flattened)       */
+  int32_t N, K, r;
+  int32_t rows_per_tile; /* filled by lora_amd_merge_plan */
+  int32_t cols_per_tile; /* filled by lora_amd_merge_plan; multiple of 8     */
+  int32_t tiles_k;       /* filled by lora_amd_merge_plan                    */
+  int64_t tile_begin;    /* filled by lora_amd_merge_plan (exclusive scan)   */
+  int32_t flags;         /* filled by lora_amd_merge_plan; bit 0: 16-byte lanes
+                            (K % 8 == 0 and w_in/w_out 16-byte aligned)      */
+  int32_t reserved;
+} lora_amd_merge_site;
+
+/* Host-side planner: fills rows_per_tile/cols_per_tile/tiles_k/tile_begin/flags of
+ * `sites_host[0..n_sites)` and returns the total tile count in *total_tiles.
+ * Pure CPU arithmetic: callable without a GPU. */
+int lora_amd_merge_plan(lora_amd_merge_site *sites_host, int32_t n_sites,
+                        int32_t w_dtype, int64_t *total_tiles);
+
+/* `sites_dev`: the planned descriptor array copied to device memory.
+ * alpha: collapse_lora's alpha (lora.py:635).  A negative alpha un-merges. */
+int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev,
+                           int32_t n_sites, int64_t total_tiles,
+                           int32_t w_dtype, int32_t ab_dtype, float alpha,
+                           int32_t rounding, void *stream);
+
+/* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
+ * target elements per tile and resident workgroups per CU. */
+int lora_amd_merge_set_tuning(int64_t tile_elems, int64_t blocks_per_cu);
+
+/* ------------------------------------------------------------------------
+ * K1/K2 primitives.  LoraInjectedLinear.forward (lora.py:53-58) is
+ *     T = rowdot(X, down)            lora.py:56  self.lora_down(input) [+ selector]
+ *     Y = rank_update(Y0, T, up, s)  lora.py:56-57 lora_up, dropout, *scale, +
+ * and its autograd (implicit in the reference) is
+ *     Gt = rowdot(G, up, scale=s)          dT
+ *     dUp   += colreduce(G, T,  s)         [N, r]
+ *     dDown += colreduce(X, Gt, 1)         [r, K]
+ *     dX  = rank_update(G @ W, Gt, down, 1)
+ * ---------------------------------------------------------------------- */
+
+/* T[M, r] (f32) = scale * X[M, K] @ F^T, F given as [r,K] or [K,r];
+ * optional selector S [r, r] (f32): T <- T @ S^T (sel_transposed=0, forward,
+ * lora.py:56,63-70) or T <- T @ S (sel_transposed=1, backward).  sel may be NULL. */
+int lora_amd_rowdot(const void *x, int64_t ldx, const void *factor, void *t_out,
+                    int64_t M, int32_t K, int32_t r, int32_t x_dtype,
+                    int32_t factor_dtype, int32_t factor_layout, float scale,
+                    const float *sel, int32_t sel_transposed, void *stream);
+
+/* Y[M, N] (y_dtype, in place) += scale * mask * T[M, r] (f32) @ F, F given as
+ * [r,N] or [N,r].  Dropout (lora.py:45,56): keep-probability 1-p with inverted
+ * scaling, generated in-kernel from Philox(seed, offset, element index); p = 0
+ * disables it.  The same (seed, offset) reproduces the same mask in rowdot_masked. */
+int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const void *factor,
+                         int64_t M, int32_t N, int32_t r, int32_t y_dtype,
+                         int32_t factor_dtype, int32_t factor_layout,
+                         float scale, float dropout_p, uint64_t seed,
+                         uint64_t offset, void *stream);
+
+/* As lora_amd_rowdot but X is first multiplied elementwise by the dropout mask
+ * of (seed, offset, p): the backward of a dropped-out rank_update. */
+int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *factor,
+                           void *t_out, int64_t M, int32_t K, int32_t r,
+                           int32_t x_dtype, int32_t factor_dtype,
+                           int32_t factor_layout, float scale, const float *sel,
+                           int32_t sel_transposed, float dropout_p,
+                           uint64_t seed, uint64_t offset, void *stream);
+
+/* D (f32) = beta * D + scale * sum_m T[m, j] * mask * X[m, k]; D is [r,K] or
+ * [K,r] per out_layout.  Two-stage reduction through `workspace` (bytes given
+ * by lora_amd_colreduce_workspace).  dropout args as above (p = 0: no mask). */
+size_t lora_amd_colreduce_workspace(int64_t M, int32_t K, int32_t r);
+int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out,
+                       int64_t M, int32_t K, int32_t r, int32_t x_dtype,
+                       int32_t out_layout, float scale, float beta,
+                       float dropout_p, uint64_t seed, uint64_t offset,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * C2/K6  flat-buffer gradient clipping + AdamW.
+ * replaces: train_lora_dreambooth.py:878-888 (clip_grad_norm_ over every UNet
+ *           parameter, AdamW.step, zero_grad) for the LoRA parameters, which
+ *           the trainer keeps in ONE flat f32 buffer (also the RCCL all-reduce
+ *           payload).
+ * ---------------------------------------------------------------------- */
+
+/* out_sumsq[0] (f32) = sum(g[i]^2).  workspace >= lora_amd_sumsq_workspace(n). */
+size_t lora_amd_sumsq_workspace(int64_t n);
+int lora_amd_sumsq(const float *g, int64_t n, float *out_sumsq, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+typedef struct lora_amd_adamw_group {
+  int64_t begin, end; /* element range [begin, end) of the flat buffer */
+  float lr;
+  float weight_decay;
+} lora_amd_adamw_group;
+
+/* One fused pass over the flat buffers.  clip coefficient is computed on the
+ * device from sumsq[0]: c = min(1, max_norm / (sqrt(sumsq) + 1e-6))
+ * (torch.nn.utils.clip_grad_norm_); max_norm <= 0 disables clipping.
+ * grad_scale multiplies g before clipping (1/world_size after a SUM all-reduce).
+ * `step` is the 1-based optimiser step (bias correction).  zero_grad != 0
+ * writes zeros back to g (optimizer.zero_grad, train_lora_dreambooth.py:888). */
+int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *exp_avg_sq,
+                        int64_t n, const lora_amd_adamw_group *groups_dev,
+                        int32_t n_groups, const float *sumsq, float grad_scale,
+                        float max_norm, float beta1, float beta2, float eps,
+                        int64_t step, int32_t zero_grad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORA_AMD_H */

@@ -1,0 +1,300 @@
+"""ctypes binding of the C-ABI in ``include/lora_amd.h`` (``csrc/liblora_amd.so``).
+
+The library is the product: every CUDA/HIP-device code path of this package goes
+through it and raises :class:`HipExtensionMissing` when it cannot be loaded —
+there is no eager/PyTorch fallback for device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblora_amd.so")
+
+OK = 0
+F32, F16, BF16 = 0, 1, 2
+FACTOR_RK, FACTOR_KR = 0, 1
+ROUND_REFERENCE, ROUND_ONCE = 0, 1
+MAX_RANK = 64
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+# every symbol include/lora_amd.h declares (tests check the .so exports them all)
+SYMBOLS = (
+    "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
+    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
+    "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
+    "lora_amd_colreduce_workspace", "lora_amd_colreduce",
+    "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw",
+)
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class MergeSite(C.Structure):
+    _fields_ = [
+        ("w_in", C.c_void_p), ("w_out", C.c_void_p), ("up", C.c_void_p), ("down", C.c_void_p),
+        ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32),
+        ("rows_per_tile", C.c_int32), ("cols_per_tile", C.c_int32), ("tiles_k", C.c_int32),
+        ("tile_begin", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class AdamWGroup(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+_lib: Optional[C.CDLL] = None
+_load_error: Optional[str] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+    lib.lora_amd_abi_version.restype = C.c_int
+    lib.lora_amd_last_error.restype = C.c_char_p
+    lib.lora_amd_target_arch.restype = C.c_char_p
+    lib.lora_amd_merge_plan.argtypes = [C.POINTER(MergeSite), i32, i32, C.POINTER(i64)]
+    lib.lora_amd_merge_batched.argtypes = [vp, i32, i64, i32, i32, f32, i32, vp]
+    lib.lora_amd_merge_set_tuning.argtypes = [i64, i64]
+    lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
+    lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
+                                           f32, u64, u64, vp]
+    lib.lora_amd_rank_update.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+    lib.lora_amd_colreduce_workspace.argtypes = [i64, i32, i32]
+    lib.lora_amd_colreduce_workspace.restype = sz
+    lib.lora_amd_colreduce.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, u64, u64,
+                                       vp, sz, vp]
+    lib.lora_amd_sumsq_workspace.argtypes = [i64]
+    lib.lora_amd_sumsq_workspace.restype = sz
+    lib.lora_amd_sumsq.argtypes = [vp, i64, vp, vp, sz, vp]
+    lib.lora_amd_clip_adamw.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, i64, i32, vp]
+    for name in ("lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_rowdot",
+                 "lora_amd_rowdot_masked", "lora_amd_rank_update", "lora_amd_colreduce", "lora_amd_sumsq",
+                 "lora_amd_clip_adamw"):
+        getattr(lib, name).restype = C.c_int
+
+
+def load() -> Optional[C.CDLL]:
+    """Load the library once; returns None (and records why) if that fails."""
+    global _lib, _load_error
+    if _lib is not None or _load_error is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        _load_error = f"{LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'`)"
+        return None
+    try:
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        if lib.lora_amd_abi_version() != 1:
+            raise OSError(f"ABI version {lib.lora_amd_abi_version()} != 1")
+        _lib = lib
+    except OSError as e:  # pragma: no cover - environment dependent
+        _load_error = f"cannot load {LIB_PATH}: {e}"
+    return _lib
+
+
+def available() -> bool:
+    return load() is not None
+
+
+def require() -> C.CDLL:
+    lib = load()
+    if lib is None:
+        raise HipExtensionMissing(
+            "lora_amd: the HIP extension is required for device tensors and is not loadable: " + str(_load_error))
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != OK:
+        msg = require().lora_amd_last_error().decode()
+        if rc == -2:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"lora_amd kernels support float32/float16/bfloat16, got {dt}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_check(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("lora_amd kernels take device tensors only")
+
+
+# ----------------------------------------------------------------------------- merge (K3)
+class MergePlan:
+    """Planned descriptor table for one (w_dtype, ab_dtype) group of sites, resident on the device."""
+
+    def __init__(self, sites: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]):
+        lib = require()
+        if len(sites) == 0:
+            raise ValueError("MergePlan: no sites")
+        w0, _, up0, _ = sites[0]
+        self.w_dtype, self.ab_dtype = w0.dtype, up0.dtype
+        self.device = w0.device
+        n = len(sites)
+        arr = (MergeSite * n)()
+        self.keep = []  # keep tensors alive as long as the plan
+        self.bytes_algorithmic = 0
+        for i, (w_in, w_out, up, down) in enumerate(sites):
+            _dev_check(w_in, w_out, up, down)
+            if w_in.dtype != self.w_dtype or w_out.dtype != self.w_dtype:
+                raise TypeError("MergePlan: mixed weight dtypes in one plan")
+            if up.dtype != self.ab_dtype or down.dtype != self.ab_dtype:
+                raise TypeError("MergePlan: mixed factor dtypes in one plan")
+            if not (w_in.is_contiguous() and w_out.is_contiguous() and up.is_contiguous() and down.is_contiguous()):
+                raise ValueError("MergePlan: tensors must be contiguous")
+            N = w_in.shape[0]
+            K = w_in.numel() // N
+            r = down.shape[0]
+            if up.shape[0] != N or up.numel() != N * r or down.numel() != r * K or w_out.shape != w_in.shape:
+                raise ValueError(f"MergePlan: site {i} shape mismatch W{tuple(w_in.shape)} up{tuple(up.shape)} "
+                                 f"down{tuple(down.shape)}")
+            s = arr[i]
+            s.w_in, s.w_out, s.up, s.down = w_in.data_ptr(), w_out.data_ptr(), up.data_ptr(), down.data_ptr()
+            s.N, s.K, s.r = N, K, r
+            self.keep.append((w_in, w_out, up, down))
+            self.bytes_algorithmic += 2 * N * K * w_in.element_size() + (N + K) * r * up.element_size()
+        total = C.c_int64(0)
+        _check(lib.lora_amd_merge_plan(arr, n, dtype_code(self.w_dtype), C.byref(total)), "lora_amd_merge_plan")
+        self.n_sites, self.total_tiles = n, total.value
+        self.host = arr
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(self.device)
+
+    def launch(self, alpha: float = 1.0, rounding: int = ROUND_REFERENCE) -> None:
+        lib = require()
+        _check(lib.lora_amd_merge_batched(self.table.data_ptr(), self.n_sites, self.total_tiles,
+                                          dtype_code(self.w_dtype), dtype_code(self.ab_dtype), float(alpha),
+                                          int(rounding), _stream()), "lora_amd_merge_batched")
+
+
+def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
+    require().lora_amd_merge_set_tuning(int(tile_elems), int(blocks_per_cu))
+
+
+# ----------------------------------------------------------------------------- K1/K2 primitives
+def _as2d(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("expected a 2-D tensor with unit inner stride")
+    return x
+
+
+def rowdot(x: torch.Tensor, factor: torch.Tensor, layout: int, scale: float = 1.0,
+           sel: Optional[torch.Tensor] = None, sel_transposed: bool = False, dropout_p: float = 0.0,
+           seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """T[M,r] (f32) = scale * (mask*X)[M,K] @ F^T (@ S^T | @ S)."""
+    lib = require()
+    _dev_check(x, factor, sel)
+    x = _as2d(x)
+    M, K = x.shape
+    factor = factor.contiguous()
+    r = factor.shape[0] if layout == FACTOR_RK else factor.shape[1]
+    if factor.numel() != r * K:
+        raise ValueError(f"rowdot: factor {tuple(factor.shape)} does not match K={K}")
+    if sel is not None:
+        sel = sel.to(torch.float32).contiguous()
+        if sel.shape != (r, r):
+            raise ValueError("rowdot: selector must be [r, r]")
+    t = torch.empty((M, r), dtype=torch.float32, device=x.device)
+    _check(lib.lora_amd_rowdot_masked(x.data_ptr(), x.stride(0), factor.data_ptr(), t.data_ptr(), M, K, r,
+                                      dtype_code(x.dtype), dtype_code(factor.dtype), layout, float(scale),
+                                      sel.data_ptr() if sel is not None else None, int(bool(sel_transposed)),
+                                      float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_rowdot")
+    return t
+
+
+def rank_update_(y: torch.Tensor, t: torch.Tensor, factor: torch.Tensor, layout: int, scale: float = 1.0,
+                 dropout_p: float = 0.0, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """Y[M,N] += scale * mask * T[M,r] @ F (in place)."""
+    lib = require()
+    _dev_check(y, t, factor)
+    y = _as2d(y)
+    M, N = y.shape
+    factor = factor.contiguous()
+    r = factor.shape[0] if layout == FACTOR_RK else factor.shape[1]
+    if t.dtype != torch.float32 or t.shape != (M, r) or not t.is_contiguous():
+        raise ValueError(f"rank_update: T must be contiguous f32 [{M},{r}]")
+    if factor.numel() != r * N:
+        raise ValueError(f"rank_update: factor {tuple(factor.shape)} does not match N={N}")
+    _check(lib.lora_amd_rank_update(y.data_ptr(), y.stride(0), t.data_ptr(), factor.data_ptr(), M, N, r,
+                                    dtype_code(y.dtype), dtype_code(factor.dtype), layout, float(scale),
+                                    float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_rank_update")
+    return y
+
+
+def colreduce(x: torch.Tensor, t: torch.Tensor, layout: int, scale: float = 1.0,
+              out: Optional[torch.Tensor] = None, beta: float = 0.0, dropout_p: float = 0.0, seed: int = 0,
+              offset: int = 0) -> torch.Tensor:
+    """D (f32, [r,K] or [K,r]) = beta*D + scale * T^T @ (mask*X)."""
+    lib = require()
+    _dev_check(x, t, out)
+    x = _as2d(x)
+    M, K = x.shape
+    r = t.shape[1]
+    if t.dtype != torch.float32 or t.shape[0] != M or not t.is_contiguous():
+        raise ValueError("colreduce: T must be contiguous f32 [M, r]")
+    shape = (r, K) if layout == FACTOR_RK else (K, r)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        beta = 0.0
+    elif out.dtype != torch.float32 or out.numel() != r * K or not out.is_contiguous():
+        raise ValueError("colreduce: out must be contiguous f32 with r*K elements")
+    ws_bytes = lib.lora_amd_colreduce_workspace(M, K, r)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+    _check(lib.lora_amd_colreduce(x.data_ptr(), x.stride(0), t.data_ptr(), out.data_ptr(), M, K, r,
+                                  dtype_code(x.dtype), layout, float(scale), float(beta), float(dropout_p),
+                                  int(seed), int(offset), ws.data_ptr(), ws.numel() * 4, _stream()),
+           "lora_amd_colreduce")
+    return out
+
+
+# ----------------------------------------------------------------------------- optimiser (C2/K6)
+def sumsq(g: torch.Tensor, out: torch.Tensor, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = require()
+    _dev_check(g, out)
+    if g.dtype != torch.float32 or not g.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("sumsq: contiguous f32 tensors expected")
+    nbytes = lib.lora_amd_sumsq_workspace(g.numel())
+    if ws is None:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
+    _check(lib.lora_amd_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()),
+           "lora_amd_sumsq")
+    return out
+
+
+def make_adamw_groups(groups: Sequence[Tuple[int, int, float, float]], device) -> torch.Tensor:
+    arr = (AdamWGroup * len(groups))()
+    for i, (b, e, lr, wd) in enumerate(groups):
+        arr[i].begin, arr[i].end, arr[i].lr, arr[i].weight_decay = int(b), int(e), float(lr), float(wd)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+def clip_adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, groups_dev: torch.Tensor,
+               n_groups: int, sumsq_t: Optional[torch.Tensor], grad_scale: float, max_norm: float, beta1: float,
+               beta2: float, eps: float, step: int, zero_grad: bool = True) -> None:
+    lib = require()
+    _dev_check(p, g, m, v, groups_dev, sumsq_t)
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("clip_adamw: flat contiguous f32 buffers of equal length expected")
+    _check(lib.lora_amd_clip_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                   groups_dev.data_ptr(), int(n_groups),
+                                   sumsq_t.data_ptr() if sumsq_t is not None else None, float(grad_scale),
+                                   float(max_norm), float(beta1), float(beta2), float(eps), int(step),
+                                   int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw")

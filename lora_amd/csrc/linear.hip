@@ -1,0 +1,663 @@
+// K1/K2 — the low-rank branch of LoraInjectedLinear (lora_diffusion/lora.py:53-58)
+// and of its autograd, as three HBM-streaming primitives:
+//
+//   rowdot       T[M,r]  = scale * X[M,K] @ F^T          (lora_down; dT in backward)
+//   rank_update  Y[M,N] += scale * mask * T[M,r] @ F      (lora_up + dropout + *scale + add)
+//   colreduce    D[r,K]  = beta*D + scale * T^T @ (mask*X) (dUp, dDown)
+//
+// The reference issues mm, mm, dropout, mul, add (5 launches, 3 extra [M,N]
+// round trips) forward and ~10 launches backward.  Here every activation byte is
+// touched once per primitive: each lane moves 16-byte chunks of 8 elements, the
+// small factor is staged in LDS as f32 (bank-conflict-free two-plane layout), the
+// per-row T vector sits in LDS, reductions over K are wave shuffles, reductions
+// over M are per-lane accumulators + an LDS tree + a second tiny kernel.
+// All of it is HBM-bound (AI ~ r flop/B): no MFMA here by design.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+constexpr int kThreads = 256;
+constexpr int kFactorLdsFloats = 8192;  // 32 KiB  [RT][cols]
+constexpr int kTLdsFloats = 2048;       // 8 KiB   [rows][RT]
+
+__device__ inline float ld_factor(const void *p, int dt, int64_t i) {
+  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
+  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
+  return (float)reinterpret_cast<const __bf16 *>(p)[i];
+}
+
+// Stage factor[:, c0:c0+ncols] (logical [r, C]; stored [r,C] or [C,r]) into LDS as
+// [RT][2][ncols/8][4] (vec) so that a lane's 8 columns are two 16-byte slots whose
+// addresses advance 16 B per lane (conflict-free ds_read_b128).  Ranks >= r are zero.
+template <int RT>
+__device__ inline void stage_factor_vec(float *s_f, const void *f, int fdt, int layout, int r,
+                                        int64_t C, int c0, int ncols) {
+  const int c8 = ncols >> 3;
+  for (int i = threadIdx.x; i < RT * ncols; i += kThreads) {
+    int j, c;
+    if (layout == LORA_AMD_FACTOR_RK) { j = i / ncols; c = i - j * ncols; }
+    else { c = i / RT; j = i - c * RT; }  // coalesced along r for [C, r]
+    float v = 0.f;
+    if (j < r) v = ld_factor(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * C + c0 + c
+                                                                   : (int64_t)(c0 + c) * r + j);
+    s_f[((j * 2 + ((c >> 2) & 1)) * c8 + (c >> 3)) * 4 + (c & 3)] = v;
+  }
+}
+
+template <int RT>
+__device__ inline void fma_chunk(const float *s_f, int c8, int cc, const float (&x)[8], float (&acc)[RT]) {
+#pragma unroll
+  for (int j = 0; j < RT; ++j) {
+    const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
+    const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + cc) * 4]);
+    float a = acc[j];
+    a = fmaf(x[0], d0.x, a); a = fmaf(x[1], d0.y, a); a = fmaf(x[2], d0.z, a); a = fmaf(x[3], d0.w, a);
+    a = fmaf(x[4], d1.x, a); a = fmaf(x[5], d1.y, a); a = fmaf(x[6], d1.z, a); a = fmaf(x[7], d1.w, a);
+    acc[j] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// rowdot: L lanes cooperate on one row (L = 2^logL chosen on the host so that
+// K/8 chunks divide evenly), a wave covers 64/L rows at a time, the K-reduction
+// finishes with logL xor-shuffles.  Lane 0 of each group applies scale/selector
+// and writes the r outputs.
+// ---------------------------------------------------------------------------
+template <class EX, int RT, bool MASKED>
+__global__ __launch_bounds__(kThreads) void rowdot_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
+    int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
+    int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
+    uint64_t seed, uint64_t offset) {
+  __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
+  __shared__ float s_sel[RT * RT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = 1 << logL, G = 64 >> logL;  // lanes per row, rows per wave-iteration
+  const int l = lane & (L - 1), g = lane >> logL;
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t m1 = min(M, m0 + rows_per_block);
+  const int rows_iter = G * (kThreads / 64);
+  const int niter = (int)((m1 - m0 + rows_iter - 1) / rows_iter);
+
+  if (sel != nullptr) {
+    for (int i = tid; i < RT * RT; i += kThreads) {
+      int a = i / RT, b = i - a * RT;
+      s_sel[i] = (a < r && b < r) ? sel[a * r + b] : 0.f;
+    }
+  }
+
+  const bool single_tile = kt_cols >= K;
+  if (single_tile) {
+    stage_factor_vec<RT>(s_f, f, fdt, layout, r, K, 0, K);
+    __syncthreads();
+  }
+
+  constexpr int U = 4;
+  for (int it = 0; it < niter; ++it) {
+    const int64_t row = m0 + (int64_t)it * rows_iter + wave * G + g;
+    const bool live = row < m1;
+    float acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += kt_cols) {
+      const int ncols = min(kt_cols, K - k0);
+      const int c8 = ncols >> 3;
+      if (!single_tile) {
+        __syncthreads();
+        stage_factor_vec<RT>(s_f, f, fdt, layout, r, K, k0, ncols);
+        __syncthreads();
+      }
+      if (live) {
+        const typename EX::storage *xr = x + row * ldx + k0;
+        for (int cb = l; cb < c8; cb += L * U) {
+          float xv[U][8];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (cb + u * L < c8) load8<EX>(xr + (cb + u * L) * 8, xv[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int cc = cb + u * L;
+            if (cc >= c8) continue;
+            if (MASKED) {
+              float mk[8];
+              dropout_mult8(seed, offset, (uint64_t)((row * K + k0) >> 3) + cc, p, mk);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) xv[u][i] *= mk[i];
+            }
+            fma_chunk<RT>(s_f, c8, cc, xv[u], acc);
+          }
+        }
+      }
+    }
+    // reduce the L partial sums of each row
+    for (int off = L >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    }
+    if (live && l == 0) {
+      float o[RT];
+      if (sel != nullptr) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a) {
+          float v = 0.f;
+#pragma unroll
+          for (int b = 0; b < RT; ++b)
+            v = fmaf(acc[b], sel_transposed ? s_sel[b * RT + a] : s_sel[a * RT + b], v);
+          o[a] = v * scale;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) o[j] = acc[j] * scale;
+      }
+      float *tr = t_out + row * r;
+#pragma unroll
+      for (int j = 0; j < RT; ++j)
+        if (j < r) tr[j] = o[j];
+    }
+  }
+}
+
+// Any K / any alignment: one wave per row, scalar lanes.
+template <class EX, bool MASKED>
+__global__ __launch_bounds__(kThreads) void rowdot_generic_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
+    int layout, float *__restrict__ t_out, int64_t M, int K, int r, float scale,
+    const float *__restrict__ sel, int sel_transposed, float p, uint64_t seed, uint64_t offset) {
+  __shared__ float s_o[kThreads / 64][LORA_AMD_MAX_RANK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+  const bool live = row < M;
+  for (int j = 0; j < r; ++j) {
+    float a = 0.f;
+    for (int k = lane; live && k < K; k += 64) {
+      float xv = EX::to_f(x[row * ldx + k]);
+      if (MASKED) {
+        uint64_t e = (uint64_t)row * K + k;
+        float mk[8];
+        dropout_mult8(seed, offset, e >> 3, p, mk);
+        xv *= mk[e & 7];
+      }
+      float fv = ld_factor(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * K + k : (int64_t)k * r + j);
+      a = fmaf(xv, fv, a);
+    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) s_o[wave][j] = a;
+  }
+  __syncthreads();
+  if (live && lane < r) {
+    float v;
+    if (sel != nullptr) {
+      v = 0.f;
+      for (int b = 0; b < r; ++b) v = fmaf(s_o[wave][b], sel_transposed ? sel[b * r + lane] : sel[lane * r + b], v);
+    } else {
+      v = s_o[wave][lane];
+    }
+    t_out[row * r + lane] = v * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// rank_update: tile = rows_per_tile x cols_per_tile of Y; the factor slab and the
+// tile's T rows live in LDS; lanes walk the tile's 16-byte chunks in flat order
+// (perfectly coalesced when ldy == N), 4 chunks in flight per lane.
+// ---------------------------------------------------------------------------
+template <class EY, int RT, bool DROP>
+__global__ __launch_bounds__(kThreads) void rank_update_kernel(
+    typename EY::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t,
+    const void *__restrict__ f, int fdt, int layout, int64_t M, int N, int r, int rows_per_tile,
+    int cols_per_tile, int tiles_n, float scale, float p, uint64_t seed, uint64_t offset) {
+  __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
+  __shared__ __attribute__((aligned(16))) float s_t[kTLdsFloats];
+  const int tid = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int64_t tr = tile / tiles_n;
+  const int tc = (int)(tile - tr * tiles_n);
+  const int64_t row0 = tr * rows_per_tile;
+  const int col0 = tc * cols_per_tile;
+  const int nrows = (int)min((int64_t)rows_per_tile, M - row0);
+  const int ncols = min(cols_per_tile, N - col0);
+  const int c8 = ncols >> 3;
+
+  stage_factor_vec<RT>(s_f, f, fdt, layout, r, N, col0, ncols);
+  for (int i = tid; i < nrows * RT; i += kThreads) {
+    int rl = i / RT, j = i - rl * RT;
+    s_t[i] = j < r ? t[(row0 + rl) * r + j] : 0.f;
+  }
+  __syncthreads();
+
+  constexpr int U = 4;
+  const int nchunk = nrows * c8;
+  const int dq = kThreads / c8, dr = kThreads % c8;
+  int rl = tid / c8, cc = tid % c8;
+  for (int c = tid; c < nchunk; c += kThreads * U) {
+    float v[U][8];
+    int rls[U], ccs[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = (c + u * kThreads) < nchunk;
+      rls[u] = rl; ccs[u] = cc;
+      if (ok[u]) load8<EY>(y + (row0 + rl) * ldy + col0 + cc * 8, v[u]);
+      rl += dq; cc += dr;
+      if (cc >= c8) { cc -= c8; ++rl; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float pr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *tr_ = s_t + rls[u] * RT;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float tj = tr_[j];
+        const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + ccs[u]) * 4]);
+        const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + ccs[u]) * 4]);
+        pr[0] = fmaf(tj, d0.x, pr[0]); pr[1] = fmaf(tj, d0.y, pr[1]);
+        pr[2] = fmaf(tj, d0.z, pr[2]); pr[3] = fmaf(tj, d0.w, pr[3]);
+        pr[4] = fmaf(tj, d1.x, pr[4]); pr[5] = fmaf(tj, d1.y, pr[5]);
+        pr[6] = fmaf(tj, d1.z, pr[6]); pr[7] = fmaf(tj, d1.w, pr[7]);
+      }
+      if (DROP) {
+        float mk[8];
+        const int64_t e = (row0 + rls[u]) * (int64_t)N + col0 + ccs[u] * 8;
+        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[u][i] = fmaf(scale, pr[i], v[u][i]);
+      store8<EY>(y + (row0 + rls[u]) * ldy + col0 + ccs[u] * 8, v[u]);
+    }
+  }
+}
+
+template <class EY, bool DROP>
+__global__ __launch_bounds__(kThreads) void rank_update_generic_kernel(
+    typename EY::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t,
+    const void *__restrict__ f, int fdt, int layout, int64_t M, int N, int r, float scale, float p,
+    uint64_t seed, uint64_t offset) {
+  const int64_t total = M * (int64_t)N;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+    const int64_t row = e / N;
+    const int col = (int)(e - row * N);
+    float a = 0.f;
+    for (int j = 0; j < r; ++j)
+      a = fmaf(t[row * r + j], ld_factor(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * N + col : (int64_t)col * r + j), a);
+    if (DROP) {
+      float mk[8];
+      dropout_mult8(seed, offset, (uint64_t)e >> 3, p, mk);
+      a *= mk[e & 7];
+    }
+    y[row * ldy + col] = EY::from_f(fmaf(scale, a, EY::to_f(y[row * ldy + col])));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// colreduce, stage 1: block = (row block, column tile of <= 256 chunks).  Thread t
+// owns chunk column t % c8 and row slot t / c8, walks its rows accumulating
+// acc[RT][8]; the row slots are then summed through LDS and the block's partial
+// [RT][ncols] goes to the workspace.  Stage 2 sums partials over row blocks.
+// ---------------------------------------------------------------------------
+constexpr int kColRowsPerBlock = 64;
+constexpr int kColMaxChunks = 256;
+
+template <class EX, int RT, bool MASKED>
+__global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
+    float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
+    uint64_t seed, uint64_t offset) {
+  // s_red doubles as the slot-reduction buffer: [slot][c8*8][4 ranks]
+  __shared__ __attribute__((aligned(16))) float s_red[kThreads * 8 * 4];
+  __shared__ float s_t[kColRowsPerBlock * RT];
+  const int tid = threadIdx.x;
+  const int64_t rb = blockIdx.x / col_tiles;
+  const int ct = (int)(blockIdx.x - rb * col_tiles);
+  const int col0 = ct * kColMaxChunks * 8;
+  const int ncols = min(kColMaxChunks * 8, K - col0);
+  const int c8 = ncols >> 3;
+  const int64_t m0 = rb * kColRowsPerBlock;
+  const int nrows = (int)min((int64_t)kColRowsPerBlock, M - m0);
+  const int nslots = kThreads / c8;  // >= 1
+  const int slot = tid / c8, cc = tid - slot * c8;
+
+  for (int i = tid; i < nrows * RT; i += kThreads) {
+    int rl = i / RT, j = i - rl * RT;
+    s_t[i] = (rank0 + j) < r ? t[(m0 + rl) * r + rank0 + j] : 0.f;
+  }
+  __syncthreads();
+
+  float acc[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+
+  if (slot < nslots) {
+    constexpr int U = 4;
+    for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+      float xv[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (rb0 + u * nslots < nrows) load8<EX>(x + (m0 + rb0 + u * nslots) * ldx + col0 + cc * 8, xv[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rl = rb0 + u * nslots;
+        if (rl >= nrows) continue;
+        if (MASKED) {
+          float mk[8];
+          const int64_t e = (m0 + rl) * (int64_t)K + col0 + cc * 8;
+          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[u][i] *= mk[i];
+        }
+        const float *tr_ = s_t + rl * RT;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const float tj = tr_[j];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, xv[u][i], acc[j][i]);
+        }
+      }
+    }
+  }
+
+  // slot reduction, 4 ranks at a time: s_red[(slot*ncols + col)*4 + jj]
+  float *pout = partial + ((int64_t)rb * RT) * K;  // [rb][RT][K] (ranks rank0..rank0+RT of this pass)
+#pragma unroll
+  for (int jb = 0; jb < RT; jb += 4) {
+    __syncthreads();
+    if (slot < nslots) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 v;
+        v.x = acc[jb][i];
+        v.y = (jb + 1 < RT) ? acc[(jb + 1) % RT][i] : 0.f;
+        v.z = (jb + 2 < RT) ? acc[(jb + 2) % RT][i] : 0.f;
+        v.w = (jb + 3 < RT) ? acc[(jb + 3) % RT][i] : 0.f;
+        *reinterpret_cast<float4 *>(&s_red[((slot * ncols) + cc * 8 + i) * 4]) = v;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < ncols * 4; i += kThreads) {
+      const int col = i >> 2, jj = i & 3;
+      if (jb + jj < RT) {
+        float sum = 0.f;
+        for (int s = 0; s < nslots; ++s) sum += s_red[(s * ncols + col) * 4 + jj];
+        pout[(int64_t)(jb + jj) * K + col0 + col] = sum;
+      }
+    }
+  }
+}
+
+// stage 2: D[j,k] = beta*D + scale * sum_b partial[b][j][k]  (j in [rank0, rank0+RT))
+__global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
+    const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
+    int RT, int rank0, int out_layout, float scale, float beta) {
+  const int64_t total = (int64_t)RT * K;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int j = (int)(i / K);
+    const int k = (int)(i - (int64_t)j * K);
+    if (rank0 + j >= r) continue;
+    float sum = 0.f;
+    for (int64_t b = 0; b < nblocks; ++b) sum += partial[(b * RT + j) * K + k];
+    const int64_t o = out_layout == LORA_AMD_FACTOR_RK ? (int64_t)(rank0 + j) * K + k : (int64_t)k * r + rank0 + j;
+    d[o] = (beta == 0.f ? 0.f : beta * d[o]) + scale * sum;
+  }
+}
+
+template <class EX, bool MASKED>
+__global__ __launch_bounds__(kThreads) void colreduce_generic_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
+    float *__restrict__ d, int64_t M, int K, int r, int out_layout, float scale, float beta, float p,
+    uint64_t seed, uint64_t offset) {
+  // one thread per (j, k); serial over M — correctness path for odd shapes only
+  const int64_t total = (int64_t)r * K;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int j = (int)(i / K);
+    const int k = (int)(i - (int64_t)j * K);
+    float sum = 0.f;
+    for (int64_t m = 0; m < M; ++m) {
+      float xv = EX::to_f(x[m * ldx + k]);
+      if (MASKED) {
+        uint64_t e = (uint64_t)m * K + k;
+        float mk[8];
+        dropout_mult8(seed, offset, e >> 3, p, mk);
+        xv *= mk[e & 7];
+      }
+      sum = fmaf(t[m * r + j], xv, sum);
+    }
+    const int64_t o = out_layout == LORA_AMD_FACTOR_RK ? (int64_t)j * K + k : (int64_t)k * r + j;
+    d[o] = (beta == 0.f ? 0.f : beta * d[o]) + scale * sum;
+  }
+}
+
+// ---- host-side helpers ------------------------------------------------------
+static inline int rank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : r <= 16 ? 16 : r <= 32 ? 32 : 64; }
+
+static inline bool vec_ok(const void *p, int64_t ld, int cols, int dt) {
+  const uintptr_t align = dt == LORA_AMD_F32 ? 32 : 16;
+  return cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)p % align) == 0;
+}
+
+// lanes per row for rowdot: maximise lane efficiency c8 / (L * ceil(c8 / L)); ties -> larger L
+static inline int pick_logL(int c8) {
+  int best = 0;
+  double best_eff = -1.0;
+  for (int lg = 0; lg <= 6; ++lg) {
+    int L = 1 << lg;
+    double eff = (double)c8 / ((double)L * ((c8 + L - 1) / L));
+    if (eff >= best_eff - 1e-9) { best_eff = eff > best_eff ? eff : best_eff; best = lg; }
+  }
+  return best;
+}
+
+template <class EX, bool MASKED>
+static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out, int64_t M, int K, int r,
+                         int fdt, int layout, float scale, const float *sel, int selT, float p,
+                         uint64_t seed, uint64_t offset, hipStream_t st) {
+  using S = typename EX::storage;
+  const S *xp = reinterpret_cast<const S *>(x);
+  float *tp = reinterpret_cast<float *>(t_out);
+  if (!vec_ok(x, ldx, K, EX::kCode)) {
+    int grid = (int)((M + 3) / 4);
+    hipLaunchKernelGGL((rowdot_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt,
+                       layout, tp, M, K, r, scale, sel, selT, p, seed, offset);
+    return check_launch("lora_amd_rowdot(generic)");
+  }
+  const int RT = rank_tile(r);
+  int kt_cols = (kFactorLdsFloats / RT) & ~7;
+  if (kt_cols > K) kt_cols = K;
+  const int logL = pick_logL(kt_cols >> 3);
+  const int rows_iter = (64 >> logL) * (kThreads / 64);
+  // enough blocks to fill 256 CUs, enough rows per block to amortise the LDS staging
+  int64_t rows_per_block = (M + 1023) / 1024;
+  rows_per_block = ((rows_per_block + rows_iter - 1) / rows_iter) * rows_iter;
+  const int grid = (int)((M + rows_per_block - 1) / rows_per_block);
+#define RD(RTV)                                                                                         \
+  hipLaunchKernelGGL((rowdot_kernel<EX, RTV, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt, \
+                     layout, tp, M, K, r, kt_cols, logL, (int)rows_per_block, scale, sel, selT, p, seed, offset)
+  switch (RT) {
+    case 4: RD(4); break;
+    case 8: RD(8); break;
+    case 16: RD(16); break;
+    case 32: RD(32); break;
+    default: RD(64); break;
+  }
+#undef RD
+  return check_launch("lora_amd_rowdot");
+}
+
+template <class EY, bool DROP>
+static int launch_rank_update(void *y, int64_t ldy, const float *t, const void *f, int64_t M, int N, int r,
+                              int fdt, int layout, float scale, float p, uint64_t seed, uint64_t offset,
+                              hipStream_t st) {
+  using S = typename EY::storage;
+  S *yp = reinterpret_cast<S *>(y);
+  if (!vec_ok(y, ldy, N, EY::kCode)) {
+    int64_t total = M * (int64_t)N;
+    int grid = (int)std::min<int64_t>((total + kThreads - 1) / kThreads, 4096);
+    hipLaunchKernelGGL((rank_update_generic_kernel<EY, DROP>), dim3(grid), dim3(kThreads), 0, st, yp, ldy, t, f,
+                       fdt, layout, M, N, r, scale, p, seed, offset);
+    return check_launch("lora_amd_rank_update(generic)");
+  }
+  const int RT = rank_tile(r);
+  int cols = (kFactorLdsFloats / RT) & ~7;
+  if (cols > N) cols = N;
+  int64_t rows = 32768 / cols;
+  const int max_rows = kTLdsFloats / RT;
+  if (rows > max_rows) rows = max_rows;
+  if (rows > 128) rows = 128;
+  if (rows < 8) rows = 8;
+  if (rows > M) rows = M;
+  const int tiles_n = (N + cols - 1) / cols;
+  const int64_t tiles = tiles_n * ((M + rows - 1) / rows);
+#define RU(RTV)                                                                                            \
+  hipLaunchKernelGGL((rank_update_kernel<EY, RTV, DROP>), dim3((unsigned)tiles), dim3(kThreads), 0, st, yp, ldy, t, \
+                     f, fdt, layout, M, N, r, (int)rows, cols, tiles_n, scale, p, seed, offset)
+  switch (RT) {
+    case 4: RU(4); break;
+    case 8: RU(8); break;
+    case 16: RU(16); break;
+    case 32: RU(32); break;
+    default: RU(64); break;
+  }
+#undef RU
+  return check_launch("lora_amd_rank_update");
+}
+
+static inline int col_rank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
+
+template <class EX, bool MASKED>
+static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d, int64_t M, int K, int r,
+                            int out_layout, float scale, float beta, float p, uint64_t seed, uint64_t offset,
+                            void *ws, size_t ws_bytes, hipStream_t st) {
+  using S = typename EX::storage;
+  const S *xp = reinterpret_cast<const S *>(x);
+  if (!vec_ok(x, ldx, K, EX::kCode)) {
+    int grid = (int)std::min<int64_t>(((int64_t)r * K + kThreads - 1) / kThreads, 4096);
+    hipLaunchKernelGGL((colreduce_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, t, d, M,
+                       K, r, out_layout, scale, beta, p, seed, offset);
+    return check_launch("lora_amd_colreduce(generic)");
+  }
+  LORA_AMD_CHECK(ws_bytes >= lora_amd_colreduce_workspace(M, K, r), LORA_AMD_EWORKSPACE,
+                 "colreduce: workspace %zu < %zu bytes", ws_bytes, lora_amd_colreduce_workspace(M, K, r));
+  const int RT = col_rank_tile(r);
+  const int64_t nrb = (M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  const int col_tiles = (K + kColMaxChunks * 8 - 1) / (kColMaxChunks * 8);
+  float *partial = reinterpret_cast<float *>(ws);
+  for (int rank0 = 0; rank0 < r; rank0 += RT) {
+    if (nrb > 0) {  // ranks beyond 16 take extra passes over X
+#define CR(RTV)                                                                                              \
+  hipLaunchKernelGGL((colreduce_stage1_kernel<EX, RTV, MASKED>), dim3((unsigned)(nrb * col_tiles)), dim3(kThreads), \
+                     0, st, xp, ldx, t, partial, M, K, r, rank0, col_tiles, p, seed, offset)
+    switch (RT) {
+      case 4: CR(4); break;
+      case 8: CR(8); break;
+      default: CR(16); break;
+    }
+    }
+#undef CR
+    int grid2 = (int)std::min<int64_t>(((int64_t)RT * K + kThreads - 1) / kThreads, 1024);
+    hipLaunchKernelGGL(colreduce_stage2_kernel, dim3(grid2), dim3(kThreads), 0, st, partial, d, nrb, K, r, RT,
+                       rank0, out_layout, scale, beta);
+  }
+  return check_launch("lora_amd_colreduce");
+}
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+#define COMMON_CHECKS(name, M, K, r, dt)                                                         \
+  LORA_AMD_CHECK((M) >= 0 && (K) > 0, LORA_AMD_EINVAL, name ": bad shape M=%lld K=%d", (long long)(M), (int)(K)); \
+  LORA_AMD_CHECK((r) >= 1 && (r) <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, name ": rank %d outside [1,%d]", (int)(r), LORA_AMD_MAX_RANK); \
+  LORA_AMD_CHECK(dtype_ok(dt), LORA_AMD_EINVAL, name ": bad dtype %d", (int)(dt));               \
+  if ((M) == 0) return LORA_AMD_OK;
+
+extern "C" int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *factor, void *t_out, int64_t M,
+                                      int32_t K, int32_t r, int32_t x_dtype, int32_t factor_dtype,
+                                      int32_t factor_layout, float scale, const float *sel,
+                                      int32_t sel_transposed, float dropout_p, uint64_t seed, uint64_t offset,
+                                      void *stream) {
+  COMMON_CHECKS("rowdot", M, K, r, x_dtype);
+  LORA_AMD_CHECK(x && factor && t_out, LORA_AMD_EINVAL, "rowdot: null pointer");
+  LORA_AMD_CHECK(dtype_ok(factor_dtype), LORA_AMD_EINVAL, "rowdot: bad factor dtype %d", factor_dtype);
+  LORA_AMD_CHECK(ldx >= K, LORA_AMD_EINVAL, "rowdot: ldx %lld < K %d", (long long)ldx, K);
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "rowdot: dropout p=%f", dropout_p);
+  hipStream_t st = (hipStream_t)stream;
+  const bool masked = dropout_p > 0.f;
+#define GO(E)                                                                                          \
+  return masked ? launch_rowdot<E, true>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, sel, \
+                                         sel_transposed, dropout_p, seed, offset, st)                  \
+                : launch_rowdot<E, false>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, sel, \
+                                          sel_transposed, 0.f, 0, 0, st)
+  switch (x_dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+}
+
+extern "C" int lora_amd_rowdot(const void *x, int64_t ldx, const void *factor, void *t_out, int64_t M, int32_t K,
+                               int32_t r, int32_t x_dtype, int32_t factor_dtype, int32_t factor_layout,
+                               float scale, const float *sel, int32_t sel_transposed, void *stream) {
+  return lora_amd_rowdot_masked(x, ldx, factor, t_out, M, K, r, x_dtype, factor_dtype, factor_layout, scale, sel,
+                                sel_transposed, 0.f, 0, 0, stream);
+}
+
+extern "C" int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const void *factor, int64_t M, int32_t N,
+                                    int32_t r, int32_t y_dtype, int32_t factor_dtype, int32_t factor_layout,
+                                    float scale, float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+  COMMON_CHECKS("rank_update", M, N, r, y_dtype);
+  LORA_AMD_CHECK(y && t && factor, LORA_AMD_EINVAL, "rank_update: null pointer");
+  LORA_AMD_CHECK(dtype_ok(factor_dtype), LORA_AMD_EINVAL, "rank_update: bad factor dtype %d", factor_dtype);
+  LORA_AMD_CHECK(ldy >= N, LORA_AMD_EINVAL, "rank_update: ldy %lld < N %d", (long long)ldy, N);
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "rank_update: dropout p=%f", dropout_p);
+  hipStream_t st = (hipStream_t)stream;
+  const bool drop = dropout_p > 0.f;
+#define GO(E)                                                                                              \
+  return drop ? launch_rank_update<E, true>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, \
+                                            dropout_p, seed, offset, st)                                   \
+              : launch_rank_update<E, false>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, 0.f, 0, 0, st)
+  switch (y_dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+}
+
+extern "C" size_t lora_amd_colreduce_workspace(int64_t M, int32_t K, int32_t r) {
+  if (M <= 0 || K <= 0 || r <= 0) return 0;
+  const int RT = col_rank_tile(r);
+  const int64_t nrb = (M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  return (size_t)nrb * RT * K * sizeof(float);
+}
+
+extern "C" int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out, int64_t M, int32_t K,
+                                  int32_t r, int32_t x_dtype, int32_t out_layout, float scale, float beta,
+                                  float dropout_p, uint64_t seed, uint64_t offset, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  LORA_AMD_CHECK(M >= 0 && K > 0, LORA_AMD_EINVAL, "colreduce: bad shape M=%lld K=%d", (long long)M, K);
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "colreduce: rank %d outside [1,%d]", r, LORA_AMD_MAX_RANK);
+  LORA_AMD_CHECK(dtype_ok(x_dtype), LORA_AMD_EINVAL, "colreduce: bad dtype %d", x_dtype);
+  LORA_AMD_CHECK(x && t && d_out, LORA_AMD_EINVAL, "colreduce: null pointer");
+  LORA_AMD_CHECK(ldx >= K, LORA_AMD_EINVAL, "colreduce: ldx %lld < K %d", (long long)ldx, K);
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "colreduce: dropout p=%f", dropout_p);
+  hipStream_t st = (hipStream_t)stream;
+  const bool masked = dropout_p > 0.f;
+#define GO(E)                                                                                               \
+  return masked ? launch_colreduce<E, true>(x, ldx, t, d_out, M, K, r, out_layout, scale, beta, dropout_p, seed, \
+                                            offset, workspace, workspace_bytes, st)                         \
+                : launch_colreduce<E, false>(x, ldx, t, d_out, M, K, r, out_layout, scale, beta, 0.f, 0, 0, \
+                                             workspace, workspace_bytes, st)
+  switch (x_dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+}

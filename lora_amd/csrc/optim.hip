@@ -1,0 +1,135 @@
+// C2/K6 — gradient-norm clipping + AdamW over ONE flat f32 buffer of LoRA parameters.
+//
+// Replaces training_scripts/train_lora_dreambooth.py:878-888: the reference's
+// clip_grad_norm_ walks every UNet parameter tensor (~860 M frozen elements) to
+// find the 288 LoRA tensors, then AdamW runs per-tensor foreach kernels and
+// zero_grad another pass.  The trainer keeps all A/B parameters, their grads and
+// both Adam moments in flat buffers (the grad buffer is also the single RCCL
+// all-reduce payload), so the whole optimiser step is two launches:
+//   sumsq       : ||g||^2 -> device scalar (two-stage, deterministic)
+//   clip_adamw  : g*=clip(norm); AdamW (torch.optim.AdamW maths); g=0
+// No host synchronisation: the clip coefficient is derived on the device.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+constexpr int kOptThreads = 256;
+constexpr int kSumsqMaxBlocks = 1024;
+
+__device__ inline float block_sum(float v, float *s_buf) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_buf[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < kOptThreads / 64; ++w) t += s_buf[w];
+  return t;
+}
+
+__global__ __launch_bounds__(kOptThreads) void sumsq_stage1(const float *__restrict__ g, int64_t n,
+                                                             float *__restrict__ partial) {
+  __shared__ float s_buf[kOptThreads / 64];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4 *g4 = reinterpret_cast<const float4 *>(g);
+  for (int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kOptThreads) {
+    float4 v = g4[i];
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += kOptThreads) acc = fmaf(g[i], g[i], acc);
+  float t = block_sum(acc, s_buf);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kOptThreads) void sumsq_stage2(const float *__restrict__ partial, int nblk,
+                                                             float *__restrict__ out) {
+  __shared__ float s_buf[kOptThreads / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kOptThreads) acc += partial[i];
+  float t = block_sum(acc, s_buf);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+__global__ __launch_bounds__(kOptThreads) void clip_adamw_kernel(
+    float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
+    const lora_amd_adamw_group *__restrict__ groups, int n_groups, const float *__restrict__ sumsq,
+    float grad_scale, float max_norm, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+    int zero_grad) {
+  float coef = grad_scale;
+  if (max_norm > 0.f) {
+    // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float total_norm = sqrtf(sumsq[0]) * fabsf(grad_scale);
+    const float c = max_norm / (total_norm + 1e-6f);
+    coef *= fminf(c, 1.0f);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kOptThreads) {
+    float lr = 0.f, wd = 0.f;
+    bool owned = false;
+    for (int k = 0; k < n_groups; ++k) {
+      if (i >= groups[k].begin && i < groups[k].end) { lr = groups[k].lr; wd = groups[k].weight_decay; owned = true; }
+    }
+    if (!owned) continue;
+    const float grad = g[i] * coef;
+    float pi = p[i];
+    pi *= (1.0f - lr * wd);                      // param.mul_(1 - lr * weight_decay)
+    float mi = m[i];
+    mi = mi + (grad - mi) * (1.0f - beta1);      // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = v[i] * beta2;
+    vi = fmaf((1.0f - beta2) * grad, grad, vi);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);             // param.addcdiv_(exp_avg, denom, value=-step_size)
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+static int sumsq_blocks(int64_t n) {
+  int64_t b = (n / 4 + kOptThreads - 1) / kOptThreads;
+  if (b < 1) b = 1;
+  return (int)std::min<int64_t>(b, kSumsqMaxBlocks);
+}
+
+extern "C" size_t lora_amd_sumsq_workspace(int64_t n) { return (size_t)kSumsqMaxBlocks * sizeof(float); }
+
+extern "C" int lora_amd_sumsq(const float *g, int64_t n, float *out_sumsq, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  LORA_AMD_CHECK(g && out_sumsq && workspace, LORA_AMD_EINVAL, "sumsq: null pointer");
+  LORA_AMD_CHECK(n >= 0, LORA_AMD_EINVAL, "sumsq: n=%lld", (long long)n);
+  LORA_AMD_CHECK(((uintptr_t)g & 15u) == 0, LORA_AMD_EINVAL, "sumsq: g must be 16-byte aligned");
+  LORA_AMD_CHECK(workspace_bytes >= lora_amd_sumsq_workspace(n), LORA_AMD_EWORKSPACE, "sumsq: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = sumsq_blocks(n);
+  float *partial = reinterpret_cast<float *>(workspace);
+  hipLaunchKernelGGL(sumsq_stage1, dim3(nblk), dim3(kOptThreads), 0, st, g, n, partial);
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(kOptThreads), 0, st, partial, nblk, out_sumsq);
+  return check_launch("lora_amd_sumsq");
+}
+
+extern "C" int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                   const lora_amd_adamw_group *groups_dev, int32_t n_groups, const float *sumsq,
+                                   float grad_scale, float max_norm, float beta1, float beta2, float eps,
+                                   int64_t step, int32_t zero_grad, void *stream) {
+  LORA_AMD_CHECK(p && g && exp_avg && exp_avg_sq && groups_dev, LORA_AMD_EINVAL, "clip_adamw: null pointer");
+  LORA_AMD_CHECK(n >= 0 && n_groups >= 1 && n_groups <= 16, LORA_AMD_EINVAL, "clip_adamw: n=%lld n_groups=%d",
+                 (long long)n, n_groups);
+  LORA_AMD_CHECK(step >= 1, LORA_AMD_EINVAL, "clip_adamw: step must be >= 1 (got %lld)", (long long)step);
+  LORA_AMD_CHECK(max_norm <= 0.f || sumsq != nullptr, LORA_AMD_EINVAL, "clip_adamw: clipping needs sumsq");
+  if (n == 0) return LORA_AMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // bias corrections in double, as torch's python scalars are
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  int grid = (int)std::min<int64_t>((n + kOptThreads - 1) / kOptThreads, 2048);
+  hipLaunchKernelGGL(clip_adamw_kernel, dim3(grid), dim3(kOptThreads), 0, st, p, g, exp_avg, exp_avg_sq, n,
+                     groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1, beta2, eps, (float)bc1,
+                     (float)std::sqrt(bc2), zero_grad);
+  return check_launch("lora_amd_clip_adamw");
+}

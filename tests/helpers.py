@@ -1,0 +1,153 @@
+"""Shared test helpers: module trees from JSON specs, reference loader, dtype helpers."""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+REFERENCE_LORA = "/root/reference/lora_diffusion/lora.py"
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+_class_cache = {}
+
+
+def named_class(name: str):
+    """An nn.Module subclass whose __name__ is ``name`` (the finder matches class-name strings)."""
+    if name not in _class_cache:
+        _class_cache[name] = type(name, (nn.Module,), {})
+    return _class_cache[name]
+
+
+def build_tree(spec, adapter_linear=None, adapter_conv=None, dim=8):
+    """spec = {"cls": str, "kind": "other|linear|conv|lora_linear|lora_conv", "children": [[name, spec], ...]}"""
+    kind = spec.get("kind", "other")
+    if kind == "linear":
+        return nn.Linear(dim, dim, bias=spec.get("bias", True))
+    if kind == "conv":
+        k = spec.get("k", 3)
+        return nn.Conv2d(dim, dim, k, padding=k // 2, bias=spec.get("bias", True))
+    if kind == "lora_linear":
+        return adapter_linear(dim, dim, spec.get("bias", True), r=spec.get("r", 2))
+    if kind == "lora_conv":
+        k = spec.get("k", 3)
+        return adapter_conv(dim, dim, k, 1, k // 2, r=spec.get("r", 2))
+    m = named_class(spec["cls"])()
+    for name, child in spec.get("children", []):
+        m.add_module(name, build_tree(child, adapter_linear, adapter_conv, dim))
+    return m
+
+
+_LORA_CHILDREN = {
+    "lora_linear": [["linear", {"cls": "Linear", "kind": "linear"}], ["lora_down", {"cls": "Linear", "kind": "linear"}],
+                    ["dropout", {"cls": "Dropout"}], ["lora_up", {"cls": "Linear", "kind": "linear"}],
+                    ["selector", {"cls": "Identity"}]],
+    "lora_conv": [["conv", {"cls": "Conv2d", "kind": "conv"}], ["lora_down", {"cls": "Conv2d", "kind": "conv"}],
+                  ["dropout", {"cls": "Dropout"}], ["lora_up", {"cls": "Conv2d", "kind": "conv"}],
+                  ["selector", {"cls": "Identity"}]],
+}
+
+
+def oracle_spec(spec):
+    """Expand adapter nodes into their registered children so oracle.Node sees what named_modules() sees."""
+    kind = spec.get("kind", "other")
+    if kind in _LORA_CHILDREN:
+        return {"cls": "LoraInjectedLinear" if kind == "lora_linear" else "LoraInjectedConv2d", "kind": kind,
+                "children": _LORA_CHILDREN[kind]}
+    out = {"cls": spec["cls"], "kind": kind}
+    out["children"] = [[n, oracle_spec(c)] for n, c in spec.get("children", [])]
+    return out
+
+
+def reference_available() -> bool:
+    return os.path.exists(REFERENCE_LORA)
+
+
+def load_reference():
+    """The real reference module, loaded by file path (its package __init__ needs torchvision/diffusers)."""
+    spec = importlib.util.spec_from_file_location("ref_lora", REFERENCE_LORA)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def module_paths(root: nn.Module):
+    return {id(m): n for n, m in root.named_modules()}
+
+
+def t2n(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+# ---- SD-like toy trees used by several tests -------------------------------------------------
+def _lin():
+    return {"cls": "Linear", "kind": "linear"}
+
+
+def attn_spec(cls="CrossAttention"):
+    return {"cls": cls, "children": [["to_q", _lin()], ["to_k", _lin()], ["to_v", _lin()],
+                                     ["to_out", {"cls": "ModuleList", "children": [["0", _lin()], ["1", {"cls": "Dropout"}]]}]]}
+
+
+def ff_spec():
+    return {"cls": "FeedForward", "children": [["net", {"cls": "ModuleList", "children": [
+        ["0", {"cls": "GEGLU", "children": [["proj", _lin()]]}], ["1", {"cls": "Dropout"}], ["2", _lin()]]}]]}
+
+
+def block_spec():
+    return {"cls": "BasicTransformerBlock", "children": [["attn1", attn_spec()], ["ff", ff_spec()],
+                                                         ["attn2", attn_spec()], ["norm1", {"cls": "LayerNorm"}]]}
+
+
+def resnet_spec(shortcut=True):
+    ch = [["norm1", {"cls": "GroupNorm"}], ["conv1", {"cls": "Conv2d", "kind": "conv"}],
+          ["time_emb_proj", _lin()], ["norm2", {"cls": "GroupNorm"}], ["conv2", {"cls": "Conv2d", "kind": "conv"}]]
+    if shortcut:
+        ch.append(["conv_shortcut", {"cls": "Conv2d", "kind": "conv", "k": 1}])
+    return {"cls": "ResnetBlock2D", "children": ch}
+
+
+def toy_unet_spec():
+    return {"cls": "ToyUNet", "children": [
+        ["conv_in", {"cls": "Conv2d", "kind": "conv"}],
+        ["down_blocks", {"cls": "ModuleList", "children": [
+            ["0", {"cls": "CrossAttnDownBlock2D", "children": [
+                ["attentions", {"cls": "ModuleList", "children": [["0", {"cls": "Transformer2DModel", "children": [
+                    ["proj_in", _lin()], ["transformer_blocks", {"cls": "ModuleList", "children": [["0", block_spec()]]}]]}]]}],
+                ["resnets", {"cls": "ModuleList", "children": [["0", resnet_spec()], ["1", resnet_spec(False)]]}]]}]]}],
+        ["up_blocks", {"cls": "ModuleList", "children": [["0", {"cls": "UpBlock2D", "children": [
+            ["resnets", {"cls": "ModuleList", "children": [["0", resnet_spec()]]}]]}]]}],
+        ["mid_block", {"cls": "UNetMidBlock2DCrossAttn", "children": [
+            ["attentions", {"cls": "ModuleList", "children": [["0", {"cls": "Transformer2DModel", "children": [
+                ["transformer_blocks", {"cls": "ModuleList", "children": [["0", block_spec()]]}]]}]]}],
+            ["resnets", {"cls": "ModuleList", "children": [["0", resnet_spec(False)]]}]]}],
+    ]}
+
+
+def toy_clip_spec():
+    layer = {"cls": "CLIPEncoderLayer", "children": [
+        ["self_attn", {"cls": "CLIPAttention", "children": [["k_proj", _lin()], ["v_proj", _lin()], ["q_proj", _lin()],
+                                                             ["out_proj", _lin()]]}],
+        ["mlp", {"cls": "CLIPMLP", "children": [["fc1", _lin()], ["fc2", _lin()]]}]]}
+    return {"cls": "ToyCLIP", "children": [["encoder", {"cls": "CLIPEncoder", "children": [
+        ["layers", {"cls": "ModuleList", "children": [["0", layer], ["1", layer]]}]]}]]}
+
+
+def nested_spec():
+    """Ancestors nested in ancestors + pre-existing adapters: stresses de-duplication quirks."""
+    return {"cls": "Root", "children": [
+        ["a", {"cls": "GEGLU", "children": [["proj", _lin()], ["inner", attn_spec("Attention")]]}],
+        ["b", {"cls": "CrossAttention", "children": [["to_q", {"cls": "LoraInjectedLinear", "kind": "lora_linear"}],
+                                                    ["to_k", _lin()],
+                                                    ["c", {"cls": "LoraInjectedConv2d", "kind": "lora_conv"}]]}],
+        ["plain", _lin()],
+    ]}
