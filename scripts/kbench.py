@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks (HIP events on the launch stream): algorithmic GB/s of each primitive."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lora_amd import _C  # noqa: E402
+from lora_amd.standin import sd15_lora_site_shapes  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def merge_plan(qkvo_only=False, r=4, wdt=torch.bfloat16, abdt=torch.float32, inplace=False):
+    shapes = sd15_lora_site_shapes()
+    if qkvo_only:
+        shapes = [s for i, s in enumerate(shapes) if i % 9 != 4]
+    sites = []
+    for N, K in shapes:
+        w = (torch.randn(N, K, device=DEV) * 0.03).to(wdt)
+        sites.append((w, w if inplace else torch.empty_like(w), (torch.randn(N, r, device=DEV) * 0.05).to(abdt),
+                      (torch.randn(r, K, device=DEV) * 0.25).to(abdt)))
+    return _C.MergePlan(sites)
+
+
+def bench_merge(args):
+    out = []
+    for qkvo in (False, True):
+        for tile, bpc in ((32768, 4), (16384, 4), (65536, 4), (32768, 2), (32768, 3), (16384, 5), (8192, 5)):
+            _C.merge_set_tuning(tile, bpc)
+            plan = merge_plan(qkvo)
+            med, best = timeit(lambda: plan.launch(0.7), iters=args.iters)
+            gbs = plan.bytes_algorithmic / med / 1e9
+            out.append(dict(kernel="merge", qkvo=qkvo, tile=tile, blocks_per_cu=bpc, sites=plan.n_sites,
+                            tiles=plan.total_tiles, MB=plan.bytes_algorithmic / 1e6, us=med * 1e6, best_us=best * 1e6,
+                            GBs=gbs, frac8=gbs / 8000))
+            print(json.dumps(out[-1]), flush=True)
+    _C.merge_set_tuning(32768, 4)
+    # plain device copy of the same bytes as a ceiling reference
+    n = int(385e6 / 2)
+    a = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    b = torch.empty_like(a)
+    med, _ = timeit(lambda: b.copy_(a), iters=args.iters)
+    print(json.dumps(dict(kernel="torch_copy", MB=2 * n * 2 / 1e6, us=med * 1e6, GBs=2 * n * 2 / med / 1e9)), flush=True)
+    return out
+
+
+def bench_linear(args):
+    r = 4
+    for (M, K, N) in ((16384, 320, 320), (16384, 320, 2560), (4096, 640, 640), (4096, 640, 5120), (1024, 1280, 1280),
+                      (1024, 1280, 10240), (308, 768, 320)):
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        y = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+        A = torch.randn(r, K, device=DEV) * 0.25
+        B = torch.randn(N, r, device=DEV) * 0.05
+        t = _C.rowdot(x, A, _C.FACTOR_RK)
+        res = dict(M=M, K=K, N=N)
+        med, _ = timeit(lambda: _C.rowdot(x, A, _C.FACTOR_RK), args.iters)
+        res["rowdot_us"], res["rowdot_GBs"] = med * 1e6, (M * K * 2 + M * r * 4) / med / 1e9
+        med, _ = timeit(lambda: _C.rank_update_(y, t, B, _C.FACTOR_KR, 1e-3), args.iters)
+        res["rank_update_us"], res["rank_update_GBs"] = med * 1e6, (2 * M * N * 2 + M * r * 4) / med / 1e9
+        med, _ = timeit(lambda: _C.colreduce(y, t, _C.FACTOR_KR, 1.0), args.iters)
+        res["colreduce_us"], res["colreduce_GBs"] = med * 1e6, (M * N * 2 + M * r * 4) / med / 1e9
+        # what the reference's op sequence costs on the same device (5 ATen launches)
+        W = torch.randn(N, K, device=DEV).to(torch.bfloat16)
+        Ab, Bb = A.to(torch.bfloat16), B.to(torch.bfloat16)
+
+        def ref_branch():
+            return y + torch.nn.functional.dropout(torch.nn.functional.linear(torch.nn.functional.linear(x, Ab), Bb), 0.0) * 0.5
+
+        med, _ = timeit(ref_branch, args.iters)
+        res["aten_branch_us"] = med * 1e6
+        med, _ = timeit(lambda: torch.nn.functional.linear(x, W), args.iters)
+        res["frozen_gemm_us"] = med * 1e6
+        res["frozen_gemm_TF"] = 2 * M * K * N / med / 1e12
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="merge,linear")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    print(torch.cuda.get_device_name(0), flush=True)
+    if "merge" in a.what:
+        bench_merge(a)
+    if "linear" in a.what:
+        bench_linear(a)

@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/lora_amd.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from lora_amd import _C
+from tests.helpers import REPO
+
+
+def _header_symbols():
+    src = open(os.path.join(REPO, "include", "lora_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lora_amd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    lib = _C.require()
+    declared = _header_symbols()
+    assert declared, "no declarations parsed from the header"
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"declared in include/lora_amd.h but not exported: {missing}"
+    assert sorted(_C.SYMBOLS) == declared, "lora_amd/_C.py SYMBOLS out of sync with the header"
+    assert lib.lora_amd_abi_version() == 1 and lib.lora_amd_target_arch() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(_C.MergeSite) == 72 and _C.MergeSite.tile_begin.offset == 56 and _C.MergeSite.N.offset == 32
+    assert C.sizeof(_C.AdamWGroup) == 24
+
+
+def test_merge_planner_is_pure_host_arithmetic():
+    lib = _C.require()
+    sites = (_C.MergeSite * 3)()
+    for s, (N, K, r) in zip(sites, [(320, 320, 4), (2560, 320, 4), (1280, 2880, 16)]):
+        s.N, s.K, s.r = N, K, r
+        s.w_in = s.w_out = 4096
+    total = C.c_int64()
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == 0
+    acc = 0
+    for s in sites:
+        assert s.cols_per_tile % 8 == 0 and s.cols_per_tile * s.r <= 8192 and s.rows_per_tile * s.r <= 2048
+        assert s.tiles_k == -(-s.K // s.cols_per_tile) and s.tile_begin == acc and s.flags & 1
+        acc += s.tiles_k * -(-s.N // s.rows_per_tile)
+    assert total.value == acc
+    sites[0].r = 65
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == -2
+    assert b"rank 65" in lib.lora_amd_last_error()
+    sites[0].r, sites[0].K = 4, 321  # odd K or misaligned weight -> scalar lanes
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == 0 and not (sites[0].flags & 1)
+
+
+def test_workspace_queries():
+    lib = _C.require()
+    assert lib.lora_amd_colreduce_workspace(16384, 320, 4) == 256 * 4 * 320 * 4
+    assert lib.lora_amd_colreduce_workspace(0, 320, 4) == 0
+    assert lib.lora_amd_sumsq_workspace(10) >= 4
+
+
+def test_device_path_never_falls_back(monkeypatch):
+    """A device tensor without the library must raise, not run an eager fallback."""
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "_load_error", "simulated: library absent")
+    with pytest.raises(_C.HipExtensionMissing):
+        _C.require()

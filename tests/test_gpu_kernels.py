@@ -1,0 +1,391 @@
+"""Parity of the HIP path (through the C-ABI) with the oracle and the reference-generated fixtures.
+
+Tolerances (stated per the north star: fp16/bf16 tolerance for floats, bit-level for layout):
+  * f32 data, f32 accumulation: |err| <= 2e-5 * (sum of |terms|)   [summation-order only]
+  * bf16 / f16 outputs: one rounding of the exact result -> rel 2^-8 / 2^-11 of the value, plus the above
+  * merge in reference rounding mode: <= 1 ulp of the weight dtype, and < 1 % of elements differ at all
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lora_amd as L
+from lora_amd import _C, ops
+from oracle import lora_numpy as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = H.GOLDEN
+DEV = "cuda:0"
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+EPS = {"f32": 0.0, "bf16": 2.0 ** -8, "f16": 2.0 ** -11}
+
+
+def _npz(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+def n(t):
+    return t.detach().float().cpu().numpy()
+
+
+def rnd(shape, dt, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DT[dt]).to(DEV)
+
+
+def close(got, want, absref, dt_out="f32", k=2e-5, msg=""):
+    """|got-want| <= k*absref + eps_out*|want| (absref = sum of |terms| of the reduction)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    tol = k * np.asarray(absref, dtype=np.float64) + EPS[dt_out] * np.abs(want) + 1e-30
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{msg}: {bad.sum()} of {bad.size} outside tolerance; worst {np.abs(got - want).max():.3e}"
+
+
+SHAPES = [(512, 320, 4), (300, 768, 4), (64, 1280, 8), (130, 2560, 4), (33, 640, 16), (17, 320, 1), (40, 4096, 64),
+          (9, 77, 3), (1, 8, 1), (257, 1288, 5)]
+
+
+@pytest.mark.parametrize("M,K,r", SHAPES)
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("layout", [_C.FACTOR_RK, _C.FACTOR_KR])
+def test_rowdot_matches_oracle(M, K, r, dt, layout):
+    x = rnd((M, K), dt, seed=1)
+    f = rnd((r, K) if layout == _C.FACTOR_RK else (K, r), "f32", 0.3, seed=2)
+    t = _C.rowdot(x, f, layout, 0.7)
+    fr = n(f) if layout == _C.FACTOR_RK else n(f).T
+    want = 0.7 * (n(x).astype(np.float64) @ fr.T.astype(np.float64))
+    absref = 0.7 * (np.abs(n(x)) @ np.abs(fr.T))
+    close(n(t), want, absref, msg=f"rowdot {M}x{K} r{r} {dt}")
+
+
+def test_rowdot_selector_and_strided_rows():
+    M, K, r = 100, 640, 4
+    big = rnd((M, K + 64), "bf16", seed=3)
+    x = big[:, :K]  # ldx = K+64
+    f = rnd((r, K), "f32", 0.3, seed=4)
+    sel = rnd((r, r), "f32", seed=5)
+    base = n(x).astype(np.float64) @ n(f).T.astype(np.float64)
+    absref = (np.abs(n(x)) @ np.abs(n(f)).T) @ np.abs(n(sel)).T
+    close(n(_C.rowdot(x, f, _C.FACTOR_RK, 1.0, sel, False)), base @ n(sel).T, absref, msg="sel fwd")
+    close(n(_C.rowdot(x, f, _C.FACTOR_RK, 1.0, sel, True)), base @ n(sel), (np.abs(n(x)) @ np.abs(n(f)).T) @ np.abs(n(sel)),
+          msg="sel bwd")
+    # unaligned base pointer -> scalar-lane kernel
+    xo = big.view(-1)[1:1 + M * K].view(M, K)
+    close(n(_C.rowdot(xo, f, _C.FACTOR_RK)), n(xo).astype(np.float64) @ n(f).T, np.abs(n(xo)) @ np.abs(n(f)).T, msg="unaligned")
+
+
+@pytest.mark.parametrize("M,N,r", [(512, 320, 4), (300, 2560, 4), (64, 10240, 4), (33, 640, 16), (129, 1280, 8),
+                                   (40, 512, 64), (9, 77, 3), (1, 8, 1), (1000, 1288, 2)])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("layout", [_C.FACTOR_RK, _C.FACTOR_KR])
+def test_rank_update_matches_oracle(M, N, r, dt, layout):
+    y0 = rnd((M, N), dt, seed=6)
+    t = rnd((M, r), "f32", seed=7)
+    f = rnd((r, N) if layout == _C.FACTOR_RK else (N, r), "f32", 0.3, seed=8)
+    fr = n(f) if layout == _C.FACTOR_RK else n(f).T
+    want = n(y0).astype(np.float64) + 0.6 * (n(t).astype(np.float64) @ fr)
+    absref = np.abs(n(y0)) + 0.6 * (np.abs(n(t)) @ np.abs(fr))
+    y = y0.clone()
+    _C.rank_update_(y, t, f, layout, 0.6)
+    close(n(y), want, absref, dt, msg=f"rank_update {M}x{N} r{r} {dt}")
+
+
+@pytest.mark.parametrize("M,K,r", [(512, 320, 4), (300, 768, 4), (1000, 2560, 4), (70, 4104, 8), (33, 640, 16), (64, 320, 40),
+                                   (9, 77, 3), (1, 8, 1), (4096, 1280, 4)])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("layout", [_C.FACTOR_RK, _C.FACTOR_KR])
+def test_colreduce_matches_oracle(M, K, r, dt, layout):
+    x = rnd((M, K), dt, seed=9)
+    t = rnd((M, r), "f32", seed=10)
+    want = 0.5 * (n(t).T.astype(np.float64) @ n(x).astype(np.float64))
+    absref = 0.5 * (np.abs(n(t)).T @ np.abs(n(x)))
+    d = _C.colreduce(x, t, layout, 0.5)
+    got = n(d) if layout == _C.FACTOR_RK else n(d).T
+    close(got, want, absref, msg=f"colreduce {M}x{K} r{r}")
+    # accumulate into an existing buffer (beta = 1): the trainer's flat-grad path
+    prev = rnd(tuple(d.shape), "f32", seed=11)
+    acc = prev.clone()
+    _C.colreduce(x, t, layout, 0.5, out=acc, beta=1.0)
+    got2 = n(acc) if layout == _C.FACTOR_RK else n(acc).T
+    pv = n(prev) if layout == _C.FACTOR_RK else n(prev).T
+    close(got2, want + pv, absref + np.abs(pv), msg="colreduce beta=1")
+
+
+def test_dropout_mask_is_shared_by_forward_and_backward_kernels():
+    M, N, p = 200, 640, 0.25
+    ones_t = torch.ones(M, 1, device=DEV)
+    ones_f = torch.ones(1, N, device=DEV)
+    y = torch.zeros(M, N, device=DEV)
+    _C.rank_update_(y, ones_t, ones_f, _C.FACTOR_RK, 1.0, p, 1234, 77)
+    mask = n(y)
+    keep = 1.0 / (1.0 - p)
+    assert set(np.unique(mask)).issubset({0.0, np.float32(keep)})
+    rate = (mask > 0).mean()
+    assert abs(rate - (1 - p)) < 4 * np.sqrt(p * (1 - p) / mask.size) + 1e-3, rate  # 4 sigma + 16-bit threshold step
+    y2 = torch.zeros(M, N, device=DEV)
+    _C.rank_update_(y2, ones_t, ones_f, _C.FACTOR_RK, 1.0, p, 1234, 77)
+    assert torch.equal(y, y2)  # deterministic in (seed, offset)
+    y3 = torch.zeros(M, N, device=DEV)
+    _C.rank_update_(y3, ones_t, ones_f, _C.FACTOR_RK, 1.0, p, 1234, 78)
+    assert not torch.equal(y, y3)
+    ones_x = torch.ones(M, N, device=DEV)
+    rs = _C.rowdot(ones_x, ones_f, _C.FACTOR_RK, 1.0, None, False, p, 1234, 77)
+    np.testing.assert_allclose(n(rs)[:, 0], mask.sum(1), rtol=1e-5)
+    cs = _C.colreduce(ones_x, ones_t, _C.FACTOR_RK, 1.0, dropout_p=p, seed=1234, offset=77)
+    np.testing.assert_allclose(n(cs)[0], mask.sum(0), rtol=1e-5)
+    # bf16 activations use the same element indexing
+    yb = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    _C.rank_update_(yb, ones_t, ones_f, _C.FACTOR_RK, 1.0, p, 1234, 77)
+    assert np.array_equal(n(yb) > 0, mask > 0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_linear_module_matches_reference_vectors(tag):
+    d = _npz("linear_cases.npz")
+    M, K = d[f"{tag}_x"].shape
+    N, r = d[f"{tag}_up"].shape
+    m = L.LoraInjectedLinear(K, N, f"{tag}_b" in d, r=r, dropout_p=0.0, scale=float(d[f"{tag}_scale"]))
+    m.linear.weight.data = torch.from_numpy(d[f"{tag}_W"])
+    if f"{tag}_b" in d:
+        m.linear.bias.data = torch.from_numpy(d[f"{tag}_b"])
+    m.lora_down.weight.data = torch.from_numpy(d[f"{tag}_down"])
+    m.lora_up.weight.data = torch.from_numpy(d[f"{tag}_up"])
+    if f"{tag}_sel" in d:
+        m.set_selector_from_diag(torch.from_numpy(np.diag(d[f"{tag}_sel"]).copy()))
+    m.to(DEV)
+    x = torch.from_numpy(d[f"{tag}_x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * torch.from_numpy(d[f"{tag}_gy"]).to(DEV)).sum().backward()
+    for name, got, want in (("y", y, d[f"{tag}_y"]), ("dx", x.grad, d[f"{tag}_dx"]),
+                            ("ddown", m.lora_down.weight.grad, d[f"{tag}_ddown"]),
+                            ("dup", m.lora_up.weight.grad, d[f"{tag}_dup"])):
+        np.testing.assert_allclose(n(got), want, rtol=2e-4, atol=2e-4 * np.abs(want).max(), err_msg=f"{tag} {name}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_linear_module_low_precision_and_autocast(dt):
+    M, K, N, r, s = 384, 320, 640, 4, 0.8
+    torch.manual_seed(0)
+    m = L.LoraInjectedLinear(K, N, True, r=r, dropout_p=0.0, scale=s)
+    m.lora_up.weight.data.normal_(0, 0.05)
+    x32 = torch.randn(2, M // 2, K)
+    gy32 = torch.randn(2, M // 2, N)
+    # (1) resident low-precision frozen weights, f32 factors
+    mb = L.LoraInjectedLinear(K, N, True, r=r, dropout_p=0.0, scale=s)
+    mb.load_state_dict(m.state_dict())
+    mb.linear.to(DT[dt])
+    mb.to(DEV)
+    xb = x32.to(DT[dt]).to(DEV).requires_grad_(True)
+    yb = mb(xb)
+    assert yb.dtype == DT[dt] and yb.shape == (2, M // 2, N)
+    (yb.float() * gy32.to(DEV)).sum().backward()
+    W, b = n(mb.linear.weight), n(mb.linear.bias)
+    X, A, B = n(xb).reshape(M, K), n(mb.lora_down.weight), n(mb.lora_up.weight)
+    Gy = n(gy32.to(DT[dt])).reshape(M, N)  # autograd hands the kernel a dt-rounded G
+    yo, _ = O.lora_linear_forward(X, W, b, A, B, s)
+    dxo, ddo, duo, _, _ = O.lora_linear_backward(Gy, X, W, A, B, s)
+    e = 4 * EPS[dt]
+    np.testing.assert_allclose(n(yb).reshape(M, N), yo, rtol=e, atol=e * np.abs(yo).max())
+    np.testing.assert_allclose(n(xb.grad).reshape(M, K), dxo, rtol=e, atol=e * np.abs(dxo).max())
+    np.testing.assert_allclose(n(mb.lora_down.weight.grad), ddo, rtol=1e-3, atol=1e-3 * np.abs(ddo).max())
+    np.testing.assert_allclose(n(mb.lora_up.weight.grad), duo, rtol=1e-3, atol=1e-3 * np.abs(duo).max())
+    assert mb.lora_up.weight.grad.dtype == torch.float32
+    # (2) reference-style autocast: f32 weights + activations, compute dtype from the autocast context
+    ma = L.LoraInjectedLinear(K, N, True, r=r, dropout_p=0.0, scale=s)
+    ma.load_state_dict(m.state_dict())
+    ma.to(DEV)
+    xa = x32.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=DT[dt]):
+        ya = ma(xa)
+    assert ya.dtype == DT[dt]
+    (ya.float() * gy32.to(DEV)).sum().backward()
+    yo2, _ = O.lora_linear_forward(O.round_to(n(xa).reshape(M, K), dt), O.round_to(n(ma.linear.weight), dt),
+                                   O.round_to(n(ma.linear.bias), dt), A, B, s)
+    np.testing.assert_allclose(n(ya).reshape(M, N), yo2, rtol=e, atol=e * np.abs(yo2).max())
+    assert xa.grad.dtype == torch.float32 and ma.lora_down.weight.grad is not None
+
+
+def test_linear_module_dropout_train_eval_and_grad_consistency():
+    M, K, N, r, p = 256, 320, 320, 4, 0.5
+    torch.manual_seed(1)
+    m = L.LoraInjectedLinear(K, N, False, r=r, dropout_p=p, scale=1.0).to(DEV)
+    m.lora_up.weight.data.normal_(0, 0.1)
+    x = torch.randn(M, K, device=DEV)
+    W, A, B = n(m.linear.weight), n(m.lora_down.weight), n(m.lora_up.weight)
+    m.eval()
+    yo, _ = O.lora_linear_forward(n(x), W, None, A, B, 1.0)
+    np.testing.assert_allclose(n(m(x)), yo, rtol=2e-4, atol=2e-4 * np.abs(yo).max())  # eval: dropout off
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    # regenerate the mask the kernels used from its (seed, offset): no mask tensor was ever stored
+    seed, off = int(torch.initial_seed()), ops._dropout_calls
+    mk = torch.zeros(M, N, device=DEV)
+    _C.rank_update_(mk, torch.ones(M, 1, device=DEV), torch.ones(1, N, device=DEV), _C.FACTOR_RK, 1.0, p, seed, off)
+    mask = n(mk)
+    assert 0.45 < (mask > 0).mean() < 0.55 and set(np.unique(mask)) == {0.0, 2.0}
+    yo, _ = O.lora_linear_forward(n(x), W, None, A, B, 1.0, None, mask)
+    np.testing.assert_allclose(n(y), yo, rtol=2e-4, atol=2e-4 * np.abs(yo).max())
+    gy = torch.randn(M, N, device=DEV)
+    (y * gy).sum().backward()
+    dxo, ddo, duo, _, _ = O.lora_linear_backward(n(gy), n(x), W, A, B, 1.0, None, mask)
+    np.testing.assert_allclose(n(xg.grad), dxo, rtol=2e-4, atol=2e-4 * np.abs(dxo).max())
+    np.testing.assert_allclose(n(m.lora_up.weight.grad), duo, rtol=2e-4, atol=2e-4 * np.abs(duo).max())
+    np.testing.assert_allclose(n(m.lora_down.weight.grad), ddo, rtol=2e-4, atol=2e-4 * np.abs(ddo).max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_conv_module_matches_reference_vectors(tag):
+    d = _npz("conv_cases.npz")
+    k, s, p, r = (int(v) for v in d[f"{tag}_geom"])
+    Co, Ci = d[f"{tag}_W"].shape[:2]
+    m = L.LoraInjectedConv2d(Ci, Co, k, s, p, r=r, dropout_p=0.0, scale=float(d[f"{tag}_scale"]))
+    for mod, key in ((m.conv, "W"), (m.lora_down, "down"), (m.lora_up, "up")):
+        mod.weight.data = torch.from_numpy(d[f"{tag}_{key}"])
+    m.conv.bias.data = torch.from_numpy(d[f"{tag}_b"])
+    m.to(DEV)
+    x = torch.from_numpy(d[f"{tag}_x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * torch.from_numpy(d[f"{tag}_gy"]).to(DEV)).sum().backward()
+    for name, got, want in (("y", y, d[f"{tag}_y"]), ("dx", x.grad, d[f"{tag}_dx"]),
+                            ("ddown", m.lora_down.weight.grad, d[f"{tag}_ddown"]),
+                            ("dup", m.lora_up.weight.grad, d[f"{tag}_dup"])):
+        np.testing.assert_allclose(n(got), want, rtol=5e-4, atol=5e-4 * np.abs(want).max(), err_msg=f"{tag} {name}")
+
+
+def _ulp(x, dt):
+    return np.abs(x) * {"bf16": 2.0 ** -7, "f16": 2.0 ** -10, "f32": 2.0 ** -22}[dt] + 1e-30
+
+
+def test_collapse_matches_reference_vectors_on_device():
+    d = _npz("collapse_cases.npz")
+    for c in json.load(open(os.path.join(G, "collapse_cases.json"))):
+        tag = c["tag"]
+        wdt, abdt = DT[c["w_dtype"]], DT[c["ab_dtype"]]
+        if c["kind"] == "linear":
+            m, root = L.LoraInjectedLinear(40, 24, False, r=4, scale=3.0), H.named_class("CrossAttention")()
+            frozen = m.linear
+        else:
+            m, root = L.LoraInjectedConv2d(8, 12, 3, 1, 1, r=4, scale=3.0), H.named_class("ResnetBlock2D")()
+            frozen = m.conv
+        frozen.weight.data = torch.from_numpy(d[f"{tag}_W"]).to(wdt)
+        m.lora_up.weight.data = torch.from_numpy(d[f"{tag}_up"]).to(abdt)
+        m.lora_down.weight.data = torch.from_numpy(d[f"{tag}_down"]).to(abdt)
+        root.add_module("site", m)
+        root.to(DEV)
+        old = frozen.weight
+        L.collapse_lora(root, c["alpha"])
+        assert frozen.weight is not old and frozen.weight.dtype == wdt and frozen.weight.shape == old.shape
+        got, ref = n(frozen.weight), d[f"{tag}_out"]
+        assert np.all(np.abs(got - ref) <= _ulp(ref, c["w_dtype"])), tag
+        assert (got != ref).mean() < 0.01, f"{tag}: {(got != ref).mean():.4f} differ"
+
+
+def test_batched_merge_many_sites_one_launch():
+    """Ragged mix of site shapes/ranks incl. column-tiled (K > LDS slab), odd K (scalar lanes), in-place."""
+    shapes = [(320, 320, 4), (640, 768, 4), (2560, 320, 4), (1280, 2880, 4), (320, 1280, 16), (77, 33, 3), (8, 8, 1),
+              (640, 5760, 8), (130, 648, 64)]
+    for wdt, abdt in (("bf16", "f32"), ("f32", "f32"), ("f16", "f16"), ("bf16", "bf16")):
+        sites, want = [], []
+        for i, (N, K, r) in enumerate(shapes):
+            w = rnd((N, K), wdt, 0.05, seed=20 + i)
+            up = rnd((N, r), abdt, 0.1, seed=40 + i)
+            down = rnd((r, K), abdt, 0.5, seed=60 + i)
+            out = w if i % 2 else torch.empty_like(w)  # odd sites merge in place
+            want.append(O.collapse(n(w), n(up), n(down), 0.9, wdt, abdt))
+            sites.append((w, out, up, down))
+        plan = _C.MergePlan(sites)
+        plan.launch(0.9, _C.ROUND_REFERENCE)
+        torch.cuda.synchronize()
+        for i, (s, ref) in enumerate(zip(sites, want)):
+            got = n(s[1])
+            assert np.all(np.abs(got - ref) <= _ulp(ref, wdt)), (wdt, abdt, shapes[i])
+            assert (got != ref).mean() < 0.01, (wdt, abdt, shapes[i], (got != ref).mean())
+    # single-rounding mode is at least as close to the exact f64 result
+    w, up, down = rnd((640, 320), "bf16", 0.05, seed=1), rnd((640, 4), "f32", 0.1, seed=2), rnd((4, 320), "f32", 0.5, seed=3)
+    o_ref, o_once = torch.empty_like(w), torch.empty_like(w)
+    _C.MergePlan([(w, o_ref, up, down)]).launch(0.9, _C.ROUND_REFERENCE)
+    _C.MergePlan([(w, o_once, up, down)]).launch(0.9, _C.ROUND_ONCE)
+    exact = n(w).astype(np.float64) + 0.9 * (n(up).astype(np.float64) @ n(down).astype(np.float64))
+    assert np.abs(n(o_once) - exact).mean() <= np.abs(n(o_ref) - exact).mean() + 1e-12
+    assert np.all(np.abs(n(o_once) - exact) <= _ulp(exact, "bf16") * 0.51 + 1e-9)
+
+
+def test_merge_full_unet_size_properties():
+    """All 144 SD1.5 sites (bf16, rank 4): alpha=0 is the identity; result equals torch's expression on device."""
+    from lora_amd.standin import sd15_lora_site_shapes
+
+    sites = []
+    for i, (N, K) in enumerate(sd15_lora_site_shapes()):
+        w = rnd((N, K), "bf16", 0.03, seed=i)
+        sites.append((w, torch.empty_like(w), rnd((N, 4), "f32", 0.05, seed=1000 + i), rnd((4, K), "f32", 0.25, seed=2000 + i)))
+    assert len(sites) == 144
+    plan = _C.MergePlan(sites)
+    assert plan.bytes_algorithmic == sum(2 * N * K * 2 + (N + K) * 4 * 4 for N, K in sd15_lora_site_shapes())
+    plan.launch(0.0)
+    assert all(torch.equal(s[0], s[1]) for s in sites)
+    plan.launch(0.75)
+    for w, out, up, down in sites[::7]:
+        ref = w + 0.75 * (up @ down).type(w.dtype)
+        diff = (out.float() - ref.float()).abs()
+        assert (diff <= ref.float().abs() * 2.0 ** -7 + 1e-30).all() and (diff > 0).float().mean() < 0.01
+
+
+def test_sumsq_and_clip_adamw_match_torch_vectors():
+    d = _npz("optimizer_case.npz")
+    p = torch.from_numpy(d["p0"]).to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    groups = _C.make_adamw_groups([(0, 700, 1e-2, 1e-2), (700, 1000, 5e-3, 1e-2)], DEV)
+    ss = torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        g = torch.from_numpy(d[f"g{step}"]).to(DEV)
+        _C.sumsq(g, ss)
+        assert abs(ss.sqrt().item() - float(d[f"norm{step}"])) <= 1e-5 * max(1.0, float(d[f"norm{step}"]))
+        _C.clip_adamw(p, g, m, v, groups, 2, ss, 1.0, 1.0, 0.9, 0.999, 1e-8, step, True)
+        np.testing.assert_allclose(n(p), d[f"p{step}"], rtol=3e-6, atol=3e-7)
+        assert g.abs().sum().item() == 0.0  # zero_grad fused
+    # grad_scale = 1/world_size after a SUM all-reduce, no clipping
+    p2 = torch.from_numpy(d["p0"]).to(DEV)
+    m2, v2 = torch.zeros_like(p2), torch.zeros_like(p2)
+    g = (torch.from_numpy(d["g1"]) * 4).to(DEV)
+    _C.clip_adamw(p2, g, m2, v2, groups, 2, None, 0.25, 0.0, 0.9, 0.999, 1e-8, 1, False)
+    pa, _, _ = O.adamw_step(d["p0"][:700], d["g1"][:700], np.zeros(700), np.zeros(700), 1, lr=1e-2)
+    np.testing.assert_allclose(n(p2)[:700], pa, rtol=3e-6, atol=3e-7)
+    assert g.abs().sum().item() > 0
+
+
+def test_full_size_sd15_shapes_against_device_torch():
+    """BASELINE config-1 sizes (B=4, 512^2): the GEGLU site M=16384,K=320,N=2560 and attn 1280."""
+    for (M, K, N) in ((16384, 320, 2560), (1024, 1280, 1280), (308, 768, 320)):
+        x, g = rnd((M, K), "bf16", seed=1), rnd((M, N), "bf16", seed=2)
+        A, B = rnd((4, K), "f32", 0.25, seed=3), rnd((N, 4), "f32", 0.05, seed=4)
+        t = _C.rowdot(x, A, _C.FACTOR_RK)
+        t_ref = x.float() @ A.t()
+        assert torch.allclose(t, t_ref, rtol=1e-4, atol=1e-4 * t_ref.abs().max().item())
+        y = rnd((M, N), "bf16", seed=5)
+        y_ref = (y.float() + 0.8 * (t_ref @ B.t())).to(torch.bfloat16)
+        _C.rank_update_(y, t, B, _C.FACTOR_KR, 0.8)
+        assert ((y.float() - y_ref.float()).abs() <= y_ref.float().abs() * 2.0 ** -7 + 1e-6).all()
+        d_up = _C.colreduce(g, t, _C.FACTOR_KR, 0.8)
+        d_ref = 0.8 * (g.float().t() @ t_ref)
+        assert torch.allclose(d_up, d_ref, rtol=2e-4, atol=2e-4 * d_ref.abs().max().item())
+        gt = _C.rowdot(g, B, _C.FACTOR_KR, 0.8)
+        d_down = _C.colreduce(x, gt, _C.FACTOR_RK)
+        dd_ref = (0.8 * (g.float() @ B)).t() @ x.float()
+        assert torch.allclose(d_down, dd_ref, rtol=2e-4, atol=2e-4 * dd_ref.abs().max().item())
+
+
+def test_bad_arguments_raise():
+    x = rnd((8, 16), "bf16")
+    with pytest.raises(ValueError):
+        _C.rowdot(x.cpu(), rnd((4, 16), "f32"), _C.FACTOR_RK)
+    with pytest.raises(TypeError):
+        _C.rowdot(x.to(torch.float64), rnd((4, 16), "f32"), _C.FACTOR_RK)
+    with pytest.raises(ValueError):
+        _C.rowdot(rnd((8, 80), "bf16"), rnd((65, 80), "f32"), _C.FACTOR_RK)  # rank > 64
+    with pytest.raises(ValueError):
+        L.LoraInjectedLinear(4, 4, r=5)

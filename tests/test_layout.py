@@ -1,0 +1,36 @@
+"""Repository contract: the product never touches the oracle; required files exist."""
+import os
+import re
+
+from tests.helpers import REPO
+
+
+def _py_files(root):
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                yield os.path.join(d, f)
+
+
+def test_product_does_not_import_oracle_or_reference():
+    bad = []
+    for root in ("lora_amd", "training_scripts"):
+        for p in _py_files(os.path.join(REPO, root)):
+            src = open(p).read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "/root/reference" in src.replace(
+                    "``/root/reference", ""):
+                bad.append(p)
+    assert not bad, f"product code references the oracle or the reference tree: {bad}"
+
+
+def test_gpu_side_code_does_not_read_reference_at_runtime():
+    for p in ("bench.py", "__graft_entry__.py"):
+        path = os.path.join(REPO, p)
+        if os.path.exists(path):
+            assert "/root/reference" not in open(path).read(), p
+
+
+def test_required_layout():
+    for p in ("include/lora_amd.h", "oracle/lora_numpy.py", "oracle/torch_ref.py", "tests/golden", "profiles",
+              "__graft_entry__.py", "lora_amd/csrc/merge.hip", "lora_amd/csrc/linear.hip", "lora_amd/csrc/optim.hip"):
+        assert os.path.exists(os.path.join(REPO, p)), p
