@@ -281,6 +281,9 @@ def test_collapse_matches_reference_vectors_on_device():
         L.collapse_lora(root, c["alpha"])
         assert frozen.weight is not old and frozen.weight.dtype == wdt and frozen.weight.shape == old.shape
         got, ref = n(frozen.weight), d[f"{tag}_out"]
+        if c["w_dtype"] == "f32":  # f32: only the r-term dot product's summation order can differ (|q| ~ 1)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7, err_msg=tag)
+            continue
         assert np.all(np.abs(got - ref) <= _ulp(ref, c["w_dtype"])), tag
         assert (got != ref).mean() < 0.01, f"{tag}: {(got != ref).mean():.4f} differ"
 
@@ -303,6 +306,9 @@ def test_batched_merge_many_sites_one_launch():
         torch.cuda.synchronize()
         for i, (s, ref) in enumerate(zip(sites, want)):
             got = n(s[1])
+            if wdt == "f32":
+                np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7)
+                continue
             assert np.all(np.abs(got - ref) <= _ulp(ref, wdt)), (wdt, abdt, shapes[i])
             assert (got != ref).mean() < 0.01, (wdt, abdt, shapes[i], (got != ref).mean())
     # single-rounding mode is at least as close to the exact f64 result
