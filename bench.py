@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py — train steps/sec of the DreamBooth LoRA step (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one optimiser update of train_lora_dreambooth.py's loop (ref :816-888) on the workload
+BASELINE.json's configs[1] names: SD1.5-shaped UNet (859.5 M params, random init — no network for
+checkpoints), reference-default LoRA injection (144 Linear sites in CrossAttention/GEGLU), rank 4,
+bf16 compute with f32 LoRA masters, batch 4 synthetic 64x64x4 latents (= 512x512 images) per GPU,
+DDPM noise, MSE, backward, flat-buffer all-reduce (RCCL), clip(1.0), AdamW(lr 1e-4, wd 1e-2).
+Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for `roofline` and `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import lora_amd as L  # noqa: E402
+from lora_amd import _C, trainer as T  # noqa: E402
+from lora_amd.standin import DDPMScheduler, sd15_unet  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_unet(device, dtype, seed=0):
+    """Random-init SD1.5-shaped UNet, built on the meta device and filled in place (fast, deterministic)."""
+    with torch.device("meta"):
+        unet = sd15_unet()
+    unet.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if p.dim() > 1:
+                p.normal_(0.0, 0.02, generator=g)
+            elif name.endswith("weight"):  # norm scales
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    unet.to(dtype)
+    unet.requires_grad_(False)
+    return unet
+
+
+def merge_roofline(unet, iters=30):
+    """K3 fused merge over all adapter sites of this UNet, timed with HIP events on the launch stream."""
+    sites = []
+    for m in unet.modules():
+        if isinstance(m, L.LoraInjectedLinear):
+            w = m.linear.weight.data
+            sites.append((w, torch.empty_like(w), m.lora_up.weight.data.contiguous(), m.lora_down.weight.data.contiguous()))
+    plan = _C.MergePlan(sites)
+    for _ in range(3):
+        plan.launch(1.0)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        plan.launch(1.0)
+        b.record()
+    torch.cuda.synchronize()
+    avg_s = sum(a.elapsed_time(b) for a, b in evs) / iters * 1e-3
+    ach = plan.bytes_algorithmic / avg_s / 1e9
+    return {"kernel": "lora_amd::merge_kernel<bf16,f32> (K3 fused W+alpha*up@down, all %d sites, 1 launch)" % plan.n_sites,
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": plan.bytes_algorithmic, "avg_launch_us": round(avg_s * 1e6, 2),
+            "launches_timed": iters}
+
+
+def cpu_baseline(rank_r=4, budget_s=25.0):
+    """The reference's algorithm (oracle/torch_ref.py restatement: the reference tree does not travel to this box)
+    on the host cores: fp32 CPU PyTorch, same UNet geometry, same step; bounded sample."""
+    from oracle import torch_ref as TR
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    unet = build_unet(torch.device("cpu"), torch.float32, seed=0)
+    params = TR.inject(unet, L.UNET_DEFAULT_TARGET_REPLACE, r=rank_r)
+    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    sched = DDPMScheduler()
+    unet.train()
+
+    def one(batch):
+        g = torch.Generator().manual_seed(0)
+        lat = torch.randn(batch, 4, 64, 64, generator=g) * 0.18215
+        ehs = torch.randn(batch, 77, 768, generator=g)
+        noise = torch.randn(batch, 4, 64, 64, generator=g)
+        t = torch.randint(0, 1000, (batch,), generator=g)
+        t0 = time.perf_counter()
+        TR.dreambooth_step(lambda x, tt, c: unet(x, tt, c).sample, params, opt, lat, noise, t, ehs, sched.alphas_cumprod)
+        return time.perf_counter() - t0
+
+    t1 = one(1)  # also the warm-up (allocator, oneDNN primitives)
+    if t1 * 4 <= budget_s:
+        t4 = one(4)
+        return {"value": round(1.0 / t4, 5), "unit": "steps/s", "cores": cores, "kind": "port",
+                "sample": f"1 full step at batch 4 (same workload) after a batch-1 warm-up step; {t4:.2f} s"}
+    t1b = one(1) if t1 <= budget_s / 2 else t1
+    return {"value": round(1.0 / (4 * t1b), 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 step at batch 1 ({t1b:.2f} s) scaled x4 to the batch-4 workload (bounded sample)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (train_batch_size, ref :285-289)")
+    ap.add_argument("--rank", type=int, default=4, dest="lora_rank")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    _C.require()
+    rank, local, world = T.init_distributed("cuda")
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+
+    unet = build_unet(dev, torch.bfloat16, seed=0)
+    L.inject_trainable_lora(unet, r=args.lora_rank)  # reference default: dropout 0, scale 1
+    T.promote_lora_to_fp32(unet)
+    unet.train()
+    state = T.FlatLoraState([{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}], max_grad_norm=1.0,
+                            device=dev)
+    n_sites = state.attach_direct_grads(unet)
+    sched = DDPMScheduler()
+    cfg = T.StepConfig()
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank data shard
+    latents = (torch.randn(args.batch, 4, 64, 64, device=dev, generator=g) * 0.18215).to(torch.bfloat16)
+    ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(torch.bfloat16)
+
+    def fwd_bwd(lat, cond):
+        return T.forward_backward(unet, sched, lat, cond, cfg)
+
+    mode = args.mode
+    runner = fwd_bwd
+    if mode == "graph":
+        try:
+            runner = T.GraphedForwardBackward(fwd_bwd, latents, ehs, state)
+        except Exception as e:  # capture unsupported in this environment: say so, run eager
+            log(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager")
+            mode, runner = "eager", fwd_bwd
+            state.zero_grad()
+
+    def step():
+        loss = runner(latents, ehs)
+        scale = state.all_reduce()
+        state.step(scale)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        out = {
+            "metric": "train steps/sec SD1.5 rank-4 512^2 (train_lora_dreambooth.py step)",
+            "value": round(args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
+                                   "latents), reference-default injection (%d Linear sites: Q/K/V/O + GEGLU), f32 LoRA "
+                                   "masters, DDPM+MSE+clip(1.0)+AdamW" % (args.lora_rank, args.batch, n_sites),
+                       "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
+                       "parallelism": f"dp{world}", "execution": mode, "host_model": "stand-in UNet2DConditionModel "
+                       "(859,520,964 params, random init)", "trainable_params": state.n,
+                       "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},
+        }
+        if not args.no_roofline:
+            out["roofline"] = merge_roofline(unet)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.lora_rank)
+            except Exception as e:  # never lose the GPU line to a host-side problem
+                out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,15 @@ int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *exp_avg_sq,
                         float max_norm, float beta1, float beta2, float eps,
                         int64_t step, int32_t zero_grad, void *stream);
 
+/* hipGraph-replayable form: the 1-based step is read from device memory, so a captured
+ * launch is identical from step to step; lora_amd_step_advance does step_dev[0] += 1. */
+int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float *exp_avg_sq,
+                            int64_t n, const lora_amd_adamw_group *groups_dev,
+                            int32_t n_groups, const float *sumsq, float grad_scale,
+                            float max_norm, float beta1, float beta2, float eps,
+                            const int64_t *step_dev, int32_t zero_grad, void *stream);
+int lora_amd_step_advance(int64_t *step_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,8 @@ SYMBOLS = (
     "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
-    "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw",
+    "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
+    "lora_amd_step_advance",
 )
 
 
@@ -74,6 +75,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_sumsq_workspace.restype = sz
     lib.lora_amd_sumsq.argtypes = [vp, i64, vp, vp, sz, vp]
     lib.lora_amd_clip_adamw.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, i64, i32, vp]
+    lib.lora_amd_clip_adamw_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, vp, i32, vp]
+    lib.lora_amd_step_advance.argtypes = [vp, vp]
+    lib.lora_amd_clip_adamw_dev.restype = lib.lora_amd_step_advance.restype = C.c_int
     for name in ("lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_rowdot",
                  "lora_amd_rowdot_masked", "lora_amd_rank_update", "lora_amd_colreduce", "lora_amd_sumsq",
                  "lora_amd_clip_adamw"):
@@ -287,14 +291,29 @@ def make_adamw_groups(groups: Sequence[Tuple[int, int, float, float]], device) -
 
 def clip_adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, groups_dev: torch.Tensor,
                n_groups: int, sumsq_t: Optional[torch.Tensor], grad_scale: float, max_norm: float, beta1: float,
-               beta2: float, eps: float, step: int, zero_grad: bool = True) -> None:
+               beta2: float, eps: float, step, zero_grad: bool = True) -> None:
+    """``step``: python int (1-based), or a device int64 tensor (hipGraph-replayable; advance it with
+    :func:`step_advance`)."""
     lib = require()
     _dev_check(p, g, m, v, groups_dev, sumsq_t)
     for t in (p, g, m, v):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
             raise ValueError("clip_adamw: flat contiguous f32 buffers of equal length expected")
+    if torch.is_tensor(step):
+        if step.dtype != torch.int64 or not step.is_cuda:
+            raise ValueError("clip_adamw: device step must be an int64 device tensor")
+        _check(lib.lora_amd_clip_adamw_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                           groups_dev.data_ptr(), int(n_groups),
+                                           sumsq_t.data_ptr() if sumsq_t is not None else None, float(grad_scale),
+                                           float(max_norm), float(beta1), float(beta2), float(eps), step.data_ptr(),
+                                           int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw_dev")
+        return
     _check(lib.lora_amd_clip_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                    groups_dev.data_ptr(), int(n_groups),
                                    sumsq_t.data_ptr() if sumsq_t is not None else None, float(grad_scale),
                                    float(max_norm), float(beta1), float(beta2), float(eps), int(step),
                                    int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw")
+
+
+def step_advance(step_dev: torch.Tensor) -> None:
+    _check(require().lora_amd_step_advance(step_dev.data_ptr(), _stream()), "lora_amd_step_advance")

@@ -57,8 +57,13 @@ __global__ __launch_bounds__(kOptThreads) void sumsq_stage2(const float *__restr
 __global__ __launch_bounds__(kOptThreads) void clip_adamw_kernel(
     float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
     const lora_amd_adamw_group *__restrict__ groups, int n_groups, const float *__restrict__ sumsq,
-    float grad_scale, float max_norm, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-    int zero_grad) {
+    float grad_scale, float max_norm, float beta1, float beta2, float eps, int64_t step_host,
+    const int64_t *__restrict__ step_dev, int zero_grad) {
+  // bias corrections in double, as torch's python scalars are; the step may live on the device so
+  // that a captured hipGraph replays unchanged from step to step
+  const double step = (double)(step_dev != nullptr ? step_dev[0] : step_host);
+  const float bc1 = (float)(1.0 - pow((double)beta1, step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
   float coef = grad_scale;
   if (max_norm > 0.f) {
     // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -113,23 +118,46 @@ extern "C" int lora_amd_sumsq(const float *g, int64_t n, float *out_sumsq, void 
   return check_launch("lora_amd_sumsq");
 }
 
+static int clip_adamw_impl(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
+                           const lora_amd_adamw_group *groups_dev, int32_t n_groups, const float *sumsq,
+                           float grad_scale, float max_norm, float beta1, float beta2, float eps, int64_t step,
+                           const int64_t *step_dev, int32_t zero_grad, void *stream) {
+  LORA_AMD_CHECK(p && g && exp_avg && exp_avg_sq && groups_dev, LORA_AMD_EINVAL, "clip_adamw: null pointer");
+  LORA_AMD_CHECK(n >= 0 && n_groups >= 1 && n_groups <= 16, LORA_AMD_EINVAL, "clip_adamw: n=%lld n_groups=%d",
+                 (long long)n, n_groups);
+  LORA_AMD_CHECK(step_dev != nullptr || step >= 1, LORA_AMD_EINVAL, "clip_adamw: step must be >= 1 (got %lld)",
+                 (long long)step);
+  LORA_AMD_CHECK(max_norm <= 0.f || sumsq != nullptr, LORA_AMD_EINVAL, "clip_adamw: clipping needs sumsq");
+  if (n == 0) return LORA_AMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = (int)std::min<int64_t>((n + kOptThreads - 1) / kOptThreads, 2048);
+  hipLaunchKernelGGL(clip_adamw_kernel, dim3(grid), dim3(kOptThreads), 0, st, p, g, exp_avg, exp_avg_sq, n,
+                     groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1, beta2, eps, step, step_dev, zero_grad);
+  return check_launch("lora_amd_clip_adamw");
+}
+
 extern "C" int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
                                    const lora_amd_adamw_group *groups_dev, int32_t n_groups, const float *sumsq,
                                    float grad_scale, float max_norm, float beta1, float beta2, float eps,
                                    int64_t step, int32_t zero_grad, void *stream) {
-  LORA_AMD_CHECK(p && g && exp_avg && exp_avg_sq && groups_dev, LORA_AMD_EINVAL, "clip_adamw: null pointer");
-  LORA_AMD_CHECK(n >= 0 && n_groups >= 1 && n_groups <= 16, LORA_AMD_EINVAL, "clip_adamw: n=%lld n_groups=%d",
-                 (long long)n, n_groups);
-  LORA_AMD_CHECK(step >= 1, LORA_AMD_EINVAL, "clip_adamw: step must be >= 1 (got %lld)", (long long)step);
-  LORA_AMD_CHECK(max_norm <= 0.f || sumsq != nullptr, LORA_AMD_EINVAL, "clip_adamw: clipping needs sumsq");
-  if (n == 0) return LORA_AMD_OK;
-  hipStream_t st = (hipStream_t)stream;
-  // bias corrections in double, as torch's python scalars are
-  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-  int grid = (int)std::min<int64_t>((n + kOptThreads - 1) / kOptThreads, 2048);
-  hipLaunchKernelGGL(clip_adamw_kernel, dim3(grid), dim3(kOptThreads), 0, st, p, g, exp_avg, exp_avg_sq, n,
-                     groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1, beta2, eps, (float)bc1,
-                     (float)std::sqrt(bc2), zero_grad);
-  return check_launch("lora_amd_clip_adamw");
+  return clip_adamw_impl(p, g, exp_avg, exp_avg_sq, n, groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1,
+                         beta2, eps, step, nullptr, zero_grad, stream);
+}
+
+extern "C" int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                       const lora_amd_adamw_group *groups_dev, int32_t n_groups,
+                                       const float *sumsq, float grad_scale, float max_norm, float beta1,
+                                       float beta2, float eps, const int64_t *step_dev, int32_t zero_grad,
+                                       void *stream) {
+  LORA_AMD_CHECK(step_dev != nullptr, LORA_AMD_EINVAL, "clip_adamw_dev: null step pointer");
+  return clip_adamw_impl(p, g, exp_avg, exp_avg_sq, n, groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1,
+                         beta2, eps, 0, step_dev, zero_grad, stream);
+}
+
+__global__ void step_advance_kernel(int64_t *step) { step[0] += 1; }
+
+extern "C" int lora_amd_step_advance(int64_t *step_dev, void *stream) {
+  LORA_AMD_CHECK(step_dev != nullptr, LORA_AMD_EINVAL, "step_advance: null pointer");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return check_launch("lora_amd_step_advance");
 }

@@ -1,0 +1,295 @@
+"""Training step of the DreamBooth/PTI LoRA loop, MI355X-first.
+
+What the reference does per step (training_scripts/train_lora_dreambooth.py:816-888) and what
+this module does instead:
+
+* ``accelerator.backward`` -> DDP bucketed NCCL all-reduce of every trainable grad
+    -> ONE ``all_reduce`` (RCCL over xGMI) of ONE flat f32 buffer that already holds every
+       LoRA gradient: the adapters' backward kernels accumulate straight into it.
+* ``clip_grad_norm_`` over *all* UNet parameters (860 M frozen elements scanned), ``AdamW.step``,
+  ``zero_grad``  -> two launches over the flat buffers (``sumsq`` + ``clip_adamw``), no host sync.
+* per-step Python -> the forward/backward can be captured once into a hipGraph and replayed.
+
+CPU tensors take a plain-torch path with the same maths (config 0 and the gloo tests).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _C
+from .lora import LoraInjectedConv2d, LoraInjectedLinear
+
+
+class FlatLoraState:
+    """Every trainable LoRA tensor (of one or more models) as views of ONE flat f32 buffer, with flat
+    gradient / Adam-moment twins.  ``groups``: ``[{"params": [...], "lr": float, "weight_decay": float}]``
+    (the reference's two param groups: UNet lr / text-encoder lr, ref :659-676)."""
+
+    def __init__(self, groups: Sequence[dict], betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
+                 device: Optional[torch.device] = None):
+        params: List[torch.nn.Parameter] = []
+        self.group_ranges, self.lrs, self.wds = [], [], []
+        pos = 0
+        self.slices = {}
+        for g in groups:
+            begin = pos
+            for p in g["params"]:
+                if id(p) in self.slices:
+                    continue
+                self.slices[id(p)] = (pos, pos + p.numel())
+                params.append(p)
+                pos += p.numel()
+            self.group_ranges.append((begin, pos))
+            self.lrs.append(float(g["lr"]))
+            self.wds.append(float(g.get("weight_decay", 1e-2)))
+        if pos == 0:
+            raise ValueError("FlatLoraState: no parameters")
+        self.params = params
+        self.n = pos
+        self.device = device or params[0].device
+        self.betas, self.eps, self.max_grad_norm = betas, float(eps), float(max_grad_norm)
+        self.flat_p = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        for p in params:
+            a, b = self.slices[id(p)]
+            self.flat_p[a:b].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[a:b].view(p.shape)  # fp32 master, aliasing the flat buffer
+            p.grad = self.flat_g[a:b].view(p.shape)
+        self.step_count = 0
+        self.on_device = self.device.type == "cuda"
+        if self.on_device:
+            _C.require()
+            self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._ws = torch.empty(1024, dtype=torch.float32, device=self.device)
+            self._groups_dev = _C.make_adamw_groups(self._group_rows(), self.device)
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def _group_rows(self):
+        return [(a, b, lr, wd) for (a, b), lr, wd in zip(self.group_ranges, self.lrs, self.wds)]
+
+    @property
+    def payload_bytes(self) -> int:
+        return self.n * 4
+
+    def set_lrs(self, lrs: Sequence[float]) -> None:
+        self.lrs = [float(x) for x in lrs]
+        if self.on_device:  # same device tensor: captured graphs keep pointing at it
+            self._groups_dev.copy_(_C.make_adamw_groups(self._group_rows(), "cpu"), non_blocking=True)
+
+    def grad_view(self, p: torch.nn.Parameter) -> torch.Tensor:
+        a, b = self.slices[id(p)]
+        return self.flat_g[a:b].view(p.shape)
+
+    def attach_direct_grads(self, *models: torch.nn.Module) -> int:
+        """Let the adapters' backward kernels accumulate dA/dB directly into ``flat_g`` (no autograd
+        AccumulateGrad launch per tensor).  Returns the number of adapters wired."""
+        n = 0
+        for model in models:
+            for m in model.modules():
+                if isinstance(m, LoraInjectedLinear) and id(m.lora_down.weight) in self.slices \
+                        and id(m.lora_up.weight) in self.slices:
+                    m.__dict__["_grad_slots"] = (self.grad_view(m.lora_down.weight), self.grad_view(m.lora_up.weight))
+                    n += 1
+        return n
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+
+    def all_reduce(self) -> float:
+        """SUM all-reduce of the flat gradient; returns the scale (1/world) the optimiser applies."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step(self, grad_scale: float = 1.0, graph_safe: bool = False) -> None:
+        """clip_grad_norm_(max_grad_norm) -> AdamW -> zero_grad over the flat buffers (ref :878-888)."""
+        self.step_count += 1
+        b1, b2 = self.betas
+        if self.on_device:
+            clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
+            if clip > 0:
+                _C.sumsq(self.flat_g, self._sumsq, self._ws)
+            if graph_safe:
+                _C.step_advance(self._step_dev)
+                step = self._step_dev
+            else:
+                step = self.step_count
+            _C.clip_adamw(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self._groups_dev,
+                          len(self.group_ranges), self._sumsq if clip > 0 else None, grad_scale, clip, b1, b2,
+                          self.eps, step, True)
+            return
+        # CPU plumbing path (same maths as csrc/optim.hip)
+        g = self.flat_g * grad_scale
+        if self.max_grad_norm and self.max_grad_norm > 0:
+            total = g.norm(2)
+            g = g * torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0)
+        bc1 = 1 - b1 ** self.step_count
+        bc2 = 1 - b2 ** self.step_count
+        for (a, b), lr, wd in zip(self.group_ranges, self.lrs, self.wds):
+            p, gg, m, v = self.flat_p[a:b], g[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b]
+            p.mul_(1 - lr * wd)
+            m.lerp_(gg, 1 - b1)
+            v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+            p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(self.eps), value=-lr / bc1)
+        self.flat_g.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.flat_g.norm(2)
+
+
+def lora_params(model: torch.nn.Module) -> List[torch.nn.Parameter]:
+    """[up, down, up, down, ...] of every adapter in registration order (the order the reference's
+    ``itertools.chain(*unet_lora_params)`` produces, ref :661, lora.py:298-299)."""
+    out = []
+    for m in model.modules():
+        if isinstance(m, (LoraInjectedLinear, LoraInjectedConv2d)):
+            out += [m.lora_up.weight, m.lora_down.weight]
+    return out
+
+
+def promote_lora_to_fp32(model: torch.nn.Module) -> None:
+    """Injection casts the new factors to the frozen weight's dtype (lora.py:295); with bf16-resident
+    frozen weights the trainable masters must go back to f32 (what autocast training keeps them at)."""
+    for p in lora_params(model):
+        if p.dtype != torch.float32:
+            p.data = p.data.float()
+
+
+@dataclass
+class StepConfig:
+    with_prior_preservation: bool = False
+    prior_loss_weight: float = 1.0
+    num_train_timesteps: int = 1000
+    t_multiplier: float = 1.0  # cli_lora_pti.py:300 (0.8 in perform_tuning)
+    prediction_type: str = "epsilon"
+    autocast_dtype: Optional[torch.dtype] = None  # reference-style mixed precision; None = model dtype
+
+
+def dreambooth_loss(model_pred: torch.Tensor, target: torch.Tensor, cfg: StepConfig) -> torch.Tensor:
+    """ref: train_lora_dreambooth.py:855-875."""
+    if cfg.with_prior_preservation:
+        pred, pred_prior = torch.chunk(model_pred, 2, dim=0)
+        tgt, tgt_prior = torch.chunk(target, 2, dim=0)
+        loss = F.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3]).mean()
+        return loss + cfg.prior_loss_weight * F.mse_loss(pred_prior.float(), tgt_prior.float(), reduction="mean")
+    return F.mse_loss(model_pred.float(), target.float(), reduction="mean")
+
+
+def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConfig,
+                     text_encoder=None, noise: Optional[torch.Tensor] = None,
+                     timesteps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """noise -> add_noise -> (text encoder) -> UNet -> loss -> backward (ref :823-877).
+    ``cond``: token ids [B, 77] when ``text_encoder`` is given, else encoder hidden states [B, 77, C]."""
+    if noise is None:
+        noise = torch.randn_like(latents)
+    if timesteps is None:
+        timesteps = torch.randint(0, int(cfg.num_train_timesteps * cfg.t_multiplier), (latents.shape[0],),
+                                  device=latents.device).long()
+    noisy = scheduler.add_noise(latents, noise, timesteps)
+    ctx = torch.autocast(latents.device.type, dtype=cfg.autocast_dtype) if cfg.autocast_dtype is not None \
+        else torch.autocast(latents.device.type, enabled=False)
+    with ctx:
+        ehs = text_encoder(cond)[0] if text_encoder is not None else cond
+        pred = unet(noisy, timesteps, ehs).sample
+    if cfg.prediction_type == "epsilon":
+        target = noise
+    elif cfg.prediction_type == "v_prediction":
+        target = scheduler.get_velocity(latents, noise, timesteps)
+    else:
+        raise ValueError(f"Unknown prediction type {cfg.prediction_type}")
+    loss = dreambooth_loss(pred, target, cfg)
+    loss.backward()
+    return loss.detach()
+
+
+class GraphedForwardBackward:
+    """The forward+backward of one step captured into a hipGraph and replayed: removes the per-kernel
+    host launch cost (thousands of launches per step) that bounds eager execution.
+
+    Inputs are copied into static buffers; noise and timesteps are drawn inside the graph from torch's
+    graph-safe Philox generator, so every replay sees fresh randomness.  Gradients land in the
+    FlatLoraState's flat buffer (static address), the loss in ``self.loss``."""
+
+    def __init__(self, fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], latents: torch.Tensor,
+                 cond: torch.Tensor, state: FlatLoraState, warmup: int = 2):
+        self.latents, self.cond = latents.clone(), cond.clone()
+        self.state = state
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn(self.latents, self.cond)
+                state.zero_grad()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = fn(self.latents, self.cond)
+
+    def __call__(self, latents: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        self.latents.copy_(latents, non_blocking=True)
+        self.cond.copy_(cond, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
+def get_lr_lambda(name: str, num_warmup_steps: int, num_training_steps: int) -> Callable[[int], float]:
+    """Multipliers of diffusers.optimization.get_scheduler (un-vendored; ref :737-742)."""
+    w, T = max(0, num_warmup_steps), max(1, num_training_steps)
+
+    def warm(s):
+        return float(s) / float(max(1, w)) if s < w else None
+
+    if name == "constant":
+        return lambda s: 1.0
+    if name == "constant_with_warmup":
+        return lambda s: warm(s) if warm(s) is not None else 1.0
+    if name == "linear":
+        return lambda s: warm(s) if warm(s) is not None else max(0.0, float(T - s) / float(max(1, T - w)))
+    if name in ("cosine", "cosine_with_restarts"):
+        cycles = 0.5 if name == "cosine" else 1.0
+
+        def f(s):
+            if warm(s) is not None:
+                return warm(s)
+            prog = float(s - w) / float(max(1, T - w))
+            if name == "cosine":
+                return max(0.0, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * prog)))
+            return 0.0 if prog >= 1.0 else max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((cycles * prog) % 1.0))))
+        return f
+    if name == "polynomial":
+        def f(s, lr_end_ratio=1e-7 / 1.0, power=1.0):
+            if warm(s) is not None:
+                return warm(s)
+            if s > T:
+                return lr_end_ratio
+            return (1 - lr_end_ratio) * (1 - (s - w) / (T - w)) ** power + lr_end_ratio
+        return f
+    raise ValueError(f"unknown lr scheduler {name!r}")
+
+
+def init_distributed(device_type: str = "cuda"):
+    """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the launcher's environment.
+    backend "nccl" on ROCm is RCCL (xGMI within the node); gloo for CPU runs."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, local, world
