@@ -144,6 +144,58 @@ int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
+ * K1/K2 fused: one launch forward, two backward, one batched reduction per step.
+ * These are what LoraInjectedLinear runs for 16-byte-friendly shapes (K%8==0, N%8==0,
+ * rank <= 16); lora_amd_linear_plan says whether a shape qualifies and sizes the
+ * workspaces.  replaces: lora.py:53-58 (+ its autograd) — 5 + ~10 ATen launches per site.
+ * ---------------------------------------------------------------------- */
+typedef struct lora_amd_linear_plan_t {
+  int32_t fused;      /* 1: the fused entry points accept this shape */
+  int32_t rank_tile;  /* RT: r rounded up to 4 / 8 / 16 */
+  int32_t nct_g;      /* column tiles of the G pass (= number of Gt partials) */
+  int32_t nparts_up, nparts_down; /* row-block partials of dUp / dDown */
+  int32_t reserved;
+  int64_t gt_part_floats;   /* nct_g * M * r          */
+  int64_t up_part_floats;   /* nparts_up * RT * N     */
+  int64_t down_part_floats; /* nparts_down * RT * K   */
+} lora_amd_linear_plan_t;
+
+int lora_amd_linear_plan(int64_t M, int32_t K, int32_t N, int32_t r, lora_amd_linear_plan_t *out);
+
+/* Y[M,N] (in place, holds X W^T + b) += scale * mask * T @ up^T with T[M,r] = (X @ down^T) @ S^T,
+ * T also written to t_out (f32) for the backward.  lora.py:53-58. */
+int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, const void *down,
+                        const void *up, float *t_out, int64_t M, int32_t K, int32_t N, int32_t r,
+                        int32_t act_dtype, int32_t factor_dtype, float scale, const float *sel,
+                        float dropout_p, uint64_t seed, uint64_t offset, void *stream);
+
+/* One pass over G[M,N]: gt_part[nct_g][M][r] = scale * (mask*G) @ up (per column tile) and
+ * up_part[nparts_up][RT][N] = scale * (mask*G)^T @ T (per row block). */
+int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
+                          float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
+                          int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
+                          uint64_t offset, void *stream);
+
+/* One pass over X[M,K] (and dX, in place, holding G @ W; may be NULL): with Gt' = (sum gt_part) @ S,
+ * down_part[nparts_down][RT][K] = Gt'^T @ X (per row block) and dX += Gt' @ down. */
+int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, const float *gt_part,
+                          int32_t nct_g, const void *down, const float *sel, float *down_part, int64_t M,
+                          int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype, void *stream);
+
+/* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
+ * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient
+ * buffer once per step.  `begin` = exclusive prefix sum of r*C over the table; total = its end. */
+typedef struct lora_amd_reduce_desc {
+  const float *part;
+  float *out;
+  int64_t begin;
+  int32_t nparts, RT, C, r, layout, reserved;
+  float scale, beta;
+} lora_amd_reduce_desc;
+
+int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
+
+/* ------------------------------------------------------------------------
  * C2/K6  flat-buffer gradient clipping + AdamW.
  * replaces: train_lora_dreambooth.py:878-888 (clip_grad_norm_ over every UNet
  *           parameter, AdamW.step, zero_grad) for the LoRA parameters, which

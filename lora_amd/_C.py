@@ -29,6 +29,8 @@ SYMBOLS = (
     "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
+    "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
+    "lora_amd_reduce_batched",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance",
 )
@@ -49,6 +51,18 @@ class MergeSite(C.Structure):
 
 class AdamWGroup(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class LinearPlan(C.Structure):
+    _fields_ = [("fused", C.c_int32), ("rank_tile", C.c_int32), ("nct_g", C.c_int32), ("nparts_up", C.c_int32),
+                ("nparts_down", C.c_int32), ("reserved", C.c_int32), ("gt_part_floats", C.c_int64),
+                ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64)]
+
+
+class ReduceDesc(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("begin", C.c_int64), ("nparts", C.c_int32),
+                ("RT", C.c_int32), ("C", C.c_int32), ("r", C.c_int32), ("layout", C.c_int32),
+                ("reserved", C.c_int32), ("scale", C.c_float), ("beta", C.c_float)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -78,6 +92,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_clip_adamw_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, vp, i32, vp]
     lib.lora_amd_step_advance.argtypes = [vp, vp]
     lib.lora_amd_clip_adamw_dev.restype = lib.lora_amd_step_advance.restype = C.c_int
+    lib.lora_amd_linear_plan.argtypes = [i64, i32, i32, i32, C.POINTER(LinearPlan)]
+    lib.lora_amd_linear_fwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, f32, u64,
+                                        u64, vp]
+    lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+    lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
+    for name in ("lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
+                 "lora_amd_reduce_batched"):
+        getattr(lib, name).restype = C.c_int
     for name in ("lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_rowdot",
                  "lora_amd_rowdot_masked", "lora_amd_rank_update", "lora_amd_colreduce", "lora_amd_sumsq",
                  "lora_amd_clip_adamw"):
@@ -317,3 +340,81 @@ def clip_adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
 
 def step_advance(step_dev: torch.Tensor) -> None:
     _check(require().lora_amd_step_advance(step_dev.data_ptr(), _stream()), "lora_amd_step_advance")
+
+
+# ----------------------------------------------------------------------------- fused K1/K2
+_plan_cache = {}
+
+
+def linear_plan(M: int, K: int, N: int, r: int) -> LinearPlan:
+    key = (M, K, N, r)
+    pl = _plan_cache.get(key)
+    if pl is None:
+        pl = LinearPlan()
+        _check(require().lora_amd_linear_plan(M, K, N, r, C.byref(pl)), "lora_amd_linear_plan")
+        _plan_cache[key] = pl
+    return pl
+
+
+def _rows_ok(t: torch.Tensor) -> bool:
+    return (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.shape[1] % 8 == 0
+            and t.data_ptr() % (32 if t.dtype == torch.float32 else 16) == 0)
+
+
+def fused_ok(x: torch.Tensor, y_cols: int, r: int) -> bool:
+    return r <= 16 and _rows_ok(x) and y_cols % 8 == 0 and bool(linear_plan(x.shape[0], x.shape[1], y_cols, r).fused)
+
+
+def linear_fwd_(x: torch.Tensor, y: torch.Tensor, down: torch.Tensor, up: torch.Tensor, scale: float,
+                sel: Optional[torch.Tensor], dropout_p: float, seed: int, offset: int) -> torch.Tensor:
+    """y += scale*mask*((x @ down^T) @ S^T) @ up^T in place; returns T [M, r] f32."""
+    lib = require()
+    M, K = x.shape
+    N = y.shape[1]
+    r = down.shape[0]
+    t = torch.empty((M, r), dtype=torch.float32, device=x.device)
+    if sel is not None:
+        sel = sel.to(torch.float32).contiguous()
+    _check(lib.lora_amd_linear_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), down.data_ptr(),
+                                   up.data_ptr(), t.data_ptr(), M, K, N, r, dtype_code(x.dtype),
+                                   dtype_code(down.dtype), float(scale), sel.data_ptr() if sel is not None else None,
+                                   float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_linear_fwd")
+    return t
+
+
+def linear_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, gt_part: torch.Tensor, up_part: torch.Tensor,
+                 scale: float, dropout_p: float, seed: int, offset: int) -> None:
+    M, N = g.shape
+    _check(require().lora_amd_linear_bwd_g(g.data_ptr(), g.stride(0), t.data_ptr(), up.data_ptr(), gt_part.data_ptr(),
+                                           up_part.data_ptr(), M, N, t.shape[1], dtype_code(g.dtype),
+                                           dtype_code(up.dtype), float(scale), float(dropout_p), int(seed),
+                                           int(offset), _stream()), "lora_amd_linear_bwd_g")
+
+
+def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Tensor, nct_g: int, down: torch.Tensor,
+                 sel: Optional[torch.Tensor], down_part: torch.Tensor) -> None:
+    M, K = x.shape
+    if sel is not None:
+        sel = sel.to(torch.float32).contiguous()
+    _check(require().lora_amd_linear_bwd_x(x.data_ptr(), x.stride(0), dx.data_ptr() if dx is not None else None,
+                                           dx.stride(0) if dx is not None else 0, gt_part.data_ptr(), int(nct_g),
+                                           down.data_ptr(), sel.data_ptr() if sel is not None else None,
+                                           down_part.data_ptr(), M, K, down.shape[0], dtype_code(x.dtype),
+                                           dtype_code(down.dtype), _stream()), "lora_amd_linear_bwd_x")
+
+
+def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, float, float]],
+                      device) -> Tuple[torch.Tensor, int, int]:
+    """rows: (part, out, nparts, RT, C, r, layout, scale, beta) -> (device table, n, total work items)."""
+    arr = (ReduceDesc * len(rows))()
+    begin = 0
+    for d, (part, out, nparts, RT, Cc, r, layout, scale, beta) in zip(arr, rows):
+        d.part, d.out, d.begin = part.data_ptr(), out.data_ptr(), begin
+        d.nparts, d.RT, d.C, d.r, d.layout, d.scale, d.beta = nparts, RT, Cc, r, layout, scale, beta
+        begin += r * Cc
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(rows), begin
+
+
+def reduce_batched(table: torch.Tensor, n: int, total: int) -> None:
+    _check(require().lora_amd_reduce_batched(table.data_ptr(), int(n), int(total), _stream()),
+           "lora_amd_reduce_batched")

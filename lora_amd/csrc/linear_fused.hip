@@ -1,0 +1,673 @@
+// K1/K2 fused — one launch for the adapter forward, two for its backward.
+//
+//   linear_fwd    Y += scale * mask * ((X A^T) S^T) B^T,  T = (X A^T) S^T saved     [after the frozen GEMM]
+//   linear_bwd_g  one pass over G:  Gt = scale*(mask*G) B   and   dUp partials = (mask*G)^T T
+//   linear_bwd_x  one pass over X and dX:  dDown partials = Gt'^T X  and  dX += Gt' A   (Gt' = Gt S)
+//   reduce_batched  ONE launch per optimiser step sums every site's partials into the flat grad buffer
+//
+// replaces: lora_diffusion/lora.py:53-58 (5 ATen launches forward, ~10 in its autograd) per site.
+//
+// Mapping ("column owner"): a thread owns 8 consecutive columns (one 16-byte chunk) of a column tile of
+// ct8 chunks (ct8 = power of two dividing the row length, <= 64 so a row segment is one wave-slice) and
+// walks the rows of its row slot.  The rank-r factor columns it needs live in registers (r*8 floats,
+// loaded once per block with 16-byte loads that are all in flight together), per-row r-vectors (T, Gt)
+// live in LDS, K-reductions are xor-shuffles over the ct8 lanes, M-reductions are register accumulators
+// + an LDS slot reduction + per-block partials.  Everything is HBM-streaming: 16 B/lane, 4 loads in flight.
+#include <algorithm>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+constexpr int kFT = 256;             // threads per block
+constexpr int kFLdsFactor = 8192;    // floats, staged factor slab (forward)
+constexpr int kFLdsT = 2048;         // floats, per-row r-vectors
+
+__device__ inline float ldf(const void *p, int dt, int64_t i) {
+  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
+  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
+  return (float)reinterpret_cast<const __bf16 *>(p)[i];
+}
+
+// Factor slab -> LDS layout [RT][2][ncols/8][4] (two conflict-free 16-byte planes per lane).
+// f32 [r,C] slabs move as float4 with 4 loads in flight per thread; anything else element-wise.
+template <int RT>
+__device__ inline void stage_factor(float *s_f, const void *f, int fdt, int layout, int r, int64_t C, int c0,
+                                    int ncols) {
+  const int c8 = ncols >> 3;
+  const bool fast = fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_RK && (C & 3) == 0 && (c0 & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(f) & 15u) == 0);
+  if (fast) {
+    const int n4 = ncols >> 2, total = RT * n4;
+    const float *fp = reinterpret_cast<const float *>(f);
+    for (int i0 = threadIdx.x; i0 < total; i0 += kFT * 4) {
+      float4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kFT;
+        dst[u] = -1;
+        if (i < total) {
+          const int j = i / n4, c4 = i - j * n4;
+          dst[u] = ((j * 2 + (c4 & 1)) * c8 + (c4 >> 1)) * 4;
+          v[u] = j < r ? *reinterpret_cast<const float4 *>(fp + (int64_t)j * C + c0 + c4 * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<float4 *>(&s_f[dst[u]]) = v[u];
+    }
+    return;
+  }
+  if (fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_KR && r == 4 && RT == 4 &&
+      ((reinterpret_cast<uintptr_t>(f) & 15u) == 0)) {
+    // up [C, 4] f32: one 16-byte load per column brings all 4 ranks; 4 loads in flight per thread
+    const float *fp = reinterpret_cast<const float *>(f);
+    for (int c0b = threadIdx.x; c0b < ncols; c0b += kFT * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0b + u * kFT;
+        if (c < ncols) v[u] = *reinterpret_cast<const float4 *>(fp + (int64_t)(c0 + c) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0b + u * kFT;
+        if (c >= ncols) continue;
+        const int base = ((c >> 2) & 1) * c8 * 4 + (c >> 3) * 4 + (c & 3);
+        s_f[base + 0 * 2 * c8 * 4] = v[u].x; s_f[base + 1 * 2 * c8 * 4] = v[u].y;
+        s_f[base + 2 * 2 * c8 * 4] = v[u].z; s_f[base + 3 * 2 * c8 * 4] = v[u].w;
+      }
+    }
+    return;
+  }
+  const int total = RT * ncols;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < total; i += kFT) {
+    int j, c;
+    if (layout == LORA_AMD_FACTOR_RK) { j = i / ncols; c = i - j * ncols; }
+    else { c = i / RT; j = i - c * RT; }
+    float v = 0.f;
+    if (j < r) v = ldf(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * C + c0 + c : (int64_t)(c0 + c) * r + j);
+    s_f[((j * 2 + ((c >> 2) & 1)) * c8 + (c >> 3)) * 4 + (c & 3)] = v;
+  }
+}
+
+// The r x 8 factor block a column-owner thread needs, straight into registers.
+template <int RT>
+__device__ inline void load_factor_cols(float (&fc)[RT][8], const void *f, int fdt, int layout, int r, int64_t C,
+                                        int col) {
+  if (fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_RK && (C & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(f) & 15u) == 0)) {
+    const float *fp = reinterpret_cast<const float *>(f);
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (j < r) {
+        a = *reinterpret_cast<const float4 *>(fp + (int64_t)j * C + col);
+        b = *reinterpret_cast<const float4 *>(fp + (int64_t)j * C + col + 4);
+      }
+      fc[j][0] = a.x; fc[j][1] = a.y; fc[j][2] = a.z; fc[j][3] = a.w;
+      fc[j][4] = b.x; fc[j][5] = b.y; fc[j][6] = b.z; fc[j][7] = b.w;
+    }
+  } else if (fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_KR && r == 4 && RT == 4 &&
+             ((reinterpret_cast<uintptr_t>(f) & 15u) == 0)) {
+    const float *fp = reinterpret_cast<const float *>(f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 a = *reinterpret_cast<const float4 *>(fp + (int64_t)(col + i) * 4);
+      fc[0][i] = a.x; fc[1 % RT][i] = a.y; fc[2 % RT][i] = a.z; fc[3 % RT][i] = a.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        fc[j][i] = j < r ? ldf(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * C + col + i
+                                                                     : (int64_t)(col + i) * r + j)
+                         : 0.f;
+  }
+}
+
+// s_t[row][RT] = (sum over nparts of part[p][m0+row][0..r)) (@ S | @ S^T), zero padded to RT.
+template <int RT>
+__device__ inline void stage_rowvecs(float *s_t, const float *part, int nparts, int64_t part_stride, int64_t m0,
+                                     int nrows, int r, const float *sel, int sel_transposed, float mult) {
+  for (int i = threadIdx.x; i < nrows * RT; i += kFT) {
+    const int rl = i / RT, j = i - rl * RT;
+    float v = 0.f;
+    if (j < r) {
+      if (sel == nullptr) {
+        for (int p = 0; p < nparts; ++p) v += part[p * part_stride + (m0 + rl) * r + j];
+      } else {
+        for (int b = 0; b < r; ++b) {
+          float tb = 0.f;
+          for (int p = 0; p < nparts; ++p) tb += part[p * part_stride + (m0 + rl) * r + b];
+          v = fmaf(tb, sel_transposed ? sel[b * r + j] : sel[j * r + b], v);
+        }
+      }
+    }
+    s_t[i] = v * mult;
+  }
+}
+
+// Slot reduction of per-thread accumulators acc[RT][8] -> out[j*ld + col0 + c] for the block's column tile.
+template <int RT>
+__device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8], int slot, int nslots, int cl,
+                                         int ct8, float *out, int64_t ld, int col0) {
+  const int ncols = ct8 * 8;
+#pragma unroll
+  for (int jb = 0; jb < RT; jb += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = make_float4(acc[jb][i], acc[(jb + 1) % RT][i], acc[(jb + 2) % RT][i], acc[(jb + 3) % RT][i]);
+      *reinterpret_cast<float4 *>(&s_red[((slot * ncols) + cl * 8 + i) * 4]) = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncols * 4; i += kFT) {
+      const int col = i >> 2, jj = i & 3;
+      float sum = 0.f;
+      for (int s = 0; s < nslots; ++s) sum += s_red[(s * ncols + col) * 4 + jj];
+      out[(int64_t)(jb + jj) * ld + col0 + col] = sum;
+    }
+  }
+}
+
+// ============================================================================ forward
+template <class E, int RT, bool DROP>
+__global__ __launch_bounds__(kFT) void linear_fwd_kernel(
+    const typename E::storage *__restrict__ x, int64_t ldx, typename E::storage *__restrict__ y, int64_t ldy,
+    const void *__restrict__ down, const void *__restrict__ up, int fdt, float *__restrict__ t_out, int64_t M, int K,
+    int N, int r, int kt_cols, int nt_cols, int logL, int rows_per_block, float scale,
+    const float *__restrict__ sel, float p, uint64_t seed, uint64_t offset) {
+  __shared__ __attribute__((aligned(16))) float s_f[kFLdsFactor];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  __shared__ float s_sel[RT * RT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = 1 << logL, G = 64 >> logL;
+  const int l = lane & (L - 1), g = lane >> logL;
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int rows_iter = G * (kFT / 64);
+  const int niter = (nrows + rows_iter - 1) / rows_iter;
+
+  if (sel != nullptr)
+    for (int i = tid; i < RT * RT; i += kFT) {
+      const int a = i / RT, b = i - a * RT;
+      s_sel[i] = (a < r && b < r) ? sel[a * r + b] : 0.f;
+    }
+  // ---- phase 1: T rows of this block (lora_down + selector), L lanes per row
+  const bool single = kt_cols >= K;
+  if (single) {
+    stage_factor<RT>(s_f, down, fdt, LORA_AMD_FACTOR_RK, r, K, 0, K);
+    __syncthreads();
+  }
+  constexpr int U = 4;
+  for (int it = 0; it < niter; ++it) {
+    const int rl = it * rows_iter + wave * G + g;
+    const bool live = rl < nrows;
+    float acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += kt_cols) {
+      const int ncols = min(kt_cols, K - k0), c8 = ncols >> 3;
+      if (!single) {
+        __syncthreads();
+        stage_factor<RT>(s_f, down, fdt, LORA_AMD_FACTOR_RK, r, K, k0, ncols);
+        __syncthreads();
+      }
+      if (live) {
+        const typename E::storage *xr = x + (m0 + rl) * ldx + k0;
+        for (int cb = l; cb < c8; cb += L * U) {
+          float xv[U][8];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (cb + u * L < c8) load8<E>(xr + (cb + u * L) * 8, xv[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int cc = cb + u * L;
+            if (cc >= c8) continue;
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+              const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
+              const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + cc) * 4]);
+              float a = acc[j];
+              a = fmaf(xv[u][0], d0.x, a); a = fmaf(xv[u][1], d0.y, a); a = fmaf(xv[u][2], d0.z, a);
+              a = fmaf(xv[u][3], d0.w, a); a = fmaf(xv[u][4], d1.x, a); a = fmaf(xv[u][5], d1.y, a);
+              a = fmaf(xv[u][6], d1.z, a); a = fmaf(xv[u][7], d1.w, a);
+              acc[j] = a;
+            }
+          }
+        }
+      }
+    }
+    for (int off = L >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    if (live && l == 0) {
+      float o[RT];
+      if (sel != nullptr) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a) {
+          float v = 0.f;
+#pragma unroll
+          for (int b = 0; b < RT; ++b) v = fmaf(acc[b], s_sel[a * RT + b], v);
+          o[a] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) o[j] = acc[j];
+      }
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        s_t[rl * RT + j] = o[j];
+        if (j < r) t_out[(m0 + rl) * r + j] = o[j];
+      }
+    }
+  }
+  // ---- phase 2: Y[rows of this block, :] += scale * mask * T @ up^T, column tile by column tile
+  for (int n0 = 0; n0 < N; n0 += nt_cols) {
+    const int ncols = min(nt_cols, N - n0), c8 = ncols >> 3;
+    __syncthreads();  // s_t complete / previous tile's readers done
+    stage_factor<RT>(s_f, up, fdt, LORA_AMD_FACTOR_KR, r, N, n0, ncols);
+    __syncthreads();
+    const int nchunk = nrows * c8;
+    const int dq = kFT / c8, dr = kFT % c8;
+    int rl = tid / c8, cc = tid % c8;
+    for (int c = tid; c < nchunk; c += kFT * U) {
+      float v[U][8];
+      int rls[U], ccs[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = (c + u * kFT) < nchunk;
+        rls[u] = rl; ccs[u] = cc;
+        if (ok[u]) load8<E>(y + (m0 + rl) * ldy + n0 + cc * 8, v[u]);
+        rl += dq; cc += dr;
+        if (cc >= c8) { cc -= c8; ++rl; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        float pr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float *tr = s_t + rls[u] * RT;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const float tj = tr[j];
+          const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + ccs[u]) * 4]);
+          const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + ccs[u]) * 4]);
+          pr[0] = fmaf(tj, d0.x, pr[0]); pr[1] = fmaf(tj, d0.y, pr[1]); pr[2] = fmaf(tj, d0.z, pr[2]);
+          pr[3] = fmaf(tj, d0.w, pr[3]); pr[4] = fmaf(tj, d1.x, pr[4]); pr[5] = fmaf(tj, d1.y, pr[5]);
+          pr[6] = fmaf(tj, d1.z, pr[6]); pr[7] = fmaf(tj, d1.w, pr[7]);
+        }
+        if (DROP) {
+          float mk[8];
+          const int64_t e = (m0 + rls[u]) * (int64_t)N + n0 + ccs[u] * 8;
+          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] = fmaf(scale, pr[i], v[u][i]);
+        store8<E>(y + (m0 + rls[u]) * ldy + n0 + ccs[u] * 8, v[u]);
+      }
+    }
+  }
+}
+
+// ============================================================================ backward, pass over G
+// grid = row blocks x column tiles (column tile fastest).  Outputs:
+//   gt_part[ct][M][r]  = scale * sum over this tile's columns of (mask*G)[m, n] * up[n, j]
+//   up_part[rb][RT][N] = scale * sum over this block's rows of (mask*G)[m, n] * T[m, j]
+template <class E, int RT, bool DROP>
+__global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
+    const typename E::storage *__restrict__ g, int64_t ldg, const float *__restrict__ t,
+    const void *__restrict__ up, int fdt, float *__restrict__ gt_part, float *__restrict__ up_part, int64_t M,
+    int N, int r, int log_ct8, int nct, int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset) {
+  __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  const int tid = threadIdx.x;
+  const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
+  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
+  const int64_t rb = blockIdx.x / nct;
+  const int ct = (int)(blockIdx.x - rb * nct);
+  const int64_t m0 = rb * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int col = (ct * ct8 + cl) * 8;
+
+  float fc[RT][8];
+  load_factor_cols<RT>(fc, up, fdt, LORA_AMD_FACTOR_KR, r, N, col);
+  stage_rowvecs<RT>(s_t, t, 1, 0, m0, nrows, r, nullptr, 0, scale);  // dUp partials carry `scale`
+  __syncthreads();
+
+  float acc[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+
+  constexpr int U = 4;
+  float *gtp = gt_part + (int64_t)ct * M * r;
+  // every lane of a wave runs the same trip count (shuffles below): bound by the first slot's rows
+  for (int rb0 = 0; rb0 < nrows; rb0 += nslots * U) {
+    float gv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots + slot;
+      if (rl < nrows) load8<E>(g + (m0 + rl) * ldg + col, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots + slot;
+      const bool live = rl < nrows;
+      float dot[RT];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) dot[j] = 0.f;
+      if (live) {
+        if (DROP) {
+          float mk[8];
+          const int64_t e = (m0 + rl) * (int64_t)N + col;
+          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) gv[u][i] *= mk[i];
+        }
+        const float *tr = s_t + rl * RT;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const float tj = tr[j];
+          float d = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            d = fmaf(gv[u][i], fc[j][i], d);
+            acc[j][i] = fmaf(tj, gv[u][i], acc[j][i]);
+          }
+          dot[j] = d;
+        }
+      }
+      for (int off = ct8 >> 1; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) dot[j] += __shfl_xor(dot[j], off, 64);
+      if (live && cl == 0) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+          if (j < r) gtp[(m0 + rl) * r + j] = scale * dot[j];
+      }
+    }
+  }
+  slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, up_part + (int64_t)rb * RT * N, N, ct * ct8 * 8);
+}
+
+// ============================================================================ backward, pass over X (and dX)
+//   Gt' = (sum_ct gt_part[ct]) @ S ;  down_part[rb][RT][K] = Gt'^T X (block rows) ;  dX += Gt' @ down
+template <class E, int RT, bool HAS_DX>
+__global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
+    const typename E::storage *__restrict__ x, int64_t ldx, typename E::storage *__restrict__ dx, int64_t lddx,
+    const float *__restrict__ gt_part, int nct_g, const void *__restrict__ down, int fdt,
+    const float *__restrict__ sel, float *__restrict__ down_part, int64_t M, int K, int r, int log_ct8, int nct,
+    int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  const int tid = threadIdx.x;
+  const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
+  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
+  const int64_t rb = blockIdx.x / nct;
+  const int ct = (int)(blockIdx.x - rb * nct);
+  const int64_t m0 = rb * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int col = (ct * ct8 + cl) * 8;
+
+  float fc[RT][8];
+  if (HAS_DX) load_factor_cols<RT>(fc, down, fdt, LORA_AMD_FACTOR_RK, r, K, col);
+  stage_rowvecs<RT>(s_t, gt_part, nct_g, M * r, m0, nrows, r, sel, 1, 1.0f);
+  __syncthreads();
+
+  float acc[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+
+  constexpr int U = 4;
+  for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+    float xv[U][8], dv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      if (rl < nrows) {
+        load8<E>(x + (m0 + rl) * ldx + col, xv[u]);
+        if (HAS_DX) load8<E>(dx + (m0 + rl) * lddx + col, dv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      if (rl >= nrows) continue;
+      const float *tr = s_t + rl * RT;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float tj = tr[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[j][i] = fmaf(tj, xv[u][i], acc[j][i]);
+          if (HAS_DX) dv[u][i] = fmaf(tj, fc[j][i], dv[u][i]);
+        }
+      }
+      if (HAS_DX) store8<E>(dx + (m0 + rl) * lddx + col, dv[u]);
+    }
+  }
+  slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, down_part + (int64_t)rb * RT * K, K, ct * ct8 * 8);
+}
+
+// ============================================================================ batched partial reduction
+// out (f32; [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c].  One launch for every descriptor.
+__global__ __launch_bounds__(kFT) void reduce_batched_kernel(const lora_amd_reduce_desc *__restrict__ descs, int n,
+                                                             int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * kFT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kFT) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const lora_amd_reduce_desc d = descs[lo];
+    const int64_t e = i - d.begin;
+    const int j = (int)(e / d.C), c = (int)(e - (int64_t)j * d.C);
+    const float *pp = d.part + (int64_t)j * d.C + c;
+    const int64_t stride = (int64_t)d.RT * d.C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= d.nparts; p += 4) {
+      s0 += pp[(p + 0) * stride]; s1 += pp[(p + 1) * stride];
+      s2 += pp[(p + 2) * stride]; s3 += pp[(p + 3) * stride];
+    }
+    for (; p < d.nparts; ++p) s0 += pp[p * stride];
+    const float sum = (s0 + s1) + (s2 + s3);
+    const int64_t o = d.layout == LORA_AMD_FACTOR_RK ? (int64_t)j * d.C + c : (int64_t)c * d.r + j;
+    d.out[o] = (d.beta == 0.f ? 0.f : d.beta * d.out[o]) + d.scale * sum;
+  }
+}
+
+// ---------------------------------------------------------------------------- host helpers
+static inline int frank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
+static inline int pow2_divisor(int c8, int cap) {
+  int v = 1;
+  while (v < cap && (c8 % (v * 2)) == 0) v *= 2;
+  return v;
+}
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline bool aligned_ok(const void *p, int64_t ld, int cols, int dt) {
+  const uintptr_t a = dt == LORA_AMD_F32 ? 32 : 16;
+  return cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)p % a) == 0;
+}
+static inline int pick_logL(int c8) {
+  int best = 0;
+  double best_eff = -1.0;
+  for (int lg = 0; lg <= 6; ++lg) {
+    const int L = 1 << lg;
+    const double eff = (double)c8 / ((double)L * ((c8 + L - 1) / L));
+    if (eff >= best_eff - 1e-9) { best_eff = std::max(eff, best_eff); best = lg; }
+  }
+  return best;
+}
+
+struct BwdGeom { int log_ct8, nct, rows_per_block; int64_t nrb; };
+static BwdGeom bwd_geom(int64_t M, int cols, int RT, int cap) {
+  BwdGeom q;
+  const int c8 = cols / 8;
+  const int ct8 = pow2_divisor(c8, cap);
+  q.log_ct8 = ilog2(ct8);
+  q.nct = c8 / ct8;
+  // rows per block: partial traffic RT*4/(rows*e) small, yet >= ~512 blocks when the matrix allows it
+  int64_t rows = 256;
+  while (rows > 32 && ((M + rows - 1) / rows) * q.nct < 512) rows >>= 1;
+  const int64_t max_rows = kFLdsT / RT;
+  if (rows > max_rows) rows = max_rows;
+  q.rows_per_block = (int)rows;
+  q.nrb = (M + rows - 1) / rows;
+  return q;
+}
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+extern "C" int lora_amd_linear_plan(int64_t M, int32_t K, int32_t N, int32_t r, lora_amd_linear_plan_t *out) {
+  LORA_AMD_CHECK(out != nullptr, LORA_AMD_EINVAL, "linear_plan: null output");
+  LORA_AMD_CHECK(M >= 0 && K > 0 && N > 0, LORA_AMD_EINVAL, "linear_plan: bad shape");
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "linear_plan: rank %d outside [1,%d]", r,
+                 LORA_AMD_MAX_RANK);
+  memset(out, 0, sizeof(*out));
+  out->rank_tile = frank_tile(r);
+  // fused kernels: 16-byte lanes, rank <= 16, row segments of >= 4 chunks per wave-slice
+  if (M == 0 || r > 16 || K % 8 || N % 8 || pow2_divisor(N / 8, 64) < 4 || pow2_divisor(K / 8, 256) < 4) return LORA_AMD_OK;
+  const BwdGeom gg = bwd_geom(M, N, out->rank_tile, 64), gx = bwd_geom(M, K, out->rank_tile, 256);
+  out->fused = 1;
+  out->nct_g = gg.nct;
+  out->gt_part_floats = (int64_t)gg.nct * M * r;
+  out->nparts_up = (int32_t)gg.nrb;
+  out->up_part_floats = gg.nrb * out->rank_tile * (int64_t)N;
+  out->nparts_down = (int32_t)gx.nrb;
+  out->down_part_floats = gx.nrb * out->rank_tile * (int64_t)K;
+  return LORA_AMD_OK;
+}
+
+#define FUSED_COMMON(name, dt, fdt)                                                                \
+  LORA_AMD_CHECK(dtype_ok(dt) && dtype_ok(fdt), LORA_AMD_EINVAL, name ": bad dtype");              \
+  LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, name ": fused path needs rank in [1,16], got %d", r); \
+  if (M == 0) return LORA_AMD_OK;
+
+extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, const void *down,
+                                   const void *up, float *t_out, int64_t M, int32_t K, int32_t N, int32_t r,
+                                   int32_t act_dtype, int32_t factor_dtype, float scale, const float *sel,
+                                   float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+  FUSED_COMMON("linear_fwd", act_dtype, factor_dtype);
+  LORA_AMD_CHECK(x && y && down && up && t_out, LORA_AMD_EINVAL, "linear_fwd: null pointer");
+  LORA_AMD_CHECK(aligned_ok(x, ldx, K, act_dtype) && aligned_ok(y, ldy, N, act_dtype), LORA_AMD_EINVAL,
+                 "linear_fwd: needs K%%8==0, N%%8==0, ld%%8==0 and 16-byte aligned rows (use the primitives otherwise)");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "linear_fwd: dropout p=%f", dropout_p);
+  const int RT = frank_tile(r);
+  int kt = (kFLdsFactor / RT) & ~7, nt = kt;
+  if (kt > K) kt = K;
+  if (nt > N) nt = N;
+  const int logL = pick_logL(kt >> 3);
+  const int rows_iter = (64 >> logL) * (kFT / 64);
+  int64_t rpb = (M + 1023) / 1024;
+  rpb = ((rpb + rows_iter - 1) / rows_iter) * rows_iter;
+  const int64_t max_rows = ((kFLdsT / RT) / rows_iter) * rows_iter;
+  if (rpb > max_rows) rpb = max_rows;
+  if (rpb < rows_iter) rpb = rows_iter;
+  const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+  hipStream_t st = (hipStream_t)stream;
+  const bool drop = dropout_p > 0.f;
+#define FW(E, RTV, D)                                                                                          \
+  hipLaunchKernelGGL((linear_fwd_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                             \
+                     reinterpret_cast<const typename E::storage *>(x), ldx, reinterpret_cast<typename E::storage *>(y), \
+                     ldy, down, up, factor_dtype, t_out, M, K, N, r, kt, nt, logL, (int)rpb, scale, sel, dropout_p, \
+                     seed, offset)
+#define FW_RT(E, D) do { if (RT == 4) FW(E, 4, D); else if (RT == 8) FW(E, 8, D); else FW(E, 16, D); } while (0)
+#define FW_E(E) do { if (drop) FW_RT(E, true); else FW_RT(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: FW_E(f32_t); break;
+    case LORA_AMD_F16: FW_E(f16_t); break;
+    default: FW_E(bf16_t); break;
+  }
+#undef FW_E
+#undef FW_RT
+#undef FW
+  return check_launch("lora_amd_linear_fwd");
+}
+
+extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
+                                     float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
+                                     int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
+                                     uint64_t offset, void *stream) {
+  FUSED_COMMON("linear_bwd_g", act_dtype, factor_dtype);
+  LORA_AMD_CHECK(g && t && up && gt_part && up_part, LORA_AMD_EINVAL, "linear_bwd_g: null pointer");
+  LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4, LORA_AMD_EINVAL,
+                 "linear_bwd_g: shape/alignment not supported by the fused path (see lora_amd_linear_plan)");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "linear_bwd_g: dropout p=%f", dropout_p);
+  const int RT = frank_tile(r);
+  const BwdGeom q = bwd_geom(M, N, RT, 64);
+  const unsigned grid = (unsigned)(q.nrb * q.nct);
+  hipStream_t st = (hipStream_t)stream;
+  const bool drop = dropout_p > 0.f;
+#define BG(E, RTV, D)                                                                                       \
+  hipLaunchKernelGGL((linear_bwd_g_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                        \
+                     reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \
+                     N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset)
+#define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else BG(E, 16, D); } while (0)
+#define BG_E(E) do { if (drop) BG_RT(E, true); else BG_RT(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: BG_E(f32_t); break;
+    case LORA_AMD_F16: BG_E(f16_t); break;
+    default: BG_E(bf16_t); break;
+  }
+#undef BG_E
+#undef BG_RT
+#undef BG
+  return check_launch("lora_amd_linear_bwd_g");
+}
+
+extern "C" int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, const float *gt_part,
+                                     int32_t nct_g, const void *down, const float *sel, float *down_part,
+                                     int64_t M, int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype,
+                                     void *stream) {
+  FUSED_COMMON("linear_bwd_x", act_dtype, factor_dtype);
+  LORA_AMD_CHECK(x && gt_part && down && down_part && nct_g >= 1, LORA_AMD_EINVAL, "linear_bwd_x: null pointer");
+  LORA_AMD_CHECK(aligned_ok(x, ldx, K, act_dtype) && pow2_divisor(K / 8, 256) >= 4, LORA_AMD_EINVAL,
+                 "linear_bwd_x: shape/alignment not supported by the fused path (see lora_amd_linear_plan)");
+  LORA_AMD_CHECK(dx == nullptr || aligned_ok(dx, lddx, K, act_dtype), LORA_AMD_EINVAL, "linear_bwd_x: dX alignment");
+  const int RT = frank_tile(r);
+  const BwdGeom q = bwd_geom(M, K, RT, 256);
+  const unsigned grid = (unsigned)(q.nrb * q.nct);
+  hipStream_t st = (hipStream_t)stream;
+  const bool has_dx = dx != nullptr;
+#define BX(E, RTV, D)                                                                                        \
+  hipLaunchKernelGGL((linear_bwd_x_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                         \
+                     reinterpret_cast<const typename E::storage *>(x), ldx, reinterpret_cast<typename E::storage *>(dx), \
+                     lddx, gt_part, nct_g, down, factor_dtype, sel, down_part, M, K, r, q.log_ct8, q.nct,     \
+                     q.rows_per_block)
+#define BX_RT(E, D) do { if (RT == 4) BX(E, 4, D); else if (RT == 8) BX(E, 8, D); else BX(E, 16, D); } while (0)
+#define BX_E(E) do { if (has_dx) BX_RT(E, true); else BX_RT(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: BX_E(f32_t); break;
+    case LORA_AMD_F16: BX_E(f16_t); break;
+    default: BX_E(bf16_t); break;
+  }
+#undef BX_E
+#undef BX_RT
+#undef BX
+  return check_launch("lora_amd_linear_bwd_x");
+}
+
+extern "C" int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total,
+                                       void *stream) {
+  LORA_AMD_CHECK(n >= 0 && total >= 0, LORA_AMD_EINVAL, "reduce_batched: bad sizes");
+  if (n == 0 || total == 0) return LORA_AMD_OK;
+  LORA_AMD_CHECK(descs_dev != nullptr, LORA_AMD_EINVAL, "reduce_batched: null table");
+  const int grid = (int)std::min<int64_t>((total + kFT - 1) / kFT, 4096);
+  hipLaunchKernelGGL(reduce_batched_kernel, dim3(grid), dim3(kFT), 0, (hipStream_t)stream, descs_dev, n, total);
+  return check_launch("lora_amd_reduce_batched");
+}

@@ -129,7 +129,7 @@ class LoraInjectedLinear(_Adapter):
         with torch.autocast(device_type=x.device.type, enabled=False):
             return ops.lora_linear(xc, wc, bc, self.lora_down.weight, self.lora_up.weight,
                                    self._selector_matrix(), self.scale, self._dropout_p(),
-                                   self.__dict__.get("_grad_slots"))
+                                   self.__dict__.get("_grad_sink"))
 
     def set_selector_from_diag(self, diag: torch.Tensor):  # ref:63-70
         assert diag.shape == (self.r,)

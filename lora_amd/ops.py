@@ -33,31 +33,79 @@ def next_dropout_stream() -> tuple:
     return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, off
 
 
+class GradSink:
+    """Where one adapter's backward leaves its parameter gradients when a trainer owns them:
+    views into the flat gradient buffer + persistent partial-sum workspaces.  The partials are summed
+    into the flat buffer by ONE batched launch per step (``FlatLoraState.reduce_pending``)."""
+
+    __slots__ = ("down_grad", "up_grad", "ws", "pending", "owner")
+
+    def __init__(self, down_grad: torch.Tensor, up_grad: torch.Tensor, owner=None):
+        self.down_grad, self.up_grad = down_grad, up_grad
+        self.ws = {}        # (M, K, N, r) -> (gt_part, up_part, down_part)
+        self.pending = None  # key of the workspace holding not-yet-reduced partials
+        self.owner = owner
+
+    def workspace(self, key, plan, device):
+        w = self.ws.get(key)
+        if w is None:
+            w = tuple(torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+                      for n in (plan.gt_part_floats, plan.up_part_floats, plan.down_part_floats))
+            self.ws[key] = w
+            if self.owner is not None:
+                self.owner._reduce_table = None  # table must be rebuilt with the new buffers
+        return w
+
+    def reduce_rows(self, key, plan):
+        _, up_part, down_part = self.ws[key]
+        _, K, N, r = key
+        return [(up_part, self.up_grad, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
+                (down_part, self.down_grad, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)]
+
+    def flush(self):
+        """Reduce this site's pending partials now (a second backward is about to overwrite them)."""
+        if self.pending is None:
+            return
+        key = self.pending
+        table, n, total = _C.make_reduce_table(self.reduce_rows(key, _C.linear_plan(*key)), self.up_grad.device)
+        _C.reduce_batched(table, n, total)
+        self.pending = None
+
+
+def _rows2d(t: torch.Tensor, cols: int) -> torch.Tensor:
+    t2 = t.reshape(-1, cols)
+    if t2.stride(-1) != 1 or (t2.shape[0] > 1 and t2.stride(0) != cols):
+        t2 = t2.contiguous()
+    return t2
+
+
 class LoraLinearFunction(torch.autograd.Function):
     """y = x W^T + b + scale * dropout((x A^T) S^T B^T)   (lora.py:53-58) and its gradient.
 
-    Saves X and the [M, r] projection T only — never an [M, N] tensor.
+    Saves X and the [M, r] projection T only — never an [M, N] tensor.  16-byte-friendly shapes take the
+    fused kernels (1 launch forward, 2 backward); anything else the three primitives.
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, down, up, sel, scale, dropout_p, grad_slots):
+    def forward(ctx, x, weight, bias, down, up, sel, scale, dropout_p, sink):
         _C.require()
-        K = weight.shape[1]
-        N = weight.shape[0]
-        x2 = x.reshape(-1, K)
-        if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) != K):
-            x2 = x2.contiguous()
+        N, K = weight.shape
+        r = down.shape[0]
+        x2 = _rows2d(x, K)
         y = F.linear(x2, weight, bias)  # frozen dense GEMM (MFMA, hipBLASLt)
-        t = _C.rowdot(x2, down, _C.FACTOR_RK, 1.0, sel, False)
         seed = off = 0
         if dropout_p > 0.0:
             seed, off = next_dropout_stream()
-        _C.rank_update_(y, t, up, _C.FACTOR_KR, scale, dropout_p, seed, off)
+        down_c, up_c = down.contiguous(), up.contiguous()
+        fused = down_c.dtype == up_c.dtype and _C.fused_ok(x2, N, r) and _C._rows_ok(y)
+        if fused:
+            t = _C.linear_fwd_(x2, y, down_c, up_c, scale, sel, dropout_p, seed, off)
+        else:
+            t = _C.rowdot(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
+            _C.rank_update_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
         ctx.save_for_backward(x2, weight, down, up, t, sel)
         ctx.scale, ctx.p, ctx.seed, ctx.off = float(scale), float(dropout_p), seed, off
-        ctx.has_bias = bias is not None
-        ctx.x_shape = x.shape
-        ctx.grad_slots = grad_slots
+        ctx.has_bias, ctx.x_shape, ctx.sink, ctx.fused = bias is not None, x.shape, sink, fused
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -65,33 +113,61 @@ class LoraLinearFunction(torch.autograd.Function):
     def backward(ctx, g):
         x2, weight, down, up, t, sel = ctx.saved_tensors
         N, K = weight.shape
-        g2 = g.reshape(-1, N)
-        if g2.stride(-1) != 1 or (g2.shape[0] > 1 and g2.stride(0) != N):
-            g2 = g2.contiguous()
+        r = down.shape[0]
+        M = x2.shape[0]
+        g2 = _rows2d(g, N)
         need_x, need_w, need_b, need_down, need_up = ctx.needs_input_grad[:5]
         s, p, seed, off = ctx.scale, ctx.p, ctx.seed, ctx.off
+        sink = ctx.sink
+        d_up = d_down = dx = None
+        down_c, up_c = down.contiguous(), up.contiguous()
 
-        gt = None
-        if need_x or need_down:
-            # dT = scale * (G .* mask) @ B (@ S)
-            gt = _C.rowdot(g2, up, _C.FACTOR_KR, s, sel, True, p, seed, off)
-        d_up = d_down = None
-        slots = ctx.grad_slots
-        if need_up:
-            if slots is not None:  # accumulate straight into the trainer's flat grad buffer
-                _C.colreduce(g2, t, _C.FACTOR_KR, s, out=slots[1], beta=1.0, dropout_p=p, seed=seed, offset=off)
+        if ctx.fused and _C._rows_ok(g2) and (need_down or need_up or need_x):
+            key = (M, K, N, r)
+            plan = _C.linear_plan(*key)
+            if sink is not None:
+                if sink.pending is not None:
+                    sink.flush()
+                gt_part, up_part, down_part = sink.workspace(key, plan, g2.device)
             else:
-                d_up = _C.colreduce(g2, t, _C.FACTOR_KR, s, dropout_p=p, seed=seed, offset=off).to(up.dtype)
-        if need_down:
-            if slots is not None:
-                _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0, out=slots[0], beta=1.0)
+                gt_part, up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
+                                               for n in (plan.gt_part_floats, plan.up_part_floats,
+                                                         plan.down_part_floats))
+            _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
+            dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM
+            if dx2 is not None and not _C._rows_ok(dx2):
+                dx2 = dx2.contiguous()
+            _C.linear_bwd_x(x2, dx2, gt_part, plan.nct_g, down_c, sel, down_part)
+            if need_x:
+                dx = dx2.view(ctx.x_shape)
+            if sink is not None:
+                sink.pending = key  # summed into the flat grad buffer by the trainer's batched reduce
             else:
-                d_down = _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0).to(down.dtype)
-        dx = None
-        if need_x:
-            dx2 = g2 @ weight  # frozen dense GEMM
-            _C.rank_update_(dx2, gt, down, _C.FACTOR_RK, 1.0)
-            dx = dx2.view(ctx.x_shape)
+                d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+                d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+                rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                        (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+                table, n, total = _C.make_reduce_table(rows, g2.device)
+                _C.reduce_batched(table, n, total)
+                d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+        else:
+            gt = None
+            if need_x or need_down:
+                gt = _C.rowdot(g2, up_c, _C.FACTOR_KR, s, sel, True, p, seed, off)  # dT = s*(G.*mask) @ B @ S
+            if need_up:
+                if sink is not None:
+                    _C.colreduce(g2, t, _C.FACTOR_KR, s, out=sink.up_grad, beta=1.0, dropout_p=p, seed=seed, offset=off)
+                else:
+                    d_up = _C.colreduce(g2, t, _C.FACTOR_KR, s, dropout_p=p, seed=seed, offset=off).to(up.dtype)
+            if need_down:
+                if sink is not None:
+                    _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0, out=sink.down_grad, beta=1.0)
+                else:
+                    d_down = _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0).to(down.dtype)
+            if need_x:
+                dx2 = g2 @ weight  # frozen dense GEMM
+                _C.rank_update_(dx2, gt, down_c, _C.FACTOR_RK, 1.0)
+                dx = dx2.view(ctx.x_shape)
         dw = g2.t() @ x2 if need_w else None
         db = g2.sum(0) if (ctx.has_bias and need_b) else None
         return dx, dw, db, d_down, d_up, None, None, None, None
@@ -99,8 +175,8 @@ class LoraLinearFunction(torch.autograd.Function):
 
 def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
                 up: torch.Tensor, sel: Optional[torch.Tensor], scale: float, dropout_p: float,
-                grad_slots=None) -> torch.Tensor:
-    return LoraLinearFunction.apply(x, weight, bias, down, up, sel, float(scale), float(dropout_p), grad_slots)
+                sink: Optional[GradSink] = None) -> torch.Tensor:
+    return LoraLinearFunction.apply(x, weight, bias, down, up, sel, float(scale), float(dropout_p), sink)
 
 
 class LoraConvUpFunction(torch.autograd.Function):

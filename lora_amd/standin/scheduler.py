@@ -17,9 +17,17 @@ class DDPMScheduler:
                                             prediction_type=prediction_type)
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).to(torch.float32)
+        self._dev_tables = {}
+
+    def _table(self, device) -> torch.Tensor:
+        # resident per device: no host->device copy inside the step (illegal during hipGraph capture)
+        t = self._dev_tables.get(device)
+        if t is None:
+            t = self._dev_tables[device] = self.alphas_cumprod.to(device=device)
+        return t
 
     def _coef(self, like: torch.Tensor, timesteps: torch.Tensor):
-        a = self.alphas_cumprod.to(device=like.device)[timesteps].to(like.dtype)
+        a = self._table(like.device)[timesteps].to(like.dtype)
         shape = (-1,) + (1,) * (like.dim() - 1)
         return a.sqrt().view(shape), (1 - a).sqrt().view(shape)
 

@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import _C
+from . import _C, ops
 from .lora import LoraInjectedConv2d, LoraInjectedLinear
 
 
@@ -64,6 +64,8 @@ class FlatLoraState:
             p.data = self.flat_p[a:b].view(p.shape)  # fp32 master, aliasing the flat buffer
             p.grad = self.flat_g[a:b].view(p.shape)
         self.step_count = 0
+        self._sinks: List[ops.GradSink] = []
+        self._reduce_table, self._reduce_sig = None, None
         self.on_device = self.device.type == "cuda"
         if self.on_device:
             _C.require()
@@ -96,15 +98,37 @@ class FlatLoraState:
             for m in model.modules():
                 if isinstance(m, LoraInjectedLinear) and id(m.lora_down.weight) in self.slices \
                         and id(m.lora_up.weight) in self.slices:
-                    m.__dict__["_grad_slots"] = (self.grad_view(m.lora_down.weight), self.grad_view(m.lora_up.weight))
+                    sink = ops.GradSink(self.grad_view(m.lora_down.weight), self.grad_view(m.lora_up.weight), self)
+                    m.__dict__["_grad_sink"] = sink
+                    self._sinks.append(sink)
                     n += 1
         return n
 
+    def reduce_pending(self) -> None:
+        """Sum every site's backward partials into the flat gradient buffer: ONE launch for all sites."""
+        live = [s for s in self._sinks if s.pending is not None]
+        if not live:
+            return
+        sig = tuple((id(s), s.pending) for s in live)
+        if self._reduce_table is None or self._reduce_sig != sig:
+            rows = []
+            for s in live:
+                rows += s.reduce_rows(s.pending, _C.linear_plan(*s.pending))
+            self._reduce_table = _C.make_reduce_table(rows, self.device)
+            self._reduce_sig = sig
+        table, n, total = self._reduce_table
+        _C.reduce_batched(table, n, total)
+        for s in live:
+            s.pending = None
+
     def zero_grad(self) -> None:
+        for s in self._sinks:
+            s.pending = None
         self.flat_g.zero_()
 
     def all_reduce(self) -> float:
         """SUM all-reduce of the flat gradient; returns the scale (1/world) the optimiser applies."""
+        self.reduce_pending()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
@@ -112,6 +136,7 @@ class FlatLoraState:
 
     def step(self, grad_scale: float = 1.0, graph_safe: bool = False) -> None:
         """clip_grad_norm_(max_grad_norm) -> AdamW -> zero_grad over the flat buffers (ref :878-888)."""
+        self.reduce_pending()
         self.step_count += 1
         b1, b2 = self.betas
         if self.on_device:
@@ -143,6 +168,7 @@ class FlatLoraState:
         self.flat_g.zero_()
 
     def grad_norm(self) -> torch.Tensor:
+        self.reduce_pending()
         return self.flat_g.norm(2)
 
 
@@ -223,16 +249,22 @@ class GraphedForwardBackward:
                  cond: torch.Tensor, state: FlatLoraState, warmup: int = 2):
         self.latents, self.cond = latents.clone(), cond.clone()
         self.state = state
+        def body():
+            loss = fn(self.latents, self.cond)
+            state.reduce_pending()  # the batched partial reduction is part of the captured work
+            return loss
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                fn(self.latents, self.cond)
+            for _ in range(warmup):  # also builds every lazily-allocated workspace / descriptor table
+                body()
                 state.zero_grad()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = fn(self.latents, self.cond)
+            self.loss = body()
 
     def __call__(self, latents: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
         self.latents.copy_(latents, non_blocking=True)

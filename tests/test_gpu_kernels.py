@@ -395,3 +395,134 @@ def test_bad_arguments_raise():
         _C.rowdot(rnd((8, 80), "bf16"), rnd((65, 80), "f32"), _C.FACTOR_RK)  # rank > 64
     with pytest.raises(ValueError):
         L.LoraInjectedLinear(4, 4, r=5)
+
+
+# ------------------------------------------------------------------------------------------ fused K1/K2
+FUSED_SHAPES = [(512, 320, 320, 4), (300, 768, 320, 4), (64, 1280, 1280, 8), (130, 320, 2560, 4), (100, 1280, 10240, 4),
+                (33, 640, 640, 16), (17, 320, 320, 1), (64, 2560, 320, 4), (308, 768, 768, 4), (1, 32, 64, 2),
+                (4096, 640, 640, 4)]
+
+
+@pytest.mark.parametrize("M,K,N,r", FUSED_SHAPES)
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
+def test_fused_linear_kernels_match_oracle(M, K, N, r, dt):
+    assert _C.linear_plan(M, K, N, r).fused == 1
+    x, W = rnd((M, K), dt, seed=1), rnd((N, K), dt, 0.05, seed=2)
+    A, B = rnd((r, K), "f32", 0.3, seed=3), rnd((N, r), "f32", 0.2, seed=4)
+    g = rnd((M, N), dt, seed=5)
+    s = 0.7
+    Xn, Wn, An, Bn, Gn = n(x), n(W), n(A), n(B), n(g)
+    # forward (y0 stands for the frozen GEMM's output)
+    y0 = rnd((M, N), dt, seed=6)
+    y = y0.clone()
+    t = _C.linear_fwd_(x, y, A, B, s, None, 0.0, 0, 0)
+    T64 = Xn.astype(np.float64) @ An.T
+    close(n(t), T64, np.abs(Xn) @ np.abs(An.T), msg="T")
+    close(n(y), n(y0) + s * (T64 @ Bn.T), np.abs(n(y0)) + s * (np.abs(Xn) @ np.abs(An.T)) @ np.abs(Bn.T), dt, msg="y")
+    # backward
+    plan = _C.linear_plan(M, K, N, r)
+    gt_part = torch.empty(plan.gt_part_floats, device=DEV)
+    up_part = torch.empty(plan.up_part_floats, device=DEV)
+    down_part = torch.empty(plan.down_part_floats, device=DEV)
+    _C.linear_bwd_g(g, t, B, gt_part, up_part, s, 0.0, 0, 0)
+    dx = (g.float() @ W.float()).to(DT[dt])  # stands for the frozen dX GEMM
+    dx0 = n(dx)
+    _C.linear_bwd_x(x, dx, gt_part, plan.nct_g, A, None, down_part)
+    d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+    rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+            (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    _C.reduce_batched(*_C.make_reduce_table(rows, DEV))
+    Tn = n(t).astype(np.float64)
+    Gt = s * (Gn.astype(np.float64) @ Bn)
+    close(n(gt_part).reshape(plan.nct_g, M, r).sum(0), Gt, s * (np.abs(Gn) @ np.abs(Bn)), msg="Gt")
+    close(n(d_up), s * (Gn.T.astype(np.float64) @ Tn), s * (np.abs(Gn.T) @ np.abs(Tn)), msg="d_up")
+    close(n(d_down), Gt.T @ Xn, np.abs(Gt.T) @ np.abs(Xn), msg="d_down")
+    close(n(dx), dx0 + Gt @ An, np.abs(dx0) + np.abs(Gt) @ np.abs(An), dt, msg="dx")
+
+
+def test_fused_linear_selector_dropout_and_bf16_factors():
+    M, K, N, r, s, p = 192, 640, 320, 4, 1.3, 0.3
+    x, y0, g = rnd((M, K), "bf16", seed=1), rnd((M, N), "bf16", seed=2), rnd((M, N), "bf16", seed=3)
+    A, B = rnd((r, K), "bf16", 0.3, seed=4), rnd((N, r), "bf16", 0.2, seed=5)  # monkeypatched adapters: W's dtype
+    sel = rnd((r, r), "f32", seed=6)
+    mk = torch.zeros(M, N, device=DEV)
+    _C.rank_update_(mk, torch.ones(M, 1, device=DEV), torch.ones(1, N, device=DEV), _C.FACTOR_RK, 1.0, p, 99, 5)
+    mask = n(mk)
+    y = y0.clone()
+    t = _C.linear_fwd_(x, y, A, B, s, sel, p, 99, 5)
+    yo, to = O.lora_linear_forward(n(x), np.zeros((N, K), np.float32), None, n(A), n(B), s, n(sel), mask)
+    np.testing.assert_allclose(n(t), to, rtol=1e-4, atol=1e-4 * np.abs(to).max())
+    np.testing.assert_allclose(n(y), n(y0) + yo, rtol=2 ** -7, atol=2 ** -7 * np.abs(yo).max())
+    plan = _C.linear_plan(M, K, N, r)
+    gt_part, up_part, down_part = (torch.empty(k, device=DEV) for k in
+                                   (plan.gt_part_floats, plan.up_part_floats, plan.down_part_floats))
+    _C.linear_bwd_g(g, t, B, gt_part, up_part, s, p, 99, 5)
+    dx = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    _C.linear_bwd_x(x, dx, gt_part, plan.nct_g, A, sel, down_part)
+    d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+    rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+            (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    _C.reduce_batched(*_C.make_reduce_table(rows, DEV))
+    dxo, ddo, duo, _, _ = O.lora_linear_backward(n(g), n(x), np.zeros((N, K), np.float32), n(A), n(B), s, n(sel), mask)
+    np.testing.assert_allclose(n(d_up), duo, rtol=1e-3, atol=1e-3 * np.abs(duo).max())
+    np.testing.assert_allclose(n(d_down), ddo, rtol=1e-3, atol=1e-3 * np.abs(ddo).max())
+    np.testing.assert_allclose(n(dx), dxo, rtol=2 ** -7, atol=2 ** -7 * np.abs(dxo).max())
+    # dX optional (first layer): same parameter gradients
+    _C.linear_bwd_x(x, None, gt_part, plan.nct_g, A, sel, down_part)
+    d_down2 = torch.empty(r, K, device=DEV)
+    _C.reduce_batched(*_C.make_reduce_table([rows[1][:1] + (d_down2,) + rows[1][2:]], DEV))
+    assert torch.equal(d_down, d_down2)
+
+
+def test_plan_rejects_unfriendly_shapes():
+    assert _C.linear_plan(16, 24, 40, 4).fused == 0    # too few 16-byte chunks per row
+    assert _C.linear_plan(16, 320, 321, 4).fused == 0  # N % 8
+    assert _C.linear_plan(16, 320, 320, 32).fused == 0  # rank > 16 -> primitives
+    assert _C.linear_plan(16384, 320, 320, 4).fused == 1
+
+
+def test_training_steps_on_device_match_cpu_path():
+    """tiny UNet, 3 optimiser steps: device (fused kernels, deferred batched reduce, fused clip+AdamW) vs the CPU path."""
+    import copy
+
+    from lora_amd import trainer as T
+    from lora_amd.standin import DDPMScheduler, tiny_unet
+
+    torch.manual_seed(0)
+    cpu = tiny_unet()
+    cpu.requires_grad_(False)
+    torch.manual_seed(5)
+    L.inject_trainable_lora(cpu, r=4)
+    for up, _ in L.extract_lora_ups_down(cpu):
+        up.weight.data.normal_(0, 0.05)
+    dev = copy.deepcopy(cpu).to(DEV)
+    cpu.train(), dev.train()
+    st_c = T.FlatLoraState([{"params": T.lora_params(cpu), "lr": 1e-3}], max_grad_norm=1.0)
+    st_d = T.FlatLoraState([{"params": T.lora_params(dev), "lr": 1e-3}], max_grad_norm=1.0, device=torch.device(DEV))
+    assert st_d.attach_direct_grads(dev) == len(L.extract_lora_ups_down(dev))
+    sched = DDPMScheduler()
+    for it in range(3):
+        g = torch.Generator().manual_seed(it)
+        lat, ehs = torch.randn(4, 4, 16, 16, generator=g), torch.randn(4, 7, 32, generator=g)
+        noise, t = torch.randn(4, 4, 16, 16, generator=g), torch.randint(0, 1000, (4,), generator=g)
+        lc = T.forward_backward(cpu, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
+        ld = T.forward_backward(dev, sched, lat.to(DEV), ehs.to(DEV), T.StepConfig(), noise=noise.to(DEV), timesteps=t.to(DEV))
+        assert abs(lc.item() - ld.item()) < 1e-4 * max(1.0, abs(lc.item()))
+        if it == 0:
+            st_d.reduce_pending()
+            np.testing.assert_allclose(n(st_d.flat_g), st_c.flat_g.numpy(), rtol=2e-3, atol=2e-5)
+        st_c.step(st_c.all_reduce())
+        st_d.step(st_d.all_reduce())
+    np.testing.assert_allclose(n(st_d.flat_p), st_c.flat_p.numpy(), rtol=1e-3, atol=5e-5)
+    # a second backward before the step flushes the first one's partials instead of overwriting them
+    g = torch.Generator().manual_seed(9)
+    lat, ehs = torch.randn(2, 4, 16, 16, generator=g).to(DEV), torch.randn(2, 7, 32, generator=g).to(DEV)
+    noise, t = torch.randn(2, 4, 16, 16, generator=g).to(DEV), torch.randint(0, 1000, (2,), generator=g).to(DEV)
+    T.forward_backward(dev, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
+    st_d.reduce_pending()
+    once = st_d.flat_g.clone()
+    st_d.zero_grad()
+    T.forward_backward(dev, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
+    T.forward_backward(dev, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
+    st_d.reduce_pending()
+    assert torch.allclose(st_d.flat_g, 2 * once, rtol=1e-4, atol=1e-6)
