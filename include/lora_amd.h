@@ -74,20 +74,27 @@ typedef struct lora_amd_merge_site {
   int32_t tiles_k;       /* filled by lora_amd_merge_plan                    */
   int64_t tile_begin;    /* filled by lora_amd_merge_plan (exclusive scan)   */
   int32_t flags;         /* filled by lora_amd_merge_plan; bit 0: 16-byte lanes
-                            (K % 8 == 0 and w_in/w_out 16-byte aligned)      */
+                            (K % 8 == 0 and w_in/w_out 16-byte aligned);
+                            bit 1: column-owner kernel (rank <= 16, K/8 has a
+                            power-of-two factor >= 4)                        */
   int32_t reserved;
 } lora_amd_merge_site;
 
-/* Host-side planner: fills rows_per_tile/cols_per_tile/tiles_k/tile_begin/flags of
- * `sites_host[0..n_sites)` and returns the total tile count in *total_tiles.
- * Pure CPU arithmetic: callable without a GPU. */
-int lora_amd_merge_plan(lora_amd_merge_site *sites_host, int32_t n_sites,
-                        int32_t w_dtype, int64_t *total_tiles);
+typedef struct lora_amd_merge_summary {
+  int64_t total_tiles;    /* grid size of the launch */
+  int32_t n_fast_sites;   /* sites on the column-owner kernel (flags bit 1) */
+  int32_t rank_tile_fast; /* 4 / 8 / 16: largest rank tile among them */
+} lora_amd_merge_summary;
 
-/* `sites_dev`: the planned descriptor array copied to device memory.
- * alpha: collapse_lora's alpha (lora.py:635).  A negative alpha un-merges. */
-int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev,
-                           int32_t n_sites, int64_t total_tiles,
+/* Host-side planner: fills rows_per_tile/cols_per_tile/tiles_k/tile_begin/flags of
+ * `sites_host[0..n_sites)` and *summary.  Pure CPU arithmetic: callable without a GPU. */
+int lora_amd_merge_plan(lora_amd_merge_site *sites_host, int32_t n_sites,
+                        int32_t w_dtype, lora_amd_merge_summary *summary);
+
+/* `sites_dev`: the planned descriptor array copied to device memory; `summary_host`: what the
+ * planner returned.  alpha: collapse_lora's alpha (lora.py:635).  A negative alpha un-merges. */
+int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev, int32_t n_sites,
+                           const lora_amd_merge_summary *summary_host,
                            int32_t w_dtype, int32_t ab_dtype, float alpha,
                            int32_t rounding, void *stream);
 

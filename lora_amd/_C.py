@@ -49,6 +49,10 @@ class MergeSite(C.Structure):
     ]
 
 
+class MergeSummary(C.Structure):
+    _fields_ = [("total_tiles", C.c_int64), ("n_fast_sites", C.c_int32), ("rank_tile_fast", C.c_int32)]
+
+
 class AdamWGroup(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
@@ -74,8 +78,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_abi_version.restype = C.c_int
     lib.lora_amd_last_error.restype = C.c_char_p
     lib.lora_amd_target_arch.restype = C.c_char_p
-    lib.lora_amd_merge_plan.argtypes = [C.POINTER(MergeSite), i32, i32, C.POINTER(i64)]
-    lib.lora_amd_merge_batched.argtypes = [vp, i32, i64, i32, i32, f32, i32, vp]
+    lib.lora_amd_merge_plan.argtypes = [C.POINTER(MergeSite), i32, i32, C.POINTER(MergeSummary)]
+    lib.lora_amd_merge_batched.argtypes = [vp, i32, C.POINTER(MergeSummary), i32, i32, f32, i32, vp]
     lib.lora_amd_merge_set_tuning.argtypes = [i64, i64]
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
@@ -197,16 +201,16 @@ class MergePlan:
             s.N, s.K, s.r = N, K, r
             self.keep.append((w_in, w_out, up, down))
             self.bytes_algorithmic += 2 * N * K * w_in.element_size() + (N + K) * r * up.element_size()
-        total = C.c_int64(0)
-        _check(lib.lora_amd_merge_plan(arr, n, dtype_code(self.w_dtype), C.byref(total)), "lora_amd_merge_plan")
-        self.n_sites, self.total_tiles = n, total.value
+        self.summary = MergeSummary()
+        _check(lib.lora_amd_merge_plan(arr, n, dtype_code(self.w_dtype), C.byref(self.summary)), "lora_amd_merge_plan")
+        self.n_sites, self.total_tiles = n, self.summary.total_tiles
         self.host = arr
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(self.device)
 
     def launch(self, alpha: float = 1.0, rounding: int = ROUND_REFERENCE) -> None:
         lib = require()
-        _check(lib.lora_amd_merge_batched(self.table.data_ptr(), self.n_sites, self.total_tiles,
+        _check(lib.lora_amd_merge_batched(self.table.data_ptr(), self.n_sites, C.byref(self.summary),
                                           dtype_code(self.w_dtype), dtype_code(self.ab_dtype), float(alpha),
                                           int(rounding), _stream()), "lora_amd_merge_batched")
 

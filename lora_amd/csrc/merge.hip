@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(
   for (int64_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int si = find_site(sites, n_sites, tile);
     const lora_amd_merge_site s = sites[si];
+    if (s.flags & 2) continue;  // handled by merge_co_kernel
     const int r = s.r;
     const int64_t tl = tile - s.tile_begin;
     const int tr = (int)(tl / s.tiles_k), tc = (int)(tl % s.tiles_k);
@@ -142,15 +143,121 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Column-owner kernel (the fast path; flags bit 1).  One block per tile of rows_per_tile x (ct8*8) columns,
+// ct8 = power of two dividing K/8.  A thread owns ONE 16-byte column chunk: its r x 8 block of `down` sits in
+// registers for the whole tile (loaded once, all loads in flight together), the tile's `up` rows sit in LDS,
+// and the thread walks rows slot, slot+nslots, ... with 4 independent 16-byte W loads in flight.  No LDS
+// traffic per element except the r floats of the row's `up`, no integer division in the loop.
+// ---------------------------------------------------------------------------
+constexpr int kMergeMaxSitesLds = 1024;
+
+template <class EW, class EAB, int RT, int ROUND>
+__global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
+    const lora_amd_merge_site *__restrict__ sites, int n_sites, int64_t total_tiles, float alpha) {
+  using SW = typename EW::storage;
+  using SAB = typename EAB::storage;
+  __shared__ int64_t s_begin[kMergeMaxSitesLds];
+  __shared__ __attribute__((aligned(16))) float s_up[kMergeLdsUpFloats];
+  const int tid = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  int si;
+  if (n_sites <= kMergeMaxSitesLds) {
+    for (int i = tid; i < n_sites; i += kMergeThreads) s_begin[i] = sites[i].tile_begin;
+    __syncthreads();
+    int lo = 0, hi = n_sites - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_begin[mid] <= tile) lo = mid; else hi = mid - 1;
+    }
+    si = lo;
+  } else {
+    si = find_site(sites, n_sites, tile);
+  }
+  const lora_amd_merge_site s = sites[si];
+  if (!(s.flags & 2)) return;  // handled by the LDS-slab kernel
+  const int r = s.r;
+  const int ct8 = s.cols_per_tile >> 3;
+  const int log_ct8 = __ffs(ct8) - 1;
+  const int nslots = kMergeThreads >> log_ct8;
+  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
+  const int64_t tl = tile - s.tile_begin;
+  const int tr = (int)(tl / s.tiles_k), tc = (int)(tl - (int64_t)tr * s.tiles_k);
+  const int row0 = tr * s.rows_per_tile;
+  const int nrows = min(s.rows_per_tile, s.N - row0);
+  const int col = (tc * ct8 + cl) * 8;
+
+  // this thread's r x 8 block of `down`
+  float fc[RT][8];
+  const SAB *dn = reinterpret_cast<const SAB *>(s.down);
+#pragma unroll
+  for (int j = 0; j < RT; ++j) {
+    if (j < r) {
+      load8<EAB>(dn + (int64_t)j * s.K + col, fc[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fc[j][i] = 0.f;
+    }
+  }
+  // the tile's rows of `up` -> LDS [nrows][RT]
+  const SAB *upp = reinterpret_cast<const SAB *>(s.up);
+  for (int i = tid; i < nrows * RT; i += kMergeThreads) {
+    const int rl = i / RT, j = i - rl * RT;
+    s_up[i] = j < r ? EAB::to_f(upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
+  }
+  __syncthreads();
+
+  const SW *win = reinterpret_cast<const SW *>(s.w_in) + (int64_t)row0 * s.K + col;
+  SW *wout = reinterpret_cast<SW *>(s.w_out) + (int64_t)row0 * s.K + col;
+  constexpr int U = kMergeUnroll;
+  for (int rb = slot; rb < nrows; rb += nslots * U) {
+    float w[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb + u * nslots;
+      if (rl < nrows) load8<EW>(win + (int64_t)rl * s.K, w[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb + u * nslots;
+      if (rl >= nrows) continue;
+      const float *upr = s_up + rl * RT;
+      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float uj = upr[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = fmaf(uj, fc[j][i], p[i]);
+      }
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = merge_one<EW, EAB, ROUND>(w[u][i], p[i], alpha);
+      store8<EW>(wout + (int64_t)rl * s.K, o);
+    }
+  }
+}
+
 template <class EW, class EAB>
-static void launch_merge(const lora_amd_merge_site *sites, int n_sites, int64_t total_tiles,
-                         float alpha, int rounding, int grid, hipStream_t st) {
-  if (rounding == LORA_AMD_ROUND_REFERENCE)
-    hipLaunchKernelGGL((merge_kernel<EW, EAB, LORA_AMD_ROUND_REFERENCE>), dim3(grid), dim3(kMergeThreads), 0, st,
-                       sites, n_sites, total_tiles, alpha);
-  else
-    hipLaunchKernelGGL((merge_kernel<EW, EAB, LORA_AMD_ROUND_ONCE>), dim3(grid), dim3(kMergeThreads), 0, st,
-                       sites, n_sites, total_tiles, alpha);
+static void launch_merge(const lora_amd_merge_site *sites, int n_sites, int64_t total_tiles, float alpha,
+                         int rounding, int grid_slab, int n_fast, int rt_fast, hipStream_t st) {
+  const bool ref = rounding == LORA_AMD_ROUND_REFERENCE;
+  if (n_fast > 0) {
+#define CO(RTV, R)                                                                                       \
+  hipLaunchKernelGGL((merge_co_kernel<EW, EAB, RTV, R>), dim3((unsigned)total_tiles), dim3(kMergeThreads), 0, st, \
+                     sites, n_sites, total_tiles, alpha)
+#define CO_R(RTV) do { if (ref) CO(RTV, LORA_AMD_ROUND_REFERENCE); else CO(RTV, LORA_AMD_ROUND_ONCE); } while (0)
+    if (rt_fast <= 4) CO_R(4); else if (rt_fast <= 8) CO_R(8); else CO_R(16);
+#undef CO_R
+#undef CO
+  }
+  if (n_fast < n_sites) {
+    if (ref)
+      hipLaunchKernelGGL((merge_kernel<EW, EAB, LORA_AMD_ROUND_REFERENCE>), dim3(grid_slab), dim3(kMergeThreads), 0,
+                         st, sites, n_sites, total_tiles, alpha);
+    else
+      hipLaunchKernelGGL((merge_kernel<EW, EAB, LORA_AMD_ROUND_ONCE>), dim3(grid_slab), dim3(kMergeThreads), 0, st,
+                         sites, n_sites, total_tiles, alpha);
+  }
 }
 
 }  // namespace lora_amd
@@ -158,8 +265,9 @@ static void launch_merge(const lora_amd_merge_site *sites, int n_sites, int64_t 
 using namespace lora_amd;
 
 extern "C" int lora_amd_merge_plan(lora_amd_merge_site *sites, int32_t n_sites, int32_t w_dtype,
-                                   int64_t *total_tiles) {
-  LORA_AMD_CHECK(sites && total_tiles && n_sites >= 0, LORA_AMD_EINVAL, "merge_plan: null argument");
+                                   lora_amd_merge_summary *summary) {
+  LORA_AMD_CHECK(sites && summary && n_sites >= 0, LORA_AMD_EINVAL, "merge_plan: null argument");
+  int n_fast = 0, rt_fast = 4;
   LORA_AMD_CHECK(dtype_ok(w_dtype), LORA_AMD_EINVAL, "merge_plan: bad w_dtype %d", w_dtype);
   int64_t acc = 0;
   for (int i = 0; i < n_sites; ++i) {
@@ -167,43 +275,72 @@ extern "C" int lora_amd_merge_plan(lora_amd_merge_site *sites, int32_t n_sites, 
     LORA_AMD_CHECK(s.N > 0 && s.K > 0, LORA_AMD_EINVAL, "merge_plan: site %d has N=%d K=%d", i, s.N, s.K);
     LORA_AMD_CHECK(s.r >= 1 && s.r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK,
                    "merge_plan: site %d rank %d outside [1,%d]", i, s.r, LORA_AMD_MAX_RANK);
-    int max_cols = (kMergeLdsDownFloats / s.r) & ~7;
-    int k8 = (s.K + 7) & ~7;
-    int cols = k8 < max_cols ? k8 : max_cols;
-    int64_t rows = g_merge_tile_elems / cols;
-    int max_rows = kMergeLdsUpFloats / s.r;
-    if (rows > max_rows) rows = max_rows;
-    if (rows > 128) rows = 128;
-    if (rows < 8) rows = 8;
-    if (rows > s.N) rows = s.N;
-    s.cols_per_tile = cols;
-    s.rows_per_tile = (int32_t)rows;
-    s.tiles_k = (s.K + cols - 1) / cols;
-    s.tile_begin = acc;
-    bool aligned = (((uintptr_t)s.w_in | (uintptr_t)s.w_out) & 15u) == 0;
-    s.flags = (s.K % 8 == 0 && aligned) ? 1 : 0;
+    const bool aligned = (((uintptr_t)s.w_in | (uintptr_t)s.w_out) & 15u) == 0;
+    const bool ab_aligned = (((uintptr_t)s.down) & 31u) == 0;
+    int ct8 = 1;
+    if (s.K % 8 == 0) {
+      const int c8 = s.K / 8;
+      while (ct8 < 256 && (c8 % (ct8 * 2)) == 0) ct8 *= 2;
+    }
     s.reserved = 0;
-    acc += (int64_t)s.tiles_k * ((s.N + rows - 1) / rows);
+    if (aligned && ab_aligned && s.K % 8 == 0 && ct8 >= 4 && s.r <= 16) {
+      // column-owner tiles: (ct8*8) columns x rows_per_tile rows
+      const int cols = ct8 * 8;
+      const int rt = s.r <= 4 ? 4 : s.r <= 8 ? 8 : 16;
+      int64_t rows = g_merge_tile_elems / cols;
+      const int nslots = kMergeThreads / ct8;
+      if (rows > kMergeLdsUpFloats / rt) rows = kMergeLdsUpFloats / rt;
+      if (rows < nslots) rows = nslots;
+      if (rows > s.N) rows = s.N;
+      s.cols_per_tile = cols;
+      s.rows_per_tile = (int32_t)rows;
+      s.tiles_k = s.K / cols;
+      s.flags = 3;
+      ++n_fast;
+      if (rt > rt_fast) rt_fast = rt;
+    } else {
+      int max_cols = (kMergeLdsDownFloats / s.r) & ~7;
+      int k8 = (s.K + 7) & ~7;
+      int cols = k8 < max_cols ? k8 : max_cols;
+      int64_t rows = g_merge_tile_elems / cols;
+      int max_rows = kMergeLdsUpFloats / s.r;
+      if (rows > max_rows) rows = max_rows;
+      if (rows > 128) rows = 128;
+      if (rows < 8) rows = 8;
+      if (rows > s.N) rows = s.N;
+      s.cols_per_tile = cols;
+      s.rows_per_tile = (int32_t)rows;
+      s.tiles_k = (s.K + cols - 1) / cols;
+      s.flags = (s.K % 8 == 0 && aligned) ? 1 : 0;
+    }
+    s.tile_begin = acc;
+    acc += (int64_t)s.tiles_k * ((s.N + s.rows_per_tile - 1) / s.rows_per_tile);
   }
-  *total_tiles = acc;
+  summary->total_tiles = acc;
+  summary->n_fast_sites = n_fast;
+  summary->rank_tile_fast = rt_fast;
   return LORA_AMD_OK;
 }
 
 extern "C" int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev, int32_t n_sites,
-                                      int64_t total_tiles, int32_t w_dtype, int32_t ab_dtype,
+                                      const lora_amd_merge_summary *summary, int32_t w_dtype, int32_t ab_dtype,
                                       float alpha, int32_t rounding, void *stream) {
-  LORA_AMD_CHECK(sites_dev && n_sites > 0 && total_tiles > 0, LORA_AMD_EINVAL, "merge: empty site table");
+  LORA_AMD_CHECK(sites_dev && summary && n_sites > 0 && summary->total_tiles > 0, LORA_AMD_EINVAL,
+                 "merge: empty site table");
   LORA_AMD_CHECK(dtype_ok(w_dtype) && dtype_ok(ab_dtype), LORA_AMD_EINVAL, "merge: bad dtype");
   LORA_AMD_CHECK(rounding == LORA_AMD_ROUND_REFERENCE || rounding == LORA_AMD_ROUND_ONCE, LORA_AMD_EINVAL,
                  "merge: bad rounding mode %d", rounding);
+  LORA_AMD_CHECK(summary->total_tiles < (1ll << 31), LORA_AMD_EINVAL, "merge: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  int64_t cap = 256 * g_merge_blocks_per_cu;
-  int grid = (int)(total_tiles < cap ? total_tiles : cap);
-#define DISPATCH_AB(EW)                                                                                   \
-  switch (ab_dtype) {                                                                                     \
-    case LORA_AMD_F32: launch_merge<EW, f32_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, st); break; \
-    case LORA_AMD_F16: launch_merge<EW, f16_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, st); break; \
-    default: launch_merge<EW, bf16_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, st); break;          \
+  const int64_t total_tiles = summary->total_tiles;
+  const int64_t cap = 256 * g_merge_blocks_per_cu;
+  const int grid = (int)(total_tiles < cap ? total_tiles : cap);
+  const int n_fast = summary->n_fast_sites, rt_fast = summary->rank_tile_fast;
+#define DISPATCH_AB(EW)                                                                                           \
+  switch (ab_dtype) {                                                                                             \
+    case LORA_AMD_F32: launch_merge<EW, f32_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, n_fast, rt_fast, st); break; \
+    case LORA_AMD_F16: launch_merge<EW, f16_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, n_fast, rt_fast, st); break; \
+    default: launch_merge<EW, bf16_t>(sites_dev, n_sites, total_tiles, alpha, rounding, grid, n_fast, rt_fast, st); break;          \
   }
   switch (w_dtype) {
     case LORA_AMD_F32: DISPATCH_AB(f32_t); break;

@@ -43,7 +43,7 @@ def merge_plan(qkvo_only=False, r=4, wdt=torch.bfloat16, abdt=torch.float32, inp
 def bench_merge(args):
     out = []
     for qkvo in (False, True):
-        for tile, bpc in ((32768, 4), (16384, 4), (65536, 4), (32768, 2), (32768, 3), (16384, 5), (8192, 5)):
+        for tile, bpc in ((32768, 4), (16384, 4), (65536, 4), (131072, 4), (8192, 4)):
             _C.merge_set_tuning(tile, bpc)
             plan = merge_plan(qkvo)
             med, best = timeit(lambda: plan.launch(0.7), iters=args.iters)
@@ -78,6 +78,18 @@ def bench_linear(args):
         res["rank_update_us"], res["rank_update_GBs"] = med * 1e6, (2 * M * N * 2 + M * r * 4) / med / 1e9
         med, _ = timeit(lambda: _C.colreduce(y, t, _C.FACTOR_KR, 1.0), args.iters)
         res["colreduce_us"], res["colreduce_GBs"] = med * 1e6, (M * N * 2 + M * r * 4) / med / 1e9
+        # fused kernels (what the adapter actually launches)
+        plan = _C.linear_plan(M, K, N, r)
+        g = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+        dx = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        gt_part, up_part, down_part = (torch.empty(k, device=DEV) for k in
+                                       (plan.gt_part_floats, plan.up_part_floats, plan.down_part_floats))
+        med, _ = timeit(lambda: _C.linear_fwd_(x, y, A, B, 1e-3, None, 0.0, 0, 0), args.iters)
+        res["fwd_us"], res["fwd_GBs"] = med * 1e6, (M * K * 2 + 2 * M * N * 2) / med / 1e9
+        med, _ = timeit(lambda: _C.linear_bwd_g(g, t, B, gt_part, up_part, 1.0, 0.0, 0, 0), args.iters)
+        res["bwd_g_us"], res["bwd_g_GBs"] = med * 1e6, (M * N * 2) / med / 1e9
+        med, _ = timeit(lambda: _C.linear_bwd_x(x, dx, gt_part, plan.nct_g, A, None, down_part), args.iters)
+        res["bwd_x_us"], res["bwd_x_GBs"] = med * 1e6, (3 * M * K * 2) / med / 1e9
         # what the reference's op sequence costs on the same device (5 ATen launches)
         W = torch.randn(N, K, device=DEV).to(torch.bfloat16)
         Ab, Bb = A.to(torch.bfloat16), B.to(torch.bfloat16)
@@ -90,7 +102,7 @@ def bench_linear(args):
         med, _ = timeit(lambda: torch.nn.functional.linear(x, W), args.iters)
         res["frozen_gemm_us"] = med * 1e6
         res["frozen_gemm_TF"] = 2 * M * K * N / med / 1e12
-        print(json.dumps(res), flush=True)
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
 if __name__ == "__main__":

@@ -36,19 +36,24 @@ def test_merge_planner_is_pure_host_arithmetic():
     for s, (N, K, r) in zip(sites, [(320, 320, 4), (2560, 320, 4), (1280, 2880, 16)]):
         s.N, s.K, s.r = N, K, r
         s.w_in = s.w_out = 4096
-    total = C.c_int64()
-    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == 0
+    summ = _C.MergeSummary()
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(summ)) == 0
     acc = 0
     for s in sites:
-        assert s.cols_per_tile % 8 == 0 and s.cols_per_tile * s.r <= 8192 and s.rows_per_tile * s.r <= 2048
-        assert s.tiles_k == -(-s.K // s.cols_per_tile) and s.tile_begin == acc and s.flags & 1
+        assert s.cols_per_tile % 8 == 0 and s.rows_per_tile * s.r <= 2048
+        assert s.tiles_k == -(-s.K // s.cols_per_tile) and s.tile_begin == acc and s.flags == 3
+        ct8 = s.cols_per_tile // 8
+        assert ct8 & (ct8 - 1) == 0 and (s.K // 8) % ct8 == 0  # power-of-two column tiles dividing the row
         acc += s.tiles_k * -(-s.N // s.rows_per_tile)
-    assert total.value == acc
+    assert summ.total_tiles == acc and summ.n_fast_sites == 3 and summ.rank_tile_fast == 16
     sites[0].r = 65
-    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == -2
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(summ)) == -2
     assert b"rank 65" in lib.lora_amd_last_error()
-    sites[0].r, sites[0].K = 4, 321  # odd K or misaligned weight -> scalar lanes
-    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(total)) == 0 and not (sites[0].flags & 1)
+    sites[0].r, sites[0].K = 4, 321  # odd K -> scalar lanes of the LDS-slab kernel
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(summ)) == 0 and sites[0].flags == 0
+    sites[0].K, sites[0].r = 328, 32  # rank > 16 or no power-of-two factor -> 16-byte lanes of the slab kernel
+    assert lib.lora_amd_merge_plan(sites, 3, _C.BF16, C.byref(summ)) == 0 and sites[0].flags == 1
+    assert summ.n_fast_sites == 2 and sites[0].cols_per_tile * sites[0].r <= 8192
 
 
 def test_workspace_queries():
