@@ -19,7 +19,7 @@ constexpr int kMergeLdsDownFloats = 8192;  // 32 KiB: [r][cols_per_tile]
 constexpr int kMergeLdsUpFloats = 2048;    // 8 KiB: [rows_per_tile][r]
 constexpr int kMergeUnroll = 4;
 
-static int64_t g_merge_tile_elems = 32768;  // tuning knob (lora_amd_set_tuning)
+static int64_t g_merge_tile_elems = 16384;  // tuning knob (lora_amd_merge_set_tuning); 16K measured best on MI355X
 static int64_t g_merge_blocks_per_cu = 4;
 
 template <class E>

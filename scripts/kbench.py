@@ -52,7 +52,7 @@ def bench_merge(args):
                             tiles=plan.total_tiles, MB=plan.bytes_algorithmic / 1e6, us=med * 1e6, best_us=best * 1e6,
                             GBs=gbs, frac8=gbs / 8000))
             print(json.dumps(out[-1]), flush=True)
-    _C.merge_set_tuning(32768, 4)
+    _C.merge_set_tuning(16384, 4)
     # plain device copy of the same bytes as a ceiling reference
     n = int(385e6 / 2)
     a = torch.empty(n, dtype=torch.bfloat16, device=DEV)
