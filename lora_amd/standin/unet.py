@@ -128,10 +128,13 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, context):
         B, C, H, W = x.shape
         h = self.proj_in(self.norm(x))
-        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        nhwc = h.is_contiguous(memory_format=torch.channels_last)
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are channels_last (NHWC)
         for blk in self.transformer_blocks:
             h = blk(h, context)
-        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        if not nhwc:
+            h = h.contiguous()
         return self.proj_out(h) + x
 
 

@@ -19,7 +19,7 @@ n = 192_634_880  # = total elements of the 144 SD1.5 sites: same footprint as th
 a = torch.randn(n // 64, device=DEV).to(torch.bfloat16).repeat(64)
 b = torch.empty_like(a)
 for _ in range(3):
-    b.copy_(a)  # vectorized_elementwise copy kernel: reads n*2 bytes, writes n*2 bytes
+    torch.neg(a, out=b)  # vectorized_elementwise_kernel<8, neg>: reads n*2 bytes, writes n*2 bytes, 16 B per lane
 torch.cuda.synchronize()
 plan = merge_plan(False)
 for _ in range(3):

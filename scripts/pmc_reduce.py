@@ -29,7 +29,7 @@ def pick(d, key):
     return sorted(vals)[len(vals) // 2] if vals else None
 
 
-cf, cw = pick(fetch, "bfloat16_copy") or pick(fetch, "copy"), pick(write, "bfloat16_copy") or pick(write, "copy")
+cf, cw = pick(fetch, "neg_kernel"), pick(write, "neg_kernel")
 mf, mw = pick(fetch, "merge_co_kernel"), pick(write, "merge_co_kernel")
 res = {"counters_raw_KiB": {"copy_fetch": cf, "copy_write": cw, "merge_fetch": mf, "merge_write": mw},
        "calibration": {"known_copy_bytes_each_way": copy_bytes,

@@ -8,6 +8,8 @@ OUT=gpurun_out
 export TMPDIR=/tmp
 mkdir -p $OUT
 ARGS="--steps 5 --warmup 3 --no-cpu-baseline"
+ONLY=${2:-all}
+if [ "$ONLY" != "pmc" ]; then
 # 1. un-profiled run first: fills MIOpen's find cache (a cold MIOpen under the profiler falls back to naive convs)
 python bench.py $ARGS > $OUT/${TAG}_bench_warm.json 2> $OUT/${TAG}_bench_warm.err
 # 2. kernel trace + stats of the same command
@@ -15,6 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ben
 python scripts/prof_summary.py $(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1) 60 > $OUT/${TAG}_bench_kernel_summary.txt
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/${TAG}_trace
+fi
 # 3. PMC passes (each counter alone; no trace domains besides kernel-trace)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python scripts/pmc_probe.py > $OUT/${TAG}_pmc_probe.txt 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python scripts/pmc_probe.py > /dev/null 2> $OUT/${TAG}_pmc_write.err
