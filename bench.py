@@ -75,9 +75,18 @@ def merge_roofline(unet, iters=30):
     torch.cuda.synchronize()
     avg_s = sum(a.elapsed_time(b) for a, b in evs) / iters * 1e-3
     ach = plan.bytes_algorithmic / avg_s / 1e9
-    return {"kernel": "lora_amd::merge_kernel<bf16,f32> (K3 fused W+alpha*up@down, all %d sites, 1 launch)" % plan.n_sites,
+    traffic, traffic_src = None, None
+    pmc = os.path.join(REPO, "profiles", "r01_merge_pmc.json")  # offline rocprofv3 --pmc passes (scripts/profile_bench.sh)
+    if os.path.exists(pmc):
+        try:
+            m = json.load(open(pmc))["merge_per_launch"]
+            if m["algorithmic_bytes"] == plan.bytes_algorithmic:
+                traffic, traffic_src = m["hbm_total_bytes"], "profiles/r01_merge_pmc.json (FETCH_SIZE/WRITE_SIZE, calibrated)"
+        except (KeyError, ValueError):
+            pass
+    return {"kernel": "lora_amd::merge_co_kernel<bf16,f32,4> (K3 fused W+alpha*up@down, all %d sites, 1 launch)" % plan.n_sites,
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": plan.bytes_algorithmic, "avg_launch_us": round(avg_s * 1e6, 2),
             "launches_timed": iters}
 
