@@ -316,8 +316,12 @@ def test_batched_merge_many_sites_one_launch():
                 np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7)
                 continue
             mag = np.maximum(np.abs(ref), np.maximum(np.abs(w0s[i]), np.abs(ref - w0s[i])))
-            assert np.all(np.abs(got - ref) <= _ulp(mag, wdt)), (wdt, abdt, shapes[i])
-            assert (got != ref).mean() < 0.01, (wdt, abdt, shapes[i], (got != ref).mean())
+            # 16-bit factors: the matmul result itself is rounded to 16 bits, so an f32 summation-order difference can
+            # flip one place of p = up@down; that flip survives the alpha-multiply and may add to a last-place flip of
+            # the final W + q rounding -> at most two places of the largest operand (never more; checked below)
+            places = 1 if abdt == "f32" else 2
+            assert np.all(np.abs(got - ref) <= places * _ulp(mag, wdt)), (wdt, abdt, shapes[i])
+            assert (got != ref).mean() < (0.01 if abdt == "f32" else 0.05), (wdt, abdt, shapes[i], (got != ref).mean())
     # single-rounding mode is at least as close to the exact f64 result
     w, up, down = rnd((640, 320), "bf16", 0.05, seed=1), rnd((640, 4), "f32", 0.1, seed=2), rnd((4, 320), "f32", 0.5, seed=3)
     o_ref, o_once = torch.empty_like(w), torch.empty_like(w)
