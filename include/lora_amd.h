@@ -203,6 +203,62 @@ typedef struct lora_amd_reduce_desc {
 int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
 
 /* ------------------------------------------------------------------------
+ * K4  LoraInjectedConv2d low-rank branch (lora.py:94-135) and its autograd, NCHW.
+ *     T  = conv_kxk(X; down)        [B, r, H, W]   lora.py:131 self.lora_down(input) [+ selector]
+ *     Y += scale * mask * conv_1x1(T; up)          lora.py:131-134 lora_up, dropout, *scale, +
+ *     Gt = scale * up^T (mask*G)    [B, r, H, W] ; dUp = scale * sum_{b,p} (mask*G) T
+ *     dDown = sum_{b,p} Gt' (x) patches(X) ;  dX += conv_transpose(Gt'; down)   (Gt' = S^T Gt)
+ * Native geometry (lora_amd_conv_plan says whether a site qualifies): stride 1, dilation 1, groups 1,
+ * kernel 1x1 (padding 0) or 3x3 (padding 1), contiguous NCHW, H*W % 8 == 0 (3x3: W % 8 == 0, W <= 512),
+ * rank <= 16.  Every ResnetBlock2D conv of SD1.5 at 512^2 / 768^2 qualifies except the 12x12 maps.
+ * Pixels are processed in 16-byte chunks of 8; a wave owns `cpw` consecutive chunks (whole image rows),
+ * the 4 waves of a workgroup split the channel loop, `split_*` workgroups split it further.
+ * ---------------------------------------------------------------------- */
+typedef struct lora_amd_conv_plan_t {
+  int32_t native;      /* 1: the entry points below accept this geometry */
+  int32_t cpw_in;      /* chunks per wave of the passes over X / dX (whole rows for 3x3) */
+  int32_t ngroups_in;  /* wave-groups of those passes  = number of dDown partials */
+  int32_t ngroups_out; /* wave-groups of the passes over Y / G (64 chunks each) = number of dUp partials */
+  int32_t split_in;    /* channel splits of conv_down_fwd (partial T sums) */
+  int32_t split_out;   /* channel splits of conv_bwd_g    (partial Gt sums) */
+  int32_t rank_pad;    /* r rounded up to a multiple of 4: row stride of the dUp/dDown partials */
+  int32_t reserved;
+  int64_t t_part_floats;    /* split_in  * B * r * H*W   workspace of conv_down_fwd */
+  int64_t gt_part_floats;   /* split_out * B * r * H*W   workspace of conv_bwd_g    */
+  int64_t up_part_floats;   /* ngroups_out * rank_pad * C_out            */
+  int64_t down_part_floats; /* ngroups_in  * rank_pad * C_in * ks * ks   */
+} lora_amd_conv_plan_t;
+
+int lora_amd_conv_plan(int32_t B, int32_t C_in, int32_t C_out, int32_t H, int32_t W, int32_t ks, int32_t r,
+                       lora_amd_conv_plan_t *out);
+
+/* t_out[B, r, H, W] (f32) = (conv_kxk(X; down)) with the optional selector S [r,r] applied across the
+ * rank dimension (lora.py:131, 140-156).  down: [r, C_in, ks, ks].  t_part: plan.t_part_floats floats. */
+int lora_amd_conv_down_fwd(const void *x, const void *down, const float *sel, float *t_part, float *t_out,
+                           int32_t B, int32_t C_in, int32_t H, int32_t W, int32_t ks, int32_t r,
+                           int32_t act_dtype, int32_t factor_dtype, void *stream);
+
+/* Y[B, C_out, H, W] (in place; holds the frozen conv's output) += scale * mask * conv_1x1(T; up),
+ * up: [C_out, r].  Dropout as lora_amd_rank_update, element index = NCHW offset of Y. */
+int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int32_t B, int32_t C_out, int32_t H, int32_t W,
+                         int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p,
+                         uint64_t seed, uint64_t offset, void *stream);
+
+/* One pass over G[B, C_out, H, W]: gt_out[B, r, H, W] (f32) = S^T (scale * up^T (mask*G)) and
+ * up_part[ngroups_out][rank_pad][C_out] = scale * sum over the group's pixels of (mask*G) T. */
+int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up, const float *sel, float *gt_part,
+                        float *gt_out, float *up_part, int32_t B, int32_t C_out, int32_t H, int32_t W, int32_t r,
+                        int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
+                        uint64_t offset, void *stream);
+
+/* One pass over X[B, C_in, H, W] (and dX in place, holding the frozen conv's input gradient; may be NULL):
+ * down_part[ngroups_in][rank_pad][C_in*ks*ks] = sum over the group's pixels of Gt' (x) patches(X), and
+ * dX += conv_transpose(Gt'; down). */
+int lora_amd_conv_bwd_x(const void *x, void *dx, const float *gt, const void *down, float *down_part, int32_t B,
+                        int32_t C_in, int32_t H, int32_t W, int32_t ks, int32_t r, int32_t act_dtype,
+                        int32_t factor_dtype, void *stream);
+
+/* ------------------------------------------------------------------------
  * C2/K6  flat-buffer gradient clipping + AdamW.
  * replaces: train_lora_dreambooth.py:878-888 (clip_grad_norm_ over every UNet
  *           parameter, AdamW.step, zero_grad) for the LoRA parameters, which

@@ -31,6 +31,7 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_reduce_batched",
+    "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance",
 )
@@ -61,6 +62,13 @@ class LinearPlan(C.Structure):
     _fields_ = [("fused", C.c_int32), ("rank_tile", C.c_int32), ("nct_g", C.c_int32), ("nparts_up", C.c_int32),
                 ("nparts_down", C.c_int32), ("reserved", C.c_int32), ("gt_part_floats", C.c_int64),
                 ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64)]
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [("native", C.c_int32), ("cpw_in", C.c_int32), ("ngroups_in", C.c_int32), ("ngroups_out", C.c_int32),
+                ("split_in", C.c_int32), ("split_out", C.c_int32), ("rank_pad", C.c_int32), ("reserved", C.c_int32),
+                ("t_part_floats", C.c_int64), ("gt_part_floats", C.c_int64), ("up_part_floats", C.c_int64),
+                ("down_part_floats", C.c_int64)]
 
 
 class ReduceDesc(C.Structure):
@@ -102,6 +110,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp]
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
+    lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
+    lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+    lib.lora_amd_conv_bwd_g.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
+                                        u64, vp]
+    lib.lora_amd_conv_bwd_x.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    for name in ("lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g",
+                 "lora_amd_conv_bwd_x"):
+        getattr(lib, name).restype = C.c_int
     for name in ("lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
                  "lora_amd_reduce_batched"):
         getattr(lib, name).restype = C.c_int
@@ -422,3 +439,57 @@ def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int,
 def reduce_batched(table: torch.Tensor, n: int, total: int) -> None:
     _check(require().lora_amd_reduce_batched(table.data_ptr(), int(n), int(total), _stream()),
            "lora_amd_reduce_batched")
+
+
+# ----------------------------------------------------------------------------- K4 conv adapter
+_conv_plan_cache = {}
+
+
+def conv_plan(B: int, C_in: int, C_out: int, H: int, W: int, ks: int, r: int) -> ConvPlan:
+    key = (B, C_in, C_out, H, W, ks, r)
+    pl = _conv_plan_cache.get(key)
+    if pl is None:
+        pl = ConvPlan()
+        _check(require().lora_amd_conv_plan(B, C_in, C_out, H, W, ks, r, C.byref(pl)), "lora_amd_conv_plan")
+        _conv_plan_cache[key] = pl
+    return pl
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return t.data_ptr() if t is not None else None
+
+
+def conv_down_fwd(x: torch.Tensor, down: torch.Tensor, sel: Optional[torch.Tensor], t_part: torch.Tensor,
+                  t_out: torch.Tensor, ks: int) -> None:
+    """t_out[B,r,H,W] (f32) = S . conv_kxk(x; down)."""
+    B, Ci, H, W = x.shape
+    _check(require().lora_amd_conv_down_fwd(x.data_ptr(), down.data_ptr(), _ptr(sel), t_part.data_ptr(),
+                                            t_out.data_ptr(), B, Ci, H, W, ks, down.shape[0], dtype_code(x.dtype),
+                                            dtype_code(down.dtype), _stream()), "lora_amd_conv_down_fwd")
+
+
+def conv_up_fwd_(y: torch.Tensor, t: torch.Tensor, up: torch.Tensor, scale: float, dropout_p: float, seed: int,
+                 offset: int) -> None:
+    """y[B,Co,H,W] += scale * mask * conv_1x1(t; up) in place."""
+    B, Co, H, W = y.shape
+    _check(require().lora_amd_conv_up_fwd(y.data_ptr(), t.data_ptr(), up.data_ptr(), B, Co, H, W, t.shape[1],
+                                          dtype_code(y.dtype), dtype_code(up.dtype), float(scale), float(dropout_p),
+                                          int(seed), int(offset), _stream()), "lora_amd_conv_up_fwd")
+
+
+def conv_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, sel: Optional[torch.Tensor], gt_part: torch.Tensor,
+               gt_out: torch.Tensor, up_part: torch.Tensor, scale: float, dropout_p: float, seed: int,
+               offset: int) -> None:
+    B, Co, H, W = g.shape
+    _check(require().lora_amd_conv_bwd_g(g.data_ptr(), t.data_ptr(), up.data_ptr(), _ptr(sel), gt_part.data_ptr(),
+                                         gt_out.data_ptr(), up_part.data_ptr(), B, Co, H, W, t.shape[1],
+                                         dtype_code(g.dtype), dtype_code(up.dtype), float(scale), float(dropout_p),
+                                         int(seed), int(offset), _stream()), "lora_amd_conv_bwd_g")
+
+
+def conv_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt: torch.Tensor, down: torch.Tensor,
+               down_part: torch.Tensor, ks: int) -> None:
+    B, Ci, H, W = x.shape
+    _check(require().lora_amd_conv_bwd_x(x.data_ptr(), _ptr(dx), gt.data_ptr(), down.data_ptr(),
+                                         down_part.data_ptr(), B, Ci, H, W, ks, down.shape[0], dtype_code(x.dtype),
+                                         dtype_code(down.dtype), _stream()), "lora_amd_conv_bwd_x")

@@ -1,0 +1,708 @@
+// K4 — low-rank branch of LoraInjectedConv2d and its gradients, NCHW, gfx950.
+//
+// replaces: lora_diffusion/lora.py:130-135 (conv2d k x k in->r, conv2d 1x1 r->out, dropout, mul, add = 5 ATen
+//           launches + 3 extra [B,C_out,H,W] round trips per site) and the autograd of that sequence.
+//
+// Layout/mapping.  NCHW keeps the pixel dimension contiguous, so a lane owns one 16-byte chunk of 8 consecutive
+// pixels of an image plane and walks the CHANNEL dimension; lane l of a wave owns chunk (group*cpw + l) of the flat
+// chunk space [B][H*W/8], `cpw` <= 64 chosen so that a wave covers whole image rows.  Consequences:
+//   * every load/store of X, Y, G, dX is a coalesced 16 B/lane access of one channel plane;
+//   * contractions over channels (T = down * X, Gt = up^T * G) accumulate in registers with no cross-lane traffic;
+//     the four waves of a workgroup take interleaved channels and are summed through LDS once per rank group,
+//     further channel splits across workgroups go through a small f32 partial buffer;
+//   * the 3x3 taps need a +-1 pixel halo inside the row (two wave shuffles per loaded row; the wave owns whole
+//     rows, so the halo never crosses a wave) and the rows above/below (two more aligned 16-byte loads, L2 hits);
+//   * contractions over pixels (dUp, dDown) are wave reductions per channel (butterfly over the 4 ranks of a
+//     rank group: 7 shuffles for 4 sums) written as per-group partials that the trainer's batched reduce folds
+//     into the flat gradient buffer.
+// The weights of the current channel (4 ranks x ks*ks taps) are wave-uniform and live in SGPRs.
+// Ranks are processed in groups of 4 (outer loop; the re-read of the activations for r > 4 is served by L2).
+//
+// Roofline: HBM for 1x1 and for 3x3 at r <= 4 (3x3: 2*9*r flop per 2-byte element = 9r flop/B vs the f32 VALU
+// balance of ~25 flop/B at 6.3 TB/s); 3x3 at r = 16 is f32-VALU bound (144 flop/B).  Algorithmic bytes per site:
+// forward  B*C_in*HW*e (X once) + 2*B*C_out*HW*e (Y read+write);  backward  B*C_out*HW*e (G once) +
+// B*C_in*HW*e (X once) + 2*B*C_in*HW*e (dX read+write); the [B,r,HW] f32 tensors are r/C of that.
+#include <algorithm>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+constexpr int kCT = 256;  // 4 waves
+
+__device__ inline float cld(const void *p, int dt, int64_t i) {
+  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
+  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
+  return (float)reinterpret_cast<const __bf16 *>(p)[i];
+}
+
+struct ChunkPos {
+  bool act;
+  int b, p0, y, x0;
+};
+
+__device__ inline ChunkPos chunk_pos(int lane, int cpw, int64_t NP, int npix8, int W) {
+  ChunkPos c;
+  const int64_t q = (int64_t)blockIdx.x * cpw + lane;
+  c.act = lane < cpw && q < NP;
+  const int64_t qq = c.act ? q : 0;
+  c.b = (int)(qq / npix8);
+  c.p0 = (int)(qq - (int64_t)c.b * npix8) * 8;
+  c.y = c.p0 / W;
+  c.x0 = c.p0 - c.y * W;
+  return c;
+}
+
+// Sums of four per-lane values over the wave: afterwards lane l (l < 4) holds the wave total of value idx4(l).
+__device__ inline int idx4(int lane) { return ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0); }
+__device__ inline float wave_sum4(float d0, float d1, float d2, float d3, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float k0 = b0 ? d2 : d0, s0 = b0 ? d0 : d2;
+  float k1 = b0 ? d3 : d1, s1 = b0 ? d1 : d3;
+  k0 += __shfl_xor(s0, 1, 64);
+  k1 += __shfl_xor(s1, 1, 64);
+  float k = b1 ? k1 : k0, s = b1 ? k0 : k1;
+  k += __shfl_xor(s, 2, 64);
+  k += __shfl_xor(k, 4, 64);
+  k += __shfl_xor(k, 8, 64);
+  k += __shfl_xor(k, 16, 64);
+  k += __shfl_xor(k, 32, 64);
+  return k;
+}
+
+__device__ inline void ld8f(const float *p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ inline void st8f(float *p, const float (&v)[8]) {
+  *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// Row chunk of a plane with its +-1 halo: w[0] = pixel p0-1, w[1..8] = the chunk, w[9] = pixel p0+8 (zeros
+// outside the row / when the row is outside the image).  All lanes of the wave must call this together.
+template <class E>
+__device__ inline void load_row_window(const typename E::storage *plane_chunk, bool ok, int x0, int W,
+                                       float (&w)[10]) {
+  float row[8];
+  if (ok) {
+    load8<E>(plane_chunk, row);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[i] = 0.f;
+  }
+  float left = __shfl_up(row[7], 1, 64), right = __shfl_down(row[0], 1, 64);
+  if (x0 == 0) left = 0.f;
+  if (x0 + 8 == W) right = 0.f;
+  w[0] = left;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i + 1] = row[i];
+  w[9] = right;
+}
+__device__ inline void load_row_window_f32(const float *plane_chunk, bool ok, int x0, int W, float (&w)[10]) {
+  float row[8];
+  if (ok) {
+    ld8f(plane_chunk, row);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[i] = 0.f;
+  }
+  float left = __shfl_up(row[7], 1, 64), right = __shfl_down(row[0], 1, 64);
+  if (x0 == 0) left = 0.f;
+  if (x0 + 8 == W) right = 0.f;
+  w[0] = left;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i + 1] = row[i];
+  w[9] = right;
+}
+
+// Sum acc[4][8] over the 4 waves of the workgroup; wave w ends up with rank w of the group in out[8].
+__device__ inline void block_rank_reduce(float *s_red, const float (&acc)[4][8], int wave, int lane, float (&out)[8]) {
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) st8f(&s_red[((wave * 4 + j) * 64 + lane) * 8], acc[j]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = 0.f;
+#pragma unroll
+  for (int w4 = 0; w4 < 4; ++w4) {
+    float v[8];
+    ld8f(&s_red[((w4 * 4 + wave) * 64 + lane) * 8], v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] += v[i];
+  }
+}
+
+// ============================================================================ T partials = conv_kxk(X; down)
+// grid (ngroups, split_in).  t_part[s][B][r][HW].
+template <class E, int KS>
+__global__ __launch_bounds__(kCT) void conv_down_fwd_kernel(const typename E::storage *__restrict__ x,
+                                                            const void *__restrict__ down, int fdt,
+                                                            float *__restrict__ t_part, int B, int C, int H, int W,
+                                                            int r, int cpw, int64_t NP, int cps) {
+  constexpr int KK = KS * KS;
+  __shared__ __attribute__((aligned(16))) float s_red[4 * 4 * 64 * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HW = H * W, npix8 = HW >> 3;
+  const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, W);
+  const int s = blockIdx.y;
+  const int c_begin = s * cps, c_end = min(C, c_begin + cps);
+  const typename E::storage *xb = x + (int64_t)cp.b * C * HW + cp.p0;
+
+  for (int rg = 0; rg * 4 < r; ++rg) {
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+      float w[4][KK];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+          w[j][t] = (rg * 4 + j < r) ? cld(down, fdt, ((int64_t)(rg * 4 + j) * C + c) * KK + t) : 0.f;
+      const typename E::storage *xp = xb + (int64_t)c * HW;
+      if (KS == 1) {
+        float xv[8];
+        if (cp.act) {
+          load8<E>(xp, xv);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[i] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(w[j][0], xv[i], acc[j][i]);
+      } else {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yy = cp.y + dy - 1;
+          float xw[10];
+          load_row_window<E>(xp + (dy - 1) * W, cp.act && yy >= 0 && yy < H, cp.x0, W, xw);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(w[j][(dy * 3 + dx) % KK], xw[i + dx], acc[j][i]);
+        }
+      }
+    }
+    float o[8];
+    block_rank_reduce(s_red, acc, wave, lane, o);
+    const int jj = rg * 4 + wave;
+    if (cp.act && jj < r) st8f(t_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+  }
+}
+
+// ============================================================================ finalize: out = mult * Sel (sum_s part[s])
+// One thread per (b, 4 pixels), all ranks.  sel_transposed: out[a] = sum_b Sel[b][a] v[b].
+__global__ __launch_bounds__(kCT) void rowvec_finalize_kernel(const float *__restrict__ part, int S,
+                                                              int64_t part_stride, const float *__restrict__ sel,
+                                                              int sel_transposed, float *__restrict__ out, int r,
+                                                              int HW, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * kCT + threadIdx.x;
+  if (i >= n4) return;
+  const int hw4 = HW >> 2;
+  const int64_t b = i / hw4;
+  const int p = (int)(i - b * hw4) * 4;
+  float4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < r) {
+      const float *pp = part + (b * r + j) * HW + p;
+      for (int s = 0; s < S; ++s) {
+        const float4 a = *reinterpret_cast<const float4 *>(pp + s * part_stride);
+        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    if (a >= r) continue;
+    float4 o = v[a];
+    if (sel != nullptr) {
+      o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int bb = 0; bb < 16; ++bb) {
+        if (bb >= r) continue;
+        const float sv = sel_transposed ? sel[bb * r + a] : sel[a * r + bb];
+        o.x = fmaf(sv, v[bb].x, o.x); o.y = fmaf(sv, v[bb].y, o.y);
+        o.z = fmaf(sv, v[bb].z, o.z); o.w = fmaf(sv, v[bb].w, o.w);
+      }
+    }
+    *reinterpret_cast<float4 *>(out + (b * r + a) * HW + p) = o;
+  }
+}
+
+// ============================================================================ Y += scale * mask * up T
+// grid (ngroups, split_out).  t: [B][r][HW] f32.
+template <class E, int RT, bool DROP>
+__global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *__restrict__ y,
+                                                          const float *__restrict__ t,
+                                                          const void *__restrict__ up, int fdt, int B, int Co, int HW,
+                                                          int r, int cpw, int64_t NP, int cps, float scale, float p,
+                                                          uint64_t seed, uint64_t offset) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int npix8 = HW >> 3;
+  const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, HW);
+  if (!cp.act) return;  // no wave-collective operations below
+  float tt[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j) {
+    if (j < r) {
+      ld8f(t + ((int64_t)cp.b * r + j) * HW + cp.p0, tt[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tt[j][i] = 0.f;
+    }
+  }
+  const int s = blockIdx.y;
+  const int c_begin = s * cps, c_end = min(Co, c_begin + cps);
+  typename E::storage *yb = y + (int64_t)cp.b * Co * HW + cp.p0;
+  constexpr int U = 4;
+  for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * U) {
+    float yv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c < c_end) load8<E>(yb + (int64_t)c * HW, yv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= c_end) continue;
+      float pr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float uj = j < r ? cld(up, fdt, (int64_t)c * r + j) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pr[i] = fmaf(uj, tt[j][i], pr[i]);
+      }
+      if (DROP) {
+        float mk[8];
+        const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
+        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv[u][i] = fmaf(scale, pr[i], yv[u][i]);
+      store8<E>(yb + (int64_t)c * HW, yv[u]);
+    }
+  }
+}
+
+// ============================================================================ pass over G
+// grid (ngroups, split_out).  gt_part[s][B][r][HW] = scale * up^T (mask*G) over the split's channels;
+// up_part[group][rank_pad][Co] = scale * sum over the group's pixels of (mask*G)[co] * T[j].
+template <class E, bool DROP>
+__global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::storage *__restrict__ g,
+                                                         const float *__restrict__ t, const void *__restrict__ up,
+                                                         int fdt, float *__restrict__ gt_part,
+                                                         float *__restrict__ up_part, int B, int Co, int HW, int r,
+                                                         int rank_pad, int cpw, int64_t NP, int cps, float scale,
+                                                         float p, uint64_t seed, uint64_t offset) {
+  __shared__ __attribute__((aligned(16))) float s_red[4 * 4 * 64 * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int npix8 = HW >> 3;
+  const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, HW);
+  const int s = blockIdx.y;
+  const int c_begin = s * cps, c_end = min(Co, c_begin + cps);
+  const typename E::storage *gb = g + (int64_t)cp.b * Co * HW + cp.p0;
+  float *upp = up_part + (int64_t)blockIdx.x * rank_pad * Co;
+
+  for (int rg = 0; rg * 4 < r; ++rg) {
+    float tt[4][8], acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cp.act && rg * 4 + j < r) {
+        ld8f(t + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, tt[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tt[j][i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    }
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+      float gv[8];
+      if (cp.act) {
+        load8<E>(gb + (int64_t)c * HW, gv);
+        if (DROP) {
+          float mk[8];
+          const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
+          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) gv[i] *= mk[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gv[i] = 0.f;
+      }
+      float d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float uj = (rg * 4 + j < r) ? cld(up, fdt, (int64_t)c * r + rg * 4 + j) : 0.f;
+        float dj = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[j][i] = fmaf(uj, gv[i], acc[j][i]);
+          dj = fmaf(gv[i], tt[j][i], dj);
+        }
+        d[j] = dj;
+      }
+      const float tot = wave_sum4(d[0], d[1], d[2], d[3], lane);
+      const int jj = rg * 4 + idx4(lane);
+      if (lane < 4 && jj < r) upp[(int64_t)jj * Co + c] = scale * tot;
+    }
+    float o[8];
+    block_rank_reduce(s_red, acc, wave, lane, o);
+    const int jj = rg * 4 + wave;
+    if (cp.act && jj < r) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= scale;
+      st8f(gt_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+    }
+  }
+}
+
+// ============================================================================ pass over X (and dX)
+// grid (ngroups, split_in).  gt: [B][r][HW] f32 (already S^T-projected).
+// down_part[group][rank_pad][C*KK] = sum over the group's pixels of gt[j][p] * X[c][p + tap];
+// dX[c][p] += sum_{j,tap} down[j][c][tap] * gt[j][p - tap].
+// A wave takes its channels in blocks of CB: the dX increments of a block stay in f32 registers across ALL rank
+// groups and are added to dX once (one rounding to the activation dtype, whatever the rank); the gt row windows
+// of a rank group (3 rows x 4 ranks x 10 pixels) are re-fetched per channel block (L1/L2 hits, [B,r,HW] is tiny).
+template <class E, int KS, bool HAS_DX>
+__global__ __launch_bounds__(kCT) void conv_bwd_x_kernel(const typename E::storage *__restrict__ x,
+                                                         typename E::storage *__restrict__ dx,
+                                                         const float *__restrict__ gt,
+                                                         const void *__restrict__ down, int fdt,
+                                                         float *__restrict__ down_part, int B, int C, int H, int W,
+                                                         int r, int rank_pad, int cpw, int64_t NP, int cps) {
+  constexpr int KK = KS * KS;
+  constexpr int CB = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HW = H * W, npix8 = HW >> 3;
+  const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, W);
+  const int s = blockIdx.y;
+  const int c_begin = s * cps, c_end = min(C, c_begin + cps);
+  const typename E::storage *xb = x + (int64_t)cp.b * C * HW + cp.p0;
+  typename E::storage *dxb = HAS_DX ? dx + (int64_t)cp.b * C * HW + cp.p0 : nullptr;
+  float *dpp = down_part + (int64_t)blockIdx.x * rank_pad * C * KK;
+  constexpr int CEN = KS == 1 ? 0 : 1;  // gw[CEN][j][1..8] = gt at the chunk's own pixels
+
+  for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * CB) {
+    float dacc[CB][8];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dacc[cb][i] = 0.f;
+    for (int rg = 0; rg * 4 < r; ++rg) {
+      // gw[dy][j][k] = gt[j][p0 - (dy-1)*W - 1 + k]  (k = 0..9); KS == 1 uses only gw[0][j][1..8]
+      float gw[KS][4][10];
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        const int yy = KS == 1 ? cp.y : cp.y - (dy - 1);
+        const int shift = KS == 1 ? 0 : -(dy - 1) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = cp.act && rg * 4 + j < r && yy >= 0 && yy < H;
+          const float *gp = gt + ((int64_t)cp.b * r + (rg * 4 + j < r ? rg * 4 + j : 0)) * HW + cp.p0 + shift;
+          if (KS == 1) {
+            float row[8];
+            if (ok) {
+              ld8f(gp, row);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) row[i] = 0.f;
+            }
+            gw[dy][j][0] = gw[dy][j][9] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gw[dy][j][i + 1] = row[i];
+          } else {
+            load_row_window_f32(gp, ok, cp.x0, W, gw[dy][j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int c = c0 + 4 * cb;
+        if (c >= c_end) continue;  // wave-uniform
+        float w[4][KK];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < KK; ++t)
+            w[j][t] = (rg * 4 + j < r) ? cld(down, fdt, ((int64_t)(rg * 4 + j) * C + c) * KK + t) : 0.f;
+        const typename E::storage *xp = xb + (int64_t)c * HW;
+        // ---- dDown partials: one wave reduction per tap
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+          float xw[10];
+          if (KS == 1) {
+            float row[8];
+            if (cp.act) {
+              load8<E>(xp, row);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) row[i] = 0.f;
+            }
+            xw[0] = xw[9] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xw[i + 1] = row[i];
+          } else {
+            const int yy = cp.y + dy - 1;
+            load_row_window<E>(xp + (dy - 1) * W, cp.act && yy >= 0 && yy < H, cp.x0, W, xw);
+          }
+#pragma unroll
+          for (int dxi = 0; dxi < KS; ++dxi) {
+            float d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float dj = 0.f;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) dj = fmaf(xw[i + (KS == 1 ? 1 : dxi)], gw[CEN][j][i + 1], dj);
+              d[j] = dj;
+            }
+            const float tot = wave_sum4(d[0], d[1], d[2], d[3], lane);
+            const int jj = rg * 4 + idx4(lane);
+            if (lane < 4 && jj < r) dpp[((int64_t)jj * C + c) * KK + dy * KS + dxi] = tot;
+          }
+        }
+        // ---- low-rank dX term of this rank group, kept in f32
+        if (HAS_DX) {
+#pragma unroll
+          for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+            for (int dxi = 0; dxi < KS; ++dxi)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                  dacc[cb][i] = fmaf(w[j][dy * KS + dxi], gw[dy][j][KS == 1 ? i + 1 : i + 2 - dxi], dacc[cb][i]);
+        }
+      }
+    }
+    if (HAS_DX && cp.act) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int c = c0 + 4 * cb;
+        if (c >= c_end) continue;
+        float dv[8];
+        load8<E>(dxb + (int64_t)c * HW, dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dv[i] += dacc[cb][i];
+        store8<E>(dxb + (int64_t)c * HW, dv);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- host
+struct ConvGeo {
+  bool native;
+  int cpw_in, ngroups_in, ngroups_out, split_in, split_out, rank_pad;
+  int64_t NP;
+};
+
+static int pick_split(int ngroups, int C, int r) {
+  int s = (512 + ngroups - 1) / ngroups;            // aim at >= 512 workgroups
+  s = std::min(s, std::max(1, C / (8 * r)));        // partial-sum traffic <= ~25 % of the activation bytes
+  s = std::min(s, std::max(1, C / 8));              // >= 2 channels per wave
+  return std::max(1, s);
+}
+static int stream_split(int ngroups, int C) {       // passes that own their output: split for parallelism only
+  return std::max(1, std::min((512 + ngroups - 1) / ngroups, C / 8));
+}
+
+// C_in / C_out may be passed as 0 by entry points that do not touch that side.
+static ConvGeo conv_geo(int B, int C_in, int C_out, int H, int W, int ks, int r) {
+  ConvGeo q;
+  memset(&q, 0, sizeof(q));
+  const int64_t HW = (int64_t)H * W;
+  q.native = B > 0 && C_in >= 0 && C_out >= 0 && H > 0 && W > 0 && (ks == 1 || ks == 3) && HW % 8 == 0 &&
+             HW < (1ll << 24) && r >= 1 && r <= 16 && (ks == 1 || (W % 8 == 0 && W <= 512));
+  if (!q.native) return q;
+  q.NP = (int64_t)B * HW / 8;
+  const int per_row = ks == 3 ? W / 8 : 1;
+  q.cpw_in = (64 / per_row) * per_row;
+  q.ngroups_in = (int)((q.NP + q.cpw_in - 1) / q.cpw_in);
+  q.ngroups_out = (int)((q.NP + 63) / 64);
+  q.split_in = C_in > 0 ? pick_split(q.ngroups_in, C_in, r) : 1;
+  q.split_out = C_out > 0 ? pick_split(q.ngroups_out, C_out, r) : 1;
+  q.rank_pad = (r + 3) & ~3;
+  return q;
+}
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+extern "C" int lora_amd_conv_plan(int32_t B, int32_t C_in, int32_t C_out, int32_t H, int32_t W, int32_t ks,
+                                  int32_t r, lora_amd_conv_plan_t *out) {
+  LORA_AMD_CHECK(out != nullptr, LORA_AMD_EINVAL, "conv_plan: null output");
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "conv_plan: rank %d outside [1,%d]", r,
+                 LORA_AMD_MAX_RANK);
+  memset(out, 0, sizeof(*out));
+  const ConvGeo q = conv_geo(B, C_in, C_out, H, W, ks, r);
+  if (!q.native) return LORA_AMD_OK;
+  const int64_t HW = (int64_t)H * W;
+  out->native = 1;
+  out->cpw_in = q.cpw_in;
+  out->ngroups_in = q.ngroups_in;
+  out->ngroups_out = q.ngroups_out;
+  out->split_in = q.split_in;
+  out->split_out = q.split_out;
+  out->rank_pad = q.rank_pad;
+  out->t_part_floats = (int64_t)q.split_in * B * r * HW;
+  out->gt_part_floats = (int64_t)q.split_out * B * r * HW;
+  out->up_part_floats = (int64_t)q.ngroups_out * q.rank_pad * C_out;
+  out->down_part_floats = (int64_t)q.ngroups_in * q.rank_pad * C_in * ks * ks;
+  return LORA_AMD_OK;
+}
+
+#define CONV_COMMON(name, Cchk)                                                                           \
+  LORA_AMD_CHECK(dtype_ok(act_dtype) && dtype_ok(factor_dtype), LORA_AMD_EINVAL, name ": bad dtype");     \
+  LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, name ": native conv path needs rank in [1,16], got %d", r); \
+  LORA_AMD_CHECK(q.native, LORA_AMD_EINVAL, name ": geometry not supported (see lora_amd_conv_plan)");
+
+static inline bool al16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+static void launch_finalize(const float *part, int S, int64_t part_stride, const float *sel, int transposed,
+                            float *out, int B, int r, int64_t HW, hipStream_t st) {
+  const int64_t n4 = (int64_t)B * HW / 4;
+  hipLaunchKernelGGL(rowvec_finalize_kernel, dim3((unsigned)((n4 + kCT - 1) / kCT)), dim3(kCT), 0, st, part, S,
+                     part_stride, sel, transposed, out, r, (int)HW, n4);
+}
+
+extern "C" int lora_amd_conv_down_fwd(const void *x, const void *down, const float *sel, float *t_part, float *t_out,
+                                      int32_t B, int32_t C_in, int32_t H, int32_t W, int32_t ks, int32_t r,
+                                      int32_t act_dtype, int32_t factor_dtype, void *stream) {
+  const ConvGeo q = conv_geo(B, C_in, 0, H, W, ks, r);
+  CONV_COMMON("conv_down_fwd", C_in);
+  LORA_AMD_CHECK(x && down && t_part && t_out && al16(x) && al16(t_part) && al16(t_out), LORA_AMD_EINVAL,
+                 "conv_down_fwd: null or unaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int S = q.split_in, cps = (C_in + S - 1) / S;
+  const bool direct = S == 1 && sel == nullptr;  // single split, no selector: partials ARE the result
+  float *dst = direct ? t_out : t_part;
+  const dim3 grid((unsigned)q.ngroups_in, (unsigned)S);
+#define CD(E, KSV)                                                                                                 \
+  hipLaunchKernelGGL((conv_down_fwd_kernel<E, KSV>), grid, dim3(kCT), 0, st,                                       \
+                     reinterpret_cast<const typename E::storage *>(x), down, factor_dtype, dst, B, C_in, H, W, r,  \
+                     q.cpw_in, q.NP, cps)
+#define CD_E(E) do { if (ks == 1) CD(E, 1); else CD(E, 3); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: CD_E(f32_t); break;
+    case LORA_AMD_F16: CD_E(f16_t); break;
+    default: CD_E(bf16_t); break;
+  }
+#undef CD_E
+#undef CD
+  if (!direct) launch_finalize(t_part, S, (int64_t)B * r * H * W, sel, 0, t_out, B, r, (int64_t)H * W, st);
+  return check_launch("lora_amd_conv_down_fwd");
+}
+
+extern "C" int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int32_t B, int32_t C_out, int32_t H,
+                                    int32_t W, int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale,
+                                    float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+  const ConvGeo q = conv_geo(B, 0, C_out, H, W, 1, r);
+  CONV_COMMON("conv_up_fwd", C_out);
+  LORA_AMD_CHECK(y && t && up && al16(y) && al16(t), LORA_AMD_EINVAL, "conv_up_fwd: null or unaligned pointer");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "conv_up_fwd: dropout p=%f", dropout_p);
+  hipStream_t st = (hipStream_t)stream;
+  // the pass streams Y: no reduction across channels, so split purely for parallelism
+  const int S = stream_split(q.ngroups_out, C_out);
+  const int cps = (C_out + S - 1) / S;
+  const dim3 grid((unsigned)q.ngroups_out, (unsigned)S);
+  const int RT = r <= 4 ? 4 : r <= 8 ? 8 : 16;
+  const bool drop = dropout_p > 0.f;
+  const int HW = H * W;
+#define CU(E, RTV, D)                                                                                            \
+  hipLaunchKernelGGL((conv_up_fwd_kernel<E, RTV, D>), grid, dim3(kCT), 0, st,                                     \
+                     reinterpret_cast<typename E::storage *>(y), t, up, factor_dtype, B, C_out, HW, r, 64, q.NP, \
+                     cps, scale, dropout_p, seed, offset)
+#define CU_RT(E, D) do { if (RT == 4) CU(E, 4, D); else if (RT == 8) CU(E, 8, D); else CU(E, 16, D); } while (0)
+#define CU_E(E) do { if (drop) CU_RT(E, true); else CU_RT(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: CU_E(f32_t); break;
+    case LORA_AMD_F16: CU_E(f16_t); break;
+    default: CU_E(bf16_t); break;
+  }
+#undef CU_E
+#undef CU_RT
+#undef CU
+  return check_launch("lora_amd_conv_up_fwd");
+}
+
+extern "C" int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up, const float *sel, float *gt_part,
+                                   float *gt_out, float *up_part, int32_t B, int32_t C_out, int32_t H, int32_t W,
+                                   int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p,
+                                   uint64_t seed, uint64_t offset, void *stream) {
+  const ConvGeo q = conv_geo(B, 0, C_out, H, W, 1, r);
+  CONV_COMMON("conv_bwd_g", C_out);
+  LORA_AMD_CHECK(g && t && up && gt_part && gt_out && up_part && al16(g) && al16(t) && al16(gt_part) && al16(gt_out),
+                 LORA_AMD_EINVAL, "conv_bwd_g: null or unaligned pointer");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "conv_bwd_g: dropout p=%f", dropout_p);
+  hipStream_t st = (hipStream_t)stream;
+  const int S = q.split_out, cps = (C_out + S - 1) / S;
+  const bool direct = S == 1 && sel == nullptr;
+  float *dst = direct ? gt_out : gt_part;
+  const dim3 grid((unsigned)q.ngroups_out, (unsigned)S);
+  const bool drop = dropout_p > 0.f;
+  const int HW = H * W;
+#define CG(E, D)                                                                                                  \
+  hipLaunchKernelGGL((conv_bwd_g_kernel<E, D>), grid, dim3(kCT), 0, st,                                           \
+                     reinterpret_cast<const typename E::storage *>(g), t, up, factor_dtype, dst, up_part, B, C_out, \
+                     HW, r, q.rank_pad, 64, q.NP, cps, scale, dropout_p, seed, offset)
+#define CG_E(E) do { if (drop) CG(E, true); else CG(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: CG_E(f32_t); break;
+    case LORA_AMD_F16: CG_E(f16_t); break;
+    default: CG_E(bf16_t); break;
+  }
+#undef CG_E
+#undef CG
+  if (!direct) launch_finalize(gt_part, S, (int64_t)B * r * HW, sel, 1, gt_out, B, r, HW, st);
+  return check_launch("lora_amd_conv_bwd_g");
+}
+
+extern "C" int lora_amd_conv_bwd_x(const void *x, void *dx, const float *gt, const void *down, float *down_part,
+                                   int32_t B, int32_t C_in, int32_t H, int32_t W, int32_t ks, int32_t r,
+                                   int32_t act_dtype, int32_t factor_dtype, void *stream) {
+  const ConvGeo q = conv_geo(B, C_in, 0, H, W, ks, r);
+  CONV_COMMON("conv_bwd_x", C_in);
+  LORA_AMD_CHECK(x && gt && down && down_part && al16(x) && al16(gt) && (dx == nullptr || al16(dx)), LORA_AMD_EINVAL,
+                 "conv_bwd_x: null or unaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  // dX is owned per (channel, chunk): channel splits need no reduction here either
+  const int S = stream_split(q.ngroups_in, C_in);
+  const int cps = (C_in + S - 1) / S;
+  const dim3 grid((unsigned)q.ngroups_in, (unsigned)S);
+  const bool has_dx = dx != nullptr;
+#define CX(E, KSV, D)                                                                                             \
+  hipLaunchKernelGGL((conv_bwd_x_kernel<E, KSV, D>), grid, dim3(kCT), 0, st,                                      \
+                     reinterpret_cast<const typename E::storage *>(x), reinterpret_cast<typename E::storage *>(dx), \
+                     gt, down, factor_dtype, down_part, B, C_in, H, W, r, q.rank_pad, q.cpw_in, q.NP, cps)
+#define CX_K(E, D) do { if (ks == 1) CX(E, 1, D); else CX(E, 3, D); } while (0)
+#define CX_E(E) do { if (has_dx) CX_K(E, true); else CX_K(E, false); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: CX_E(f32_t); break;
+    case LORA_AMD_F16: CX_E(f16_t); break;
+    default: CX_E(bf16_t); break;
+  }
+#undef CX_E
+#undef CX_K
+#undef CX
+  return check_launch("lora_amd_conv_bwd_x");
+}

@@ -171,9 +171,9 @@ class LoraInjectedConv2d(_Adapter):
         wc, bc = self._shadow(w, dt, "w"), self._shadow(b, dt, "b")
         c = self.conv
         with torch.autocast(device_type=x.device.type, enabled=False):
-            y0 = F.conv2d(xc, wc, bc, c.stride, c.padding, c.dilation, c.groups)  # frozen dense conv (MIOpen)
-            return ops.lora_conv_branch(xc, y0, self.lora_down.weight, self.lora_up.weight, self._selector_matrix(),
-                                        c.stride, c.padding, c.dilation, c.groups, self.scale, self._dropout_p())
+            return ops.lora_conv(xc, wc, bc, self.lora_down.weight, self.lora_up.weight, self._selector_matrix(),
+                                 c.stride, c.padding, c.dilation, c.groups, self.scale, self._dropout_p(),
+                                 self.__dict__.get("_grad_sink"))
 
     def set_selector_from_diag(self, diag: torch.Tensor):  # ref:140-156
         assert diag.shape == (self.r,)

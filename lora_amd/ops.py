@@ -38,38 +38,62 @@ class GradSink:
     views into the flat gradient buffer + persistent partial-sum workspaces.  The partials are summed
     into the flat buffer by ONE batched launch per step (``FlatLoraState.reduce_pending``)."""
 
-    __slots__ = ("down_grad", "up_grad", "ws", "pending", "owner")
+    __slots__ = ("down_grad", "up_grad", "ws", "rows", "pending", "owner")
 
     def __init__(self, down_grad: torch.Tensor, up_grad: torch.Tensor, owner=None):
         self.down_grad, self.up_grad = down_grad, up_grad
-        self.ws = {}        # (M, K, N, r) -> (gt_part, up_part, down_part)
+        self.ws = {}        # shape key -> tuple of persistent workspaces
+        self.rows = {}      # shape key -> reduce_batched rows folding that workspace's partials into the grads
         self.pending = None  # key of the workspace holding not-yet-reduced partials
         self.owner = owner
 
+    def _new(self, key, w, rows):
+        self.ws[key], self.rows[key] = w, rows
+        if self.owner is not None:
+            self.owner._reduce_table = None  # table must be rebuilt with the new buffers
+        return w
+
     def workspace(self, key, plan, device):
+        """Linear site, key = (M, K, N, r): (gt_part, up_part, down_part)."""
         w = self.ws.get(key)
         if w is None:
             w = tuple(torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
                       for n in (plan.gt_part_floats, plan.up_part_floats, plan.down_part_floats))
-            self.ws[key] = w
-            if self.owner is not None:
-                self.owner._reduce_table = None  # table must be rebuilt with the new buffers
+            _, K, N, r = key
+            self._new(key, w, [(w[1], self.up_grad, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
+                               (w[2], self.down_grad, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)])
         return w
 
-    def reduce_rows(self, key, plan):
-        _, up_part, down_part = self.ws[key]
-        _, K, N, r = key
-        return [(up_part, self.up_grad, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
-                (down_part, self.down_grad, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)]
+    def conv_workspace(self, key, plan, device):
+        """Conv site, key = ("conv", B, Ci, Co, H, W, ks, r): (t_part, gt_part, gt, up_part, down_part)."""
+        w = self.ws.get(key)
+        if w is None:
+            _, B, Ci, Co, H, W, ks, r = key
+            w = conv_buffers(plan, B, r, H * W, device)
+            self._new(key, w, conv_reduce_rows(w, plan, Ci, Co, ks, r, self.up_grad, self.down_grad, 1.0))
+        return w
+
+    def reduce_rows(self, key, plan=None):
+        return self.rows[key]
 
     def flush(self):
         """Reduce this site's pending partials now (a second backward is about to overwrite them)."""
         if self.pending is None:
             return
-        key = self.pending
-        table, n, total = _C.make_reduce_table(self.reduce_rows(key, _C.linear_plan(*key)), self.up_grad.device)
+        table, n, total = _C.make_reduce_table(self.rows[self.pending], self.up_grad.device)
         _C.reduce_batched(table, n, total)
         self.pending = None
+
+
+def conv_buffers(plan, B: int, r: int, HW: int, device):
+    f = lambda n: torch.empty(max(int(n), 1), dtype=torch.float32, device=device)  # noqa: E731
+    return (f(plan.t_part_floats), f(plan.gt_part_floats), f(B * r * HW), f(plan.up_part_floats),
+            f(plan.down_part_floats))
+
+
+def conv_reduce_rows(w, plan, Ci, Co, ks, r, up_grad, down_grad, beta):
+    return [(w[3], up_grad, plan.ngroups_out, plan.rank_pad, Co, r, _C.FACTOR_KR, 1.0, beta),
+            (w[4], down_grad, plan.ngroups_in, plan.rank_pad, Ci * ks * ks, r, _C.FACTOR_RK, 1.0, beta)]
 
 
 def _rows2d(t: torch.Tensor, cols: int) -> torch.Tensor:
@@ -233,13 +257,115 @@ class LoraConvUpFunction(torch.autograd.Function):
         return g, dt_out, dup_out, None, None
 
 
-def lora_conv_branch(x, y0, down_w, up_w, sel, stride, padding, dilation, groups, scale, dropout_p):
-    """Low-rank branch of LoraInjectedConv2d added onto ``y0`` (the frozen conv's output).
+class LoraConvFunction(torch.autograd.Function):
+    """``y = conv(x; W) + b + scale * dropout(conv1x1(S . conv_kxk(x; down); up))`` (lora.py:130-135) and its
+    gradient for the native geometry (stride 1, "same" 1x1 / 3x3, groups 1, NCHW; ``_C.conv_plan(...).native``).
 
-    The k x k down-projection to r channels runs as a library conv for now (a HIP
-    implicit-GEMM kernel replaces it in a later round); the 1x1 up-projection,
-    dropout, scale and the add are one fused HIP kernel per sample.
-    """
+    The frozen convolution and its input gradient are MIOpen calls; everything low-rank is csrc/conv.hip:
+    forward 2 launches (+1 tiny finalize when the channel loop is split), backward 2 (+1), the parameter
+    gradients leave as per-group partials for the batched reduce.  Saves X and T [B,r,H,W] f32 only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, down, up, sel, ks, scale, dropout_p, sink):
+        _C.require()
+        B, Ci, H, W = x.shape
+        Co, r = weight.shape[0], down.shape[0]
+        pad = (ks - 1) // 2
+        x = x.contiguous()
+        y = F.conv2d(x, weight, bias, 1, pad)  # frozen dense conv (MIOpen, MFMA)
+        if not y.is_contiguous():
+            y = y.contiguous()
+        plan = _C.conv_plan(B, Ci, Co, H, W, ks, r)
+        key = ("conv", B, Ci, Co, H, W, ks, r)
+        t_part = sink.conv_workspace(key, plan, x.device)[0] if sink is not None else \
+            torch.empty(max(int(plan.t_part_floats), 1), dtype=torch.float32, device=x.device)
+        t = torch.empty((B, r, H, W), dtype=torch.float32, device=x.device)
+        down_c, up_c = down.contiguous(), up.contiguous()
+        sel_c = sel.to(torch.float32).contiguous() if sel is not None else None
+        _C.conv_down_fwd(x, down_c, sel_c, t_part, t, ks)
+        seed = off = 0
+        if dropout_p > 0.0:
+            seed, off = next_dropout_stream()
+        _C.conv_up_fwd_(y, t, up_c, scale, dropout_p, seed, off)
+        ctx.save_for_backward(x, weight, down, up, t, sel_c)
+        ctx.ks, ctx.scale, ctx.p, ctx.seed, ctx.off, ctx.sink = ks, float(scale), float(dropout_p), seed, off, sink
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight, down, up, t, sel = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co, r, ks = weight.shape[0], down.shape[0], ctx.ks
+        pad = (ks - 1) // 2
+        need_x, need_w, need_b, need_down, need_up = ctx.needs_input_grad[:5]
+        g = g.contiguous()
+        plan = _C.conv_plan(B, Ci, Co, H, W, ks, r)
+        key = ("conv", B, Ci, Co, H, W, ks, r)
+        sink = ctx.sink
+        if sink is not None:
+            if sink.pending is not None:
+                sink.flush()
+            bufs = sink.conv_workspace(key, plan, g.device)
+        else:
+            bufs = conv_buffers(plan, B, r, H * W, g.device)
+        _, gt_part, gt, up_part, down_part = bufs
+        down_c, up_c = down.contiguous(), up.contiguous()
+        _C.conv_bwd_g(g, t, up_c, sel, gt_part, gt, up_part, ctx.scale, ctx.p, ctx.seed, ctx.off)
+        dx = None
+        if need_x:  # frozen dense conv's input gradient (MIOpen), then the low-rank term is added in place
+            dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+            if not dx.is_contiguous():
+                dx = dx.contiguous()
+        _C.conv_bwd_x(x, dx, gt, down_c, down_part, ks)
+        d_down = d_up = None
+        if sink is not None:
+            sink.pending = key
+        else:
+            d_up = torch.empty(up.shape, dtype=torch.float32, device=g.device)
+            d_down = torch.empty(down.shape, dtype=torch.float32, device=g.device)
+            table, n, total = _C.make_reduce_table(conv_reduce_rows(bufs, plan, Ci, Co, ks, r, d_up, d_down, 0.0),
+                                                   g.device)
+            _C.reduce_batched(table, n, total)
+            d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+        dw = db = None
+        if need_w:
+            dw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if ctx.has_bias and need_b:
+            db = g.sum((0, 2, 3))
+        return dx, dw, db, d_down, d_up, None, None, None, None, None
+
+
+def conv_native_ok(x: torch.Tensor, weight: torch.Tensor, r: int, stride, padding, dilation, groups) -> bool:
+    if x.dim() != 4 or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1):
+        return False
+    kh, kw = weight.shape[2], weight.shape[3]
+    if kh != kw or kh not in (1, 3) or tuple(padding) != ((kh - 1) // 2,) * 2:
+        return False
+    B, Ci, H, W = x.shape
+    return bool(_C.conv_plan(B, Ci, weight.shape[0], H, W, kh, r).native)
+
+
+def lora_conv(x, weight, bias, down_w, up_w, sel, stride, padding, dilation, groups, scale, dropout_p, sink=None):
+    """LoraInjectedConv2d forward on device tensors: the native kernels when the geometry qualifies, else the frozen
+    conv + ``lora_conv_branch`` (library conv for the k x k down-projection, HIP kernel for the rest)."""
+    r = down_w.shape[0]
+    if down_w.dtype == up_w.dtype and conv_native_ok(x, weight, r, stride, padding, dilation, groups):
+        return LoraConvFunction.apply(x, weight, bias, down_w, up_w, sel, int(weight.shape[2]), float(scale),
+                                      float(dropout_p), sink)
+    y0 = F.conv2d(x, weight, bias, stride, padding, dilation, groups)
+    return lora_conv_branch(x, y0, down_w, up_w, sel, stride, padding, dilation, groups, scale, dropout_p)
+
+
+def lora_conv_branch(x, y0, down_w, up_w, sel, stride, padding, dilation, groups, scale, dropout_p):
+    """Low-rank branch of LoraInjectedConv2d added onto ``y0`` (the frozen conv's output) for geometries
+    outside the native set (strided / dilated / grouped / odd spatial sizes).
+
+    The k x k down-projection to r channels runs as a library conv; the 1x1 up-projection,
+    dropout, scale and the add are one fused HIP kernel per sample."""
     t = F.conv2d(x, down_w if down_w.dtype == x.dtype else down_w.to(x.dtype), None, stride, padding, dilation,
                  groups)
     if sel is not None:

@@ -96,7 +96,7 @@ class FlatLoraState:
         n = 0
         for model in models:
             for m in model.modules():
-                if isinstance(m, LoraInjectedLinear) and id(m.lora_down.weight) in self.slices \
+                if isinstance(m, (LoraInjectedLinear, LoraInjectedConv2d)) and id(m.lora_down.weight) in self.slices \
                         and id(m.lora_up.weight) in self.slices:
                     sink = ops.GradSink(self.grad_view(m.lora_down.weight), self.grad_view(m.lora_up.weight), self)
                     m.__dict__["_grad_sink"] = sink
@@ -113,7 +113,7 @@ class FlatLoraState:
         if self._reduce_table is None or self._reduce_sig != sig:
             rows = []
             for s in live:
-                rows += s.reduce_rows(s.pending, _C.linear_plan(*s.pending))
+                rows += s.reduce_rows(s.pending)
             self._reduce_table = _C.make_reduce_table(rows, self.device)
             self._reduce_sig = sig
         table, n, total = self._reduce_table

@@ -104,14 +104,61 @@ def conv2d(x, w, b=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     return y.astype(F32)
 
 
-def lora_conv2d_forward(x, W, b, down, up, scale=1.0, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None):
+def lora_conv2d_forward(x, W, b, down, up, scale=1.0, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None,
+                        selector=None):
     """ref: lora_diffusion/lora.py:130-135 (ctor :94-128): ``conv(x) + dropout(up1x1(down_kxk(x))) * scale``;
     down [r,C,kh,kw] shares the frozen conv's geometry, up [Co,r,1,1]."""
     t = conv2d(x, down, None, stride, padding, dilation)
+    if selector is not None:
+        t = np.einsum("aj,bjhw->bahw", np.asarray(selector, dtype=F32), t).astype(F32)
     branch = conv2d(t, up)
     if mask is not None:
         branch = branch * np.asarray(mask, dtype=F32)
     return (conv2d(x, W, b, stride, padding, dilation) + branch * F32(scale)).astype(F32), t
+
+
+def _col2im(dcols, x_shape, kh, kw, stride, padding, dilation):
+    """Adjoint of ``_im2col``: scatter-add [B, C*kh*kw, Ho*Wo] back onto the (padded) input grid."""
+    B, C, H, W = x_shape
+    sh, sw = stride
+    ph, pw = padding
+    dh, dw = dilation
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    d6 = np.asarray(dcols, dtype=F32).reshape(B, C, kh, kw, Ho, Wo)
+    dxp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=F32)
+    for i in range(kh):
+        for j in range(kw):
+            dxp[:, :, i * dh: i * dh + sh * Ho: sh, j * dw: j * dw + sw * Wo: sw] += d6[:, :, i, j]
+    return dxp[:, :, ph: ph + H, pw: pw + W]
+
+
+def lora_conv2d_backward(g, x, W, down, up, scale=1.0, stride=(1, 1), padding=(0, 0), dilation=(1, 1), selector=None,
+                         mask=None):
+    """Autograd of lora.py:130-135 (implicit in the reference): returns dx, d_down, d_up for
+    ``conv(x; W) + scale * mask * up1x1(S . down_kxk(x))`` given the output gradient ``g`` [B,Co,Ho,Wo].
+    ``selector`` is the [r, r] matrix applied across the rank channels between down and up (lora.py:140-156)."""
+    g, x, W, down, up = (np.asarray(a, dtype=F32) for a in (g, x, W, down, up))
+    Co, Ci, kh, kw = W.shape
+    r = down.shape[0]
+    cols, Ho, Wo = _im2col(x, kh, kw, stride, padding, dilation)          # [B, Ci*kh*kw, P]
+    B, P = x.shape[0], Ho * Wo
+    t = np.einsum("jk,bkp->bjp", down.reshape(r, -1), cols)
+    if selector is not None:
+        t = np.einsum("aj,bjp->bap", np.asarray(selector, dtype=F32), t)
+    gm = g.reshape(B, Co, P)
+    if mask is not None:
+        gm = gm * np.asarray(mask, dtype=F32).reshape(B, Co, P)
+    up2 = up.reshape(Co, r)
+    d_up = F32(scale) * np.einsum("bop,bjp->oj", gm, t)
+    gt = F32(scale) * np.einsum("oj,bop->bjp", up2, gm)
+    if selector is not None:
+        gt = np.einsum("aj,bap->bjp", np.asarray(selector, dtype=F32), gt)   # S^T gt
+    d_down = np.einsum("bjp,bkp->jk", gt, cols).reshape(down.shape)
+    dcols = np.einsum("jk,bjp->bkp", down.reshape(r, -1), gt) + np.einsum("ok,bop->bkp", W.reshape(Co, -1),
+                                                                            g.reshape(B, Co, P))
+    dx = _col2im(dcols, x.shape, kh, kw, stride, padding, dilation)
+    return dx.astype(F32), d_down.astype(F32), d_up.reshape(up.shape).astype(F32)
 
 
 def realize_as_lora(up, down, scale):

@@ -78,6 +78,28 @@ def conv_cases():
     np.savez(os.path.join(OUT, "conv_cases.npz"), **out)
 
 
+def conv_native_cases():
+    """LoraInjectedConv2d on geometries the native HIP path accepts (stride 1, same padding, W % 8 == 0)."""
+    out = {}
+    cases = [("n1", 2, 16, 24, 8, 16, 3, 4, 1.0), ("n2", 3, 20, 12, 4, 8, 1, 2, 0.7),
+             ("n3", 1, 24, 16, 16, 24, 3, 8, 1.3), ("n4", 2, 12, 40, 8, 8, 3, 6, 0.9),
+             ("n5", 5, 9, 17, 2, 8, 1, 5, 1.1)]
+    for tag, B, Ci, Co, Hh, Ww, k, r, scale in cases:
+        torch.manual_seed(300 + int(tag[1]))
+        m = ref.LoraInjectedConv2d(Ci, Co, k, 1, (k - 1) // 2, r=r, dropout_p=0.0, scale=scale)
+        m.lora_up.weight.data.normal_(0, 0.2)
+        x = torch.randn(B, Ci, Hh, Ww, requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        (y * gy).sum().backward()
+        out.update({f"{tag}_x": H.t2n(x), f"{tag}_W": H.t2n(m.conv.weight), f"{tag}_b": H.t2n(m.conv.bias),
+                    f"{tag}_down": H.t2n(m.lora_down.weight), f"{tag}_up": H.t2n(m.lora_up.weight),
+                    f"{tag}_gy": H.t2n(gy), f"{tag}_y": H.t2n(y), f"{tag}_dx": H.t2n(x.grad),
+                    f"{tag}_ddown": H.t2n(m.lora_down.weight.grad), f"{tag}_dup": H.t2n(m.lora_up.weight.grad),
+                    f"{tag}_geom": np.array([k, 1, (k - 1) // 2, r], dtype=np.int64), f"{tag}_scale": np.float32(scale)})
+    np.savez(os.path.join(OUT, "conv_native_cases.npz"), **out)
+
+
 def collapse_cases():
     """collapse_lora (ref:635-669) on single-site trees, several dtype combinations."""
     out = {}
@@ -233,8 +255,13 @@ def optimizer_cases():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:  # regenerate only the named fixture sets, e.g. `make_golden.py conv_native_cases`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     linear_cases()
     conv_cases()
+    conv_native_cases()
     collapse_cases()
     traversal_cases()
     injection_and_file_cases()

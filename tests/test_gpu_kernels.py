@@ -537,3 +537,172 @@ def test_training_steps_on_device_match_cpu_path():
     T.forward_backward(dev, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
     st_d.reduce_pending()
     assert torch.allclose(st_d.flat_g, 2 * once, rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- K4 native conv adapter (csrc/conv.hip)
+@pytest.mark.parametrize("tag", ["n1", "n2", "n3", "n4", "n5"])
+def test_conv_native_module_matches_reference_vectors(tag):
+    """LoraInjectedConv2d on native geometries vs vectors produced by the reference itself (f32)."""
+    d = _npz("conv_native_cases.npz")
+    k, s, p, r = (int(v) for v in d[f"{tag}_geom"])
+    Co, Ci = d[f"{tag}_W"].shape[:2]
+    B, _, Hh, Ww = d[f"{tag}_x"].shape
+    assert _C.conv_plan(B, Ci, Co, Hh, Ww, k, r).native == 1
+    m = L.LoraInjectedConv2d(Ci, Co, k, s, p, r=r, dropout_p=0.0, scale=float(d[f"{tag}_scale"]))
+    for mod, key in ((m.conv, "W"), (m.lora_down, "down"), (m.lora_up, "up")):
+        mod.weight.data = torch.from_numpy(d[f"{tag}_{key}"])
+    m.conv.bias.data = torch.from_numpy(d[f"{tag}_b"])
+    m.to(DEV)
+    x = torch.from_numpy(d[f"{tag}_x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * torch.from_numpy(d[f"{tag}_gy"]).to(DEV)).sum().backward()
+    for name, got, want in (("y", y, d[f"{tag}_y"]), ("dx", x.grad, d[f"{tag}_dx"]),
+                            ("ddown", m.lora_down.weight.grad, d[f"{tag}_ddown"]),
+                            ("dup", m.lora_up.weight.grad, d[f"{tag}_dup"])):
+        assert got.shape == want.shape, (tag, name)
+        # the frozen conv runs in MIOpen (its own summation order); the low-rank terms are f32 fma chains
+        np.testing.assert_allclose(n(got), want, rtol=5e-4, atol=5e-4 * np.abs(want).max(), err_msg=f"{tag} {name}")
+
+
+CONV_KERNEL_CASES = [(2, 32, 48, 16, 16, 3, 4, "f32", False, 0.0), (1, 40, 24, 8, 32, 3, 16, "bf16", False, 0.0),
+                     (3, 16, 64, 8, 8, 1, 4, "bf16", True, 0.0), (2, 24, 24, 24, 24, 3, 8, "f16", True, 0.0),
+                     (4, 64, 32, 8, 8, 3, 3, "f32", False, 0.25), (2, 320, 320, 32, 32, 3, 4, "bf16", False, 0.0),
+                     (1, 640, 320, 16, 16, 1, 16, "bf16", False, 0.0), (1, 8, 8, 96, 96, 3, 5, "f32", False, 0.0)]
+
+
+@pytest.mark.parametrize("B,Ci,Co,Hh,Ww,ks,r,dt,use_sel,p", CONV_KERNEL_CASES)
+def test_conv_kernels_match_oracle(B, Ci, Co, Hh, Ww, ks, r, dt, use_sel, p):
+    """The four conv entry points called through the C-ABI vs the numpy oracle (frozen conv = 0 so that
+    only the low-rank terms are compared; the dropout mask is recovered from the kernel itself)."""
+    plan = _C.conv_plan(B, Ci, Co, Hh, Ww, ks, r)
+    assert plan.native == 1
+    pad, HW, scale = (ks - 1) // 2, Hh * Ww, 0.7
+    x, g = rnd((B, Ci, Hh, Ww), dt, seed=1), rnd((B, Co, Hh, Ww), dt, seed=2)
+    down, up = rnd((r, Ci, ks, ks), "f32", 0.2, seed=3), rnd((Co, r, 1, 1), "f32", 0.3, seed=4)
+    sel = rnd((r, r), "f32", 0.5, seed=5) if use_sel else None
+    seed, off = 1234, 7
+    bufs = ops.conv_buffers(plan, B, r, HW, DEV)
+    t_part, gt_part, gt, up_part, down_part = bufs
+    t = torch.empty((B, r, Hh, Ww), dtype=torch.float32, device=DEV)
+    _C.conv_down_fwd(x, down, sel, t_part, t, ks)
+    y0 = rnd((B, Co, Hh, Ww), dt, seed=6)
+    mask = None
+    if p > 0:  # recover the mask: update zeros with T = ones-projection
+        probe = torch.zeros((B, Co, Hh, Ww), dtype=DT[dt], device=DEV)
+        ones_t = torch.ones((B, 1, Hh, Ww), dtype=torch.float32, device=DEV)
+        _C.conv_up_fwd_(probe, ones_t, torch.ones((Co, 1, 1, 1), device=DEV), 1.0, p, seed, off)
+        mask = n(probe)
+        keep = (mask != 0).mean()
+        assert abs(keep - (1 - p)) < 0.02, keep
+        np.testing.assert_allclose(mask[mask != 0], 1.0 / (1 - p), rtol=1e-2)
+        mask = (mask != 0).astype(np.float32) / np.float32(1 - p)
+    y = y0.clone()
+    _C.conv_up_fwd_(y, t, up, scale, p, seed, off)
+    seln = n(sel) if use_sel else None
+    yo, t_o = O.lora_conv2d_forward(n(x), np.zeros((Co, Ci, ks, ks), np.float32), None, n(down), n(up), scale, (1, 1),
+                                    (pad, pad), (1, 1), mask=mask, selector=seln)
+    absx = np.abs(n(x)).max() * np.abs(n(down)).sum(axis=(1, 2, 3)).max()
+    close(n(t), t_o, absx, "f32", msg="T")
+    absy = np.abs(t_o).max() * np.abs(n(up)).sum(axis=1).max() * scale * (1.0 / (1 - p))
+    close(n(y), yo + n(y0), absy + np.abs(n(y0)), dt, msg="Y")
+    # backward
+    dx0 = rnd((B, Ci, Hh, Ww), dt, seed=8)
+    dx = dx0.clone()
+    _C.conv_bwd_g(g, t, up, sel, gt_part, gt, up_part, scale, p, seed, off)
+    _C.conv_bwd_x(x, dx, gt, down, down_part, ks)
+    d_up = torch.empty((Co, r, 1, 1), device=DEV)
+    d_down = torch.empty((r, Ci, ks, ks), device=DEV)
+    table, nn_, total = _C.make_reduce_table(ops.conv_reduce_rows(bufs, plan, Ci, Co, ks, r, d_up, d_down, 0.0), DEV)
+    _C.reduce_batched(table, nn_, total)
+    dxo, ddo, duo = O.lora_conv2d_backward(n(g), n(x), np.zeros((Co, Ci, ks, ks), np.float32), n(down), n(up), scale,
+                                           (1, 1), (pad, pad), (1, 1), selector=seln, mask=mask)
+    kk = 1e-4  # f32 sums over up to B*H*W (dUp/dDown) or C*9 (T, Gt) terms in a different order than numpy
+    np.testing.assert_allclose(n(d_up), duo, rtol=kk * 10, atol=kk * np.abs(duo).max() + 1e-6, err_msg="dUp")
+    np.testing.assert_allclose(n(d_down), ddo, rtol=kk * 10, atol=kk * np.abs(ddo).max() + 1e-6, err_msg="dDown")
+    close(n(dx), dxo + n(dx0), np.abs(dxo).max() + np.abs(n(dx0)), dt, k=1e-4, msg="dX")  # ONE rounding, any rank
+    # dDown-only variant (input does not need a gradient) writes the same partials
+    down_part.zero_()
+    _C.conv_bwd_x(x, None, gt, down, down_part, ks)
+    d_down2 = torch.empty_like(d_down)
+    rows = ops.conv_reduce_rows(bufs, plan, Ci, Co, ks, r, d_up, d_down2, 0.0)[1:]
+    table, nn_, total = _C.make_reduce_table(rows, DEV)
+    _C.reduce_batched(table, nn_, total)
+    np.testing.assert_allclose(n(d_down2), n(d_down), rtol=1e-6, atol=1e-7)
+
+
+def test_conv_native_bf16_module_against_device_torch():
+    """SD1.5-sized ResNet conv site (bf16, rank 16, dropout off): module vs the same op sequence in torch on device."""
+    torch.manual_seed(0)
+    B, Ci, Co, Hh = 2, 640, 320, 32
+    m = L.LoraInjectedConv2d(Ci, Co, 3, 1, 1, r=16, dropout_p=0.0, scale=1.0)
+    m.lora_up.weight.data.normal_(0, 0.05)
+    m.to(DEV).to(torch.bfloat16)
+    m.lora_up.weight.data = m.lora_up.weight.data.float()
+    m.lora_down.weight.data = m.lora_down.weight.data.float()
+    x = torch.randn(B, Ci, Hh, Hh, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(B, Co, Hh, Hh, device=DEV).to(torch.bfloat16)
+    y = m(x)
+    (y.float() * gy.float()).sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    dn, upw = m.lora_down.weight.detach().clone().requires_grad_(True), m.lora_up.weight.detach().clone().requires_grad_(True)
+    F = torch.nn.functional
+    yr = F.conv2d(xr, m.conv.weight.float(), m.conv.bias.float(), 1, 1) + F.conv2d(F.conv2d(xr, dn, None, 1, 1), upw)
+    (yr * gy.float()).sum().backward()
+    assert (y.float() - yr).abs().max() <= 2.0 ** -7 * yr.abs().max() + 1e-3
+    assert (x.grad.float() - xr.grad).abs().max() <= 2.0 ** -6 * xr.grad.abs().max()
+    for got, want in ((m.lora_down.weight.grad, dn.grad), (m.lora_up.weight.grad, upw.grad)):
+        assert (got - want).abs().max() <= 2e-3 * want.abs().max(), (got - want).abs().max() / want.abs().max()
+
+
+def test_conv_plan_geometry():
+    assert _C.conv_plan(4, 320, 320, 64, 64, 3, 4).native == 1
+    assert _C.conv_plan(1, 1280, 1280, 12, 12, 3, 16).native == 0   # 12-pixel rows are not 16-byte chunks
+    assert _C.conv_plan(1, 1280, 1280, 12, 12, 1, 16).native == 1   # 1x1 only needs H*W % 8 == 0
+    assert _C.conv_plan(1, 64, 64, 8, 8, 5, 4).native == 0
+    assert _C.conv_plan(1, 64, 64, 8, 8, 3, 17).native == 0
+    pl = _C.conv_plan(1, 320, 320, 96, 96, 3, 16)
+    assert pl.cpw_in == 60 and pl.ngroups_in == (96 * 96 // 8 + 59) // 60 and pl.rank_pad == 16
+
+
+@pytest.mark.parametrize("extended", [False, True])
+def test_training_steps_extended_injection_device_vs_cpu(extended):
+    """tiny UNet with Linear (+Conv2d) adapters, 2 optimiser steps, 32x32 latents: native conv kernels where the maps
+    are 16-byte friendly, the library-conv branch elsewhere; gradients land in the flat buffer either way."""
+    import copy
+
+    from lora_amd import trainer as T
+    from lora_amd.standin import DDPMScheduler, tiny_unet
+
+    torch.manual_seed(0)
+    cpu = tiny_unet()
+    cpu.requires_grad_(False)
+    torch.manual_seed(5)
+    if extended:
+        L.inject_trainable_lora_extended(cpu, r=4)
+    else:
+        L.inject_trainable_lora(cpu, r=4)
+    for mod in cpu.modules():
+        if isinstance(mod, (L.LoraInjectedLinear, L.LoraInjectedConv2d)):
+            mod.dropout.p = 0.0
+            mod.lora_up.weight.data.normal_(0, 0.05)
+    dev = copy.deepcopy(cpu).to(DEV)
+    cpu.train(), dev.train()
+    st_c = T.FlatLoraState([{"params": T.lora_params(cpu), "lr": 1e-3}], max_grad_norm=1.0)
+    st_d = T.FlatLoraState([{"params": T.lora_params(dev), "lr": 1e-3}], max_grad_norm=1.0, device=torch.device(DEV))
+    n_sites = st_d.attach_direct_grads(dev)
+    assert n_sites == len(L.extract_lora_ups_down(dev, L.UNET_EXTENDED_TARGET_REPLACE))
+    sched = DDPMScheduler()
+    for it in range(2):
+        g = torch.Generator().manual_seed(it)
+        lat, ehs = torch.randn(2, 4, 32, 32, generator=g), torch.randn(2, 7, 32, generator=g)
+        noise, t = torch.randn(2, 4, 32, 32, generator=g), torch.randint(0, 1000, (2,), generator=g)
+        lc = T.forward_backward(cpu, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=t)
+        ld = T.forward_backward(dev, sched, lat.to(DEV), ehs.to(DEV), T.StepConfig(), noise=noise.to(DEV), timesteps=t.to(DEV))
+        assert abs(lc.item() - ld.item()) < 2e-4 * max(1.0, abs(lc.item()))
+        if it == 0:
+            st_d.reduce_pending()
+            np.testing.assert_allclose(n(st_d.flat_g), st_c.flat_g.numpy(), rtol=5e-3, atol=5e-5)
+        st_c.step(st_c.all_reduce())
+        st_d.step(st_d.all_reduce())
+    # AdamW normalises the update: where a gradient is ~0 its sign decides +-lr, so allow 15 % of the 2*lr bound
+    np.testing.assert_allclose(n(st_d.flat_p), st_c.flat_p.numpy(), rtol=2e-3, atol=3e-4)

@@ -66,6 +66,44 @@ def test_conv_forward_matches_reference(tag):
     np.testing.assert_allclose(H.t2n(up.grad), d[f"{tag}_dup"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("fn,tag", [("conv_cases.npz", t) for t in "abc"] +
+                         [("conv_native_cases.npz", t) for t in ("n1", "n2", "n3", "n4", "n5")])
+def test_conv_backward_oracle_matches_reference(fn, tag):
+    """numpy restatement of the conv adapter's autograd vs gradients produced by the reference itself."""
+    d = _npz(fn)
+    k, s, p, r = (int(v) for v in d[f"{tag}_geom"])
+    sc = float(d[f"{tag}_scale"])
+    y, _ = O.lora_conv2d_forward(d[f"{tag}_x"], d[f"{tag}_W"], d[f"{tag}_b"], d[f"{tag}_down"], d[f"{tag}_up"], sc,
+                                 (s, s), (p, p))
+    np.testing.assert_allclose(y, d[f"{tag}_y"], rtol=1e-4, atol=1e-4)
+    dx, ddown, dup = O.lora_conv2d_backward(d[f"{tag}_gy"], d[f"{tag}_x"], d[f"{tag}_W"], d[f"{tag}_down"],
+                                            d[f"{tag}_up"], sc, (s, s), (p, p))
+    np.testing.assert_allclose(dx, d[f"{tag}_dx"], rtol=1e-4, atol=1e-4 * np.abs(d[f"{tag}_dx"]).max())
+    np.testing.assert_allclose(ddown, d[f"{tag}_ddown"], rtol=1e-4, atol=1e-4 * np.abs(d[f"{tag}_ddown"]).max())
+    np.testing.assert_allclose(dup, d[f"{tag}_dup"], rtol=1e-4, atol=1e-4 * np.abs(d[f"{tag}_dup"]).max())
+
+
+def test_conv_selector_oracle_is_consistent_with_torch():
+    """The reference cannot run a conv selector (it installs a 2-D Conv2d weight, lora.py:151); the oracle's
+    selector maths is pinned against torch autograd of the intended 1x1 rank-mixing conv instead."""
+    g = torch.Generator().manual_seed(3)
+    B, Ci, Co, Hh, Ww, r = 2, 6, 5, 4, 8, 3
+    x = torch.randn(B, Ci, Hh, Ww, generator=g, requires_grad=True)
+    W, down = torch.randn(Co, Ci, 3, 3, generator=g) * 0.2, (torch.randn(r, Ci, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    up, sel = (torch.randn(Co, r, 1, 1, generator=g) * 0.4).requires_grad_(True), torch.randn(r, r, generator=g)
+    gy = torch.randn(B, Co, Hh, Ww, generator=g)
+    F = torch.nn.functional
+    y = F.conv2d(x, W, None, 1, 1) + 0.8 * F.conv2d(F.conv2d(F.conv2d(x, down, None, 1, 1), sel.reshape(r, r, 1, 1)), up)
+    (y * gy).sum().backward()
+    yo, _ = O.lora_conv2d_forward(H.t2n(x), H.t2n(W), None, H.t2n(down), H.t2n(up), 0.8, (1, 1), (1, 1), selector=H.t2n(sel))
+    dx, ddown, dup = O.lora_conv2d_backward(H.t2n(gy), H.t2n(x), H.t2n(W), H.t2n(down), H.t2n(up), 0.8, (1, 1), (1, 1),
+                                            selector=H.t2n(sel))
+    np.testing.assert_allclose(yo, H.t2n(y), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dx, H.t2n(x.grad), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ddown, H.t2n(down.grad), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dup, H.t2n(up.grad), rtol=1e-4, atol=1e-5)
+
+
 def test_collapse_matches_reference_per_dtype():
     d = _npz("collapse_cases.npz")
     cases = json.load(open(os.path.join(G, "collapse_cases.json")))
