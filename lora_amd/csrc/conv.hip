@@ -54,18 +54,29 @@ __device__ inline ChunkPos chunk_pos(int lane, int cpw, int64_t NP, int npix8, i
   return c;
 }
 
+// Cross-lane moves on the DPP path (no LDS crossbar traffic): quad permutes, rotates inside a 16-lane row, and
+// whole-wave shifts by one lane (gfx9-family wave_shr:1 / wave_shl:1).
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float lane_from_prev(float v) { return dpp_mov<0x138>(v); }  // lane l <- lane l-1 (lane 0 <- 0)
+__device__ inline float lane_from_next(float v) { return dpp_mov<0x130>(v); }  // lane l <- lane l+1 (lane 63 <- 0)
+
 // Sums of four per-lane values over the wave: afterwards lane l (l < 4) holds the wave total of value idx4(l).
+// Butterfly over the two low lane bits (3 quad permutes for 4 values), then lanes with equal (l & 3) are folded:
+// rotate-by-4 and rotate-by-8 inside each 16-lane row (DPP), xor-16 and xor-32 across rows (2 LDS permutes).
 __device__ inline int idx4(int lane) { return ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0); }
 __device__ inline float wave_sum4(float d0, float d1, float d2, float d3, int lane) {
   const bool b0 = lane & 1, b1 = lane & 2;
   float k0 = b0 ? d2 : d0, s0 = b0 ? d0 : d2;
   float k1 = b0 ? d3 : d1, s1 = b0 ? d1 : d3;
-  k0 += __shfl_xor(s0, 1, 64);
-  k1 += __shfl_xor(s1, 1, 64);
+  k0 += dpp_mov<0xB1>(s0);  // quad_perm [1,0,3,2] = xor 1
+  k1 += dpp_mov<0xB1>(s1);
   float k = b1 ? k1 : k0, s = b1 ? k0 : k1;
-  k += __shfl_xor(s, 2, 64);
-  k += __shfl_xor(k, 4, 64);
-  k += __shfl_xor(k, 8, 64);
+  k += dpp_mov<0x4E>(s);    // quad_perm [2,3,0,1] = xor 2
+  k += dpp_mov<0x124>(k);   // row_ror:4
+  k += dpp_mov<0x128>(k);   // row_ror:8
   k += __shfl_xor(k, 16, 64);
   k += __shfl_xor(k, 32, 64);
   return k;
@@ -92,7 +103,17 @@ __device__ inline void load_row_window(const typename E::storage *plane_chunk, b
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[i] = 0.f;
   }
-  float left = __shfl_up(row[7], 1, 64), right = __shfl_down(row[0], 1, 64);
+  float left = lane_from_prev(row[7]), right = lane_from_next(row[0]);
+  if (x0 == 0) left = 0.f;
+  if (x0 + 8 == W) right = 0.f;
+  w[0] = left;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i + 1] = row[i];
+  w[9] = right;
+}
+// The same from a row chunk that is already in registers (zeros when the row is outside the image).
+__device__ inline void row_window(const float (&row)[8], int x0, int W, float (&w)[10]) {
+  float left = lane_from_prev(row[7]), right = lane_from_next(row[0]);
   if (x0 == 0) left = 0.f;
   if (x0 + 8 == W) right = 0.f;
   w[0] = left;
@@ -108,7 +129,7 @@ __device__ inline void load_row_window_f32(const float *plane_chunk, bool ok, in
 #pragma unroll
     for (int i = 0; i < 8; ++i) row[i] = 0.f;
   }
-  float left = __shfl_up(row[7], 1, 64), right = __shfl_down(row[0], 1, 64);
+  float left = lane_from_prev(row[7]), right = lane_from_next(row[0]);
   if (x0 == 0) left = 0.f;
   if (x0 + 8 == W) right = 0.f;
   w[0] = left;
@@ -134,55 +155,83 @@ __device__ inline void block_rank_reduce(float *s_red, const float (&acc)[4][8],
   }
 }
 
+// Wave-uniform weights of one channel: w[j][t] = f[(rank0+j) * stride_j + t] for j < 4, zero beyond rank r.
+// `f` is f32 in the constant/global address space and every index is uniform -> scalar (SMEM) loads.
+template <int KK>
+__device__ inline void load_weights(const float *__restrict__ f, int64_t stride_j, int rank0, int r, float (&w)[4][KK]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jj = rank0 + j;
+    const float *wp = f + (int64_t)(jj < r ? jj : r - 1) * stride_j;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float v = wp[t];
+      w[j][t] = jj < r ? v : 0.f;
+    }
+  }
+}
+
 // ============================================================================ T partials = conv_kxk(X; down)
-// grid (ngroups, split_in).  t_part[s][B][r][HW].
+// grid (ngroups, split_in, rank groups).  t_part[s][B][r][HW].  Two channels per trip: all row loads of both are
+// issued before the first FMA (6 x 16 B in flight per lane for 3x3).
 template <class E, int KS>
 __global__ __launch_bounds__(kCT) void conv_down_fwd_kernel(const typename E::storage *__restrict__ x,
-                                                            const void *__restrict__ down, int fdt,
+                                                            const float *__restrict__ down,
                                                             float *__restrict__ t_part, int B, int C, int H, int W,
                                                             int r, int cpw, int64_t NP, int cps) {
   constexpr int KK = KS * KS;
+  constexpr int U = 2;
   __shared__ __attribute__((aligned(16))) float s_red[4 * 4 * 64 * 8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int HW = H * W, npix8 = HW >> 3;
   const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, W);
-  const int s = blockIdx.y;
+  const int s = blockIdx.y, rg = blockIdx.z;
   const int c_begin = s * cps, c_end = min(C, c_begin + cps);
   const typename E::storage *xb = x + (int64_t)cp.b * C * HW + cp.p0;
+  bool rok[KS];
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy) {
+    const int yy = cp.y + dy - (KS >> 1);
+    rok[dy] = cp.act && yy >= 0 && yy < H;
+  }
 
-  for (int rg = 0; rg * 4 < r; ++rg) {
-    float acc[4][8];
+  float acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-    for (int c = c_begin + wave; c < c_end; c += 4) {
-      float w[4][KK];
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+  for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * U) {
+    float rows[U][KS][8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
 #pragma unroll
-        for (int t = 0; t < KK; ++t)
-          w[j][t] = (rg * 4 + j < r) ? cld(down, fdt, ((int64_t)(rg * 4 + j) * C + c) * KK + t) : 0.f;
-      const typename E::storage *xp = xb + (int64_t)c * HW;
-      if (KS == 1) {
-        float xv[8];
-        if (cp.act) {
-          load8<E>(xp, xv);
+      for (int dy = 0; dy < KS; ++dy) {
+        if (c < c_end && rok[dy]) {
+          load8<E>(xb + (int64_t)c * HW + (dy - (KS >> 1)) * W, rows[u][dy]);
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xv[i] = 0.f;
+          for (int i = 0; i < 8; ++i) rows[u][dy][i] = 0.f;
         }
+      }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= c_end) continue;  // wave-uniform
+      float w[4][KK];
+      load_weights<KK>(down + (int64_t)c * KK, (int64_t)C * KK, rg * 4, r, w);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(w[j][0], xv[i], acc[j][i]);
-      } else {
+      for (int dy = 0; dy < KS; ++dy) {
+        if (KS == 1) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int yy = cp.y + dy - 1;
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(w[j][0], rows[u][dy][i], acc[j][i]);
+        } else {
           float xw[10];
-          load_row_window<E>(xp + (dy - 1) * W, cp.act && yy >= 0 && yy < H, cp.x0, W, xw);
+          row_window(rows[u][dy], cp.x0, W, xw);
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -192,19 +241,52 @@ __global__ __launch_bounds__(kCT) void conv_down_fwd_kernel(const typename E::st
         }
       }
     }
-    float o[8];
-    block_rank_reduce(s_red, acc, wave, lane, o);
-    const int jj = rg * 4 + wave;
-    if (cp.act && jj < r) st8f(t_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+  }
+  float o[8];
+  block_rank_reduce(s_red, acc, wave, lane, o);
+  const int jj = rg * 4 + wave;
+  if (cp.act && jj < r) st8f(t_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+}
+
+// ============================================================================ finalize: out = Sel (sum_s part[s])
+// sum kernel: 64 outputs (float4 each) x 4 split-slices per workgroup; every thread keeps 4 independent loads in
+// flight and the slices meet in LDS.  Deterministic (fixed summation order), no atomics.
+__global__ __launch_bounds__(kCT) void partial_sum_kernel(const float *__restrict__ part, int S, int64_t part_stride,
+                                                          float *__restrict__ out, int64_t n4) {
+  __shared__ float4 s_acc[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (i < n4) {
+    const float4 *pp = reinterpret_cast<const float4 *>(part) + i;
+    const int64_t st4 = part_stride >> 2;
+    int s = sl;
+    for (; s + 12 < S; s += 16) {
+      const float4 v0 = pp[(int64_t)s * st4], v1 = pp[(int64_t)(s + 4) * st4], v2 = pp[(int64_t)(s + 8) * st4],
+                   v3 = pp[(int64_t)(s + 12) * st4];
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < S; s += 4) {
+      const float4 v0 = pp[(int64_t)s * st4];
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+  }
+  s_acc[sl][o] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                             (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    const float4 b0 = s_acc[0][o], b1 = s_acc[1][o], b2 = s_acc[2][o], b3 = s_acc[3][o];
+    reinterpret_cast<float4 *>(out)[i] = make_float4((b0.x + b1.x) + (b2.x + b3.x), (b0.y + b1.y) + (b2.y + b3.y),
+                                                     (b0.z + b1.z) + (b2.z + b3.z), (b0.w + b1.w) + (b2.w + b3.w));
   }
 }
 
-// ============================================================================ finalize: out = mult * Sel (sum_s part[s])
-// One thread per (b, 4 pixels), all ranks.  sel_transposed: out[a] = sum_b Sel[b][a] v[b].
-__global__ __launch_bounds__(kCT) void rowvec_finalize_kernel(const float *__restrict__ part, int S,
-                                                              int64_t part_stride, const float *__restrict__ sel,
-                                                              int sel_transposed, float *__restrict__ out, int r,
-                                                              int HW, int64_t n4) {
+// selector (rare: set_lora_diag): io[b][a][p] <- sum_j Sel[a][j] io[b][j][p]  (transposed: Sel[j][a]), in place.
+__global__ __launch_bounds__(kCT) void selector_mix_kernel(float *__restrict__ io, const float *__restrict__ sel,
+                                                           int sel_transposed, int r, int HW, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * kCT + threadIdx.x;
   if (i >= n4) return;
   const int hw4 = HW >> 2;
@@ -212,31 +294,20 @@ __global__ __launch_bounds__(kCT) void rowvec_finalize_kernel(const float *__res
   const int p = (int)(i - b * hw4) * 4;
   float4 v[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < r) {
-      const float *pp = part + (b * r + j) * HW + p;
-      for (int s = 0; s < S; ++s) {
-        const float4 a = *reinterpret_cast<const float4 *>(pp + s * part_stride);
-        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
-      }
-    }
-  }
+  for (int j = 0; j < 16; ++j)
+    v[j] = j < r ? *reinterpret_cast<const float4 *>(io + (b * r + j) * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int a = 0; a < 16; ++a) {
     if (a >= r) continue;
-    float4 o = v[a];
-    if (sel != nullptr) {
-      o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int bb = 0; bb < 16; ++bb) {
-        if (bb >= r) continue;
-        const float sv = sel_transposed ? sel[bb * r + a] : sel[a * r + bb];
-        o.x = fmaf(sv, v[bb].x, o.x); o.y = fmaf(sv, v[bb].y, o.y);
-        o.z = fmaf(sv, v[bb].z, o.z); o.w = fmaf(sv, v[bb].w, o.w);
-      }
+    for (int bb = 0; bb < 16; ++bb) {
+      if (bb >= r) continue;
+      const float sv = sel_transposed ? sel[bb * r + a] : sel[a * r + bb];
+      o.x = fmaf(sv, v[bb].x, o.x); o.y = fmaf(sv, v[bb].y, o.y);
+      o.z = fmaf(sv, v[bb].z, o.z); o.w = fmaf(sv, v[bb].w, o.w);
     }
-    *reinterpret_cast<float4 *>(out + (b * r + a) * HW + p) = o;
+    *reinterpret_cast<float4 *>(io + (b * r + a) * HW + p) = o;
   }
 }
 
@@ -245,7 +316,7 @@ __global__ __launch_bounds__(kCT) void rowvec_finalize_kernel(const float *__res
 template <class E, int RT, bool DROP>
 __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *__restrict__ y,
                                                           const float *__restrict__ t,
-                                                          const void *__restrict__ up, int fdt, int B, int Co, int HW,
+                                                          const float *__restrict__ up, int B, int Co, int HW,
                                                           int r, int cpw, int64_t NP, int cps, float scale, float p,
                                                           uint64_t seed, uint64_t offset) {
   const int lane = threadIdx.x & 63;
@@ -281,7 +352,8 @@ __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *_
       float pr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
-        const float uj = j < r ? cld(up, fdt, (int64_t)c * r + j) : 0.f;
+        const float uv = up[(int64_t)c * r + (j < r ? j : r - 1)];
+        const float uj = j < r ? uv : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) pr[i] = fmaf(uj, tt[j][i], pr[i]);
       }
@@ -300,62 +372,71 @@ __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *_
 }
 
 // ============================================================================ pass over G
-// grid (ngroups, split_out).  gt_part[s][B][r][HW] = scale * up^T (mask*G) over the split's channels;
+// grid (ngroups, split_out, rank groups).  gt_part[s][B][r][HW] = scale * up^T (mask*G) over the split's channels;
 // up_part[group][rank_pad][Co] = scale * sum over the group's pixels of (mask*G)[co] * T[j].
 template <class E, bool DROP>
 __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::storage *__restrict__ g,
-                                                         const float *__restrict__ t, const void *__restrict__ up,
-                                                         int fdt, float *__restrict__ gt_part,
-                                                         float *__restrict__ up_part, int B, int Co, int HW, int r,
-                                                         int rank_pad, int cpw, int64_t NP, int cps, float scale,
-                                                         float p, uint64_t seed, uint64_t offset) {
+                                                         const float *__restrict__ t, const float *__restrict__ up,
+                                                         float *__restrict__ gt_part, float *__restrict__ up_part,
+                                                         int B, int Co, int HW, int r, int rank_pad, int cpw,
+                                                         int64_t NP, int cps, float scale, float p, uint64_t seed,
+                                                         uint64_t offset) {
+  constexpr int U = 4;
   __shared__ __attribute__((aligned(16))) float s_red[4 * 4 * 64 * 8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int npix8 = HW >> 3;
   const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, HW);
-  const int s = blockIdx.y;
+  const int s = blockIdx.y, rg = blockIdx.z;
   const int c_begin = s * cps, c_end = min(Co, c_begin + cps);
   const typename E::storage *gb = g + (int64_t)cp.b * Co * HW + cp.p0;
   float *upp = up_part + (int64_t)blockIdx.x * rank_pad * Co;
 
-  for (int rg = 0; rg * 4 < r; ++rg) {
-    float tt[4][8], acc[4][8];
+  float tt[4][8], acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (cp.act && rg * 4 + j < r) {
-        ld8f(t + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, tt[j]);
-      } else {
+  for (int j = 0; j < 4; ++j) {
+    if (cp.act && rg * 4 + j < r) {
+      ld8f(t + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, tt[j]);
+    } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) tt[j][i] = 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+      for (int i = 0; i < 8; ++i) tt[j][i] = 0.f;
     }
-    for (int c = c_begin + wave; c < c_end; c += 4) {
-      float gv[8];
-      if (cp.act) {
-        load8<E>(gb + (int64_t)c * HW, gv);
-        if (DROP) {
-          float mk[8];
-          const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
-          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) gv[i] *= mk[i];
-        }
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+  }
+  for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * U) {
+    float gv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c < c_end && cp.act) {
+        load8<E>(gb + (int64_t)c * HW, gv[u]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gv[i] = 0.f;
+        for (int i = 0; i < 8; ++i) gv[u][i] = 0.f;
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= c_end) continue;  // wave-uniform
+      if (DROP && cp.act) {
+        float mk[8];
+        const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
+        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gv[u][i] *= mk[i];
+      }
+      float w[4][1];
+      load_weights<1>(up + (int64_t)c * r, 1, rg * 4, r, w);
       float d[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float uj = (rg * 4 + j < r) ? cld(up, fdt, (int64_t)c * r + rg * 4 + j) : 0.f;
         float dj = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          acc[j][i] = fmaf(uj, gv[i], acc[j][i]);
-          dj = fmaf(gv[i], tt[j][i], dj);
+          acc[j][i] = fmaf(w[j][0], gv[u][i], acc[j][i]);
+          dj = fmaf(gv[u][i], tt[j][i], dj);
         }
         d[j] = dj;
       }
@@ -363,31 +444,137 @@ __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::stora
       const int jj = rg * 4 + idx4(lane);
       if (lane < 4 && jj < r) upp[(int64_t)jj * Co + c] = scale * tot;
     }
-    float o[8];
-    block_rank_reduce(s_red, acc, wave, lane, o);
-    const int jj = rg * 4 + wave;
-    if (cp.act && jj < r) {
+  }
+  float o[8];
+  block_rank_reduce(s_red, acc, wave, lane, o);
+  const int jj = rg * 4 + wave;
+  if (cp.act && jj < r) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= scale;
-      st8f(gt_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+    for (int i = 0; i < 8; ++i) o[i] *= scale;
+    st8f(gt_part + (((int64_t)s * B + cp.b) * r + jj) * HW + cp.p0, o);
+  }
+}
+
+// ============================================================================ passes over X and over dX
+// gt: [B][r][HW] f32 (already S^T-projected).  Two light kernels instead of one register-bound one: the dDown pass
+// reads X, the dX pass reads/writes dX; they share only the tiny gt / down operands.
+
+// One gt row window: gw[j][k] = gt[rank0+j][p0 + shift - 1 + k], k = 0..9 (zeros outside the row / image / rank).
+template <int KS>
+__device__ inline void load_gt_row(const float *__restrict__ gt, const ChunkPos &cp, int r, int rank0, bool row_ok,
+                                   int shift, int W, int HW, float (&gw)[4][10]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = row_ok && rank0 + j < r;
+    const float *gp = gt + ((int64_t)cp.b * r + (rank0 + j < r ? rank0 + j : 0)) * HW + cp.p0 + shift;
+    if (KS == 1) {
+      float row[8];
+      if (ok) {
+        ld8f(gp, row);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = 0.f;
+      }
+      gw[j][0] = gw[j][9] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gw[j][i + 1] = row[i];
+    } else {
+      load_row_window_f32(gp, ok, cp.x0, W, gw[j]);
     }
   }
 }
 
-// ============================================================================ pass over X (and dX)
-// grid (ngroups, split_in).  gt: [B][r][HW] f32 (already S^T-projected).
-// down_part[group][rank_pad][C*KK] = sum over the group's pixels of gt[j][p] * X[c][p + tap];
-// dX[c][p] += sum_{j,tap} down[j][c][tap] * gt[j][p - tap].
-// A wave takes its channels in blocks of CB: the dX increments of a block stay in f32 registers across ALL rank
-// groups and are added to dX once (one rounding to the activation dtype, whatever the rank); the gt row windows
-// of a rank group (3 rows x 4 ranks x 10 pixels) are re-fetched per channel block (L1/L2 hits, [B,r,HW] is tiny).
-template <class E, int KS, bool HAS_DX>
-__global__ __launch_bounds__(kCT) void conv_bwd_x_kernel(const typename E::storage *__restrict__ x,
-                                                         typename E::storage *__restrict__ dx,
-                                                         const float *__restrict__ gt,
-                                                         const void *__restrict__ down, int fdt,
-                                                         float *__restrict__ down_part, int B, int C, int H, int W,
-                                                         int r, int rank_pad, int cpw, int64_t NP, int cps) {
+// down_part[group][rank_pad][C*KK] = sum over the group's pixels of gt[j][p] * X[c][p + tap].
+// grid (ngroups_in, split, rank groups).  The wave's gt chunk (4 ranks x 8 pixels) stays in registers; two channels
+// per trip with all X row loads issued first; one butterfly wave reduction per tap.
+template <class E, int KS>
+__global__ __launch_bounds__(kCT) void conv_bwd_down_kernel(const typename E::storage *__restrict__ x,
+                                                            const float *__restrict__ gt,
+                                                            float *__restrict__ down_part, int B, int C, int H, int W,
+                                                            int r, int rank_pad, int cpw, int64_t NP, int cps) {
+  constexpr int KK = KS * KS;
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HW = H * W, npix8 = HW >> 3;
+  const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, W);
+  const int s = blockIdx.y, rg = blockIdx.z;
+  const int c_begin = s * cps, c_end = min(C, c_begin + cps);
+  const typename E::storage *xb = x + (int64_t)cp.b * C * HW + cp.p0;
+  float *dpp = down_part + (int64_t)blockIdx.x * rank_pad * C * KK;
+  bool rok[KS];
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy) {
+    const int yy = cp.y + dy - (KS >> 1);
+    rok[dy] = cp.act && yy >= 0 && yy < H;
+  }
+  float g0[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (cp.act && rg * 4 + j < r) {
+      ld8f(gt + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, g0[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g0[j][i] = 0.f;
+    }
+  }
+  for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * U) {
+    float rows[U][KS][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        if (c < c_end && rok[dy]) {
+          load8<E>(xb + (int64_t)c * HW + (dy - (KS >> 1)) * W, rows[u][dy]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) rows[u][dy][i] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= c_end) continue;  // wave-uniform
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        float xw[10];
+        if (KS == 1) {
+          xw[0] = xw[9] = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xw[i + 1] = rows[u][dy][i];
+        } else {
+          row_window(rows[u][dy], cp.x0, W, xw);
+        }
+#pragma unroll
+        for (int dxi = 0; dxi < KS; ++dxi) {
+          float d[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dj = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dj = fmaf(xw[i + (KS == 1 ? 1 : dxi)], g0[j][i], dj);
+            d[j] = dj;
+          }
+          const float tot = wave_sum4(d[0], d[1], d[2], d[3], lane);
+          const int jj = rg * 4 + idx4(lane);
+          if (lane < 4 && jj < r) dpp[((int64_t)jj * C + c) * KK + dy * KS + dxi] = tot;
+        }
+      }
+    }
+  }
+}
+
+// dX[c][p] += sum_{j,tap} down[j][c][tap] * gt[j][p - tap].  grid (ngroups_in, split).
+// A wave takes its channels four at a time: their dX increments stay in f32 registers across ALL rank groups and
+// all three tap rows and are added to dX once (one rounding to the activation dtype, whatever the rank).  The gt
+// row windows (4 ranks x 10 pixels) are fetched per (rank group, tap row) - L1/L2 hits, [B,r,HW] is tiny.
+template <class E, int KS>
+__global__ __launch_bounds__(kCT) void conv_bwd_dx_kernel(typename E::storage *__restrict__ dx,
+                                                          const float *__restrict__ gt,
+                                                          const float *__restrict__ down, int B, int C, int H, int W,
+                                                          int r, int cpw, int64_t NP, int cps) {
   constexpr int KK = KS * KS;
   constexpr int CB = 4;
   const int lane = threadIdx.x & 63;
@@ -396,113 +583,51 @@ __global__ __launch_bounds__(kCT) void conv_bwd_x_kernel(const typename E::stora
   const ChunkPos cp = chunk_pos(lane, cpw, NP, npix8, W);
   const int s = blockIdx.y;
   const int c_begin = s * cps, c_end = min(C, c_begin + cps);
-  const typename E::storage *xb = x + (int64_t)cp.b * C * HW + cp.p0;
-  typename E::storage *dxb = HAS_DX ? dx + (int64_t)cp.b * C * HW + cp.p0 : nullptr;
-  float *dpp = down_part + (int64_t)blockIdx.x * rank_pad * C * KK;
-  constexpr int CEN = KS == 1 ? 0 : 1;  // gw[CEN][j][1..8] = gt at the chunk's own pixels
+  typename E::storage *dxb = dx + (int64_t)cp.b * C * HW + cp.p0;
 
   for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * CB) {
+    float dv[CB][8];
+    if (cp.act) {  // issued now, consumed after the rank loop
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        if (c0 + 4 * cb < c_end) load8<E>(dxb + (int64_t)(c0 + 4 * cb) * HW, dv[cb]);
+    }
     float dacc[CB][8];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int i = 0; i < 8; ++i) dacc[cb][i] = 0.f;
     for (int rg = 0; rg * 4 < r; ++rg) {
-      // gw[dy][j][k] = gt[j][p0 - (dy-1)*W - 1 + k]  (k = 0..9); KS == 1 uses only gw[0][j][1..8]
-      float gw[KS][4][10];
-#pragma unroll
+#pragma unroll 1  // keep ONE row window live (unrolled, the compiler hoists all three and drops to 1 wave/SIMD)
       for (int dy = 0; dy < KS; ++dy) {
+        // source row of tap row dy: y - (dy - 1)
         const int yy = KS == 1 ? cp.y : cp.y - (dy - 1);
-        const int shift = KS == 1 ? 0 : -(dy - 1) * W;
+        float gw[4][10];
+        load_gt_row<KS>(gt, cp, r, rg * 4, cp.act && yy >= 0 && yy < H, KS == 1 ? 0 : -(dy - 1) * W, W, HW, gw);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool ok = cp.act && rg * 4 + j < r && yy >= 0 && yy < H;
-          const float *gp = gt + ((int64_t)cp.b * r + (rg * 4 + j < r ? rg * 4 + j : 0)) * HW + cp.p0 + shift;
-          if (KS == 1) {
-            float row[8];
-            if (ok) {
-              ld8f(gp, row);
-            } else {
+        for (int cb = 0; cb < CB; ++cb) {
+          const int c = c0 + 4 * cb;
+          if (c >= c_end) continue;  // wave-uniform
+          float w[4][KS];
+          load_weights<KS>(down + (int64_t)c * KK + dy * KS, (int64_t)C * KK, rg * 4, r, w);
 #pragma unroll
-              for (int i = 0; i < 8; ++i) row[i] = 0.f;
-            }
-            gw[dy][j][0] = gw[dy][j][9] = 0.f;
+          for (int dxi = 0; dxi < KS; ++dxi)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gw[dy][j][i + 1] = row[i];
-          } else {
-            load_row_window_f32(gp, ok, cp.x0, W, gw[dy][j]);
-          }
-        }
-      }
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const int c = c0 + 4 * cb;
-        if (c >= c_end) continue;  // wave-uniform
-        float w[4][KK];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < KK; ++t)
-            w[j][t] = (rg * 4 + j < r) ? cld(down, fdt, ((int64_t)(rg * 4 + j) * C + c) * KK + t) : 0.f;
-        const typename E::storage *xp = xb + (int64_t)c * HW;
-        // ---- dDown partials: one wave reduction per tap
-#pragma unroll
-        for (int dy = 0; dy < KS; ++dy) {
-          float xw[10];
-          if (KS == 1) {
-            float row[8];
-            if (cp.act) {
-              load8<E>(xp, row);
-            } else {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) row[i] = 0.f;
-            }
-            xw[0] = xw[9] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xw[i + 1] = row[i];
-          } else {
-            const int yy = cp.y + dy - 1;
-            load_row_window<E>(xp + (dy - 1) * W, cp.act && yy >= 0 && yy < H, cp.x0, W, xw);
-          }
-#pragma unroll
-          for (int dxi = 0; dxi < KS; ++dxi) {
-            float d[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float dj = 0.f;
-#pragma unroll
-              for (int i = 0; i < 8; ++i) dj = fmaf(xw[i + (KS == 1 ? 1 : dxi)], gw[CEN][j][i + 1], dj);
-              d[j] = dj;
-            }
-            const float tot = wave_sum4(d[0], d[1], d[2], d[3], lane);
-            const int jj = rg * 4 + idx4(lane);
-            if (lane < 4 && jj < r) dpp[((int64_t)jj * C + c) * KK + dy * KS + dxi] = tot;
-          }
-        }
-        // ---- low-rank dX term of this rank group, kept in f32
-        if (HAS_DX) {
-#pragma unroll
-          for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-            for (int dxi = 0; dxi < KS; ++dxi)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                  dacc[cb][i] = fmaf(w[j][dy * KS + dxi], gw[dy][j][KS == 1 ? i + 1 : i + 2 - dxi], dacc[cb][i]);
+              for (int i = 0; i < 8; ++i)
+                dacc[cb][i] = fmaf(w[j][dxi], gw[j][KS == 1 ? i + 1 : i + 2 - dxi], dacc[cb][i]);
         }
       }
     }
-    if (HAS_DX && cp.act) {
+    if (cp.act) {
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         const int c = c0 + 4 * cb;
         if (c >= c_end) continue;
-        float dv[8];
-        load8<E>(dxb + (int64_t)c * HW, dv);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dv[i] += dacc[cb][i];
-        store8<E>(dxb + (int64_t)c * HW, dv);
+        for (int i = 0; i < 8; ++i) dv[cb][i] += dacc[cb][i];
+        store8<E>(dxb + (int64_t)c * HW, dv[cb]);
       }
     }
   }
@@ -517,8 +642,9 @@ struct ConvGeo {
 
 static int pick_split(int ngroups, int C, int r) {
   int s = (512 + ngroups - 1) / ngroups;            // aim at >= 512 workgroups
-  s = std::min(s, std::max(1, C / (8 * r)));        // partial-sum traffic <= ~25 % of the activation bytes
+  s = std::min(s, std::max(1, C / (4 * r)));        // partial-sum traffic <= ~50 % of the activation bytes
   s = std::min(s, std::max(1, C / 8));              // >= 2 channels per wave
+  s = std::min(s, 32);                              // bounded depth of the partial-sum kernel
   return std::max(1, s);
 }
 static int stream_split(int ngroups, int C) {       // passes that own their output: split for parallelism only
@@ -572,7 +698,9 @@ extern "C" int lora_amd_conv_plan(int32_t B, int32_t C_in, int32_t C_out, int32_
 }
 
 #define CONV_COMMON(name, Cchk)                                                                           \
-  LORA_AMD_CHECK(dtype_ok(act_dtype) && dtype_ok(factor_dtype), LORA_AMD_EINVAL, name ": bad dtype");     \
+  LORA_AMD_CHECK(dtype_ok(act_dtype), LORA_AMD_EINVAL, name ": bad dtype");                               \
+  LORA_AMD_CHECK(factor_dtype == LORA_AMD_F32, LORA_AMD_EINVAL,                                           \
+                 name ": the conv path takes f32 factors (the trainable masters); convert 16-bit factors first"); \
   LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, name ": native conv path needs rank in [1,16], got %d", r); \
   LORA_AMD_CHECK(q.native, LORA_AMD_EINVAL, name ": geometry not supported (see lora_amd_conv_plan)");
 
@@ -580,9 +708,16 @@ static inline bool al16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 static void launch_finalize(const float *part, int S, int64_t part_stride, const float *sel, int transposed,
                             float *out, int B, int r, int64_t HW, hipStream_t st) {
-  const int64_t n4 = (int64_t)B * HW / 4;
-  hipLaunchKernelGGL(rowvec_finalize_kernel, dim3((unsigned)((n4 + kCT - 1) / kCT)), dim3(kCT), 0, st, part, S,
-                     part_stride, sel, transposed, out, r, (int)HW, n4);
+  if (S > 1) {
+    const int64_t n4 = (int64_t)B * r * HW / 4;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(kCT), 0, st, part, S, part_stride,
+                       out, n4);
+  }
+  if (sel != nullptr) {
+    const int64_t n4 = (int64_t)B * HW / 4;
+    hipLaunchKernelGGL(selector_mix_kernel, dim3((unsigned)((n4 + kCT - 1) / kCT)), dim3(kCT), 0, st, out, sel,
+                       transposed, r, (int)HW, n4);
+  }
 }
 
 extern "C" int lora_amd_conv_down_fwd(const void *x, const void *down, const float *sel, float *t_part, float *t_out,
@@ -594,13 +729,13 @@ extern "C" int lora_amd_conv_down_fwd(const void *x, const void *down, const flo
                  "conv_down_fwd: null or unaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   const int S = q.split_in, cps = (C_in + S - 1) / S;
-  const bool direct = S == 1 && sel == nullptr;  // single split, no selector: partials ARE the result
+  const bool direct = S == 1;  // single split: the partials ARE the result
   float *dst = direct ? t_out : t_part;
-  const dim3 grid((unsigned)q.ngroups_in, (unsigned)S);
+  const dim3 grid((unsigned)q.ngroups_in, (unsigned)S, (unsigned)((r + 3) / 4));
 #define CD(E, KSV)                                                                                                 \
   hipLaunchKernelGGL((conv_down_fwd_kernel<E, KSV>), grid, dim3(kCT), 0, st,                                       \
-                     reinterpret_cast<const typename E::storage *>(x), down, factor_dtype, dst, B, C_in, H, W, r,  \
-                     q.cpw_in, q.NP, cps)
+                     reinterpret_cast<const typename E::storage *>(x), reinterpret_cast<const float *>(down), dst, \
+                     B, C_in, H, W, r, q.cpw_in, q.NP, cps)
 #define CD_E(E) do { if (ks == 1) CD(E, 1); else CD(E, 3); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: CD_E(f32_t); break;
@@ -609,7 +744,7 @@ extern "C" int lora_amd_conv_down_fwd(const void *x, const void *down, const flo
   }
 #undef CD_E
 #undef CD
-  if (!direct) launch_finalize(t_part, S, (int64_t)B * r * H * W, sel, 0, t_out, B, r, (int64_t)H * W, st);
+  launch_finalize(t_part, S, (int64_t)B * r * H * W, sel, 0, t_out, B, r, (int64_t)H * W, st);
   return check_launch("lora_amd_conv_down_fwd");
 }
 
@@ -630,8 +765,8 @@ extern "C" int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int
   const int HW = H * W;
 #define CU(E, RTV, D)                                                                                            \
   hipLaunchKernelGGL((conv_up_fwd_kernel<E, RTV, D>), grid, dim3(kCT), 0, st,                                     \
-                     reinterpret_cast<typename E::storage *>(y), t, up, factor_dtype, B, C_out, HW, r, 64, q.NP, \
-                     cps, scale, dropout_p, seed, offset)
+                     reinterpret_cast<typename E::storage *>(y), t, reinterpret_cast<const float *>(up), B, C_out, \
+                     HW, r, 64, q.NP, cps, scale, dropout_p, seed, offset)
 #define CU_RT(E, D) do { if (RT == 4) CU(E, 4, D); else if (RT == 8) CU(E, 8, D); else CU(E, 16, D); } while (0)
 #define CU_E(E) do { if (drop) CU_RT(E, true); else CU_RT(E, false); } while (0)
   switch (act_dtype) {
@@ -656,15 +791,15 @@ extern "C" int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up
   LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "conv_bwd_g: dropout p=%f", dropout_p);
   hipStream_t st = (hipStream_t)stream;
   const int S = q.split_out, cps = (C_out + S - 1) / S;
-  const bool direct = S == 1 && sel == nullptr;
+  const bool direct = S == 1;
   float *dst = direct ? gt_out : gt_part;
-  const dim3 grid((unsigned)q.ngroups_out, (unsigned)S);
+  const dim3 grid((unsigned)q.ngroups_out, (unsigned)S, (unsigned)((r + 3) / 4));
   const bool drop = dropout_p > 0.f;
   const int HW = H * W;
 #define CG(E, D)                                                                                                  \
   hipLaunchKernelGGL((conv_bwd_g_kernel<E, D>), grid, dim3(kCT), 0, st,                                           \
-                     reinterpret_cast<const typename E::storage *>(g), t, up, factor_dtype, dst, up_part, B, C_out, \
-                     HW, r, q.rank_pad, 64, q.NP, cps, scale, dropout_p, seed, offset)
+                     reinterpret_cast<const typename E::storage *>(g), t, reinterpret_cast<const float *>(up), dst, \
+                     up_part, B, C_out, HW, r, q.rank_pad, 64, q.NP, cps, scale, dropout_p, seed, offset)
 #define CG_E(E) do { if (drop) CG(E, true); else CG(E, false); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: CG_E(f32_t); break;
@@ -673,7 +808,7 @@ extern "C" int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up
   }
 #undef CG_E
 #undef CG
-  if (!direct) launch_finalize(gt_part, S, (int64_t)B * r * HW, sel, 1, gt_out, B, r, HW, st);
+  launch_finalize(gt_part, S, (int64_t)B * r * HW, sel, 1, gt_out, B, r, HW, st);
   return check_launch("lora_amd_conv_bwd_g");
 }
 
@@ -685,24 +820,28 @@ extern "C" int lora_amd_conv_bwd_x(const void *x, void *dx, const float *gt, con
   LORA_AMD_CHECK(x && gt && down && down_part && al16(x) && al16(gt) && (dx == nullptr || al16(dx)), LORA_AMD_EINVAL,
                  "conv_bwd_x: null or unaligned pointer");
   hipStream_t st = (hipStream_t)stream;
-  // dX is owned per (channel, chunk): channel splits need no reduction here either
+  // both passes own their outputs per (channel, chunk) / (rank, channel): channel splits need no reduction
   const int S = stream_split(q.ngroups_in, C_in);
   const int cps = (C_in + S - 1) / S;
-  const dim3 grid((unsigned)q.ngroups_in, (unsigned)S);
-  const bool has_dx = dx != nullptr;
-#define CX(E, KSV, D)                                                                                             \
-  hipLaunchKernelGGL((conv_bwd_x_kernel<E, KSV, D>), grid, dim3(kCT), 0, st,                                      \
-                     reinterpret_cast<const typename E::storage *>(x), reinterpret_cast<typename E::storage *>(dx), \
-                     gt, down, factor_dtype, down_part, B, C_in, H, W, r, q.rank_pad, q.cpw_in, q.NP, cps)
-#define CX_K(E, D) do { if (ks == 1) CX(E, 1, D); else CX(E, 3, D); } while (0)
-#define CX_E(E) do { if (has_dx) CX_K(E, true); else CX_K(E, false); } while (0)
+  const dim3 grid_dn((unsigned)q.ngroups_in, (unsigned)S, (unsigned)((r + 3) / 4));
+  const dim3 grid_dx((unsigned)q.ngroups_in, (unsigned)S);
+#define CX(E, KSV)                                                                                                  \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((conv_bwd_down_kernel<E, KSV>), grid_dn, dim3(kCT), 0, st,                                   \
+                       reinterpret_cast<const typename E::storage *>(x), gt, down_part, B, C_in, H, W, r, q.rank_pad, \
+                       q.cpw_in, q.NP, cps);                                                                        \
+    if (dx != nullptr)                                                                                              \
+      hipLaunchKernelGGL((conv_bwd_dx_kernel<E, KSV>), grid_dx, dim3(kCT), 0, st,                                   \
+                         reinterpret_cast<typename E::storage *>(dx), gt, reinterpret_cast<const float *>(down), B, \
+                         C_in, H, W, r, q.cpw_in, q.NP, cps);                                                       \
+  } while (0)
+#define CX_E(E) do { if (ks == 1) CX(E, 1); else CX(E, 3); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: CX_E(f32_t); break;
     case LORA_AMD_F16: CX_E(f16_t); break;
     default: CX_E(bf16_t); break;
   }
 #undef CX_E
-#undef CX_K
 #undef CX
   return check_launch("lora_amd_conv_bwd_x");
 }

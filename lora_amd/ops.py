@@ -280,7 +280,7 @@ class LoraConvFunction(torch.autograd.Function):
         t_part = sink.conv_workspace(key, plan, x.device)[0] if sink is not None else \
             torch.empty(max(int(plan.t_part_floats), 1), dtype=torch.float32, device=x.device)
         t = torch.empty((B, r, H, W), dtype=torch.float32, device=x.device)
-        down_c, up_c = down.contiguous(), up.contiguous()
+        down_c, up_c = down.float().contiguous(), up.float().contiguous()  # f32 masters: no-ops in training
         sel_c = sel.to(torch.float32).contiguous() if sel is not None else None
         _C.conv_down_fwd(x, down_c, sel_c, t_part, t, ks)
         seed = off = 0
@@ -311,7 +311,7 @@ class LoraConvFunction(torch.autograd.Function):
         else:
             bufs = conv_buffers(plan, B, r, H * W, g.device)
         _, gt_part, gt, up_part, down_part = bufs
-        down_c, up_c = down.contiguous(), up.contiguous()
+        down_c, up_c = down.float().contiguous(), up.float().contiguous()
         _C.conv_bwd_g(g, t, up_c, sel, gt_part, gt, up_part, ctx.scale, ctx.p, ctx.seed, ctx.off)
         dx = None
         if need_x:  # frozen dense conv's input gradient (MIOpen), then the low-rank term is added in place

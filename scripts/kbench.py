@@ -14,17 +14,32 @@ from lora_amd.standin import sd15_lora_site_shapes  # noqa: E402
 DEV = "cuda:0"
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=20, warm=3, inner=20):
+    """Median / best time of ONE call of ``fn``: ``inner`` back-to-back calls are captured into a hipGraph and the
+    replay is bracketed by HIP events on the launch stream, so the host's ctypes/launch cost (~5-10 us per call,
+    more than many of these kernels take) is not what is measured.  Includes the ~1.5 us dependent-launch gap."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        for _ in range(inner):
+            fn()
+    graph.replay()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in evs:
         a.record()
-        fn()
+        graph.replay()
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    ts = sorted(a.elapsed_time(b) * 1e-3 / inner for a, b in evs)
     return ts[len(ts) // 2], ts[0]
 
 
@@ -105,9 +120,48 @@ def bench_linear(args):
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
+def bench_conv(args):
+    """K4 conv-adapter kernels at SD1.5 ResNet sites (bf16 activations, f32 factors)."""
+    from lora_amd import ops
+
+    for (B, Ci, Co, Hh, ks, r) in ((4, 320, 320, 64, 3, 4), (4, 640, 640, 32, 3, 4), (4, 1280, 1280, 16, 3, 4),
+                                   (4, 2560, 1280, 8, 3, 4), (4, 640, 320, 64, 1, 4), (1, 320, 320, 96, 3, 16),
+                                   (1, 1280, 640, 48, 3, 16), (1, 1920, 1280, 24, 3, 16)):
+        plan = _C.conv_plan(B, Ci, Co, Hh, Hh, ks, r)
+        x = torch.randn(B, Ci, Hh, Hh, device=DEV).to(torch.bfloat16)
+        y = torch.randn(B, Co, Hh, Hh, device=DEV).to(torch.bfloat16)
+        g = torch.randn(B, Co, Hh, Hh, device=DEV).to(torch.bfloat16)
+        dx = torch.randn(B, Ci, Hh, Hh, device=DEV).to(torch.bfloat16)
+        down = torch.randn(r, Ci, ks, ks, device=DEV) * 0.1
+        up = torch.randn(Co, r, 1, 1, device=DEV) * 0.05
+        bufs = ops.conv_buffers(plan, B, r, Hh * Hh, DEV)
+        t_part, gt_part, gt, up_part, down_part = bufs
+        t = torch.empty(B, r, Hh, Hh, device=DEV)
+        ex, ey = B * Ci * Hh * Hh * 2, B * Co * Hh * Hh * 2
+        res = dict(B=B, Ci=Ci, Co=Co, HW=Hh, ks=ks, r=r, split_in=plan.split_in, split_out=plan.split_out,
+                   groups_in=plan.ngroups_in)
+        med, _ = timeit(lambda: _C.conv_down_fwd(x, down, None, t_part, t, ks), args.iters)
+        res["down_us"], res["down_GBs"] = med * 1e6, ex / med / 1e9
+        med, _ = timeit(lambda: _C.conv_up_fwd_(y, t, up, 1e-3, 0.0, 0, 0), args.iters)
+        res["up_us"], res["up_GBs"] = med * 1e6, 2 * ey / med / 1e9
+        med, _ = timeit(lambda: _C.conv_bwd_g(g, t, up, None, gt_part, gt, up_part, 1.0, 0.0, 0, 0), args.iters)
+        res["bwd_g_us"], res["bwd_g_GBs"] = med * 1e6, ey / med / 1e9
+        med, _ = timeit(lambda: _C.conv_bwd_x(x, dx, gt, down, down_part, ks), args.iters)
+        res["bwd_x_us"], res["bwd_x_GBs"] = med * 1e6, 3 * ex / med / 1e9
+        W = (torch.randn(Co, Ci, ks, ks, device=DEV) * 0.02).to(torch.bfloat16)
+        downb, upb = down.to(torch.bfloat16), up.to(torch.bfloat16)
+        pad = (ks - 1) // 2
+        F = torch.nn.functional
+        med, _ = timeit(lambda: y + F.conv2d(F.conv2d(x, downb, None, 1, pad), upb) * 0.5, args.iters)
+        res["aten_branch_fwd_us"] = med * 1e6
+        med, _ = timeit(lambda: F.conv2d(x, W, None, 1, pad), args.iters)
+        res["frozen_conv_us"] = med * 1e6
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="merge,linear")
+    ap.add_argument("--what", default="merge,linear,conv")
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), flush=True)
@@ -115,3 +169,5 @@ if __name__ == "__main__":
         bench_merge(a)
     if "linear" in a.what:
         bench_linear(a)
+    if "conv" in a.what:
+        bench_conv(a)

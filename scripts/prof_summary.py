@@ -6,11 +6,15 @@ from collections import defaultdict
 
 path = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+by_grid = len(sys.argv) > 3 and sys.argv[3] == "by-grid"  # separate rows per launch geometry (= per problem shape)
 agg = defaultdict(lambda: [0, 0])
 with open(path) as f:
     for row in csv.DictReader(f):
         d = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-        a = agg[row["Kernel_Name"]]
+        key = row["Kernel_Name"]
+        if by_grid:
+            key = f'[{row.get("Grid_Size_X", "?")}x{row.get("Grid_Size_Y", "?")}x{row.get("Grid_Size_Z", "?")}] ' + key
+        a = agg[key]
         a[0] += 1
         a[1] += d
 tot = sum(v[1] for v in agg.values())
