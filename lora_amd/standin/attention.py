@@ -1,0 +1,88 @@
+"""Attention core of the stand-in UNet: ``scaled_dot_product_attention`` with a per-shape choice of library kernel.
+
+Host-model plumbing, not a product kernel: the dense QK^T / PV contractions stay on the library's MFMA flash kernels
+(north star: "MFMA only for the frozen attention/ResNet GEMMs").  SD1.5's head sizes are 40 / 80 / 160; on MI355X /
+PyTorch-ROCm 2.10 the flash kernel at D=40, S=4096 runs 2.7x slower than the memory-efficient kernel on the same
+tensors zero-padded to D=64 (scripts/sdpa_probe.py: 2673 us vs 984 us fwd+bwd), so each (Sq, Sk, D, dtype) shape
+picks the fastest of {flash, efficient} x {as is, head dim padded to the next 64/128/256} once, timed on first use
+(outside hipGraph capture), and sticks to it.  Zero padding of the head dimension leaves QK^T and the kept columns of
+PV unchanged; the softmax scale is passed explicitly.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+try:
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+except ImportError:  # pragma: no cover
+    SDPBackend = sdpa_kernel = None
+
+_CHOICE: Dict[Tuple, Tuple[Optional[str], int]] = {}
+_TUNE = os.environ.get("LORA_AMD_SDPA_TUNE", "1") != "0"
+
+
+def _padded(d: int) -> int:
+    return 64 if d <= 64 else 128 if d <= 128 else 256 if d <= 256 else d
+
+
+def _run(q, k, v, backend: Optional[str], pad_to: int):
+    d = q.shape[-1]
+    scale = d ** -0.5
+    if pad_to > d:
+        q, k, v = (F.pad(t, (0, pad_to - d)) for t in (q, k, v))
+    if backend is None or sdpa_kernel is None:
+        o = F.scaled_dot_product_attention(q, k, v, scale=scale)
+    else:
+        with sdpa_kernel(getattr(SDPBackend, backend)):
+            o = F.scaled_dot_product_attention(q, k, v, scale=scale)
+    return o[..., :d] if pad_to > d else o
+
+
+def _tune(q, k, v) -> Tuple[Optional[str], int]:
+    d = q.shape[-1]
+    cands = [(None, d), ("EFFICIENT_ATTENTION", d)]
+    if _padded(d) > d:
+        cands += [("EFFICIENT_ATTENTION", _padded(d)), ("FLASH_ATTENTION", _padded(d))]
+    best, best_t = (None, d), float("inf")
+    for be, pad in cands:
+        try:
+            qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+            go = torch.randn_like(q)
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                _run(qq, kk, vv, be, pad).backward(go)
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b)
+        except Exception:  # noqa: BLE001 - a backend that rejects the shape is simply not a candidate
+            continue
+        if t < best_t:
+            best, best_t = (be, pad), t
+    return best
+
+
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d)) v for [B, H, S, d] tensors."""
+    if not q.is_cuda:
+        return F.scaled_dot_product_attention(q, k, v)
+    key = (q.shape[0], q.shape[1], q.shape[2], k.shape[2], q.shape[3], q.dtype, q.requires_grad or k.requires_grad)
+    choice = _CHOICE.get(key)
+    if choice is None:
+        if _TUNE and q.dtype in (torch.bfloat16, torch.float16) and not torch.cuda.is_current_stream_capturing():
+            with torch.enable_grad():
+                choice = _tune(q, k, v)
+            _CHOICE[key] = choice
+        else:
+            choice = (None, q.shape[-1])
+    return _run(q, k, v, *choice)
+
+
+def choices():
+    return dict(_CHOICE)

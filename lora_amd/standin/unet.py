@@ -17,6 +17,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .attention import sdpa
 from torch.utils.checkpoint import checkpoint
 
 
@@ -73,7 +75,7 @@ class CrossAttention(nn.Module):
         q = self.to_q(x).view(B, T, h, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)  # dense contraction: MFMA (flash kernels on ROCm)
+        o = sdpa(q, k, v)  # dense contraction: library MFMA flash kernels, fastest variant per shape (attention.py)
         o = o.transpose(1, 2).reshape(B, T, -1)
         return self.to_out[1](self.to_out[0](o))
 
