@@ -18,6 +18,7 @@ python scripts/prof_summary.py $(find $OUT/${TAG}_trace -name "*kernel_trace.csv
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/${TAG}_trace
 fi
+if [ "$ONLY" == "trace" ]; then head -45 $OUT/${TAG}_bench_kernel_summary.txt | cut -c1-180; exit 0; fi
 # 3. PMC passes (each counter alone; no trace domains besides kernel-trace)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python scripts/pmc_probe.py > $OUT/${TAG}_pmc_probe.txt 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python scripts/pmc_probe.py > /dev/null 2> $OUT/${TAG}_pmc_write.err
