@@ -86,6 +86,11 @@ class StandinTokenizer:
         return [self._word_id(t) for t in tokens]
 
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        if self.added:  # added tokens are matched verbatim wherever they occur, as HF tokenizers do
+            import re
+
+            pat = "(" + "|".join(re.escape(t) for t in sorted(self.added, key=len, reverse=True)) + ")"
+            text = " ".join(p for p in re.split(pat, text) if p)
         ids = [self._word_id(w) for w in text.replace(",", " , ").split()]
         return [self.bos_token_id] + ids + [self.eos_token_id] if add_special_tokens else ids
 
@@ -212,3 +217,133 @@ def collate(examples, tokenizer, with_prior_preservation: bool):
     ids = tokenizer.pad({"input_ids": ids}, padding="max_length", max_length=tokenizer.model_max_length,
                         return_tensors="pt").input_ids
     return {"input_ids": ids, "pixel_values": px}
+
+
+def load_host_models(path: str, vae_path: Optional[str], revision: Optional[str], tokenizer_name: Optional[str], device,
+                     standin: str = "sd15", seed: Optional[int] = None):
+    """(tokenizer, text_encoder, vae, unet, noise_scheduler, description).
+
+    The real ``diffusers`` / ``transformers`` modules when ``path`` is a checkpoint directory and ``diffusers`` is
+    importable (ref train_lora_dreambooth.py:566-594, 678-680; cli_lora_pti.py:49-128); otherwise the stand-ins of this
+    package: SD1.5-shaped (or tiny) random-init UNet, random-init CLIP text encoder from ``transformers``' config
+    class, the fixed stand-in VAE encoder and the hash tokenizer."""
+    try:
+        import diffusers  # noqa: F401
+        real = os.path.isdir(path)
+    except ImportError:
+        real = False
+    if real:
+        from diffusers import AutoencoderKL, DDPMScheduler, UNet2DConditionModel
+        from transformers import CLIPTextModel, CLIPTokenizer
+
+        tok = CLIPTokenizer.from_pretrained(tokenizer_name or path, subfolder=None if tokenizer_name else "tokenizer",
+                                            revision=revision)
+        te = CLIPTextModel.from_pretrained(path, subfolder="text_encoder", revision=revision)
+        vae = AutoencoderKL.from_pretrained(vae_path or path, subfolder=None if vae_path else "vae",
+                                            revision=None if vae_path else revision)
+        unet = UNet2DConditionModel.from_pretrained(path, subfolder="unet", revision=revision)
+        sched = DDPMScheduler.from_config(path, subfolder="scheduler")
+        return tok, te, vae, unet, sched, "diffusers checkpoint " + path
+    from . import DDPMScheduler, clip_text_model, sd15_unet, tiny_unet
+
+    if seed is None:
+        torch.manual_seed(0)
+    tok = StandinTokenizer()
+    if standin == "tiny":
+        te = clip_text_model(hidden=32, layers=2, heads=2)
+        unet = tiny_unet(cross_attention_dim=32)
+    else:
+        te = clip_text_model()
+        with torch.device("meta"):
+            unet = sd15_unet()
+        unet.to_empty(device=device)
+        g = torch.Generator(device=device).manual_seed(0 if seed is None else seed)
+        with torch.no_grad():
+            for name, prm in unet.named_parameters():
+                if prm.dim() > 1:
+                    prm.normal_(0.0, 0.02, generator=g)
+                elif name.endswith("weight"):
+                    prm.fill_(1.0)
+                else:
+                    prm.zero_()
+    return tok, te, StandinVAE(), unet, DDPMScheduler(), f"stand-in models ({standin}; random init, no checkpoint)"
+
+
+# ----------------------------------------------------------------------------- pivotal-tuning dataset
+# A few caption templates per mode (the reference carries the textual-inversion template lists, dataset.py:12-70).
+TEMPLATES = {
+    "object": ["a photo of a {}", "a rendering of a {}", "a cropped photo of the {}", "a close-up photo of a {}",
+               "a bright photo of the {}", "a good photo of a {}", "a photo of the small {}", "a photo of one {}"],
+    "style": ["a painting in the style of {}", "a rendering in the style of {}", "a picture in the style of {}",
+              "a close-up painting in the style of {}", "a bright painting in the style of {}"],
+    "null": ["{}"],
+}
+
+
+class PivotalTuningDataset(torch.utils.data.Dataset):
+    """Images + captions for pivotal tuning (role of dataset.py:119-311).  Caption = a template around the joined
+    placeholder tokens (``use_template``), or the file stem with ``token_map`` substitutions; optional
+    ``{idx}.mask.png`` loss masks with ``use_mask_captioned_data``.  ``instance_data_root`` may be ``synthetic:N``."""
+
+    def __init__(self, instance_data_root: str, tokenizer, token_map: Optional[dict] = None,
+                 use_template: Optional[str] = None, size: int = 512, h_flip: bool = True, resize: bool = True,
+                 use_mask_captioned_data: bool = False, seed: int = 0):
+        assert not (use_mask_captioned_data and use_template), "Can't use both mask caption data and template."
+        self.size, self.tokenizer, self.resize, self.h_flip = size, tokenizer, resize, h_flip
+        self.token_map, self.use_template = token_map or {}, use_template
+        self.rng = np.random.default_rng(seed)
+        self.masks: List[Optional[str]] = []
+        if instance_data_root.startswith("synthetic:"):
+            n = int(instance_data_root.split(":", 1)[1])
+            self.items = synthetic_images(n, size, seed)
+            self.captions = [f"synthetic image {i} of DUMMY" for i in range(n)]
+            self.masks = [None] * n
+        else:
+            if not os.path.isdir(instance_data_root):
+                raise ValueError("Instance images root doesn't exists.")
+            if use_mask_captioned_data:
+                srcs = sorted(f for f in list_images(instance_data_root) if f.endswith("src.jpg"))
+                self.items, self.masks = [], []
+                for f in srcs:
+                    idx = int(os.path.basename(f).split(".")[0])
+                    m = os.path.join(instance_data_root, f"{idx}.mask.png")
+                    if os.path.exists(m):
+                        self.items.append(f)
+                        self.masks.append(m)
+                    else:
+                        print(f"Mask not found for {f}")
+                self.captions = [ln.strip() for ln in open(os.path.join(instance_data_root, "caption.txt"))]
+            else:
+                self.items = [f for f in list_images(instance_data_root) if not f.endswith("mask.png")]
+                self.captions = [os.path.basename(f).split(".")[0] for f in self.items]
+                self.masks = [None] * len(self.items)
+            assert len(self.items) > 0, "No images found in the instance data root."
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, index):
+        i = index % len(self.items)
+        item = self.items[i]
+        img = item if torch.is_tensor(item) else load_image(item, self.size, True, self.rng, self.resize)
+        if self.use_template:
+            assert self.token_map, "token_map should be specified when using template"
+            text = TEMPLATES[self.use_template][int(self.rng.integers(len(TEMPLATES[self.use_template])))].format(
+                "".join(self.token_map.values()))
+        else:
+            text = self.captions[i % len(self.captions)].strip()
+            for tok, val in self.token_map.items():
+                text = text.replace(tok, val)
+        ex = {"instance_images": img}
+        if self.masks[i] is not None:
+            from PIL import Image
+
+            m = Image.open(self.masks[i]).convert("L").resize((self.size, self.size))
+            ex["mask"] = torch.from_numpy(np.asarray(m, dtype=np.float32) / 255.0)[None]
+        if self.h_flip and self.rng.random() > 0.5:
+            ex["instance_images"] = torch.flip(ex["instance_images"], dims=[2])
+            if "mask" in ex:
+                ex["mask"] = torch.flip(ex["mask"], dims=[2])
+        ex["instance_prompt_ids"] = self.tokenizer(text, padding="do_not_pad", truncation=True,
+                                                   max_length=self.tokenizer.model_max_length).input_ids
+        return ex

@@ -30,3 +30,21 @@ def test_cli_on_device(tmp_path, graph):
     assert all(torch.isfinite(u).all() for u in ups) and max(float(u.abs().max()) for u in ups) > 0
     te_ups = loras["text_encoder"][0][0::2]
     assert max(float(u.abs().max()) for u in te_ups) > 0  # the text-encoder adapters trained too
+
+
+def test_pti_extended_on_device(tmp_path):
+    """cli_lora_pti with --use_extended_lora at rank 16 (BASELINE configs[3] geometry at toy size): TI phase, then LoRA
+    tuning with Linear + Conv2d adapters on the HIP kernels (dropout 0.1 on the conv adapters, as the reference's
+    extended injection leaves it)."""
+    from lora_amd import cli_lora_pti as pti
+
+    out = str(tmp_path / "pti")
+    pti.train(instance_data_dir="synthetic:4", pretrained_model_name_or_path="standin", output_dir=out, standin="tiny",
+              placeholder_tokens="<s1>", use_template="object", resolution=256, train_batch_size=2,
+              max_train_steps_ti=2, max_train_steps_tuning=4, save_steps=4, gradient_accumulation_steps=1,
+              lora_rank=16, use_extended_lora=True, device="cuda:0", out_name="final")
+    loras, embeds = L.load_safeloras_both(os.path.join(out, "final.safetensors"))
+    ups = loras["unet"][0][0::2]
+    assert any(u.dim() == 4 for u in ups) and all(torch.isfinite(u).all() for u in ups)
+    conv_ups = [u for u in ups if u.dim() == 4]
+    assert max(float(u.abs().max()) for u in conv_ups) > 0 and set(embeds) == {"<s1>"}

@@ -119,50 +119,10 @@ def parse_args(input_args=None):
 
 
 def load_models(args, device):
-    """(tokenizer, text_encoder, vae, unet, noise_scheduler, what) — the real diffusers/transformers modules when a
+    """(tokenizer, text_encoder, vae, unet, noise_scheduler, what): the real diffusers/transformers modules when a
     checkpoint directory and ``diffusers`` are available (ref :566-594, 678-680), the stand-ins otherwise."""
-    path = args.pretrained_model_name_or_path
-    try:
-        import diffusers  # noqa: F401
-        have_diffusers = os.path.isdir(path)
-    except ImportError:
-        have_diffusers = False
-    if have_diffusers:
-        from diffusers import AutoencoderKL, DDPMScheduler, UNet2DConditionModel
-        from transformers import CLIPTextModel, CLIPTokenizer
-
-        tok = CLIPTokenizer.from_pretrained(args.tokenizer_name or path, subfolder=None if args.tokenizer_name else "tokenizer",
-                                            revision=args.revision)
-        te = CLIPTextModel.from_pretrained(path, subfolder="text_encoder", revision=args.revision)
-        vae = AutoencoderKL.from_pretrained(args.pretrained_vae_name_or_path or path,
-                                            subfolder=None if args.pretrained_vae_name_or_path else "vae",
-                                            revision=None if args.pretrained_vae_name_or_path else args.revision)
-        unet = UNet2DConditionModel.from_pretrained(path, subfolder="unet", revision=args.revision)
-        sched = DDPMScheduler.from_config(path, subfolder="scheduler")
-        return tok, te, vae, unet, sched, "diffusers checkpoint " + path
-    from lora_amd.standin import DDPMScheduler, clip_text_model, sd15_unet, tiny_unet
-
-    if args.seed is None:
-        torch.manual_seed(0)
-    tok = SIO.StandinTokenizer()
-    if args.standin == "tiny":
-        te = clip_text_model(hidden=32, layers=2, heads=2)
-        unet = tiny_unet(cross_attention_dim=32)
-    else:
-        te = clip_text_model()
-        with torch.device("meta"):
-            unet = sd15_unet()
-        unet.to_empty(device=device)
-        g = torch.Generator(device=device).manual_seed(0 if args.seed is None else args.seed)
-        with torch.no_grad():
-            for name, prm in unet.named_parameters():
-                if prm.dim() > 1:
-                    prm.normal_(0.0, 0.02, generator=g)
-                elif name.endswith("weight"):
-                    prm.fill_(1.0)
-                else:
-                    prm.zero_()
-    return tok, te, SIO.StandinVAE(), unet, DDPMScheduler(), f"stand-in models ({args.standin}; random init, no checkpoint)"
+    return SIO.load_host_models(args.pretrained_model_name_or_path, args.pretrained_vae_name_or_path, args.revision,
+                                args.tokenizer_name, device, args.standin, args.seed)
 
 
 def main(args):
