@@ -127,6 +127,38 @@ __device__ inline void dropout_mult8(uint64_t seed, uint64_t offset, uint64_t ch
   }
 }
 
+// ---- cross-lane moves on the DPP path (no LDS crossbar traffic) ------------
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float lane_from_prev(float v) { return dpp_mov<0x138>(v); }  // wave_shr:1  lane l <- l-1 (lane 0 <- 0)
+__device__ inline float lane_from_next(float v) { return dpp_mov<0x130>(v); }  // wave_shl:1  lane l <- l+1 (lane 63 <- 0)
+
+// Sums of FOUR per-lane values over groups of 2^logn consecutive lanes (logn in [2, 6]) with a butterfly instead of
+// four independent xor-reductions: 3 quad permutes transpose-and-add the 4 values over the 2 low lane bits, then lanes
+// with equal (lane & 3) are folded with rotate-by-4 / rotate-by-8 inside a 16-lane row (DPP) and xor-16 / xor-32
+// across rows (LDS permutes).  5..7 cross-lane ops instead of 4*logn.
+// Result: valid in the lanes whose position inside the group is < 4; lane l holds the group total of value idx4(l).
+__device__ inline int idx4(int lane) { return ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0); }
+__device__ inline float group_sum4(float d0, float d1, float d2, float d3, int lane, int logn) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float k0 = b0 ? d2 : d0, s0 = b0 ? d0 : d2;
+  float k1 = b0 ? d3 : d1, s1 = b0 ? d1 : d3;
+  k0 += dpp_mov<0xB1>(s0);  // quad_perm [1,0,3,2] = xor 1
+  k1 += dpp_mov<0xB1>(s1);
+  float k = b1 ? k1 : k0, s = b1 ? k0 : k1;
+  k += dpp_mov<0x4E>(s);    // quad_perm [2,3,0,1] = xor 2
+  if (logn >= 3) k += dpp_mov<0x12C>(k);  // row_ror:12: lane i <- lane i+4 of its 16-lane row (positions 0..3 <- 4..7)
+  if (logn >= 4) k += dpp_mov<0x128>(k);  // row_ror:8:  lane i <- lane i+8
+  if (logn >= 5) k += __shfl_xor(k, 16, 64);
+  if (logn >= 6) k += __shfl_xor(k, 32, 64);
+  return k;
+}
+__device__ inline float wave_sum4(float d0, float d1, float d2, float d3, int lane) {
+  return group_sum4(d0, d1, d2, d3, lane, 6);
+}
+
 // XCD-major remap of a 1-D grid: consecutive logical tiles land on the same XCD
 // (block b is observed on XCD b % 8; speed only, never correctness).
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t nblk) {

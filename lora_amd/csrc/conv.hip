@@ -54,34 +54,6 @@ __device__ inline ChunkPos chunk_pos(int lane, int cpw, int64_t NP, int npix8, i
   return c;
 }
 
-// Cross-lane moves on the DPP path (no LDS crossbar traffic): quad permutes, rotates inside a 16-lane row, and
-// whole-wave shifts by one lane (gfx9-family wave_shr:1 / wave_shl:1).
-template <int CTRL>
-__device__ inline float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ inline float lane_from_prev(float v) { return dpp_mov<0x138>(v); }  // lane l <- lane l-1 (lane 0 <- 0)
-__device__ inline float lane_from_next(float v) { return dpp_mov<0x130>(v); }  // lane l <- lane l+1 (lane 63 <- 0)
-
-// Sums of four per-lane values over the wave: afterwards lane l (l < 4) holds the wave total of value idx4(l).
-// Butterfly over the two low lane bits (3 quad permutes for 4 values), then lanes with equal (l & 3) are folded:
-// rotate-by-4 and rotate-by-8 inside each 16-lane row (DPP), xor-16 and xor-32 across rows (2 LDS permutes).
-__device__ inline int idx4(int lane) { return ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0); }
-__device__ inline float wave_sum4(float d0, float d1, float d2, float d3, int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float k0 = b0 ? d2 : d0, s0 = b0 ? d0 : d2;
-  float k1 = b0 ? d3 : d1, s1 = b0 ? d1 : d3;
-  k0 += dpp_mov<0xB1>(s0);  // quad_perm [1,0,3,2] = xor 1
-  k1 += dpp_mov<0xB1>(s1);
-  float k = b1 ? k1 : k0, s = b1 ? k0 : k1;
-  k += dpp_mov<0x4E>(s);    // quad_perm [2,3,0,1] = xor 2
-  k += dpp_mov<0x124>(k);   // row_ror:4
-  k += dpp_mov<0x128>(k);   // row_ror:8
-  k += __shfl_xor(k, 16, 64);
-  k += __shfl_xor(k, 32, 64);
-  return k;
-}
-
 __device__ inline void ld8f(const float *p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;

@@ -244,6 +244,19 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
         }
       }
     }
+    if (sel == nullptr && logL >= 2) {
+      // butterfly: lanes l < 4 of the row's lane group end up with the totals of ranks jb + idx4(l)
+#pragma unroll
+      for (int jb = 0; jb < RT; jb += 4) {
+        const float tot = group_sum4(acc[jb], acc[(jb + 1) % RT], acc[(jb + 2) % RT], acc[(jb + 3) % RT], lane, logL);
+        const int j = jb + idx4(l);
+        if (live && l < 4) {
+          s_t[rl * RT + j] = tot;
+          if (j < r) t_out[(m0 + rl) * r + j] = tot;
+        }
+      }
+      continue;
+    }
     for (int off = L >> 1; off > 0; off >>= 1)
 #pragma unroll
       for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
@@ -387,13 +400,11 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
           dot[j] = d;
         }
       }
-      for (int off = ct8 >> 1; off > 0; off >>= 1)
 #pragma unroll
-        for (int j = 0; j < RT; ++j) dot[j] += __shfl_xor(dot[j], off, 64);
-      if (live && cl == 0) {
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-          if (j < r) gtp[(m0 + rl) * r + j] = scale * dot[j];
+      for (int jb = 0; jb < RT; jb += 4) {  // ct8 >= 4 lanes per row segment (plan): butterfly, 5..7 cross-lane ops
+        const float tot = group_sum4(dot[jb], dot[(jb + 1) % RT], dot[(jb + 2) % RT], dot[(jb + 3) % RT], tid, log_ct8);
+        const int j = jb + idx4(cl);
+        if (live && cl < 4 && j < r) gtp[(m0 + rl) * r + j] = scale * tot;
       }
     }
   }
