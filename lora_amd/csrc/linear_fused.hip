@@ -154,6 +154,8 @@ __device__ inline void stage_rowvecs(float *s_t, const float *part, int nparts, 
 }
 
 // Slot reduction of per-thread accumulators acc[RT][8] -> out[j*ld + col0 + c] for the block's column tile.
+// LDS image [4 ranks][slot][col]: every thread drops its 8 columns as two 16-byte writes per rank, the summing pass
+// reads consecutive columns with consecutive lanes (conflict-free) and stores 256-byte runs of one output row.
 template <int RT>
 __device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8], int slot, int nslots, int cl,
                                          int ct8, float *out, int64_t ld, int col0) {
@@ -162,15 +164,19 @@ __device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8]
   for (int jb = 0; jb < RT; jb += 4) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float4 v = make_float4(acc[jb][i], acc[(jb + 1) % RT][i], acc[(jb + 2) % RT][i], acc[(jb + 3) % RT][i]);
-      *reinterpret_cast<float4 *>(&s_red[((slot * ncols) + cl * 8 + i) * 4]) = v;
+    for (int jj = 0; jj < 4; ++jj) {
+      float *dst = &s_red[((jj * nslots + slot) * ncols) + cl * 8];
+      *reinterpret_cast<float4 *>(dst) = make_float4(acc[(jb + jj) % RT][0], acc[(jb + jj) % RT][1],
+                                                     acc[(jb + jj) % RT][2], acc[(jb + jj) % RT][3]);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[(jb + jj) % RT][4], acc[(jb + jj) % RT][5],
+                                                         acc[(jb + jj) % RT][6], acc[(jb + jj) % RT][7]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ncols * 4; i += kFT) {
-      const int col = i >> 2, jj = i & 3;
+      const int jj = i / ncols, col = i - jj * ncols;
+      const float *src = &s_red[(jj * nslots) * ncols + col];
       float sum = 0.f;
-      for (int s = 0; s < nslots; ++s) sum += s_red[(s * ncols + col) * 4 + jj];
+      for (int s = 0; s < nslots; ++s) sum += src[s * ncols];
       out[(int64_t)(jb + jj) * ld + col0 + col] = sum;
     }
   }
@@ -181,7 +187,7 @@ template <class E, int RT, bool DROP>
 __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
     const typename E::storage *__restrict__ x, int64_t ldx, typename E::storage *__restrict__ y, int64_t ldy,
     const void *__restrict__ down, const void *__restrict__ up, int fdt, float *__restrict__ t_out, int64_t M, int K,
-    int N, int r, int kt_cols, int nt_cols, int logL, int rows_per_block, float scale,
+    int N, int r, int kt_cols, int nt_cols, int cols_per_y, int logL, int rows_per_block, float scale,
     const float *__restrict__ sel, float p, uint64_t seed, uint64_t offset) {
   __shared__ __attribute__((aligned(16))) float s_f[kFLdsFactor];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
         const int j = jb + idx4(l);
         if (live && l < 4) {
           s_t[rl * RT + j] = tot;
-          if (j < r) t_out[(m0 + rl) * r + j] = tot;
+          if (j < r && blockIdx.y == 0) t_out[(m0 + rl) * r + j] = tot;
         }
       }
       continue;
@@ -277,13 +283,15 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         s_t[rl * RT + j] = o[j];
-        if (j < r) t_out[(m0 + rl) * r + j] = o[j];
+        if (j < r && blockIdx.y == 0) t_out[(m0 + rl) * r + j] = o[j];
       }
     }
   }
   // ---- phase 2: Y[rows of this block, :] += scale * mask * T @ up^T, column tile by column tile
-  for (int n0 = 0; n0 < N; n0 += nt_cols) {
-    const int ncols = min(nt_cols, N - n0), c8 = ncols >> 3;
+  // wide outputs (GEGLU) put column groups on grid.y: each group recomputes its rows of T (X is K/N of the traffic)
+  const int n_begin = blockIdx.y * cols_per_y, n_end = min(N, n_begin + cols_per_y);
+  for (int n0 = n_begin; n0 < n_end; n0 += nt_cols) {
+    const int ncols = min(nt_cols, n_end - n0), c8 = ncols >> 3;
     __syncthreads();  // s_t complete / previous tile's readers done
     stage_factor<RT>(s_f, up, fdt, LORA_AMD_FACTOR_KR, r, N, n0, ncols);
     __syncthreads();
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
     int N, int r, int log_ct8, int nct, int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset) {
   __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];  // this block's Gt rows, stored once at the end
   const int tid = threadIdx.x;
   const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
   const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
@@ -404,9 +413,14 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
       for (int jb = 0; jb < RT; jb += 4) {  // ct8 >= 4 lanes per row segment (plan): butterfly, 5..7 cross-lane ops
         const float tot = group_sum4(dot[jb], dot[(jb + 1) % RT], dot[(jb + 2) % RT], dot[(jb + 3) % RT], tid, log_ct8);
         const int j = jb + idx4(cl);
-        if (live && cl < 4 && j < r) gtp[(m0 + rl) * r + j] = scale * tot;
+        if (live && cl < 4) s_gt[rl * RT + j] = scale * tot;
       }
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < nrows * r; i += kFT) {  // contiguous [nrows][r] run of gt_part
+    const int rl = i / r, j = i - rl * r;
+    gtp[m0 * r + i] = s_gt[rl * RT + j];
   }
   slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, up_part + (int64_t)rb * RT * N, N, ct * ct8 * 8);
 }
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
     int rows_per_block) {
   __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];  // this block's Gt rows, stored once at the end
   const int tid = threadIdx.x;
   const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
   const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
@@ -530,11 +545,16 @@ static BwdGeom bwd_geom(int64_t M, int cols, int RT, int cap) {
   const int ct8 = pow2_divisor(c8, cap);
   q.log_ct8 = ilog2(ct8);
   q.nct = c8 / ct8;
-  // rows per block: partial traffic RT*4/(rows*e) small, yet >= ~512 blocks when the matrix allows it
-  int64_t rows = 256;
-  while (rows > 32 && ((M + rows - 1) / rows) * q.nct < 512) rows >>= 1;
+  // rows per block: as many workgroups as stay co-resident (3 per CU by LDS -> 768) and no more, so that no CU is
+  // left with an extra workgroup while the rest idle; >= 32 rows (partials are RT*4/(rows*e) of the stream) and
+  // <= kFLdsT/RT rows (their r-vectors live in LDS)
   const int64_t max_rows = kFLdsT / RT;
+  const int64_t resident = 3 * 256;
+  int64_t rows = (M * q.nct + resident - 1) / resident;
+  if (rows < 32) rows = 32;
+  while (rows < max_rows && ((M + rows - 1) / rows) * q.nct > resident) ++rows;
   if (rows > max_rows) rows = max_rows;
+  if (rows > M) rows = M;
   q.rows_per_block = (int)rows;
   q.nrb = (M + rows - 1) / rows;
   return q;
@@ -589,14 +609,23 @@ extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t 
   const int64_t max_rows = ((kFLdsT / RT) / rows_iter) * rows_iter;
   if (rpb > max_rows) rpb = max_rows;
   if (rpb < rows_iter) rpb = rows_iter;
-  const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+  const unsigned gx = (unsigned)((M + rpb - 1) / rpb);
+  // column groups only where the output is much wider than the input (N >= 4K: the GEGLU projections) and the row
+  // blocks alone are at most one per CU (measured: splitting 512 row blocks of the 16384-row site costs 15 %);
+  // ~1024 workgroups in total
+  int ny = 1;
+  if (N >= 4 * K && gx <= 256) ny = (int)std::min<int64_t>(std::max<int64_t>(1, 1024 / gx), (N + 1023) / 1024);
+  int cols_per_y = (((N + ny - 1) / ny) + 7) & ~7;
+  ny = (N + cols_per_y - 1) / cols_per_y;
+  if (nt > cols_per_y) nt = cols_per_y;
+  const dim3 grid(gx, (unsigned)ny);
   hipStream_t st = (hipStream_t)stream;
   const bool drop = dropout_p > 0.f;
 #define FW(E, RTV, D)                                                                                          \
-  hipLaunchKernelGGL((linear_fwd_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                             \
+  hipLaunchKernelGGL((linear_fwd_kernel<E, RTV, D>), grid, dim3(kFT), 0, st,                                   \
                      reinterpret_cast<const typename E::storage *>(x), ldx, reinterpret_cast<typename E::storage *>(y), \
-                     ldy, down, up, factor_dtype, t_out, M, K, N, r, kt, nt, logL, (int)rpb, scale, sel, dropout_p, \
-                     seed, offset)
+                     ldy, down, up, factor_dtype, t_out, M, K, N, r, kt, nt, cols_per_y, logL, (int)rpb, scale, sel, \
+                     dropout_p, seed, offset)
 #define FW_RT(E, D) do { if (RT == 4) FW(E, 4, D); else if (RT == 8) FW(E, 8, D); else FW(E, 16, D); } while (0)
 #define FW_E(E) do { if (drop) FW_RT(E, true); else FW_RT(E, false); } while (0)
   switch (act_dtype) {
