@@ -68,12 +68,14 @@ def merge_roofline(unet, iters=30):
         plan.launch(1.0)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    inner = 4  # back-to-back launches per event pair: the host's launch cost is not what is measured
     for a, b in evs:
         a.record()
-        plan.launch(1.0)
+        for _ in range(inner):
+            plan.launch(1.0)
         b.record()
     torch.cuda.synchronize()
-    avg_s = sum(a.elapsed_time(b) for a, b in evs) / iters * 1e-3
+    avg_s = sum(a.elapsed_time(b) for a, b in evs) / (iters * inner) * 1e-3
     ach = plan.bytes_algorithmic / avg_s / 1e9
     traffic, traffic_src = None, None
     pmc = os.path.join(REPO, "profiles", "r01_merge_pmc.json")  # offline rocprofv3 --pmc passes (scripts/profile_bench.sh)
@@ -88,7 +90,7 @@ def merge_roofline(unet, iters=30):
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": plan.bytes_algorithmic, "avg_launch_us": round(avg_s * 1e6, 2),
-            "launches_timed": iters}
+            "launches_timed": iters * inner}
 
 
 def usable_cores() -> int:

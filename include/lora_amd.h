@@ -99,7 +99,8 @@ int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev, int32_t n_sites
                            int32_t rounding, void *stream);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
- * target elements per tile and resident workgroups per CU. */
+ * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100
+ * means "blocks_per_cu - 100, with non-temporal W loads/stores" (the default), < 100 turns them off (A/B runs). */
 int lora_amd_merge_set_tuning(int64_t tile_elems, int64_t blocks_per_cu);
 
 /* ------------------------------------------------------------------------

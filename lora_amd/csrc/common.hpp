@@ -73,6 +73,25 @@ __device__ inline void store8(typename E::storage *p, const float (&in)[8]) {
   *reinterpret_cast<Chunk8<E> *>(p) = c;
 }
 
+// Non-temporal variants for data that is streamed exactly once (the merge's W): the lines are not kept in L2/MALL
+// ahead of data other kernels will re-use.
+template <class E>
+__device__ inline void load8_nt(const typename E::storage *p, float (&out)[8]) {
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  union { V v; Chunk8<E> c; } u;
+  u.v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = E::to_f(u.c.v[i]);
+}
+template <class E>
+__device__ inline void store8_nt(typename E::storage *p, const float (&in)[8]) {
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  union { V v; Chunk8<E> c; } u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u.c.v[i] = E::from_f(in[i]);
+  __builtin_nontemporal_store(u.v, reinterpret_cast<V *>(p));
+}
+
 // Round an f32 value to E's precision and back (used to reproduce torch's
 // per-op rounding in the merge kernel).
 template <class E>

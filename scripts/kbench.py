@@ -58,7 +58,7 @@ def merge_plan(qkvo_only=False, r=4, wdt=torch.bfloat16, abdt=torch.float32, inp
 def bench_merge(args):
     out = []
     for qkvo in (False, True):
-        for tile, bpc in ((32768, 4), (16384, 4), (65536, 4), (131072, 4), (8192, 4)):
+        for tile, bpc in ((16384, 4), (16384, 104), (32768, 4), (32768, 104), (8192, 104)):
             _C.merge_set_tuning(tile, bpc)
             plan = merge_plan(qkvo)
             med, best = timeit(lambda: plan.launch(0.7), iters=args.iters)
@@ -67,7 +67,7 @@ def bench_merge(args):
                             tiles=plan.total_tiles, MB=plan.bytes_algorithmic / 1e6, us=med * 1e6, best_us=best * 1e6,
                             GBs=gbs, frac8=gbs / 8000))
             print(json.dumps(out[-1]), flush=True)
-    _C.merge_set_tuning(16384, 4)
+    _C.merge_set_tuning(16384, 104)
     # plain device copy of the same bytes as a ceiling reference
     n = int(385e6 / 2)
     a = torch.empty(n, dtype=torch.bfloat16, device=DEV)
