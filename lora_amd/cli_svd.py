@@ -46,7 +46,7 @@ def _fix_signs(U: torch.Tensor, Vh: torch.Tensor) -> Tuple[torch.Tensor, torch.T
     return U * sgn[None, :], Vh * sgn[:, None]
 
 
-def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 3,
+def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 4,
              generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Top-``rank`` singular triplets (U [N,r], S [r], Vh [r,K]) of a 2-D f32 matrix.
 
