@@ -9,5 +9,6 @@ from .lora import (  # noqa: F401  (underscore names the reference's CLIs import
     _find_modules, _find_modules_v2, _find_children, _text_lora_path, _ti_lora_path,
 )
 from . import _C  # noqa: F401
+from .lora_manager import DummySafeTensorObject, LoRAManager, lora_join  # noqa: F401  (reference __init__.py:3)
 
 __version__ = "0.1.0"
