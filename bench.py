@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--rank", type=int, default=4, dest="lora_rank")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--channels-last", type=int, default=0, help="NHWC activations/conv weights (MIOpen igemm layout)")
+    ap.add_argument("--conv-find", type=int, default=0, help="torch.backends.cudnn.benchmark: MIOpen Find picks the "
+                    "frozen convs' kernels by timing them once (slow first step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -177,6 +179,7 @@ def main():
         return cpu_worker(args.cpu_worker)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.backends.cudnn.benchmark = bool(args.conv_find)
     _C.require()
     rank, local, world = T.init_distributed("cuda")
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
