@@ -190,6 +190,16 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
                           int32_t nct_g, const void *down, const float *sel, float *down_part, int64_t M,
                           int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype, void *stream);
 
+/* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, T = X down^T also
+ * written to t_out (f32 [M,r]) for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch of
+ * lora.py:53-58 (no dropout, no selector: those keep lora_amd_linear_fwd).  bf16/f16 X, W, bias, Y; f32 factors
+ * (down [r,K], up [N,r]); K % 64 == 0, N % 8 == 0, r <= 16, 16-byte-aligned rows.  `tile`: 0 = pick by grid size,
+ * 1 = 64x320, 2 = 64x160, 3 = 32x160 output tile per workgroup. */
+int lora_amd_linear_gemm_supported(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype);
+int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *w, int64_t ldw, const void *bias, void *y,
+                             int64_t ldy, const float *down, const float *up, float *t_out, int64_t M, int32_t K,
+                             int32_t N, int32_t r, int32_t act_dtype, float scale, int32_t tile, void *stream);
+
 /* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
  * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient
  * buffer once per step.  `begin` = exclusive prefix sum of r*C over the table; total = its end. */

@@ -30,7 +30,7 @@ SYMBOLS = (
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
-    "lora_amd_reduce_batched",
+    "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance",
@@ -110,6 +110,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp]
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
+    lib.lora_amd_linear_gemm_supported.argtypes = [i64, i32, i32, i32, i32]
+    lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp]
+    lib.lora_amd_linear_gemm_supported.restype = lib.lora_amd_linear_gemm_fwd.restype = C.c_int
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp]
@@ -493,3 +496,72 @@ def conv_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt: torch.Tensor, do
     _check(require().lora_amd_conv_bwd_x(x.data_ptr(), _ptr(dx), gt.data_ptr(), down.data_ptr(),
                                          down_part.data_ptr(), B, Ci, H, W, ks, down.shape[0], dtype_code(x.dtype),
                                          dtype_code(down.dtype), _stream()), "lora_amd_conv_bwd_x")
+
+
+# ----------------------------------------------------------------------------- K1 fully fused (MFMA GEMM + LoRA)
+def gemm_supported(x: torch.Tensor, weight: torch.Tensor, y_cols: int, r: int) -> bool:
+    return (x.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x.dtype and weight.is_contiguous()
+            and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and weight.data_ptr() % 16 == 0
+            and bool(require().lora_amd_linear_gemm_supported(x.shape[0], x.shape[1], y_cols, r, dtype_code(x.dtype))))
+
+
+def linear_gemm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
+                    up: torch.Tensor, scale: float, tile: int = 0):
+    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch."""
+    M, K = x.shape
+    N, r = weight.shape[0], down.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    t = torch.empty((M, r), dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_linear_gemm_fwd(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
+                                              _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(), up.data_ptr(),
+                                              t.data_ptr(), M, K, N, r, dtype_code(x.dtype), float(scale), int(tile),
+                                              _stream()), "lora_amd_linear_gemm_fwd")
+    return y, t
+
+
+_gemm_choice = {}
+GEMM_TILES = (22, 23, 24, 21)  # stages*10 + shape (see lora_amd_linear_gemm_fwd)
+
+
+def gemm_choice(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
+                up: torch.Tensor, scale: float) -> int:
+    """Which forward runs this (M, K, N, r, dtype) site: 0 = library GEMM + ``linear_fwd`` (two launches), else the tile
+    code of the fully fused MFMA kernel.  Decided ONCE per shape by timing both on the live tensors (never inside a
+    hipGraph capture: there the answer is the cached one, or 0).  ``LORA_AMD_GEMM=0`` pins the two-launch path,
+    ``LORA_AMD_GEMM=<tile>`` pins a tile."""
+    env = os.environ.get("LORA_AMD_GEMM")
+    if env is not None:
+        return int(env)
+    key = (x.shape[0], x.shape[1], weight.shape[0], down.shape[0], x.dtype, bias is not None)
+    c = _gemm_choice.get(key)
+    if c is not None:
+        return c
+    if torch.cuda.is_current_stream_capturing():
+        return 0
+    import torch.nn.functional as F
+
+    def run(tile):
+        if tile == 0:
+            y = F.linear(x, weight, bias)
+            linear_fwd_(x, y, down, up, scale, None, 0.0, 0, 0)
+        else:
+            linear_gemm_fwd(x, weight, bias, down, up, scale, tile)
+
+    best, best_t = 0, float("inf")
+    fused0 = fused_ok(x, weight.shape[0], down.shape[0])
+    for tile in ((0,) if fused0 else ()) + GEMM_TILES:
+        for _ in range(2):
+            run(tile)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            run(tile)
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b)
+        if t < best_t:
+            best, best_t = tile, t
+    _gemm_choice[key] = best
+    return best

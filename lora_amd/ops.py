@@ -116,17 +116,26 @@ class LoraLinearFunction(torch.autograd.Function):
         N, K = weight.shape
         r = down.shape[0]
         x2 = _rows2d(x, K)
-        y = F.linear(x2, weight, bias)  # frozen dense GEMM (MFMA, hipBLASLt)
         seed = off = 0
         if dropout_p > 0.0:
             seed, off = next_dropout_stream()
         down_c, up_c = down.contiguous(), up.contiguous()
-        fused = down_c.dtype == up_c.dtype and _C.fused_ok(x2, N, r) and _C._rows_ok(y)
-        if fused:
-            t = _C.linear_fwd_(x2, y, down_c, up_c, scale, sel, dropout_p, seed, off)
+        tile = 0
+        if (dropout_p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
+                and _C.gemm_supported(x2, weight, N, r)):
+            # ONE launch on the matrix cores (frozen GEMM + low-rank branch) where that measured faster for this shape
+            tile = _C.gemm_choice(x2, weight, bias, down_c, up_c, scale)
+        if tile:
+            y, t = _C.linear_gemm_fwd(x2, weight, bias, down_c, up_c, scale, tile)
+            fused = _C.fused_ok(x2, N, r)
         else:
-            t = _C.rowdot(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
-            _C.rank_update_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
+            y = F.linear(x2, weight, bias)  # frozen dense GEMM (MFMA, hipBLASLt)
+            fused = down_c.dtype == up_c.dtype and _C.fused_ok(x2, N, r) and _C._rows_ok(y)
+            if fused:
+                t = _C.linear_fwd_(x2, y, down_c, up_c, scale, sel, dropout_p, seed, off)
+            else:
+                t = _C.rowdot(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
+                _C.rank_update_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
         ctx.save_for_backward(x2, weight, down, up, t, sel)
         ctx.scale, ctx.p, ctx.seed, ctx.off = float(scale), float(dropout_p), seed, off
         ctx.has_bias, ctx.x_shape, ctx.sink, ctx.fused = bias is not None, x.shape, sink, fused

@@ -105,6 +105,21 @@ def bench_linear(args):
         res["bwd_g_us"], res["bwd_g_GBs"] = med * 1e6, (M * N * 2) / med / 1e9
         med, _ = timeit(lambda: _C.linear_bwd_x(x, dx, gt_part, plan.nct_g, A, None, down_part), args.iters)
         res["bwd_x_us"], res["bwd_x_GBs"] = med * 1e6, (3 * M * K * 2) / med / 1e9
+        # K1 fully fused (one MFMA kernel: frozen GEMM + LoRA branch) per output-tile choice
+        Wf = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV).to(torch.bfloat16)
+        if _C.gemm_supported(x, Wf, N, r):
+            tiles = (21, 22, 23, 24, 31, 32, 33, 34)
+            for tile in tiles:
+                med, _ = timeit(lambda: _C.linear_gemm_fwd(x, Wf, bias, A, B, 1e-3, tile), args.iters)
+                res[f"gemm_fused_t{tile}_us"] = med * 1e6
+            best = min(res[f"gemm_fused_t{t}_us"] for t in tiles)
+            res["gemm_fused_best_us"] = best
+            res["gemm_fused_TF"] = 2 * M * K * N / best / 1e6
+            res["gemm_fused_GBs"] = (M * K + N * K + M * N) * 2 / best / 1e3
+        med, _ = timeit(lambda: _C.linear_fwd_(x, torch.nn.functional.linear(x, Wf, bias), A, B, 1e-3, None, 0.0, 0, 0),
+                        args.iters)
+        res["gemm_plus_lora_us"] = med * 1e6
         # what the reference's op sequence costs on the same device (5 ATen launches)
         W = torch.randn(N, K, device=DEV).to(torch.bfloat16)
         Ab, Bb = A.to(torch.bfloat16), B.to(torch.bfloat16)

@@ -707,3 +707,28 @@ def test_training_steps_extended_injection_device_vs_cpu(extended):
         st_d.step(st_d.all_reduce())
     # AdamW normalises the update: where a gradient is ~0 its sign decides +-lr, so allow 15 % of the 2*lr bound
     np.testing.assert_allclose(n(st_d.flat_p), st_c.flat_p.numpy(), rtol=2e-3, atol=3e-4)
+
+
+# ----------------------------------------------------------------------------- K1 fully fused MFMA GEMM + LoRA (gemm_fused.hip)
+GEMM_SHAPES = [(16384, 320, 320, 4), (4096, 640, 640, 4), (1024, 1280, 1280, 8), (308, 768, 320, 4), (256, 1280, 10240, 4),
+               (1000, 320, 2560, 16), (77, 64, 24, 3), (130, 768, 768, 1)]
+
+
+@pytest.mark.parametrize("M,K,N,r", GEMM_SHAPES)
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("tile", [0, 21, 22, 23, 24, 31, 32, 33, 34])
+def test_fused_gemm_matches_oracle(M, K, N, r, dt, tile):
+    """Y = X W^T + b + s (X down^T) up^T and T through lora_amd_linear_gemm_fwd vs the numpy oracle (asymmetric
+    operands: a transposed tile or fragment would not pass).  Tolerance: f32-accumulated 16-bit products, one output
+    rounding, plus the reference-faithful rounding of T to the activation dtype before the up-projection."""
+    x, w = rnd((M, K), dt, 1.0, seed=1), rnd((N, K), dt, 0.05, seed=2)
+    b = rnd((N,), dt, 0.5, seed=3)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
+    y, t = _C.linear_gemm_fwd(x, w, b, down, up, 0.7, tile)
+    X, W, Bv, A, U = n(x), n(w), n(b), n(down), n(up)  # `down` enters at f32 precision (hi + lo split)
+    t_ref = X @ A.T
+    close(n(t), t_ref, np.abs(X) @ np.abs(A).T, "f32", k=3e-5, msg="T")
+    U16 = O.round_to(0.7 * U, dt)
+    y_ref = X @ W.T + Bv + O.round_to(t_ref, dt) @ U16.T
+    absref = np.abs(X) @ np.abs(W).T + np.abs(Bv) + np.abs(t_ref) @ np.abs(U16).T
+    close(n(y), y_ref, absref, dt, k=2e-3 if dt == "bf16" else 3e-4, msg="Y")
