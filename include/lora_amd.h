@@ -178,7 +178,7 @@ int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, const 
                         float dropout_p, uint64_t seed, uint64_t offset, void *stream);
 
 /* One pass over G[M,N]: gt_part[nct_g][M][r] = scale * (mask*G) @ up (per column tile) and
- * up_part[nparts_up][RT][N] = scale * (mask*G)^T @ T (per row block). */
+ * up_part[nparts_up][RT][N] = scale * (mask*G)^T @ T (per row block).  gt_part may be NULL (dUp partials only). */
 int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
                           float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
                           int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
@@ -190,15 +190,21 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
                           int32_t nct_g, const void *down, const float *sel, float *down_part, int64_t M,
                           int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype, void *stream);
 
-/* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, T = X down^T also
- * written to t_out (f32 [M,r]) for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch of
- * lora.py:53-58 (no dropout, no selector: those keep lora_amd_linear_fwd).  bf16/f16 X, W, bias, Y; f32 factors
- * (down [r,K], up [N,r]); K % 64 == 0, N % 8 == 0, r <= 16, 16-byte-aligned rows.  `tile`: 0 = pick by grid size,
- * 1 = 64x320, 2 = 64x160, 3 = 32x160 output tile per workgroup. */
+/* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, and
+ * t_out[M,r] (f32) = t_scale * X down^T for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch
+ * of lora.py:53-58 (no dropout, no selector: those keep lora_amd_linear_fwd).  bf16/f16 X, W, bias, Y; f32 factors;
+ * K % 64 == 0, N % 8 == 0, r <= 16, 16-byte-aligned rows.
+ * factor_layout: bit 0 set = `down` is stored [K, r] instead of [r, K]; bit 1 set = `up` is stored [r, N] instead of
+ * [N, r].  With both set the SAME entry point computes the input gradient of the site,
+ *     dX[M,K] = G[M,N] W[N,K] + scale * (G up) down,   Gt = scale * G up,
+ * when called as (x = G, w = W^T [K,N], y = dX, down = up [N,r], up = down [r,K], K <-> N swapped, t_scale = scale).
+ * tile = 10 * stages + shape (shape 1: 64x320, 2: 64x160, 3: 32x160, 4: 128x160 outputs per workgroup; stages 2|3 LDS
+ * ring slots); 0 = pick by grid size. */
 int lora_amd_linear_gemm_supported(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype);
 int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *w, int64_t ldw, const void *bias, void *y,
                              int64_t ldy, const float *down, const float *up, float *t_out, int64_t M, int32_t K,
-                             int32_t N, int32_t r, int32_t act_dtype, float scale, int32_t tile, void *stream);
+                             int32_t N, int32_t r, int32_t act_dtype, float scale, float t_scale,
+                             int32_t factor_layout, int32_t tile, void *stream);
 
 /* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
  * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient

@@ -111,7 +111,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
     lib.lora_amd_linear_gemm_supported.argtypes = [i64, i32, i32, i32, i32]
-    lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp]
+    lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32,
+                                             i32, vp]
     lib.lora_amd_linear_gemm_supported.restype = lib.lora_amd_linear_gemm_fwd.restype = C.c_int
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -406,10 +407,11 @@ def linear_fwd_(x: torch.Tensor, y: torch.Tensor, down: torch.Tensor, up: torch.
     return t
 
 
-def linear_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, gt_part: torch.Tensor, up_part: torch.Tensor,
-                 scale: float, dropout_p: float, seed: int, offset: int) -> None:
+def linear_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, gt_part: Optional[torch.Tensor],
+                 up_part: torch.Tensor, scale: float, dropout_p: float, seed: int, offset: int) -> None:
+    """``gt_part`` None: dUp partials only."""
     M, N = g.shape
-    _check(require().lora_amd_linear_bwd_g(g.data_ptr(), g.stride(0), t.data_ptr(), up.data_ptr(), gt_part.data_ptr(),
+    _check(require().lora_amd_linear_bwd_g(g.data_ptr(), g.stride(0), t.data_ptr(), up.data_ptr(), _ptr(gt_part),
                                            up_part.data_ptr(), M, N, t.shape[1], dtype_code(g.dtype),
                                            dtype_code(up.dtype), float(scale), float(dropout_p), int(seed),
                                            int(offset), _stream()), "lora_amd_linear_bwd_g")
@@ -507,17 +509,26 @@ def gemm_supported(x: torch.Tensor, weight: torch.Tensor, y_cols: int, r: int) -
 
 
 def linear_gemm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
-                    up: torch.Tensor, scale: float, tile: int = 0):
-    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch."""
+                    up: torch.Tensor, scale: float, tile: int = 0, t_scale: float = 1.0, factor_layout: int = 0):
+    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch (see include/lora_amd.h)."""
     M, K = x.shape
-    N, r = weight.shape[0], down.shape[0]
+    N = weight.shape[0]
+    r = down.shape[1] if factor_layout & 1 else down.shape[0]
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x.device)
     _check(require().lora_amd_linear_gemm_fwd(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
                                               _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(), up.data_ptr(),
-                                              t.data_ptr(), M, K, N, r, dtype_code(x.dtype), float(scale), int(tile),
-                                              _stream()), "lora_amd_linear_gemm_fwd")
+                                              t.data_ptr(), M, K, N, r, dtype_code(x.dtype), float(scale),
+                                              float(t_scale), int(factor_layout), int(tile), _stream()),
+           "lora_amd_linear_gemm_fwd")
     return y, t
+
+
+def linear_gemm_dx(g: torch.Tensor, weight_t: torch.Tensor, down: torch.Tensor, up: torch.Tensor, scale: float,
+                   tile: int = 0):
+    """(dX [M,K], Gt [M,r] f32): dX = G W + scale (G up) down, Gt = scale G up, ONE launch of the same MFMA kernel on
+    the resident transposed weight ``weight_t`` [K, N] (factors read in place: up [N,r] k-major, down [r,K])."""
+    return linear_gemm_fwd(g, weight_t, None, up, down, scale, tile, t_scale=scale, factor_layout=3)
 
 
 _gemm_choice = {}
@@ -564,4 +575,71 @@ def gemm_choice(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         if t < best_t:
             best, best_t = tile, t
     _gemm_choice[key] = best
+    return best
+
+
+_wt_cache = {}
+
+
+def weight_t(weight: torch.Tensor) -> torch.Tensor:
+    """Resident transposed copy [K, N] of a frozen [N, K] weight (the fused dX kernel contracts over N and wants it
+    contiguous); built once per (storage, version) — frozen weights do not change during training, 288 GB of HBM make
+    the second layout of the adapted sites (385 MB for the SD1.5 UNet) a non-issue."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape))
+    wt = _wt_cache.get(key)
+    if wt is None:
+        if len(_wt_cache) > 4096:
+            _wt_cache.clear()
+        wt = weight.detach().t().contiguous()
+        _wt_cache[key] = wt
+    return wt
+
+
+_gemm_choice_bwd = {}
+
+
+def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: torch.Tensor, down: torch.Tensor,
+                    up: torch.Tensor, scale: float, bufs) -> int:
+    """As :func:`gemm_choice` for the backward of a site: 0 = G pass + library GEMM + X/dX pass, else the tile of the
+    fused MFMA dX kernel (then: fused dX/Gt launch + dUp-only G pass + dDown-only X pass)."""
+    env = os.environ.get("LORA_AMD_GEMM_BWD", os.environ.get("LORA_AMD_GEMM"))
+    if env is not None:
+        return int(env)
+    M, N = g.shape
+    K, r = x.shape[1], down.shape[0]
+    key = (M, K, N, r, g.dtype)
+    c = _gemm_choice_bwd.get(key)
+    if c is not None:
+        return c
+    if torch.cuda.is_current_stream_capturing():
+        return 0
+    gt_part, up_part, down_part = bufs
+    plan = linear_plan(M, K, N, r)
+    wt = weight_t(weight)
+
+    def run(tile):
+        if tile == 0:
+            linear_bwd_g(g, t, up, gt_part, up_part, scale, 0.0, 0, 0)
+            dx = g @ weight
+            linear_bwd_x(x, dx, gt_part, plan.nct_g, down, None, down_part)
+        else:
+            dx, gt = linear_gemm_dx(g, wt, down, up, scale, tile)
+            linear_bwd_g(g, t, up, None, up_part, scale, 0.0, 0, 0)
+            linear_bwd_x(x, None, gt, 1, down, None, down_part)
+
+    best, best_t = 0, float("inf")
+    for tile in (0,) + GEMM_TILES:
+        for _ in range(2):
+            run(tile)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            run(tile)
+        b.record()
+        torch.cuda.synchronize()
+        tt = a.elapsed_time(b)
+        if tt < best_t:
+            best, best_t = tile, tt
+    _gemm_choice_bwd[key] = best
     return best

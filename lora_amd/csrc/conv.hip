@@ -31,12 +31,6 @@ namespace lora_amd {
 
 constexpr int kCT = 256;  // 4 waves
 
-__device__ inline float cld(const void *p, int dt, int64_t i) {
-  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
-  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
-  return (float)reinterpret_cast<const __bf16 *>(p)[i];
-}
-
 struct ChunkPos {
   bool act;
   int b, p0, y, x0;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
     const typename E::storage *__restrict__ x, int64_t ldx, const typename E::storage *__restrict__ w, int64_t ldw,
     const typename E::storage *__restrict__ bias, typename E::storage *__restrict__ y, int64_t ldy,
     const float *__restrict__ down, const float *__restrict__ up, float *__restrict__ t_out, int64_t M, int K, int N,
-    int r, float scale) {
+    int r, float scale, float t_scale, int flayout) {
   using S = typename E::storage;
   using F = typename MfmaT<E>::frag;
   constexpr int BM = 32 * RS, BN = 32 * CS;
@@ -127,15 +127,23 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
 
   // one step's slabs -> ring slot: X rows, W rows, and 4 rank rows of `down` per wave (f32, 16-byte chunks swizzled by
   // the rank; ranks past r re-read row r-1 and are zeroed when the fragment is built)
+  // flayout bit 0: `down` is given as [K, r] (k-major): the 64 x r block of a step is one contiguous run, DMA'd
+  // linearly ([k][r] in LDS, scalar fragment reads); else [r, K]: 4 rank rows per wave, 16-byte chunks swizzled by rank.
+  // flayout bit 1: `up` is given as [r, N].  (The backward dX = G W + (G up) down reuses this kernel on W^T with
+  // down' = up [N,r] read k-major and up' = down [r,K]: no transposed factor copies.)
+  const bool dn_kr = flayout & 1, up_rk = flayout & 2;
   const int dn_w = wave < RG ? wave : 0;  // waves past the rank groups re-stage group 0 (keeps L uniform per wave)
   const int dn_rank = min(dn_w * 4 + (lane >> 4), r - 1);
-  const float *dn_src = down + (int64_t)dn_rank * K + (((lane & 15) ^ ((dn_w * 4 + (lane >> 4)) & 15)) << 2);
+  const int kr_chunk = min(dn_w * 64 + lane, 16 * r - 1);  // 16-byte chunk of the contiguous 64*r*4-byte block
+  const float *dn_src = dn_kr ? down + (kr_chunk << 2)
+                              : down + (int64_t)dn_rank * K + (((lane & 15) ^ ((dn_w * 4 + (lane >> 4)) & 15)) << 2);
+  const int64_t dn_step = dn_kr ? (int64_t)kBK * r : kBK;
 #define ISSUE(step, slot)                                                               \
   do {                                                                                  \
     char *xs_ = smem + (slot) * SB, *ws_ = xs_ + XB, *ds_ = ws_ + WB;                   \
     stage_slab<S>(x, ldx, m0, M, (step) * kBK, xs_, BM, wave, lane);                    \
     stage_slab<S>(w, ldw, n0, N, (step) * kBK, ws_, BN, wave, lane);                    \
-    glds16(dn_src + (step) * kBK, ds_ + dn_w * 1024);                                   \
+    glds16(dn_src + (step) * dn_step, ds_ + dn_w * 1024);                               \
   } while (0)
 
 #pragma unroll
@@ -150,7 +158,14 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
     const int n = n0 + (wn * CS + j) * 16 + l15;
     const int nc = n < N ? n : N - 1;  // clamped addresses, branch-free loads (all in flight together), then select
     float uv[8];
-    if ((r & 3) == 0) {  // whole 16-byte groups of ranks: r = 4 -> one load in lane group 0, r = 16 -> two in groups 0, 1
+    if (up_rk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rank = lg * 8 + e;
+        const float v = up[(int64_t)(rank < r ? rank : r - 1) * N + nc];
+        uv[e] = (rank < r && n < N) ? scale * v : 0.f;
+      }
+    } else if ((r & 3) == 0) {  // whole 16-byte groups of ranks: r = 4 -> one load in lane group 0, r = 16 -> two in groups 0, 1
       const int g0 = lg * 8 < r ? lg * 8 : 0, g1 = lg * 8 + 4 < r ? lg * 8 + 4 : 0;
       const float4 a = *reinterpret_cast<const float4 *>(up + (int64_t)nc * r + g0);
       const float4 b = *reinterpret_cast<const float4 *>(up + (int64_t)nc * r + g1);
@@ -189,12 +204,22 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < CS; ++j) acc[i][j] = MfmaT<E>::mma(a[i], b[j], acc[i][j]);
       if (t_owner) {
-        const int c0 = ks * 8 + lg * 2;
-        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(ds + l15 * 256 + (((c0) ^ l15) << 4));
-        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(ds + l15 * 256 + (((c0 + 1) ^ l15) << 4));
         const bool live = l15 < r;
-        const float dv[8] = {live ? p0[0] : 0.f, live ? p0[1] : 0.f, live ? p0[2] : 0.f, live ? p0[3] : 0.f,
-                             live ? p1[0] : 0.f, live ? p1[1] : 0.f, live ? p1[2] : 0.f, live ? p1[3] : 0.f};
+        float dv[8];
+        if (dn_kr) {
+          const int jc = live ? l15 : r - 1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = *reinterpret_cast<const float *>(ds + (((ks * 32 + lg * 8 + e) * r + jc) << 2));
+            dv[e] = live ? v : 0.f;
+          }
+        } else {
+          const int c0 = ks * 8 + lg * 2;
+          const f32x4 p0 = *reinterpret_cast<const f32x4 *>(ds + l15 * 256 + (((c0) ^ l15) << 4));
+          const f32x4 p1 = *reinterpret_cast<const f32x4 *>(ds + l15 * 256 + (((c0 + 1) ^ l15) << 4));
+          dv[0] = live ? p0[0] : 0.f; dv[1] = live ? p0[1] : 0.f; dv[2] = live ? p0[2] : 0.f; dv[3] = live ? p0[3] : 0.f;
+          dv[4] = live ? p1[0] : 0.f; dv[5] = live ? p1[1] : 0.f; dv[6] = live ? p1[2] : 0.f; dv[7] = live ? p1[3] : 0.f;
+        }
         // the f32 master factor enters as hi + lo 16-bit parts (two MFMAs): T keeps the precision of the two-launch
         // path (f32 factors) instead of rounding `down` to the activation dtype
         float dl[8];
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
       for (int i = 0; i < 4; ++i) {
         const int rl = row_base + i;
         reinterpret_cast<S *>(ts)[rl * 16 + l15] = E::from_f(tacc[q][i]);
-        if (blockIdx.x == 0 && l15 < r && m0 + rl < M) t_out[(m0 + rl) * r + l15] = tacc[q][i];
+        if (blockIdx.x == 0 && l15 < r && m0 + rl < M) t_out[(m0 + rl) * r + l15] = t_scale * tacc[q][i];
       }
     }
   }
@@ -280,7 +305,7 @@ extern "C" int lora_amd_linear_gemm_supported(int64_t M, int32_t K, int32_t N, i
 extern "C" int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *w, int64_t ldw, const void *bias,
                                         void *y, int64_t ldy, const float *down, const float *up, float *t_out,
                                         int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
-                                        int32_t tile, void *stream) {
+                                        float t_scale, int32_t factor_layout, int32_t tile, void *stream) {
   LORA_AMD_CHECK(lora_amd_linear_gemm_supported(M, K, N, r, act_dtype), LORA_AMD_EINVAL,
                  "linear_gemm_fwd: needs bf16/f16 activations, K %% 64 == 0, N %% 8 == 0, rank <= 16");
   LORA_AMD_CHECK(x && w && y && down && up && t_out, LORA_AMD_EINVAL, "linear_gemm_fwd: null pointer");
@@ -303,7 +328,7 @@ extern "C" int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *
                      dim3(kGT), 0, st, reinterpret_cast<const typename E::storage *>(x), ldx,                      \
                      reinterpret_cast<const typename E::storage *>(w), ldw,                                        \
                      reinterpret_cast<const typename E::storage *>(bias), reinterpret_cast<typename E::storage *>(y), \
-                     ldy, down, up, t_out, M, K, N, r, scale)
+                     ldy, down, up, t_out, M, K, N, r, scale, t_scale, factor_layout)
 #define GF_R(E, RSV, CSV, NSV) do { if (rg == 1) GF(E, RSV, CSV, NSV, 1); else GF(E, RSV, CSV, NSV, 4); } while (0)
 #define GF_S(E, RSV, CSV) do { if (stages == 3) GF_R(E, RSV, CSV, 3); else GF_R(E, RSV, CSV, 2); } while (0)
 #define GF_T(E)                                                                        \

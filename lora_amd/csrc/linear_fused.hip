@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
 
   constexpr int U = 4;
+  const bool want_gt = gt_part != nullptr;  // nullptr: dUp partials only (Gt came out of the fused MFMA dX kernel)
   float *gtp = gt_part + (int64_t)ct * M * r;
   // every lane of a wave runs the same trip count (shuffles below): bound by the first slot's rows
   for (int rb0 = 0; rb0 < nrows; rb0 += nslots * U) {
@@ -409,19 +410,23 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
           dot[j] = d;
         }
       }
+      if (want_gt) {
 #pragma unroll
-      for (int jb = 0; jb < RT; jb += 4) {  // ct8 >= 4 lanes per row segment (plan): butterfly, 5..7 cross-lane ops
-        const float tot = group_sum4(dot[jb], dot[(jb + 1) % RT], dot[(jb + 2) % RT], dot[(jb + 3) % RT], tid, log_ct8);
-        const int j = jb + idx4(cl);
-        if (live && cl < 4) s_gt[rl * RT + j] = scale * tot;
+        for (int jb = 0; jb < RT; jb += 4) {  // ct8 >= 4 lanes per row segment (plan): butterfly, 5..7 cross-lane ops
+          const float tot =
+              group_sum4(dot[jb], dot[(jb + 1) % RT], dot[(jb + 2) % RT], dot[(jb + 3) % RT], tid, log_ct8);
+          const int j = jb + idx4(cl);
+          if (live && cl < 4) s_gt[rl * RT + j] = scale * tot;
+        }
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < nrows * r; i += kFT) {  // contiguous [nrows][r] run of gt_part
-    const int rl = i / r, j = i - rl * r;
-    gtp[m0 * r + i] = s_gt[rl * RT + j];
-  }
+  if (want_gt)
+    for (int i = tid; i < nrows * r; i += kFT) {  // contiguous [nrows][r] run of gt_part
+      const int rl = i / r, j = i - rl * r;
+      gtp[m0 * r + i] = s_gt[rl * RT + j];
+    }
   slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, up_part + (int64_t)rb * RT * N, N, ct * ct8 * 8);
 }
 
@@ -435,7 +440,6 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
     int rows_per_block) {
   __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
-  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];  // this block's Gt rows, stored once at the end
   const int tid = threadIdx.x;
   const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
   const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
@@ -644,7 +648,7 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
                                      int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
                                      uint64_t offset, void *stream) {
   FUSED_COMMON("linear_bwd_g", act_dtype, factor_dtype);
-  LORA_AMD_CHECK(g && t && up && gt_part && up_part, LORA_AMD_EINVAL, "linear_bwd_g: null pointer");
+  LORA_AMD_CHECK(g && t && up && up_part, LORA_AMD_EINVAL, "linear_bwd_g: null pointer");
   LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4, LORA_AMD_EINVAL,
                  "linear_bwd_g: shape/alignment not supported by the fused path (see lora_amd_linear_plan)");
   LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "linear_bwd_g: dropout p=%f", dropout_p);

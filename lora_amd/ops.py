@@ -166,11 +166,22 @@ class LoraLinearFunction(torch.autograd.Function):
                 gt_part, up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
                                                for n in (plan.gt_part_floats, plan.up_part_floats,
                                                          plan.down_part_floats))
-            _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
-            dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM
-            if dx2 is not None and not _C._rows_ok(dx2):
-                dx2 = dx2.contiguous()
-            _C.linear_bwd_x(x2, dx2, gt_part, plan.nct_g, down_c, sel, down_part)
+            tile = 0
+            if (need_x and p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
+                    and weight.is_contiguous() and _C.gemm_supported(g2, _C.weight_t(weight), K, r)):
+                tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
+            if tile:
+                # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch on the resident W^T; the two light passes
+                # that remain only produce the parameter-gradient partials
+                dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
+                _C.linear_bwd_g(g2, t, up_c, None, up_part, s, 0.0, 0, 0)
+                _C.linear_bwd_x(x2, None, gt, 1, down_c, None, down_part)
+            else:
+                _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
+                dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM
+                if dx2 is not None and not _C._rows_ok(dx2):
+                    dx2 = dx2.contiguous()
+                _C.linear_bwd_x(x2, dx2, gt_part, plan.nct_g, down_c, sel, down_part)
             if need_x:
                 dx = dx2.view(ctx.x_shape)
             if sink is not None:

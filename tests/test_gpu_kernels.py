@@ -732,3 +732,35 @@ def test_fused_gemm_matches_oracle(M, K, N, r, dt, tile):
     y_ref = X @ W.T + Bv + O.round_to(t_ref, dt) @ U16.T
     absref = np.abs(X) @ np.abs(W).T + np.abs(Bv) + np.abs(t_ref) @ np.abs(U16).T
     close(n(y), y_ref, absref, dt, k=2e-3 if dt == "bf16" else 3e-4, msg="Y")
+
+
+@pytest.mark.parametrize("M,K,N,r", [(4096, 640, 640, 4), (1000, 320, 2560, 16), (308, 768, 320, 4), (130, 768, 768, 3)])
+@pytest.mark.parametrize("tile", [0, 22, 24, 33])
+def test_fused_gemm_input_gradient(M, K, N, r, tile):
+    """dX = G W + s (G up) down and Gt = s G up through the same MFMA kernel on W^T with the factors read in place
+    (factor_layout 3), then the dUp-only / dDown-only passes: against the oracle's backward."""
+    dt, s = "bf16", 0.6
+    x, g, w = rnd((M, K), dt, 1.0, seed=1), rnd((M, N), dt, 1.0, seed=2), rnd((N, K), dt, 0.05, seed=3)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
+    dx, gt = _C.linear_gemm_dx(g, _C.weight_t(w), down, up, s, tile)
+    G, X, W, A, U = n(g), n(x), n(w), n(down), n(up)
+    gt_ref = s * (G @ U)
+    close(n(gt), gt_ref, s * (np.abs(G) @ np.abs(U)), "f32", k=3e-5, msg="Gt")
+    dx_ref = G @ W + O.round_to(G @ U, dt) @ O.round_to(s * A, dt)
+    close(n(dx), dx_ref, np.abs(G) @ np.abs(W) + np.abs(gt_ref) @ np.abs(A), dt, k=2e-3, msg="dX")
+    # parameter gradients from the two light passes
+    plan = _C.linear_plan(M, K, N, r)
+    if plan.fused:
+        t = torch.from_numpy(X @ A.T).to(DEV)
+        up_part = torch.empty(plan.up_part_floats, device=DEV)
+        down_part = torch.empty(plan.down_part_floats, device=DEV)
+        _C.linear_bwd_g(g, t, up, None, up_part, s, 0.0, 0, 0)
+        _C.linear_bwd_x(x, None, gt, 1, down, None, down_part)
+        d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+        rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+        table, nn_, total = _C.make_reduce_table(rows, DEV)
+        _C.reduce_batched(table, nn_, total)
+        _, ddo, duo, _, _ = O.lora_linear_backward(G, X, W, A, U, s)
+        np.testing.assert_allclose(n(d_up), duo, rtol=1e-3, atol=1e-3 * np.abs(duo).max())
+        np.testing.assert_allclose(n(d_down), ddo, rtol=1e-3, atol=1e-3 * np.abs(ddo).max())
