@@ -32,5 +32,7 @@ def test_gpu_side_code_does_not_read_reference_at_runtime():
 
 def test_required_layout():
     for p in ("include/lora_amd.h", "oracle/lora_numpy.py", "oracle/torch_ref.py", "tests/golden", "profiles",
-              "__graft_entry__.py", "lora_amd/csrc/merge.hip", "lora_amd/csrc/linear.hip", "lora_amd/csrc/optim.hip"):
+              "__graft_entry__.py", "lora_amd/csrc/merge.hip", "lora_amd/csrc/linear.hip", "lora_amd/csrc/optim.hip",
+              "lora_amd/csrc/linear_fused.hip", "lora_amd/csrc/gemm_fused.hip", "lora_amd/csrc/conv.hip", "DESIGN.md",
+              "INTEGRATION.md", "bench.py", "training_scripts/train_lora_dreambooth.py", "lora_amd/cli_lora_pti.py"):
         assert os.path.exists(os.path.join(REPO, p)), p
