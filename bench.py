@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--rank", type=int, default=4, dest="lora_rank")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--channels-last", type=int, default=0, help="NHWC activations/conv weights (MIOpen igemm layout)")
+    ap.add_argument("--extended", type=int, default=0, help="inject_trainable_lora_extended: + ResnetBlock2D Conv2d "
+                    "adapters (BASELINE configs[3] geometry; not the headline workload)")
+    ap.add_argument("--text-encoder", type=int, default=0, help="also train CLIP text-encoder LoRA (configs[2] geometry)")
+    ap.add_argument("--res", type=int, default=512, help="image resolution (latents are res/8)")
     ap.add_argument("--conv-find", type=int, default=0, help="torch.backends.cudnn.benchmark: MIOpen Find picks the "
                     "frozen convs' kernels by timing them once (slow first step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,23 +194,40 @@ def main():
     unet = build_unet(dev, torch.bfloat16, seed=0)
     if args.channels_last:
         unet.to(memory_format=torch.channels_last)
-    L.inject_trainable_lora(unet, r=args.lora_rank)  # reference default: dropout 0, scale 1
+    if args.extended:
+        L.inject_trainable_lora_extended(unet, r=args.lora_rank)  # conv adapters keep the constructor's dropout 0.1
+    else:
+        L.inject_trainable_lora(unet, r=args.lora_rank)  # reference default: dropout 0, scale 1
     T.promote_lora_to_fp32(unet)
     unet.train()
-    state = T.FlatLoraState([{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}], max_grad_norm=1.0,
-                            device=dev)
-    n_sites = state.attach_direct_grads(unet)
+    groups = [{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}]
+    text_encoder = None
+    if args.text_encoder:
+        from lora_amd.standin import clip_text_model
+
+        text_encoder = clip_text_model().to(dev).to(torch.bfloat16)
+        text_encoder.requires_grad_(False)
+        L.inject_trainable_lora(text_encoder, target_replace_module=["CLIPAttention"], r=args.lora_rank)
+        T.promote_lora_to_fp32(text_encoder)
+        text_encoder.train()
+        groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
+    state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
+    n_sites = state.attach_direct_grads(unet, *([text_encoder] if text_encoder is not None else []))
     sched = DDPMScheduler()
     cfg = T.StepConfig()
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank data shard
-    latents = (torch.randn(args.batch, 4, 64, 64, device=dev, generator=g) * 0.18215).to(torch.bfloat16)
+    hw = args.res // 8
+    latents = (torch.randn(args.batch, 4, hw, hw, device=dev, generator=g) * 0.18215).to(torch.bfloat16)
     if args.channels_last:
         latents = latents.contiguous(memory_format=torch.channels_last)
-    ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(torch.bfloat16)
+    if text_encoder is not None:
+        ehs = torch.randint(0, 49408, (args.batch, 77), device=dev, generator=g)
+    else:
+        ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(torch.bfloat16)
 
     def fwd_bwd(lat, cond):
-        return T.forward_backward(unet, sched, lat, cond, cfg)
+        return T.forward_backward(unet, sched, lat, cond, cfg, text_encoder=text_encoder)
 
     mode = args.mode
     runner = fwd_bwd
@@ -249,9 +270,13 @@ def main():
             "value": round(args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
-                                   "latents), reference-default injection (%d Linear sites: Q/K/V/O + GEGLU), f32 LoRA "
-                                   "masters, DDPM+MSE+clip(1.0)+AdamW" % (args.lora_rank, args.batch, n_sites),
+            "config": {"workload": ("BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
+                                    "latents), reference-default injection (%d Linear sites: Q/K/V/O + GEGLU), f32 LoRA "
+                                    "masters, DDPM+MSE+clip(1.0)+AdamW" % (args.lora_rank, args.batch, n_sites))
+                       if not (args.extended or args.text_encoder or args.res != 512) else
+                       ("non-headline variant: rank %d, batch %d/GPU, %dx%d, extended=%d, text_encoder=%d, %d adapter "
+                        "sites" % (args.lora_rank, args.batch, args.res, args.res, args.extended, args.text_encoder,
+                                   n_sites)),
                        "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
                        "parallelism": f"dp{world}", "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
                        "(859,520,964 params, random init)", "trainable_params": state.n,
