@@ -764,3 +764,25 @@ def test_fused_gemm_input_gradient(M, K, N, r, tile):
         _, ddo, duo, _, _ = O.lora_linear_backward(G, X, W, A, U, s)
         np.testing.assert_allclose(n(d_up), duo, rtol=1e-3, atol=1e-3 * np.abs(duo).max())
         np.testing.assert_allclose(n(d_down), ddo, rtol=1e-3, atol=1e-3 * np.abs(ddo).max())
+
+
+def test_fused_gemm_random_shapes_against_device_torch():
+    """40 seeded random (M, K, N, r, dtype, tile) draws incl. ragged M / N tails: fused kernel vs torch on the device."""
+    rng = np.random.default_rng(0)
+    for it in range(40):
+        M = int(rng.integers(1, 700))
+        K = 64 * int(rng.integers(1, 9))
+        N = 8 * int(rng.integers(2, 90))
+        r = int(rng.integers(1, 17))
+        dt = ["bf16", "f16"][it % 2]
+        tile = [0, 21, 22, 23, 24, 31, 32, 33, 34][it % 9]
+        x, w, b = rnd((M, K), dt, 1.0, seed=it), rnd((N, K), dt, 0.1, seed=100 + it), rnd((N,), dt, 0.3, seed=200 + it)
+        down, up = rnd((r, K), "f32", 0.2, seed=300 + it), rnd((N, r), "f32", 0.3, seed=400 + it)
+        y, t = _C.linear_gemm_fwd(x, w, b if it % 3 else None, down, up, 0.5, tile)
+        xf, wf = x.float(), w.float()
+        t_ref = xf @ down.t()
+        y_ref = xf @ wf.t() + (b.float() if it % 3 else 0.0) + 0.5 * (t_ref @ up.t())
+        tag = (M, K, N, r, dt, tile)
+        assert (t - t_ref).abs().max() <= 1e-4 * (xf.abs() @ down.abs().t()).max() + 1e-6, tag
+        tol = (2.0 ** -7 if dt == "bf16" else 2.0 ** -10) * (y_ref.abs().max() + (t_ref.abs() @ up.abs().t()).max())
+        assert (y.float() - y_ref).abs().max() <= tol, (tag, float((y.float() - y_ref).abs().max()), float(tol))
