@@ -315,6 +315,16 @@ int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float *exp_avg_s
                             const int64_t *step_dev, int32_t zero_grad, void *stream);
 int lora_amd_step_advance(int64_t *step_dev, void *stream);
 
+/* Textual-inversion step of pivotal tuning over the placeholder rows ONLY (replaces cli_lora_pti.py:433-479: AdamW
+ * over the whole [vocab, hidden] embedding table, norm decay, restoring every other row).  One launch:
+ * for token t = ids_dev[i]: g = grad_scale * table_grad[t]; AdamW(lr, betas, eps, decoupled weight_decay, 1-based
+ * step) on the f32 master row rows[i] with moments exp_avg[i] / exp_avg_sq[i]; if decay_lambda >= 0 the row is rescaled
+ * to norm + decay_lambda * (target_norm - norm) (the reference: lambda = min(1, 100 lr), target 0.4); table[t] = row. */
+int lora_amd_ti_rows_step(void *table, const void *table_grad, const int64_t *ids_dev, int32_t n_tokens,
+                          int32_t hidden, int32_t table_dtype, float *rows, float *exp_avg, float *exp_avg_sq,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                          int64_t step, float decay_lambda, float target_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

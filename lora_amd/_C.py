@@ -33,7 +33,7 @@ SYMBOLS = (
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
-    "lora_amd_step_advance",
+    "lora_amd_step_advance", "lora_amd_ti_rows_step",
 )
 
 
@@ -103,6 +103,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_clip_adamw.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, i64, i32, vp]
     lib.lora_amd_clip_adamw_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, vp, i32, vp]
     lib.lora_amd_step_advance.argtypes = [vp, vp]
+    lib.lora_amd_ti_rows_step.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, f32, i64, f32, f32,
+                                          vp]
+    lib.lora_amd_ti_rows_step.restype = C.c_int
     lib.lora_amd_clip_adamw_dev.restype = lib.lora_amd_step_advance.restype = C.c_int
     lib.lora_amd_linear_plan.argtypes = [i64, i32, i32, i32, C.POINTER(LinearPlan)]
     lib.lora_amd_linear_fwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, f32, u64,
@@ -643,3 +646,19 @@ def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: t
             best, best_t = tile, tt
     _gemm_choice_bwd[key] = best
     return best
+
+
+def ti_rows_step(table: torch.Tensor, table_grad: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, m: torch.Tensor,
+                 v: torch.Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 grad_scale: float = 1.0, decay_lambda: float = -1.0, target_norm: float = 0.4) -> None:
+    """Placeholder-row AdamW + norm decay + scatter in one launch (see include/lora_amd.h)."""
+    _dev_check(table, table_grad, ids, rows, m, v)
+    if not (table.is_contiguous() and table_grad.is_contiguous() and rows.is_contiguous()):
+        raise ValueError("ti_rows_step: contiguous tensors expected")
+    if ids.dtype != torch.int64 or rows.dtype != torch.float32 or table_grad.dtype != table.dtype:
+        raise ValueError("ti_rows_step: ids int64, rows f32, grad in the table's dtype expected")
+    _check(require().lora_amd_ti_rows_step(table.data_ptr(), table_grad.data_ptr(), ids.data_ptr(), ids.numel(),
+                                           table.shape[1], dtype_code(table.dtype), rows.data_ptr(), m.data_ptr(),
+                                           v.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                           float(weight_decay), float(grad_scale), int(step), float(decay_lambda),
+                                           float(target_norm), _stream()), "lora_amd_ti_rows_step")

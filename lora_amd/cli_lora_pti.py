@@ -136,33 +136,45 @@ def loss_step(batch, unet, vae, text_encoder, scheduler, train_inpainting=False,
 
 
 class PlaceholderRows:
-    """AdamW over the placeholder rows of the token-embedding table only (see module docstring)."""
+    """AdamW + norm decay over the placeholder rows of the token-embedding table only (see module docstring).  On the
+    device the whole update (gather the rows' gradient, AdamW on f32 master rows, decay toward norm 0.4, scatter back)
+    is ONE launch of ``lora_amd_ti_rows_step``; on CPU the same maths in torch."""
 
     def __init__(self, text_encoder, token_ids: List[int], lr: float, weight_decay: float):
         self.emb = text_encoder.get_input_embeddings().weight
         self.ids = torch.tensor(token_ids, dtype=torch.long, device=self.emb.device)
-        self.rows = torch.nn.Parameter(self.emb.data[self.ids].float().clone())
-        self.opt = torch.optim.AdamW([self.rows], lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=weight_decay)
+        self.rows = self.emb.data[self.ids].float().clone().contiguous()
+        self.m, self.v = torch.zeros_like(self.rows), torch.zeros_like(self.rows)
+        self.weight_decay, self.t = float(weight_decay), 0
 
-    def step(self, lr: float, world: int = 1):
-        g = self.emb.grad[self.ids].float()
+    def step(self, lr: float, world: int = 1, clip_ti_decay: bool = False):
+        """One optimiser step on the rows from ``emb.grad`` (averaged over ``world`` ranks), optional norm decay with
+        lambda = min(1, 100 lr) (ref :451-469), rows written back; every other row of the table is untouched."""
+        self.t += 1
+        lam = min(1.0, 100 * lr) if clip_ti_decay and len(self.ids) else -1.0
+        grad = self.emb.grad
         if world > 1:
+            g = grad[self.ids].contiguous()
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            g /= world
-        self.rows.grad = g
-        for grp in self.opt.param_groups:
-            grp["lr"] = lr
-        self.opt.step()
-        self.emb.grad = None
+            grad[self.ids] = g
+        if self.emb.is_cuda:
+            from . import _C
 
-    @torch.no_grad()
-    def decay_and_write(self, lr: float, clip_ti_decay: bool):
-        """ref :451-479 — pull the row norms toward 0.4 with strength min(1, 100*lr); every other row stays as it was."""
-        if clip_ti_decay and len(self.ids):
-            pre = self.rows.norm(dim=-1, keepdim=True)
-            lam = min(1.0, 100 * lr)
-            self.rows.copy_(F.normalize(self.rows, dim=-1) * (pre + lam * (0.4 - pre)))
-        self.emb.data[self.ids] = self.rows.data.to(self.emb.dtype)
+            _C.ti_rows_step(self.emb.data, grad.contiguous(), self.ids, self.rows, self.m, self.v, lr, self.t,
+                            weight_decay=self.weight_decay, grad_scale=1.0 / world, decay_lambda=lam)
+        else:
+            g = grad[self.ids].float() / world
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            self.rows.mul_(1 - lr * self.weight_decay)
+            self.m.lerp_(g, 1 - b1)
+            self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = self.v.sqrt() / math.sqrt(1 - b2 ** self.t) + eps
+            self.rows.addcdiv_(self.m, denom, value=-lr / (1 - b1 ** self.t))
+            if lam >= 0:
+                pre = self.rows.norm(dim=-1, keepdim=True)
+                self.rows.copy_(F.normalize(self.rows, dim=-1) * (pre + lam * (0.4 - pre)))
+            self.emb.data[self.ids] = self.rows.to(self.emb.dtype)
+        self.emb.grad = None
         return self.rows.norm(dim=-1)
 
 
@@ -187,8 +199,7 @@ def train_inversion(unet, vae, text_encoder, dataloader, num_steps: int, schedul
             loss = loss_step(batch, unet, vae, text_encoder, scheduler, cached_latents=cached_latents) / accum_iter
             loss.backward()
             if global_step % accum_iter == 0:  # (sic) ref :433 — also fires on the very first micro-batch
-                rows.step(lr, world)
-                norm = rows.decay_and_write(lr, clip_ti_decay)
+                norm = rows.step(lr, world, clip_ti_decay)
                 if is_main and global_step % (10 * accum_iter) == 0:
                     print(f"TI step {global_step} loss {loss.item() * accum_iter:.5f} lr {lr:.3e} norm {norm.tolist()}")
             global_step += 1
@@ -219,8 +230,7 @@ def perform_tuning(unet, vae, text_encoder, dataloader, num_steps, scheduler, st
             loss.backward()
             state.step(state.all_reduce())
             if rows is not None:  # continue_inversion
-                rows.step(rows_lr * mult, world)
-                rows.decay_and_write(rows_lr * mult, False)
+                rows.step(rows_lr * mult, world, False)
             global_step += 1
             if is_main and global_step % 10 == 0:
                 print(f"tuning step {global_step}/{num_steps} loss {loss.item():.5f} lr {state.lrs[0]:.3e}")

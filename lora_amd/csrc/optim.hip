@@ -154,6 +154,70 @@ extern "C" int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float
                          beta2, eps, 0, step_dev, zero_grad, stream);
 }
 
+// ---------------------------------------------------------------------------- textual-inversion rows (PTI phase 1)
+// One workgroup per placeholder token: gather its gradient row from the embedding-table gradient, AdamW on the f32
+// master row, pull the row norm toward 0.4 (ref cli_lora_pti.py:451-469), scatter the row back into the table.
+// replaces: AdamW over the whole [vocab, hidden] table + normalisation + restoring every other row (:433-479).
+template <class E>
+__global__ __launch_bounds__(kOptThreads) void ti_rows_step_kernel(
+    typename E::storage *__restrict__ table, const typename E::storage *__restrict__ table_grad,
+    const int64_t *__restrict__ ids, float *__restrict__ rows, float *__restrict__ m, float *__restrict__ v, int hidden,
+    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t step, float decay_lambda,
+    float target_norm) {
+  __shared__ float s_buf[kOptThreads / 64];
+  const int64_t tok = ids[blockIdx.x];
+  float *row = rows + (int64_t)blockIdx.x * hidden, *mr = m + (int64_t)blockIdx.x * hidden,
+        *vr = v + (int64_t)blockIdx.x * hidden;
+  const double st = (double)step;
+  const float bc1 = (float)(1.0 - pow((double)beta1, st));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, st));
+  float sq = 0.f;
+  for (int i = threadIdx.x; i < hidden; i += kOptThreads) {
+    const float grad = E::to_f(table_grad[tok * hidden + i]) * grad_scale;
+    float pi = row[i] * (1.0f - lr * weight_decay);
+    float mi = mr[i];
+    mi = mi + (grad - mi) * (1.0f - beta1);
+    float vi = vr[i] * beta2;
+    vi = fmaf((1.0f - beta2) * grad, grad, vi);
+    pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    row[i] = pi; mr[i] = mi; vr[i] = vi;
+    sq = fmaf(pi, pi, sq);
+  }
+  const float norm = sqrtf(block_sum(sq, s_buf));
+  // F.normalize(row) * (norm + lambda * (target - norm)); lambda < 0 disables the decay
+  const float mult = decay_lambda >= 0.f ? (norm + decay_lambda * (target_norm - norm)) / fmaxf(norm, 1e-12f) : 1.0f;
+  for (int i = threadIdx.x; i < hidden; i += kOptThreads) {
+    const float pi = row[i] * mult;
+    row[i] = pi;
+    table[tok * hidden + i] = E::from_f(pi);
+  }
+}
+
+extern "C" int lora_amd_ti_rows_step(void *table, const void *table_grad, const int64_t *ids_dev, int32_t n_tokens,
+                                     int32_t hidden, int32_t table_dtype, float *rows, float *exp_avg,
+                                     float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, float grad_scale, int64_t step, float decay_lambda,
+                                     float target_norm, void *stream) {
+  LORA_AMD_CHECK(table && table_grad && ids_dev && rows && exp_avg && exp_avg_sq, LORA_AMD_EINVAL,
+                 "ti_rows_step: null pointer");
+  LORA_AMD_CHECK(dtype_ok(table_dtype) && hidden > 0 && n_tokens >= 0 && step >= 1, LORA_AMD_EINVAL,
+                 "ti_rows_step: bad argument");
+  if (n_tokens == 0) return LORA_AMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define TI(E)                                                                                                   \
+  hipLaunchKernelGGL((ti_rows_step_kernel<E>), dim3(n_tokens), dim3(kOptThreads), 0, st,                          \
+                     reinterpret_cast<typename E::storage *>(table),                                             \
+                     reinterpret_cast<const typename E::storage *>(table_grad), ids_dev, rows, exp_avg, exp_avg_sq, \
+                     hidden, lr, beta1, beta2, eps, weight_decay, grad_scale, step, decay_lambda, target_norm)
+  switch (table_dtype) {
+    case LORA_AMD_F32: TI(f32_t); break;
+    case LORA_AMD_F16: TI(f16_t); break;
+    default: TI(bf16_t); break;
+  }
+#undef TI
+  return check_launch("lora_amd_ti_rows_step");
+}
+
 __global__ void step_advance_kernel(int64_t *step) { step[0] += 1; }
 
 extern "C" int lora_amd_step_advance(int64_t *step_dev, void *stream) {

@@ -100,8 +100,7 @@ def test_placeholder_rows_equal_full_table_adamw():
         tgt = torch.randn(2, 4, Hd, generator=torch.Generator().manual_seed(step))
         for e in (emb_a, emb_b):
             ((e(tok) - tgt) ** 2).mean().backward()
-        rows.step(lr)
-        rows.decay_and_write(lr, True)
+        rows.step(lr, 1, True)
         opt.step()
         opt.zero_grad()
         with torch.no_grad():

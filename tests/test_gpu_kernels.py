@@ -786,3 +786,36 @@ def test_fused_gemm_random_shapes_against_device_torch():
         assert (t - t_ref).abs().max() <= 1e-4 * (xf.abs() @ down.abs().t()).max() + 1e-6, tag
         tol = (2.0 ** -7 if dt == "bf16" else 2.0 ** -10) * (y_ref.abs().max() + (t_ref.abs() @ up.abs().t()).max())
         assert (y.float() - y_ref).abs().max() <= tol, (tag, float((y.float() - y_ref).abs().max()), float(tol))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_ti_rows_step_matches_full_table_adamw(dt):
+    """lora_amd_ti_rows_step (placeholder rows only, one launch) == the reference's AdamW over the whole embedding
+    table + norm decay toward 0.4 + restoring every other row (cli_lora_pti.py:433-479), 4 steps."""
+    torch.manual_seed(0)
+    V, Hd, ids, lr, wd = 300, 768, [297, 299], 5e-3, 0.01
+    table0 = torch.randn(V, Hd) * 0.02
+    table = table0.clone().to(DT[dt]).to(DEV)
+    ref = torch.nn.Parameter(table0.clone().to(DT[dt]).float())
+    opt = torch.optim.AdamW([ref], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    orig = ref.data.clone()
+    keep = torch.ones(V, dtype=torch.bool)
+    keep[ids] = False
+    idt = torch.tensor(ids, device=DEV)
+    rows = table[idt].float().clone()
+    m, v = torch.zeros_like(rows), torch.zeros_like(rows)
+    for step in range(1, 5):
+        g = torch.randn(V, Hd, generator=torch.Generator().manual_seed(step)) * 0.1
+        g = g.to(DT[dt])
+        ref.grad = g.float().clone()
+        opt.step()
+        with torch.no_grad():
+            pre = ref[~keep].norm(dim=-1, keepdim=True)
+            lam = min(1.0, 100 * lr)
+            ref[~keep] = torch.nn.functional.normalize(ref[~keep], dim=-1) * (pre + lam * (0.4 - pre))
+            ref[keep] = orig[keep]
+        _C.ti_rows_step(table, g.to(DEV), idt, rows, m, v, lr, step, weight_decay=wd, decay_lambda=lam)
+    np.testing.assert_allclose(n(rows), ref.data[~keep].numpy(), rtol=2e-5, atol=2e-6)
+    tol = 0 if dt == "f32" else 2.0 ** -8
+    np.testing.assert_allclose(n(table)[ids], ref.data[~keep].numpy(), rtol=tol + 2e-5, atol=2e-6)
+    assert torch.equal(table[keep.to(DEV)].cpu(), table0.to(DT[dt])[keep])  # every other row untouched
