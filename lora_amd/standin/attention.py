@@ -21,7 +21,9 @@ try:
 except ImportError:  # pragma: no cover
     SDPBackend = sdpa_kernel = None
 
-_CHOICE: Dict[Tuple, Tuple[Optional[str], int]] = {}
+from .._C import _TuneCache  # noqa: E402  (shared JSON cache of per-shape choices, LORA_AMD_TUNE_CACHE)
+
+_CHOICE = _TuneCache("sdpa")
 _TUNE = os.environ.get("LORA_AMD_SDPA_TUNE", "1") != "0"
 
 
@@ -72,13 +74,16 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """softmax(q k^T / sqrt(d)) v for [B, H, S, d] tensors."""
     if not q.is_cuda:
         return F.scaled_dot_product_attention(q, k, v)
-    key = (q.shape[0], q.shape[1], q.shape[2], k.shape[2], q.shape[3], q.dtype, q.requires_grad or k.requires_grad)
+    key = repr((q.shape[0], q.shape[1], q.shape[2], k.shape[2], q.shape[3], str(q.dtype),
+                q.requires_grad or k.requires_grad))
     choice = _CHOICE.get(key)
+    if choice is not None:
+        choice = tuple(choice)
     if choice is None:
         if _TUNE and q.dtype in (torch.bfloat16, torch.float16) and not torch.cuda.is_current_stream_capturing():
             with torch.enable_grad():
                 choice = _tune(q, k, v)
-            _CHOICE[key] = choice
+            _CHOICE[key] = list(choice)
         else:
             choice = (None, q.shape[-1])
     return _run(q, k, v, *choice)

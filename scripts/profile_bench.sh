@@ -6,6 +6,7 @@ set -u
 TAG=${1:-r01}
 OUT=gpurun_out
 export TMPDIR=/tmp
+export LORA_AMD_TUNE_CACHE=/tmp/lora_amd_tune_${TAG}.json   # the warm run times the candidates, the traced run re-uses them
 mkdir -p $OUT
 ARGS="--steps 5 --warmup 3 --no-cpu-baseline"
 ONLY=${2:-all}
