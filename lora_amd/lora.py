@@ -17,11 +17,10 @@ from __future__ import annotations
 
 import json
 from itertools import groupby
-from typing import Dict, Iterator, List, Optional, Sequence, Set, Tuple, Type, Union
+from typing import Dict, Iterator, List, Optional, Set, Tuple, Type, Union
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _C, ops
 

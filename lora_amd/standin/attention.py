@@ -11,7 +11,7 @@ PV unchanged; the softmax scale is passed explicitly.
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.nn.functional as F

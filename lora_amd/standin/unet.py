@@ -12,7 +12,7 @@ Weights are random-init: there is no network to fetch checkpoints.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 import torch.nn as nn

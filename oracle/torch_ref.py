@@ -8,8 +8,7 @@ of the GPU box, where ``/root/reference`` does not exist.
 """
 from __future__ import annotations
 
-import itertools
-from typing import Iterable, List, Optional, Tuple
+from typing import Iterable, List, Tuple
 
 import torch
 import torch.nn as nn
