@@ -93,6 +93,39 @@ def merge_roofline(unet, iters=30):
             "launches_timed": iters * inner}
 
 
+def gemm_roofline(iters=20):
+    """K1 fully fused MFMA kernel (frozen GEMM + LoRA branch, csrc/gemm_fused.hip) at the two largest site shapes of the
+    workload, timed like the merge: informational second roofline (this kernel is what the step spends its adapter time
+    in; its bound is the matrix pipe / L2, not HBM)."""
+    out = []
+    for (M, K, N) in ((16384, 320, 320), (16384, 320, 2560)):
+        g = torch.Generator(device="cuda").manual_seed(0)
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+        down = torch.randn(4, K, device="cuda", generator=g) * 0.25
+        up = torch.randn(N, 4, device="cuda", generator=g) * 0.05
+        if not _C.gemm_supported(x, w, N, 4):
+            continue
+        tile = _C.gemm_choice(x, w, b, down, up, 1.0) or (24 if N > 4 * K else 22)
+        for _ in range(3):
+            _C.linear_gemm_fwd(x, w, b, down, up, 1.0, tile)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            _C.linear_gemm_fwd(x, w, b, down, up, 1.0, tile)
+        e.record()
+        torch.cuda.synchronize()
+        sec = a.elapsed_time(e) / iters * 1e-3
+        flops, byts = 2.0 * M * K * N + 2.0 * M * 4 * (K + N), (M * K + N * K + M * N) * 2 + (N + K) * 4 * 4 + M * 4 * 4
+        out.append({"kernel": "lora_amd::linear_gemm_fwd_kernel<bf16> (K1 fully fused, tile %d)" % tile,
+                    "site": [M, K, N, 4], "bound": "mfma", "achieved": round(flops / sec / 1e12, 1), "peak": 2500.0,
+                    "unit": "TFLOP/s", "frac": round(flops / sec / 2.5e15, 4), "avg_launch_us": round(sec * 1e6, 2),
+                    "algorithmic_GBs": round(byts / sec / 1e9, 1)})
+    return out
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -284,6 +317,7 @@ def main():
         }
         if not args.no_roofline:
             out["roofline"] = merge_roofline(unet)
+            out["roofline_fused_gemm"] = gemm_roofline()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.lora_rank)
         print(json.dumps(out), flush=True)
