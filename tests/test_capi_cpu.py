@@ -69,3 +69,15 @@ def test_device_path_never_falls_back(monkeypatch):
     monkeypatch.setattr(_C, "_load_error", "simulated: library absent")
     with pytest.raises(_C.HipExtensionMissing):
         _C.require()
+
+
+def test_tune_cache_roundtrip(tmp_path, monkeypatch):
+    """Per-shape kernel choices persist through LORA_AMD_TUNE_CACHE (so a profiled re-run does not re-time candidates)."""
+    path = str(tmp_path / "tune.json")
+    monkeypatch.setenv("LORA_AMD_TUNE_CACHE", path)
+    a = _C._TuneCache("gemm_fwd")
+    a["(1, 2, 3)"] = 22
+    b = _C._TuneCache("sdpa")
+    b["(4, 5)"] = ["EFFICIENT_ATTENTION", 64]
+    assert _C._TuneCache("gemm_fwd")["(1, 2, 3)"] == 22 and _C._TuneCache("sdpa")["(4, 5)"] == ["EFFICIENT_ATTENTION", 64]
+    assert "(1, 2, 3)" not in _C._TuneCache("gemm_bwd")
