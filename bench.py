@@ -286,6 +286,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if rank == 0:  # which kernels the per-shape tuning settled on (stderr; the JSON line stays alone on stdout)
+        from lora_amd.standin import attention as _att
+
+        log("[bench] attention kernels:", {k: v for k, v in _att.choices().items()})
+        log("[bench] fused-GEMM forward tiles:", dict(_C._gemm_choice))
+        log("[bench] fused-GEMM backward tiles:", dict(_C._gemm_choice_bwd))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

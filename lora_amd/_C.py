@@ -586,13 +586,16 @@ def _gpu_time(fn, inner: int = 5) -> float:
             for _ in range(inner):
                 fn()
         graph.replay()
-        torch.cuda.synchronize()
-        a.record()
-        graph.replay()
-        graph.replay()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / (2 * inner)
+        best = float("inf")
+        for _ in range(3):  # minimum over repeats: one stall must not decide the kernel of a whole training run
+            torch.cuda.synchronize()
+            a.record()
+            graph.replay()
+            graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / (2 * inner))
+        return best
     except Exception:  # noqa: BLE001 - e.g. a library call that cannot be captured: time it eagerly instead
         torch.cuda.synchronize()
         a.record()

@@ -54,15 +54,17 @@ def _tune(q, k, v) -> Tuple[Optional[str], int]:
         try:
             qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
             go = torch.randn_like(q)
-            for it in range(3):
-                if it == 1:
-                    torch.cuda.synchronize()
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                _run(qq, kk, vv, be, pad).backward(go)
-            b.record()
-            torch.cuda.synchronize()
-            t = a.elapsed_time(b)
+            _run(qq, kk, vv, be, pad).backward(go)  # warm: lazy kernel loading / JIT is not what is compared
+            t = float("inf")
+            for _ in range(3):  # minimum over repeats: one stall must not pick the wrong kernel for the whole run
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(2):
+                    _run(qq, kk, vv, be, pad).backward(go)
+                b.record()
+                torch.cuda.synchronize()
+                t = min(t, a.elapsed_time(b))
         except Exception:  # noqa: BLE001 - a backend that rejects the shape is simply not a candidate
             continue
         if t < best_t:
