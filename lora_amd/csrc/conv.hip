@@ -23,6 +23,7 @@
 // forward  B*C_in*HW*e (X once) + 2*B*C_out*HW*e (Y read+write);  backward  B*C_out*HW*e (G once) +
 // B*C_in*HW*e (X once) + 2*B*C_in*HW*e (dX read+write); the [B,r,HW] f32 tensors are r/C of that.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -48,6 +49,25 @@ __device__ inline ChunkPos chunk_pos(int lane, int cpw, int64_t NP, int npix8, i
   return c;
 }
 
+// Branch-free masked loads: the address is always a valid one (callers clamp it), the value is zeroed afterwards.
+// A load under `if (ok)` becomes a branch with its own s_waitcnt, i.e. one HBM round trip PER load; selected loads
+// all issue back to back.  The 16-byte vector type also carries the alignment the compiler otherwise gives up on for
+// `plane + row * W` (it then splits the access into four 2-byte-aligned pieces).
+template <class E>
+__device__ inline void load8_sel(const typename E::storage *p, bool ok, float (&out)[8]) {
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  union { V v; Chunk8<E> c; } u;
+  u.v = *reinterpret_cast<const V *>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = ok ? E::to_f(u.c.v[i]) : 0.f;
+}
+__device__ inline void ld8f_sel(const float *p, bool ok, float (&v)[8]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = ok ? a[i] : 0.f; v[i + 4] = ok ? b[i] : 0.f; }
+}
+
 __device__ inline void ld8f(const float *p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -63,12 +83,7 @@ template <class E>
 __device__ inline void load_row_window(const typename E::storage *plane_chunk, bool ok, int x0, int W,
                                        float (&w)[10]) {
   float row[8];
-  if (ok) {
-    load8<E>(plane_chunk, row);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) row[i] = 0.f;
-  }
+  load8_sel<E>(plane_chunk, ok, row);
   float left = lane_from_prev(row[7]), right = lane_from_next(row[0]);
   if (x0 == 0) left = 0.f;
   if (x0 + 8 == W) right = 0.f;
@@ -89,12 +104,7 @@ __device__ inline void row_window(const float (&row)[8], int x0, int W, float (&
 }
 __device__ inline void load_row_window_f32(const float *plane_chunk, bool ok, int x0, int W, float (&w)[10]) {
   float row[8];
-  if (ok) {
-    ld8f(plane_chunk, row);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) row[i] = 0.f;
-  }
+  ld8f_sel(plane_chunk, ok, row);
   float left = lane_from_prev(row[7]), right = lane_from_next(row[0]);
   if (x0 == 0) left = 0.f;
   if (x0 + 8 == W) right = 0.f;
@@ -174,12 +184,9 @@ __global__ __launch_bounds__(kCT) void conv_down_fwd_kernel(const typename E::st
       const int c = c0 + 4 * u;
 #pragma unroll
       for (int dy = 0; dy < KS; ++dy) {
-        if (c < c_end && rok[dy]) {
-          load8<E>(xb + (int64_t)c * HW + (dy - (KS >> 1)) * W, rows[u][dy]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) rows[u][dy][i] = 0.f;
-        }
+        const bool ok = c < c_end && rok[dy];  // clamped (always valid) address, zeroed afterwards: no branch
+        load8_sel<E>(xb + (int64_t)(c < c_end ? c : c_end - 1) * HW + (rok[dy] ? (dy - (KS >> 1)) * W : 0), ok,
+                     rows[u][dy]);
       }
     }
 #pragma unroll
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + 4 * u;
-      if (c < c_end) load8<E>(yb + (int64_t)c * HW, yv[u]);
+      load8_sel<E>(yb + (int64_t)(c < c_end ? c : c_end - 1) * HW, c < c_end, yv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -361,12 +368,7 @@ __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::stora
   float tt[4][8], acc[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (cp.act && rg * 4 + j < r) {
-      ld8f(t + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, tt[j]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) tt[j][i] = 0.f;
-    }
+    ld8f_sel(t + ((int64_t)cp.b * r + (rg * 4 + j < r ? rg * 4 + j : 0)) * HW + cp.p0, cp.act && rg * 4 + j < r, tt[j]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
   }
@@ -375,12 +377,7 @@ __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::stora
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + 4 * u;
-      if (c < c_end && cp.act) {
-        load8<E>(gb + (int64_t)c * HW, gv[u]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) gv[u][i] = 0.f;
-      }
+      load8_sel<E>(gb + (int64_t)(c < c_end ? c : c_end - 1) * HW, c < c_end && cp.act, gv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -432,15 +429,10 @@ __device__ inline void load_gt_row(const float *__restrict__ gt, const ChunkPos 
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bool ok = row_ok && rank0 + j < r;
-    const float *gp = gt + ((int64_t)cp.b * r + (rank0 + j < r ? rank0 + j : 0)) * HW + cp.p0 + shift;
+    const float *gp = gt + ((int64_t)cp.b * r + (rank0 + j < r ? rank0 + j : 0)) * HW + cp.p0 + (row_ok ? shift : 0);
     if (KS == 1) {
       float row[8];
-      if (ok) {
-        ld8f(gp, row);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) row[i] = 0.f;
-      }
+      ld8f_sel(gp, ok, row);
       gw[j][0] = gw[j][9] = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) gw[j][i + 1] = row[i];
@@ -477,12 +469,7 @@ __global__ __launch_bounds__(kCT) void conv_bwd_down_kernel(const typename E::st
   float g0[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (cp.act && rg * 4 + j < r) {
-      ld8f(gt + ((int64_t)cp.b * r + rg * 4 + j) * HW + cp.p0, g0[j]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g0[j][i] = 0.f;
-    }
+    ld8f_sel(gt + ((int64_t)cp.b * r + (rg * 4 + j < r ? rg * 4 + j : 0)) * HW + cp.p0, cp.act && rg * 4 + j < r, g0[j]);
   }
   for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * U) {
     float rows[U][KS][8];
@@ -491,12 +478,9 @@ __global__ __launch_bounds__(kCT) void conv_bwd_down_kernel(const typename E::st
       const int c = c0 + 4 * u;
 #pragma unroll
       for (int dy = 0; dy < KS; ++dy) {
-        if (c < c_end && rok[dy]) {
-          load8<E>(xb + (int64_t)c * HW + (dy - (KS >> 1)) * W, rows[u][dy]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) rows[u][dy][i] = 0.f;
-        }
+        const bool ok = c < c_end && rok[dy];  // clamped (always valid) address, zeroed afterwards: no branch
+        load8_sel<E>(xb + (int64_t)(c < c_end ? c : c_end - 1) * HW + (rok[dy] ? (dy - (KS >> 1)) * W : 0), ok,
+                     rows[u][dy]);
       }
     }
 #pragma unroll
@@ -553,10 +537,10 @@ __global__ __launch_bounds__(kCT) void conv_bwd_dx_kernel(typename E::storage *_
 
   for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * CB) {
     float dv[CB][8];
-    if (cp.act) {  // issued now, consumed after the rank loop
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        if (c0 + 4 * cb < c_end) load8<E>(dxb + (int64_t)(c0 + 4 * cb) * HW, dv[cb]);
+    for (int cb = 0; cb < CB; ++cb) {  // issued now (branch-free, clamped), consumed after the rank loop
+      const int c = c0 + 4 * cb;
+      load8_sel<E>(dxb + (int64_t)(c < c_end ? c : c_end - 1) * HW, c < c_end, dv[cb]);
     }
     float dacc[CB][8];
 #pragma unroll
@@ -607,6 +591,8 @@ struct ConvGeo {
 };
 
 static int pick_split(int ngroups, int C, int r) {
+  if (const char *e = getenv("LORA_AMD_CONV_SPLIT"))  // tuning knob (scripts/kbench.py sweeps it)
+    return std::max(1, std::min(atoi(e), std::max(1, C / 8)));
   int s = (512 + ngroups - 1) / ngroups;            // aim at >= 512 workgroups
   s = std::min(s, std::max(1, C / (4 * r)));        // partial-sum traffic <= ~50 % of the activation bytes
   s = std::min(s, std::max(1, C / 8));              // >= 2 channels per wave
@@ -614,7 +600,8 @@ static int pick_split(int ngroups, int C, int r) {
   return std::max(1, s);
 }
 static int stream_split(int ngroups, int C) {       // passes that own their output: split for parallelism only
-  return std::max(1, std::min((512 + ngroups - 1) / ngroups, C / 8));
+  if (const char *e = getenv("LORA_AMD_CONV_SPLIT")) return std::max(1, std::min(atoi(e), std::max(1, C / 8)));
+  return std::max(1, std::min((1024 + ngroups - 1) / ngroups, C / 8));  // measured: the dX / dDown passes keep gaining to ~1000 workgroups
 }
 
 // C_in / C_out may be passed as 0 by entry points that do not touch that side.
