@@ -49,25 +49,6 @@ __device__ inline ChunkPos chunk_pos(int lane, int cpw, int64_t NP, int npix8, i
   return c;
 }
 
-// Branch-free masked loads: the address is always a valid one (callers clamp it), the value is zeroed afterwards.
-// A load under `if (ok)` becomes a branch with its own s_waitcnt, i.e. one HBM round trip PER load; selected loads
-// all issue back to back.  The 16-byte vector type also carries the alignment the compiler otherwise gives up on for
-// `plane + row * W` (it then splits the access into four 2-byte-aligned pieces).
-template <class E>
-__device__ inline void load8_sel(const typename E::storage *p, bool ok, float (&out)[8]) {
-  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
-  union { V v; Chunk8<E> c; } u;
-  u.v = *reinterpret_cast<const V *>(p);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = ok ? E::to_f(u.c.v[i]) : 0.f;
-}
-__device__ inline void ld8f_sel(const float *p, bool ok, float (&v)[8]) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { v[i] = ok ? a[i] : 0.f; v[i + 4] = ok ? b[i] : 0.f; }
-}
-
 __device__ inline void ld8f(const float *p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;

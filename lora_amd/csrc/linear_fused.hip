@@ -230,8 +230,10 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
         for (int cb = l; cb < c8; cb += L * U) {
           float xv[U][8];
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (cb + u * L < c8) load8<E>(xr + (cb + u * L) * 8, xv[u]);
+          for (int u = 0; u < U; ++u) {  // clamped address + select: the U loads issue back to back (no branch/wait each)
+            const int cc = cb + u * L;
+            load8_sel<E>(xr + (cc < c8 ? cc : cb) * 8, cc < c8, xv[u]);
+          }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int cc = cb + u * L;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
       for (int u = 0; u < U; ++u) {
         ok[u] = (c + u * kFT) < nchunk;
         rls[u] = rl; ccs[u] = cc;
-        if (ok[u]) load8<E>(y + (m0 + rl) * ldy + n0 + cc * 8, v[u]);
+        load8_sel<E>(y + (m0 + (ok[u] ? rl : rls[0])) * ldy + n0 + (ok[u] ? cc : ccs[0]) * 8, ok[u], v[u]);
         rl += dq; cc += dr;
         if (cc >= c8) { cc -= c8; ++rl; }
       }
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots + slot;
-      if (rl < nrows) load8<E>(g + (m0 + rl) * ldg + col, gv[u]);
+      load8_sel<E>(g + (m0 + (rl < nrows ? rl : nrows - 1)) * ldg + col, rl < nrows, gv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -466,10 +468,9 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots;
-      if (rl < nrows) {
-        load8<E>(x + (m0 + rl) * ldx + col, xv[u]);
-        if (HAS_DX) load8<E>(dx + (m0 + rl) * lddx + col, dv[u]);
-      }
+      const int rc = rl < nrows ? rl : nrows - 1;
+      load8_sel<E>(x + (m0 + rc) * ldx + col, rl < nrows, xv[u]);
+      if (HAS_DX) load8_sel<E>(dx + (m0 + rc) * lddx + col, rl < nrows, dv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
