@@ -306,7 +306,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "train steps/sec SD1.5 rank-4 512^2 (train_lora_dreambooth.py step)",
-            "value": round(args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "value": round(args.steps * world / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
@@ -317,7 +317,8 @@ def main():
                         "sites" % (args.lora_rank, args.batch, args.res, args.res, args.extended, args.text_encoder,
                                    n_sites)),
                        "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
-                       "parallelism": f"dp{world}", "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
+                       "parallelism": f"dp{world}", "value_counts": "per-rank train steps summed over ranks (weak scaling: every rank "
+                       "steps its own batch; optimizer steps/s = value / n_gpus)", "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
                        "(859,520,964 params, random init)", "trainable_params": state.n,
                        "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},
         }
