@@ -325,6 +325,33 @@ int lora_amd_ti_rows_step(void *table, const void *table_grad, const int64_t *id
                           float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                           int64_t step, float decay_lambda, float target_norm, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Frozen host-model fusions of the training step (train_lora_dreambooth.py:838-892 calls unet(...)): the
+ * normalisation / activation passes between the adapted sites.  Not part of the reference's LoRA interface —
+ * they replace ATen sequences of the UNet the reference trains through (ResnetBlock2D norm+SiLU, GEGLU gate).
+ * Affine parameters are frozen: backward produces the input gradient only.
+ * ---------------------------------------------------------------------- */
+
+/* GroupNorm over NCHW-contiguous x [B, C, HW] (HW % 8 == 0, C % groups == 0), y = act(gn(x) * gamma + beta) with
+ * act = SiLU when `act` != 0.  gamma / beta have the activation dtype.  stats [B*groups][2] f32 receives
+ * (mean, rstd) for the backward.  Two launches; workspace >= lora_amd_groupnorm_workspace bytes (0 = unsupported). */
+size_t lora_amd_groupnorm_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups);
+int lora_amd_groupnorm_supported(int32_t B, int32_t C, int32_t HW, int32_t groups);
+int lora_amd_groupnorm_fwd(const void *x, const void *gamma, const void *beta, void *y, float *stats,
+                           void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                           int32_t groups, float eps, int32_t act, int32_t dtype, void *stream);
+/* dx = d loss / d x given gout = d loss / d y; x, stats as in the forward. */
+int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, const void *beta,
+                           const float *stats, void *dx, void *workspace, size_t workspace_bytes, int32_t B,
+                           int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream);
+
+/* GEGLU gate behind the adapted projection: y [M, 2*inner] = [h | gate]; out [M, inner] = h * gelu(gate) (erf form).
+ * Backward writes gy [M, 2*inner] = [gout * gelu(gate) | gout * h * gelu'(gate)] in one pass (no cat). */
+int lora_amd_geglu_fwd(const void *y, int64_t ldy, void *out, int64_t ldo, int64_t M, int32_t inner, int32_t dtype,
+                       void *stream);
+int lora_amd_geglu_bwd(const void *y, int64_t ldy, const void *gout, int64_t ldg, void *gy, int64_t ldgy, int64_t M,
+                       int32_t inner, int32_t dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

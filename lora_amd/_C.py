@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -34,6 +34,8 @@ SYMBOLS = (
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance", "lora_amd_ti_rows_step",
+    "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
+    "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
 )
 
 
@@ -123,6 +125,16 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_conv_bwd_g.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
                                         u64, vp]
     lib.lora_amd_conv_bwd_x.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_groupnorm_workspace.argtypes = [i32, i32, i32, i32]
+    lib.lora_amd_groupnorm_workspace.restype = sz
+    lib.lora_amd_groupnorm_supported.argtypes = [i32, i32, i32, i32]
+    lib.lora_amd_groupnorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
+    lib.lora_amd_groupnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.lora_amd_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    for name in ("lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
+                 "lora_amd_geglu_fwd", "lora_amd_geglu_bwd"):
+        getattr(lib, name).restype = C.c_int
     for name in ("lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g",
                  "lora_amd_conv_bwd_x"):
         getattr(lib, name).restype = C.c_int
@@ -712,3 +724,71 @@ def ti_rows_step(table: torch.Tensor, table_grad: torch.Tensor, ids: torch.Tenso
                                            v.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                            float(weight_decay), float(grad_scale), int(step), float(decay_lambda),
                                            float(target_norm), _stream()), "lora_amd_ti_rows_step")
+
+
+# ----------------------------------------------------------------------------- frozen host-model fusions (hostops.hip)
+_gn_ws_cache: Dict[Tuple[int, int, int, int], int] = {}
+
+
+def groupnorm_workspace(B: int, C_: int, HW: int, groups: int) -> int:
+    """Bytes of f32 slice statistics the two GroupNorm launches exchange; 0 = geometry not supported."""
+    key = (B, C_, HW, groups)
+    n = _gn_ws_cache.get(key)
+    if n is None:
+        n = _gn_ws_cache[key] = int(require().lora_amd_groupnorm_workspace(B, C_, HW, groups))
+    return n
+
+
+def groupnorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                  act: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """y = act(group_norm(x) * gamma + beta) for NCHW-contiguous x; returns (y, stats [B*groups, 2] = mean, rstd)."""
+    _dev_check(x, gamma, beta)
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_workspace(B, C_, HW, groups)
+    if nbytes == 0:
+        raise ValueError(f"lora_amd_groupnorm: geometry {tuple(x.shape)} / {groups} groups not supported")
+    y = torch.empty_like(x)
+    stats = torch.empty(B * groups, 2, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                            stats.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups, eps,
+                                            1 if act else 0, dtype_code(x.dtype), _stream()), "lora_amd_groupnorm_fwd")
+    return y, stats
+
+
+def groupnorm_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, stats: torch.Tensor,
+                  groups: int, act: bool) -> torch.Tensor:
+    _dev_check(x, gout, gamma, beta, stats)
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_workspace(B, C_, HW, groups)
+    dx = torch.empty_like(x)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            stats.data_ptr(), dx.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups,
+                                            1 if act else 0, dtype_code(x.dtype), _stream()), "lora_amd_groupnorm_bwd")
+    return dx
+
+
+def geglu_fwd(y: torch.Tensor) -> torch.Tensor:
+    """out [..., inner] = y[..., :inner] * gelu(y[..., inner:]) for a row-contiguous y [..., 2*inner]."""
+    _dev_check(y)
+    y2 = _as2d(y.reshape(-1, y.shape[-1]))
+    inner = y2.shape[1] // 2
+    out = torch.empty(*y.shape[:-1], inner, dtype=y.dtype, device=y.device)
+    _check(require().lora_amd_geglu_fwd(y2.data_ptr(), y2.stride(0), out.data_ptr(), inner, y2.shape[0], inner,
+                                        dtype_code(y.dtype), _stream()), "lora_amd_geglu_fwd")
+    return out
+
+
+def geglu_bwd(y: torch.Tensor, gout: torch.Tensor) -> torch.Tensor:
+    """Gradient w.r.t. y [..., 2*inner] given gout [..., inner] (one pass, both halves written in place of a cat)."""
+    _dev_check(y, gout)
+    y2, g2 = _as2d(y.reshape(-1, y.shape[-1])), _as2d(gout.reshape(-1, gout.shape[-1]))
+    inner = y2.shape[1] // 2
+    gy = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    _check(require().lora_amd_geglu_bwd(y2.data_ptr(), y2.stride(0), g2.data_ptr(), g2.stride(0), gy.data_ptr(),
+                                        2 * inner, y2.shape[0], inner, dtype_code(y.dtype), _stream()),
+           "lora_amd_geglu_bwd")
+    return gy

@@ -85,6 +85,26 @@ __device__ inline void load8_sel(const typename E::storage *p, bool ok, float (&
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = ok ? E::to_f(u.c.v[i]) : 0.f;
 }
+// The same in two steps, for kernels that want every load of a thread issued before the first value is converted
+// (hipcc otherwise tends to convert chunk 0 — s_waitcnt vmcnt(0) — before it issues the load of chunk 1).
+template <class E>
+struct Raw8 {
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  V v;
+};
+template <class E>
+__device__ inline Raw8<E> load8_raw(const typename E::storage *p) {
+  Raw8<E> r;
+  r.v = *reinterpret_cast<const typename Raw8<E>::V *>(p);
+  return r;
+}
+template <class E>
+__device__ inline void unpack8_sel(const Raw8<E> &r, bool ok, float (&out)[8]) {
+  union { typename Raw8<E>::V v; Chunk8<E> c; } u;
+  u.v = r.v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = ok ? E::to_f(u.c.v[i]) : 0.f;
+}
 __device__ inline void ld8f_sel(const float *p, bool ok, float (&v)[8]) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);

@@ -1,0 +1,555 @@
+// Pointwise / normalisation fusions of the FROZEN host model that the training step
+// (training_scripts/train_lora_dreambooth.py:838-892 -> unet(...)) spends its launches on
+// between the adapted Linear / Conv2d sites:
+//
+//   GroupNorm (+ SiLU)   ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out
+//                        ATen: 4 launches forward (moments, fused params, normalise, silu), 5 backward, and it
+//                        keeps the normalised tensor AND the SiLU input alive for backward.
+//                        Here: 2 launches each way (slice statistics, apply), only x and [B,G] (mean, rstd) kept.
+//   GEGLU gate           GEGLU.forward right behind the adapted `proj` (lora_diffusion/lora.py:14 targets GEGLU):
+//                        h * gelu(gate): ATen = chunk, gelu, mul (5 tensor passes) forward and
+//                        gelu_backward, 2 mul, cat (13 passes) backward.  Here: one launch each way (3 / 5 passes);
+//                        the backward writes the [M, 2*inner] gradient in place of the cat, which is exactly the G
+//                        operand the adapter backward kernels stream next.
+//
+// All of it is HBM-bound streaming with 16-byte lanes; reductions are per (sample, group) and split into slices so
+// that ~1000 workgroups are in flight even when B*G = 128.  Affine parameters are frozen (the reference trains only
+// the LoRA factors), so no dgamma / dbeta is produced; callers that train them must use the library path.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+constexpr int kHT = 256;       // threads per workgroup
+constexpr int kHU = 4;         // 16-byte chunks per thread held in registers
+constexpr int kHMaxSlices = 256;
+
+__device__ inline float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ inline float sigmoidf(float z) { return fast_rcp(1.f + __expf(-z)); }
+// d/dz [z * sigmoid(z)]
+__device__ inline float silu_grad(float z) {
+  const float s = sigmoidf(z);
+  return s * (1.f + z * (1.f - s));
+}
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below f32 round-off of the products it feeds)
+__device__ inline float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = fast_rcp(1.f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.f - p * t * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+__device__ inline float gelu_cdf(float g) { return 0.5f * (1.f + erf_as(g * 0.70710678118654752f)); }
+__device__ inline float gelu_pdf(float g) { return 0.39894228040143268f * __expf(-0.5f * g * g); }
+
+// Sum of two per-thread values over the workgroup; every thread receives both totals.
+__device__ inline void block_sum2(float &a, float &b, float (*s)[2]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();  // previous use of s is over
+  if (lane == 0) { s[wave][0] = a; s[wave][1] = b; }
+  __syncthreads();
+  a = (s[0][0] + s[1][0]) + (s[2][0] + s[3][0]);
+  b = (s[0][1] + s[1][1]) + (s[2][1] + s[3][1]);
+}
+
+// One (sample, group) = `chunks` consecutive 16-byte chunks of an NCHW tensor, cut into S slices of `per_block`.
+struct GnGeo {
+  int cpg, chunks, per_block, S;
+  int64_t span;
+  bool ok;
+};
+static GnGeo gn_geo(int B, int C, int HW, int G) {
+  GnGeo q{};
+  q.ok = B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && HW % 8 == 0;
+  if (!q.ok) return q;
+  q.cpg = C / G;
+  q.span = (int64_t)q.cpg * HW;
+  q.ok = q.span / 8 <= (int64_t)kHMaxSlices * kHT * kHU;
+  if (!q.ok) return q;
+  q.chunks = (int)(q.span / 8);
+  int64_t pb = (int64_t)B * G * q.chunks / 1024;  // aim at ~1000 workgroups
+  pb = std::max<int64_t>(64, std::min<int64_t>(pb, kHT * kHU));
+  pb = std::min<int64_t>(pb, q.chunks);
+  q.per_block = (int)pb;
+  q.S = (q.chunks + q.per_block - 1) / q.per_block;
+  return q;
+}
+
+struct GnBlock {
+  int64_t bg;       // sample * G + group
+  int slice, nloc;  // slice index, chunks in this slice
+  int64_t base;     // first element of the slice in the tensor
+  int c0;           // first channel of the group
+};
+__device__ inline GnBlock gn_block(int G, int cpg, int HW, int chunks, int per_block, int S) {
+  GnBlock b;
+  b.bg = blockIdx.x / S;
+  b.slice = (int)(blockIdx.x - b.bg * S);
+  b.nloc = min(per_block, chunks - b.slice * per_block);
+  b.base = b.bg * (int64_t)cpg * HW + (int64_t)b.slice * per_block * 8;
+  b.c0 = (int)(b.bg % G) * cpg;
+  return b;
+}
+
+// gamma / beta of the channel each of the thread's chunks lies in (HW % 8 == 0: a chunk never straddles channels).
+// Loaded up front, next to the activation loads, so that nothing later waits on a dependent scalar fetch.
+template <class E>
+__device__ inline void gn_load_affine(const typename E::storage *__restrict__ gamma,
+                                      const typename E::storage *__restrict__ beta, const GnBlock &b, int per_block,
+                                      int HW, float (&ga)[kHU], float (&be)[kHU]) {
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = threadIdx.x + u * kHT;
+    const int c = b.c0 + ((b.slice * per_block + (i < b.nloc ? i : 0)) * 8) / HW;
+    ga[u] = E::to_f(gamma[c]);
+    be[u] = E::to_f(beta[c]);
+  }
+}
+// Keep the compiler from sinking loads below (or hoisting their consumers above) this point: without it hipcc
+// consumes the first chunk before issuing the second load, i.e. one HBM round trip per chunk.
+#define LORA_AMD_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+
+// ---- GroupNorm forward ---------------------------------------------------------------------------------------------
+// Stage 1: slice mean and M2 = sum (x - slice mean)^2 with the slice held in registers (no E[x^2] - mean^2
+// cancellation).  part[bg][slice] = (mean, M2); the slice's element count follows from the geometry.
+template <class E>
+__global__ __launch_bounds__(kHT) void gn_stats_kernel(const typename E::storage *__restrict__ x,
+                                                       float *__restrict__ part, int G, int cpg, int HW, int chunks,
+                                                       int per_block, int S) {
+  __shared__ float s_red[4][2];
+  const GnBlock b = gn_block(G, cpg, HW, chunks, per_block, S);
+  const int tid = threadIdx.x;
+  float v[kHU][8];
+  float sum = 0.f, zero = 0.f;
+  Raw8<E> raw[kHU];
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    raw[u] = load8_raw<E>(x + b.base + (int64_t)(i < b.nloc ? i : 0) * 8);
+  }
+  LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    unpack8_sel<E>(raw[u], tid + u * kHT < b.nloc, v[u]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[u][e];
+  }
+  block_sum2(sum, zero, s_red);
+  const float mean = sum / (float)(b.nloc * 8);
+  float m2 = 0.f;
+  zero = 0.f;
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    if (tid + u * kHT < b.nloc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[u][e] - mean;
+        m2 = fmaf(d, d, m2);
+      }
+    }
+  }
+  block_sum2(m2, zero, s_red);
+  if (tid == 0) {
+    part[(b.bg * S + b.slice) * 2 + 0] = mean;
+    part[(b.bg * S + b.slice) * 2 + 1] = m2;
+  }
+}
+
+// Stage 2: merge the S slice statistics (Chan et al.), normalise, affine, optional SiLU.
+template <class E, bool ACT>
+__global__ __launch_bounds__(kHT) void gn_apply_kernel(const typename E::storage *__restrict__ x,
+                                                       const typename E::storage *__restrict__ gamma,
+                                                       const typename E::storage *__restrict__ beta,
+                                                       typename E::storage *__restrict__ y,
+                                                       const float *__restrict__ part, float *__restrict__ stats,
+                                                       int G, int cpg, int HW, int chunks, int per_block, int S,
+                                                       float eps) {
+  __shared__ float s_red[4][2];
+  const GnBlock b = gn_block(G, cpg, HW, chunks, per_block, S);
+  const int tid = threadIdx.x;
+  // issue the slice's loads first; the statistics merge below overlaps their latency
+  Raw8<E> raw[kHU];
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    raw[u] = load8_raw<E>(x + b.base + (int64_t)(i < b.nloc ? i : 0) * 8);
+  }
+  float gam[kHU], bet[kHU];
+  gn_load_affine<E>(gamma, beta, b, per_block, HW, gam, bet);
+  const float n_all = (float)chunks * 8.f;
+  const int ts = tid < S ? tid : 0;
+  const float n_t = tid < S ? 8.f * (float)min(per_block, chunks - ts * per_block) : 0.f;
+  const float mean_t = part[(b.bg * S + ts) * 2 + 0];
+  const float m2_t = tid < S ? part[(b.bg * S + ts) * 2 + 1] : 0.f;
+  LORA_AMD_LOADS_ISSUED();
+  float a = n_t * mean_t, zero = 0.f;
+  block_sum2(a, zero, s_red);
+  const float mean = a / n_all;
+  const float dm = mean_t - mean;
+  float m2 = fmaf(n_t * dm, dm, m2_t);
+  zero = 0.f;
+  block_sum2(m2, zero, s_red);
+  const float rstd = rsqrtf(m2 / n_all + eps);
+  if (b.slice == 0 && tid == 0) {
+    stats[b.bg * 2 + 0] = mean;
+    stats[b.bg * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    if (i < b.nloc) {
+      const float ga = gam[u] * rstd;
+      const float be = fmaf(-mean, ga, bet[u]);
+      float o[8], v[8];
+      unpack8_sel<E>(raw[u], true, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = fmaf(v[e], ga, be);
+        o[e] = ACT ? z * sigmoidf(z) : z;
+      }
+      store8<E>(y + b.base + (int64_t)i * 8, o);
+    }
+  }
+}
+
+// ---- GroupNorm backward (input gradient only: gamma / beta are frozen) --------------------------------------------
+// t = gamma * dL/dz,  xh = (x - mean) * rstd;  dx = rstd * (t - mean_g(t) - xh * mean_g(t * xh)).
+template <class E, bool ACT>
+__device__ inline void gn_bwd_terms(const float (&xv)[8], const float (&gv)[8], float ga_r, float be, float gam,
+                                    float mean, float rstd, float (&t)[8], float (&xh)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    xh[e] = (xv[e] - mean) * rstd;
+    float dz = gv[e];
+    if (ACT) dz *= silu_grad(fmaf(xv[e], ga_r, be));
+    t[e] = gam * dz;
+  }
+}
+
+template <class E, bool ACT>
+__global__ __launch_bounds__(kHT) void gn_bwd_stats_kernel(const typename E::storage *__restrict__ x,
+                                                           const typename E::storage *__restrict__ gout,
+                                                           const typename E::storage *__restrict__ gamma,
+                                                           const typename E::storage *__restrict__ beta,
+                                                           const float *__restrict__ stats, float *__restrict__ part,
+                                                           int G, int cpg, int HW, int chunks, int per_block, int S) {
+  __shared__ float s_red[4][2];
+  const GnBlock b = gn_block(G, cpg, HW, chunks, per_block, S);
+  const int tid = threadIdx.x;
+  Raw8<E> xr[kHU], gr[kHU];
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    const int64_t off = b.base + (int64_t)(i < b.nloc ? i : 0) * 8;
+    xr[u] = load8_raw<E>(x + off);
+    gr[u] = load8_raw<E>(gout + off);
+  }
+  float gam[kHU], bet[kHU];
+  gn_load_affine<E>(gamma, beta, b, per_block, HW, gam, bet);
+  const float mean = stats[b.bg * 2 + 0], rstd = stats[b.bg * 2 + 1];
+  LORA_AMD_LOADS_ISSUED();
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    if (i < b.nloc) {
+      const float ga_r = gam[u] * rstd, be = fmaf(-mean, ga_r, bet[u]);
+      float t[8], xh[8], xv[8], gv[8];
+      unpack8_sel<E>(xr[u], true, xv);
+      unpack8_sel<E>(gr[u], true, gv);
+      gn_bwd_terms<E, ACT>(xv, gv, ga_r, be, gam[u], mean, rstd, t, xh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1 += t[e];
+        s2 = fmaf(t[e], xh[e], s2);
+      }
+    }
+  }
+  block_sum2(s1, s2, s_red);
+  if (tid == 0) {
+    part[(b.bg * S + b.slice) * 2 + 0] = s1;
+    part[(b.bg * S + b.slice) * 2 + 1] = s2;
+  }
+}
+
+template <class E, bool ACT>
+__global__ __launch_bounds__(kHT) void gn_bwd_apply_kernel(const typename E::storage *__restrict__ x,
+                                                           const typename E::storage *__restrict__ gout,
+                                                           const typename E::storage *__restrict__ gamma,
+                                                           const typename E::storage *__restrict__ beta,
+                                                           const float *__restrict__ stats,
+                                                           const float *__restrict__ part,
+                                                           typename E::storage *__restrict__ dx, int G, int cpg,
+                                                           int HW, int chunks, int per_block, int S) {
+  __shared__ float s_red[4][2];
+  const GnBlock b = gn_block(G, cpg, HW, chunks, per_block, S);
+  const int tid = threadIdx.x;
+  Raw8<E> xr[kHU], gr[kHU];
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    const int64_t off = b.base + (int64_t)(i < b.nloc ? i : 0) * 8;
+    xr[u] = load8_raw<E>(x + off);
+    gr[u] = load8_raw<E>(gout + off);
+  }
+  float gam[kHU], bet[kHU];
+  gn_load_affine<E>(gamma, beta, b, per_block, HW, gam, bet);
+  const int ts = tid < S ? tid : 0;
+  float s1 = part[(b.bg * S + ts) * 2 + 0], s2 = part[(b.bg * S + ts) * 2 + 1];
+  const float mean = stats[b.bg * 2 + 0], rstd = stats[b.bg * 2 + 1];
+  LORA_AMD_LOADS_ISSUED();
+  if (tid >= S) s1 = s2 = 0.f;
+  block_sum2(s1, s2, s_red);
+  const float inv_n = 1.f / ((float)chunks * 8.f);
+  const float c1 = s1 * inv_n, c2 = s2 * inv_n;
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const int i = tid + u * kHT;
+    if (i < b.nloc) {
+      const float ga_r = gam[u] * rstd, be = fmaf(-mean, ga_r, bet[u]);
+      float t[8], xh[8], o[8], xv[8], gv[8];
+      unpack8_sel<E>(xr[u], true, xv);
+      unpack8_sel<E>(gr[u], true, gv);
+      gn_bwd_terms<E, ACT>(xv, gv, ga_r, be, gam[u], mean, rstd, t, xh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (t[e] - c1 - xh[e] * c2);
+      store8<E>(dx + b.base + (int64_t)i * 8, o);
+    }
+  }
+}
+
+// ---- GEGLU gate ----------------------------------------------------------------------------------------------------
+// y = [h | gate] per row (2 * inner columns);  out = h * gelu(gate)   (exact erf form, F.gelu's default).
+template <class E>
+__global__ __launch_bounds__(kHT) void geglu_fwd_kernel(const typename E::storage *__restrict__ y, int64_t ldy,
+                                                        typename E::storage *__restrict__ out, int64_t ldo,
+                                                        int64_t M, int c8) {
+  const uint32_t total = (uint32_t)(M * c8);  // host checks M * c8 < 2^31
+  const uint32_t i0 = blockIdx.x * (uint32_t)(kHT * kHU) + threadIdx.x;
+  Raw8<E> hr[kHU], gr[kHU];
+  int64_t rows[kHU];
+  int cols[kHU];
+  const uint32_t dq = (uint32_t)kHT / (uint32_t)c8, dr = (uint32_t)kHT % (uint32_t)c8;
+  const uint32_t row0 = min(i0, total - 1) / (uint32_t)c8, col0 = min(i0, total - 1) - row0 * (uint32_t)c8;
+  uint32_t row = row0, col = col0;
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    const bool ok = i0 + u * kHT < total;  // chunks past the end re-read the block's first chunk
+    rows[u] = ok ? row : row0;
+    cols[u] = (int)(ok ? col : col0) * 8;
+    row += dq; col += dr;
+    if (col >= (uint32_t)c8) { col -= c8; ++row; }
+    const typename E::storage *p = y + rows[u] * ldy + cols[u];
+    hr[u] = load8_raw<E>(p);
+    gr[u] = load8_raw<E>(p + (int64_t)c8 * 8);
+  }
+  LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+  for (int u = 0; u < kHU; ++u) {
+    if (i0 + u * kHT < total) {
+      float o[8], h[8], g[8];
+      unpack8_sel<E>(hr[u], true, h);
+      unpack8_sel<E>(gr[u], true, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = h[e] * (g[e] * gelu_cdf(g[e]));
+      store8<E>(out + rows[u] * ldo + cols[u], o);
+    }
+  }
+}
+
+// gy[:, :inner] = gout * gelu(gate);  gy[:, inner:] = gout * h * gelu'(gate)
+template <class E>
+__global__ __launch_bounds__(kHT) void geglu_bwd_kernel(const typename E::storage *__restrict__ y, int64_t ldy,
+                                                        const typename E::storage *__restrict__ gout, int64_t ldg,
+                                                        typename E::storage *__restrict__ gy, int64_t ldgy,
+                                                        int64_t M, int c8) {
+  constexpr int U = 2;
+  const uint32_t total = (uint32_t)(M * c8);  // host checks M * c8 < 2^31
+  const uint32_t i0 = blockIdx.x * (uint32_t)(kHT * U) + threadIdx.x;
+  Raw8<E> hr[U], gr[U], gor[U];
+  int64_t rows[U];
+  int cols[U];
+  const uint32_t dq = (uint32_t)kHT / (uint32_t)c8, dr = (uint32_t)kHT % (uint32_t)c8;
+  const uint32_t row0 = min(i0, total - 1) / (uint32_t)c8, col0 = min(i0, total - 1) - row0 * (uint32_t)c8;
+  uint32_t row = row0, col = col0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool ok = i0 + u * kHT < total;
+    rows[u] = ok ? row : row0;
+    cols[u] = (int)(ok ? col : col0) * 8;
+    row += dq; col += dr;
+    if (col >= (uint32_t)c8) { col -= c8; ++row; }
+    const typename E::storage *p = y + rows[u] * ldy + cols[u];
+    hr[u] = load8_raw<E>(p);
+    gr[u] = load8_raw<E>(p + (int64_t)c8 * 8);
+    gor[u] = load8_raw<E>(gout + rows[u] * ldg + cols[u]);
+  }
+  LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (i0 + u * kHT < total) {
+      float dh[8], dg[8], h[8], g[8], go[8];
+      unpack8_sel<E>(hr[u], true, h);
+      unpack8_sel<E>(gr[u], true, g);
+      unpack8_sel<E>(gor[u], true, go);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float cdf = gelu_cdf(g[e]);
+        dh[e] = go[e] * (g[e] * cdf);
+        dg[e] = go[e] * h[e] * fmaf(g[e], gelu_pdf(g[e]), cdf);
+      }
+      typename E::storage *q = gy + rows[u] * ldgy + cols[u];
+      store8<E>(q, dh);
+      store8<E>(q + (int64_t)c8 * 8, dg);
+    }
+  }
+}
+
+static inline bool aligned_for(const void *p, int dt) { return ((uintptr_t)p % (dt == LORA_AMD_F32 ? 32 : 16)) == 0; }
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+extern "C" size_t lora_amd_groupnorm_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups) {
+  const GnGeo q = gn_geo(B, C, HW, groups);
+  return q.ok ? (size_t)B * groups * q.S * 2 * sizeof(float) : 0;
+}
+
+extern "C" int lora_amd_groupnorm_supported(int32_t B, int32_t C, int32_t HW, int32_t groups) {
+  return gn_geo(B, C, HW, groups).ok ? 1 : 0;
+}
+
+#define GN_CHECKS(name)                                                                                              \
+  const GnGeo q = gn_geo(B, C, HW, groups);                                                                          \
+  LORA_AMD_CHECK(q.ok, LORA_AMD_EINVAL, name ": geometry B=%d C=%d HW=%d groups=%d not supported", B, C, HW, groups); \
+  LORA_AMD_CHECK(dtype_ok(dtype), LORA_AMD_EINVAL, name ": bad dtype %d", dtype);                                    \
+  LORA_AMD_CHECK(workspace_bytes >= lora_amd_groupnorm_workspace(B, C, HW, groups), LORA_AMD_EWORKSPACE,             \
+                 name ": workspace %zu < %zu bytes", workspace_bytes, lora_amd_groupnorm_workspace(B, C, HW, groups)); \
+  const dim3 grid((unsigned)((int64_t)B * groups * q.S)), block(kHT);                                                \
+  hipStream_t st = (hipStream_t)stream;                                                                              \
+  float *part = reinterpret_cast<float *>(workspace)
+
+extern "C" int lora_amd_groupnorm_fwd(const void *x, const void *gamma, const void *beta, void *y, float *stats,
+                                      void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                      int32_t groups, float eps, int32_t act, int32_t dtype, void *stream) {
+  GN_CHECKS("groupnorm_fwd");
+  LORA_AMD_CHECK(x && gamma && beta && y && stats && workspace, LORA_AMD_EINVAL, "groupnorm_fwd: null pointer");
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(y, dtype), LORA_AMD_EINVAL, "groupnorm_fwd: unaligned tensor");
+#define GO(E)                                                                                                        \
+  {                                                                                                                  \
+    using S = typename E::storage;                                                                                   \
+    hipLaunchKernelGGL((gn_stats_kernel<E>), grid, block, 0, st, (const S *)x, part, groups, q.cpg, HW, q.chunks,    \
+                       q.per_block, q.S);                                                                            \
+    if (act)                                                                                                         \
+      hipLaunchKernelGGL((gn_apply_kernel<E, true>), grid, block, 0, st, (const S *)x, (const S *)gamma,             \
+                         (const S *)beta, (S *)y, part, stats, groups, q.cpg, HW, q.chunks, q.per_block, q.S, eps);  \
+    else                                                                                                             \
+      hipLaunchKernelGGL((gn_apply_kernel<E, false>), grid, block, 0, st, (const S *)x, (const S *)gamma,            \
+                         (const S *)beta, (S *)y, part, stats, groups, q.cpg, HW, q.chunks, q.per_block, q.S, eps);  \
+  }                                                                                                                  \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+  return check_launch("lora_amd_groupnorm_fwd");
+}
+
+extern "C" int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, const void *beta,
+                                      const float *stats, void *dx, void *workspace, size_t workspace_bytes,
+                                      int32_t B, int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype,
+                                      void *stream) {
+  GN_CHECKS("groupnorm_bwd");
+  LORA_AMD_CHECK(x && gout && gamma && beta && stats && dx && workspace, LORA_AMD_EINVAL,
+                 "groupnorm_bwd: null pointer");
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(gout, dtype) && aligned_for(dx, dtype), LORA_AMD_EINVAL,
+                 "groupnorm_bwd: unaligned tensor");
+#define GO2(E, A)                                                                                                    \
+  {                                                                                                                  \
+    using S = typename E::storage;                                                                                   \
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<E, A>), grid, block, 0, st, (const S *)x, (const S *)gout,               \
+                       (const S *)gamma, (const S *)beta, stats, part, groups, q.cpg, HW, q.chunks, q.per_block,     \
+                       q.S);                                                                                         \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<E, A>), grid, block, 0, st, (const S *)x, (const S *)gout,               \
+                       (const S *)gamma, (const S *)beta, stats, part, (S *)dx, groups, q.cpg, HW, q.chunks,         \
+                       q.per_block, q.S);                                                                            \
+  }
+#define GO(E)                  \
+  if (act) GO2(E, true) else GO2(E, false) \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+#undef GO2
+  return check_launch("lora_amd_groupnorm_bwd");
+}
+
+#define GEGLU_CHECKS(name)                                                                                      \
+  LORA_AMD_CHECK(M >= 0 && inner > 0 && inner % 8 == 0, LORA_AMD_EINVAL, name ": bad shape M=%lld inner=%d",     \
+                 (long long)M, inner);                                                                          \
+  LORA_AMD_CHECK(dtype_ok(dtype), LORA_AMD_EINVAL, name ": bad dtype %d", dtype);                                \
+  if (M == 0) return LORA_AMD_OK;                                                                               \
+  hipStream_t st = (hipStream_t)stream;                                                                         \
+  const int c8 = inner / 8;                                                                                     \
+  const int64_t total = M * c8;                                                                                 \
+  LORA_AMD_CHECK(total < (1ll << 31), LORA_AMD_EINVAL, name ": M * inner / 8 = %lld exceeds 2^31", (long long)total)
+
+extern "C" int lora_amd_geglu_fwd(const void *y, int64_t ldy, void *out, int64_t ldo, int64_t M, int32_t inner,
+                                  int32_t dtype, void *stream) {
+  GEGLU_CHECKS("geglu_fwd");
+  LORA_AMD_CHECK(y && out, LORA_AMD_EINVAL, "geglu_fwd: null pointer");
+  LORA_AMD_CHECK(ldy >= 2 * (int64_t)inner && ldo >= inner && ldy % 8 == 0 && ldo % 8 == 0 && aligned_for(y, dtype) &&
+                     aligned_for(out, dtype),
+                 LORA_AMD_EINVAL, "geglu_fwd: rows must be 16-byte aligned (ldy=%lld ldo=%lld)", (long long)ldy,
+                 (long long)ldo);
+  const dim3 grid((unsigned)((total + kHT * kHU - 1) / (kHT * kHU))), block(kHT);
+#define GO(E)                                                                                                    \
+  hipLaunchKernelGGL((geglu_fwd_kernel<E>), grid, block, 0, st, (const typename E::storage *)y, ldy,             \
+                     (typename E::storage *)out, ldo, M, c8);                                                    \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+  return check_launch("lora_amd_geglu_fwd");
+}
+
+extern "C" int lora_amd_geglu_bwd(const void *y, int64_t ldy, const void *gout, int64_t ldg, void *gy, int64_t ldgy,
+                                  int64_t M, int32_t inner, int32_t dtype, void *stream) {
+  GEGLU_CHECKS("geglu_bwd");
+  LORA_AMD_CHECK(y && gout && gy, LORA_AMD_EINVAL, "geglu_bwd: null pointer");
+  LORA_AMD_CHECK(ldy >= 2 * (int64_t)inner && ldgy >= 2 * (int64_t)inner && ldg >= inner && ldy % 8 == 0 &&
+                     ldgy % 8 == 0 && ldg % 8 == 0 && aligned_for(y, dtype) && aligned_for(gout, dtype) &&
+                     aligned_for(gy, dtype),
+                 LORA_AMD_EINVAL, "geglu_bwd: rows must be 16-byte aligned");
+  const dim3 grid((unsigned)((total + kHT * 2 - 1) / (kHT * 2))), block(kHT);
+#define GO(E)                                                                                                    \
+  hipLaunchKernelGGL((geglu_bwd_kernel<E>), grid, block, 0, st, (const typename E::storage *)y, ldy,             \
+                     (const typename E::storage *)gout, ldg, (typename E::storage *)gy, ldgy, M, c8);            \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+  return check_launch("lora_amd_geglu_bwd");
+}

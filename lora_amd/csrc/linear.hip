@@ -115,8 +115,10 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
         for (int cb = l; cb < c8; cb += L * U) {
           float xv[U][8];
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (cb + u * L < c8) load8<EX>(xr + (cb + u * L) * 8, xv[u]);
+          for (int u = 0; u < U; ++u) {  // clamped address + select: all U loads in flight (common.hpp)
+            const int cc = cb + u * L;
+            load8_sel<EX>(xr + (cc < c8 ? cc : cb) * 8, cc < c8, xv[u]);
+          }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int cc = cb + u * L;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void rank_update_kernel(
     for (int u = 0; u < U; ++u) {
       ok[u] = (c + u * kThreads) < nchunk;
       rls[u] = rl; ccs[u] = cc;
-      if (ok[u]) load8<EY>(y + (row0 + rl) * ldy + col0 + cc * 8, v[u]);
+      load8_sel<EY>(y + (row0 + (ok[u] ? rl : rls[0])) * ldy + col0 + (ok[u] ? cc : ccs[0]) * 8, ok[u], v[u]);
       rl += dq; cc += dr;
       if (cc >= c8) { cc -= c8; ++rl; }
     }
@@ -295,13 +297,14 @@ __global__ __launch_bounds__(kThreads) void rank_update_generic_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// colreduce, stage 1: block = (row block, column tile of <= 256 chunks).  Thread t
-// owns chunk column t % c8 and row slot t / c8, walks its rows accumulating
-// acc[RT][8]; the row slots are then summed through LDS and the block's partial
-// [RT][ncols] goes to the workspace.  Stage 2 sums partials over row blocks.
+// colreduce, stage 1: block = (row block, column tile of <= 64 chunks: one wave
+// reads one contiguous 1-2 KB run per row).  Thread t owns chunk column t % c8 and
+// row slot t / c8 (>= 4 slots), walks its rows accumulating acc[RT][8]; the row
+// slots are then summed through LDS and the block's partial [RT][ncols] goes to
+// the workspace.  Stage 2 sums partials over row blocks.
 // ---------------------------------------------------------------------------
 constexpr int kColRowsPerBlock = 64;
-constexpr int kColMaxChunks = 256;
+constexpr int kColMaxChunks = 64;
 
 template <class EX, int RT, bool MASKED>
 __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
@@ -339,8 +342,10 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
     for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
       float xv[U][8];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (rb0 + u * nslots < nrows) load8<EX>(x + (m0 + rb0 + u * nslots) * ldx + col0 + cc * 8, xv[u]);
+      for (int u = 0; u < U; ++u) {
+        const int rl = rb0 + u * nslots;
+        load8_sel<EX>(x + (m0 + (rl < nrows ? rl : rb0)) * ldx + col0 + cc * 8, rl < nrows, xv[u]);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int rl = rb0 + u * nslots;
@@ -391,19 +396,41 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
   }
 }
 
-// stage 2: D[j,k] = beta*D + scale * sum_b partial[b][j][k]  (j in [rank0, rank0+RT))
+// stage 2: D[j,k] = beta*D + scale * sum_b partial[b][j][k]  (j in [rank0, rank0+RT)).
+// Block = 64 consecutive (j,k) elements x 4 waves; wave w sums row blocks w, w+4, ... (8 loads in
+// flight per lane), the four wave sums meet in LDS.
 __global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
     const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
     int RT, int rank0, int out_layout, float scale, float beta) {
+  __shared__ float s_sum[kThreads];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t total = (int64_t)RT * K;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ic = i < total ? i : total - 1;
+  const int64_t stride = total;  // floats between consecutive row blocks
+  constexpr int U = 8;
+  float sum = 0.f;
+  for (int64_t b = wave; b < nblocks; b += 4 * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t bb = b + 4 * u;
+      const float x = partial[(bb < nblocks ? bb : b) * stride + ic];
+      v[u] = bb < nblocks ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum += v[u];
+  }
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  if (wave == 0 && i < total) {
+    sum = (s_sum[lane] + s_sum[64 + lane]) + (s_sum[128 + lane] + s_sum[192 + lane]);
     const int j = (int)(i / K);
     const int k = (int)(i - (int64_t)j * K);
-    if (rank0 + j >= r) continue;
-    float sum = 0.f;
-    for (int64_t b = 0; b < nblocks; ++b) sum += partial[(b * RT + j) * K + k];
-    const int64_t o = out_layout == LORA_AMD_FACTOR_RK ? (int64_t)(rank0 + j) * K + k : (int64_t)k * r + rank0 + j;
-    d[o] = (beta == 0.f ? 0.f : beta * d[o]) + scale * sum;
+    if (rank0 + j < r) {
+      const int64_t o = out_layout == LORA_AMD_FACTOR_RK ? (int64_t)(rank0 + j) * K + k : (int64_t)k * r + rank0 + j;
+      d[o] = (beta == 0.f ? 0.f : beta * d[o]) + scale * sum;
+    }
   }
 }
 
@@ -559,7 +586,7 @@ static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d
     }
     }
 #undef CR
-    int grid2 = (int)std::min<int64_t>(((int64_t)RT * K + kThreads - 1) / kThreads, 1024);
+    const int grid2 = (int)(((int64_t)RT * K + 63) / 64);
     hipLaunchKernelGGL(colreduce_stage2_kernel, dim3(grid2), dim3(kThreads), 0, st, partial, d, nrb, K, r, RT,
                        rank0, out_layout, scale, beta);
   }

@@ -1,0 +1,79 @@
+"""Fused normalisation / activation passes of the frozen stand-in UNet (``csrc/hostops.hip``).
+
+The reference's training step runs diffusers' UNet through ATen (`train_lora_dreambooth.py:838-892`); between the
+adapted sites that is GroupNorm -> SiLU (4 + 5 launches fwd/bwd, two extra saved tensors) and the GEGLU gate behind the
+adapted ``proj`` (chunk, gelu, mul; gelu_backward, 2 mul, cat).  On a device with the HIP library these run as
+2 + 2 and 1 + 1 launches that save only the block input (and [B, G] statistics).
+
+The affine parameters of the host model are frozen in LoRA training; when they do require grad, when the tensor is
+not NCHW-contiguous, or on CPU, the ATen sequence runs instead (same mathematics).  ``LORA_AMD_HOSTOPS=0`` forces
+that path everywhere (A/B measurements).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _C
+
+_ENABLED = os.environ.get("LORA_AMD_HOSTOPS", "1") != "0"
+_DTYPES = (torch.bfloat16, torch.float16, torch.float32)
+
+
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups: int, eps: float, act: bool):
+        y, stats = _C.groupnorm_fwd(x, weight, bias, groups, eps, act)
+        ctx.save_for_backward(x, weight, bias, stats)
+        ctx.groups, ctx.act = groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, bias, stats = ctx.saved_tensors
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _C.groupnorm_bwd(x, gout.contiguous(), weight, bias, stats, ctx.groups, ctx.act)
+        return dx, None, None, None, None, None
+
+
+def _gn_native(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
+    if not (_ENABLED and x.is_cuda and x.dim() >= 3 and x.dtype in _DTYPES and x.is_contiguous()):
+        return False
+    w, b = norm.weight, norm.bias
+    if w is None or b is None or w.requires_grad or b.requires_grad or w.dtype != x.dtype or b.dtype != x.dtype:
+        return False
+    B, C = x.shape[0], x.shape[1]
+    return _C.groupnorm_workspace(B, C, x.numel() // (B * C), norm.num_groups) > 0
+
+
+def group_norm_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True) -> torch.Tensor:
+    """``silu(norm(x))`` (``act``) or ``norm(x)`` — ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm."""
+    if _gn_native(x, norm):
+        return _GroupNormAct.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
+    y = norm(x)
+    return F.silu(y) if act else y
+
+
+class _Geglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return _C.geglu_fwd(y)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (y,) = ctx.saved_tensors
+        return _C.geglu_bwd(y, gout.contiguous())
+
+
+def geglu(y: torch.Tensor) -> torch.Tensor:
+    """``h * gelu(gate)`` for ``y = [h | gate]`` along the last dimension (GEGLU.forward after ``proj``)."""
+    if (_ENABLED and y.is_cuda and y.dtype in _DTYPES and y.is_contiguous() and y.shape[-1] % 16 == 0
+            and y.numel() > 0 and y.data_ptr() % 32 == 0):
+        return _Geglu.apply(y)
+    h, gate = y.chunk(2, dim=-1)
+    return h * F.gelu(gate)

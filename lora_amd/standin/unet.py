@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import sdpa
+from .fused import geglu, group_norm_act
 from torch.utils.checkpoint import checkpoint
 
 
@@ -86,8 +87,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
-        return h * F.gelu(gate)
+        return geglu(self.proj(x))  # h * gelu(gate): one launch each way behind the adapted proj (fused.py)
 
 
 class FeedForward(nn.Module):
@@ -129,7 +129,7 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x))
+        h = self.proj_in(group_norm_act(x, self.norm, act=False))
         nhwc = h.is_contiguous(memory_format=torch.channels_last)
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are channels_last (NHWC)
         for blk in self.transformer_blocks:
@@ -154,9 +154,9 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
-        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = self.conv1(group_norm_act(x, self.norm1))  # GroupNorm + SiLU: two launches each way (fused.py)
         h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        h = self.conv2(self.dropout(group_norm_act(h, self.norm2)))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
@@ -326,7 +326,7 @@ class UNet2DConditionModel(nn.Module):
             n = len(blk.resnets)
             take, skips = skips[-n:], skips[:-n]
             h = self._run(blk, h, take, temb, encoder_hidden_states)
-        return UNetOutput(self.conv_out(self.conv_act(self.conv_norm_out(h))))
+        return UNetOutput(self.conv_out(group_norm_act(h, self.conv_norm_out)))
 
 
 def sd15_unet(**kw) -> UNet2DConditionModel:

@@ -1,0 +1,144 @@
+"""Frozen host-model fusions (csrc/hostops.hip) against the ATen sequences they replace, evaluated in f32.
+
+Tolerances: f32 tensors rel 1e-4 / abs 2e-5 (fast exp / rcp, A&S erf: <= 1.5e-7 absolute); bf16 / f16 outputs one
+rounding of the f32 result (rel 2^-7 / 2^-10) plus the same absolute floor scaled to the data.
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from lora_amd import _C
+from lora_amd.standin import fused
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: (1e-4, 2e-5), torch.bfloat16: (2.0 ** -7, 2e-2), torch.float16: (2.0 ** -10, 2e-3)}
+
+
+def _close(got, want, dt, scale=1.0, msg=""):
+    rtol, atol = TOL[dt]
+    torch.testing.assert_close(got.float().cpu(), want.float().cpu(), rtol=rtol, atol=atol * scale, msg=lambda m: f"{msg}: {m}")
+
+
+GN_SHAPES = [(4, 320, 64, 64, 32), (2, 640, 32, 32, 32), (2, 1280, 8, 8, 32), (1, 960, 16, 16, 32), (3, 64, 4, 6, 8),
+             (2, 32, 8, 8, 32), (1, 1920, 48, 48, 32), (2, 96, 2, 4, 3)]
+
+
+@pytest.mark.parametrize("B,C,H,W,G", GN_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_act_forward_backward(B, C, H, W, G, dt, act):
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    # per-channel offsets several sigma wide: the statistics must not lose them to cancellation
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + torch.randn(1, C, 1, 1, generator=g) * 3.0).to(dt).to(DEV)
+    norm = nn.GroupNorm(G, C, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(B, C, H, W, generator=g).to(dt).to(DEV)
+    assert fused._gn_native(x, norm), "geometry expected on the HIP path"
+
+    xg = x.clone().requires_grad_(True)
+    y = fused.group_norm_act(xg, norm, act)
+    y.backward(gout)
+
+    xr = x.float().requires_grad_(True)
+    yr = F.group_norm(xr, G, norm.weight.float(), norm.bias.float(), norm.eps)
+    if act:
+        yr = F.silu(yr)
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
+
+
+def test_groupnorm_statistics_and_fallbacks():
+    x = torch.randn(2, 64, 8, 8, device=DEV) * 2 + 5
+    norm = nn.GroupNorm(8, 64).to(DEV).requires_grad_(False)
+    y, stats = _C.groupnorm_fwd(x, norm.weight, norm.bias, 8, norm.eps, False)
+    xg = x.view(2, 8, -1)
+    torch.testing.assert_close(stats[:, 0], xg.mean(-1).reshape(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[:, 1], (xg.var(-1, unbiased=False) + norm.eps).rsqrt().reshape(-1), rtol=1e-5, atol=1e-6)
+    # no gradient requested for x -> backward skipped, still usable under no_grad
+    with torch.no_grad():
+        _close(fused.group_norm_act(x, norm, True), F.silu(norm(x)), torch.float32)
+    # HW % 8 != 0, trainable affine, channels_last and CPU tensors take the ATen sequence
+    assert not fused._gn_native(torch.randn(1, 32, 6, 6, device=DEV), nn.GroupNorm(8, 32).to(DEV).requires_grad_(False))
+    assert not fused._gn_native(x, nn.GroupNorm(8, 64).to(DEV))
+    assert not fused._gn_native(x.contiguous(memory_format=torch.channels_last), norm)
+    assert not fused._gn_native(x.cpu(), norm)
+    t = nn.GroupNorm(8, 64).to(DEV)
+    fused.group_norm_act(x.clone().requires_grad_(True), t, True).sum().backward()
+    assert t.weight.grad is not None and t.bias.grad is not None
+    with pytest.raises(ValueError):
+        _C.groupnorm_fwd(torch.randn(1, 32, 6, 6, device=DEV), norm.weight[:32], norm.bias[:32], 8, 1e-5, True)
+
+
+@pytest.mark.parametrize("shape", [(4, 4096, 2560), (2, 1024, 5120), (3, 77, 64), (1, 1, 16), (5, 333, 48)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float16])
+def test_geglu_forward_backward(shape, dt):
+    g = torch.Generator().manual_seed(sum(shape))
+    y = (torch.randn(*shape, generator=g) * 2.0).to(dt).to(DEV)
+    gout = torch.randn(*shape[:-1], shape[-1] // 2, generator=g).to(dt).to(DEV)
+    yg = y.clone().requires_grad_(True)
+    out = fused.geglu(yg)
+    assert out.shape == gout.shape
+    out.backward(gout)
+
+    yr = y.float().requires_grad_(True)
+    h, gate = yr.chunk(2, dim=-1)
+    outr = h * F.gelu(gate)
+    outr.backward(gout.float())
+    _close(out, outr, dt, msg="forward")
+    _close(yg.grad, yr.grad, dt, scale=float(yr.grad.abs().max()) + 1e-6, msg="gradient")
+
+
+def test_geglu_tails_and_fallback():
+    # gelu tails: the erf approximation must not leak (gate -> -inf gives 0, +inf gives h)
+    gate = torch.tensor([-30.0, -8.0, -1e-3, 0.0, 1e-3, 8.0, 30.0, 1.0], device=DEV)
+    y = torch.cat([torch.full((8,), 2.0, device=DEV), gate]).view(1, 16)
+    torch.testing.assert_close(fused.geglu(y), 2.0 * F.gelu(gate).view(1, 8), rtol=1e-5, atol=3e-7)
+    odd = torch.randn(3, 20, device=DEV)  # inner = 10: not 16-byte friendly -> ATen sequence
+    h, gt = odd.chunk(2, dim=-1)
+    torch.testing.assert_close(fused.geglu(odd), h * F.gelu(gt))
+    with pytest.raises(RuntimeError):
+        _C.geglu_fwd(odd)
+
+
+def test_standin_unet_same_loss_and_gradients_with_and_without_fusions(monkeypatch):
+    """Tiny UNet in f32: the fused passes must reproduce the ATen sequence's loss and adapter gradients."""
+    import lora_amd as L
+    from lora_amd.standin import tiny_unet
+
+    torch.manual_seed(0)
+    unet = tiny_unet().to(DEV)
+    unet.requires_grad_(False)
+    L.inject_trainable_lora(unet, r=4)
+    for _, _, up, down in _iter_adapters(unet):
+        nn.init.normal_(up.weight, std=0.05)
+    lat = torch.randn(2, 4, 16, 16, device=DEV)
+    ctx = torch.randn(2, 7, 32, device=DEV)
+    t = torch.tensor([10, 500], device=DEV)
+
+    def run(enabled):
+        monkeypatch.setattr(fused, "_ENABLED", enabled)
+        for p in unet.parameters():
+            p.grad = None
+        loss = unet(lat, t, ctx).sample.float().pow(2).mean()
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in unet.parameters() if p.requires_grad])
+        return loss.detach(), grads
+
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(g1, g0, rtol=1e-3, atol=1e-5 * float(g0.abs().max()))
+
+
+def _iter_adapters(model):
+    from lora_amd.lora import LoraInjectedLinear
+
+    for name, m in model.named_modules():
+        if isinstance(m, LoraInjectedLinear):
+            yield name, m, m.lora_up, m.lora_down
