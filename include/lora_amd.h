@@ -345,6 +345,14 @@ int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, c
                            const float *stats, void *dx, void *workspace, size_t workspace_bytes, int32_t B,
                            int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream);
 
+/* LayerNorm over the last dimension of row-contiguous x [M, K] (K % 8 == 0, K <= 2560; gamma / beta in the activation
+ * dtype, frozen).  stats [M][2] f32 = (mean, rstd).  One launch each way. */
+int lora_amd_layernorm_supported(int32_t K);
+int lora_amd_layernorm_fwd(const void *x, const void *gamma, const void *beta, void *y, float *stats, int64_t M,
+                           int32_t K, float eps, int32_t dtype, void *stream);
+int lora_amd_layernorm_bwd(const void *x, const void *gout, const void *gamma, const float *stats, void *dx,
+                           int64_t M, int32_t K, int32_t dtype, void *stream);
+
 /* GEGLU gate behind the adapted projection: y [M, 2*inner] = [h | gate]; out [M, inner] = h * gelu(gate) (erf form).
  * Backward writes gy [M, 2*inner] = [gout * gelu(gate) | gout * h * gelu'(gate)] in one pass (no cat). */
 int lora_amd_geglu_fwd(const void *y, int64_t ldy, void *out, int64_t ldo, int64_t M, int32_t inner, int32_t dtype,

@@ -36,6 +36,7 @@ SYMBOLS = (
     "lora_amd_step_advance", "lora_amd_ti_rows_step",
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
     "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
+    "lora_amd_layernorm_supported", "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd",
 )
 
 
@@ -132,8 +133,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_groupnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
     lib.lora_amd_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.lora_amd_layernorm_supported.argtypes = [i32]
+    lib.lora_amd_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
+    lib.lora_amd_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
     for name in ("lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
-                 "lora_amd_geglu_fwd", "lora_amd_geglu_bwd"):
+                 "lora_amd_geglu_fwd", "lora_amd_geglu_bwd", "lora_amd_layernorm_supported",
+                 "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd"):
         getattr(lib, name).restype = C.c_int
     for name in ("lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g",
                  "lora_amd_conv_bwd_x"):
@@ -792,3 +797,30 @@ def geglu_bwd(y: torch.Tensor, gout: torch.Tensor) -> torch.Tensor:
                                         2 * inner, y2.shape[0], inner, dtype_code(y.dtype), _stream()),
            "lora_amd_geglu_bwd")
     return gy
+
+
+def layernorm_supported(K: int) -> bool:
+    return bool(require().lora_amd_layernorm_supported(K))
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LayerNorm over the last dimension of a contiguous x; returns (y, stats [rows, 2] = mean, rstd)."""
+    _dev_check(x, gamma, beta)
+    K = x.shape[-1]
+    M = x.numel() // K
+    y = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                            stats.data_ptr(), M, K, eps, dtype_code(x.dtype), _stream()),
+           "lora_amd_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    _dev_check(x, gout, gamma, stats)
+    K = x.shape[-1]
+    dx = torch.empty_like(x)
+    _check(require().lora_amd_layernorm_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
+                                            dx.data_ptr(), x.numel() // K, K, dtype_code(x.dtype), _stream()),
+           "lora_amd_layernorm_bwd")
+    return dx

@@ -58,6 +58,31 @@ def group_norm_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True) -> tor
     return F.silu(y) if act else y
 
 
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        y, stats = _C.layernorm_fwd(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, stats = ctx.saved_tensors
+        dx = _C.layernorm_bwd(x, gout.contiguous(), weight, stats) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
+
+
+def layer_norm(x: torch.Tensor, norm: nn.LayerNorm) -> torch.Tensor:
+    """``norm(x)`` over the last dimension (BasicTransformerBlock.norm1/2/3): one launch each way."""
+    w, b = norm.weight, norm.bias
+    if (_ENABLED and x.is_cuda and x.dtype in _DTYPES and x.is_contiguous() and x.numel() > 0
+            and len(norm.normalized_shape) == 1 and w is not None and b is not None
+            and not (w.requires_grad or b.requires_grad) and w.dtype == x.dtype and b.dtype == x.dtype
+            and x.data_ptr() % 32 == 0 and _C.layernorm_supported(x.shape[-1])):
+        return _LayerNorm.apply(x, w, b, norm.eps)
+    return norm(x)
+
+
 class _Geglu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y):

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import sdpa
-from .fused import geglu, group_norm_act
+from .fused import geglu, group_norm_act, layer_norm
 from torch.utils.checkpoint import checkpoint
 
 
@@ -113,9 +113,9 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
 
     def forward(self, x, context):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
-        return self.ff(self.norm3(x)) + x
+        x = self.attn1(layer_norm(x, self.norm1)) + x
+        x = self.attn2(layer_norm(x, self.norm2), context) + x
+        return self.ff(layer_norm(x, self.norm3)) + x
 
 
 class Transformer2DModel(nn.Module):
@@ -129,11 +129,24 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.proj_in(group_norm_act(x, self.norm, act=False))
-        nhwc = h.is_contiguous(memory_format=torch.channels_last)
-        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are channels_last (NHWC)
+        n = group_norm_act(x, self.norm, act=False)
+        nhwc = n.is_contiguous(memory_format=torch.channels_last) and not n.is_contiguous()
+        # A 1x1 convolution IS the token-major linear map.  On NCHW activations run it there: one library GEMM with
+        # the bias in its epilogue instead of a MIOpen call wrapped in NCHW<->NHWC transposes plus a strided bias add
+        # (proj_in / proj_out are not adapter sites of the reference's target classes; if they have been replaced,
+        # or the activations are channels_last, keep the convolution).
+        as_linear = (not nhwc and type(self.proj_in) is nn.Conv2d and type(self.proj_out) is nn.Conv2d
+                     and self.proj_in.kernel_size == (1, 1) and self.proj_out.kernel_size == (1, 1))
+        if as_linear:
+            h = n.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = F.linear(h, self.proj_in.weight.view(C, C), self.proj_in.bias)
+        else:
+            h = self.proj_in(n).permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are NHWC
         for blk in self.transformer_blocks:
             h = blk(h, context)
+        if as_linear:
+            h = F.linear(h, self.proj_out.weight.view(C, C), self.proj_out.bias)
+            return h.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous() + x
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         if not nhwc:
             h = h.contiguous()

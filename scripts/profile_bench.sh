@@ -8,7 +8,7 @@ OUT=gpurun_out
 export TMPDIR=/tmp
 export LORA_AMD_TUNE_CACHE=/tmp/lora_amd_tune_${TAG}.json   # the warm run times the candidates, the traced run re-uses them
 mkdir -p $OUT
-ARGS="--steps 5 --warmup 3 --no-cpu-baseline"
+ARGS="--steps 5 --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-}"
 ONLY=${2:-all}
 if [ "$ONLY" != "pmc" ]; then
 # 1. un-profiled run first: fills MIOpen's find cache (a cold MIOpen under the profiler falls back to naive convs)

@@ -94,6 +94,54 @@ def test_geglu_forward_backward(shape, dt):
     _close(yg.grad, yr.grad, dt, scale=float(yr.grad.abs().max()) + 1e-6, msg="gradient")
 
 
+@pytest.mark.parametrize("shape", [(4, 4096, 320), (4, 1024, 640), (2, 256, 1280), (3, 77, 768), (1, 5, 8), (7, 33, 2560),
+                                   (2, 9, 1024)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float16])
+def test_layernorm_forward_backward(shape, dt):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 1.5 + torch.randn(shape[-1], generator=g) * 2.0).to(dt).to(DEV)
+    norm = nn.LayerNorm(shape[-1]).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(shape[-1], generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(shape[-1], generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(*shape, generator=g).to(dt).to(DEV)
+    xg = x.clone().requires_grad_(True)
+    y = fused.layer_norm(xg, norm)
+    assert type(y.grad_fn).__name__ == "_LayerNormBackward", "expected the HIP path"
+    y.backward(gout)
+    xr = x.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (shape[-1],), norm.weight.float(), norm.bias.float(), norm.eps)
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
+
+
+def test_layernorm_fallbacks():
+    x = torch.randn(4, 10, 100, device=DEV)  # K % 8 != 0
+    n = nn.LayerNorm(100).to(DEV).requires_grad_(False)
+    torch.testing.assert_close(fused.layer_norm(x, n), n(x))
+    assert not _C.layernorm_supported(100) and not _C.layernorm_supported(4096) and _C.layernorm_supported(2560)
+    t = nn.LayerNorm(64).to(DEV)  # trainable affine -> ATen (its gradients must exist)
+    fused.layer_norm(torch.randn(3, 64, device=DEV, requires_grad=True), t).sum().backward()
+    assert t.weight.grad is not None
+
+
+def test_transformer2d_linear_projection_equals_conv(monkeypatch):
+    from lora_amd.standin.unet import Transformer2DModel
+
+    torch.manual_seed(0)
+    m = Transformer2DModel(64, 2, 32, groups=8).to(DEV).requires_grad_(False)
+    x = torch.randn(2, 64, 8, 8, device=DEV, requires_grad=True)
+    ctx = torch.randn(2, 7, 32, device=DEV)
+    y1 = m(x, ctx)
+    (g1,) = torch.autograd.grad(y1.square().sum(), x)
+    y0 = m(x.contiguous(memory_format=torch.channels_last), ctx)  # channels_last keeps the convolutions
+    (g0,) = torch.autograd.grad(y0.square().sum(), x)
+    torch.testing.assert_close(y1, y0.contiguous(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(g1, g0.contiguous(), rtol=1e-3, atol=1e-4)
+
+
 def test_geglu_tails_and_fallback():
     # gelu tails: the erf approximation must not leak (gate -> -inf gives 0, +inf gives h)
     gate = torch.tensor([-30.0, -8.0, -1e-3, 0.0, 1e-3, 8.0, 30.0, 1.0], device=DEV)
