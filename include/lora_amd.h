@@ -190,6 +190,13 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
                           int32_t nct_g, const void *down, const float *sel, float *down_part, int64_t M,
                           int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype, void *stream);
 
+/* Both factor-gradient partials in ONE launch, for sites whose input gradient and Gt [M, r] came out of
+ * lora_amd_linear_gemm_fwd (factor_layout 3): up_part as in lora_amd_linear_bwd_g (with T scaled by `scale`),
+ * down_part as in lora_amd_linear_bwd_x with dx = NULL and one Gt part (`sel` [r, r] or NULL).  No dropout. */
+int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
+                                int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
+                                int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, void *stream);
+
 /* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, and
  * t_out[M,r] (f32) = t_scale * X down^T for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch
  * of lora.py:53-58 (no dropout, no selector: those keep lora_amd_linear_fwd).  bf16/f16 X, W, bias, Y; f32 factors;

@@ -30,6 +30,7 @@ SYMBOLS = (
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
+    "lora_amd_linear_bwd_factors",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
@@ -115,6 +116,8 @@ def _declare(lib: C.CDLL) -> None:
                                         u64, vp]
     lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp]
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]
+    lib.lora_amd_linear_bwd_factors.restype = C.c_int
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
     lib.lora_amd_linear_gemm_supported.argtypes = [i64, i32, i32, i32, i32]
     lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32,
@@ -449,6 +452,17 @@ def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Ten
                                            dtype_code(down.dtype), _stream()), "lora_amd_linear_bwd_x")
 
 
+def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, x: torch.Tensor, gt: torch.Tensor,
+                       down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None) -> None:
+    """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it)."""
+    _dev_check(g, t, up_part, x, gt, down_part, sel)
+    _check(require().lora_amd_linear_bwd_factors(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
+                                                 x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
+                                                 down_part.data_ptr(), g.shape[0], x.shape[1], g.shape[1], r,
+                                                 dtype_code(g.dtype), float(scale), _stream()),
+           "lora_amd_linear_bwd_factors")
+
+
 def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, float, float]],
                       device) -> Tuple[torch.Tensor, int, int]:
     """rows: (part, out, nparts, RT, C, r, layout, scale, beta) -> (device table, n, total work items)."""
@@ -680,7 +694,7 @@ _gemm_choice_bwd = _TuneCache("gemm_bwd")
 def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: torch.Tensor, down: torch.Tensor,
                     up: torch.Tensor, scale: float, bufs) -> int:
     """As :func:`gemm_choice` for the backward of a site: 0 = G pass + library GEMM + X/dX pass, else the tile of the
-    fused MFMA dX kernel (then: fused dX/Gt launch + dUp-only G pass + dDown-only X pass)."""
+    fused MFMA dX kernel (then: fused dX/Gt launch + ONE launch for the dUp / dDown partials)."""
     env = os.environ.get("LORA_AMD_GEMM_BWD", os.environ.get("LORA_AMD_GEMM"))
     if env is not None:
         return int(env)
@@ -703,8 +717,7 @@ def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: t
             linear_bwd_x(x, dx, gt_part, plan.nct_g, down, None, down_part)
         else:
             dx, gt = linear_gemm_dx(g, wt, down, up, scale, tile)
-            linear_bwd_g(g, t, up, None, up_part, scale, 0.0, 0, 0)
-            linear_bwd_x(x, None, gt, 1, down, None, down_part)
+            linear_bwd_factors(g, t, up_part, x, gt, down_part, r, scale)
 
     best, best_t = 0, float("inf")
     for tile in (0,) + GEMM_TILES:

@@ -492,6 +492,79 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
   slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, down_part + (int64_t)rb * RT * K, K, ct * ct8 * 8);
 }
 
+// ============================================================================ backward, both factor gradients
+// When the input gradient and Gt came out of the fused MFMA launch (gemm_fused.hip), what is left of the backward are
+// two outer-product column sums of the same shape:
+//   up_part[rb][RT][N]   = sum over the block's rows of (scale * T)[m, j]  * G[m, n]
+//   down_part[rb][RT][K] = sum over the block's rows of (Gt @ S)[m, j]     * X[m, k]
+// ONE launch runs both: workgroups [0, a.nblocks) stream G, the rest stream X (no dropout here: the fused MFMA
+// launch does not take it).
+struct FactorJob {
+  const void *data;      // [M, C] activations
+  int64_t ld;
+  const float *rowvec;   // [M, r] f32
+  const float *sel;      // [r, r] applied to the row vectors (X job), or null
+  float *part;           // [nrb][RT][C]
+  float mult;
+  int C, log_ct8, nct, rows_per_block, nblocks;
+};
+
+template <class E, int RT>
+__global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, FactorJob b, int64_t M, int r) {
+  __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  const bool first = (int)blockIdx.x < a.nblocks;
+  const int bid = first ? (int)blockIdx.x : (int)blockIdx.x - a.nblocks;
+  const typename E::storage *data = reinterpret_cast<const typename E::storage *>(first ? a.data : b.data);
+  const int64_t ld = first ? a.ld : b.ld;
+  const float *rowvec = first ? a.rowvec : b.rowvec;
+  const float *sel = first ? a.sel : b.sel;
+  float *part = first ? a.part : b.part;
+  const float mult = first ? a.mult : b.mult;
+  const int C = first ? a.C : b.C, log_ct8 = first ? a.log_ct8 : b.log_ct8, nct = first ? a.nct : b.nct;
+  const int rows_per_block = first ? a.rows_per_block : b.rows_per_block;
+
+  const int tid = threadIdx.x;
+  const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
+  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
+  const int64_t rb = bid / nct;
+  const int ct = (int)(bid - rb * nct);
+  const int64_t m0 = rb * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int col = (ct * ct8 + cl) * 8;
+
+  stage_rowvecs<RT>(s_t, rowvec, 1, 0, m0, nrows, r, sel, 1, mult);
+  __syncthreads();
+
+  float acc[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+
+  constexpr int U = 4;
+  for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + col, rl < nrows, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      const float *tr = s_t + (rl < nrows ? rl : 0) * RT;  // rows past the end contribute v = 0
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float tj = tr[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, v[u][i], acc[j][i]);
+      }
+    }
+  }
+  slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, part + (int64_t)rb * RT * C, C, ct * ct8 * 8);
+}
+
 // ============================================================================ batched partial reduction
 // out (f32; [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c].  One launch for every descriptor.
 __global__ __launch_bounds__(kFT) void reduce_batched_kernel(const lora_amd_reduce_desc *__restrict__ descs, int n,
@@ -705,6 +778,33 @@ extern "C" int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64
 #undef BX_RT
 #undef BX
   return check_launch("lora_amd_linear_bwd_x");
+}
+
+extern "C" int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
+                                           int64_t ldx, const float *gt, const float *sel, float *down_part,
+                                           int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
+                                           void *stream) {
+  FUSED_COMMON("linear_bwd_factors", act_dtype, LORA_AMD_F32);
+  LORA_AMD_CHECK(g && t && up_part && x && gt && down_part, LORA_AMD_EINVAL, "linear_bwd_factors: null pointer");
+  LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4 && aligned_ok(x, ldx, K, act_dtype) &&
+                     pow2_divisor(K / 8, 256) >= 4,
+                 LORA_AMD_EINVAL, "linear_bwd_factors: shape/alignment not supported (see lora_amd_linear_plan)");
+  const int RT = frank_tile(r);
+  const BwdGeom qg = bwd_geom(M, N, RT, 64), qx = bwd_geom(M, K, RT, 256);
+  FactorJob a{g, ldg, t, nullptr, up_part, scale, N, qg.log_ct8, qg.nct, qg.rows_per_block, (int)(qg.nrb * qg.nct)};
+  FactorJob b{x, ldx, gt, sel, down_part, 1.0f, K, qx.log_ct8, qx.nct, qx.rows_per_block, (int)(qx.nrb * qx.nct)};
+  const unsigned grid = (unsigned)(a.nblocks + b.nblocks);
+  hipStream_t st = (hipStream_t)stream;
+#define BF(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a, b, M, r)
+#define BF_E(E) do { if (RT == 4) BF(E, 4); else if (RT == 8) BF(E, 8); else BF(E, 16); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: BF_E(f32_t); break;
+    case LORA_AMD_F16: BF_E(f16_t); break;
+    default: BF_E(bf16_t); break;
+  }
+#undef BF_E
+#undef BF
+  return check_launch("lora_amd_linear_bwd_factors");
 }
 
 extern "C" int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total,

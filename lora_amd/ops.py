@@ -171,11 +171,10 @@ class LoraLinearFunction(torch.autograd.Function):
                     and weight.is_contiguous() and _C.gemm_supported(g2, _C.weight_t(weight), K, r)):
                 tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
             if tile:
-                # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch on the resident W^T; the two light passes
-                # that remain only produce the parameter-gradient partials
+                # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch on the resident W^T; what remains are the
+                # parameter-gradient partials (G^T T and Gt^T X), both in one more launch
                 dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
-                _C.linear_bwd_g(g2, t, up_c, None, up_part, s, 0.0, 0, 0)
-                _C.linear_bwd_x(x2, None, gt, 1, down_c, None, down_part)
+                _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s)
             else:
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
                 dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM

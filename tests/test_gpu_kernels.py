@@ -764,6 +764,10 @@ def test_fused_gemm_input_gradient(M, K, N, r, tile):
         _, ddo, duo, _, _ = O.lora_linear_backward(G, X, W, A, U, s)
         np.testing.assert_allclose(n(d_up), duo, rtol=1e-3, atol=1e-3 * np.abs(duo).max())
         np.testing.assert_allclose(n(d_down), ddo, rtol=1e-3, atol=1e-3 * np.abs(ddo).max())
+        # the ONE-launch form of the same two passes (what the autograd function uses) writes identical partials
+        up_part2, down_part2 = torch.zeros_like(up_part), torch.zeros_like(down_part)
+        _C.linear_bwd_factors(g, t, up_part2, x, gt, down_part2, r, s)
+        assert torch.equal(up_part2, up_part) and torch.equal(down_part2, down_part)
 
 
 def test_fused_gemm_random_shapes_against_device_torch():
