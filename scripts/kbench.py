@@ -174,9 +174,55 @@ def bench_conv(args):
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
+def bench_hostops(args):
+    """GroupNorm(+SiLU), LayerNorm and the GEGLU gate of the frozen UNet: HIP passes vs the ATen sequences (bf16)."""
+    import torch.nn as nn
+
+    from lora_amd.standin import fused
+
+    F = torch.nn.functional
+
+    def both(tag, shape, run_fused, run_aten, nbytes_fwd, nbytes_bwd):
+        res = {"op": tag, "shape": list(shape)}
+        for name, run in (("hip", run_fused), ("aten", run_aten)):
+            fwd, bwd = run()
+            res[f"{name}_fwd_us"] = timeit(fwd, args.iters)[0] * 1e6
+            res[f"{name}_fwd_bwd_us"] = timeit(bwd, args.iters)[0] * 1e6
+        res["hip_fwd_GBs"] = nbytes_fwd / res["hip_fwd_us"] / 1e3
+        res["hip_bwd_GBs"] = nbytes_bwd / max(res["hip_fwd_bwd_us"] - res["hip_fwd_us"], 1e-3) / 1e3
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+
+    for B, C_, H in ((4, 320, 64), (4, 640, 32), (4, 1280, 16), (4, 1280, 8), (4, 960, 64), (4, 2560, 16)):
+        x = torch.randn(B, C_, H, H, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        go = torch.randn_like(x)
+        norm = nn.GroupNorm(32, C_).to(DEV).to(torch.bfloat16).requires_grad_(False)
+        e = x.numel() * 2
+        both("groupnorm_silu", x.shape,
+             lambda: (lambda: fused.group_norm_act(x, norm, True), lambda: fused.group_norm_act(x, norm, True).backward(go)),
+             lambda: (lambda: F.silu(norm(x)), lambda: F.silu(norm(x)).backward(go)), 3 * e, 5 * e)
+    for M, K in ((16384, 320), (4096, 640), (1024, 1280), (256, 1280)):
+        x = torch.randn(4, M // 4, K, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        go = torch.randn_like(x)
+        ln = nn.LayerNorm(K).to(DEV).to(torch.bfloat16).requires_grad_(False)
+        e = x.numel() * 2
+        both("layernorm", x.shape, lambda: (lambda: fused.layer_norm(x, ln), lambda: fused.layer_norm(x, ln).backward(go)),
+             lambda: (lambda: ln(x), lambda: ln(x).backward(go)), 2 * e, 3 * e)
+    for M, inner in ((16384, 1280), (4096, 2560), (1024, 5120), (256, 5120)):
+        y = torch.randn(4, M // 4, 2 * inner, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        go = torch.randn(4, M // 4, inner, device=DEV, dtype=torch.bfloat16)
+        e = M * inner * 2
+
+        def aten():
+            h, g = y.chunk(2, dim=-1)
+            return h * F.gelu(g)
+
+        both("geglu", y.shape, lambda: (lambda: fused.geglu(y), lambda: fused.geglu(y).backward(go)),
+             lambda: (aten, lambda: aten().backward(go)), 3 * e, 5 * e)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="merge,linear,conv")
+    ap.add_argument("--what", default="merge,linear,conv,hostops")
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), flush=True)
@@ -186,3 +232,5 @@ if __name__ == "__main__":
         bench_linear(a)
     if "conv" in a.what:
         bench_conv(a)
+    if "hostops" in a.what:
+        bench_hostops(a)

@@ -98,3 +98,42 @@ def test_tiny_unet_runs_and_checkpoints():
     y2 = u(x, t, ctx).sample
     assert torch.allclose(y, y2, atol=1e-5)  # up = 0 at init: adapters are the identity (ref:51)
     y2.sum().backward()
+
+
+def test_transformer2d_token_major_projection_equals_the_1x1_convolutions():
+    """proj_in / proj_out run as token-major GEMMs on NCHW activations; channels_last keeps the convolutions: same map."""
+    import torch.nn.functional as F
+    from lora_amd.standin.unet import Transformer2DModel
+
+    torch.manual_seed(0)
+    m = Transformer2DModel(32, 2, 16, groups=8)
+    x = torch.randn(2, 32, 4, 6, requires_grad=True)
+    ctx = torch.randn(2, 5, 16)
+    y1 = m(x, ctx)
+    (g1,) = torch.autograd.grad(y1.square().sum(), x)
+    y0 = m(x.contiguous(memory_format=torch.channels_last), ctx)
+    (g0,) = torch.autograd.grad(y0.square().sum(), x)
+    torch.testing.assert_close(y1, y0.contiguous(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, g0.contiguous(), rtol=1e-4, atol=1e-5)
+    # an adapter injected into the projection (custom target class) keeps the module call
+    L.inject_trainable_lora_extended(m, target_replace_module={"Transformer2DModel"}, r=2)
+    assert type(m.proj_in).__name__ == "LoraInjectedConv2d"
+    y2 = m(x, ctx)  # lora_up is zero-initialised: same output through the module path
+    torch.testing.assert_close(y2, y1, rtol=1e-5, atol=1e-5)
+    del F
+
+
+def test_fused_host_passes_fall_back_to_aten_on_cpu():
+    import torch.nn.functional as F
+    from lora_amd.standin import fused
+
+    x = torch.randn(2, 16, 4, 4)
+    gn = nn.GroupNorm(4, 16).requires_grad_(False)
+    torch.testing.assert_close(fused.group_norm_act(x, gn, True), F.silu(gn(x)))
+    torch.testing.assert_close(fused.group_norm_act(x, gn, False), gn(x))
+    ln = nn.LayerNorm(16).requires_grad_(False)
+    t = torch.randn(3, 5, 16)
+    torch.testing.assert_close(fused.layer_norm(t, ln), ln(t))
+    y = torch.randn(3, 5, 32)
+    h, g = y.chunk(2, dim=-1)
+    torch.testing.assert_close(fused.geglu(y), h * F.gelu(g))
