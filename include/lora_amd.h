@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 1
+#define LORA_AMD_ABI_VERSION 2
 
 /* status codes */
 #define LORA_AMD_OK 0
@@ -124,22 +124,22 @@ int lora_amd_rowdot(const void *x, int64_t ldx, const void *factor, void *t_out,
 
 /* Y[M, N] (y_dtype, in place) += scale * mask * T[M, r] (f32) @ F, F given as
  * [r,N] or [N,r].  Dropout (lora.py:45,56): keep-probability 1-p with inverted
- * scaling, generated in-kernel from Philox(seed, offset, element index); p = 0
- * disables it.  The same (seed, offset) reproduces the same mask in rowdot_masked. */
+ * scaling, generated in-kernel from Philox(seed, offset, offset_dev, element index); p = 0
+ * disables it.  The same (seed, offset, offset_dev) reproduces the same mask in rowdot_masked. */
 int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const void *factor,
                          int64_t M, int32_t N, int32_t r, int32_t y_dtype,
                          int32_t factor_dtype, int32_t factor_layout,
                          float scale, float dropout_p, uint64_t seed,
-                         uint64_t offset, void *stream);
+                         uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* As lora_amd_rowdot but X is first multiplied elementwise by the dropout mask
- * of (seed, offset, p): the backward of a dropped-out rank_update. */
+ * of (seed, offset, offset_dev, p): the backward of a dropped-out rank_update. */
 int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *factor,
                            void *t_out, int64_t M, int32_t K, int32_t r,
                            int32_t x_dtype, int32_t factor_dtype,
                            int32_t factor_layout, float scale, const float *sel,
                            int32_t sel_transposed, float dropout_p,
-                           uint64_t seed, uint64_t offset, void *stream);
+                           uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* D (f32) = beta * D + scale * sum_m T[m, j] * mask * X[m, k]; D is [r,K] or
  * [K,r] per out_layout.  Two-stage reduction through `workspace` (bytes given
@@ -148,7 +148,7 @@ size_t lora_amd_colreduce_workspace(int64_t M, int32_t K, int32_t r);
 int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out,
                        int64_t M, int32_t K, int32_t r, int32_t x_dtype,
                        int32_t out_layout, float scale, float beta,
-                       float dropout_p, uint64_t seed, uint64_t offset,
+                       float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
@@ -175,14 +175,14 @@ int lora_amd_linear_plan(int64_t M, int32_t K, int32_t N, int32_t r, lora_amd_li
 int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, const void *down,
                         const void *up, float *t_out, int64_t M, int32_t K, int32_t N, int32_t r,
                         int32_t act_dtype, int32_t factor_dtype, float scale, const float *sel,
-                        float dropout_p, uint64_t seed, uint64_t offset, void *stream);
+                        float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* One pass over G[M,N]: gt_part[nct_g][M][r] = scale * (mask*G) @ up (per column tile) and
  * up_part[nparts_up][RT][N] = scale * (mask*G)^T @ T (per row block).  gt_part may be NULL (dUp partials only). */
 int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
                           float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
                           int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
-                          uint64_t offset, void *stream);
+                          uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* One pass over X[M,K] (and dX, in place, holding G @ W; may be NULL): with Gt' = (sum gt_part) @ S,
  * down_part[nparts_down][RT][K] = Gt'^T @ X (per row block) and dX += Gt' @ down. */
@@ -266,14 +266,14 @@ int lora_amd_conv_down_fwd(const void *x, const void *down, const float *sel, fl
  * up: [C_out, r].  Dropout as lora_amd_rank_update, element index = NCHW offset of Y. */
 int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int32_t B, int32_t C_out, int32_t H, int32_t W,
                          int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p,
-                         uint64_t seed, uint64_t offset, void *stream);
+                         uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* One pass over G[B, C_out, H, W]: gt_out[B, r, H, W] (f32) = S^T (scale * up^T (mask*G)) and
  * up_part[ngroups_out][rank_pad][C_out] = scale * sum over the group's pixels of (mask*G) T. */
 int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up, const float *sel, float *gt_part,
                         float *gt_out, float *up_part, int32_t B, int32_t C_out, int32_t H, int32_t W, int32_t r,
                         int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
-                        uint64_t offset, void *stream);
+                        uint64_t offset, const uint64_t *offset_dev, void *stream);
 
 /* One pass over X[B, C_in, H, W] (and dX in place, holding the frozen conv's input gradient; may be NULL):
  * down_part[ngroups_in][rank_pad][C_in*ks*ks] = sum over the group's pixels of Gt' (x) patches(X), and
@@ -314,13 +314,24 @@ int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *exp_avg_sq,
                         int64_t step, int32_t zero_grad, void *stream);
 
 /* hipGraph-replayable form: the 1-based step is read from device memory, so a captured
- * launch is identical from step to step; lora_amd_step_advance does step_dev[0] += 1. */
+ * launch is identical from step to step; lora_amd_step_advance does step_dev[0] += 1.
+ * `scaler` (NULL = off): the 4-float loss-scaling state lora_amd_loss_scale_update maintains; the gradient is
+ * additionally multiplied by scaler[2] and the whole update is skipped (grads still zeroed) when scaler[3] == 0. */
 int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float *exp_avg_sq,
                             int64_t n, const lora_amd_adamw_group *groups_dev,
                             int32_t n_groups, const float *sumsq, float grad_scale,
                             float max_norm, float beta1, float beta2, float eps,
-                            const int64_t *step_dev, int32_t zero_grad, void *stream);
+                            const int64_t *step_dev, const float *scaler, int32_t zero_grad, void *stream);
 int lora_amd_step_advance(int64_t *step_dev, void *stream);
+
+/* Dynamic fp16 loss scaling on the device (the GradScaler accelerate wraps around the reference's step when
+ * mixed_precision="fp16", train_lora_dreambooth.py:489-494).  state = {scale for the next backward, finite-step
+ * count, 1/scale of the step being applied, finite flag}.  Call after lora_amd_sumsq of the scaled (all-reduced)
+ * gradient and before lora_amd_clip_adamw_dev: inf/nan -> scale *= backoff_factor and the update is skipped;
+ * growth_interval finite steps in a row -> scale *= growth_factor.  step_dev (may be NULL) advances only on
+ * applied steps. */
+int lora_amd_loss_scale_update(float *state, const float *sumsq, int64_t *step_dev, float growth_factor,
+                               float backoff_factor, int32_t growth_interval, void *stream);
 
 /* Textual-inversion step of pivotal tuning over the placeholder rows ONLY (replaces cli_lora_pti.py:433-479: AdamW
  * over the whole [vocab, hidden] embedding table, norm decay, restoring every other row).  One launch:

@@ -20,6 +20,7 @@ F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
 ROUND_REFERENCE, ROUND_ONCE = 0, 1
 MAX_RANK = 64
+ABI_VERSION = 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -34,7 +35,7 @@ SYMBOLS = (
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
-    "lora_amd_step_advance", "lora_amd_ti_rows_step",
+    "lora_amd_step_advance", "lora_amd_loss_scale_update", "lora_amd_ti_rows_step",
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
     "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
     "lora_amd_layernorm_supported", "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd",
@@ -95,17 +96,19 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_merge_set_tuning.argtypes = [i64, i64]
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
-                                           f32, u64, u64, vp]
-    lib.lora_amd_rank_update.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+                                           f32, u64, u64, vp, vp]
+    lib.lora_amd_rank_update.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
     lib.lora_amd_colreduce_workspace.argtypes = [i64, i32, i32]
     lib.lora_amd_colreduce_workspace.restype = sz
-    lib.lora_amd_colreduce.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, u64, u64,
+    lib.lora_amd_colreduce.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, u64, u64, vp,
                                        vp, sz, vp]
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
     lib.lora_amd_sumsq_workspace.restype = sz
     lib.lora_amd_sumsq.argtypes = [vp, i64, vp, vp, sz, vp]
     lib.lora_amd_clip_adamw.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, i64, i32, vp]
-    lib.lora_amd_clip_adamw_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, vp, i32, vp]
+    lib.lora_amd_clip_adamw_dev.argtypes = [vp, vp, vp, vp, i64, vp, i32, vp, f32, f32, f32, f32, f32, vp, vp, i32, vp]
+    lib.lora_amd_loss_scale_update.argtypes = [vp, vp, vp, f32, f32, i32, vp]
+    lib.lora_amd_loss_scale_update.restype = C.c_int
     lib.lora_amd_step_advance.argtypes = [vp, vp]
     lib.lora_amd_ti_rows_step.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, f32, i64, f32, f32,
                                           vp]
@@ -113,8 +116,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_clip_adamw_dev.restype = lib.lora_amd_step_advance.restype = C.c_int
     lib.lora_amd_linear_plan.argtypes = [i64, i32, i32, i32, C.POINTER(LinearPlan)]
     lib.lora_amd_linear_fwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, f32, u64,
-                                        u64, vp]
-    lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+                                        u64, vp, vp]
+    lib.lora_amd_linear_bwd_g.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]
     lib.lora_amd_linear_bwd_factors.restype = C.c_int
@@ -125,9 +128,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_gemm_supported.restype = lib.lora_amd_linear_gemm_fwd.restype = C.c_int
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
-    lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp]
+    lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
     lib.lora_amd_conv_bwd_g.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
-                                        u64, vp]
+                                        u64, vp, vp]
     lib.lora_amd_conv_bwd_x.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_groupnorm_workspace.argtypes = [i32, i32, i32, i32]
     lib.lora_amd_groupnorm_workspace.restype = sz
@@ -166,8 +169,8 @@ def load() -> Optional[C.CDLL]:
     try:
         lib = C.CDLL(LIB_PATH)
         _declare(lib)
-        if lib.lora_amd_abi_version() != 1:
-            raise OSError(f"ABI version {lib.lora_amd_abi_version()} != 1")
+        if lib.lora_amd_abi_version() != ABI_VERSION:
+            raise OSError(f"ABI version {lib.lora_amd_abi_version()} != {ABI_VERSION} (rebuild: make -C lora_amd/csrc)")
         _lib = lib
     except OSError as e:  # pragma: no cover - environment dependent
         _load_error = f"cannot load {LIB_PATH}: {e}"
@@ -203,6 +206,16 @@ def dtype_code(dt: torch.dtype) -> int:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _off(offset):
+    """Dropout offset argument pair (scalar, device pointer): a python int, or a 1-element int64 device tensor whose
+    value the kernel reads at run time (hipGraph-replay / recompute-safe, see ``ops.next_dropout_stream``)."""
+    if torch.is_tensor(offset):
+        if offset.dtype != torch.int64 or not offset.is_cuda or offset.numel() != 1:
+            raise ValueError("dropout offset tensor must be a 1-element int64 device tensor")
+        return 0, offset.data_ptr()
+    return int(offset), None
 
 
 def _dev_check(*ts: torch.Tensor) -> None:
@@ -290,7 +303,7 @@ def rowdot(x: torch.Tensor, factor: torch.Tensor, layout: int, scale: float = 1.
     _check(lib.lora_amd_rowdot_masked(x.data_ptr(), x.stride(0), factor.data_ptr(), t.data_ptr(), M, K, r,
                                       dtype_code(x.dtype), dtype_code(factor.dtype), layout, float(scale),
                                       sel.data_ptr() if sel is not None else None, int(bool(sel_transposed)),
-                                      float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_rowdot")
+                                      float(dropout_p), int(seed), *_off(offset), _stream()), "lora_amd_rowdot")
     return t
 
 
@@ -309,7 +322,7 @@ def rank_update_(y: torch.Tensor, t: torch.Tensor, factor: torch.Tensor, layout:
         raise ValueError(f"rank_update: factor {tuple(factor.shape)} does not match N={N}")
     _check(lib.lora_amd_rank_update(y.data_ptr(), y.stride(0), t.data_ptr(), factor.data_ptr(), M, N, r,
                                     dtype_code(y.dtype), dtype_code(factor.dtype), layout, float(scale),
-                                    float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_rank_update")
+                                    float(dropout_p), int(seed), *_off(offset), _stream()), "lora_amd_rank_update")
     return y
 
 
@@ -334,7 +347,7 @@ def colreduce(x: torch.Tensor, t: torch.Tensor, layout: int, scale: float = 1.0,
     ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
     _check(lib.lora_amd_colreduce(x.data_ptr(), x.stride(0), t.data_ptr(), out.data_ptr(), M, K, r,
                                   dtype_code(x.dtype), layout, float(scale), float(beta), float(dropout_p),
-                                  int(seed), int(offset), ws.data_ptr(), ws.numel() * 4, _stream()),
+                                  int(seed), *_off(offset), ws.data_ptr(), ws.numel() * 4, _stream()),
            "lora_amd_colreduce")
     return out
 
@@ -362,9 +375,10 @@ def make_adamw_groups(groups: Sequence[Tuple[int, int, float, float]], device) -
 
 def clip_adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, groups_dev: torch.Tensor,
                n_groups: int, sumsq_t: Optional[torch.Tensor], grad_scale: float, max_norm: float, beta1: float,
-               beta2: float, eps: float, step, zero_grad: bool = True) -> None:
+               beta2: float, eps: float, step, zero_grad: bool = True, scaler: Optional[torch.Tensor] = None) -> None:
     """``step``: python int (1-based), or a device int64 tensor (hipGraph-replayable; advance it with
-    :func:`step_advance`)."""
+    :func:`step_advance` or, with loss scaling, :func:`loss_scale_update`).  ``scaler``: the 4-float loss-scaling
+    state (device-step form only)."""
     lib = require()
     _dev_check(p, g, m, v, groups_dev, sumsq_t)
     for t in (p, g, m, v):
@@ -377,13 +391,26 @@ def clip_adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
                                            groups_dev.data_ptr(), int(n_groups),
                                            sumsq_t.data_ptr() if sumsq_t is not None else None, float(grad_scale),
                                            float(max_norm), float(beta1), float(beta2), float(eps), step.data_ptr(),
-                                           int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw_dev")
+                                           _ptr(scaler), int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw_dev")
         return
+    if scaler is not None:
+        raise ValueError("clip_adamw: loss scaling needs the device step counter")
     _check(lib.lora_amd_clip_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                    groups_dev.data_ptr(), int(n_groups),
                                    sumsq_t.data_ptr() if sumsq_t is not None else None, float(grad_scale),
                                    float(max_norm), float(beta1), float(beta2), float(eps), int(step),
                                    int(bool(zero_grad)), _stream()), "lora_amd_clip_adamw")
+
+
+def loss_scale_update(state: torch.Tensor, sumsq_t: torch.Tensor, step_dev: Optional[torch.Tensor],
+                      growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000) -> None:
+    """GradScaler.update() + the finite check of GradScaler.step(), on the device (see include/lora_amd.h)."""
+    _dev_check(state, sumsq_t, step_dev)
+    if state.dtype != torch.float32 or state.numel() != 4 or not state.is_contiguous():
+        raise ValueError("loss_scale_update: state must be 4 contiguous f32 values")
+    _check(require().lora_amd_loss_scale_update(state.data_ptr(), sumsq_t.data_ptr(), _ptr(step_dev),
+                                                float(growth_factor), float(backoff_factor), int(growth_interval),
+                                                _stream()), "lora_amd_loss_scale_update")
 
 
 def step_advance(step_dev: torch.Tensor) -> None:
@@ -426,7 +453,7 @@ def linear_fwd_(x: torch.Tensor, y: torch.Tensor, down: torch.Tensor, up: torch.
     _check(lib.lora_amd_linear_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), down.data_ptr(),
                                    up.data_ptr(), t.data_ptr(), M, K, N, r, dtype_code(x.dtype),
                                    dtype_code(down.dtype), float(scale), sel.data_ptr() if sel is not None else None,
-                                   float(dropout_p), int(seed), int(offset), _stream()), "lora_amd_linear_fwd")
+                                   float(dropout_p), int(seed), *_off(offset), _stream()), "lora_amd_linear_fwd")
     return t
 
 
@@ -437,7 +464,7 @@ def linear_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, gt_part: Op
     _check(require().lora_amd_linear_bwd_g(g.data_ptr(), g.stride(0), t.data_ptr(), up.data_ptr(), _ptr(gt_part),
                                            up_part.data_ptr(), M, N, t.shape[1], dtype_code(g.dtype),
                                            dtype_code(up.dtype), float(scale), float(dropout_p), int(seed),
-                                           int(offset), _stream()), "lora_amd_linear_bwd_g")
+                                           *_off(offset), _stream()), "lora_amd_linear_bwd_g")
 
 
 def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Tensor, nct_g: int, down: torch.Tensor,
@@ -513,7 +540,7 @@ def conv_up_fwd_(y: torch.Tensor, t: torch.Tensor, up: torch.Tensor, scale: floa
     B, Co, H, W = y.shape
     _check(require().lora_amd_conv_up_fwd(y.data_ptr(), t.data_ptr(), up.data_ptr(), B, Co, H, W, t.shape[1],
                                           dtype_code(y.dtype), dtype_code(up.dtype), float(scale), float(dropout_p),
-                                          int(seed), int(offset), _stream()), "lora_amd_conv_up_fwd")
+                                          int(seed), *_off(offset), _stream()), "lora_amd_conv_up_fwd")
 
 
 def conv_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, sel: Optional[torch.Tensor], gt_part: torch.Tensor,
@@ -523,7 +550,7 @@ def conv_bwd_g(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, sel: Optional
     _check(require().lora_amd_conv_bwd_g(g.data_ptr(), t.data_ptr(), up.data_ptr(), _ptr(sel), gt_part.data_ptr(),
                                          gt_out.data_ptr(), up_part.data_ptr(), B, Co, H, W, t.shape[1],
                                          dtype_code(g.dtype), dtype_code(up.dtype), float(scale), float(dropout_p),
-                                         int(seed), int(offset), _stream()), "lora_amd_conv_bwd_g")
+                                         int(seed), *_off(offset), _stream()), "lora_amd_conv_bwd_g")
 
 
 def conv_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt: torch.Tensor, down: torch.Tensor,
@@ -676,16 +703,27 @@ _wt_cache = {}
 
 def weight_t(weight: torch.Tensor) -> torch.Tensor:
     """Resident transposed copy [K, N] of a frozen [N, K] weight (the fused dX kernel contracts over N and wants it
-    contiguous); built once per (storage, version) — frozen weights do not change during training, 288 GB of HBM make
-    the second layout of the adapted sites (385 MB for the SD1.5 UNet) a non-issue."""
+    contiguous); built once per weight — frozen weights do not change during training, 288 GB of HBM make the second
+    layout of the adapted sites (385 MB for the SD1.5 UNet) a non-issue.
+
+    The entry keeps the SOURCE tensor alive: as long as it is cached its memory cannot be handed to another tensor by
+    the caching allocator, so "same data_ptr / version / dtype / shape" really means "same weight" (an entry keyed on
+    the address alone could return another site's transpose after a free + re-allocation).  In-place edits through
+    ``.data`` do not bump ``_version``; code that rewrites a frozen weight in place must call
+    :func:`invalidate_weight_caches` (``collapse_lora``, ``monkeypatch_*`` and ``Module._apply`` of the adapters do)."""
     key = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape))
-    wt = _wt_cache.get(key)
-    if wt is None:
-        if len(_wt_cache) > 4096:
+    hit = _wt_cache.get(key)
+    if hit is None:
+        if len(_wt_cache) >= 2048:
             _wt_cache.clear()
-        wt = weight.detach().t().contiguous()
-        _wt_cache[key] = wt
-    return wt
+        src = weight.detach()
+        hit = _wt_cache[key] = (src, src.t().contiguous())
+    return hit[1]
+
+
+def invalidate_weight_caches() -> None:
+    """Drop every derived layout of frozen weights (transposes for the fused dX kernel)."""
+    _wt_cache.clear()
 
 
 _gemm_choice_bwd = _TuneCache("gemm_bwd")

@@ -11,4 +11,4 @@ from .lora import (  # noqa: F401  (underscore names the reference's CLIs import
 from . import _C  # noqa: F401
 from .lora_manager import DummySafeTensorObject, LoRAManager, lora_join  # noqa: F401  (reference __init__.py:3)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -147,12 +147,16 @@ class PlaceholderRows:
         self.m, self.v = torch.zeros_like(self.rows), torch.zeros_like(self.rows)
         self.weight_decay, self.t = float(weight_decay), 0
 
-    def step(self, lr: float, world: int = 1, clip_ti_decay: bool = False):
+    def step(self, lr: float, world: int = 1, clip_ti_decay: bool = False, inv_scale=None):
         """One optimiser step on the rows from ``emb.grad`` (averaged over ``world`` ranks), optional norm decay with
         lambda = min(1, 100 lr) (ref :451-469), rows written back; every other row of the table is untouched."""
         self.t += 1
         lam = min(1.0, 100 * lr) if clip_ti_decay and len(self.ids) else -1.0
         grad = self.emb.grad
+        if inv_scale is not None:  # fp16 loss scaling: the table gradient carries the scale of this backward; a
+            # non-finite row gradient (the LoRA step of the same batch was skipped) leaves the rows where they are
+            grad = torch.nan_to_num(grad.float() * inv_scale, nan=0.0, posinf=0.0, neginf=0.0).to(grad.dtype)
+            self.emb.grad = grad
         if world > 1:
             g = grad[self.ids].contiguous()
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
@@ -227,10 +231,10 @@ def perform_tuning(unet, vae, text_encoder, dataloader, num_steps, scheduler, st
             state.set_lrs([b * mult for b in base_lrs])
             loss = loss_step(batch, unet, vae, text_encoder, scheduler, t_mutliplier=0.8, mixed_precision=True,
                              mask_temperature=mask_temperature, cached_latents=cached_latents)
-            loss.backward()
+            (loss * state.loss_scale if state.loss_scale is not None else loss).backward()
             state.step(state.all_reduce())
             if rows is not None:  # continue_inversion
-                rows.step(rows_lr * mult, world, False)
+                rows.step(rows_lr * mult, world, False, inv_scale=state.scaler[2] if state.scaler is not None else None)
             global_step += 1
             if is_main and global_step % 10 == 0:
                 print(f"tuning step {global_step}/{num_steps} loss {loss.item():.5f} lr {state.lrs[0]:.3e}")
@@ -334,7 +338,7 @@ def train(instance_data_dir: str, pretrained_model_name_or_path: str, output_dir
     if perform_inversion and placeholder_token_ids:
         rows = PlaceholderRows(text_encoder, placeholder_token_ids, ti_lr, weight_decay_ti)
         train_inversion(unet, vae, text_encoder, dataloader, max_train_steps_ti, noise_scheduler, rows, ti_lr,
-                        T.get_lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps_ti), save_steps,
+                        T.get_lr_lambda(lr_scheduler, lr_warmup_steps, max_train_steps_ti, lr_init=ti_lr), save_steps,
                         placeholder_token_ids, placeholder_tokens, output_dir, cached_latents,
                         accum_iter=gradient_accumulation_steps, clip_ti_decay=clip_ti_decay, world=world,
                         is_main=is_main)
@@ -370,8 +374,10 @@ def train(instance_data_dir: str, pretrained_model_name_or_path: str, output_dir
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
     if dev.type == "cuda":
         state.attach_direct_grads(unet, *([text_encoder] if train_text_encoder else []))
+    if wdt == torch.float16:
+        state.enable_loss_scaling()
     perform_tuning(unet, vae, text_encoder, dataloader, max_train_steps_tuning, noise_scheduler, state, list(state.lrs),
-                   T.get_lr_lambda(lr_scheduler_lora, lr_warmup_steps_lora, max_train_steps_tuning), save_steps,
+                   T.get_lr_lambda(lr_scheduler_lora, lr_warmup_steps_lora, max_train_steps_tuning, lr_init=unet_lr), save_steps,
                    placeholder_token_ids, placeholder_tokens, output_dir, lora_unet_target_modules,
                    lora_clip_target_modules, mask_temperature, out_name, cached_latents, rows, rows_lr, world, is_main)
     if world > 1:

@@ -185,6 +185,14 @@ __device__ inline void dropout_mult8(uint64_t seed, uint64_t offset, uint64_t ch
   }
 }
 
+// Effective Philox offset of a launch: the scalar argument plus (optionally) a value read from device memory.  The
+// device part is what makes dropout correct under hipGraph replay and activation checkpointing: the host draws it with
+// torch's generator INSIDE the captured / recomputed region, so every replay sees a fresh value and a recompute sees
+// the forward's value again, while the scalar arguments stay baked into the graph.
+__device__ inline uint64_t dropout_offset(uint64_t offset, const uint64_t *offset_dev) {
+  return offset_dev != nullptr ? offset + __builtin_nontemporal_load(offset_dev) : offset;
+}
+
 // ---- cross-lane moves on the DPP path (no LDS crossbar traffic) ------------
 template <int CTRL>
 __device__ inline float dpp_mov(float v) {

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *_
                                                           const float *__restrict__ t,
                                                           const float *__restrict__ up, int B, int Co, int HW,
                                                           int r, int cpw, int64_t NP, int cps, float scale, float p,
-                                                          uint64_t seed, uint64_t offset) {
+                                                          uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int npix8 = HW >> 3;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kCT) void conv_up_fwd_kernel(typename E::storage *_
       if (DROP) {
         float mk[8];
         const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
-        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+        dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
       }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::stora
                                                          float *__restrict__ gt_part, float *__restrict__ up_part,
                                                          int B, int Co, int HW, int r, int rank_pad, int cpw,
                                                          int64_t NP, int cps, float scale, float p, uint64_t seed,
-                                                         uint64_t offset) {
+                                                         uint64_t offset, const uint64_t *offset_dev) {
   constexpr int U = 4;
   __shared__ __attribute__((aligned(16))) float s_red[4 * 4 * 64 * 8];
   const int lane = threadIdx.x & 63;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kCT) void conv_bwd_g_kernel(const typename E::stora
       if (DROP && cp.act) {
         float mk[8];
         const int64_t e = ((int64_t)cp.b * Co + c) * HW + cp.p0;
-        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+        dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) gv[u][i] *= mk[i];
       }
@@ -684,7 +684,7 @@ extern "C" int lora_amd_conv_down_fwd(const void *x, const void *down, const flo
 
 extern "C" int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int32_t B, int32_t C_out, int32_t H,
                                     int32_t W, int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale,
-                                    float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+                                    float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream) {
   const ConvGeo q = conv_geo(B, 0, C_out, H, W, 1, r);
   CONV_COMMON("conv_up_fwd", C_out);
   LORA_AMD_CHECK(y && t && up && al16(y) && al16(t), LORA_AMD_EINVAL, "conv_up_fwd: null or unaligned pointer");
@@ -700,7 +700,7 @@ extern "C" int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int
 #define CU(E, RTV, D)                                                                                            \
   hipLaunchKernelGGL((conv_up_fwd_kernel<E, RTV, D>), grid, dim3(kCT), 0, st,                                     \
                      reinterpret_cast<typename E::storage *>(y), t, reinterpret_cast<const float *>(up), B, C_out, \
-                     HW, r, 64, q.NP, cps, scale, dropout_p, seed, offset)
+                     HW, r, 64, q.NP, cps, scale, dropout_p, seed, offset, offset_dev)
 #define CU_RT(E, D) do { if (RT == 4) CU(E, 4, D); else if (RT == 8) CU(E, 8, D); else CU(E, 16, D); } while (0)
 #define CU_E(E) do { if (drop) CU_RT(E, true); else CU_RT(E, false); } while (0)
   switch (act_dtype) {
@@ -717,7 +717,7 @@ extern "C" int lora_amd_conv_up_fwd(void *y, const float *t, const void *up, int
 extern "C" int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up, const float *sel, float *gt_part,
                                    float *gt_out, float *up_part, int32_t B, int32_t C_out, int32_t H, int32_t W,
                                    int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale, float dropout_p,
-                                   uint64_t seed, uint64_t offset, void *stream) {
+                                   uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream) {
   const ConvGeo q = conv_geo(B, 0, C_out, H, W, 1, r);
   CONV_COMMON("conv_bwd_g", C_out);
   LORA_AMD_CHECK(g && t && up && gt_part && gt_out && up_part && al16(g) && al16(t) && al16(gt_part) && al16(gt_out),
@@ -733,7 +733,7 @@ extern "C" int lora_amd_conv_bwd_g(const void *g, const float *t, const void *up
 #define CG(E, D)                                                                                                  \
   hipLaunchKernelGGL((conv_bwd_g_kernel<E, D>), grid, dim3(kCT), 0, st,                                           \
                      reinterpret_cast<const typename E::storage *>(g), t, reinterpret_cast<const float *>(up), dst, \
-                     up_part, B, C_out, HW, r, q.rank_pad, 64, q.NP, cps, scale, dropout_p, seed, offset)
+                     up_part, B, C_out, HW, r, q.rank_pad, 64, q.NP, cps, scale, dropout_p, seed, offset, offset_dev)
 #define CG_E(E) do { if (drop) CG(E, true); else CG(E, false); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: CG_E(f32_t); break;

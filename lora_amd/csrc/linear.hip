@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
     int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
     int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
-    uint64_t seed, uint64_t offset) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
   __shared__ float s_sel[RT * RT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
             if (cc >= c8) continue;
             if (MASKED) {
               float mk[8];
-              dropout_mult8(seed, offset, (uint64_t)((row * K + k0) >> 3) + cc, p, mk);
+              dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)((row * K + k0) >> 3) + cc, p, mk);
 #pragma unroll
               for (int i = 0; i < 8; ++i) xv[u][i] *= mk[i];
             }
@@ -167,7 +167,7 @@ template <class EX, bool MASKED>
 __global__ __launch_bounds__(kThreads) void rowdot_generic_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
     int layout, float *__restrict__ t_out, int64_t M, int K, int r, float scale,
-    const float *__restrict__ sel, int sel_transposed, float p, uint64_t seed, uint64_t offset) {
+    const float *__restrict__ sel, int sel_transposed, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   __shared__ float s_o[kThreads / 64][LORA_AMD_MAX_RANK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + wave;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void rowdot_generic_kernel(
       if (MASKED) {
         uint64_t e = (uint64_t)row * K + k;
         float mk[8];
-        dropout_mult8(seed, offset, e >> 3, p, mk);
+        dropout_mult8(seed, dropout_offset(offset, offset_dev), e >> 3, p, mk);
         xv *= mk[e & 7];
       }
       float fv = ld_factor(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * K + k : (int64_t)k * r + j);
@@ -210,7 +210,7 @@ template <class EY, int RT, bool DROP>
 __global__ __launch_bounds__(kThreads) void rank_update_kernel(
     typename EY::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t,
     const void *__restrict__ f, int fdt, int layout, int64_t M, int N, int r, int rows_per_tile,
-    int cols_per_tile, int tiles_n, float scale, float p, uint64_t seed, uint64_t offset) {
+    int cols_per_tile, int tiles_n, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
   __shared__ __attribute__((aligned(16))) float s_t[kTLdsFloats];
   const int tid = threadIdx.x;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void rank_update_kernel(
       if (DROP) {
         float mk[8];
         const int64_t e = (row0 + rls[u]) * (int64_t)N + col0 + ccs[u] * 8;
-        dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+        dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
       }
@@ -279,7 +279,7 @@ template <class EY, bool DROP>
 __global__ __launch_bounds__(kThreads) void rank_update_generic_kernel(
     typename EY::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t,
     const void *__restrict__ f, int fdt, int layout, int64_t M, int N, int r, float scale, float p,
-    uint64_t seed, uint64_t offset) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   const int64_t total = M * (int64_t)N;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
     const int64_t row = e / N;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void rank_update_generic_kernel(
       a = fmaf(t[row * r + j], ld_factor(f, fdt, layout == LORA_AMD_FACTOR_RK ? (int64_t)j * N + col : (int64_t)col * r + j), a);
     if (DROP) {
       float mk[8];
-      dropout_mult8(seed, offset, (uint64_t)e >> 3, p, mk);
+      dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)e >> 3, p, mk);
       a *= mk[e & 7];
     }
     y[row * ldy + col] = EY::from_f(fmaf(scale, a, EY::to_f(y[row * ldy + col])));
@@ -310,7 +310,7 @@ template <class EX, int RT, bool MASKED>
 __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
-    uint64_t seed, uint64_t offset) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   // s_red doubles as the slot-reduction buffer: [slot][c8*8][4 ranks]
   __shared__ __attribute__((aligned(16))) float s_red[kThreads * 8 * 4];
   __shared__ float s_t[kColRowsPerBlock * RT];
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
         if (MASKED) {
           float mk[8];
           const int64_t e = (m0 + rl) * (int64_t)K + col0 + cc * 8;
-          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+          dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
           for (int i = 0; i < 8; ++i) xv[u][i] *= mk[i];
         }
@@ -438,7 +438,7 @@ template <class EX, bool MASKED>
 __global__ __launch_bounds__(kThreads) void colreduce_generic_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ d, int64_t M, int K, int r, int out_layout, float scale, float beta, float p,
-    uint64_t seed, uint64_t offset) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   // one thread per (j, k); serial over M — correctness path for odd shapes only
   const int64_t total = (int64_t)r * K;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void colreduce_generic_kernel(
       if (MASKED) {
         uint64_t e = (uint64_t)m * K + k;
         float mk[8];
-        dropout_mult8(seed, offset, e >> 3, p, mk);
+        dropout_mult8(seed, dropout_offset(offset, offset_dev), e >> 3, p, mk);
         xv *= mk[e & 7];
       }
       sum = fmaf(t[m * r + j], xv, sum);
@@ -483,14 +483,14 @@ static inline int pick_logL(int c8) {
 template <class EX, bool MASKED>
 static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out, int64_t M, int K, int r,
                          int fdt, int layout, float scale, const float *sel, int selT, float p,
-                         uint64_t seed, uint64_t offset, hipStream_t st) {
+                         uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
   using S = typename EX::storage;
   const S *xp = reinterpret_cast<const S *>(x);
   float *tp = reinterpret_cast<float *>(t_out);
   if (!vec_ok(x, ldx, K, EX::kCode)) {
     int grid = (int)((M + 3) / 4);
     hipLaunchKernelGGL((rowdot_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt,
-                       layout, tp, M, K, r, scale, sel, selT, p, seed, offset);
+                       layout, tp, M, K, r, scale, sel, selT, p, seed, offset, offset_dev);
     return check_launch("lora_amd_rowdot(generic)");
   }
   const int RT = rank_tile(r);
@@ -504,7 +504,7 @@ static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out,
   const int grid = (int)((M + rows_per_block - 1) / rows_per_block);
 #define RD(RTV)                                                                                         \
   hipLaunchKernelGGL((rowdot_kernel<EX, RTV, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt, \
-                     layout, tp, M, K, r, kt_cols, logL, (int)rows_per_block, scale, sel, selT, p, seed, offset)
+                     layout, tp, M, K, r, kt_cols, logL, (int)rows_per_block, scale, sel, selT, p, seed, offset, offset_dev)
   switch (RT) {
     case 4: RD(4); break;
     case 8: RD(8); break;
@@ -518,7 +518,7 @@ static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out,
 
 template <class EY, bool DROP>
 static int launch_rank_update(void *y, int64_t ldy, const float *t, const void *f, int64_t M, int N, int r,
-                              int fdt, int layout, float scale, float p, uint64_t seed, uint64_t offset,
+                              int fdt, int layout, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                               hipStream_t st) {
   using S = typename EY::storage;
   S *yp = reinterpret_cast<S *>(y);
@@ -526,7 +526,7 @@ static int launch_rank_update(void *y, int64_t ldy, const float *t, const void *
     int64_t total = M * (int64_t)N;
     int grid = (int)std::min<int64_t>((total + kThreads - 1) / kThreads, 4096);
     hipLaunchKernelGGL((rank_update_generic_kernel<EY, DROP>), dim3(grid), dim3(kThreads), 0, st, yp, ldy, t, f,
-                       fdt, layout, M, N, r, scale, p, seed, offset);
+                       fdt, layout, M, N, r, scale, p, seed, offset, offset_dev);
     return check_launch("lora_amd_rank_update(generic)");
   }
   const int RT = rank_tile(r);
@@ -542,7 +542,7 @@ static int launch_rank_update(void *y, int64_t ldy, const float *t, const void *
   const int64_t tiles = tiles_n * ((M + rows - 1) / rows);
 #define RU(RTV)                                                                                            \
   hipLaunchKernelGGL((rank_update_kernel<EY, RTV, DROP>), dim3((unsigned)tiles), dim3(kThreads), 0, st, yp, ldy, t, \
-                     f, fdt, layout, M, N, r, (int)rows, cols, tiles_n, scale, p, seed, offset)
+                     f, fdt, layout, M, N, r, (int)rows, cols, tiles_n, scale, p, seed, offset, offset_dev)
   switch (RT) {
     case 4: RU(4); break;
     case 8: RU(8); break;
@@ -558,14 +558,14 @@ static inline int col_rank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
 
 template <class EX, bool MASKED>
 static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d, int64_t M, int K, int r,
-                            int out_layout, float scale, float beta, float p, uint64_t seed, uint64_t offset,
+                            int out_layout, float scale, float beta, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                             void *ws, size_t ws_bytes, hipStream_t st) {
   using S = typename EX::storage;
   const S *xp = reinterpret_cast<const S *>(x);
   if (!vec_ok(x, ldx, K, EX::kCode)) {
     int grid = (int)std::min<int64_t>(((int64_t)r * K + kThreads - 1) / kThreads, 4096);
     hipLaunchKernelGGL((colreduce_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, t, d, M,
-                       K, r, out_layout, scale, beta, p, seed, offset);
+                       K, r, out_layout, scale, beta, p, seed, offset, offset_dev);
     return check_launch("lora_amd_colreduce(generic)");
   }
   LORA_AMD_CHECK(ws_bytes >= lora_amd_colreduce_workspace(M, K, r), LORA_AMD_EWORKSPACE,
@@ -578,7 +578,7 @@ static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d
     if (nrb > 0) {  // ranks beyond 16 take extra passes over X
 #define CR(RTV)                                                                                              \
   hipLaunchKernelGGL((colreduce_stage1_kernel<EX, RTV, MASKED>), dim3((unsigned)(nrb * col_tiles)), dim3(kThreads), \
-                     0, st, xp, ldx, t, partial, M, K, r, rank0, col_tiles, p, seed, offset)
+                     0, st, xp, ldx, t, partial, M, K, r, rank0, col_tiles, p, seed, offset, offset_dev)
     switch (RT) {
       case 4: CR(4); break;
       case 8: CR(8); break;
@@ -606,7 +606,7 @@ using namespace lora_amd;
 extern "C" int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *factor, void *t_out, int64_t M,
                                       int32_t K, int32_t r, int32_t x_dtype, int32_t factor_dtype,
                                       int32_t factor_layout, float scale, const float *sel,
-                                      int32_t sel_transposed, float dropout_p, uint64_t seed, uint64_t offset,
+                                      int32_t sel_transposed, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                                       void *stream) {
   COMMON_CHECKS("rowdot", M, K, r, x_dtype);
   LORA_AMD_CHECK(x && factor && t_out, LORA_AMD_EINVAL, "rowdot: null pointer");
@@ -617,9 +617,9 @@ extern "C" int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *fa
   const bool masked = dropout_p > 0.f;
 #define GO(E)                                                                                          \
   return masked ? launch_rowdot<E, true>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, sel, \
-                                         sel_transposed, dropout_p, seed, offset, st)                  \
+                                         sel_transposed, dropout_p, seed, offset, offset_dev, st)                  \
                 : launch_rowdot<E, false>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, sel, \
-                                          sel_transposed, 0.f, 0, 0, st)
+                                          sel_transposed, 0.f, 0, 0, nullptr, st)
   switch (x_dtype) {
     case LORA_AMD_F32: GO(f32_t);
     case LORA_AMD_F16: GO(f16_t);
@@ -632,12 +632,12 @@ extern "C" int lora_amd_rowdot(const void *x, int64_t ldx, const void *factor, v
                                int32_t r, int32_t x_dtype, int32_t factor_dtype, int32_t factor_layout,
                                float scale, const float *sel, int32_t sel_transposed, void *stream) {
   return lora_amd_rowdot_masked(x, ldx, factor, t_out, M, K, r, x_dtype, factor_dtype, factor_layout, scale, sel,
-                                sel_transposed, 0.f, 0, 0, stream);
+                                sel_transposed, 0.f, 0, 0, nullptr, stream);
 }
 
 extern "C" int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const void *factor, int64_t M, int32_t N,
                                     int32_t r, int32_t y_dtype, int32_t factor_dtype, int32_t factor_layout,
-                                    float scale, float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+                                    float scale, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream) {
   COMMON_CHECKS("rank_update", M, N, r, y_dtype);
   LORA_AMD_CHECK(y && t && factor, LORA_AMD_EINVAL, "rank_update: null pointer");
   LORA_AMD_CHECK(dtype_ok(factor_dtype), LORA_AMD_EINVAL, "rank_update: bad factor dtype %d", factor_dtype);
@@ -647,8 +647,8 @@ extern "C" int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const 
   const bool drop = dropout_p > 0.f;
 #define GO(E)                                                                                              \
   return drop ? launch_rank_update<E, true>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, \
-                                            dropout_p, seed, offset, st)                                   \
-              : launch_rank_update<E, false>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, 0.f, 0, 0, st)
+                                            dropout_p, seed, offset, offset_dev, st)                                   \
+              : launch_rank_update<E, false>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, 0.f, 0, 0, nullptr, st)
   switch (y_dtype) {
     case LORA_AMD_F32: GO(f32_t);
     case LORA_AMD_F16: GO(f16_t);
@@ -666,7 +666,7 @@ extern "C" size_t lora_amd_colreduce_workspace(int64_t M, int32_t K, int32_t r) 
 
 extern "C" int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out, int64_t M, int32_t K,
                                   int32_t r, int32_t x_dtype, int32_t out_layout, float scale, float beta,
-                                  float dropout_p, uint64_t seed, uint64_t offset, void *workspace,
+                                  float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *workspace,
                                   size_t workspace_bytes, void *stream) {
   LORA_AMD_CHECK(M >= 0 && K > 0, LORA_AMD_EINVAL, "colreduce: bad shape M=%lld K=%d", (long long)M, K);
   LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "colreduce: rank %d outside [1,%d]", r, LORA_AMD_MAX_RANK);
@@ -678,8 +678,8 @@ extern "C" int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, fl
   const bool masked = dropout_p > 0.f;
 #define GO(E)                                                                                               \
   return masked ? launch_colreduce<E, true>(x, ldx, t, d_out, M, K, r, out_layout, scale, beta, dropout_p, seed, \
-                                            offset, workspace, workspace_bytes, st)                         \
-                : launch_colreduce<E, false>(x, ldx, t, d_out, M, K, r, out_layout, scale, beta, 0.f, 0, 0, \
+                                            offset, offset_dev, workspace, workspace_bytes, st)                         \
+                : launch_colreduce<E, false>(x, ldx, t, d_out, M, K, r, out_layout, scale, beta, 0.f, 0, 0, nullptr, \
                                              workspace, workspace_bytes, st)
   switch (x_dtype) {
     case LORA_AMD_F32: GO(f32_t);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
     const typename E::storage *__restrict__ x, int64_t ldx, typename E::storage *__restrict__ y, int64_t ldy,
     const void *__restrict__ down, const void *__restrict__ up, int fdt, float *__restrict__ t_out, int64_t M, int K,
     int N, int r, int kt_cols, int nt_cols, int cols_per_y, int logL, int rows_per_block, float scale,
-    const float *__restrict__ sel, float p, uint64_t seed, uint64_t offset) {
+    const float *__restrict__ sel, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   __shared__ __attribute__((aligned(16))) float s_f[kFLdsFactor];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
   __shared__ float s_sel[RT * RT];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
         if (DROP) {
           float mk[8];
           const int64_t e = (m0 + rls[u]) * (int64_t)N + n0 + ccs[u] * 8;
-          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+          dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
           for (int i = 0; i < 8; ++i) pr[i] *= mk[i];
         }
@@ -349,7 +349,7 @@ template <class E, int RT, bool DROP>
 __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
     const typename E::storage *__restrict__ g, int64_t ldg, const float *__restrict__ t,
     const void *__restrict__ up, int fdt, float *__restrict__ gt_part, float *__restrict__ up_part, int64_t M,
-    int N, int r, int log_ct8, int nct, int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset) {
+    int N, int r, int log_ct8, int nct, int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
   __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];  // this block's Gt rows, stored once at the end
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
         if (DROP) {
           float mk[8];
           const int64_t e = (m0 + rl) * (int64_t)N + col;
-          dropout_mult8(seed, offset, (uint64_t)(e >> 3), p, mk);
+          dropout_mult8(seed, dropout_offset(offset, offset_dev), (uint64_t)(e >> 3), p, mk);
 #pragma unroll
           for (int i = 0; i < 8; ++i) gv[u][i] *= mk[i];
         }
@@ -670,7 +670,7 @@ extern "C" int lora_amd_linear_plan(int64_t M, int32_t K, int32_t N, int32_t r, 
 extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, const void *down,
                                    const void *up, float *t_out, int64_t M, int32_t K, int32_t N, int32_t r,
                                    int32_t act_dtype, int32_t factor_dtype, float scale, const float *sel,
-                                   float dropout_p, uint64_t seed, uint64_t offset, void *stream) {
+                                   float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream) {
   FUSED_COMMON("linear_fwd", act_dtype, factor_dtype);
   LORA_AMD_CHECK(x && y && down && up && t_out, LORA_AMD_EINVAL, "linear_fwd: null pointer");
   LORA_AMD_CHECK(aligned_ok(x, ldx, K, act_dtype) && aligned_ok(y, ldy, N, act_dtype), LORA_AMD_EINVAL,
@@ -703,7 +703,7 @@ extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t 
   hipLaunchKernelGGL((linear_fwd_kernel<E, RTV, D>), grid, dim3(kFT), 0, st,                                   \
                      reinterpret_cast<const typename E::storage *>(x), ldx, reinterpret_cast<typename E::storage *>(y), \
                      ldy, down, up, factor_dtype, t_out, M, K, N, r, kt, nt, cols_per_y, logL, (int)rpb, scale, sel, \
-                     dropout_p, seed, offset)
+                     dropout_p, seed, offset, offset_dev)
 #define FW_RT(E, D) do { if (RT == 4) FW(E, 4, D); else if (RT == 8) FW(E, 8, D); else FW(E, 16, D); } while (0)
 #define FW_E(E) do { if (drop) FW_RT(E, true); else FW_RT(E, false); } while (0)
   switch (act_dtype) {
@@ -720,7 +720,7 @@ extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t 
 extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
                                      float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
                                      int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
-                                     uint64_t offset, void *stream) {
+                                     uint64_t offset, const uint64_t *offset_dev, void *stream) {
   FUSED_COMMON("linear_bwd_g", act_dtype, factor_dtype);
   LORA_AMD_CHECK(g && t && up && up_part, LORA_AMD_EINVAL, "linear_bwd_g: null pointer");
   LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4, LORA_AMD_EINVAL,
@@ -734,7 +734,7 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
 #define BG(E, RTV, D)                                                                                       \
   hipLaunchKernelGGL((linear_bwd_g_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                        \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \
-                     N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset)
+                     N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset, offset_dev)
 #define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else BG(E, 16, D); } while (0)
 #define BG_E(E) do { if (drop) BG_RT(E, true); else BG_RT(E, false); } while (0)
   switch (act_dtype) {

@@ -58,14 +58,21 @@ __global__ __launch_bounds__(kOptThreads) void clip_adamw_kernel(
     float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
     const lora_amd_adamw_group *__restrict__ groups, int n_groups, const float *__restrict__ sumsq,
     float grad_scale, float max_norm, float beta1, float beta2, float eps, int64_t step_host,
-    const int64_t *__restrict__ step_dev, int zero_grad) {
+    const int64_t *__restrict__ step_dev, const float *__restrict__ scaler, int zero_grad) {
   // bias corrections in double, as torch's python scalars are; the step may live on the device so
   // that a captured hipGraph replays unchanged from step to step
   const double step = (double)(step_dev != nullptr ? step_dev[0] : step_host);
   const float bc1 = (float)(1.0 - pow((double)beta1, step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+  // fp16 loss scaling (lora_amd_loss_scale_update ran before this launch): scaler[2] = 1 / (scale the backward used),
+  // scaler[3] = 0 when the reduced gradient holds inf/nan -> the update is skipped (GradScaler.step), grads still zeroed
+  bool apply = true;
+  if (scaler != nullptr) {
+    grad_scale *= scaler[2];
+    apply = scaler[3] != 0.f;
+  }
   float coef = grad_scale;
-  if (max_norm > 0.f) {
+  if (max_norm > 0.f && apply) {
     // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
     const float total_norm = sqrtf(sumsq[0]) * fabsf(grad_scale);
     const float c = max_norm / (total_norm + 1e-6f);
@@ -78,6 +85,10 @@ __global__ __launch_bounds__(kOptThreads) void clip_adamw_kernel(
       if (i >= groups[k].begin && i < groups[k].end) { lr = groups[k].lr; wd = groups[k].weight_decay; owned = true; }
     }
     if (!owned) continue;
+    if (!apply) {
+      if (zero_grad) g[i] = 0.f;
+      continue;
+    }
     const float grad = g[i] * coef;
     float pi = p[i];
     pi *= (1.0f - lr * wd);                      // param.mul_(1 - lr * weight_decay)
@@ -121,7 +132,7 @@ extern "C" int lora_amd_sumsq(const float *g, int64_t n, float *out_sumsq, void 
 static int clip_adamw_impl(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
                            const lora_amd_adamw_group *groups_dev, int32_t n_groups, const float *sumsq,
                            float grad_scale, float max_norm, float beta1, float beta2, float eps, int64_t step,
-                           const int64_t *step_dev, int32_t zero_grad, void *stream) {
+                           const int64_t *step_dev, const float *scaler, int32_t zero_grad, void *stream) {
   LORA_AMD_CHECK(p && g && exp_avg && exp_avg_sq && groups_dev, LORA_AMD_EINVAL, "clip_adamw: null pointer");
   LORA_AMD_CHECK(n >= 0 && n_groups >= 1 && n_groups <= 16, LORA_AMD_EINVAL, "clip_adamw: n=%lld n_groups=%d",
                  (long long)n, n_groups);
@@ -132,7 +143,7 @@ static int clip_adamw_impl(float *p, float *g, float *exp_avg, float *exp_avg_sq
   hipStream_t st = (hipStream_t)stream;
   int grid = (int)std::min<int64_t>((n + kOptThreads - 1) / kOptThreads, 2048);
   hipLaunchKernelGGL(clip_adamw_kernel, dim3(grid), dim3(kOptThreads), 0, st, p, g, exp_avg, exp_avg_sq, n,
-                     groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1, beta2, eps, step, step_dev, zero_grad);
+                     groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1, beta2, eps, step, step_dev, scaler, zero_grad);
   return check_launch("lora_amd_clip_adamw");
 }
 
@@ -141,17 +152,51 @@ extern "C" int lora_amd_clip_adamw(float *p, float *g, float *exp_avg, float *ex
                                    float grad_scale, float max_norm, float beta1, float beta2, float eps,
                                    int64_t step, int32_t zero_grad, void *stream) {
   return clip_adamw_impl(p, g, exp_avg, exp_avg_sq, n, groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1,
-                         beta2, eps, step, nullptr, zero_grad, stream);
+                         beta2, eps, step, nullptr, nullptr, zero_grad, stream);
 }
 
 extern "C" int lora_amd_clip_adamw_dev(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n,
                                        const lora_amd_adamw_group *groups_dev, int32_t n_groups,
                                        const float *sumsq, float grad_scale, float max_norm, float beta1,
-                                       float beta2, float eps, const int64_t *step_dev, int32_t zero_grad,
-                                       void *stream) {
+                                       float beta2, float eps, const int64_t *step_dev, const float *scaler,
+                                       int32_t zero_grad, void *stream) {
   LORA_AMD_CHECK(step_dev != nullptr, LORA_AMD_EINVAL, "clip_adamw_dev: null step pointer");
+  LORA_AMD_CHECK(scaler == nullptr || sumsq != nullptr, LORA_AMD_EINVAL, "clip_adamw_dev: loss scaling needs sumsq");
   return clip_adamw_impl(p, g, exp_avg, exp_avg_sq, n, groups_dev, n_groups, sumsq, grad_scale, max_norm, beta1,
-                         beta2, eps, 0, step_dev, zero_grad, stream);
+                         beta2, eps, 0, step_dev, scaler, zero_grad, stream);
+}
+
+// Dynamic loss scaling for fp16 training (what accelerate's GradScaler does around the reference's step,
+// train_lora_dreambooth.py:489-494 mixed_precision="fp16"), entirely on the device so that a captured step replays:
+//   state[0] scale the NEXT backward multiplies the loss by   state[1] consecutive finite steps
+//   state[2] 1 / (scale of the step being applied)            state[3] 1 = gradient finite, 0 = skip this update
+// Runs after sumsq (of the still-scaled, already all-reduced gradient) and before clip_adamw; advances the optimiser
+// step counter only when the update will be applied (a skipped step does not count, as with GradScaler).
+__global__ void loss_scale_update_kernel(float *state, const float *sumsq, int64_t *step_dev, float growth,
+                                         float backoff, int interval) {
+  const float scale = state[0];
+  const bool finite = isfinite(sumsq[0]);
+  state[2] = 1.0f / scale;
+  state[3] = finite ? 1.0f : 0.0f;
+  if (finite) {
+    const float good = state[1] + 1.0f;
+    if (good >= (float)interval) { state[0] = scale * growth; state[1] = 0.f; }
+    else state[1] = good;
+    if (step_dev != nullptr) step_dev[0] += 1;
+  } else {
+    state[0] = fmaxf(scale * backoff, 1.0f);
+    state[1] = 0.f;
+  }
+}
+
+extern "C" int lora_amd_loss_scale_update(float *state, const float *sumsq, int64_t *step_dev, float growth_factor,
+                                          float backoff_factor, int32_t growth_interval, void *stream) {
+  LORA_AMD_CHECK(state && sumsq, LORA_AMD_EINVAL, "loss_scale_update: null pointer");
+  LORA_AMD_CHECK(growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1,
+                 LORA_AMD_EINVAL, "loss_scale_update: bad factors");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, sumsq, step_dev,
+                     growth_factor, backoff_factor, growth_interval);
+  return check_launch("lora_amd_loss_scale_update");
 }
 
 // ---------------------------------------------------------------------------- textual-inversion rows (PTI phase 1)

@@ -80,18 +80,39 @@ class _Adapter(nn.Module):
 
     def _shadow(self, t: Optional[torch.Tensor], dt: torch.dtype, slot: str) -> Optional[torch.Tensor]:
         """Frozen tensor in the compute dtype, kept resident instead of re-cast every forward
-        (the reference's autocast re-casts every fp32 weight every step, SURVEY.md §3.1 note b)."""
+        (the reference's autocast re-casts every fp32 weight every step, SURVEY.md §3.1 note b).
+
+        A hit needs the SAME tensor object (``is``) at the same address and version: a replaced Parameter
+        (``collapse_lora`` installs a new one, ref:646) can never alias an old entry even if the allocator gives it the
+        freed address.  In-place edits through ``.data`` are invisible to ``_version``: call
+        :func:`invalidate_caches` after such an edit."""
         if t is None or t.dtype == dt:
             return t
         if t.requires_grad:
             return t.to(dt)
         cache = self.__dict__.setdefault("_shadow_cache", {})
         hit = cache.get(slot)
-        if hit is not None and hit[0] == (t.data_ptr(), t._version, dt):
-            return hit[1]
+        if hit is not None and hit[0] is t and hit[1] == (t.data_ptr(), t._version, dt):
+            return hit[2]
         c = t.detach().to(dt)
-        cache[slot] = ((t.data_ptr(), t._version, dt), c)
+        cache[slot] = (t, (t.data_ptr(), t._version, dt), c)
         return c
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .half(): every derived layout is stale
+        self.__dict__.pop("_shadow_cache", None)
+        _C.invalidate_weight_caches()
+        return super()._apply(fn, *args, **kwargs)
+
+
+def invalidate_caches(model: Optional[nn.Module] = None) -> None:
+    """Forget the compute-dtype shadows and transposed layouts derived from frozen weights (all adapters of ``model``,
+    or just the global transposes when ``model`` is None).  Needed only after an in-place edit of a frozen weight
+    through ``.data``; replacing Parameters, ``.to()``, ``collapse_lora`` and ``monkeypatch_*`` do it themselves."""
+    _C.invalidate_weight_caches()
+    if model is not None:
+        for m in model.modules():
+            if isinstance(m, _Adapter):
+                m.__dict__.pop("_shadow_cache", None)
 
 
 class LoraInjectedLinear(_Adapter):
@@ -447,6 +468,7 @@ def collapse_lora(model, alpha=1.0):
         ops.merge_sites(device_sites, alpha, _C.ROUND_REFERENCE)
         for frozen, new_w in installs:
             frozen.weight = nn.Parameter(new_w)
+    invalidate_caches(model)
 
 
 # --------------------------------------------------------------------------- inference-time patching
@@ -519,6 +541,7 @@ def monkeypatch_remove_lora(model):
         if src.bias is not None:
             plain.bias = src.bias
         parent._modules[name] = plain
+    _C.invalidate_weight_caches()
 
 
 def monkeypatch_add_lora(model, loras, target_replace_module=DEFAULT_TARGET_REPLACE, alpha: float = 1.0,

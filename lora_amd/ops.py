@@ -8,7 +8,6 @@ are the hand-written kernels of ``csrc/linear.hip``.
 """
 from __future__ import annotations
 
-import threading
 from typing import Optional
 
 import torch
@@ -16,20 +15,20 @@ import torch.nn.functional as F
 
 from . import _C
 
-_dropout_lock = threading.Lock()
-_dropout_calls = 0
+def next_dropout_stream(device) -> tuple:
+    """(seed, offset) of one dropout mask.  ``seed`` is torch's seed (a launch-time scalar); ``offset`` is a
+    1-element int64 DEVICE tensor drawn from torch's device generator, which the kernels read at run time
+    (``offset_dev`` of the C-ABI).  Drawing it with torch's generator is what keeps the mask correct everywhere the
+    forward can be re-executed without this Python code running again, or with it running twice:
 
+    * hipGraph replay (``trainer.GraphedForwardBackward``): the draw is a captured kernel on torch's graph-safe Philox
+      state, so every replay sees a fresh value (a host counter would be baked into the graph);
+    * activation checkpointing: ``torch.utils.checkpoint`` restores the generator state before the recompute, so the
+      recomputed forward regenerates the SAME masks as the original one;
+    * ``torch.manual_seed`` makes the whole sequence reproducible.
 
-def next_dropout_stream() -> tuple:
-    """(seed, offset) for one dropout mask: torch's seed + a per-process call counter.
-
-    Deterministic under ``torch.manual_seed``; the mask is regenerated in backward
-    from the same pair, so no [M, N] mask tensor ever exists in HBM.
-    """
-    global _dropout_calls
-    with _dropout_lock:
-        _dropout_calls += 1
-        off = _dropout_calls
+    The backward regenerates the mask from the same pair: no [M, N] mask tensor ever exists in HBM."""
+    off = torch.empty(1, dtype=torch.int64, device=device).random_(0, 1 << 62)
     return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, off
 
 
@@ -118,7 +117,7 @@ class LoraLinearFunction(torch.autograd.Function):
         x2 = _rows2d(x, K)
         seed = off = 0
         if dropout_p > 0.0:
-            seed, off = next_dropout_stream()
+            seed, off = next_dropout_stream(x.device)
         down_c, up_c = down.contiguous(), up.contiguous()
         tile = 0
         if (dropout_p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
@@ -242,7 +241,7 @@ class LoraConvUpFunction(torch.autograd.Function):
         for b in range(B):
             seed = off = 0
             if dropout_p > 0.0:
-                seed, off = next_dropout_stream()
+                seed, off = next_dropout_stream(y0.device)
             streams.append((seed, off))
             _C.rank_update_(y0[b].view(Co, H * W), up2, t[b].view(r, H * W), _C.FACTOR_RK, scale, dropout_p,
                             seed, off)
@@ -304,7 +303,7 @@ class LoraConvFunction(torch.autograd.Function):
         _C.conv_down_fwd(x, down_c, sel_c, t_part, t, ks)
         seed = off = 0
         if dropout_p > 0.0:
-            seed, off = next_dropout_stream()
+            seed, off = next_dropout_stream(x.device)
         _C.conv_up_fwd_(y, t, up_c, scale, dropout_p, seed, off)
         ctx.save_for_backward(x, weight, down, up, t, sel_c)
         ctx.ks, ctx.scale, ctx.p, ctx.seed, ctx.off, ctx.sink = ks, float(scale), float(dropout_p), seed, off, sink

@@ -73,6 +73,29 @@ class FlatLoraState:
             self._ws = torch.empty(1024, dtype=torch.float32, device=self.device)
             self._groups_dev = _C.make_adamw_groups(self._group_rows(), self.device)
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.scaler: Optional[torch.Tensor] = None  # fp16 loss-scaling state, see enable_loss_scaling()
+        self._scaler_cfg = (2.0, 0.5, 2000)
+        # DDP broadcasts the parameters of rank 0 when it wraps the model (the reference's accelerator.prepare,
+        # train_lora_dreambooth.py:744-757): replicas must not depend on every process having drawn the same
+        # random numbers before injection
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat_p, 0)
+
+    def enable_loss_scaling(self, init_scale: float = 65536.0, growth_factor: float = 2.0,
+                            backoff_factor: float = 0.5, growth_interval: int = 2000) -> torch.Tensor:
+        """Dynamic loss scaling for fp16 compute (torch.cuda.amp.GradScaler's defaults; accelerate wraps the
+        reference's step in one when mixed_precision="fp16", ref :489-494).  Returns the 4-float state tensor
+        ``[scale, finite steps, 1/scale of the step being applied, finite flag]``; the step multiplies the loss by
+        ``state[0]`` (``forward_backward(..., loss_scale=state.loss_scale)``), the optimiser un-scales, skips
+        non-finite steps and adapts the scale — all on the device, no host sync, hipGraph-replayable."""
+        self.scaler = torch.tensor([init_scale, 0.0, 1.0 / init_scale, 1.0], dtype=torch.float32, device=self.device)
+        self._scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
+        return self.scaler
+
+    @property
+    def loss_scale(self) -> Optional[torch.Tensor]:
+        """0-d view of the current loss scale (None when loss scaling is off)."""
+        return self.scaler[0] if self.scaler is not None else None
 
     def _group_rows(self):
         return [(a, b, lr, wd) for (a, b), lr, wd in zip(self.group_ranges, self.lrs, self.wds)]
@@ -141,18 +164,40 @@ class FlatLoraState:
         b1, b2 = self.betas
         if self.on_device:
             clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
-            if clip > 0:
+            scaling = self.scaler is not None
+            if clip > 0 or scaling:
                 _C.sumsq(self.flat_g, self._sumsq, self._ws)
-            if graph_safe:
+            if scaling:  # finite check, un-scale factor, scale adaptation; the step counter advances only if applied
+                if not graph_safe and self.step_count == 1:
+                    self._step_dev.zero_()
+                _C.loss_scale_update(self.scaler, self._sumsq, self._step_dev, *self._scaler_cfg)
+                step = self._step_dev
+            elif graph_safe:
                 _C.step_advance(self._step_dev)
                 step = self._step_dev
             else:
                 step = self.step_count
             _C.clip_adamw(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self._groups_dev,
-                          len(self.group_ranges), self._sumsq if clip > 0 else None, grad_scale, clip, b1, b2,
-                          self.eps, step, True)
+                          len(self.group_ranges), self._sumsq if (clip > 0 or scaling) else None, grad_scale, clip,
+                          b1, b2, self.eps, step, True, scaler=self.scaler)
             return
         # CPU plumbing path (same maths as csrc/optim.hip)
+        if self.scaler is not None:
+            growth, backoff, interval = self._scaler_cfg
+            scale = float(self.scaler[0])
+            finite = bool(torch.isfinite(self.flat_g).all())
+            self.scaler[2], self.scaler[3] = 1.0 / scale, float(finite)
+            if not finite:
+                self.scaler[0], self.scaler[1] = max(scale * backoff, 1.0), 0.0
+                self.step_count -= 1
+                self.flat_g.zero_()
+                return
+            good = float(self.scaler[1]) + 1.0
+            if good >= interval:
+                self.scaler[0], self.scaler[1] = scale * growth, 0.0
+            else:
+                self.scaler[1] = good
+            grad_scale = grad_scale / scale
         g = self.flat_g * grad_scale
         if self.max_grad_norm and self.max_grad_norm > 0:
             total = g.norm(2)
@@ -212,9 +257,11 @@ def dreambooth_loss(model_pred: torch.Tensor, target: torch.Tensor, cfg: StepCon
 
 def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConfig,
                      text_encoder=None, noise: Optional[torch.Tensor] = None,
-                     timesteps: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     timesteps: Optional[torch.Tensor] = None, loss_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """noise -> add_noise -> (text encoder) -> UNet -> loss -> backward (ref :823-877).
-    ``cond``: token ids [B, 77] when ``text_encoder`` is given, else encoder hidden states [B, 77, C]."""
+    ``cond``: token ids [B, 77] when ``text_encoder`` is given, else encoder hidden states [B, 77, C].
+    ``loss_scale``: 0-d tensor the loss is multiplied by before the backward (fp16: ``FlatLoraState.loss_scale``);
+    the returned loss is the un-scaled one."""
     if noise is None:
         noise = torch.randn_like(latents)
     if timesteps is None:
@@ -233,7 +280,7 @@ def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConf
     else:
         raise ValueError(f"Unknown prediction type {cfg.prediction_type}")
     loss = dreambooth_loss(pred, target, cfg)
-    loss.backward()
+    (loss * loss_scale if loss_scale is not None else loss).backward()
     return loss.detach()
 
 
@@ -273,8 +320,10 @@ class GraphedForwardBackward:
         return self.loss
 
 
-def get_lr_lambda(name: str, num_warmup_steps: int, num_training_steps: int) -> Callable[[int], float]:
-    """Multipliers of diffusers.optimization.get_scheduler (un-vendored; ref :737-742)."""
+def get_lr_lambda(name: str, num_warmup_steps: int, num_training_steps: int,
+                  lr_init: float = 1.0) -> Callable[[int], float]:
+    """Multipliers of diffusers.optimization.get_scheduler (un-vendored; ref :737-742).  ``lr_init`` (the optimiser's
+    base learning rate) only matters for "polynomial", whose floor is the absolute ``lr_end = 1e-7``."""
     w, T = max(0, num_warmup_steps), max(1, num_training_steps)
 
     def warm(s):
@@ -298,7 +347,7 @@ def get_lr_lambda(name: str, num_warmup_steps: int, num_training_steps: int) -> 
             return 0.0 if prog >= 1.0 else max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((cycles * prog) % 1.0))))
         return f
     if name == "polynomial":
-        def f(s, lr_end_ratio=1e-7 / 1.0, power=1.0):
+        def f(s, lr_end_ratio=1e-7 / float(lr_init), power=1.0):
             if warm(s) is not None:
                 return warm(s)
             if s > T:

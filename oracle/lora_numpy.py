@@ -114,6 +114,8 @@ def lora_conv2d_forward(x, W, b, down, up, scale=1.0, stride=(1, 1), padding=(0,
     branch = conv2d(t, up)
     if mask is not None:
         branch = branch * np.asarray(mask, dtype=F32)
+    if W is None:  # low-rank branch only (real-size sites: the frozen conv is a library call, not under test)
+        return (branch * F32(scale)).astype(F32), t
     return (conv2d(x, W, b, stride, padding, dilation) + branch * F32(scale)).astype(F32), t
 
 
@@ -138,9 +140,9 @@ def lora_conv2d_backward(g, x, W, down, up, scale=1.0, stride=(1, 1), padding=(0
     """Autograd of lora.py:130-135 (implicit in the reference): returns dx, d_down, d_up for
     ``conv(x; W) + scale * mask * up1x1(S . down_kxk(x))`` given the output gradient ``g`` [B,Co,Ho,Wo].
     ``selector`` is the [r, r] matrix applied across the rank channels between down and up (lora.py:140-156)."""
-    g, x, W, down, up = (np.asarray(a, dtype=F32) for a in (g, x, W, down, up))
-    Co, Ci, kh, kw = W.shape
-    r = down.shape[0]
+    g, x, down, up = (np.asarray(a, dtype=F32) for a in (g, x, down, up))
+    r, _, kh, kw = down.shape
+    Co = up.shape[0]
     cols, Ho, Wo = _im2col(x, kh, kw, stride, padding, dilation)          # [B, Ci*kh*kw, P]
     B, P = x.shape[0], Ho * Wo
     t = np.einsum("jk,bkp->bjp", down.reshape(r, -1), cols)
@@ -155,8 +157,9 @@ def lora_conv2d_backward(g, x, W, down, up, scale=1.0, stride=(1, 1), padding=(0
     if selector is not None:
         gt = np.einsum("aj,bap->bjp", np.asarray(selector, dtype=F32), gt)   # S^T gt
     d_down = np.einsum("bjp,bkp->jk", gt, cols).reshape(down.shape)
-    dcols = np.einsum("jk,bjp->bkp", down.reshape(r, -1), gt) + np.einsum("ok,bop->bkp", W.reshape(Co, -1),
-                                                                            g.reshape(B, Co, P))
+    dcols = np.einsum("jk,bjp->bkp", down.reshape(r, -1), gt)
+    if W is not None:  # W None: low-rank terms only
+        dcols = dcols + np.einsum("ok,bop->bkp", np.asarray(W, dtype=F32).reshape(Co, -1), g.reshape(B, Co, P))
     dx = _col2im(dcols, x.shape, kh, kw, stride, padding, dilation)
     return dx.astype(F32), d_down.astype(F32), d_up.reshape(up.shape).astype(F32)
 

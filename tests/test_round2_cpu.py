@@ -1,0 +1,115 @@
+"""Round-2 host-side additions: the torch-only safetensors reader, fp16 loss scaling, lr floor of the polynomial
+schedule, cache invalidation, console entry points."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lora_amd as L
+from lora_amd import _C, trainer as T
+from lora_amd.safe_open import safe_open as py_safe_open
+from tests import helpers as H
+
+G = H.GOLDEN
+
+
+def test_pure_python_safe_open_equals_safetensors_on_reference_file():
+    """lora_amd/safe_open.py (role of lora_diffusion/safe_open.py:1-68) against the real library on a file the
+    reference wrote, and through parse_safeloras (ref lora.py:538-596)."""
+    from safetensors import safe_open
+
+    path = os.path.join(G, "mini_ref.safetensors")
+    a, b = py_safe_open(path, framework="pt", device="cpu"), safe_open(path, framework="pt", device="cpu")
+    assert sorted(a.keys()) == sorted(b.keys()) and dict(a.metadata()) == dict(b.metadata())
+    for k in b.keys():
+        ta, tb = a.get_tensor(k), b.get_tensor(k)
+        assert ta.dtype == tb.dtype and ta.shape == tb.shape and torch.equal(ta, tb), k
+    pa, pb = L.parse_safeloras(a), L.parse_safeloras(b)
+    assert set(pa) == set(pb)
+    for name in pa:
+        assert pa[name][1] == pb[name][1] and sorted(pa[name][2]) == sorted(pb[name][2])
+        assert all(torch.equal(x, y) for x, y in zip(pa[name][0], pb[name][0]))
+    assert set(L.parse_safeloras_embeds(a)) == set(L.parse_safeloras_embeds(b))
+    with pytest.raises(ValueError):
+        py_safe_open(path, framework="np")
+
+
+def test_pure_python_safe_open_rejects_truncated_files(tmp_path):
+    p = tmp_path / "bad.safetensors"
+    hdr = json.dumps({"x": {"dtype": "F32", "shape": [4], "data_offsets": [0, 16]}}).encode()
+    p.write_bytes(len(hdr).to_bytes(8, "little") + hdr + b"\0" * 8)  # payload shorter than the header says
+    with pytest.raises(ValueError):
+        py_safe_open(str(p))
+    p.write_bytes(b"\1\2")
+    with pytest.raises(ValueError):
+        py_safe_open(str(p))
+
+
+def test_polynomial_schedule_floor_is_absolute_lr_end():
+    """diffusers get_polynomial_decay_schedule_with_warmup: lr decays to lr_end = 1e-7 ABSOLUTE (ref :737-742 calls
+    get_scheduler, un-vendored), i.e. the multiplier floor is 1e-7 / lr_init."""
+    f = T.get_lr_lambda("polynomial", 2, 10, lr_init=1e-4)
+    assert f(0) == 0.0 and f(1) == 0.5
+    assert abs(f(2) - 1.0) < 1e-12 and abs(f(6) - ((1 - 1e-3) * 0.5 + 1e-3)) < 1e-12
+    assert abs(f(10) - 1e-3) < 1e-12 and abs(f(11) - 1e-3) < 1e-12
+    assert abs(1e-4 * f(11) - 1e-7) < 1e-15
+
+
+def test_loss_scaling_cpu_path_skips_nonfinite_steps_and_adapts():
+    p = torch.nn.Parameter(torch.ones(16))
+    st = T.FlatLoraState([{"params": [p], "lr": 1e-2, "weight_decay": 0.0}], max_grad_norm=0.0)
+    sc = st.enable_loss_scaling(init_scale=8.0, growth_interval=2)
+    assert float(st.loss_scale) == 8.0
+    # a scaled gradient: the update must equal the one of the un-scaled gradient
+    ref = torch.nn.Parameter(torch.ones(16))
+    st_ref = T.FlatLoraState([{"params": [ref], "lr": 1e-2, "weight_decay": 0.0}], max_grad_norm=0.0)
+    g = torch.linspace(-1, 1, 16)
+    st.flat_g.copy_(g * 8.0), st_ref.flat_g.copy_(g)
+    st.step(), st_ref.step()
+    np.testing.assert_allclose(st.flat_p.numpy(), st_ref.flat_p.numpy(), rtol=1e-6)
+    assert sc.tolist()[:2] == [8.0, 1.0]
+    # an overflowed backward: parameters and moments untouched, scale halves, the step does not count
+    before, m_before = st.flat_p.clone(), st.exp_avg.clone()
+    st.flat_g.copy_(g * 8.0)
+    st.flat_g[3] = float("inf")
+    st.step()
+    assert torch.equal(st.flat_p, before) and torch.equal(st.exp_avg, m_before) and st.step_count == 1
+    assert sc.tolist()[0] == 4.0 and sc.tolist()[3] == 0.0 and float(st.flat_g.abs().sum()) == 0.0
+    # two finite steps in a row (growth_interval=2): scale doubles
+    for _ in range(2):
+        st.flat_g.copy_(g * float(st.loss_scale))
+        st.step()
+    assert sc.tolist()[0] == 8.0 and st.step_count == 3
+
+
+def test_shadow_cache_cannot_alias_a_replaced_parameter():
+    """a compute-dtype shadow keyed on (data_ptr, version) alone can hit a NEW Parameter that the allocator
+    placed at the freed address; the entry now also requires the same tensor object."""
+    m = L.LoraInjectedLinear(8, 8, r=2)
+    w0 = m.linear.weight
+    w0.requires_grad_(False)
+    s0 = m._shadow(w0, torch.bfloat16, "w")
+    assert m._shadow(w0, torch.bfloat16, "w") is s0  # resident
+    twin = torch.nn.Parameter(w0.data, requires_grad=False)  # same storage, same version, different object
+    twin.data = w0.data
+    assert twin.data_ptr() == w0.data_ptr()
+    assert m._shadow(twin, torch.bfloat16, "w") is not s0
+    m.to(torch.float64)  # Module._apply drops the derived layouts
+    assert "_shadow_cache" not in m.__dict__
+    L.invalidate_caches(m)  # public hook for in-place edits through .data
+
+
+def test_console_entry_points_match_reference_setup():
+    """ref setup.py:14-21: lora_add / lora_pti / lora_distill (lora_ppim = preprocessing, out of scope)."""
+    import importlib
+
+    src = open(os.path.join(H.REPO, "pyproject.toml")).read()
+    block = src.split("[project.scripts]")[1].split("[")[0]
+    entries = dict(line.replace('"', "").split(" = ") for line in block.strip().splitlines())
+    assert set(entries) == {"lora_add", "lora_pti", "lora_distill"}
+    for target in entries.values():
+        mod, fn = target.split(":")
+        assert mod.split(".")[-1] in ("cli_lora_add", "cli_lora_pti", "cli_svd")
+        assert callable(getattr(importlib.import_module(mod), fn))

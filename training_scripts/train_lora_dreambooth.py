@@ -183,6 +183,8 @@ def main(args):
                             max_grad_norm=args.max_grad_norm, device=device)
     if device.type == "cuda":
         state.attach_direct_grads(unet, *([text_encoder] if args.train_text_encoder else []))
+    if weight_dtype == torch.float16:  # fp16 activation gradients underflow without it (accelerate's GradScaler)
+        state.enable_loss_scaling()
     base_lrs = list(state.lrs)
 
     dataset = SIO.DreamBoothDataset(args.instance_data_dir, args.instance_prompt, tokenizer,
@@ -202,7 +204,7 @@ def main(args):
         args.max_train_steps = args.num_train_epochs * steps_per_epoch
     args.num_train_epochs = math.ceil(args.max_train_steps / steps_per_epoch)
     lr_lambda = T.get_lr_lambda(args.lr_scheduler, args.lr_warmup_steps * args.gradient_accumulation_steps,
-                                args.max_train_steps * args.gradient_accumulation_steps)
+                                args.max_train_steps * args.gradient_accumulation_steps, lr_init=args.learning_rate)
     cfg = T.StepConfig(with_prior_preservation=args.with_prior_preservation, prior_loss_weight=args.prior_loss_weight,
                        num_train_timesteps=noise_scheduler.config.num_train_timesteps,
                        prediction_type=getattr(noise_scheduler.config, "prediction_type", "epsilon"))
@@ -225,7 +227,8 @@ def main(args):
         return lat.to(weight_dtype), batch["input_ids"].to(device)
 
     te_arg = text_encoder  # the reference always runs the text encoder inside the step (ref :840)
-    fwd_bwd = lambda lat, ids: T.forward_backward(unet, noise_scheduler, lat, ids, cfg, text_encoder=te_arg)  # noqa: E731
+    fwd_bwd = lambda lat, ids: T.forward_backward(unet, noise_scheduler, lat, ids, cfg, text_encoder=te_arg,  # noqa: E731
+                                                  loss_scale=state.loss_scale)
     graphed = None
     global_step, last_save, t0 = 0, 0, time.perf_counter()
     done = False
