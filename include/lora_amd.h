@@ -213,6 +213,40 @@ int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *w, int64_t 
                              int32_t N, int32_t r, int32_t act_dtype, float scale, float t_scale,
                              int32_t factor_layout, int32_t tile, void *stream);
 
+/* K1/K2 weight-stationary form (csrc/gemm_ws.hip): one launch for up to LORA_AMD_WS_MAX_SITES sites that read the SAME
+ * input X[M,K] (lora.py:53-58 called on to_q / to_k / to_v with one tensor): per site
+ *     Y = X B^T + bias + scale * (X down^T) up^T,     t_out[M,r] (f32) = t_scale * X down^T   (t_out may be NULL)
+ * with B [N,K] given PRE-PACKED in MFMA fragment order (lora_amd_ws_pack; frozen weights are packed once and stay
+ * resident), so that a workgroup keeps its [64*CS columns][K] panel in registers and only X streams (LDS-DMA ring).
+ * Supported contraction lengths K: 320, 640, 768, 1280 (lora_amd_ws_config returns 0 otherwise), bf16/f16, rank <= 16,
+ * N % 4 == 0, ldy % 4 == 0.  flayout as in lora_amd_linear_gemm_fwd (bit 0: down is [K,r]; bit 1: up is [r,N]);
+ * bit 2: accumulate, Y += ... (the input gradients of sites that shared an input meet in one dX).
+ * The input gradient of a site is the same call on the weight packed in the other orientation:
+ *     dX[M,K'] = G[M,N'] W[N',K'] + scale (G up) down,  Gt = scale G up:
+ *     x = G, K = N', site = {wp = pack(W viewed as B[k'][n'] : stride_n = 1, stride_k = ldw), N = K', down = up [N',r]
+ *     (flayout bit 0), up = down [r,K'] (bit 1), t_scale = scale, bias = NULL}.
+ * row_groups: 0 = choose (about one workgroup per CU; a multiple of 8 so that the panels of a row group share an XCD). */
+#define LORA_AMD_WS_MAX_SITES 4
+typedef struct lora_amd_ws_site {
+  const void *wp;    /* packed B, lora_amd_ws_packed_elems(N, K) elements */
+  const void *bias;  /* [N] activation dtype, or NULL */
+  void *y;           /* [M, N] activation dtype, row stride ldy */
+  const float *down; /* [r, K] (or [K, r]) f32 */
+  const float *up;   /* [N, r] (or [r, N]) f32 */
+  float *t_out;      /* [M, r] f32 or NULL */
+  int64_t ldy;
+  int32_t N, r, panel_begin /* filled by the launcher */, flayout;
+  float scale, t_scale;
+} lora_amd_ws_site;
+
+int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);
+int64_t lora_amd_ws_packed_elems(int32_t N, int32_t K);
+/* Pack B (element (n, k) at w[n * stride_n + k * stride_k], n < N, k < K) into fragment order (zero-padded panels). */
+int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, int32_t dtype, void *out,
+                     void *stream);
+int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
+                       const lora_amd_ws_site *sites /* host array */, int32_t nsites, int32_t row_groups, void *stream);
+
 /* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
  * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient
  * buffer once per step.  `begin` = exclusive prefix sum of r*C over the table; total = its end. */

@@ -33,6 +33,7 @@ SYMBOLS = (
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
+    "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance", "lora_amd_loss_scale_update", "lora_amd_ti_rows_step",
@@ -74,6 +75,15 @@ class ConvPlan(C.Structure):
                 ("split_in", C.c_int32), ("split_out", C.c_int32), ("rank_pad", C.c_int32), ("reserved", C.c_int32),
                 ("t_part_floats", C.c_int64), ("gt_part_floats", C.c_int64), ("up_part_floats", C.c_int64),
                 ("down_part_floats", C.c_int64)]
+
+
+WS_MAX_SITES = 4
+
+
+class WsSite(C.Structure):
+    _fields_ = [("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
+                ("t_out", C.c_void_p), ("ldy", C.c_int64), ("N", C.c_int32), ("r", C.c_int32),
+                ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float)]
 
 
 class ReduceDesc(C.Structure):
@@ -126,6 +136,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32,
                                              i32, vp]
     lib.lora_amd_linear_gemm_supported.restype = lib.lora_amd_linear_gemm_fwd.restype = C.c_int
+    lib.lora_amd_ws_config.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.lora_amd_ws_packed_elems.argtypes = [i32, i32]
+    lib.lora_amd_ws_packed_elems.restype = i64
+    lib.lora_amd_ws_pack.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp]
+    lib.lora_amd_linear_ws.argtypes = [vp, i64, i64, i32, i32, C.POINTER(WsSite), i32, i32, vp]
+    lib.lora_amd_ws_config.restype = lib.lora_amd_ws_pack.restype = lib.lora_amd_linear_ws.restype = C.c_int
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
@@ -722,8 +738,89 @@ def weight_t(weight: torch.Tensor) -> torch.Tensor:
 
 
 def invalidate_weight_caches() -> None:
-    """Drop every derived layout of frozen weights (transposes for the fused dX kernel)."""
+    """Drop every derived layout of frozen weights (transposes and fragment-order packs for the fused kernels)."""
     _wt_cache.clear()
+    _ws_cache.clear()
+
+
+# ----------------------------------------------------------------------------- K1/K2 weight-stationary (gemm_ws.hip)
+_WS_K = (320, 640, 768, 1280)
+_ws_cache = {}
+
+
+def ws_supported(x: torch.Tensor, K: int, N: int, r: int) -> bool:
+    """Can the weight-stationary kernel run a site of contraction length K, width N, rank r on input rows ``x``?"""
+    return (K in _WS_K and x.dtype in (torch.bfloat16, torch.float16) and r <= 16 and N % 4 == 0 and x.dim() == 2
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def ws_pack(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """Frozen weight [N, K] in MFMA fragment order (``lora_amd_ws_pack``), built once and kept resident like
+    :func:`weight_t` (same keep-the-source-alive cache discipline).  ``transposed``: pack W^T — the operand of the
+    input gradient dX = G W (contraction over N) — straight from the [N, K] storage."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
+    hit = _ws_cache.get(key)
+    if hit is None:
+        if len(_ws_cache) >= 4096:
+            _ws_cache.clear()
+        lib = require()
+        src = weight.detach()
+        if src.dim() != 2 or src.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("ws_pack: 2-D bf16/f16 weight expected")
+        n_out, k_c = (src.shape[1], src.shape[0]) if transposed else (src.shape[0], src.shape[1])
+        sn, sk = (src.stride(1), src.stride(0)) if transposed else (src.stride(0), src.stride(1))
+        elems = lib.lora_amd_ws_packed_elems(n_out, k_c)
+        if elems == 0:
+            raise ValueError(f"ws_pack: contraction length {k_c} has no weight-stationary kernel")
+        out = torch.empty(elems, dtype=src.dtype, device=src.device)
+        _check(lib.lora_amd_ws_pack(src.data_ptr(), sn, sk, n_out, k_c, dtype_code(src.dtype), out.data_ptr(), _stream()),
+               "lora_amd_ws_pack")
+        hit = _ws_cache[key] = (src, out)
+    return hit[1]
+
+
+def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
+    """One launch for every site in ``sites`` (all reading ``x`` [M, K]); each site is a dict with ``wp`` (packed
+    weight), ``N``, ``down``, ``up``, ``scale`` and optionally ``bias``, ``y`` (output buffer, allocated if absent),
+    ``want_t`` (default True), ``t_scale``, ``flayout``.  Returns [(y, t), ...]."""
+    lib = require()
+    M, K = x.shape
+    if not 1 <= len(sites) <= WS_MAX_SITES:
+        raise ValueError(f"linear_ws: 1..{WS_MAX_SITES} sites")
+    arr = (WsSite * len(sites))()
+    outs, keep = [], []
+    for d, s in zip(arr, sites):
+        N, fl = int(s["N"]), int(s.get("flayout", 0))
+        down, up = s["down"], s["up"]
+        r = down.shape[1] if fl & 1 else down.shape[0]
+        if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
+            raise ValueError("linear_ws: contiguous f32 factors expected")
+        y = s.get("y")
+        if y is None:
+            y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        t = torch.empty((M, r), dtype=torch.float32, device=x.device) if s.get("want_t", True) else None
+        bias = s.get("bias")
+        d.wp, d.bias, d.y, d.down, d.up, d.t_out = (s["wp"].data_ptr(), _ptr(bias), y.data_ptr(), down.data_ptr(),
+                                                    up.data_ptr(), _ptr(t))
+        d.ldy, d.N, d.r, d.panel_begin, d.flayout = y.stride(0), N, r, 0, fl
+        d.scale, d.t_scale = float(s["scale"]), float(s.get("t_scale", 1.0))
+        outs.append((y, t))
+        keep.append((down, up, bias))
+    _check(lib.lora_amd_linear_ws(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), arr, len(sites), int(row_groups),
+                                  _stream()), "lora_amd_linear_ws")
+    return outs
+
+
+def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0):
+    """(y, t) of ONE site through the weight-stationary kernel (same contract as :func:`linear_gemm_fwd`)."""
+    return linear_ws(x, [dict(wp=ws_pack(weight), N=weight.shape[0], bias=bias, down=down, up=up, scale=scale)],
+                     row_groups)[0]
+
+
+def linear_ws_dx(g, weight, down, up, scale, row_groups: int = 0):
+    """(dX [M,K], Gt [M,r] f32) = (G W + scale (G up) down, scale G up) of one site, weight-stationary on W^T."""
+    return linear_ws(g, [dict(wp=ws_pack(weight, True), N=weight.shape[1], down=up, up=down, scale=scale,
+                              t_scale=scale, flayout=3)], row_groups)[0]
 
 
 _gemm_choice_bwd = _TuneCache("gemm_bwd")

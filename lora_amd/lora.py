@@ -157,6 +157,36 @@ class LoraInjectedLinear(_Adapter):
         self.selector.weight.data = torch.diag(diag).to(self.lora_up.weight.device).to(self.lora_up.weight.dtype)
 
 
+def lora_linear_group(adapters, x: torch.Tensor):
+    """Apply several ``LoraInjectedLinear`` adapters to the SAME input in one launch where that is possible (device
+    tensors, 16-bit compute, no dropout in effect, no selector, f32 factors, equal rank, shapes the weight-stationary
+    kernel covers); returns the list of outputs, or None when the caller should simply call the adapters one by one.
+
+    What host code with q/k/v (or k/v) projections on one tensor calls: ``lora_amd/standin/unet.py::CrossAttention``
+    and ``LoraAmdAttnProcessor`` for a ``diffusers`` attention block.  Numerically each output equals the adapter's own
+    ``forward`` on the fused path (same kernels, same rounding points)."""
+    if not x.is_cuda or len(adapters) < 2 or not all(isinstance(a, LoraInjectedLinear) for a in adapters):
+        return None
+    a0 = adapters[0]
+    w0 = a0.linear.weight
+    dt = _autocast_dtype(x, w0)
+    if dt not in (torch.bfloat16, torch.float16):
+        return None
+    r = a0.r
+    for a in adapters:
+        if (a.r != r or a._dropout_p() > 0.0 or a._selector_matrix() is not None
+                or a.lora_down.weight.dtype != torch.float32 or a.lora_up.weight.dtype != torch.float32
+                or a.linear.weight.requires_grad or a.linear.in_features != a0.linear.in_features):
+            return None
+    xc = x if x.dtype == dt else x.to(dt)
+    if not ops.linear_group_ok(xc, [(a.linear.out_features, a.linear.in_features) for a in adapters], r):
+        return None
+    sites = [(a._shadow(a.linear.weight, dt, "w"), a._shadow(a.linear.bias, dt, "b"), a.lora_down.weight,
+              a.lora_up.weight, a.scale, a.__dict__.get("_grad_sink")) for a in adapters]
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        return list(ops.lora_linear_group(xc, sites))
+
+
 class LoraInjectedConv2d(_Adapter):
     """ref:73-156.  ``lora_down`` copies the frozen conv's geometry (in -> r), ``lora_up`` is 1x1 (r -> out)."""
 

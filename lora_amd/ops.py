@@ -221,6 +221,109 @@ def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return LoraLinearFunction.apply(x, weight, bias, down, up, sel, float(scale), float(dropout_p), sink)
 
 
+class LoraLinearGroupFunction(torch.autograd.Function):
+    """Several LoraInjectedLinear sites applied to ONE input (attn1's to_q / to_k / to_v, attn2's to_k / to_v: the
+    reference calls lora.py:53-58 once per site on the same tensor) as one weight-stationary launch forward
+    (``_C.linear_ws``: the input is fetched from HBM once) and one autograd node backward, which also sums the sites'
+    input gradients inside the kernels (accumulate flag) instead of leaving n - 1 ``add`` launches to autograd.
+
+    Inputs: x, n, then per site (weight, bias, down, up, scale, sink).  Eligibility is the caller's job
+    (``lora.lora_linear_group``): no dropout, no selector, f32 factors, 16-bit activations, supported K and N."""
+
+    @staticmethod
+    def forward(ctx, x, n, *args):
+        _C.require()
+        sites = [args[6 * i:6 * i + 6] for i in range(n)]
+        K = sites[0][0].shape[1]
+        x2 = _rows2d(x, K)
+        descs = [dict(wp=_C.ws_pack(w), N=w.shape[0], bias=b, down=d.contiguous(), up=u.contiguous(), scale=float(sc))
+                 for (w, b, d, u, sc, _) in sites]
+        outs = _C.linear_ws(x2, descs)
+        ctx.save_for_backward(x2, *[t for _, t in outs], *[a for s_ in sites for a in (s_[0], s_[2], s_[3])])
+        ctx.n, ctx.x_shape = n, x.shape
+        ctx.meta = [(float(sc), sink, b is not None) for (_, b, _, _, sc, sink) in sites]
+        return tuple(y.view(*x.shape[:-1], y.shape[1]) for y, _ in outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x2, ts, rest = saved[0], saved[1:1 + n], saved[1 + n:]
+        M, K = x2.shape
+        need_x = ctx.needs_input_grad[0]
+        dx2 = None
+        out = [None, None]
+        per_site = []
+        for i in range(n):
+            weight, down, up = rest[3 * i:3 * i + 3]
+            scale, sink, has_bias = ctx.meta[i]
+            g = grads[i]
+            base = 2 + 6 * i
+            need_w, need_b, need_down, need_up = ctx.needs_input_grad[base:base + 4]
+            d_down = d_up = dw = db = None
+            if g is not None:
+                N, r = weight.shape[0], down.shape[0]
+                g2 = _rows2d(g, N)
+                if not _C._rows_ok(g2):
+                    g2 = g2.contiguous()
+                down_c, up_c = down.contiguous(), up.contiguous()
+                key = (M, K, N, r)
+                plan = _C.linear_plan(*key)
+                if sink is not None:
+                    if sink.pending is not None:
+                        sink.flush()
+                    gt_part, up_part, down_part = sink.workspace(key, plan, g2.device)
+                else:
+                    gt_part, up_part, down_part = (torch.empty(max(int(k_), 1), dtype=torch.float32, device=g2.device)
+                                                   for k_ in (plan.gt_part_floats, plan.up_part_floats,
+                                                              plan.down_part_floats))
+                # dX (+)= G W + s (G up) down and Gt = s G up: weight-stationary on W^T, accumulating across the sites
+                first = dx2 is None
+                if first:
+                    dx2 = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+                (_, gt), = _C.linear_ws(g2, [dict(wp=_C.ws_pack(weight, True), N=K, down=up_c, up=down_c, scale=scale,
+                                                  t_scale=scale, flayout=3 if first else 7, y=dx2)])
+                _C.linear_bwd_factors(g2, ts[i], up_part, x2, gt, down_part, r, scale)
+                if sink is not None:
+                    sink.pending = key
+                else:
+                    d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+                    d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+                    rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                            (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+                    table, nn_, total = _C.make_reduce_table(rows, g2.device)
+                    _C.reduce_batched(table, nn_, total)
+                    d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+                if need_w:
+                    dw = g2.t() @ x2
+                if has_bias and need_b:
+                    db = g2.sum(0)
+            per_site += [dw, db, d_down, d_up, None, None]
+        if need_x and dx2 is not None:
+            out[0] = dx2.view(ctx.x_shape)
+        return tuple(out + per_site)
+
+
+def lora_linear_group(x: torch.Tensor, sites) -> tuple:
+    """``sites``: [(weight, bias, down, up, scale, sink), ...] all applied to ``x``; returns one output per site."""
+    flat = [a for s_ in sites for a in s_]
+    return LoraLinearGroupFunction.apply(x, len(sites), *flat)
+
+
+def linear_group_ok(x: torch.Tensor, shapes, r: int) -> bool:
+    """Can ``lora_linear_group`` run sites of (N, K) ``shapes`` on ``x``: weight-stationary forward (contraction K) and
+    input gradient (contraction N), plus the one-launch factor-gradient pass."""
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or not 1 <= len(shapes) <= _C.WS_MAX_SITES:
+        return False
+    K = shapes[0][1]
+    x2 = x.reshape(-1, K) if x.shape[-1] == K else None
+    if x2 is None or any(k != K for _, k in shapes):
+        return False
+    return all(_C.ws_supported(x2, K, N, r) and N in _C._WS_K and K % 4 == 0 and _C.fused_ok(x2, N, r)
+               for N, _ in shapes)
+
+
 class LoraConvUpFunction(torch.autograd.Function):
     """``y0 += scale * dropout(conv1x1(t; up))`` in NCHW, in place on the frozen conv's output
     (lora.py:116-123, 130-135).  Per sample, Y_b viewed as [C_out, H*W] gets the rank-r update

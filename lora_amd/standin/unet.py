@@ -12,6 +12,7 @@ Weights are random-init: there is no network to fetch checkpoints.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -57,6 +58,25 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(self.act(self.linear_1(x)))
 
 
+def project_qkv(attn, x, context=None):
+    """to_q / to_k / to_v of an attention block.  When the projections are LoRA adapters that read the same tensor
+    (self-attention: all three; cross-attention: to_k and to_v on the text states) they go out as ONE launch of the
+    weight-stationary kernel (``lora.lora_linear_group``); otherwise module by module, as diffusers does."""
+    ctx = x if context is None else context
+    if x.is_cuda and os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0":
+        from ..lora import lora_linear_group
+
+        if context is None:
+            out = lora_linear_group([attn.to_q, attn.to_k, attn.to_v], x)
+            if out is not None:
+                return out
+        else:
+            kv = lora_linear_group([attn.to_k, attn.to_v], ctx)
+            if kv is not None:
+                return [attn.to_q(x)] + kv
+    return [attn.to_q(x), attn.to_k(ctx), attn.to_v(ctx)]
+
+
 class CrossAttention(nn.Module):
     def __init__(self, query_dim: int, cross_attention_dim: Optional[int] = None, heads: int = 8, dim_head: int = 64,
                  dropout: float = 0.0):
@@ -73,9 +93,10 @@ class CrossAttention(nn.Module):
         ctx = x if context is None else context
         B, T, _ = x.shape
         h = self.heads
-        q = self.to_q(x).view(B, T, h, -1).transpose(1, 2)
-        k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
-        v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
+        q, k, v = project_qkv(self, x, context)
+        q = q.view(B, T, h, -1).transpose(1, 2)
+        k = k.view(B, ctx.shape[1], h, -1).transpose(1, 2)
+        v = v.view(B, ctx.shape[1], h, -1).transpose(1, 2)
         o = sdpa(q, k, v)  # dense contraction: library MFMA flash kernels, fastest variant per shape (attention.py)
         o = o.transpose(1, 2).reshape(B, T, -1)
         return self.to_out[1](self.to_out[0](o))

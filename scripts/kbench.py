@@ -135,6 +135,65 @@ def bench_linear(args):
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
+def bench_ws(args):
+    """K1/K2 weight-stationary fused GEMM (gemm_ws.hip) vs the LDS-ring kernel and the library GEMM + linear_fwd."""
+    r = 4
+    HBM = 8.0e12
+    for (M, K, N) in ((16384, 320, 320), (16384, 320, 2560), (4096, 640, 640), (4096, 640, 5120), (1024, 1280, 1280),
+                      (1024, 1280, 10240), (256, 1280, 1280), (308, 768, 320), (308, 768, 1280)):
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV).to(torch.bfloat16)
+        A = torch.randn(r, K, device=DEV) * 0.25
+        B = torch.randn(N, r, device=DEV) * 0.05
+        byts = (M * K + N * K + M * N) * 2 + (N + K) * r * 4 + M * r * 4
+        res = dict(M=M, K=K, N=N, MB=round(byts / 1e6, 2), floor_us_8TBs=round(byts / HBM * 1e6, 2))
+        wp = _C.ws_pack(W)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        site = dict(wp=wp, N=N, bias=bias, down=A, up=B, scale=1e-3, y=y)
+        for rg in (0, 8, 16, 32, 64, 128, 256):
+            med, best = timeit(lambda: _C.linear_ws(x, [site], rg), args.iters)
+            res[f"ws_rg{rg}_us"] = med * 1e6
+        bestk = min((v, k) for k, v in res.items() if k.startswith("ws_rg"))
+        res["ws_best"], res["ws_best_us"] = bestk[1], bestk[0]
+        res["ws_frac8"] = byts / (bestk[0] * 1e-6) / HBM
+        if _C.gemm_supported(x, W, N, r):
+            res["ring_best_us"] = min(timeit(lambda: _C.linear_gemm_fwd(x, W, bias, A, B, 1e-3, t_), args.iters)[0]
+                                      for t_ in (22, 23, 24, 32, 34)) * 1e6
+        plan_ok = _C.fused_ok(x, N, r)
+        if plan_ok:
+            med, _ = timeit(lambda: _C.linear_fwd_(x, torch.nn.functional.linear(x, W, bias), A, B, 1e-3, None, 0.0, 0, 0),
+                            args.iters)
+            res["lib_gemm_plus_lora_us"] = med * 1e6
+        med, _ = timeit(lambda: torch.nn.functional.linear(x, W, bias), args.iters)
+        res["lib_gemm_us"] = med * 1e6
+        # input gradient: contraction over N (only where N is a supported contraction length)
+        if N in (320, 640, 768, 1280):
+            g = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+            wpt = _C.ws_pack(W, True)
+            dx = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+            st = dict(wp=wpt, N=K, down=B, up=A, scale=1.0, t_scale=1.0, flayout=3, y=dx)
+            med, _ = timeit(lambda: _C.linear_ws(g, [st]), args.iters)
+            res["ws_dx_us"] = med * 1e6
+            med, _ = timeit(lambda: g @ W, args.iters)
+            res["lib_dx_us"] = med * 1e6
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+    # q | k | v of one attention block in ONE launch vs three
+    for (M, K) in ((16384, 320), (4096, 640), (1024, 1280)):
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        sites = []
+        for i in range(3):
+            W = (torch.randn(K, K, device=DEV) * 0.03).to(torch.bfloat16)
+            sites.append(dict(wp=_C.ws_pack(W), N=K, down=torch.randn(r, K, device=DEV) * 0.25,
+                              up=torch.randn(K, r, device=DEV) * 0.05, scale=1e-3,
+                              y=torch.empty(M, K, dtype=torch.bfloat16, device=DEV)))
+        one, _ = timeit(lambda: _C.linear_ws(x, sites), args.iters)
+        three, _ = timeit(lambda: [_C.linear_ws(x, [s_]) for s_ in sites], args.iters)
+        byts = (M * K + 3 * K * K + 3 * M * K) * 2
+        print(json.dumps(dict(qkv=[M, K], one_launch_us=round(one * 1e6, 2), three_launches_us=round(three * 1e6, 2),
+                              frac8_one=round(byts / one / HBM, 3))), flush=True)
+
+
 def bench_conv(args):
     """K4 conv-adapter kernels at SD1.5 ResNet sites (bf16 activations, f32 factors)."""
     from lora_amd import ops
@@ -222,7 +281,7 @@ def bench_hostops(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="merge,linear,conv,hostops")
+    ap.add_argument("--what", default="merge,linear,ws,conv,hostops")
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), flush=True)
@@ -230,6 +289,8 @@ if __name__ == "__main__":
         bench_merge(a)
     if "linear" in a.what:
         bench_linear(a)
+    if "ws" in a.what:
+        bench_ws(a)
     if "conv" in a.what:
         bench_conv(a)
     if "hostops" in a.what:

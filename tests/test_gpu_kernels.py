@@ -221,9 +221,12 @@ def test_linear_module_dropout_train_eval_and_grad_consistency():
     np.testing.assert_allclose(n(m(x)), yo, rtol=2e-4, atol=2e-4 * np.abs(yo).max())  # eval: dropout off
     m.train()
     xg = x.clone().requires_grad_(True)
+    torch.manual_seed(77)
     y = m(xg)
-    # regenerate the mask the kernels used from its (seed, offset): no mask tensor was ever stored
-    seed, off = int(torch.initial_seed()), ops._dropout_calls
+    # regenerate the mask the kernels used from its (seed, offset): no mask tensor was ever stored.  The offset is a
+    # device value drawn from torch's generator (ops.next_dropout_stream), so the same seed draws it again
+    torch.manual_seed(77)
+    seed, off = ops.next_dropout_stream(DEV)
     mk = torch.zeros(M, N, device=DEV)
     _C.rank_update_(mk, torch.ones(M, 1, device=DEV), torch.ones(1, N, device=DEV), _C.FACTOR_RK, 1.0, p, seed, off)
     mask = n(mk)

@@ -48,3 +48,18 @@ def test_bench_roofline_entry_reports_the_binding_roof():
     assert 0.16 < e["frac"] < 0.18 and e["mfma_frac"] < e["hbm_frac"]
     e = bench.roofline_entry(2.0 * 8192 ** 3, 3 * 8192 * 8192 * 2, 1e-3)  # square GEMM: 2731 flop/B
     assert e["bound"] == "mfma" and e["unit"] == "TFLOP/s" and abs(e["frac"] - 0.4398) < 1e-3
+
+
+def test_bench_self_launch_fails_loudly_without_enough_gpus():
+    """`python bench.py --gpus N` must start N ranks itself or refuse; it may never report a 1-GPU run as N."""
+    import argparse
+
+    import pytest
+    import torch
+
+    import bench
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could actually launch 2 ranks")
+    with pytest.raises(SystemExit, match="--gpus 2 requested"):
+        bench.self_launch(argparse.Namespace(gpus=2))
