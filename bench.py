@@ -112,10 +112,11 @@ def roofline_entry(flops: float, byts: float, sec: float) -> dict:
 
 
 def gemm_roofline(iters=20):
-    """K1 fully fused MFMA kernel (frozen GEMM + LoRA branch, csrc/gemm_fused.hip) at the two largest site shapes of the
-    workload, timed like the merge: informational second roofline (this kernel is what the step spends its adapter time
-    in).  With K = 320 both sites sit below the machine balance, so the byte roof binds; what the kernel actually runs
-    into first is the L2 -> LDS rate of re-streaming its W slabs."""
+    """K1 fully fused MFMA kernel (frozen GEMM + LoRA branch in one launch) at the two largest site shapes of the
+    workload, with the kernel the step itself uses there (`_C.gemm_choice`: weight-stationary csrc/gemm_ws.hip or the
+    LDS-ring csrc/gemm_fused.hip), timed like the merge: informational second roofline.  With K = 320 both sites sit
+    below the machine balance, so the byte roof binds; what the kernels run into first is the per-CU L2 -> CU rate of
+    pulling the weight panel (every workgroup needs the whole [N, 320] panel for its 64 rows)."""
     out = []
     for (M, K, N) in ((16384, 320, 320), (16384, 320, 2560)):
         g = torch.Generator(device="cuda").manual_seed(0)
@@ -124,22 +125,28 @@ def gemm_roofline(iters=20):
         b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
         down = torch.randn(4, K, device="cuda", generator=g) * 0.25
         up = torch.randn(N, 4, device="cuda", generator=g) * 0.05
-        if not _C.gemm_supported(x, w, N, 4):
+        tile = _C.gemm_choice(x, w, b, down, up, 1.0)
+        if tile == _C.WS_TILE:
+            y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            site = dict(wp=_C.ws_pack(w), N=N, bias=b, down=down, up=up, scale=1.0, y=y)
+            run, name = (lambda: _C.linear_ws(x, [site])), "lora_amd::linear_ws_kernel<bf16> (K1 fused, weight-stationary)"
+        elif tile and _C.gemm_supported(x, w, N, 4):
+            run = lambda: _C.linear_gemm_fwd(x, w, b, down, up, 1.0, tile)  # noqa: E731
+            name = "lora_amd::linear_gemm_fwd_kernel<bf16> (K1 fused, LDS ring, tile %d)" % tile
+        else:
             continue
-        tile = _C.gemm_choice(x, w, b, down, up, 1.0) or (24 if N > 4 * K else 22)
         for _ in range(3):
-            _C.linear_gemm_fwd(x, w, b, down, up, 1.0, tile)
+            run()
         torch.cuda.synchronize()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(iters):
-            _C.linear_gemm_fwd(x, w, b, down, up, 1.0, tile)
+            run()
         e.record()
         torch.cuda.synchronize()
         sec = a.elapsed_time(e) / iters * 1e-3
         flops, byts = 2.0 * M * K * N + 2.0 * M * 4 * (K + N), (M * K + N * K + M * N) * 2 + (N + K) * 4 * 4 + M * 4 * 4
-        out.append({"kernel": "lora_amd::linear_gemm_fwd_kernel<bf16> (K1 fully fused, tile %d)" % tile,
-                    "site": [M, K, N, 4], **roofline_entry(flops, byts, sec)})
+        out.append({"kernel": name, "site": [M, K, N, 4], **roofline_entry(flops, byts, sec)})
     return out
 
 

@@ -680,33 +680,76 @@ def _gpu_time(fn, inner: int = 5) -> float:
         return a.elapsed_time(b) / inner
 
 
+WS_TILE = 50  # kernel code of the weight-stationary kernel next to the LDS-ring tiles (stages*10 + shape) and 0
+AUTOTUNE = os.environ.get("LORA_AMD_AUTOTUNE", "0") == "1"
+
+
+def static_fwd_choice(M: int, K: int, N: int, ws_ok: bool, ring_ok: bool) -> int:
+    """Which kernel runs the forward of an (M, K, N) site: a fixed function of the shape (round 1 timed the candidates
+    on every box, which made numerics — the fused kernels round T and scale*up to the activation dtype, the two-launch
+    path does not — depend on a timing race).  Table from scripts/kbench.py --what ws on MI355X (profiles/r02_kbench_ws.log),
+    us per launch WS / LDS-ring / library GEMM + linear_fwd:
+        (16384,320,320) 13.5 / 14.6 / 25    (16384,320,2560) 61 / 68 / 81     (4096,640,640) 16.8 / 16.5 / 18.6
+        (4096,640,5120) 78 / 52 / 65        (1024,1280,1280) 23.4 / 23.8 / 19.0   (1024,1280,10240) 129 / 46 / 49
+        (256,1280,1280) 9.5 / 23 / 13.8     (308,768,320) 8.1 / 15.9 / 9.8     (308,768,1280) 8.3 / 16 / 12.4
+    i.e. weight-stationary while a panel is amortised over few enough columns, the LDS ring for the wide GEGLU
+    projections at K >= 640, the library GEMM + one fused launch for the square 1280 sites."""
+    wide = N >= 4 * K
+    if ws_ok:
+        if K <= 320 or K == 768:
+            return WS_TILE
+        if K == 640 and not wide:
+            return WS_TILE
+        if K == 1280 and not wide and M <= 512:
+            return WS_TILE
+    if ring_ok and wide and K >= 640:
+        return 24 if K == 640 else 0
+    if ring_ok and K < 640 and M >= 4096:
+        return 24 if wide else 22
+    return 0
+
+
+def static_bwd_choice(M: int, K: int, N: int, ws_ok: bool) -> int:
+    """Backward of a site (dX = G W + ..., contraction over N): weight-stationary on W^T for N = 320 / 640 (13.8 / 22 us
+    against library GEMM + two streaming passes at 14 + 16 / 12.7 + 16), the three-launch path elsewhere."""
+    return WS_TILE if ws_ok and N in (320, 640) and M >= 2048 else 0
+
+
 def gemm_choice(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
                 up: torch.Tensor, scale: float) -> int:
-    """Which forward runs this (M, K, N, r, dtype) site: 0 = library GEMM + ``linear_fwd`` (two launches), else the tile
-    code of the fully fused MFMA kernel.  Decided ONCE per shape by timing both on the live tensors (never inside a
-    hipGraph capture: there the answer is the cached one, or 0).  ``LORA_AMD_GEMM=0`` pins the two-launch path,
-    ``LORA_AMD_GEMM=<tile>`` pins a tile."""
+    """Which forward runs this (M, K, N, r, dtype) site: 0 = library GEMM + ``linear_fwd`` (two launches), WS_TILE =
+    weight-stationary kernel, else the tile code of the LDS-ring MFMA kernel.  Default: :func:`static_fwd_choice`
+    (deterministic).  ``LORA_AMD_GEMM=<code>`` pins one; ``LORA_AMD_AUTOTUNE=1`` times the candidates once per shape on
+    the live tensors instead (never inside a hipGraph capture: there the answer is the cached one, or the static one)."""
     env = os.environ.get("LORA_AMD_GEMM")
     if env is not None:
         return int(env)
-    key = repr((x.shape[0], x.shape[1], weight.shape[0], down.shape[0], str(x.dtype), bias is not None))
+    M, K = x.shape
+    N, r = weight.shape[0], down.shape[0]
+    ws_ok = ws_supported(x, K, N, r) and weight.dtype == x.dtype
+    ring_ok = gemm_supported(x, weight, N, r)
+    if not AUTOTUNE:
+        return static_fwd_choice(M, K, N, ws_ok, ring_ok)
+    key = repr((M, K, N, r, str(x.dtype), bias is not None))
     c = _gemm_choice.get(key)
     if c is not None:
         return c
     if torch.cuda.is_current_stream_capturing():
-        return 0
+        return static_fwd_choice(M, K, N, ws_ok, ring_ok)
     import torch.nn.functional as F
 
     def run(tile):
         if tile == 0:
             y = F.linear(x, weight, bias)
             linear_fwd_(x, y, down, up, scale, None, 0.0, 0, 0)
+        elif tile == WS_TILE:
+            linear_ws_fwd(x, weight, bias, down, up, scale)
         else:
             linear_gemm_fwd(x, weight, bias, down, up, scale, tile)
 
     best, best_t = 0, float("inf")
-    fused0 = fused_ok(x, weight.shape[0], down.shape[0])
-    for tile in ((0,) if fused0 else ()) + GEMM_TILES:
+    fused0 = fused_ok(x, N, r)
+    for tile in ((0,) if fused0 else ()) + (GEMM_TILES if ring_ok else ()) + ((WS_TILE,) if ws_ok else ()):
         t = _gpu_time(lambda: run(tile))
         if t < best_t:
             best, best_t = tile, t
@@ -828,22 +871,26 @@ _gemm_choice_bwd = _TuneCache("gemm_bwd")
 
 def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: torch.Tensor, down: torch.Tensor,
                     up: torch.Tensor, scale: float, bufs) -> int:
-    """As :func:`gemm_choice` for the backward of a site: 0 = G pass + library GEMM + X/dX pass, else the tile of the
-    fused MFMA dX kernel (then: fused dX/Gt launch + ONE launch for the dUp / dDown partials)."""
+    """As :func:`gemm_choice` for the backward of a site: 0 = G pass + library GEMM + X/dX pass, WS_TILE = fused dX/Gt
+    on the weight-stationary kernel, else the tile of the LDS-ring kernel on the resident W^T (then: fused dX/Gt launch
+    + ONE launch for the dUp / dDown partials)."""
     env = os.environ.get("LORA_AMD_GEMM_BWD", os.environ.get("LORA_AMD_GEMM"))
     if env is not None:
         return int(env)
     M, N = g.shape
     K, r = x.shape[1], down.shape[0]
+    ws_ok = ws_supported(g, N, K, r) and weight.dtype == g.dtype and weight.is_contiguous()
+    if not AUTOTUNE:
+        return static_bwd_choice(M, K, N, ws_ok)
     key = repr((M, K, N, r, str(g.dtype)))
     c = _gemm_choice_bwd.get(key)
     if c is not None:
         return c
     if torch.cuda.is_current_stream_capturing():
-        return 0
+        return static_bwd_choice(M, K, N, ws_ok)
     gt_part, up_part, down_part = bufs
     plan = linear_plan(M, K, N, r)
-    wt = weight_t(weight)
+    ring_ok = gemm_supported(g, weight_t(weight), K, r)
 
     def run(tile):
         if tile == 0:
@@ -851,11 +898,14 @@ def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: t
             dx = g @ weight
             linear_bwd_x(x, dx, gt_part, plan.nct_g, down, None, down_part)
         else:
-            dx, gt = linear_gemm_dx(g, wt, down, up, scale, tile)
+            if tile == WS_TILE:
+                dx, gt = linear_ws_dx(g, weight, down, up, scale)
+            else:
+                dx, gt = linear_gemm_dx(g, weight_t(weight), down, up, scale, tile)
             linear_bwd_factors(g, t, up_part, x, gt, down_part, r, scale)
 
     best, best_t = 0, float("inf")
-    for tile in (0,) + GEMM_TILES:
+    for tile in (0,) + (GEMM_TILES if ring_ok else ()) + ((WS_TILE,) if ws_ok else ()):
         tt = _gpu_time(lambda: run(tile))
         if tt < best_t:
             best, best_t = tile, tt

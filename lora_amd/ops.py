@@ -121,10 +121,13 @@ class LoraLinearFunction(torch.autograd.Function):
         down_c, up_c = down.contiguous(), up.contiguous()
         tile = 0
         if (dropout_p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
-                and _C.gemm_supported(x2, weight, N, r)):
-            # ONE launch on the matrix cores (frozen GEMM + low-rank branch) where that measured faster for this shape
+                and x2.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x2.dtype):
+            # ONE launch on the matrix cores (frozen GEMM + low-rank branch): which kernel is a fixed function of the shape
             tile = _C.gemm_choice(x2, weight, bias, down_c, up_c, scale)
-        if tile:
+        if tile == _C.WS_TILE:
+            y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale)
+            fused = _C.fused_ok(x2, N, r)
+        elif tile:
             y, t = _C.linear_gemm_fwd(x2, weight, bias, down_c, up_c, scale, tile)
             fused = _C.fused_ok(x2, N, r)
         else:
@@ -167,12 +170,17 @@ class LoraLinearFunction(torch.autograd.Function):
                                                          plan.down_part_floats))
             tile = 0
             if (need_x and p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
-                    and weight.is_contiguous() and _C.gemm_supported(g2, _C.weight_t(weight), K, r)):
+                    and weight.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float16)
+                    and weight.dtype == g2.dtype):
                 tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
             if tile:
-                # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch on the resident W^T; what remains are the
-                # parameter-gradient partials (G^T T and Gt^T X), both in one more launch
-                dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
+                # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch (weight-stationary on W^T packed in
+                # fragment order, or the LDS-ring kernel on the resident W^T); what remains are the parameter-gradient
+                # partials (G^T T and Gt^T X), both in one more launch
+                if tile == _C.WS_TILE:
+                    dx2, gt = _C.linear_ws_dx(g2, weight, down_c, up_c, s)
+                else:
+                    dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
                 _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s)
             else:
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
