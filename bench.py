@@ -264,6 +264,104 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def svd_worker(spec: str) -> None:
+    """Child process of svd_bench(): the reference recipe (cli_svd.py:30-47: full torch.linalg.svd per site + signed
+    quantile clamp) on the host cores for a few sites, timed."""
+    from oracle import torch_ref as TR  # noqa: F401  (the recipe itself is three torch calls, restated below)
+
+    threads, rank = (int(v) for v in spec.split(","))
+    torch.set_num_threads(threads)
+    out = []
+    for (N, K) in ((320, 320), (640, 640), (1280, 1280), (1280, 2560)):
+        g = torch.Generator().manual_seed(0)
+        res = torch.randn(N, K, generator=g)
+        t0 = time.perf_counter()
+        U, S, Vh = torch.linalg.svd(res)
+        U = U[:, :rank] @ torch.diag(S[:rank])
+        Vh = Vh[:rank, :]
+        hi = torch.quantile(torch.cat([U.flatten(), Vh.flatten()]), 0.99)
+        U.clamp(-hi, hi), Vh.clamp(-hi, hi)
+        out.append({"shape": [N, K], "seconds": time.perf_counter() - t0})
+    print(json.dumps({"sites": out, "threads": threads}), flush=True)
+
+
+def svd_bench(args) -> dict:
+    """BASELINE configs[4]: SVD distillation of a fully fine-tuned SD1.5 UNet to rank-8 LoRA over the 224 sites of the
+    extended injection (shapes of lora_amd.standin.sd15_lora_site_shapes(extended=True); W_tuned = W_base + planted
+    rank-12 update + noise, synthetic).  One "step" = all 224 sites through lora_amd.cli_svd.distill_group (batched
+    randomized subspace iteration on the HIP passes + clamp).  The dominant kernels stream the f32 residuals:
+    (2 n_iter + 2) passes over sum(N K) * 4 bytes."""
+    from collections import Counter
+
+    from lora_amd import cli_svd as S
+    from lora_amd.standin import sd15_lora_site_shapes
+
+    dev = torch.device("cuda", 0)
+    rank, n_iter = 8, 4
+    shapes = Counter(sd15_lora_site_shapes(extended=True))
+    g = torch.Generator(device=dev).manual_seed(0)
+    groups = []
+    for (N, K), cnt in sorted(shapes.items()):
+        base = torch.randn(cnt, N, K, device=dev, generator=g) * 0.05
+        u = torch.randn(cnt, N, 12, device=dev, generator=g)
+        v = torch.randn(cnt, 12, K, device=dev, generator=g)
+        sv = torch.tensor([3.0 * 0.6 ** i for i in range(12)], device=dev)
+        tuned = base + torch.bmm(u / u.norm(dim=1, keepdim=True) * sv, v / v.norm(dim=2, keepdim=True)) * 0.2 \
+            + 1e-4 * torch.randn(cnt, N, K, device=dev, generator=g)
+        groups.append((list(tuned), list(base)))
+    n_sites = sum(shapes.values())
+    elems = sum(N * K * c for (N, K), c in shapes.items())
+
+    def step():
+        gen = torch.Generator(device=dev).manual_seed(1)
+        last = None
+        for tuned, base in groups:
+            last = S.distill_group(tuned, base, rank, 0.99, gen, n_iter=n_iter)
+        return last
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        up, down = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    passes = 2 * n_iter + 2
+    byts = passes * elems * 4 + 2 * elems * 4  # the residual passes + reading W_tuned and W_base once
+    out = {"metric": "cli_svd distillation, SD1.5 UNet -> rank-8 LoRA (224 sites, extended injection)",
+           "value": round(n_sites / dt, 2), "unit": "sites/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 "
+                                  "sites (31 shape groups, 730 M weight elements), randomized subspace iteration n_iter=4 "
+                                  "batched per shape group on the HIP rowdot/colreduce passes, on-device CholeskyQR3",
+                      "sites": n_sites, "groups": len(groups), "weight_elements": elems},
+           "roofline": {"kernel": "lora_amd::rowdot_kernel / colreduce_stage1_kernel <f32> (batched residual passes)",
+                        "bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes,
+                        "note": "whole-step figure: includes the small dense steps (Gram, Cholesky, final SVD) and launch gaps"}}
+    if not args.no_cpu_baseline:
+        import subprocess
+
+        threads = min(usable_cores(), 64)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--svd-worker", f"{threads},{rank}"],
+                               capture_output=True, text=True, timeout=240, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            tot = sum(s_["seconds"] for s_ in rec["sites"])
+            out["cpu_baseline"] = {"value": round(len(rec["sites"]) / tot, 3), "unit": "sites/s", "cores": threads,
+                                   "kind": "port", "sites": rec["sites"],
+                                   "sample": "the reference recipe (full torch.linalg.svd + signed 0.99-quantile clamp, "
+                                             "cli_svd.py:30-47) on 4 of the 224 sites (320^2, 640^2, 1280^2, 1280x2560), f32; "
+                                             "the largest sites (10240x1280, 1280x23040) cost far more than these"}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": threads, "kind": "port",
+                                   "sample": f"sample did not finish: {type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,9 +382,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--svd", action="store_true", help="time BASELINE configs[4] (cli_svd distillation, 224 sites) "
+                    "instead of the training step; prints its own JSON line")
+    ap.add_argument("--svd-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
+    if args.svd_worker:
+        return svd_worker(args.svd_worker)
+    if args.svd:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        _C.require()
+        if args.steps == 20:
+            args.steps = 3
+        print(json.dumps(svd_bench(args)), flush=True)
+        return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -151,6 +151,24 @@ int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, float *d_out,
                        float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+
+
+/* Batched forms (grid.y = matrix index; strides in elements between consecutive matrices of a stack) and the small
+ * dense step of CholeskyQR, for the SVD distillation of cli_svd.py:24-92 (every same-shape site of a model in one
+ * launch instead of one torch.linalg.svd per site).
+ *   rowdot_batched:    T_b[M, r] (f32) = scale * X_b[M, K] @ F_b^T           (F_b [r, K] or [K, r])
+ *   colreduce_batched: D_b (f32, [r, K] or [K, r]) = scale * T_b^T @ X_b     (workspace: batch * colreduce_workspace)
+ *   chol_inverse_batched: out_b = L_b^{-1} with G_b + shift_rel * tr(G_b)/l * I = L_b L_b^T  (l <= 32), so that
+ *                      Q_b = Y_b L_b^{-T} = rowdot_batched(Y_b, out_b) is orthonormal when G_b = Y_b^T Y_b. */
+int lora_amd_rowdot_batched(const void *x, int64_t ldx, int64_t stride_x, const void *factor, int64_t stride_factor,
+                            float *t_out, int64_t stride_t, int32_t batch, int64_t M, int32_t K, int32_t r,
+                            int32_t x_dtype, int32_t factor_dtype, int32_t factor_layout, float scale, void *stream);
+int lora_amd_colreduce_batched(const void *x, int64_t ldx, int64_t stride_x, const float *t, int64_t stride_t,
+                               float *d_out, int64_t stride_d, int32_t batch, int64_t M, int32_t K, int32_t r,
+                               int32_t x_dtype, int32_t out_layout, float scale, void *workspace,
+                               size_t workspace_bytes, void *stream);
+int lora_amd_chol_inverse_batched(const float *gram, float *out, int32_t l, int32_t batch, float shift_rel,
+                                  void *stream);
 /* ------------------------------------------------------------------------
  * K1/K2 fused: one launch forward, two backward, one batched reduction per step.
  * These are what LoraInjectedLinear runs for 16-byte-friendly shapes (K%8==0, N%8==0,

@@ -30,6 +30,7 @@ SYMBOLS = (
     "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
+    "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
@@ -112,6 +113,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_colreduce_workspace.restype = sz
     lib.lora_amd_colreduce.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, u64, u64, vp,
                                        vp, sz, vp]
+    lib.lora_amd_rowdot_batched.argtypes = [vp, i64, i64, vp, i64, vp, i64, i32, i64, i32, i32, i32, i32, i32, f32, vp]
+    lib.lora_amd_colreduce_batched.argtypes = [vp, i64, i64, vp, i64, vp, i64, i32, i64, i32, i32, i32, i32, f32, vp, sz, vp]
+    lib.lora_amd_chol_inverse_batched.argtypes = [vp, vp, i32, i32, f32, vp]
+    lib.lora_amd_rowdot_batched.restype = lib.lora_amd_colreduce_batched.restype = C.c_int
+    lib.lora_amd_chol_inverse_batched.restype = C.c_int
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
     lib.lora_amd_sumsq_workspace.restype = sz
     lib.lora_amd_sumsq.argtypes = [vp, i64, vp, vp, sz, vp]
@@ -365,6 +371,53 @@ def colreduce(x: torch.Tensor, t: torch.Tensor, layout: int, scale: float = 1.0,
                                   dtype_code(x.dtype), layout, float(scale), float(beta), float(dropout_p),
                                   int(seed), *_off(offset), ws.data_ptr(), ws.numel() * 4, _stream()),
            "lora_amd_colreduce")
+    return out
+
+
+# ----------------------------------------------------------------------------- batched forms (SVD distillation)
+def rowdot_batched(x: torch.Tensor, factor: torch.Tensor, layout: int = FACTOR_RK, scale: float = 1.0) -> torch.Tensor:
+    """T [B, M, r] (f32) = scale * X [B, M, K] @ F^T for a stack of matrices: ONE launch (grid.y = B)."""
+    lib = require()
+    _dev_check(x, factor)
+    if x.dim() != 3 or factor.dim() != 3 or not x.is_contiguous() or not factor.is_contiguous():
+        raise ValueError("rowdot_batched: contiguous [B, M, K] and [B, r, K] / [B, K, r] stacks expected")
+    B, M, K = x.shape
+    r = factor.shape[1] if layout == FACTOR_RK else factor.shape[2]
+    if factor.shape[0] != B or factor.numel() != B * r * K:
+        raise ValueError("rowdot_batched: factor stack does not match")
+    t = torch.empty((B, M, r), dtype=torch.float32, device=x.device)
+    _check(lib.lora_amd_rowdot_batched(x.data_ptr(), K, M * K, factor.data_ptr(), r * K, t.data_ptr(), M * r, B, M, K, r,
+                                       dtype_code(x.dtype), dtype_code(factor.dtype), layout, float(scale), _stream()),
+           "lora_amd_rowdot_batched")
+    return t
+
+
+def colreduce_batched(x: torch.Tensor, t: torch.Tensor, layout: int = FACTOR_RK, scale: float = 1.0) -> torch.Tensor:
+    """D [B, r, K] (or [B, K, r]) (f32) = scale * T^T @ X for stacks X [B, M, K], T [B, M, r]: ONE launch pair."""
+    lib = require()
+    _dev_check(x, t)
+    if x.dim() != 3 or t.dim() != 3 or not x.is_contiguous() or not t.is_contiguous() or t.dtype != torch.float32:
+        raise ValueError("colreduce_batched: contiguous [B, M, K] and f32 [B, M, r] stacks expected")
+    B, M, K = x.shape
+    r = t.shape[2]
+    out = torch.empty((B, r, K) if layout == FACTOR_RK else (B, K, r), dtype=torch.float32, device=x.device)
+    nbytes = lib.lora_amd_colreduce_workspace(M, K, r) * B
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    _check(lib.lora_amd_colreduce_batched(x.data_ptr(), K, M * K, t.data_ptr(), M * r, out.data_ptr(), r * K, B, M, K, r,
+                                          dtype_code(x.dtype), layout, float(scale), ws.data_ptr(), ws.numel() * 4,
+                                          _stream()), "lora_amd_colreduce_batched")
+    return out
+
+
+def chol_inverse_batched(gram: torch.Tensor, shift_rel: float = 0.0) -> torch.Tensor:
+    """L^{-1} [B, l, l] for G + shift_rel * tr(G)/l * I = L L^T (l <= 32): the small dense step of CholeskyQR."""
+    lib = require()
+    _dev_check(gram)
+    if gram.dim() != 3 or gram.shape[1] != gram.shape[2] or gram.dtype != torch.float32 or not gram.is_contiguous():
+        raise ValueError("chol_inverse_batched: contiguous f32 [B, l, l] expected")
+    out = torch.empty_like(gram)
+    _check(lib.lora_amd_chol_inverse_batched(gram.data_ptr(), out.data_ptr(), gram.shape[1], gram.shape[0],
+                                             float(shift_rel), _stream()), "lora_amd_chol_inverse_batched")
     return out
 
 

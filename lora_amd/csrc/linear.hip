@@ -22,6 +22,12 @@ constexpr int kThreads = 256;
 constexpr int kFactorLdsFloats = 8192;  // 32 KiB  [RT][cols]
 constexpr int kTLdsFloats = 2048;       // 8 KiB   [rows][RT]
 
+// Batched launches (grid.y = matrix index): element strides between consecutive matrices of a stack.  The SVD
+// distillation (cli_svd.py) runs the same pass over every same-shape site of a model in one launch.
+struct BatchStride {
+  int64_t x, f_bytes, t, d, partial;
+};
+
 __device__ inline float ld_factor(const void *p, int dt, int64_t i) {
   if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
   if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
@@ -70,9 +76,12 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
     int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
     int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
-    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
   __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
   __shared__ float s_sel[RT * RT];
+  x += blockIdx.y * bs.x;
+  f = reinterpret_cast<const char *>(f) + blockIdx.y * bs.f_bytes;
+  t_out += blockIdx.y * bs.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = 1 << logL, G = 64 >> logL;  // lanes per row, rows per wave-iteration
   const int l = lane & (L - 1), g = lane >> logL;
@@ -310,7 +319,10 @@ template <class EX, int RT, bool MASKED>
 __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
-    uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
+  x += blockIdx.y * bs.x;
+  t += blockIdx.y * bs.t;
+  partial += blockIdx.y * bs.partial;
   // s_red doubles as the slot-reduction buffer: [slot][c8*8][4 ranks]
   __shared__ __attribute__((aligned(16))) float s_red[kThreads * 8 * 4];
   __shared__ float s_t[kColRowsPerBlock * RT];
@@ -401,8 +413,10 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
 // flight per lane), the four wave sums meet in LDS.
 __global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
     const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
-    int RT, int rank0, int out_layout, float scale, float beta) {
+    int RT, int rank0, int out_layout, float scale, float beta, BatchStride bs) {
   __shared__ float s_sum[kThreads];
+  partial += blockIdx.y * bs.partial;
+  d += blockIdx.y * bs.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t total = (int64_t)RT * K;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -483,10 +497,13 @@ static inline int pick_logL(int c8) {
 template <class EX, bool MASKED>
 static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out, int64_t M, int K, int r,
                          int fdt, int layout, float scale, const float *sel, int selT, float p,
-                         uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+                         uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st, int batch = 1,
+                         BatchStride bs = BatchStride{0, 0, 0, 0, 0}) {
   using S = typename EX::storage;
   const S *xp = reinterpret_cast<const S *>(x);
   float *tp = reinterpret_cast<float *>(t_out);
+  LORA_AMD_CHECK(batch == 1 || (vec_ok(x, ldx, K, EX::kCode) && bs.x % 8 == 0), LORA_AMD_EINVAL,
+                 "rowdot: batched launches need 16-byte-friendly rows");
   if (!vec_ok(x, ldx, K, EX::kCode)) {
     int grid = (int)((M + 3) / 4);
     hipLaunchKernelGGL((rowdot_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt,
@@ -503,8 +520,8 @@ static int launch_rowdot(const void *x, int64_t ldx, const void *f, void *t_out,
   rows_per_block = ((rows_per_block + rows_iter - 1) / rows_iter) * rows_iter;
   const int grid = (int)((M + rows_per_block - 1) / rows_per_block);
 #define RD(RTV)                                                                                         \
-  hipLaunchKernelGGL((rowdot_kernel<EX, RTV, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, f, fdt, \
-                     layout, tp, M, K, r, kt_cols, logL, (int)rows_per_block, scale, sel, selT, p, seed, offset, offset_dev)
+  hipLaunchKernelGGL((rowdot_kernel<EX, RTV, MASKED>), dim3(grid, batch), dim3(kThreads), 0, st, xp, ldx, f, fdt, \
+                     layout, tp, M, K, r, kt_cols, logL, (int)rows_per_block, scale, sel, selT, p, seed, offset, offset_dev, bs)
   switch (RT) {
     case 4: RD(4); break;
     case 8: RD(8); break;
@@ -559,17 +576,21 @@ static inline int col_rank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
 template <class EX, bool MASKED>
 static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d, int64_t M, int K, int r,
                             int out_layout, float scale, float beta, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
-                            void *ws, size_t ws_bytes, hipStream_t st) {
+                            void *ws, size_t ws_bytes, hipStream_t st, int batch = 1,
+                            BatchStride bs = BatchStride{0, 0, 0, 0, 0}) {
   using S = typename EX::storage;
   const S *xp = reinterpret_cast<const S *>(x);
+  LORA_AMD_CHECK(batch == 1 || (vec_ok(x, ldx, K, EX::kCode) && bs.x % 8 == 0), LORA_AMD_EINVAL,
+                 "colreduce: batched launches need 16-byte-friendly rows");
   if (!vec_ok(x, ldx, K, EX::kCode)) {
     int grid = (int)std::min<int64_t>(((int64_t)r * K + kThreads - 1) / kThreads, 4096);
     hipLaunchKernelGGL((colreduce_generic_kernel<EX, MASKED>), dim3(grid), dim3(kThreads), 0, st, xp, ldx, t, d, M,
                        K, r, out_layout, scale, beta, p, seed, offset, offset_dev);
     return check_launch("lora_amd_colreduce(generic)");
   }
-  LORA_AMD_CHECK(ws_bytes >= lora_amd_colreduce_workspace(M, K, r), LORA_AMD_EWORKSPACE,
-                 "colreduce: workspace %zu < %zu bytes", ws_bytes, lora_amd_colreduce_workspace(M, K, r));
+  LORA_AMD_CHECK(ws_bytes >= lora_amd_colreduce_workspace(M, K, r) * (size_t)batch, LORA_AMD_EWORKSPACE,
+                 "colreduce: workspace %zu < %zu bytes", ws_bytes, lora_amd_colreduce_workspace(M, K, r) * (size_t)batch);
+  bs.partial = (int64_t)(lora_amd_colreduce_workspace(M, K, r) / sizeof(float));
   const int RT = col_rank_tile(r);
   const int64_t nrb = (M + kColRowsPerBlock - 1) / kColRowsPerBlock;
   const int col_tiles = (K + kColMaxChunks * 8 - 1) / (kColMaxChunks * 8);
@@ -577,8 +598,8 @@ static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d
   for (int rank0 = 0; rank0 < r; rank0 += RT) {
     if (nrb > 0) {  // ranks beyond 16 take extra passes over X
 #define CR(RTV)                                                                                              \
-  hipLaunchKernelGGL((colreduce_stage1_kernel<EX, RTV, MASKED>), dim3((unsigned)(nrb * col_tiles)), dim3(kThreads), \
-                     0, st, xp, ldx, t, partial, M, K, r, rank0, col_tiles, p, seed, offset, offset_dev)
+  hipLaunchKernelGGL((colreduce_stage1_kernel<EX, RTV, MASKED>), dim3((unsigned)(nrb * col_tiles), batch), dim3(kThreads), \
+                     0, st, xp, ldx, t, partial, M, K, r, rank0, col_tiles, p, seed, offset, offset_dev, bs)
     switch (RT) {
       case 4: CR(4); break;
       case 8: CR(8); break;
@@ -587,8 +608,8 @@ static int launch_colreduce(const void *x, int64_t ldx, const float *t, float *d
     }
 #undef CR
     const int grid2 = (int)(((int64_t)RT * K + 63) / 64);
-    hipLaunchKernelGGL(colreduce_stage2_kernel, dim3(grid2), dim3(kThreads), 0, st, partial, d, nrb, K, r, RT,
-                       rank0, out_layout, scale, beta);
+    hipLaunchKernelGGL(colreduce_stage2_kernel, dim3(grid2, batch), dim3(kThreads), 0, st, partial, d, nrb, K, r, RT,
+                       rank0, out_layout, scale, beta, bs);
   }
   return check_launch("lora_amd_colreduce");
 }
@@ -687,4 +708,103 @@ extern "C" int lora_amd_colreduce(const void *x, int64_t ldx, const float *t, fl
     default: GO(bf16_t);
   }
 #undef GO
+}
+
+// ---- batched forms (cli_svd.py: every same-shape site of a model in one launch) ---------------------------------
+extern "C" int lora_amd_rowdot_batched(const void *x, int64_t ldx, int64_t stride_x, const void *factor,
+                                       int64_t stride_factor, float *t_out, int64_t stride_t, int32_t batch, int64_t M,
+                                       int32_t K, int32_t r, int32_t x_dtype, int32_t factor_dtype,
+                                       int32_t factor_layout, float scale, void *stream) {
+  COMMON_CHECKS("rowdot_batched", M, K, r, x_dtype);
+  LORA_AMD_CHECK(x && factor && t_out && batch >= 1 && batch <= 65535, LORA_AMD_EINVAL, "rowdot_batched: bad argument");
+  LORA_AMD_CHECK(dtype_ok(factor_dtype) && ldx >= K, LORA_AMD_EINVAL, "rowdot_batched: bad factor dtype / ldx");
+  BatchStride bs{stride_x, stride_factor * dtype_size(factor_dtype), stride_t, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+#define GO(E)                                                                                                     \
+  return launch_rowdot<E, false>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, nullptr, 0, 0.f, 0, \
+                                 0, nullptr, st, batch, bs)
+  switch (x_dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+}
+
+extern "C" int lora_amd_colreduce_batched(const void *x, int64_t ldx, int64_t stride_x, const float *t, int64_t stride_t,
+                                          float *d_out, int64_t stride_d, int32_t batch, int64_t M, int32_t K, int32_t r,
+                                          int32_t x_dtype, int32_t out_layout, float scale, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+  LORA_AMD_CHECK(M >= 0 && K > 0 && r >= 1 && r <= LORA_AMD_MAX_RANK && dtype_ok(x_dtype), LORA_AMD_EINVAL,
+                 "colreduce_batched: bad shape / dtype");
+  LORA_AMD_CHECK(x && t && d_out && batch >= 1 && batch <= 65535 && ldx >= K, LORA_AMD_EINVAL,
+                 "colreduce_batched: bad argument");
+  BatchStride bs{stride_x, 0, stride_t, stride_d, 0};
+  hipStream_t st = (hipStream_t)stream;
+#define GO(E)                                                                                                       \
+  return launch_colreduce<E, false>(x, ldx, t, d_out, M, K, r, out_layout, scale, 0.f, 0.f, 0, 0, nullptr, workspace, \
+                                    workspace_bytes, st, batch, bs)
+  switch (x_dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+}
+
+// Inverse Cholesky factor of a stack of small Gram matrices, for CholeskyQR on the device (cli_svd.py):
+//   G' = G + shift_rel * trace(G) / l * I,   G' = L L^T,   out = L^{-1}  ([l][l] row-major, lower triangular)
+// so that Q = Y L^{-T} — one lora_amd_rowdot_batched(Y, factor = out) — has orthonormal columns when G = Y^T Y.
+// One wave per matrix (l <= 32), f64 inside (the matrices are tiny; the input Gram is what limits accuracy: callers run
+// the shifted pass first and an unshifted one after it, "shifted CholeskyQR3").
+__global__ __launch_bounds__(64) void chol_inverse_kernel(const float *__restrict__ gram, float *__restrict__ out, int l,
+                                                           float shift_rel) {
+  __shared__ double A[32][33];
+  __shared__ double X[32][33];
+  const int lane = threadIdx.x;
+  const float *g = gram + (int64_t)blockIdx.x * l * l;
+  float *o = out + (int64_t)blockIdx.x * l * l;
+  double tr = 0.0;
+  for (int i = 0; i < l; ++i) tr += (double)g[i * l + i];
+  const double shift = (double)shift_rel * tr / (double)l;
+  for (int idx = lane; idx < l * l; idx += 64) {
+    const int i = idx / l, j = idx - i * l;
+    A[i][j] = 0.5 * ((double)g[i * l + j] + (double)g[j * l + i]) + (i == j ? shift : 0.0);
+  }
+  __syncthreads();
+  const double tiny = 1e-30 + 1e-14 * tr / (double)l;
+  for (int j = 0; j < l; ++j) {
+    double d = A[j][j];
+    d = sqrt(d > tiny ? d : tiny);
+    __syncthreads();
+    if (lane == j) A[j][j] = d;
+    if (lane > j && lane < l) A[lane][j] /= d;
+    __syncthreads();
+    if (lane > j && lane < l) {
+      const double lij = A[lane][j];
+      for (int k = j + 1; k <= lane; ++k) A[lane][k] -= lij * A[k][j];
+    }
+    __syncthreads();
+  }
+  // forward substitution, lane = column c of the inverse: L x = e_c
+  if (lane < l) {
+    for (int i = 0; i < l; ++i) {
+      double s = i == lane ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= A[i][k] * X[k][lane];
+      X[i][lane] = i < lane ? 0.0 : s / A[i][i];
+    }
+  }
+  __syncthreads();
+  for (int idx = lane; idx < l * l; idx += 64) {
+    const int i = idx / l, j = idx - i * l;
+    o[idx] = (float)X[i][j];
+  }
+}
+
+extern "C" int lora_amd_chol_inverse_batched(const float *gram, float *out, int32_t l, int32_t batch, float shift_rel,
+                                             void *stream) {
+  LORA_AMD_CHECK(gram && out && l >= 1 && l <= 32 && batch >= 1, LORA_AMD_EINVAL,
+                 "chol_inverse_batched: l in [1,32], batch >= 1");
+  hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, gram, out, l, shift_rel);
+  return check_launch("lora_amd_chol_inverse_batched");
 }

@@ -673,3 +673,84 @@ def test_linear_group_forward_backward_vs_oracle(K, Ns, M):
     assert L.lora_linear_group(mods, x.detach()) is None
     mods[0].dropout.p = 0.0
     assert L.lora_linear_group(mods, x.detach().cpu()) is None
+
+
+# ----------------------------------------------------------------------------- f1: batched pieces of the SVD distillation
+def test_batched_rowdot_colreduce_and_cholesky_qr():
+    """lora_amd_rowdot_batched / colreduce_batched / chol_inverse_batched against torch on a stack of matrices, and the
+    shifted CholeskyQR3 built from them (cli_svd._orth) on an ill-conditioned block."""
+    from lora_amd import cli_svd as S
+
+    g = torch.Generator().manual_seed(0)
+    B, N, K, l = 3, 700, 328, 16
+    x = torch.randn(B, N, K, generator=g).to(DEV)
+    f = torch.randn(B, l, K, generator=g).to(DEV)
+    t = _C.rowdot_batched(x, f, _C.FACTOR_RK, 0.5)
+    want = 0.5 * torch.bmm(x, f.transpose(1, 2))
+    assert (t - want).abs().max() <= 2e-5 * torch.bmm(x.abs(), f.abs().transpose(1, 2)).max()
+    fk = f.transpose(1, 2).contiguous()
+    assert torch.allclose(_C.rowdot_batched(x, fk, _C.FACTOR_KR, 0.5), t, rtol=1e-5, atol=1e-4)
+    d = _C.colreduce_batched(x, t, _C.FACTOR_RK)
+    wd = torch.bmm(t.transpose(1, 2), x)
+    assert (d - wd).abs().max() <= 2e-5 * torch.bmm(t.abs().transpose(1, 2), x.abs()).max()
+    dk = _C.colreduce_batched(x, t, _C.FACTOR_KR)
+    assert torch.allclose(dk, d.transpose(1, 2), rtol=1e-5, atol=1e-3)
+    for b in range(B):  # the batched launch equals the single-matrix entry points
+        assert torch.equal(_C.rowdot(x[b], f[b], _C.FACTOR_RK, 0.5), t[b])
+    # Cholesky inverse: L^{-1} (G + shift) L^{-T} = I
+    y = torch.randn(B, N, l, generator=g).to(DEV)
+    gram = torch.bmm(y.transpose(1, 2), y)
+    linv = _C.chol_inverse_batched(gram.contiguous(), 0.0)
+    eye = torch.bmm(torch.bmm(linv, gram), linv.transpose(1, 2))
+    assert (eye - torch.eye(l, device=DEV)).abs().max() < 1e-4
+    assert linv.triu(1).abs().max() == 0
+    # CholeskyQR3 on columns spanning 3.5 orders of magnitude of singular values (cond^2 of the Gram ~ 1e7)
+    u, _ = torch.linalg.qr(torch.randn(B, N, l, generator=g))
+    v, _ = torch.linalg.qr(torch.randn(B, l, l, generator=g))
+    sv = torch.logspace(0, -3.5, l)
+    ill = (u * sv) @ v.transpose(1, 2)
+    q = S._orth(ill.to(DEV).contiguous())
+    qtq = torch.bmm(q.transpose(1, 2), q)
+    assert (qtq - torch.eye(l, device=DEV)).abs().max() < 5e-5
+    # same column space: projecting the input onto Q reproduces it
+    proj = torch.bmm(q, torch.bmm(q.transpose(1, 2), ill.to(DEV)))
+    assert (proj - ill.to(DEV)).norm() <= 1e-3 * ill.norm() * 10 ** -0.0
+
+
+def test_distill_group_equals_per_site_recipe_on_device():
+    """cli_svd.overwrite_base on a toy model pair: grouped batched device path vs the reference recipe per site (CPU,
+    exact SVD), compared through the un-clamped rank-r product (sign-free) and the clamp threshold."""
+    from lora_amd import cli_svd as S
+
+    Holder = H.named_class("CrossAttention")
+
+    def tree(seed):
+        torch.manual_seed(seed)
+        t = Holder()
+        for nm in ("to_q", "to_k", "to_v"):
+            t.add_module(nm, torch.nn.Linear(64, 48, bias=False))
+        t.add_module("to_out", torch.nn.Linear(64, 96, bias=False))
+        return t
+
+    base = tree(0)
+    tuned = copy.deepcopy(base)
+    g = torch.Generator().manual_seed(1)
+    for m in tuned.children():  # planted rank-5 update well above the f32 noise floor
+        u, v = torch.randn(m.out_features, 5, generator=g), torch.randn(5, m.in_features, generator=g)
+        m.weight.data += (u * torch.tensor([1.0, 0.5, 0.25, 0.12, 0.06])) @ v * 0.05
+    ours_b, ours_t = copy.deepcopy(base).to(DEV), copy.deepcopy(tuned).to(DEV)
+    quiet(L.inject_trainable_lora, ours_b, r=4), quiet(L.inject_trainable_lora, ours_t, r=4)
+    quiet(S.overwrite_base, ours_b, ours_t, rank=4, clamp_quantile=0.99)
+    for name in ("to_q", "to_k", "to_v", "to_out"):
+        res = (getattr(tuned, name).weight.data - getattr(base, name).weight.data).float()
+        up_ref, down_ref, hi_ref, U_ref, Vh_ref = _reference_recipe(res, 4, 0.99)
+        m = getattr(ours_b, name)
+        up, down = m.lora_up.weight.data.cpu(), m.lora_down.weight.data.cpu()
+        assert up.shape == up_ref.shape and down.shape == down_ref.shape
+        sgn = torch.sign((down * Vh_ref).sum(1))
+        assert float(up.abs().max()) <= hi_ref * 1.1 and float(down.abs().max()) <= hi_ref * 1.1
+        prod, prod_ref = up @ down, up_ref @ down_ref
+        assert (prod - prod_ref).norm() <= 0.05 * prod_ref.norm(), name
+        # rows that the clamp did not touch agree with the reference's singular vectors up to sign
+        inner = (down.abs() < 0.9 * hi_ref) & (Vh_ref.abs() < 0.9 * hi_ref)
+        assert ((down * sgn[:, None] - Vh_ref).abs()[inner]).max() <= 5e-3 * Vh_ref.abs().max(), name
