@@ -10,14 +10,14 @@ one LAPACK-style call per site, 224 of them) is replaced by randomized subspace 
 BATCHED over every same-shape site of the model (``distill_group``): the residuals of a group are stacked [B, N, K] and
 each step of the iteration is ONE launch for the whole stack —
 
-    Y  = dW Omega^T          ``lora_amd_rowdot_batched``      [B, N, l]   l = r + oversample (rounded up to 8)
-    Z  = dW^T Q              ``lora_amd_colreduce_batched``   [B, K, l]
+    Y  = dW Omega            ``lora_amd_colreduce_batched`` over the transposed stack   [B, N, l]
+    Z  = dW^T Q              ``lora_amd_colreduce_batched`` over the stack              [B, K, l]   (l = 2r rounded up to 8)
     Q  = orth(Y)             shifted CholeskyQR3 on the device: Gram = Y^T Y (colreduce_batched of Y with itself),
                              L^{-1} of the small Gram (``lora_amd_chol_inverse_batched``, one wave per matrix),
                              Q = Y L^{-T} (rowdot_batched); shift on the first pass, two clean passes after it
 
-— all HBM-streaming passes over dW with a skinny factor (``csrc/linear.hip``), plus one batched small SVD
-([B, l, K], torch) at the end.  With ``n_iter`` power iterations the captured subspace error decays like
+— all HBM-streaming passes over dW with a skinny factor (``csrc/linear.hip``), plus one batched l x l SVD (torch) of
+the triangular-factor-sized core at the end.  With ``n_iter`` power iterations the captured subspace error decays like
 (s_{l+1}/s_r)^(2 n_iter + 1); the defaults reproduce ``up @ down`` of the reference to ~1e-4 relative on
 distillation-like spectra.  The signs of singular vectors are arbitrary (LAPACK's are too, and the reference's clamp
 threshold - a quantile of SIGNED entries - inherits that arbitrariness); the device path fixes them by making the
@@ -65,7 +65,8 @@ def _orth(y: torch.Tensor) -> torch.Tensor:
 
 
 def _sketch_width(rank: int, oversample: int, N: int, K: int) -> int:
-    l = -(-(rank + oversample) // 8) * 8
+    """Sketch columns: rank + max(oversample, rank) rounded up to the kernels' 8-column granule, at most 32."""
+    l = -(-(rank + max(oversample, rank)) // 8) * 8
     return min(l, 32)
 
 
@@ -85,19 +86,28 @@ def topr_svd_batched(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter
     if not group_supported(N, K, rank, oversample):
         raise ValueError(f"topr_svd_batched: shape {N}x{K} rank {rank} is outside the batched device path")
     delta = delta.float().contiguous()
-    omega = torch.randn(B, l, K, device=delta.device, dtype=torch.float32, generator=generator)
-    q = _orth(_C.rowdot_batched(delta, omega, _C.FACTOR_RK))             # [B, N, l]
+    # both products of the iteration as column-reduction passes (the faster primitive: ~2 TB/s on f32 rows, the row-dot
+    # form re-stages its factor tile per few rows of a tall-and-wide weight): dW^T Q streams dW, dW Qz streams the
+    # resident transposed stack (a second f32 layout of the residuals; 288 GB of HBM)
+    delta_t = delta.transpose(1, 2).contiguous()
+    omega = torch.randn(B, K, l, device=delta.device, dtype=torch.float32, generator=generator)
+    q = _orth(_C.colreduce_batched(delta_t, omega, _C.FACTOR_KR))        # [B, N, l] = orth(dW Omega)
     for _ in range(n_iter):
         qz = _orth(_C.colreduce_batched(delta, q, _C.FACTOR_KR))         # [B, K, l] = orth(dW^T Q)
-        q = _orth(_C.rowdot_batched(delta, qz, _C.FACTOR_KR))            # [B, N, l] = orth(dW Qz)
+        q = _orth(_C.colreduce_batched(delta_t, qz, _C.FACTOR_KR))       # [B, N, l] = orth(dW Qz)
     b = _C.colreduce_batched(delta, q, _C.FACTOR_RK)                     # [B, l, K] = Q^T dW
-    ub, s, vh = torch.linalg.svd(b, full_matrices=False)                 # small and batched
+    # small SVD of b [l, K]: b^T = Qb Rb with Qb = orth(b^T) (the same CholeskyQR3), SVD of the l x l factor Rb^T = b Qb
+    # (batched, tiny), b = Ub S (Qb Vb)^T.  (A batched gesvd on [B, l, K] is 10-20x slower here; the Gram/eigh route
+    # loses the orthonormality of the weak directions.)
+    qb = _orth(b.transpose(1, 2).contiguous())                           # [B, K, l]
+    ub, s, vbh = torch.linalg.svd(torch.bmm(b, qb), full_matrices=False)  # [B, l, l]
     u = torch.bmm(q, ub[:, :, :rank])
-    vh = vh[:, :rank]
+    vh = torch.bmm(vbh[:, :rank], qb.transpose(1, 2))
+    s = s[:, :rank]
     idx = vh.abs().argmax(dim=2, keepdim=True)
     sgn = torch.sign(vh.gather(2, idx)).squeeze(2)
     sgn = torch.where(sgn == 0, torch.ones_like(sgn), sgn)
-    return u * sgn[:, None, :], s[:, :rank], vh * sgn[:, :, None]
+    return u * sgn[:, None, :], s, vh * sgn[:, :, None]
 
 
 def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 4,

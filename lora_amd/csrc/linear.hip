@@ -756,7 +756,7 @@ extern "C" int lora_amd_colreduce_batched(const void *x, int64_t ldx, int64_t st
 //   G' = G + shift_rel * trace(G) / l * I,   G' = L L^T,   out = L^{-1}  ([l][l] row-major, lower triangular)
 // so that Q = Y L^{-T} — one lora_amd_rowdot_batched(Y, factor = out) — has orthonormal columns when G = Y^T Y.
 // One wave per matrix (l <= 32), f64 inside (the matrices are tiny; the input Gram is what limits accuracy: callers run
-// the shifted pass first and an unshifted one after it, "shifted CholeskyQR3").
+// the shifted pass first and an unshifted one after it, "shifted CholeskyQR3").  Rank-deficient blocks: see `floor_`.
 __global__ __launch_bounds__(64) void chol_inverse_kernel(const float *__restrict__ gram, float *__restrict__ out, int l,
                                                            float shift_rel) {
   __shared__ double A[32][33];
@@ -772,10 +772,15 @@ __global__ __launch_bounds__(64) void chol_inverse_kernel(const float *__restric
     A[i][j] = 0.5 * ((double)g[i * l + j] + (double)g[j * l + i]) + (i == j ? shift : 0.0);
   }
   __syncthreads();
-  const double tiny = 1e-30 + 1e-14 * tr / (double)l;
+  // a pivot below the noise floor of an f32-accumulated Gram matrix is a direction the block does not have (an exactly
+  // low-rank residual sketched wider than its rank): it is dropped — L[j][j] = inf makes row and column j of L^{-1}
+  // zero, so the corresponding column of Q = Y L^{-T} is zero instead of amplified rounding noise
+  double dmax = 0.0;
+  for (int i = 0; i < l; ++i) dmax = fmax(dmax, A[i][i]);
+  const double floor_ = 1e-30 + 1e-6 * dmax;
   for (int j = 0; j < l; ++j) {
     double d = A[j][j];
-    d = sqrt(d > tiny ? d : tiny);
+    d = d > floor_ ? sqrt(d) : (double)INFINITY;
     __syncthreads();
     if (lane == j) A[j][j] = d;
     if (lane > j && lane < l) A[lane][j] /= d;
