@@ -17,6 +17,12 @@ CASES = {  # name -> algorithmic bytes (bf16 activations, f32 factors, r = 4); M
     "linear_fwd_kernel": ("fwd (16384,320,2560): read X, read+write Y", 16384 * 320 * 2 + 2 * 16384 * 2560 * 2),
     "linear_bwd_g_kernel": ("G pass (16384,2560): read G", 16384 * 2560 * 2),
     "linear_bwd_x_kernel": ("X pass (16384,320): read X, read+write dX", 3 * 16384 * 320 * 2),
+    "linear_ws_kernel": ("K1 fused, weight-stationary (16384,320,2560): read X, W, write Y",
+                         (16384 * 320 + 2560 * 320 + 16384 * 2560) * 2),
+    "linear_gemm_fwd_kernel": ("K1 fused, LDS ring tile 24 (16384,320,2560): read X, W, write Y",
+                               (16384 * 320 + 2560 * 320 + 16384 * 2560) * 2),
+    "linear_bwd_factors_kernel": ("dUp + dDown partials in one launch (16384,320,2560): read G, read X",
+                                  16384 * 2560 * 2 + 16384 * 320 * 2),
     "conv_down_fwd_kernel": ("conv down 3x3 (4,320,64x64): read X", 4 * 320 * 4096 * 2),
     "conv_up_fwd_kernel": ("conv up (4,320,64x64): read+write Y", 2 * 4 * 320 * 4096 * 2),
     "conv_bwd_g_kernel": ("conv G pass: read G", 4 * 320 * 4096 * 2),
@@ -55,6 +61,18 @@ def run():
         _C.linear_bwd_g(g, t, B, gt_part, up_part, 1.0, 0.0, 0, 0)
         flush.fill_(3.0)
         _C.linear_bwd_x(x, dx, gt_part, plan.nct_g, A, None, down_part)
+    W_ = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV).to(torch.bfloat16)
+    yb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    site = dict(wp=_C.ws_pack(W_), N=N, bias=bias, down=A, up=B, scale=1e-3, y=yb)
+    gt1 = torch.randn(M, r, device=DEV)
+    for _ in range(3):
+        flush.fill_(1.0)
+        _C.linear_ws(x, [site])
+        flush.fill_(2.0)
+        _C.linear_gemm_fwd(x, W_, bias, A, B, 1e-3, 24)
+        flush.fill_(3.0)
+        _C.linear_bwd_factors(g, t, up_part, x, gt1, down_part, r, 1.0)
     Bc, C, Hh, ks = 4, 320, 64, 3
     cp = _C.conv_plan(Bc, C, C, Hh, Hh, ks, r)
     xc = torch.randn(Bc, C, Hh, Hh, device=DEV).to(torch.bfloat16)

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-2 evidence batch (run on the GPU box from the repo root): bench lines for the headline and the other BASELINE
+# geometries, kernel trace of the headline step, PMC traffic of the adapter kernels.  Outputs under gpurun_out/.
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+python bench.py > $OUT/r02_bench_line.json 2> $OUT/r02_bench_line.err
+python bench.py --text-encoder 1 --rank 8 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg2.json 2> /dev/null
+python bench.py --extended 1 --rank 16 --res 768 --batch 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3.json 2> /dev/null
+python bench.py --with-prior-preservation 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_prior.json 2> /dev/null
+python bench.py --svd --warmup 1 > $OUT/r02_bench_svd.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r02_trace -o bench -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/r02_bench_traced.json 2> $OUT/r02_bench_traced.err
+python scripts/prof_summary.py $(find $OUT/r02_trace -name "*kernel_trace.csv" | head -1) 60 > $OUT/r02_bench_kernel_trace_summary.txt
+rm -rf $OUT/r02_trace
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/r02_pmc_f -o p -- python scripts/pmc_kernels.py run > /dev/null 2> $OUT/r02_pmc_f.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/r02_pmc_w -o p -- python scripts/pmc_kernels.py run > /dev/null 2> $OUT/r02_pmc_w.err
+python scripts/pmc_kernels.py reduce $OUT/r02_pmc_f $OUT/r02_pmc_w > $OUT/r02_adapter_pmc.json 2> $OUT/r02_pmc_reduce.err
+rm -rf $OUT/r02_pmc_f $OUT/r02_pmc_w
+for f in r02_bench_line r02_bench_cfg2 r02_bench_cfg3 r02_bench_prior r02_bench_svd; do python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1]); print("$f", d["value"], d["unit"], d.get("ms_per_step"))
+except Exception as e: print("$f FAILED", e)
+PY
+done
+head -c 1800 $OUT/r02_adapter_pmc.json

@@ -113,3 +113,78 @@ def test_console_entry_points_match_reference_setup():
         mod, fn = target.split(":")
         assert mod.split(".")[-1] in ("cli_lora_add", "cli_lora_pti", "cli_svd")
         assert callable(getattr(importlib.import_module(mod), fn))
+
+
+def test_load_host_models_real_branch_with_fake_diffusers(tmp_path, monkeypatch):
+    """standin.io.load_host_models takes its diffusers branch when the package is importable and the path is a
+    directory (ref train_lora_dreambooth.py:566-594, 678-680): exercised with a fake ``diffusers`` whose classes hand
+    back small modules, incl. an attention block with the processor API."""
+    import sys
+    import types
+
+    import torch.nn as nn
+
+    from lora_amd.diffusers_glue import LoraAmdAttnProcessor
+    from lora_amd.standin import io as SIO
+
+    class Attention(nn.Module):  # the shape of diffusers.models.attention_processor.Attention that matters here
+        def __init__(self, dim=16, heads=2, ctx=None):
+            super().__init__()
+            self.heads, self.scale = heads, (dim // heads) ** -0.5
+            self.to_q = nn.Linear(dim, dim, bias=False)
+            self.to_k = nn.Linear(ctx or dim, dim, bias=False)
+            self.to_v = nn.Linear(ctx or dim, dim, bias=False)
+            self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+            self.processor = None
+
+        def set_processor(self, p):
+            self.processor = p
+
+        def forward(self, x, encoder_hidden_states=None):
+            return self.processor(self, x, encoder_hidden_states)
+
+    class FakeUNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn1, self.attn2 = Attention(), Attention(ctx=8)
+
+        @classmethod
+        def from_pretrained(cls, path, subfolder=None, revision=None):
+            return cls()
+
+    class Loader:
+        @classmethod
+        def from_pretrained(cls, *a, **k):
+            return nn.Identity()
+
+        @classmethod
+        def from_config(cls, *a, **k):
+            return "sched"
+
+    fake = types.ModuleType("diffusers")
+    fake.AutoencoderKL, fake.DDPMScheduler, fake.UNet2DConditionModel = Loader, Loader, FakeUNet
+    monkeypatch.setitem(sys.modules, "diffusers", fake)
+    import transformers
+
+    monkeypatch.setattr(transformers.CLIPTokenizer, "from_pretrained", classmethod(lambda cls, *a, **k: "tok"))
+    monkeypatch.setattr(transformers.CLIPTextModel, "from_pretrained", classmethod(lambda cls, *a, **k: nn.Identity()))
+    tok, te, vae, unet, sched, what = SIO.load_host_models(str(tmp_path), None, None, None, "cpu")
+    assert tok == "tok" and sched == "sched" and isinstance(unet, FakeUNet) and "2 attention blocks" in what
+    assert isinstance(unet.attn1.processor, LoraAmdAttnProcessor)
+    # the processor computes plain multi-head attention (self and cross), also with adapters injected (CPU: module by module)
+    torch.manual_seed(0)
+    x, ctx = torch.randn(2, 5, 16), torch.randn(2, 3, 8)
+
+    def ref(a, x, c):
+        q, k, v = a.to_q(x), a.to_k(c), a.to_v(c)
+        B, T, _ = x.shape
+        q, k, v = (t.view(B, t.shape[1], a.heads, -1).transpose(1, 2) for t in (q, k, v))
+        o = torch.softmax(q @ k.transpose(-1, -2) * a.scale, -1) @ v
+        return a.to_out[0](o.transpose(1, 2).reshape(B, T, -1))
+
+    assert torch.allclose(unet.attn1(x), ref(unet.attn1, x, x), atol=1e-5)
+    assert torch.allclose(unet.attn2(x, ctx), ref(unet.attn2, x, ctx), atol=1e-5)
+    type(unet.attn1).__name__ = "Attention"
+    L.inject_trainable_lora(unet, r=2)
+    assert isinstance(unet.attn1.to_q, L.LoraInjectedLinear)
+    assert torch.allclose(unet.attn1(x), ref(unet.attn1, x, x), atol=1e-5)
