@@ -482,7 +482,7 @@ def collapse_lora(model, alpha=1.0):
         print("Collapsing Lin Lora in" if is_lin else "Collapsing Conv Lora in", name)
         frozen = m.linear if is_lin else m.conv
         w, up, down = frozen.weight.data, m.lora_up.weight.data, m.lora_down.weight.data
-        if w.is_cuda:
+        if w.is_cuda and m.r <= _C.MAX_RANK:  # (rank-joined LoRAs beyond the kernels' rank limit: the torch expression)
             up = up.to(w.device).contiguous()
             down = down.to(w.device)
             if down.dtype != up.dtype:

@@ -102,6 +102,53 @@ def _rows2d(t: torch.Tensor, cols: int) -> torch.Tensor:
     return t2
 
 
+# ---- ranks beyond the kernels' LORA_AMD_MAX_RANK (64): the reference accepts any r <= min(in, out), and rank-joined LoRA
+# files (lora_manager.lora_join, LoRAManager) pass 64 quickly.  The primitives are linear in the rank dimension, so the
+# rank is cut into chunks of <= 64; a selector (an [r, r] matrix across ALL ranks) is applied to the assembled T with
+# one small matmul in between.
+def _rank_chunks(r: int):
+    return [(a, min(a + _C.MAX_RANK, r)) for a in range(0, r, _C.MAX_RANK)]
+
+
+def _slice_factor(f: torch.Tensor, layout: int, a: int, b: int) -> torch.Tensor:
+    return (f[a:b] if layout == _C.FACTOR_RK else f[:, a:b]).contiguous()
+
+
+def rowdot_any(x, f, layout, scale=1.0, sel=None, sel_t=False, p=0.0, seed=0, off=0):
+    r = f.shape[0] if layout == _C.FACTOR_RK else f.shape[1]
+    if r <= _C.MAX_RANK:
+        return _C.rowdot(x, f, layout, scale, sel, sel_t, p, seed, off)
+    t = torch.cat([_C.rowdot(x, _slice_factor(f, layout, a, b), layout, scale, None, False, p, seed, off)
+                   for a, b in _rank_chunks(r)], dim=1)
+    if sel is not None:
+        t = t @ (sel.float() if sel_t else sel.float().t())
+    return t.contiguous()
+
+
+def rank_update_any_(y, t, f, layout, scale=1.0, p=0.0, seed=0, off=0):
+    r = t.shape[1]
+    if r <= _C.MAX_RANK:
+        return _C.rank_update_(y, t, f, layout, scale, p, seed, off)
+    if p > 0.0:  # the mask belongs to the SUM over ranks: one masked update with the full product is needed
+        raise ValueError(f"lora_amd: dropout with rank {r} > {_C.MAX_RANK} is not supported on device")
+    for a, b in _rank_chunks(r):
+        _C.rank_update_(y, t[:, a:b].contiguous(), _slice_factor(f, layout, a, b), layout, scale, 0.0, 0, 0)
+    return y
+
+
+def colreduce_any(x, t, layout, scale=1.0, out=None, beta=0.0, p=0.0, seed=0, off=0):
+    r = t.shape[1]
+    if r <= _C.MAX_RANK:
+        return _C.colreduce(x, t, layout, scale, out=out, beta=beta, dropout_p=p, seed=seed, offset=off)
+    parts = [_C.colreduce(x, t[:, a:b].contiguous(), layout, scale, dropout_p=p, seed=seed, offset=off)
+             for a, b in _rank_chunks(r)]
+    full = torch.cat(parts, dim=0 if layout == _C.FACTOR_RK else 1)
+    if out is None:
+        return full
+    out.mul_(beta).add_(full.view_as(out))
+    return out
+
+
 class LoraLinearFunction(torch.autograd.Function):
     """y = x W^T + b + scale * dropout((x A^T) S^T B^T)   (lora.py:53-58) and its gradient.
 
@@ -136,8 +183,8 @@ class LoraLinearFunction(torch.autograd.Function):
             if fused:
                 t = _C.linear_fwd_(x2, y, down_c, up_c, scale, sel, dropout_p, seed, off)
             else:
-                t = _C.rowdot(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
-                _C.rank_update_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
+                t = rowdot_any(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
+                rank_update_any_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
         ctx.save_for_backward(x2, weight, down, up, t, sel)
         ctx.scale, ctx.p, ctx.seed, ctx.off = float(scale), float(dropout_p), seed, off
         ctx.has_bias, ctx.x_shape, ctx.sink, ctx.fused = bias is not None, x.shape, sink, fused
@@ -203,20 +250,20 @@ class LoraLinearFunction(torch.autograd.Function):
         else:
             gt = None
             if need_x or need_down:
-                gt = _C.rowdot(g2, up_c, _C.FACTOR_KR, s, sel, True, p, seed, off)  # dT = s*(G.*mask) @ B @ S
+                gt = rowdot_any(g2, up_c, _C.FACTOR_KR, s, sel, True, p, seed, off)  # dT = s*(G.*mask) @ B @ S
             if need_up:
                 if sink is not None:
-                    _C.colreduce(g2, t, _C.FACTOR_KR, s, out=sink.up_grad, beta=1.0, dropout_p=p, seed=seed, offset=off)
+                    colreduce_any(g2, t, _C.FACTOR_KR, s, out=sink.up_grad, beta=1.0, p=p, seed=seed, off=off)
                 else:
-                    d_up = _C.colreduce(g2, t, _C.FACTOR_KR, s, dropout_p=p, seed=seed, offset=off).to(up.dtype)
+                    d_up = colreduce_any(g2, t, _C.FACTOR_KR, s, p=p, seed=seed, off=off).to(up.dtype)
             if need_down:
                 if sink is not None:
-                    _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0, out=sink.down_grad, beta=1.0)
+                    colreduce_any(x2, gt, _C.FACTOR_RK, 1.0, out=sink.down_grad, beta=1.0)
                 else:
-                    d_down = _C.colreduce(x2, gt, _C.FACTOR_RK, 1.0).to(down.dtype)
+                    d_down = colreduce_any(x2, gt, _C.FACTOR_RK, 1.0).to(down.dtype)
             if need_x:
                 dx2 = g2 @ weight  # frozen dense GEMM
-                _C.rank_update_(dx2, gt, down_c, _C.FACTOR_RK, 1.0)
+                rank_update_any_(dx2, gt, down_c, _C.FACTOR_RK, 1.0)
                 dx = dx2.view(ctx.x_shape)
         dw = g2.t() @ x2 if need_w else None
         db = g2.sum(0) if (ctx.has_bias and need_b) else None

@@ -762,3 +762,35 @@ def test_distill_group_equals_per_site_recipe_on_device():
         assert (m.lora_down.weight.data - down1).abs().max() <= 1e-4 * down1.abs().max(), nm
         hi = float(torch.cat([up1.flatten(), down1.flatten()]).max())
         assert float(m.lora_down.weight.data.min()) >= -hi * (1 + 1e-6)  # clamped symmetrically (ref :42-47)
+
+
+def test_rank_beyond_kernel_limit_is_chunked_not_refused():
+    """the reference accepts any r <= min(in, out) and rank-joined files pass 64 quickly; on device the rank
+    dimension is cut into chunks of <= LORA_AMD_MAX_RANK (forward, backward, selector) and collapse_lora takes the torch
+    expression for such a site."""
+    torch.manual_seed(0)
+    K, N, r, M = 256, 192, 96, 70
+    m = L.LoraInjectedLinear(K, N, True, r=r, dropout_p=0.0, scale=0.7).to(DEV)
+    m.lora_up.weight.data.normal_(0, 0.05)
+    diag = torch.linspace(0.2, 1.5, r)
+    m.set_selector_from_diag(diag)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    y = m(x)
+    g = torch.randn(M, N, device=DEV)
+    y.backward(g)
+    W, b, A, U = (t.detach().double().cpu() for t in (m.linear.weight, m.linear.bias, m.lora_down.weight, m.lora_up.weight))
+    xd = x.detach().double().cpu().requires_grad_(True)
+    A.requires_grad_(True), U.requires_grad_(True)
+    yr = xd @ W.t() + b + 0.7 * (((xd @ A.t()) * diag.double()) @ U.t())
+    yr.backward(g.double().cpu())
+    for got, want, nm in ((y, yr, "y"), (x.grad, xd.grad, "dx"), (m.lora_down.weight.grad, A.grad, "ddown"),
+                          (m.lora_up.weight.grad, U.grad, "dup")):
+        # the frozen f32 GEMM may run on reduced-precision matrix cores (smoke() uses the same bound)
+        assert (got.detach().double().cpu() - want.detach()).abs().max() <= 2e-3 * want.detach().abs().max(), nm
+    holder = H.named_class("CrossAttention")()
+    m.selector = torch.nn.Identity()
+    holder.add_module("to_q", m)
+    w0 = m.linear.weight.detach().clone()
+    quiet(L.collapse_lora, holder, 0.5)
+    want = w0 + 0.5 * (m.lora_up.weight.detach() @ m.lora_down.weight.detach())
+    assert torch.allclose(m.linear.weight.detach(), want, rtol=1e-5, atol=1e-6)
