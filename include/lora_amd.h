@@ -352,6 +352,16 @@ int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, c
                            const float *stats, void *dx, void *workspace, size_t workspace_bytes, int32_t B,
                            int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream);
 
+/* The same for channels_last activations (memory [B][HW][C], C % 8 == 0): aff [B][4][C] f32 receives the per-channel
+ * (gamma*rstd, beta - mean*gamma*rstd, mean, rstd) the backward needs.  Three launches each way. */
+size_t lora_amd_groupnorm_nhwc_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups);
+int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, void *y, float *aff,
+                                void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                int32_t groups, float eps, int32_t act, int32_t dtype, void *stream);
+int lora_amd_groupnorm_nhwc_bwd(const void *x, const void *gout, const void *gamma, const float *aff, void *dx,
+                                void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                int32_t groups, int32_t act, int32_t dtype, void *stream);
+
 /* LayerNorm over the last dimension of row-contiguous x [M, K] (K % 8 == 0, K <= 2560; gamma / beta in the activation
  * dtype, frozen).  stats [M][2] f32 = (mean, rstd).  One launch each way. */
 int lora_amd_layernorm_supported(int32_t K);

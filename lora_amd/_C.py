@@ -38,6 +38,7 @@ SYMBOLS = (
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
     "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
     "lora_amd_layernorm_supported", "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd",
+    "lora_amd_groupnorm_nhwc_workspace", "lora_amd_groupnorm_nhwc_fwd", "lora_amd_groupnorm_nhwc_bwd",
 )
 
 
@@ -136,6 +137,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_groupnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
     lib.lora_amd_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_workspace.argtypes = [i32, i32, i32, i32]
+    lib.lora_amd_groupnorm_nhwc_workspace.restype = sz
+    lib.lora_amd_groupnorm_nhwc_fwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_fwd.restype = lib.lora_amd_groupnorm_nhwc_bwd.restype = C.c_int
     lib.lora_amd_layernorm_supported.argtypes = [i32]
     lib.lora_amd_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
     lib.lora_amd_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
@@ -836,4 +842,49 @@ def layernorm_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, stat
     _check(require().lora_amd_layernorm_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
                                             dx.data_ptr(), x.numel() // K, K, dtype_code(x.dtype), _stream()),
            "lora_amd_layernorm_bwd")
+    return dx
+
+
+_gn_nhwc_ws_cache: Dict[Tuple[int, int, int, int], int] = {}
+
+
+def groupnorm_nhwc_workspace(B: int, C_: int, HW: int, groups: int) -> int:
+    key = (B, C_, HW, groups)
+    n = _gn_nhwc_ws_cache.get(key)
+    if n is None:
+        n = _gn_nhwc_ws_cache[key] = int(require().lora_amd_groupnorm_nhwc_workspace(B, C_, HW, groups))
+    return n
+
+
+def groupnorm_nhwc_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                       act: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GroupNorm (+SiLU) of a channels_last x [B, C, H, W]; returns (y channels_last, aff [B, 4, C] f32)."""
+    _dev_check(x, gamma, beta)
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_nhwc_workspace(B, C_, HW, groups)
+    if nbytes == 0:
+        raise ValueError(f"lora_amd_groupnorm_nhwc: geometry {tuple(x.shape)} / {groups} groups not supported")
+    y = torch.empty_like(x)  # preserves the channels_last strides
+    aff = torch.empty(B, 4, C_, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_nhwc_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                 aff.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups, eps,
+                                                 1 if act else 0, dtype_code(x.dtype), _stream()),
+           "lora_amd_groupnorm_nhwc_fwd")
+    return y, aff
+
+
+def groupnorm_nhwc_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, aff: torch.Tensor, groups: int,
+                       act: bool) -> torch.Tensor:
+    _dev_check(x, gout, gamma, aff)
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_nhwc_workspace(B, C_, HW, groups)
+    dx = torch.empty_like(x)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_nhwc_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), aff.data_ptr(),
+                                                 dx.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups,
+                                                 1 if act else 0, dtype_code(x.dtype), _stream()),
+           "lora_amd_groupnorm_nhwc_bwd")
     return dx

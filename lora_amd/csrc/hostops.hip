@@ -544,6 +544,324 @@ static inline int ln_logL(int c8) {
   return -1;
 }
 
+// ---- GroupNorm on channels_last (NHWC) activations -------------------------------------------------------------------
+// Memory is [B][HW][C]: a group is C/G adjacent channels of every pixel, so the reduction runs over pixels.  Every
+// streaming kernel uses a column-owner mapping: thread = (pixel slot, 16-byte channel chunk), the chunk is fixed for
+// the thread's lifetime (its per-channel vectors are loaded once), consecutive lanes read consecutive chunks of one
+// pixel (contiguous runs of cw * 16 bytes).  Statistics are per channel and per pixel slice (shifted sums -> mean, M2),
+// a tiny finalize kernel folds slices and the group's channels together (Chan) and expands the result per channel:
+//   aff[b][0][c] = gamma*rstd, aff[b][1][c] = beta - mean*gamma*rstd, aff[b][2][c] = mean, aff[b][3][c] = rstd
+// so that the apply kernels are pure per-channel affine maps.  3 + 3 launches; MIOpen's NHWC kernels then need no
+// NCHW<->NHWC transposes around them and the transformer blocks read the activations as tokens without a copy.
+constexpr int kNU = 4;  // pixels in flight per thread
+
+struct GnNhwcGeo {
+  int c8, cw, tiles, nslots, px, S;
+  bool ok;
+};
+static GnNhwcGeo gn_nhwc_geo(int B, int C, int HW, int G) {
+  GnNhwcGeo q{};
+  q.ok = B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0 && C % 8 == 0;
+  if (!q.ok) return q;
+  q.c8 = C / 8;
+  int best = 1, best_act = 0;
+  for (int d = 1; d <= std::min(q.c8, 128); ++d) {
+    if (q.c8 % d) continue;
+    const int act = (kHT / d) * d;
+    if (act >= best_act) { best_act = act; best = d; }
+  }
+  q.cw = best;
+  q.tiles = q.c8 / q.cw;
+  q.nslots = kHT / q.cw;
+  int64_t px = std::max<int64_t>(2 * q.nslots * kNU, (int64_t)HW * B * q.tiles / 768);
+  px = std::min<int64_t>(px, HW);
+  q.px = (int)px;
+  q.S = (HW + q.px - 1) / q.px;
+  return q;
+}
+
+struct NhwcBlock {
+  int b, s, col, slot, np;
+  bool active;
+  int64_t base;  // element offset of (b, first pixel of the slice, this thread's chunk)
+};
+__device__ inline NhwcBlock nhwc_block(int C, int HW, int cw, int tiles, int nslots, int px, int S) {
+  NhwcBlock k;
+  const int bs = blockIdx.x / tiles, tile = blockIdx.x - bs * tiles;
+  k.b = bs / S;
+  k.s = bs - k.b * S;
+  k.slot = threadIdx.x / cw;
+  const int cl = threadIdx.x - k.slot * cw;
+  k.active = k.slot < nslots;
+  k.col = tile * cw + cl;
+  const int p0 = k.s * px;
+  k.np = min(px, HW - p0);
+  k.base = ((int64_t)k.b * HW + p0) * C + (int64_t)k.col * 8;
+  return k;
+}
+
+__device__ inline void ld8f(const float *p, float (&v)[8]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+}
+__device__ inline void st8f(float *p, const float (&v)[8]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[i + 4]; }
+  *reinterpret_cast<f4 *>(p) = a;
+  *reinterpret_cast<f4 *>(p + 4) = b;
+}
+
+// Sum acc0 / acc1 (8 channels each) over the pixel slots of the block; slot 0 receives the totals.
+__device__ inline void nhwc_slot_reduce(float (&a0)[8], float (&a1)[8], const NhwcBlock &k, int cw, int nslots,
+                                        float *s_red /* [2][kHT][8] */) {
+  if (k.active) {
+    st8f(s_red + (size_t)threadIdx.x * 8, a0);
+    st8f(s_red + (size_t)(kHT + threadIdx.x) * 8, a1);
+  }
+  __syncthreads();
+  if (k.active && k.slot == 0) {
+    for (int sl = 1; sl < nslots; ++sl) {
+      float t0[8], t1[8];
+      ld8f(s_red + (size_t)(sl * cw + threadIdx.x) * 8, t0);
+      ld8f(s_red + (size_t)(kHT + sl * cw + threadIdx.x) * 8, t1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] += t0[e]; a1[e] += t1[e]; }
+    }
+  }
+}
+
+// part[((b*S + s)*2 + 0)*C + c] = slice mean of channel c, [.. + 1] = slice M2
+template <class E>
+__global__ __launch_bounds__(kHT) void gn_nhwc_stats_kernel(const typename E::storage *__restrict__ x,
+                                                            float *__restrict__ part, int C, int HW, int cw, int tiles,
+                                                            int nslots, int px, int S) {
+  __shared__ __attribute__((aligned(16))) float s_red[2 * kHT * 8];
+  const NhwcBlock k = nhwc_block(C, HW, cw, tiles, nslots, px, S);
+  float sh[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  if (k.active) {
+    unpack8_sel<E>(load8_raw<E>(x + k.base), true, sh);  // shift = the slice's first pixel (same for every slot)
+    for (int p = k.slot; p < k.np; p += nslots * kNU) {
+      Raw8<E> raw[kNU];
+#pragma unroll
+      for (int u = 0; u < kNU; ++u) {
+        const int pp = p + u * nslots;
+        raw[u] = load8_raw<E>(x + k.base + (int64_t)(pp < k.np ? pp : p) * C);
+      }
+      LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+      for (int u = 0; u < kNU; ++u) {
+        float v[8];
+        unpack8_sel<E>(raw[u], true, v);
+        if (p + u * nslots < k.np) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[e] - sh[e];
+            s1[e] += d;
+            s2[e] = fmaf(d, d, s2[e]);
+          }
+        }
+      }
+    }
+  }
+  nhwc_slot_reduce(s1, s2, k, cw, nslots, s_red);
+  if (k.active && k.slot == 0) {
+    const float inv_n = 1.f / (float)k.np;
+    float mean[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[e] = sh[e] + s1[e] * inv_n;
+      m2[e] = fmaxf(s2[e] - s1[e] * s1[e] * inv_n, 0.f);
+    }
+    float *o = part + ((int64_t)(k.b * S + k.s) * 2) * C + (int64_t)k.col * 8;
+    st8f(o, mean);
+    st8f(o + C, m2);
+  }
+}
+
+// One workgroup per (sample, group): fold slices x channels, expand per channel.
+template <class E>
+__global__ __launch_bounds__(kHT) void gn_nhwc_finalize_kernel(const float *__restrict__ part,
+                                                               const typename E::storage *__restrict__ gamma,
+                                                               const typename E::storage *__restrict__ beta,
+                                                               float *__restrict__ aff, int C, int HW, int G, int px,
+                                                               int S, float eps) {
+  __shared__ float s_red[4][2];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
+  const int items = S * cpg;
+  float a = 0.f, zero = 0.f;
+  for (int i = threadIdx.x; i < items; i += kHT) {
+    const int s = i / cpg, c = g * cpg + (i - s * cpg);
+    a += (float)min(px, HW - s * px) * part[((int64_t)(b * S + s) * 2) * C + c];
+  }
+  block_sum2(a, zero, s_red);
+  const float n_all = (float)HW * (float)cpg;
+  const float mean = a / n_all;
+  float m2 = 0.f;
+  zero = 0.f;
+  for (int i = threadIdx.x; i < items; i += kHT) {
+    const int s = i / cpg, c = g * cpg + (i - s * cpg);
+    const float *pp = part + ((int64_t)(b * S + s) * 2) * C + c;
+    const float dm = pp[0] - mean;
+    m2 += pp[C] + (float)min(px, HW - s * px) * dm * dm;
+  }
+  block_sum2(m2, zero, s_red);
+  const float rstd = rsqrtf(m2 / n_all + eps);
+  for (int cc = threadIdx.x; cc < cpg; cc += kHT) {
+    const int c = g * cpg + cc;
+    const float ga = E::to_f(gamma[c]) * rstd;
+    float *o = aff + (int64_t)b * 4 * C + c;
+    o[0] = ga;
+    o[C] = fmaf(-mean, ga, E::to_f(beta[c]));
+    o[2 * C] = mean;
+    o[3 * C] = rstd;
+  }
+}
+
+template <class E, bool ACT>
+__global__ __launch_bounds__(kHT) void gn_nhwc_apply_kernel(const typename E::storage *__restrict__ x,
+                                                            const float *__restrict__ aff,
+                                                            typename E::storage *__restrict__ y, int C, int HW, int cw,
+                                                            int tiles, int nslots, int px, int S) {
+  const NhwcBlock k = nhwc_block(C, HW, cw, tiles, nslots, px, S);
+  if (!k.active) return;
+  float ga[8], be[8];
+  ld8f(aff + (int64_t)k.b * 4 * C + (int64_t)k.col * 8, ga);
+  ld8f(aff + (int64_t)k.b * 4 * C + C + (int64_t)k.col * 8, be);
+  for (int p = k.slot; p < k.np; p += nslots * kNU) {
+    Raw8<E> raw[kNU];
+#pragma unroll
+    for (int u = 0; u < kNU; ++u) {
+      const int pp = p + u * nslots;
+      raw[u] = load8_raw<E>(x + k.base + (int64_t)(pp < k.np ? pp : p) * C);
+    }
+    LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+    for (int u = 0; u < kNU; ++u) {
+      const int pp = p + u * nslots;
+      if (pp < k.np) {
+        float v[8], o[8];
+        unpack8_sel<E>(raw[u], true, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float z = fmaf(v[e], ga[e], be[e]);
+          o[e] = ACT ? z * sigmoidf(z) : z;
+        }
+        store8<E>(y + k.base + (int64_t)pp * C, o);
+      }
+    }
+  }
+}
+
+// backward: t = gamma * dz, xh = (x - mean) * rstd;  per channel and pixel slice: sum t, sum t*xh
+template <class E, bool ACT>
+__device__ inline void gn_nhwc_terms(const float (&v)[8], const float (&go)[8], const float (&ga)[8],
+                                     const float (&be)[8], const float (&mean)[8], const float (&rstd)[8],
+                                     const float (&gam)[8], float (&t)[8], float (&xh)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    xh[e] = (v[e] - mean[e]) * rstd[e];
+    float dz = go[e];
+    if (ACT) dz *= silu_grad(fmaf(v[e], ga[e], be[e]));
+    t[e] = gam[e] * dz;
+  }
+}
+
+template <class E, bool ACT, bool APPLY>
+__global__ __launch_bounds__(kHT) void gn_nhwc_bwd_kernel(const typename E::storage *__restrict__ x,
+                                                          const typename E::storage *__restrict__ gout,
+                                                          const typename E::storage *__restrict__ gamma,
+                                                          const float *__restrict__ aff,
+                                                          float *__restrict__ part,        // !APPLY: out [B][S][2][C]
+                                                          const float *__restrict__ cvec,  // APPLY: [B][2][C] = c1, c2
+                                                          typename E::storage *__restrict__ dx, int C, int HW, int cw,
+                                                          int tiles, int nslots, int px, int S) {
+  __shared__ __attribute__((aligned(16))) float s_red[APPLY ? 8 : 2 * kHT * 8];
+  const NhwcBlock k = nhwc_block(C, HW, cw, tiles, nslots, px, S);
+  float ga[8], be[8], mean[8], rstd[8], gam[8], c1[8], c2[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = c1[e] = c2[e] = 0.f;
+  if (k.active) {
+    const float *ab = aff + (int64_t)k.b * 4 * C + (int64_t)k.col * 8;
+    ld8f(ab, ga);
+    ld8f(ab + C, be);
+    ld8f(ab + 2 * C, mean);
+    ld8f(ab + 3 * C, rstd);
+    unpack8_sel<E>(load8_raw<E>(gamma + (int64_t)k.col * 8), true, gam);
+    if (APPLY) {
+      ld8f(cvec + (int64_t)k.b * 2 * C + (int64_t)k.col * 8, c1);
+      ld8f(cvec + (int64_t)k.b * 2 * C + C + (int64_t)k.col * 8, c2);
+    }
+    for (int p = k.slot; p < k.np; p += nslots * kNU) {
+      Raw8<E> xr[kNU], gr[kNU];
+#pragma unroll
+      for (int u = 0; u < kNU; ++u) {
+        const int pp = p + u * nslots;
+        const int64_t off = k.base + (int64_t)(pp < k.np ? pp : p) * C;
+        xr[u] = load8_raw<E>(x + off);
+        gr[u] = load8_raw<E>(gout + off);
+      }
+      LORA_AMD_LOADS_ISSUED();
+#pragma unroll
+      for (int u = 0; u < kNU; ++u) {
+        const int pp = p + u * nslots;
+        if (pp < k.np) {
+          float v[8], go[8], t[8], xh[8];
+          unpack8_sel<E>(xr[u], true, v);
+          unpack8_sel<E>(gr[u], true, go);
+          gn_nhwc_terms<E, ACT>(v, go, ga, be, mean, rstd, gam, t, xh);
+          if (APPLY) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd[e] * (t[e] - c1[e] - xh[e] * c2[e]);
+            store8<E>(dx + k.base + (int64_t)pp * C, o);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s1[e] += t[e];
+              s2[e] = fmaf(t[e], xh[e], s2[e]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!APPLY) {
+    nhwc_slot_reduce(s1, s2, k, cw, nslots, s_red);
+    if (k.active && k.slot == 0) {
+      float *o = part + ((int64_t)(k.b * S + k.s) * 2) * C + (int64_t)k.col * 8;
+      st8f(o, s1);
+      st8f(o + C, s2);
+    }
+  }
+}
+
+// cvec[b][0][c] = (sum over the group of s1) / n, cvec[b][1][c] = (sum of s2) / n, expanded per channel
+__global__ __launch_bounds__(kHT) void gn_nhwc_bwd_finalize_kernel(const float *__restrict__ part,
+                                                                   float *__restrict__ cvec, int C, int HW, int G,
+                                                                   int S) {
+  __shared__ float s_red[4][2];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, cpg = C / G;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < S * cpg; i += kHT) {
+    const int s = i / cpg, c = g * cpg + (i - s * cpg);
+    const float *pp = part + ((int64_t)(b * S + s) * 2) * C + c;
+    s1 += pp[0];
+    s2 += pp[C];
+  }
+  block_sum2(s1, s2, s_red);
+  const float inv_n = 1.f / ((float)HW * (float)cpg);
+  for (int cc = threadIdx.x; cc < cpg; cc += kHT) {
+    cvec[(int64_t)b * 2 * C + g * cpg + cc] = s1 * inv_n;
+    cvec[(int64_t)b * 2 * C + C + g * cpg + cc] = s2 * inv_n;
+  }
+}
+
 static inline bool aligned_for(const void *p, int dt) { return ((uintptr_t)p % (dt == LORA_AMD_F32 ? 32 : 16)) == 0; }
 
 }  // namespace lora_amd
@@ -733,4 +1051,87 @@ extern "C" int lora_amd_layernorm_bwd(const void *x, const void *gout, const voi
   }
 #undef GO
   return check_launch("lora_amd_layernorm_bwd");
+}
+
+// ---- channels_last GroupNorm entry points ----------------------------------------------------------------------
+static size_t gn_nhwc_part_floats(const GnNhwcGeo &q, int B, int C) { return (size_t)B * q.S * 2 * C; }
+
+extern "C" size_t lora_amd_groupnorm_nhwc_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups) {
+  const GnNhwcGeo q = gn_nhwc_geo(B, C, HW, groups);
+  return q.ok ? (gn_nhwc_part_floats(q, B, C) + (size_t)B * 2 * C) * sizeof(float) : 0;
+}
+
+#define GN_NHWC_CHECKS(name)                                                                                          \
+  const GnNhwcGeo q = gn_nhwc_geo(B, C, HW, groups);                                                                  \
+  LORA_AMD_CHECK(q.ok, LORA_AMD_EINVAL, name ": geometry B=%d C=%d HW=%d groups=%d not supported", B, C, HW, groups); \
+  LORA_AMD_CHECK(dtype_ok(dtype), LORA_AMD_EINVAL, name ": bad dtype %d", dtype);                                     \
+  LORA_AMD_CHECK(workspace_bytes >= lora_amd_groupnorm_nhwc_workspace(B, C, HW, groups), LORA_AMD_EWORKSPACE,         \
+                 name ": workspace %zu bytes too small", workspace_bytes);                                            \
+  const dim3 grid((unsigned)((int64_t)B * q.S * q.tiles)), gridg((unsigned)(B * groups)), block(kHT);                 \
+  hipStream_t st = (hipStream_t)stream;                                                                               \
+  float *part = reinterpret_cast<float *>(workspace);                                                                 \
+  float *cvec = part + gn_nhwc_part_floats(q, B, C);                                                                  \
+  (void)cvec
+
+extern "C" int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, void *y, float *aff,
+                                           void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                           int32_t groups, float eps, int32_t act, int32_t dtype, void *stream) {
+  GN_NHWC_CHECKS("groupnorm_nhwc_fwd");
+  LORA_AMD_CHECK(x && gamma && beta && y && aff && workspace, LORA_AMD_EINVAL, "groupnorm_nhwc_fwd: null pointer");
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(y, dtype) && ((uintptr_t)aff % 32) == 0, LORA_AMD_EINVAL,
+                 "groupnorm_nhwc_fwd: unaligned tensor");
+#define GO(E)                                                                                                         \
+  {                                                                                                                   \
+    using S_ = typename E::storage;                                                                                   \
+    hipLaunchKernelGGL((gn_nhwc_stats_kernel<E>), grid, block, 0, st, (const S_ *)x, part, C, HW, q.cw, q.tiles,      \
+                       q.nslots, q.px, q.S);                                                                          \
+    hipLaunchKernelGGL((gn_nhwc_finalize_kernel<E>), gridg, block, 0, st, part, (const S_ *)gamma, (const S_ *)beta,  \
+                       aff, C, HW, groups, q.px, q.S, eps);                                                           \
+    if (act)                                                                                                          \
+      hipLaunchKernelGGL((gn_nhwc_apply_kernel<E, true>), grid, block, 0, st, (const S_ *)x, aff, (S_ *)y, C, HW,     \
+                         q.cw, q.tiles, q.nslots, q.px, q.S);                                                         \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gn_nhwc_apply_kernel<E, false>), grid, block, 0, st, (const S_ *)x, aff, (S_ *)y, C, HW,    \
+                         q.cw, q.tiles, q.nslots, q.px, q.S);                                                         \
+  }                                                                                                                   \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+  return check_launch("lora_amd_groupnorm_nhwc_fwd");
+}
+
+extern "C" int lora_amd_groupnorm_nhwc_bwd(const void *x, const void *gout, const void *gamma, const float *aff,
+                                           void *dx, void *workspace, size_t workspace_bytes, int32_t B, int32_t C,
+                                           int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream) {
+  GN_NHWC_CHECKS("groupnorm_nhwc_bwd");
+  LORA_AMD_CHECK(x && gout && gamma && aff && dx && workspace, LORA_AMD_EINVAL, "groupnorm_nhwc_bwd: null pointer");
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(gout, dtype) && aligned_for(dx, dtype) &&
+                     aligned_for(gamma, dtype) && ((uintptr_t)aff % 32) == 0,
+                 LORA_AMD_EINVAL, "groupnorm_nhwc_bwd: unaligned tensor");
+#define GO2(E, A)                                                                                                     \
+  {                                                                                                                   \
+    using S_ = typename E::storage;                                                                                   \
+    hipLaunchKernelGGL((gn_nhwc_bwd_kernel<E, A, false>), grid, block, 0, st, (const S_ *)x, (const S_ *)gout,        \
+                       (const S_ *)gamma, aff, part, (const float *)nullptr, (S_ *)nullptr, C, HW, q.cw, q.tiles,     \
+                       q.nslots, q.px, q.S);                                                                          \
+    hipLaunchKernelGGL(gn_nhwc_bwd_finalize_kernel, gridg, block, 0, st, part, cvec, C, HW, groups, q.S);             \
+    hipLaunchKernelGGL((gn_nhwc_bwd_kernel<E, A, true>), grid, block, 0, st, (const S_ *)x, (const S_ *)gout,         \
+                       (const S_ *)gamma, aff, (float *)nullptr, cvec, (S_ *)dx, C, HW, q.cw, q.tiles, q.nslots,      \
+                       q.px, q.S);                                                                                    \
+  }
+#define GO(E) \
+  if (act) GO2(E, true) else GO2(E, false) \
+  break
+  switch (dtype) {
+    case LORA_AMD_F32: GO(f32_t);
+    case LORA_AMD_F16: GO(f16_t);
+    default: GO(bf16_t);
+  }
+#undef GO
+#undef GO2
+  return check_launch("lora_amd_groupnorm_nhwc_bwd");
 }

@@ -40,20 +40,57 @@ class _GroupNormAct(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class _GroupNormActNHWC(torch.autograd.Function):
+    """The same for channels_last activations (memory [B][HW][C]); saves x and the per-channel affine [B, 4, C]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups: int, eps: float, act: bool):
+        y, aff = _C.groupnorm_nhwc_fwd(x, weight, bias, groups, eps, act)
+        ctx.save_for_backward(x, weight, aff)
+        ctx.groups, ctx.act = groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, aff = ctx.saved_tensors
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gout = gout.contiguous(memory_format=torch.channels_last)
+            dx = _C.groupnorm_nhwc_bwd(x, gout, weight, aff, ctx.groups, ctx.act)
+        return dx, None, None, None, None, None
+
+
+def _frozen_affine(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
+    w, b = norm.weight, norm.bias
+    return not (w is None or b is None or w.requires_grad or b.requires_grad or w.dtype != x.dtype
+                or b.dtype != x.dtype)
+
+
 def _gn_native(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
     if not (_ENABLED and x.is_cuda and x.dim() >= 3 and x.dtype in _DTYPES and x.is_contiguous()):
         return False
-    w, b = norm.weight, norm.bias
-    if w is None or b is None or w.requires_grad or b.requires_grad or w.dtype != x.dtype or b.dtype != x.dtype:
+    if not _frozen_affine(x, norm):
         return False
     B, C = x.shape[0], x.shape[1]
     return _C.groupnorm_workspace(B, C, x.numel() // (B * C), norm.num_groups) > 0
+
+
+def _gn_native_nhwc(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
+    if not (_ENABLED and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 32 == 0):
+        return False
+    if not _frozen_affine(x, norm):
+        return False
+    B, C = x.shape[0], x.shape[1]
+    return _C.groupnorm_nhwc_workspace(B, C, x.numel() // (B * C), norm.num_groups) > 0
 
 
 def group_norm_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True) -> torch.Tensor:
     """``silu(norm(x))`` (``act``) or ``norm(x)`` — ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm."""
     if _gn_native(x, norm):
         return _GroupNormAct.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
+    if _gn_native_nhwc(x, norm):
+        return _GroupNormActNHWC.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
     y = norm(x)
     return F.silu(y) if act else y
 

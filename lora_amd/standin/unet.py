@@ -131,22 +131,23 @@ class Transformer2DModel(nn.Module):
         B, C, H, W = x.shape
         n = group_norm_act(x, self.norm, act=False)
         nhwc = n.is_contiguous(memory_format=torch.channels_last) and not n.is_contiguous()
-        # A 1x1 convolution IS the token-major linear map.  On NCHW activations run it there: one library GEMM with
-        # the bias in its epilogue instead of a MIOpen call wrapped in NCHW<->NHWC transposes plus a strided bias add
-        # (proj_in / proj_out are not adapter sites of the reference's target classes; if they have been replaced,
-        # or the activations are channels_last, keep the convolution).
-        as_linear = (not nhwc and type(self.proj_in) is nn.Conv2d and type(self.proj_out) is nn.Conv2d
+        # A 1x1 convolution IS the token-major linear map: one library GEMM with the bias in its epilogue instead of a
+        # MIOpen call (on NCHW activations wrapped in NCHW<->NHWC transposes) plus a strided bias add.  On channels_last
+        # activations the token view is free in both directions (proj_in / proj_out are not adapter sites of the
+        # reference's target classes; if they have been replaced, keep the module call).
+        as_linear = (type(self.proj_in) is nn.Conv2d and type(self.proj_out) is nn.Conv2d
                      and self.proj_in.kernel_size == (1, 1) and self.proj_out.kernel_size == (1, 1))
         if as_linear:
-            h = n.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = n.permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when the activations are NHWC, else one copy
             h = F.linear(h, self.proj_in.weight.view(C, C), self.proj_in.bias)
         else:
-            h = self.proj_in(n).permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are NHWC
+            h = self.proj_in(n).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         if as_linear:
             h = F.linear(h, self.proj_out.weight.view(C, C), self.proj_out.bias)
-            return h.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous() + x
+            h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)  # channels_last strides
+            return (h if nhwc else h.contiguous()) + x
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         if not nhwc:
             h = h.contiguous()

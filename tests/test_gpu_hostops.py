@@ -53,6 +53,40 @@ def test_groupnorm_act_forward_backward(B, C, H, W, G, dt, act):
     _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
 
 
+NHWC_SHAPES = [(4, 320, 64, 64, 32), (2, 640, 32, 32, 32), (2, 1280, 8, 8, 32), (1, 960, 16, 16, 32), (3, 64, 4, 6, 8),
+               (2, 32, 8, 8, 32), (1, 1920, 24, 24, 32), (2, 96, 3, 5, 3), (2, 2560, 8, 8, 32), (1, 88, 5, 7, 11)]
+
+
+@pytest.mark.parametrize("B,C,H,W,G", NHWC_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_act_channels_last_forward_backward(B, C, H, W, G, dt, act):
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + torch.randn(1, C, 1, 1, generator=g) * 3.0).to(dt).to(DEV)
+    x = x.contiguous(memory_format=torch.channels_last)
+    norm = nn.GroupNorm(G, C, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(B, C, H, W, generator=g).to(dt).to(DEV)  # NCHW-contiguous on purpose: converted inside
+    assert fused._gn_native_nhwc(x, norm) and not fused._gn_native(x, norm)
+
+    xg = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    y = fused.group_norm_act(xg, norm, act)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gout)
+    assert xg.grad.shape == x.shape
+
+    xr = x.float().contiguous().requires_grad_(True)
+    yr = F.group_norm(xr, G, norm.weight.float(), norm.bias.float(), norm.eps)
+    if act:
+        yr = F.silu(yr)
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
+
+
 def test_groupnorm_statistics_and_fallbacks():
     x = torch.randn(2, 64, 8, 8, device=DEV) * 2 + 5
     norm = nn.GroupNorm(8, 64).to(DEV).requires_grad_(False)

@@ -111,10 +111,22 @@ def test_transformer2d_token_major_projection_equals_the_1x1_convolutions():
     ctx = torch.randn(2, 5, 16)
     y1 = m(x, ctx)
     (g1,) = torch.autograd.grad(y1.square().sum(), x)
-    y0 = m(x.contiguous(memory_format=torch.channels_last), ctx)
+    yc = m(x.contiguous(memory_format=torch.channels_last), ctx)  # token view is free on NHWC activations
+    assert yc.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1, yc.contiguous(), rtol=1e-5, atol=1e-5)
+
+    class Conv1x1(nn.Conv2d):  # any subclass keeps the module call (what an injected adapter looks like)
+        pass
+
+    for name in ("proj_in", "proj_out"):
+        old = getattr(m, name)
+        new = Conv1x1(32, 32, 1)
+        new.load_state_dict(old.state_dict())
+        setattr(m, name, new)
+    y0 = m(x, ctx)
     (g0,) = torch.autograd.grad(y0.square().sum(), x)
-    torch.testing.assert_close(y1, y0.contiguous(), rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(g1, g0.contiguous(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     # an adapter injected into the projection (custom target class) keeps the module call
     L.inject_trainable_lora_extended(m, target_replace_module={"Transformer2DModel"}, r=2)
     assert type(m.proj_in).__name__ == "LoraInjectedConv2d"
