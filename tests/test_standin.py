@@ -128,9 +128,11 @@ def test_transformer2d_token_major_projection_equals_the_1x1_convolutions():
     torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     # an adapter injected into the projection (custom target class) keeps the module call
-    L.inject_trainable_lora_extended(m, target_replace_module={"Transformer2DModel"}, r=2)
-    assert type(m.proj_in).__name__ == "LoraInjectedConv2d"
-    y2 = m(x, ctx)  # lora_up is zero-initialised: same output through the module path
+    torch.manual_seed(0)
+    m2 = Transformer2DModel(32, 2, 16, groups=8)
+    L.inject_trainable_lora_extended(m2, target_replace_module={"Transformer2DModel"}, r=2)
+    assert type(m2.proj_in).__name__ == "LoraInjectedConv2d"
+    y2 = m2(x, ctx)  # same seed, lora_up zero-initialised: same output through the module path
     torch.testing.assert_close(y2, y1, rtol=1e-5, atol=1e-5)
     del F
 
