@@ -44,11 +44,20 @@ def _run(q, k, v, backend: Optional[str], pad_to: int):
     return o[..., :d] if pad_to > d else o
 
 
+def _pad_candidates(d: int):
+    """Head sizes worth timing: as is, and the next multiples of 16 / 32 / 64-128-256 (what the library kernels are
+    specialised for: 40 -> 48, 64; 80 -> 96, 128).  LORA_AMD_SDPA_PADS=0 keeps only the 64/128/256 step."""
+    if os.environ.get("LORA_AMD_SDPA_PADS", "1") == "0":
+        return sorted({d, _padded(d)})
+    return sorted({d, -(-d // 16) * 16, -(-d // 32) * 32, _padded(d)})
+
+
 def _tune(q, k, v) -> Tuple[Optional[str], int]:
     d = q.shape[-1]
     cands = [(None, d), ("EFFICIENT_ATTENTION", d)]
-    if _padded(d) > d:
-        cands += [("EFFICIENT_ATTENTION", _padded(d)), ("FLASH_ATTENTION", _padded(d))]
+    for pad in _pad_candidates(d):
+        if pad > d:
+            cands += [("EFFICIENT_ATTENTION", pad), ("FLASH_ATTENTION", pad)]
     best, best_t = (None, d), float("inf")
     for be, pad in cands:
         try:
