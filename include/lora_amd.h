@@ -353,10 +353,13 @@ int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, c
                            int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream);
 
 /* The same for channels_last activations (memory [B][HW][C], C % 8 == 0): aff [B][4][C] f32 receives the per-channel
- * (gamma*rstd, beta - mean*gamma*rstd, mean, rstd) the backward needs.  Three launches each way. */
+ * (gamma*rstd, beta - mean*gamma*rstd, mean, rstd) the backward needs.  Three launches each way.
+ * `addend` [B][C] f32 (or NULL) is added to x before the normalisation (time-embedding projection + the bias of the
+ * producing convolution in ResnetBlock2D) at no streaming cost; it is folded into aff, the backward needs no change
+ * (the gradient w.r.t. the addend is the per-(sample, channel) sum of dx). */
 size_t lora_amd_groupnorm_nhwc_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups);
-int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, void *y, float *aff,
-                                void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, const float *addend, void *y,
+                                float *aff, void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
                                 int32_t groups, float eps, int32_t act, int32_t dtype, void *stream);
 int lora_amd_groupnorm_nhwc_bwd(const void *x, const void *gout, const void *gamma, const float *aff, void *dx,
                                 void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,

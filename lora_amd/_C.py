@@ -139,7 +139,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
     lib.lora_amd_groupnorm_nhwc_workspace.argtypes = [i32, i32, i32, i32]
     lib.lora_amd_groupnorm_nhwc_workspace.restype = sz
-    lib.lora_amd_groupnorm_nhwc_fwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
     lib.lora_amd_groupnorm_nhwc_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_groupnorm_nhwc_fwd.restype = lib.lora_amd_groupnorm_nhwc_bwd.restype = C.c_int
     lib.lora_amd_layernorm_supported.argtypes = [i32]
@@ -857,9 +857,13 @@ def groupnorm_nhwc_workspace(B: int, C_: int, HW: int, groups: int) -> int:
 
 
 def groupnorm_nhwc_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
-                       act: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """GroupNorm (+SiLU) of a channels_last x [B, C, H, W]; returns (y channels_last, aff [B, 4, C] f32)."""
-    _dev_check(x, gamma, beta)
+                       act: bool, addend: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GroupNorm (+SiLU) of a channels_last x [B, C, H, W] (+ addend [B, C] f32 before the normalisation); returns
+    (y channels_last, aff [B, 4, C] f32)."""
+    _dev_check(x, gamma, beta, addend)
+    if addend is not None and (addend.dtype != torch.float32 or not addend.is_contiguous()
+                               or tuple(addend.shape) != (x.shape[0], x.shape[1])):
+        raise ValueError("groupnorm_nhwc_fwd: addend must be a contiguous float32 [B, C] tensor")
     B, C_ = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C_)
     nbytes = groupnorm_nhwc_workspace(B, C_, HW, groups)
@@ -868,8 +872,8 @@ def groupnorm_nhwc_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     y = torch.empty_like(x)  # preserves the channels_last strides
     aff = torch.empty(B, 4, C_, dtype=torch.float32, device=x.device)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    _check(require().lora_amd_groupnorm_nhwc_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                                 aff.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups, eps,
+    _check(require().lora_amd_groupnorm_nhwc_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(addend),
+                                                 y.data_ptr(), aff.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups, eps,
                                                  1 if act else 0, dtype_code(x.dtype), _stream()),
            "lora_amd_groupnorm_nhwc_fwd")
     return y, aff

@@ -684,11 +684,16 @@ __global__ __launch_bounds__(kHT) void gn_nhwc_stats_kernel(const typename E::st
   }
 }
 
-// One workgroup per (sample, group): fold slices x channels, expand per channel.
+// One workgroup per (sample, group): fold slices x channels, expand per channel.  `addend` [B][C] (f32, may be null)
+// is a per-(sample, channel) term added to x BEFORE the normalisation (ResnetBlock2D: the time-embedding projection and
+// the bias of the convolution that produced x).  A per-channel shift moves only the channel means, so it costs nothing
+// in the streaming kernels: slice means are shifted here, and the expanded affine absorbs it,
+//   z = ((x + add) - mean) * rstd * gamma + beta = x * a + (beta + (add - mean) * a),   xh = (x - (mean - add)) * rstd.
 template <class E>
 __global__ __launch_bounds__(kHT) void gn_nhwc_finalize_kernel(const float *__restrict__ part,
                                                                const typename E::storage *__restrict__ gamma,
                                                                const typename E::storage *__restrict__ beta,
+                                                               const float *__restrict__ addend,
                                                                float *__restrict__ aff, int C, int HW, int G, int px,
                                                                int S, float eps) {
   __shared__ float s_red[4][2];
@@ -697,7 +702,8 @@ __global__ __launch_bounds__(kHT) void gn_nhwc_finalize_kernel(const float *__re
   float a = 0.f, zero = 0.f;
   for (int i = threadIdx.x; i < items; i += kHT) {
     const int s = i / cpg, c = g * cpg + (i - s * cpg);
-    a += (float)min(px, HW - s * px) * part[((int64_t)(b * S + s) * 2) * C + c];
+    const float add = addend != nullptr ? addend[(int64_t)b * C + c] : 0.f;
+    a += (float)min(px, HW - s * px) * (part[((int64_t)(b * S + s) * 2) * C + c] + add);
   }
   block_sum2(a, zero, s_red);
   const float n_all = (float)HW * (float)cpg;
@@ -707,18 +713,20 @@ __global__ __launch_bounds__(kHT) void gn_nhwc_finalize_kernel(const float *__re
   for (int i = threadIdx.x; i < items; i += kHT) {
     const int s = i / cpg, c = g * cpg + (i - s * cpg);
     const float *pp = part + ((int64_t)(b * S + s) * 2) * C + c;
-    const float dm = pp[0] - mean;
+    const float add = addend != nullptr ? addend[(int64_t)b * C + c] : 0.f;
+    const float dm = pp[0] + add - mean;
     m2 += pp[C] + (float)min(px, HW - s * px) * dm * dm;
   }
   block_sum2(m2, zero, s_red);
   const float rstd = rsqrtf(m2 / n_all + eps);
   for (int cc = threadIdx.x; cc < cpg; cc += kHT) {
     const int c = g * cpg + cc;
+    const float add = addend != nullptr ? addend[(int64_t)b * C + c] : 0.f;
     const float ga = E::to_f(gamma[c]) * rstd;
     float *o = aff + (int64_t)b * 4 * C + c;
     o[0] = ga;
-    o[C] = fmaf(-mean, ga, E::to_f(beta[c]));
-    o[2 * C] = mean;
+    o[C] = fmaf(add - mean, ga, E::to_f(beta[c]));
+    o[2 * C] = mean - add;
     o[3 * C] = rstd;
   }
 }
@@ -1073,8 +1081,8 @@ extern "C" size_t lora_amd_groupnorm_nhwc_workspace(int32_t B, int32_t C, int32_
   float *cvec = part + gn_nhwc_part_floats(q, B, C);                                                                  \
   (void)cvec
 
-extern "C" int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, void *y, float *aff,
-                                           void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+extern "C" int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, const float *addend,
+                                           void *y, float *aff, void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
                                            int32_t groups, float eps, int32_t act, int32_t dtype, void *stream) {
   GN_NHWC_CHECKS("groupnorm_nhwc_fwd");
   LORA_AMD_CHECK(x && gamma && beta && y && aff && workspace, LORA_AMD_EINVAL, "groupnorm_nhwc_fwd: null pointer");
@@ -1086,7 +1094,7 @@ extern "C" int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, con
     hipLaunchKernelGGL((gn_nhwc_stats_kernel<E>), grid, block, 0, st, (const S_ *)x, part, C, HW, q.cw, q.tiles,      \
                        q.nslots, q.px, q.S);                                                                          \
     hipLaunchKernelGGL((gn_nhwc_finalize_kernel<E>), gridg, block, 0, st, part, (const S_ *)gamma, (const S_ *)beta,  \
-                       aff, C, HW, groups, q.px, q.S, eps);                                                           \
+                       addend, aff, C, HW, groups, q.px, q.S, eps);                                                   \
     if (act)                                                                                                          \
       hipLaunchKernelGGL((gn_nhwc_apply_kernel<E, true>), grid, block, 0, st, (const S_ *)x, aff, (S_ *)y, C, HW,     \
                          q.cw, q.tiles, q.nslots, q.px, q.S);                                                         \

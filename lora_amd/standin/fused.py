@@ -12,6 +12,7 @@ that path everywhere (A/B measurements).
 from __future__ import annotations
 
 import os
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -44,20 +45,26 @@ class _GroupNormActNHWC(torch.autograd.Function):
     """The same for channels_last activations (memory [B][HW][C]); saves x and the per-channel affine [B, 4, C]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups: int, eps: float, act: bool):
-        y, aff = _C.groupnorm_nhwc_fwd(x, weight, bias, groups, eps, act)
+    def forward(ctx, x, weight, bias, groups: int, eps: float, act: bool, addend):
+        add32 = None if addend is None else addend.detach().to(torch.float32).contiguous()
+        y, aff = _C.groupnorm_nhwc_fwd(x, weight, bias, groups, eps, act, add32)
         ctx.save_for_backward(x, weight, aff)
         ctx.groups, ctx.act = groups, act
+        ctx.add_dtype = None if addend is None else addend.dtype
         return y
 
     @staticmethod
     def backward(ctx, gout):
         x, weight, aff = ctx.saved_tensors
-        dx = None
-        if ctx.needs_input_grad[0]:
+        dx = dadd = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[6]:
             gout = gout.contiguous(memory_format=torch.channels_last)
             dx = _C.groupnorm_nhwc_bwd(x, gout, weight, aff, ctx.groups, ctx.act)
-        return dx, None, None, None, None, None
+            if ctx.needs_input_grad[6]:  # only when something upstream of the addend trains (extended injection)
+                dadd = dx.sum(dim=(2, 3), dtype=torch.float32).to(ctx.add_dtype)
+            if not ctx.needs_input_grad[0]:
+                dx = None
+        return dx, None, None, None, None, None, dadd
 
 
 def _frozen_affine(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
@@ -85,12 +92,17 @@ def _gn_native_nhwc(x: torch.Tensor, norm: nn.GroupNorm) -> bool:
     return _C.groupnorm_nhwc_workspace(B, C, x.numel() // (B * C), norm.num_groups) > 0
 
 
-def group_norm_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True) -> torch.Tensor:
-    """``silu(norm(x))`` (``act``) or ``norm(x)`` — ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm."""
+def group_norm_act(x: torch.Tensor, norm: nn.GroupNorm, act: bool = True,
+                   addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``silu(norm(x))`` (``act``) or ``norm(x)`` — ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm.
+    ``addend`` [B, C] is added to x (broadcast over the pixels) before the normalisation; the channels_last kernels
+    absorb it for free, every other path adds it first."""
+    if _gn_native_nhwc(x, norm):
+        return _GroupNormActNHWC.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act, addend)
+    if addend is not None:
+        x = x + addend[:, :, None, None].to(x.dtype)
     if _gn_native(x, norm):
         return _GroupNormAct.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
-    if _gn_native_nhwc(x, norm):
-        return _GroupNormActNHWC.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
     y = norm(x)
     return F.silu(y) if act else y
 

@@ -168,9 +168,17 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
-        h = self.conv1(group_norm_act(x, self.norm1))  # GroupNorm + SiLU: two launches each way (fused.py)
-        h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(group_norm_act(h, self.norm2)))
+        n1 = group_norm_act(x, self.norm1)  # GroupNorm + SiLU as HIP passes (fused.py)
+        t = self.time_emb_proj(self.nonlinearity(temb))  # [B, C_out]
+        if type(self.conv1) is nn.Conv2d and self.conv1.bias is not None:
+            # the convolution's bias and the time embedding are both per-(sample, channel) terms in front of norm2:
+            # one small [B, C] add instead of two passes over the activation (none at all on channels_last)
+            c1 = self.conv1
+            h = F.conv2d(n1, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups)
+            t = t + c1.bias
+        else:
+            h = self.conv1(n1)
+        h = self.conv2(self.dropout(group_norm_act(h, self.norm2, addend=t)))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 

@@ -87,6 +87,34 @@ def test_groupnorm_act_channels_last_forward_backward(B, C, H, W, G, dt, act):
     _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
 
 
+@pytest.mark.parametrize("B,C,H,W,G", [(4, 320, 32, 32, 32), (2, 1280, 8, 8, 32), (3, 64, 4, 6, 8)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+def test_groupnorm_addend_is_x_plus_broadcast(B, C, H, W, G, dt, layout):
+    """group_norm_act(x, addend=t) == group_norm_act(x + t[:, :, None, None]) incl. gradients w.r.t. x and t (the
+    channels_last kernels fold t into the statistics / affine; NCHW adds it first)."""
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5).to(dt).to(DEV)
+    t = (torch.randn(B, C, generator=g) * 2.0).to(dt).to(DEV)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    norm = nn.GroupNorm(G, C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(B, C, H, W, generator=g).to(dt).to(DEV)
+    xg, tg = x.clone(memory_format=torch.preserve_format).requires_grad_(True), t.clone().requires_grad_(True)
+    y = fused.group_norm_act(xg, norm, True, addend=tg)
+    y.backward(gout)
+    xr, tr = x.float().contiguous().requires_grad_(True), t.float().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr + tr[:, :, None, None], G, norm.weight.float(), norm.bias.float(), norm.eps))
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="dx")
+    _close(tg.grad, tr.grad, dt, scale=float(tr.grad.abs().max()) + 1e-6, msg="d addend")
+
+
 def test_groupnorm_statistics_and_fallbacks():
     x = torch.randn(2, 64, 8, 8, device=DEV) * 2 + 5
     norm = nn.GroupNorm(8, 64).to(DEV).requires_grad_(False)

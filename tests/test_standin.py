@@ -151,3 +151,24 @@ def test_fused_host_passes_fall_back_to_aten_on_cpu():
     y = torch.randn(3, 5, 32)
     h, g = y.chunk(2, dim=-1)
     torch.testing.assert_close(fused.geglu(y), h * F.gelu(g))
+
+
+def test_resnet_block_folds_conv_bias_and_time_embedding_into_one_addend():
+    import torch.nn.functional as F
+    from lora_amd.standin.unet import ResnetBlock2D
+
+    torch.manual_seed(0)
+    blk = ResnetBlock2D(16, 32, temb_channels=24, groups=4)
+    x, temb = torch.randn(2, 16, 6, 6, requires_grad=True), torch.randn(2, 24)
+    y = blk(x, temb)
+    h = blk.conv1(F.silu(blk.norm1(x)))  # the reference order of operations (diffusers ResnetBlock2D)
+    h = h + blk.time_emb_proj(F.silu(temb))[:, :, None, None]
+    h = blk.conv2(F.silu(blk.norm2(h)))
+    want = blk.conv_shortcut(x) + h
+    torch.testing.assert_close(y, want, rtol=1e-5, atol=1e-5)
+    (g1,) = torch.autograd.grad(y.square().sum(), x, retain_graph=True)
+    (g0,) = torch.autograd.grad(want.square().sum(), x)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
+    # channels_last input: same numbers (ATen fallbacks on CPU)
+    yc = blk(x.contiguous(memory_format=torch.channels_last), temb)
+    torch.testing.assert_close(yc.contiguous(), want, rtol=1e-5, atol=1e-5)
