@@ -573,7 +573,9 @@ static GnNhwcGeo gn_nhwc_geo(int B, int C, int HW, int G) {
   q.cw = best;
   q.tiles = q.c8 / q.cw;
   q.nslots = kHT / q.cw;
-  int64_t px = std::max<int64_t>(2 * q.nslots * kNU, (int64_t)HW * B * q.tiles / 768);
+  // pixels per workgroup: ~768 workgroups on the large maps, at least two pixels per slot on the small ones (the
+  // per-channel partials are 8 bytes per channel and slice: keep them a small fraction of the stream)
+  int64_t px = std::max<int64_t>(2 * q.nslots, (int64_t)HW * B * q.tiles / 768);
   px = std::min<int64_t>(px, HW);
   q.px = (int)px;
   q.S = (HW + q.px - 1) / q.px;
