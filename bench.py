@@ -161,7 +161,20 @@ def cpu_worker(spec: str) -> None:
         return time.perf_counter() - t0
 
     one(1, 8)  # warm-up: allocator, oneDNN primitive caches, thread pool
-    print(json.dumps({"seconds": one(batch, res), "threads": threads}), flush=True)
+    step_s = one(batch, res)
+    # the graded kernel's CPU counterpart: the reference's collapse op sequence over all adapter sites, fp32
+    sites = [(m.frozen.weight.detach(), m.up.detach(), m.down.detach()) for m in TR.sites_of(unet)
+             if isinstance(m, TR.RefLinearSite)]
+    merge_s = float("inf")
+    with torch.no_grad():
+        for _ in range(2):  # second pass: pages of the 0.77 GB of fp32 weights are resident
+            t0 = time.perf_counter()
+            for W, up, down in sites:
+                TR.collapse(W, up, down, 0.5)
+            merge_s = min(merge_s, time.perf_counter() - t0)
+    elems = sum(W.numel() for W, _, _ in sites)
+    print(json.dumps({"seconds": step_s, "threads": threads, "merge_seconds": merge_s, "merge_sites": len(sites),
+                      "merge_elems": elems}), flush=True)
 
 
 def cpu_baseline(rank_r=4):
@@ -182,9 +195,16 @@ def cpu_baseline(rank_r=4):
                                   f"{batch},{res},{threads},{rank_r}"], capture_output=True, text=True,
                                  timeout=timeout_s, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
-            sec = json.loads(line)["seconds"]
-            return {"value": round(1.0 / (sec * factor), 6), "unit": "steps/s", "cores": threads, "kind": "port",
+            rec = json.loads(line)
+            sec = rec["seconds"]
+            res_ = {"value": round(1.0 / (sec * factor), 6), "unit": "steps/s", "cores": threads, "kind": "port",
                     "host_cores_usable": cores, "sample": f"{what}; measured {sec:.2f} s on {threads} threads, fp32"}
+            if rec.get("merge_seconds"):  # the merge (roofline kernel) on the same cores: reference op sequence, fp32
+                ms = rec["merge_seconds"]
+                res_["merge"] = {"ms": round(ms * 1e3, 2), "sites": rec["merge_sites"],
+                                 "algorithmic_GBs": round(2 * rec["merge_elems"] * 4 / ms / 1e9, 2), "dtype": "f32",
+                                 "what": "reference collapse_lora op sequence (mm, cast, mul, add) over every Linear site"}
+            return res_
         except subprocess.TimeoutExpired:
             errs.append(f"batch {batch} {res}x{res} latents: > {timeout_s} s")
         except Exception as e:  # noqa: BLE001

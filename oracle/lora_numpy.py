@@ -324,3 +324,72 @@ def adamw_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, weig
     denom = np.sqrt(v) / F32(np.sqrt(bc2)) + F32(eps)
     p -= F32(lr / bc1) * (m / denom)
     return p.astype(F32), m.astype(F32), v.astype(F32)
+
+
+# --------------------------------------------------------------------------- frozen host-model passes
+# The UNet blocks the reference trains through (diffusers ResnetBlock2D / BasicTransformerBlock / GEGLU, un-vendored)
+# call torch's group_norm, silu, layer_norm and gelu between the adapter sites; restated here in float64 numpy and
+# pinned against torch CPU outputs (tests/golden/hostops_cases.npz, scripts/make_golden.py::hostops_cases).
+def _erf(x: np.ndarray) -> np.ndarray:
+    import math
+
+    return np.vectorize(math.erf, otypes=[np.float64])(x)
+
+
+def _silu_and_grad(z: np.ndarray):
+    s = 1.0 / (1.0 + np.exp(-z))
+    return z * s, s * (1.0 + z * (1.0 - s))
+
+
+def group_norm_act(x, groups: int, weight, bias, eps: float = 1e-5, act: bool = True):
+    """y = silu(group_norm(x)) (``act``) or group_norm(x) for NCHW x; returns (y, cache)."""
+    x = np.asarray(x, np.float64)
+    B, C = x.shape[:2]
+    xg = x.reshape(B, groups, -1)
+    mean = xg.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(xg.var(-1, keepdims=True) + eps)
+    xh = ((xg - mean) * rstd).reshape(x.shape)
+    shape = (1, C) + (1,) * (x.ndim - 2)
+    z = xh * np.asarray(weight, np.float64).reshape(shape) + np.asarray(bias, np.float64).reshape(shape)
+    y = _silu_and_grad(z)[0] if act else z
+    return y, (xh, rstd, z, np.asarray(weight, np.float64).reshape(shape), groups, act)
+
+
+def group_norm_act_backward(gout, cache):
+    """Input gradient of :func:`group_norm_act` (affine parameters frozen)."""
+    xh, rstd, z, w, groups, act = cache
+    dz = np.asarray(gout, np.float64) * (_silu_and_grad(z)[1] if act else 1.0)
+    t = dz * w
+    B = xh.shape[0]
+    tg, xg = t.reshape(B, groups, -1), xh.reshape(B, groups, -1)
+    dx = rstd * (tg - tg.mean(-1, keepdims=True) - xg * (tg * xg).mean(-1, keepdims=True))
+    return dx.reshape(xh.shape)
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    x = np.asarray(x, np.float64)
+    mean = x.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(x.var(-1, keepdims=True) + eps)
+    xh = (x - mean) * rstd
+    return xh * np.asarray(weight, np.float64) + np.asarray(bias, np.float64), (xh, rstd, np.asarray(weight, np.float64))
+
+
+def layer_norm_backward(gout, cache):
+    xh, rstd, w = cache
+    t = np.asarray(gout, np.float64) * w
+    return rstd * (t - t.mean(-1, keepdims=True) - xh * (t * xh).mean(-1, keepdims=True))
+
+
+def geglu(y):
+    """h * gelu(gate) for y = [h | gate] along the last axis (erf form, F.gelu's default)."""
+    y = np.asarray(y, np.float64)
+    h, g = np.split(y, 2, axis=-1)
+    return h * (g * 0.5 * (1.0 + _erf(g / np.sqrt(2.0))))
+
+
+def geglu_backward(y, gout):
+    y, gout = np.asarray(y, np.float64), np.asarray(gout, np.float64)
+    h, g = np.split(y, 2, axis=-1)
+    cdf = 0.5 * (1.0 + _erf(g / np.sqrt(2.0)))
+    pdf = np.exp(-0.5 * g * g) / np.sqrt(2.0 * np.pi)
+    return np.concatenate([gout * g * cdf, gout * h * (cdf + g * pdf)], axis=-1)

@@ -96,6 +96,12 @@ def sites_of(model: nn.Module):
     return [m for m in model.modules() if isinstance(m, (RefLinearSite, RefConvSite))]
 
 
+def collapse(W: torch.Tensor, up: torch.Tensor, down: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """``collapse_lora`` for one Linear site (lora_diffusion/lora.py:646-655): materialise ``up @ down`` in the factor
+    dtype, cast to W's dtype, scale, add — three passes over an [N, K] tensor plus the new Parameter."""
+    return ((up @ down).type(W.dtype) * alpha + W).to(W.dtype)
+
+
 def dreambooth_step(unet, params, optimizer, latents, noise, timesteps, ehs, alphas_cumprod, max_grad_norm=1.0,
                     with_prior_preservation=False, prior_loss_weight=1.0):
     """ref: training_scripts/train_lora_dreambooth.py:824-888 with VAE/text-encoder outputs given:

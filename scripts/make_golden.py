@@ -253,6 +253,42 @@ def optimizer_cases():
     np.savez(os.path.join(OUT, "optimizer_case.npz"), **out)
 
 
+def hostops_cases():
+    """The ATen sequences the training step runs inside the UNet blocks between the adapter sites (diffusers'
+    ResnetBlock2D / BasicTransformerBlock / GEGLU call exactly these torch functions): GroupNorm -> SiLU, LayerNorm,
+    chunk -> gelu -> mul, with their autograd input gradients.  CPU, fp32, one thread."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for i, (B, C, hh, ww, G, act) in enumerate([(2, 64, 8, 8, 8, 1), (1, 96, 4, 6, 3, 0), (2, 32, 8, 8, 32, 1)]):
+        x = (torch.randn(B, C, hh, ww, generator=g) * 1.5 + torch.randn(1, C, 1, 1, generator=g) * 3.0).requires_grad_(True)
+        w, b = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g) * 0.3
+        go = torch.randn(B, C, hh, ww, generator=g)
+        y = F.group_norm(x, G, w, b, 1e-5)
+        if act:
+            y = F.silu(y)
+        y.backward(go)
+        out.update({f"gn{i}_x": H.t2n(x), f"gn{i}_w": H.t2n(w), f"gn{i}_b": H.t2n(b), f"gn{i}_go": H.t2n(go),
+                    f"gn{i}_y": H.t2n(y), f"gn{i}_dx": H.t2n(x.grad), f"gn{i}_meta": np.array([G, act])})
+    for i, shape in enumerate([(3, 7, 64), (2, 5, 320)]):
+        x = (torch.randn(*shape, generator=g) * 1.5 + torch.randn(shape[-1], generator=g) * 2.0).requires_grad_(True)
+        w, b = torch.randn(shape[-1], generator=g) * 0.5 + 1.0, torch.randn(shape[-1], generator=g) * 0.3
+        go = torch.randn(*shape, generator=g)
+        y = F.layer_norm(x, (shape[-1],), w, b, 1e-5)
+        y.backward(go)
+        out.update({f"ln{i}_x": H.t2n(x), f"ln{i}_w": H.t2n(w), f"ln{i}_b": H.t2n(b), f"ln{i}_go": H.t2n(go),
+                    f"ln{i}_y": H.t2n(y), f"ln{i}_dx": H.t2n(x.grad)})
+    for i, shape in enumerate([(2, 9, 64), (1, 3, 32)]):
+        yin = (torch.randn(*shape, generator=g) * 2.0).requires_grad_(True)
+        go = torch.randn(*shape[:-1], shape[-1] // 2, generator=g)
+        h, gate = yin.chunk(2, dim=-1)
+        o = h * F.gelu(gate)
+        o.backward(go)
+        out.update({f"gg{i}_y": H.t2n(yin), f"gg{i}_go": H.t2n(go), f"gg{i}_out": H.t2n(o), f"gg{i}_dy": H.t2n(yin.grad)})
+    np.savez(os.path.join(OUT, "hostops_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:  # regenerate only the named fixture sets, e.g. `make_golden.py conv_native_cases`
@@ -267,6 +303,7 @@ if __name__ == "__main__":
     injection_and_file_cases()
     example_lora_manifest()
     optimizer_cases()
+    hostops_cases()
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn:40s} {os.path.getsize(os.path.join(OUT, fn)):>9d} B")

@@ -216,6 +216,57 @@ def test_geglu_tails_and_fallback():
         _C.geglu_fwd(odd)
 
 
+def test_host_passes_match_golden_vectors_and_oracle():
+    """HIP passes on the committed torch-CPU vectors (tests/golden/hostops_cases.npz) and against the numpy oracle."""
+    import os
+
+    import numpy as np
+
+    from oracle import lora_numpy as O
+    from tests import helpers as H
+
+    d = np.load(os.path.join(H.GOLDEN, "hostops_cases.npz"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    for i in range(3):
+        groups, act = (int(v) for v in d[f"gn{i}_meta"])
+        x = dev(d[f"gn{i}_x"]).requires_grad_(True)
+        norm = nn.GroupNorm(groups, x.shape[1]).to(DEV)
+        with torch.no_grad():
+            norm.weight.copy_(dev(d[f"gn{i}_w"]))
+            norm.bias.copy_(dev(d[f"gn{i}_b"]))
+        norm.requires_grad_(False)
+        assert fused._gn_native(x, norm)
+        y = fused.group_norm_act(x, norm, bool(act))
+        y.backward(dev(d[f"gn{i}_go"]))
+        _close(y, torch.from_numpy(d[f"gn{i}_y"]), torch.float32, msg=f"gn{i} forward vs golden")
+        _close(x.grad, torch.from_numpy(d[f"gn{i}_dx"]), torch.float32, scale=float(np.abs(d[f"gn{i}_dx"]).max()),
+               msg=f"gn{i} dx vs golden")
+        yo, cache = O.group_norm_act(d[f"gn{i}_x"], groups, d[f"gn{i}_w"], d[f"gn{i}_b"], 1e-5, bool(act))
+        _close(y, torch.from_numpy(yo), torch.float32, msg=f"gn{i} forward vs oracle")
+    for i in range(2):
+        x = dev(d[f"ln{i}_x"]).requires_grad_(True)
+        ln = nn.LayerNorm(x.shape[-1]).to(DEV)
+        with torch.no_grad():
+            ln.weight.copy_(dev(d[f"ln{i}_w"]))
+            ln.bias.copy_(dev(d[f"ln{i}_b"]))
+        ln.requires_grad_(False)
+        y = fused.layer_norm(x, ln)
+        assert type(y.grad_fn).__name__ == "_LayerNormBackward"
+        y.backward(dev(d[f"ln{i}_go"]))
+        _close(y, torch.from_numpy(d[f"ln{i}_y"]), torch.float32, msg=f"ln{i} forward vs golden")
+        _close(x.grad, torch.from_numpy(d[f"ln{i}_dx"]), torch.float32, scale=float(np.abs(d[f"ln{i}_dx"]).max()),
+               msg=f"ln{i} dx vs golden")
+    for i in range(2):
+        yin = dev(d[f"gg{i}_y"]).requires_grad_(True)
+        out = fused.geglu(yin)
+        assert type(out.grad_fn).__name__ == "_GegluBackward"
+        out.backward(dev(d[f"gg{i}_go"]))
+        _close(out, torch.from_numpy(d[f"gg{i}_out"]), torch.float32, msg=f"geglu{i} forward vs golden")
+        _close(yin.grad, torch.from_numpy(d[f"gg{i}_dy"]), torch.float32, scale=float(np.abs(d[f"gg{i}_dy"]).max()),
+               msg=f"geglu{i} gradient vs golden")
+        _close(out, torch.from_numpy(O.geglu(d[f"gg{i}_y"])), torch.float32, msg=f"geglu{i} vs oracle")
+
+
 def test_standin_unet_same_loss_and_gradients_with_and_without_fusions(monkeypatch):
     """Tiny UNet in f32: the fused passes must reproduce the ATen sequence's loss and adapter gradients."""
     import lora_amd as L

@@ -208,3 +208,22 @@ def test_ddpm_schedule_and_loss():
     assert abs(O.dreambooth_loss(x, n) - float(((x - n) ** 2).mean())) < 1e-6
     lp = O.dreambooth_loss(x, n, True, 0.5)
     assert abs(lp - (float(((x[:1] - n[:1]) ** 2).mean()) + 0.5 * float(((x[1:] - n[1:]) ** 2).mean()))) < 1e-5
+
+
+def test_host_pass_oracles_match_torch_vectors():
+    """GroupNorm(+SiLU), LayerNorm and the GEGLU gate (the ATen calls of the UNet blocks between the adapter sites):
+    numpy restatement vs the torch CPU vectors of scripts/make_golden.py::hostops_cases."""
+    d = np.load(os.path.join(H.GOLDEN, "hostops_cases.npz"))
+    for i in range(3):
+        groups, act = (int(v) for v in d[f"gn{i}_meta"])
+        y, cache = O.group_norm_act(d[f"gn{i}_x"], groups, d[f"gn{i}_w"], d[f"gn{i}_b"], 1e-5, bool(act))
+        np.testing.assert_allclose(y, d[f"gn{i}_y"], rtol=2e-5, atol=2e-5)
+        dx = O.group_norm_act_backward(d[f"gn{i}_go"], cache)
+        np.testing.assert_allclose(dx, d[f"gn{i}_dx"], rtol=2e-4, atol=2e-5)
+    for i in range(2):
+        y, cache = O.layer_norm(d[f"ln{i}_x"], d[f"ln{i}_w"], d[f"ln{i}_b"])
+        np.testing.assert_allclose(y, d[f"ln{i}_y"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(O.layer_norm_backward(d[f"ln{i}_go"], cache), d[f"ln{i}_dx"], rtol=2e-4, atol=2e-5)
+    for i in range(2):
+        np.testing.assert_allclose(O.geglu(d[f"gg{i}_y"]), d[f"gg{i}_out"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(O.geglu_backward(d[f"gg{i}_y"], d[f"gg{i}_go"]), d[f"gg{i}_dy"], rtol=2e-5, atol=2e-6)
