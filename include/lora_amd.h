@@ -372,6 +372,13 @@ int lora_amd_layernorm_fwd(const void *x, const void *gamma, const void *beta, v
                            int32_t K, float eps, int32_t dtype, void *stream);
 int lora_amd_layernorm_bwd(const void *x, const void *gout, const void *gamma, const float *stats, void *dx,
                            int64_t M, int32_t K, int32_t dtype, void *stream);
+/* The residual add in front of the norm in the same pass: sum_out = x + res (rounded to the activation dtype, what the
+ * residual stream carries on), y = layernorm(sum_out).  Backward: dx = d layernorm / d sum (given gout, evaluated at
+ * x = sum_out) + gsum, the gradient arriving through the residual stream; it is the gradient of both addends. */
+int lora_amd_add_layernorm_fwd(const void *x, const void *res, const void *gamma, const void *beta, void *sum_out,
+                               void *y, float *stats, int64_t M, int32_t K, float eps, int32_t dtype, void *stream);
+int lora_amd_add_layernorm_bwd(const void *x, const void *gout, const void *gsum, const void *gamma,
+                               const float *stats, void *dx, int64_t M, int32_t K, int32_t dtype, void *stream);
 
 /* GEGLU gate behind the adapted projection: y [M, 2*inner] = [h | gate]; out [M, inner] = h * gelu(gate) (erf form).
  * Backward writes gy [M, 2*inner] = [gout * gelu(gate) | gout * h * gelu'(gate)] in one pass (no cat). */

@@ -39,6 +39,7 @@ SYMBOLS = (
     "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
     "lora_amd_layernorm_supported", "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd",
     "lora_amd_groupnorm_nhwc_workspace", "lora_amd_groupnorm_nhwc_fwd", "lora_amd_groupnorm_nhwc_bwd",
+    "lora_amd_add_layernorm_fwd", "lora_amd_add_layernorm_bwd",
 )
 
 
@@ -142,6 +143,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_groupnorm_nhwc_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
     lib.lora_amd_groupnorm_nhwc_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_groupnorm_nhwc_fwd.restype = lib.lora_amd_groupnorm_nhwc_bwd.restype = C.c_int
+    lib.lora_amd_add_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
+    lib.lora_amd_add_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    lib.lora_amd_add_layernorm_fwd.restype = lib.lora_amd_add_layernorm_bwd.restype = C.c_int
     lib.lora_amd_layernorm_supported.argtypes = [i32]
     lib.lora_amd_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
     lib.lora_amd_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
@@ -891,4 +895,30 @@ def groupnorm_nhwc_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor,
                                                  dx.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups,
                                                  1 if act else 0, dtype_code(x.dtype), _stream()),
            "lora_amd_groupnorm_nhwc_bwd")
+    return dx
+
+
+def add_layernorm_fwd(x: torch.Tensor, res: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                      eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(x + res, layernorm(x + res), stats) in one pass over contiguous x / res of the same shape."""
+    _dev_check(x, res, gamma, beta)
+    K = x.shape[-1]
+    M = x.numel() // K
+    s, y = torch.empty_like(x), torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_add_layernorm_fwd(x.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                s.data_ptr(), y.data_ptr(), stats.data_ptr(), M, K, eps,
+                                                dtype_code(x.dtype), _stream()), "lora_amd_add_layernorm_fwd")
+    return s, y, stats
+
+
+def add_layernorm_bwd(s: torch.Tensor, gout: torch.Tensor, gsum: Optional[torch.Tensor], gamma: torch.Tensor,
+                      stats: torch.Tensor) -> torch.Tensor:
+    """Gradient of both addends: layernorm backward at the saved sum + the gradient of the residual stream."""
+    _dev_check(s, gout, gsum, gamma, stats)
+    K = s.shape[-1]
+    dx = torch.empty_like(s)
+    _check(require().lora_amd_add_layernorm_bwd(s.data_ptr(), gout.data_ptr(), _ptr(gsum), gamma.data_ptr(),
+                                                stats.data_ptr(), dx.data_ptr(), s.numel() // K, K,
+                                                dtype_code(s.dtype), _stream()), "lora_amd_add_layernorm_bwd")
     return dx

@@ -426,21 +426,27 @@ __device__ inline float group_allsum(float v, int logL) {
   return v;
 }
 
-template <class E>
+// ADD: the row is x + res (the residual add in front of norm2 / norm3), rounded to the activation dtype exactly as the
+// separate add would, written to sum_out for the residual stream, and normalised in the same pass.
+template <class E, bool ADD>
 __global__ __launch_bounds__(kHT) void ln_fwd_kernel(const typename E::storage *__restrict__ x,
+                                                     const typename E::storage *__restrict__ res,
                                                      const typename E::storage *__restrict__ gamma,
                                                      const typename E::storage *__restrict__ beta,
+                                                     typename E::storage *__restrict__ sum_out,
                                                      typename E::storage *__restrict__ y, float *__restrict__ stats,
                                                      int64_t M, int c8, int logL, float eps) {
   const int L = 1 << logL, l = threadIdx.x & (L - 1);
   const int64_t row = (int64_t)blockIdx.x * (kHT >> logL) + (threadIdx.x >> logL);
   const bool live = row < M;
-  const typename E::storage *xr = x + (live ? row : 0) * (int64_t)c8 * 8;
-  Raw8<E> raw[kLU], gr[kLU], br[kLU];
+  const int64_t rbase = (live ? row : 0) * (int64_t)c8 * 8;
+  const typename E::storage *xr = x + rbase;
+  Raw8<E> raw[kLU], rr[ADD ? kLU : 1], gr[kLU], br[kLU];
 #pragma unroll
   for (int u = 0; u < kLU; ++u) {
     const int cc = l + u * L, cs = cc < c8 ? cc : l;
     raw[u] = load8_raw<E>(xr + cs * 8);
+    if (ADD) rr[u] = load8_raw<E>(res + rbase + cs * 8);
     gr[u] = load8_raw<E>(gamma + cs * 8);
     br[u] = load8_raw<E>(beta + cs * 8);
   }
@@ -448,7 +454,15 @@ __global__ __launch_bounds__(kHT) void ln_fwd_kernel(const typename E::storage *
   float v[kLU][8], sum = 0.f;
 #pragma unroll
   for (int u = 0; u < kLU; ++u) {
-    unpack8_sel<E>(raw[u], l + u * L < c8, v[u]);
+    const bool ok = l + u * L < c8;
+    unpack8_sel<E>(raw[u], ok, v[u]);
+    if (ADD) {
+      float rv[8];
+      unpack8_sel<E>(rr[u], ok, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = round_to<E>(v[u][e] + rv[e]);
+      if (ok && live) store8<E>(sum_out + row * (int64_t)c8 * 8 + (l + u * L) * 8, v[u]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += v[u][e];
   }
@@ -485,9 +499,11 @@ __global__ __launch_bounds__(kHT) void ln_fwd_kernel(const typename E::storage *
 }
 
 // dx = rstd * (t - mean(t) - xh * mean(t * xh)),  t = gamma * gout,  xh = (x - mean) * rstd   (gamma / beta frozen)
-template <class E>
+// ADDG: dx additionally receives gsum, the gradient that reaches the same row through the residual stream.
+template <class E, bool ADDG>
 __global__ __launch_bounds__(kHT) void ln_bwd_kernel(const typename E::storage *__restrict__ x,
                                                      const typename E::storage *__restrict__ gout,
+                                                     const typename E::storage *__restrict__ gsum,
                                                      const typename E::storage *__restrict__ gamma,
                                                      const float *__restrict__ stats,
                                                      typename E::storage *__restrict__ dx, int64_t M, int c8,
@@ -496,12 +512,13 @@ __global__ __launch_bounds__(kHT) void ln_bwd_kernel(const typename E::storage *
   const int64_t row = (int64_t)blockIdx.x * (kHT >> logL) + (threadIdx.x >> logL);
   const bool live = row < M;
   const int64_t rbase = (live ? row : 0) * (int64_t)c8 * 8;
-  Raw8<E> xr[kLU], gor[kLU], gr[kLU];
+  Raw8<E> xr[kLU], gor[kLU], gsr[ADDG ? kLU : 1], gr[kLU];
 #pragma unroll
   for (int u = 0; u < kLU; ++u) {
     const int cc = l + u * L, cs = cc < c8 ? cc : l;
     xr[u] = load8_raw<E>(x + rbase + cs * 8);
     gor[u] = load8_raw<E>(gout + rbase + cs * 8);
+    if (ADDG) gsr[u] = load8_raw<E>(gsum + rbase + cs * 8);
     gr[u] = load8_raw<E>(gamma + cs * 8);
   }
   const float mean = stats[(live ? row : 0) * 2 + 0], rstd = stats[(live ? row : 0) * 2 + 1];
@@ -532,6 +549,12 @@ __global__ __launch_bounds__(kHT) void ln_bwd_kernel(const typename E::storage *
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = rstd * (t[u][e] - c1 - xh[u][e] * c2);
+      if (ADDG) {
+        float gs[8];
+        unpack8_sel<E>(gsr[u], true, gs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += gs[e];
+      }
       store8<E>(dx + row * (int64_t)c8 * 8 + cc * 8, o);
     }
   }
@@ -1025,14 +1048,31 @@ extern "C" int lora_amd_layernorm_supported(int32_t K) { return K > 0 && K % 8 =
 
 extern "C" int lora_amd_layernorm_fwd(const void *x, const void *gamma, const void *beta, void *y, float *stats,
                                       int64_t M, int32_t K, float eps, int32_t dtype, void *stream) {
+  return lora_amd_add_layernorm_fwd(x, nullptr, gamma, beta, nullptr, y, stats, M, K, eps, dtype, stream);
+}
+
+extern "C" int lora_amd_add_layernorm_fwd(const void *x, const void *res, const void *gamma, const void *beta,
+                                          void *sum_out, void *y, float *stats, int64_t M, int32_t K, float eps,
+                                          int32_t dtype, void *stream) {
   LN_CHECKS("layernorm_fwd");
   LORA_AMD_CHECK(x && gamma && beta && y && stats, LORA_AMD_EINVAL, "layernorm_fwd: null pointer");
-  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(y, dtype) && aligned_for(gamma, dtype) && aligned_for(beta, dtype),
+  LORA_AMD_CHECK((res == nullptr) == (sum_out == nullptr), LORA_AMD_EINVAL,
+                 "layernorm_fwd: res and sum_out go together");
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(y, dtype) && aligned_for(gamma, dtype) && aligned_for(beta, dtype) &&
+                     aligned_for(res, dtype) && aligned_for(sum_out, dtype),
                  LORA_AMD_EINVAL, "layernorm_fwd: unaligned tensor");
+  const bool add = res != nullptr;
 #define GO(E)                                                                                                    \
-  hipLaunchKernelGGL((ln_fwd_kernel<E>), grid, block, 0, st, (const typename E::storage *)x,                     \
-                     (const typename E::storage *)gamma, (const typename E::storage *)beta,                      \
-                     (typename E::storage *)y, stats, M, c8, logL, eps);                                         \
+  if (add)                                                                                                       \
+    hipLaunchKernelGGL((ln_fwd_kernel<E, true>), grid, block, 0, st, (const typename E::storage *)x,             \
+                       (const typename E::storage *)res, (const typename E::storage *)gamma,                     \
+                       (const typename E::storage *)beta, (typename E::storage *)sum_out,                        \
+                       (typename E::storage *)y, stats, M, c8, logL, eps);                                       \
+  else                                                                                                           \
+    hipLaunchKernelGGL((ln_fwd_kernel<E, false>), grid, block, 0, st, (const typename E::storage *)x,            \
+                       (const typename E::storage *)nullptr, (const typename E::storage *)gamma,                 \
+                       (const typename E::storage *)beta, (typename E::storage *)nullptr,                        \
+                       (typename E::storage *)y, stats, M, c8, logL, eps);                                       \
   break
   switch (dtype) {
     case LORA_AMD_F32: GO(f32_t);
@@ -1045,14 +1085,26 @@ extern "C" int lora_amd_layernorm_fwd(const void *x, const void *gamma, const vo
 
 extern "C" int lora_amd_layernorm_bwd(const void *x, const void *gout, const void *gamma, const float *stats,
                                       void *dx, int64_t M, int32_t K, int32_t dtype, void *stream) {
+  return lora_amd_add_layernorm_bwd(x, gout, nullptr, gamma, stats, dx, M, K, dtype, stream);
+}
+
+extern "C" int lora_amd_add_layernorm_bwd(const void *x, const void *gout, const void *gsum, const void *gamma,
+                                          const float *stats, void *dx, int64_t M, int32_t K, int32_t dtype,
+                                          void *stream) {
   LN_CHECKS("layernorm_bwd");
   LORA_AMD_CHECK(x && gout && gamma && stats && dx, LORA_AMD_EINVAL, "layernorm_bwd: null pointer");
-  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(gout, dtype) && aligned_for(dx, dtype) && aligned_for(gamma, dtype),
+  LORA_AMD_CHECK(aligned_for(x, dtype) && aligned_for(gout, dtype) && aligned_for(dx, dtype) && aligned_for(gamma, dtype) &&
+                     aligned_for(gsum, dtype),
                  LORA_AMD_EINVAL, "layernorm_bwd: unaligned tensor");
 #define GO(E)                                                                                                    \
-  hipLaunchKernelGGL((ln_bwd_kernel<E>), grid, block, 0, st, (const typename E::storage *)x,                     \
-                     (const typename E::storage *)gout, (const typename E::storage *)gamma, stats,               \
-                     (typename E::storage *)dx, M, c8, logL);                                                    \
+  if (gsum != nullptr)                                                                                           \
+    hipLaunchKernelGGL((ln_bwd_kernel<E, true>), grid, block, 0, st, (const typename E::storage *)x,             \
+                       (const typename E::storage *)gout, (const typename E::storage *)gsum,                     \
+                       (const typename E::storage *)gamma, stats, (typename E::storage *)dx, M, c8, logL);       \
+  else                                                                                                           \
+    hipLaunchKernelGGL((ln_bwd_kernel<E, false>), grid, block, 0, st, (const typename E::storage *)x,            \
+                       (const typename E::storage *)gout, (const typename E::storage *)nullptr,                  \
+                       (const typename E::storage *)gamma, stats, (typename E::storage *)dx, M, c8, logL);       \
   break
   switch (dtype) {
     case LORA_AMD_F32: GO(f32_t);

@@ -132,6 +132,40 @@ def layer_norm(x: torch.Tensor, norm: nn.LayerNorm) -> torch.Tensor:
     return norm(x)
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps: float):
+        s, y, stats = _C.add_layernorm_fwd(a, b, weight, bias, eps)
+        ctx.save_for_backward(s, weight, stats)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, gs, gy):
+        s, weight, stats = ctx.saved_tensors
+        if gy is None:  # only the sum was used downstream
+            return gs, gs, None, None, None
+        dx = _C.add_layernorm_bwd(s, gy.contiguous(), None if gs is None else gs.contiguous(), weight, stats)
+        return dx, dx, None, None, None
+
+
+def _ln_native(x: torch.Tensor, norm: nn.LayerNorm) -> bool:
+    w, b = norm.weight, norm.bias
+    return (_ENABLED and x.is_cuda and x.dtype in _DTYPES and x.is_contiguous() and x.numel() > 0
+            and len(norm.normalized_shape) == 1 and w is not None and b is not None
+            and not (w.requires_grad or b.requires_grad) and w.dtype == x.dtype and b.dtype == x.dtype
+            and x.data_ptr() % 32 == 0 and _C.layernorm_supported(x.shape[-1]))
+
+
+def add_layer_norm(a: torch.Tensor, b: torch.Tensor, norm: nn.LayerNorm):
+    """``s = a + b; return s, norm(s)`` — the residual add of a transformer block and the norm that follows it, in one
+    pass each way (the sum is rounded to the activation dtype exactly as the separate add would)."""
+    if a.shape == b.shape and a.dtype == b.dtype and _ln_native(a, norm) and b.is_contiguous() and b.is_cuda \
+            and b.data_ptr() % 32 == 0:
+        return _AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
+    s = a + b
+    return s, layer_norm(s, norm)
+
+
 class _Geglu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y):

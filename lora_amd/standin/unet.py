@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import sdpa
-from .fused import geglu, group_norm_act, layer_norm
+from .fused import add_layer_norm, geglu, group_norm_act, layer_norm
 from torch.utils.checkpoint import checkpoint
 
 
@@ -113,9 +113,10 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
 
     def forward(self, x, context):
-        x = self.attn1(layer_norm(x, self.norm1)) + x
-        x = self.attn2(layer_norm(x, self.norm2), context) + x
-        return self.ff(layer_norm(x, self.norm3)) + x
+        # each residual add runs inside the LayerNorm pass that follows it (fused.add_layer_norm)
+        x, n = add_layer_norm(self.attn1(layer_norm(x, self.norm1)), x, self.norm2)
+        x, n = add_layer_norm(self.attn2(n, context), x, self.norm3)
+        return self.ff(n) + x
 
 
 class Transformer2DModel(nn.Module):

@@ -179,6 +179,33 @@ def test_layernorm_forward_backward(shape, dt):
     _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
 
 
+@pytest.mark.parametrize("shape", [(4, 4096, 320), (2, 256, 1280), (3, 77, 768), (1, 5, 8)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_add_layernorm_equals_add_then_layernorm(shape, dt):
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    a = (torch.randn(*shape, generator=g) * 1.5).to(dt).to(DEV)
+    b = (torch.randn(*shape, generator=g) * 1.5 + torch.randn(shape[-1], generator=g)).to(dt).to(DEV)
+    norm = nn.LayerNorm(shape[-1]).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(shape[-1], generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(shape[-1], generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gs, gy = torch.randn(*shape, generator=g).to(dt).to(DEV), torch.randn(*shape, generator=g).to(dt).to(DEV)
+    ag, bg = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    s, y = fused.add_layer_norm(ag, bg, norm)
+    assert type(y.grad_fn).__name__ == "_AddLayerNormBackward"
+    torch.autograd.backward([s, y], [gs, gy])
+    assert torch.equal(s, a + b), "the sum must be exactly what the separate add produces"
+    ar, br = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    sr = (ar + br).to(dt).float() if dt != torch.float32 else ar + br  # the norm sees the rounded sum
+    sr_ = (ar + br)
+    yr = F.layer_norm(sr_ + (sr - sr_).detach(), (shape[-1],), norm.weight.float(), norm.bias.float(), norm.eps)
+    torch.autograd.backward([sr_, yr], [gs.float(), gy.float()])
+    _close(y, yr, dt, msg="norm output")
+    _close(ag.grad, ar.grad, dt, scale=float(ar.grad.abs().max()) + 1e-6, msg="gradient of a")
+    assert torch.equal(ag.grad, bg.grad)
+
+
 def test_layernorm_fallbacks():
     x = torch.randn(4, 10, 100, device=DEV)  # K % 8 != 0
     n = nn.LayerNorm(100).to(DEV).requires_grad_(False)
