@@ -81,3 +81,29 @@ def test_tune_cache_roundtrip(tmp_path, monkeypatch):
     b["(4, 5)"] = ["EFFICIENT_ATTENTION", 64]
     assert _C._TuneCache("gemm_fwd")["(1, 2, 3)"] == 22 and _C._TuneCache("sdpa")["(4, 5)"] == ["EFFICIENT_ATTENTION", 64]
     assert "(1, 2, 3)" not in _C._TuneCache("gemm_bwd")
+
+
+def test_host_pass_geometry_is_pure_host_arithmetic():
+    """GroupNorm / LayerNorm planners of csrc/hostops.hip: every normalisation of the SD1.5 UNet at 512^2 and 768^2 is
+    supported, the slice statistics stay a small fraction of the tensor, unsupported geometries say so."""
+    lib = _C.require()
+    sd15 = [(320, 64), (640, 64), (640, 32), (960, 64), (1280, 32), (1920, 32), (1280, 16), (2560, 16), (1280, 8),
+            (2560, 8), (320, 96), (960, 96), (1920, 48), (2560, 24), (2560, 12)]
+    for C_, hw in sd15:
+        for B in (1, 4, 8):
+            ws = lib.lora_amd_groupnorm_workspace(B, C_, hw * hw, 32)
+            assert ws > 0 and lib.lora_amd_groupnorm_supported(B, C_, hw * hw, 32) == 1
+            slices = ws // (B * 32 * 2 * 4)
+            assert 1 <= slices <= 256
+            assert ws <= max(B * C_ * hw * hw * 2 // 64, 4096), (B, C_, hw, ws)  # << one bf16 pass over the tensor
+    assert lib.lora_amd_groupnorm_workspace(1, 32, 36, 8) == 0  # HW % 8 != 0
+    assert lib.lora_amd_groupnorm_workspace(1, 30, 64, 8) == 0  # C % groups != 0
+    assert lib.lora_amd_groupnorm_supported(0, 32, 64, 8) == 0
+    for K in (8, 320, 640, 768, 1024, 1280, 2560):
+        assert lib.lora_amd_layernorm_supported(K) == 1
+    for K in (0, 4, 100, 2568, 4096):
+        assert lib.lora_amd_layernorm_supported(K) == 0
+    # argument checks of the compute entry points run before any launch: no GPU needed to see them
+    assert lib.lora_amd_geglu_fwd(None, 16, None, 8, 4, 10, _C.BF16, None) != 0
+    assert b"inner" in lib.lora_amd_last_error()
+    assert lib.lora_amd_layernorm_fwd(None, None, None, None, None, 4, 100, 1e-5, _C.BF16, None) != 0
