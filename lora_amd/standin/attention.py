@@ -31,17 +31,21 @@ def _padded(d: int) -> int:
     return 64 if d <= 64 else 128 if d <= 128 else 256 if d <= 256 else d
 
 
-def _run(q, k, v, backend: Optional[str], pad_to: int):
+def _run(q, k, v, backend: Optional[str], pad_to: int, pad_v: bool = True):
+    """``pad_to`` > d zero-pads the head dimension of q and k (and of v when ``pad_v``; with v left as is the output
+    comes back unpadded — one pad and one slice copy fewer each way — where the kernel accepts Dv != Dk)."""
     d = q.shape[-1]
     scale = d ** -0.5
     if pad_to > d:
-        q, k, v = (F.pad(t, (0, pad_to - d)) for t in (q, k, v))
+        q, k = F.pad(q, (0, pad_to - d)), F.pad(k, (0, pad_to - d))
+        if pad_v:
+            v = F.pad(v, (0, pad_to - d))
     if backend is None or sdpa_kernel is None:
         o = F.scaled_dot_product_attention(q, k, v, scale=scale)
     else:
         with sdpa_kernel(getattr(SDPBackend, backend)):
             o = F.scaled_dot_product_attention(q, k, v, scale=scale)
-    return o[..., :d] if pad_to > d else o
+    return o[..., :d] if (pad_to > d and pad_v) else o
 
 
 def _pad_candidates(d: int):
@@ -57,27 +61,27 @@ def _tune(q, k, v) -> Tuple[Optional[str], int]:
     cands = [(None, d), ("EFFICIENT_ATTENTION", d)]
     for pad in _pad_candidates(d):
         if pad > d:
-            cands += [("EFFICIENT_ATTENTION", pad), ("FLASH_ATTENTION", pad)]
+            cands += [("EFFICIENT_ATTENTION", pad), ("FLASH_ATTENTION", pad), ("EFFICIENT_ATTENTION", pad, False)]
     best, best_t = (None, d), float("inf")
-    for be, pad in cands:
+    for cand in cands:
         try:
             qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
             go = torch.randn_like(q)
-            _run(qq, kk, vv, be, pad).backward(go)  # warm: lazy kernel loading / JIT is not what is compared
+            _run(qq, kk, vv, *cand).backward(go)  # warm: lazy kernel loading / JIT is not what is compared
             t = float("inf")
             for _ in range(3):  # minimum over repeats: one stall must not pick the wrong kernel for the whole run
                 torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(2):
-                    _run(qq, kk, vv, be, pad).backward(go)
+                    _run(qq, kk, vv, *cand).backward(go)
                 b.record()
                 torch.cuda.synchronize()
                 t = min(t, a.elapsed_time(b))
         except Exception:  # noqa: BLE001 - a backend that rejects the shape is simply not a candidate
             continue
         if t < best_t:
-            best, best_t = (be, pad), t
+            best, best_t = tuple(cand), t
     return best
 
 
