@@ -196,6 +196,13 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
 int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
                                 int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
                                 int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, void *stream);
+/* The same for head-padded G and / or X rows (see lora_amd_linear_gemm_fwd_heads): g_head_* describe G [M, heads*D],
+ * x_head_* describe X; the partials stay dense. */
+int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
+                                      int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
+                                      int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
+                                      int32_t g_head_dim, int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad,
+                                      void *stream);
 
 /* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, and
  * t_out[M,r] (f32) = t_scale * X down^T for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch
@@ -212,6 +219,18 @@ int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *w, int64_t 
                              int64_t ldy, const float *down, const float *up, float *t_out, int64_t M, int32_t K,
                              int32_t N, int32_t r, int32_t act_dtype, float scale, float t_scale,
                              int32_t factor_layout, int32_t tile, void *stream);
+
+/* The same with head-padded activations: a row of `heads` runs of d elements stored with every run padded to D
+ * (d, D multiples of 8; the layout attention kernels want for head sizes 40 / 80).  x_head_dim/x_head_pad describe
+ * the X operand (logical K = heads * d, physical row length heads * D, pad never read), y_head_dim/y_head_pad the
+ * output (pad written as zeros; needs 160 % d == 0 so that an output tile owns whole heads).  0 = dense.  Removes
+ * the pad / slice copies around the attention core: q, k, v projections write the padded layout, the output
+ * projection reads it, and the input-gradient call (factor_layout 3) does the same in the other direction. */
+int lora_amd_linear_gemm_fwd_heads(const void *x, int64_t ldx, const void *w, int64_t ldw, const void *bias, void *y,
+                                   int64_t ldy, const float *down, const float *up, float *t_out, int64_t M,
+                                   int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, float t_scale,
+                                   int32_t factor_layout, int32_t tile, int32_t x_head_dim, int32_t x_head_pad,
+                                   int32_t y_head_dim, int32_t y_head_pad, void *stream);
 
 /* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
  * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient

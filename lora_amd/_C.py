@@ -30,7 +30,7 @@ SYMBOLS = (
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
-    "lora_amd_linear_bwd_factors",
+    "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_heads", "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
@@ -120,6 +120,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]
     lib.lora_amd_linear_bwd_factors.restype = C.c_int
+    lib.lora_amd_linear_bwd_factors_heads.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32,
+                                                      i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors_heads.restype = C.c_int
+    lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
+                                                   f32, f32, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
     lib.lora_amd_linear_gemm_supported.argtypes = [i64, i32, i32, i32, i32]
     lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32,
@@ -463,13 +469,19 @@ def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Ten
 
 
 def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, x: torch.Tensor, gt: torch.Tensor,
-                       down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None) -> None:
-    """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it)."""
+                       down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None,
+                       g_heads=None, x_heads=None) -> None:
+    """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it).
+    ``g_heads`` / ``x_heads`` = (heads, d, D) when G / X rows are head-padded (logical N / K = heads * d)."""
     _dev_check(g, t, up_part, x, gt, down_part, sel)
-    _check(require().lora_amd_linear_bwd_factors(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
-                                                 x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
-                                                 down_part.data_ptr(), g.shape[0], x.shape[1], g.shape[1], r,
-                                                 dtype_code(g.dtype), float(scale), _stream()),
+    N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
+    K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+    gd, gD = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    _check(require().lora_amd_linear_bwd_factors_heads(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
+                                                       x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
+                                                       down_part.data_ptr(), g.shape[0], K, N, r,
+                                                       dtype_code(g.dtype), float(scale), gd, gD, xd, xD, _stream()),
            "lora_amd_linear_bwd_factors")
 
 
@@ -552,27 +564,54 @@ def gemm_supported(x: torch.Tensor, weight: torch.Tensor, y_cols: int, r: int) -
             and bool(require().lora_amd_linear_gemm_supported(x.shape[0], x.shape[1], y_cols, r, dtype_code(x.dtype))))
 
 
+Heads = Optional[Tuple[int, int, int]]  # (heads, d, D): `heads` runs of d elements, each stored padded to D
+
+
+def heads_width(cols: int, lay: Heads) -> int:
+    """Physical row length of a [*, cols] tensor stored with the head layout ``lay`` (None: dense)."""
+    if lay is None:
+        return cols
+    h, d, D = lay
+    if h * d != cols:
+        raise ValueError(f"head layout {lay} does not describe {cols} columns")
+    return h * D
+
+
 def linear_gemm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
-                    up: torch.Tensor, scale: float, tile: int = 0, t_scale: float = 1.0, factor_layout: int = 0):
-    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch (see include/lora_amd.h)."""
-    M, K = x.shape
-    N = weight.shape[0]
+                    up: torch.Tensor, scale: float, tile: int = 0, t_scale: float = 1.0, factor_layout: int = 0,
+                    x_heads: Heads = None, y_heads: Heads = None):
+    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch (see include/lora_amd.h).  With
+    ``x_heads`` the rows of x are head-padded (logical K = weight.shape[1]); with ``y_heads`` y comes back head-padded
+    ([M, heads*D], pad zeroed)."""
+    M = x.shape[0]
+    N, K = weight.shape
+    if x.shape[1] != heads_width(K, x_heads):
+        raise ValueError(f"linear_gemm_fwd: x has {x.shape[1]} columns, expected {heads_width(K, x_heads)}")
     r = down.shape[1] if factor_layout & 1 else down.shape[0]
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, heads_width(N, y_heads)), dtype=x.dtype, device=x.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x.device)
-    _check(require().lora_amd_linear_gemm_fwd(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
-                                              _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(), up.data_ptr(),
-                                              t.data_ptr(), M, K, N, r, dtype_code(x.dtype), float(scale),
-                                              float(t_scale), int(factor_layout), int(tile), _stream()),
-           "lora_amd_linear_gemm_fwd")
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    yd, yD = (y_heads[1], y_heads[2]) if y_heads else (0, 0)
+    _check(require().lora_amd_linear_gemm_fwd_heads(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
+                                                    _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(),
+                                                    up.data_ptr(), t.data_ptr(), M, K, N, r, dtype_code(x.dtype),
+                                                    float(scale), float(t_scale), int(factor_layout), int(tile),
+                                                    xd, xD, yd, yD, _stream()), "lora_amd_linear_gemm_fwd")
     return y, t
 
 
 def linear_gemm_dx(g: torch.Tensor, weight_t: torch.Tensor, down: torch.Tensor, up: torch.Tensor, scale: float,
-                   tile: int = 0):
+                   tile: int = 0, g_heads: Heads = None, dx_heads: Heads = None):
     """(dX [M,K], Gt [M,r] f32): dX = G W + scale (G up) down, Gt = scale G up, ONE launch of the same MFMA kernel on
-    the resident transposed weight ``weight_t`` [K, N] (factors read in place: up [N,r] k-major, down [r,K])."""
-    return linear_gemm_fwd(g, weight_t, None, up, down, scale, tile, t_scale=scale, factor_layout=3)
+    the resident transposed weight ``weight_t`` [K, N] (factors read in place: up [N,r] k-major, down [r,K]).
+    ``g_heads``: G arrives head-padded (the site's output was); ``dx_heads``: dX is written head-padded (its input was)."""
+    return linear_gemm_fwd(g, weight_t, None, up, down, scale, tile, t_scale=scale, factor_layout=3,
+                           x_heads=g_heads, y_heads=dx_heads)
+
+
+def heads_tile_ok(lay: Heads) -> bool:
+    """Output head layouts the fused kernel can write: an output tile (160 or 320 columns) must own whole heads."""
+    return lay is None or (lay[1] % 8 == 0 and lay[2] % 8 == 0 and 160 % lay[1] == 0)
 
 
 GEMM_TILES = (22, 23, 24, 21)  # stages*10 + shape (see lora_amd_linear_gemm_fwd)
@@ -682,6 +721,21 @@ def gemm_choice(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 _wt_cache = {}
+
+
+def gemm_choice_cached(M: int, K: int, N: int, r: int, dtype: torch.dtype, has_bias: bool) -> Optional[int]:
+    """The forward tile :func:`gemm_choice` settled on for this shape, or None if it has not been timed yet."""
+    env = os.environ.get("LORA_AMD_GEMM")
+    if env is not None:
+        return int(env)
+    return _gemm_choice.get(repr((M, K, N, r, str(dtype), has_bias)))
+
+
+def gemm_choice_bwd_cached(M: int, K: int, N: int, r: int, dtype: torch.dtype) -> Optional[int]:
+    env = os.environ.get("LORA_AMD_GEMM_BWD", os.environ.get("LORA_AMD_GEMM"))
+    if env is not None:
+        return int(env)
+    return _gemm_choice_bwd.get(repr((M, K, N, r, str(dtype))))
 
 
 def weight_t(weight: torch.Tensor) -> torch.Tensor:

@@ -104,5 +104,30 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return _run(q, k, v, *choice)
 
 
+FORCE_PAD: Optional[int] = None  # tests: take the padded-layout path with this head size, on any device
+
+
+def padded_choice(B: int, H: int, Sq: int, Sk: int, d: int, dtype, grad: bool):
+    """(backend, D) if the kernel chosen for this shape runs on q, k, v all zero-padded to head size D > d, else None.
+    Only a choice that has already been made counts (the first call of a shape goes through :func:`sdpa`, which times
+    the candidates); callers that can produce / consume the padded layout directly then skip the pad and slice copies."""
+    if FORCE_PAD is not None:
+        return (None, FORCE_PAD) if FORCE_PAD > d else None
+    c = _CHOICE.get(repr((B, H, Sq, Sk, d, str(dtype), grad)))
+    if c is None or c[1] <= d or (len(c) > 2 and not c[2]):
+        return None
+    return c[0], c[1]
+
+
+def sdpa_padded(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, d: int, backend: Optional[str]) -> torch.Tensor:
+    """The attention core on tensors that already carry the padded head size (pad columns zero); ``d`` is the true
+    head size (softmax scale)."""
+    scale = d ** -0.5
+    if backend is None or sdpa_kernel is None or not q.is_cuda:
+        return F.scaled_dot_product_attention(q, k, v, scale=scale)
+    with sdpa_kernel(getattr(SDPBackend, backend)):
+        return F.scaled_dot_product_attention(q, k, v, scale=scale)
+
+
 def choices():
     return dict(_CHOICE)

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import attention
 from .attention import sdpa
 from .fused import add_layer_norm, geglu, group_norm_act, layer_norm
 from torch.utils.checkpoint import checkpoint
@@ -63,7 +64,7 @@ class CrossAttention(nn.Module):
         super().__init__()
         inner = heads * dim_head
         ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
-        self.heads = heads
+        self.heads, self.dim_head = heads, dim_head
         self.to_q = nn.Linear(query_dim, inner, bias=False)
         self.to_k = nn.Linear(ctx, inner, bias=False)
         self.to_v = nn.Linear(ctx, inner, bias=False)
@@ -73,12 +74,40 @@ class CrossAttention(nn.Module):
         ctx = x if context is None else context
         B, T, _ = x.shape
         h = self.heads
+        d = self.dim_head
+        grad = torch.is_grad_enabled() and (x.requires_grad or ctx.requires_grad or _trains(self))
+        pad = attention.padded_choice(B, h, T, ctx.shape[1], d, x.dtype, grad)
+        if pad is not None:
+            # the chosen attention kernel wants head size D > d: the projections write / read that layout themselves
+            # (fused GEMM epilogue and operand remap, ops.lora_linear) instead of pad + slice copies around the core
+            backend, D = pad
+            lay = (h, d, D)
+            q = _project(self.to_q, x, None, lay).view(B, T, h, D).transpose(1, 2)
+            k = _project(self.to_k, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+            v = _project(self.to_v, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+            o = attention.sdpa_padded(q, k, v, d, backend).transpose(1, 2).reshape(B, T, h * D)
+            return self.to_out[1](_project(self.to_out[0], o, lay, None))
         q = self.to_q(x).view(B, T, h, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], h, -1).transpose(1, 2)
         o = sdpa(q, k, v)  # dense contraction: library MFMA flash kernels, fastest variant per shape (attention.py)
         o = o.transpose(1, 2).reshape(B, T, -1)
         return self.to_out[1](self.to_out[0](o))
+
+
+def _trains(module: nn.Module) -> bool:
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _project(lin: nn.Module, x: torch.Tensor, in_heads, out_heads) -> torch.Tensor:
+    """A q / k / v / out projection on head-padded activations: adapters handle the layout themselves
+    (``forward_heads``), a plain Linear gets dense copies around it."""
+    if hasattr(lin, "forward_heads"):
+        return lin.forward_heads(x, in_heads, out_heads)
+    from ..ops import pack_heads, unpack_heads
+
+    y = lin(unpack_heads(x, in_heads) if in_heads else x)
+    return pack_heads(y, out_heads) if out_heads else y
 
 
 class GEGLU(nn.Module):

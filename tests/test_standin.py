@@ -172,3 +172,39 @@ def test_resnet_block_folds_conv_bias_and_time_embedding_into_one_addend():
     # channels_last input: same numbers (ATen fallbacks on CPU)
     yc = blk(x.contiguous(memory_format=torch.channels_last), temb)
     torch.testing.assert_close(yc.contiguous(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_attention_padded_head_layout_plumbing_equals_regular_path():
+    """The padded-head-layout route through CrossAttention (projections via ``forward_heads``, core on padded tensors)
+    gives the regular route's output and gradients; on CPU the layout conversions are dense copies."""
+    from lora_amd import ops
+    from lora_amd.standin import attention
+    from lora_amd.standin.unet import CrossAttention
+
+    torch.manual_seed(0)
+    y = torch.randn(2, 5, 8 * 40)
+    p = ops.pack_heads(y, (8, 40, 64))
+    assert p.shape == (2, 5, 512) and torch.equal(ops.unpack_heads(p, (8, 40, 64)), y)
+    assert float(p.view(2, 5, 8, 64)[..., 40:].abs().max()) == 0
+    for ctx_dim, inject in ((None, True), (48, True), (None, False)):
+        att = CrossAttention(64, ctx_dim, heads=4, dim_head=24)
+        if inject:
+            L.inject_trainable_lora(att, target_replace_module={"CrossAttention"}, r=4)
+            for m in att.modules():
+                if type(m).__name__ == "LoraInjectedLinear":
+                    nn.init.normal_(m.lora_up.weight, std=0.1)
+        x = torch.randn(2, 9, 64, requires_grad=True)
+        c = None if ctx_dim is None else torch.randn(2, 7, 48)
+        leaves = [x] + [q for q in att.parameters() if q.requires_grad]
+        try:
+            attention.FORCE_PAD = None
+            y0 = att(x, c)
+            g0 = torch.autograd.grad(y0.square().sum(), leaves)
+            attention.FORCE_PAD = 32
+            y1 = att(x, c)
+            g1 = torch.autograd.grad(y1.square().sum(), leaves)
+        finally:
+            attention.FORCE_PAD = None
+        torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
+        for a, b in zip(g1, g0):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
