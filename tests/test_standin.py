@@ -208,3 +208,24 @@ def test_attention_padded_head_layout_plumbing_equals_regular_path():
         torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
         for a, b in zip(g1, g0):
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_unet_channels_last_equals_nchw():
+    """The whole stand-in UNet on channels_last activations (token views instead of copies in Transformer2DModel,
+    GroupNorm addend, add+LayerNorm) computes what it computes on NCHW; on CPU every fused pass is its ATen fallback."""
+    torch.manual_seed(0)
+    unet = tiny_unet()
+    L.inject_trainable_lora(unet, r=2)
+    for m in unet.modules():
+        if type(m).__name__ == "LoraInjectedLinear":
+            nn.init.normal_(m.lora_up.weight, std=0.05)
+    lat, t, ctx = torch.randn(2, 4, 16, 16), torch.tensor([3, 700]), torch.randn(2, 7, 32)
+    leaves = [p for p in unet.parameters() if p.requires_grad]
+    y0 = unet(lat, t, ctx).sample
+    g0 = torch.autograd.grad(y0.square().mean(), leaves)
+    unet.to(memory_format=torch.channels_last)
+    y1 = unet(lat.contiguous(memory_format=torch.channels_last), t, ctx).sample
+    g1 = torch.autograd.grad(y1.square().mean(), leaves)
+    torch.testing.assert_close(y1.contiguous(), y0, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-6)
