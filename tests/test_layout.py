@@ -36,3 +36,15 @@ def test_required_layout():
               "lora_amd/csrc/linear_fused.hip", "lora_amd/csrc/gemm_fused.hip", "lora_amd/csrc/conv.hip", "DESIGN.md",
               "INTEGRATION.md", "bench.py", "training_scripts/train_lora_dreambooth.py", "lora_amd/cli_lora_pti.py"):
         assert os.path.exists(os.path.join(REPO, p)), p
+
+
+def test_bench_roofline_entry_reports_the_binding_roof():
+    """bench.roofline_entry: below the machine balance (2.5 PF / 8 TB/s = 312 flop/B) the byte roof binds."""
+    import bench
+
+    M, K, N = 16384, 320, 320
+    e = bench.roofline_entry(2.0 * M * K * N, (M * K + N * K + M * N) * 2, 15.7e-6)
+    assert e["bound"] == "hbm" and e["unit"] == "GB/s" and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
+    assert 0.16 < e["frac"] < 0.18 and e["mfma_frac"] < e["hbm_frac"]
+    e = bench.roofline_entry(2.0 * 8192 ** 3, 3 * 8192 * 8192 * 2, 1e-3)  # square GEMM: 2731 flop/B
+    assert e["bound"] == "mfma" and e["unit"] == "TFLOP/s" and abs(e["frac"] - 0.4398) < 1e-3
