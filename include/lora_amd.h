@@ -214,6 +214,13 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
 int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
                                 int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
                                 int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, void *stream);
+/* The same for head-padded G and / or X rows (see lora_amd_linear_gemm_fwd_heads): g_head_* describe G [M, heads*D],
+ * x_head_* describe X; the partials stay dense. */
+int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
+                                      int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
+                                      int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
+                                      int32_t g_head_dim, int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad,
+                                      void *stream);
 
 /* K1 fully fused on the matrix cores: Y[M,N] = X[M,K] W[N,K]^T + bias + scale * (X down^T) up^T, and
  * t_out[M,r] (f32) = t_scale * X down^T for the backward.  ONE launch replaces the frozen addmm AND the low-rank branch
@@ -264,6 +271,18 @@ int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t 
                      void *stream);
 int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
                        const lora_amd_ws_site *sites /* host array */, int32_t nsites, int32_t row_groups, void *stream);
+
+/* lora_amd_linear_gemm_fwd with head-padded activations: a row of `heads` runs of d elements stored with every run padded to D
+ * (d, D multiples of 8; the layout attention kernels want for head sizes 40 / 80).  x_head_dim/x_head_pad describe
+ * the X operand (logical K = heads * d, physical row length heads * D, pad never read), y_head_dim/y_head_pad the
+ * output (pad written as zeros; needs 160 % d == 0 so that an output tile owns whole heads).  0 = dense.  Removes
+ * the pad / slice copies around the attention core: q, k, v projections write the padded layout, the output
+ * projection reads it, and the input-gradient call (factor_layout 3) does the same in the other direction. */
+int lora_amd_linear_gemm_fwd_heads(const void *x, int64_t ldx, const void *w, int64_t ldw, const void *bias, void *y,
+                                   int64_t ldy, const float *down, const float *up, float *t_out, int64_t M,
+                                   int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, float t_scale,
+                                   int32_t factor_layout, int32_t tile, int32_t x_head_dim, int32_t x_head_pad,
+                                   int32_t y_head_dim, int32_t y_head_pad, void *stream);
 
 /* out (f32, [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c], part laid out [nparts][RT][C].
  * ONE launch covers every descriptor: the trainer reduces all sites' partials into its flat gradient
@@ -415,6 +434,19 @@ int lora_amd_groupnorm_bwd(const void *x, const void *gout, const void *gamma, c
                            const float *stats, void *dx, void *workspace, size_t workspace_bytes, int32_t B,
                            int32_t C, int32_t HW, int32_t groups, int32_t act, int32_t dtype, void *stream);
 
+/* The same for channels_last activations (memory [B][HW][C], C % 8 == 0): aff [B][4][C] f32 receives the per-channel
+ * (gamma*rstd, beta - mean*gamma*rstd, mean, rstd) the backward needs.  Three launches each way.
+ * `addend` [B][C] f32 (or NULL) is added to x before the normalisation (time-embedding projection + the bias of the
+ * producing convolution in ResnetBlock2D) at no streaming cost; it is folded into aff, the backward needs no change
+ * (the gradient w.r.t. the addend is the per-(sample, channel) sum of dx). */
+size_t lora_amd_groupnorm_nhwc_workspace(int32_t B, int32_t C, int32_t HW, int32_t groups);
+int lora_amd_groupnorm_nhwc_fwd(const void *x, const void *gamma, const void *beta, const float *addend, void *y,
+                                float *aff, void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                int32_t groups, float eps, int32_t act, int32_t dtype, void *stream);
+int lora_amd_groupnorm_nhwc_bwd(const void *x, const void *gout, const void *gamma, const float *aff, void *dx,
+                                void *workspace, size_t workspace_bytes, int32_t B, int32_t C, int32_t HW,
+                                int32_t groups, int32_t act, int32_t dtype, void *stream);
+
 /* LayerNorm over the last dimension of row-contiguous x [M, K] (K % 8 == 0, K <= 2560; gamma / beta in the activation
  * dtype, frozen).  stats [M][2] f32 = (mean, rstd).  One launch each way. */
 int lora_amd_layernorm_supported(int32_t K);
@@ -422,6 +454,13 @@ int lora_amd_layernorm_fwd(const void *x, const void *gamma, const void *beta, v
                            int32_t K, float eps, int32_t dtype, void *stream);
 int lora_amd_layernorm_bwd(const void *x, const void *gout, const void *gamma, const float *stats, void *dx,
                            int64_t M, int32_t K, int32_t dtype, void *stream);
+/* The residual add in front of the norm in the same pass: sum_out = x + res (rounded to the activation dtype, what the
+ * residual stream carries on), y = layernorm(sum_out).  Backward: dx = d layernorm / d sum (given gout, evaluated at
+ * x = sum_out) + gsum, the gradient arriving through the residual stream; it is the gradient of both addends. */
+int lora_amd_add_layernorm_fwd(const void *x, const void *res, const void *gamma, const void *beta, void *sum_out,
+                               void *y, float *stats, int64_t M, int32_t K, float eps, int32_t dtype, void *stream);
+int lora_amd_add_layernorm_bwd(const void *x, const void *gout, const void *gsum, const void *gamma,
+                               const float *stats, void *dx, int64_t M, int32_t K, int32_t dtype, void *stream);
 
 /* GEGLU gate behind the adapted projection: y [M, 2*inner] = [h | gate]; out [M, inner] = h * gelu(gate) (erf form).
  * Backward writes gy [M, 2*inner] = [gout * gelu(gate) | gout * h * gelu'(gate)] in one pass (no cat). */

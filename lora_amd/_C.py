@@ -32,7 +32,7 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
-    "lora_amd_linear_bwd_factors",
+    "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_heads", "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
@@ -41,6 +41,8 @@ SYMBOLS = (
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
     "lora_amd_geglu_fwd", "lora_amd_geglu_bwd",
     "lora_amd_layernorm_supported", "lora_amd_layernorm_fwd", "lora_amd_layernorm_bwd",
+    "lora_amd_groupnorm_nhwc_workspace", "lora_amd_groupnorm_nhwc_fwd", "lora_amd_groupnorm_nhwc_bwd",
+    "lora_amd_add_layernorm_fwd", "lora_amd_add_layernorm_bwd",
 )
 
 
@@ -137,6 +139,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]
     lib.lora_amd_linear_bwd_factors.restype = C.c_int
+    lib.lora_amd_linear_bwd_factors_heads.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32,
+                                                      i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors_heads.restype = C.c_int
+    lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
+                                                   f32, f32, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
     lib.lora_amd_reduce_batched.argtypes = [vp, i32, i64, vp]
     lib.lora_amd_linear_gemm_supported.argtypes = [i64, i32, i32, i32, i32]
     lib.lora_amd_linear_gemm_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32,
@@ -161,6 +169,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_groupnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp]
     lib.lora_amd_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_workspace.argtypes = [i32, i32, i32, i32]
+    lib.lora_amd_groupnorm_nhwc_workspace.restype = sz
+    lib.lora_amd_groupnorm_nhwc_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, f32, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_groupnorm_nhwc_fwd.restype = lib.lora_amd_groupnorm_nhwc_bwd.restype = C.c_int
+    lib.lora_amd_add_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
+    lib.lora_amd_add_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    lib.lora_amd_add_layernorm_fwd.restype = lib.lora_amd_add_layernorm_bwd.restype = C.c_int
     lib.lora_amd_layernorm_supported.argtypes = [i32]
     lib.lora_amd_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]
     lib.lora_amd_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp]
@@ -549,13 +565,19 @@ def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Ten
 
 
 def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, x: torch.Tensor, gt: torch.Tensor,
-                       down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None) -> None:
-    """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it)."""
+                       down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None,
+                       g_heads=None, x_heads=None) -> None:
+    """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it).
+    ``g_heads`` / ``x_heads`` = (heads, d, D) when G / X rows are head-padded (logical N / K = heads * d)."""
     _dev_check(g, t, up_part, x, gt, down_part, sel)
-    _check(require().lora_amd_linear_bwd_factors(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
-                                                 x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
-                                                 down_part.data_ptr(), g.shape[0], x.shape[1], g.shape[1], r,
-                                                 dtype_code(g.dtype), float(scale), _stream()),
+    N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
+    K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+    gd, gD = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    _check(require().lora_amd_linear_bwd_factors_heads(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
+                                                       x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
+                                                       down_part.data_ptr(), g.shape[0], K, N, r,
+                                                       dtype_code(g.dtype), float(scale), gd, gD, xd, xD, _stream()),
            "lora_amd_linear_bwd_factors")
 
 
@@ -638,27 +660,54 @@ def gemm_supported(x: torch.Tensor, weight: torch.Tensor, y_cols: int, r: int) -
             and bool(require().lora_amd_linear_gemm_supported(x.shape[0], x.shape[1], y_cols, r, dtype_code(x.dtype))))
 
 
+Heads = Optional[Tuple[int, int, int]]  # (heads, d, D): `heads` runs of d elements, each stored padded to D
+
+
+def heads_width(cols: int, lay: Heads) -> int:
+    """Physical row length of a [*, cols] tensor stored with the head layout ``lay`` (None: dense)."""
+    if lay is None:
+        return cols
+    h, d, D = lay
+    if h * d != cols:
+        raise ValueError(f"head layout {lay} does not describe {cols} columns")
+    return h * D
+
+
 def linear_gemm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
-                    up: torch.Tensor, scale: float, tile: int = 0, t_scale: float = 1.0, factor_layout: int = 0):
-    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch (see include/lora_amd.h)."""
-    M, K = x.shape
-    N = weight.shape[0]
+                    up: torch.Tensor, scale: float, tile: int = 0, t_scale: float = 1.0, factor_layout: int = 0,
+                    x_heads: Heads = None, y_heads: Heads = None):
+    """(y [M,N], t [M,r] f32) = fused frozen GEMM + LoRA branch in one launch (see include/lora_amd.h).  With
+    ``x_heads`` the rows of x are head-padded (logical K = weight.shape[1]); with ``y_heads`` y comes back head-padded
+    ([M, heads*D], pad zeroed)."""
+    M = x.shape[0]
+    N, K = weight.shape
+    if x.shape[1] != heads_width(K, x_heads):
+        raise ValueError(f"linear_gemm_fwd: x has {x.shape[1]} columns, expected {heads_width(K, x_heads)}")
     r = down.shape[1] if factor_layout & 1 else down.shape[0]
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, heads_width(N, y_heads)), dtype=x.dtype, device=x.device)
     t = torch.empty((M, r), dtype=torch.float32, device=x.device)
-    _check(require().lora_amd_linear_gemm_fwd(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
-                                              _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(), up.data_ptr(),
-                                              t.data_ptr(), M, K, N, r, dtype_code(x.dtype), float(scale),
-                                              float(t_scale), int(factor_layout), int(tile), _stream()),
-           "lora_amd_linear_gemm_fwd")
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    yd, yD = (y_heads[1], y_heads[2]) if y_heads else (0, 0)
+    _check(require().lora_amd_linear_gemm_fwd_heads(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
+                                                    _ptr(bias), y.data_ptr(), y.stride(0), down.data_ptr(),
+                                                    up.data_ptr(), t.data_ptr(), M, K, N, r, dtype_code(x.dtype),
+                                                    float(scale), float(t_scale), int(factor_layout), int(tile),
+                                                    xd, xD, yd, yD, _stream()), "lora_amd_linear_gemm_fwd")
     return y, t
 
 
 def linear_gemm_dx(g: torch.Tensor, weight_t: torch.Tensor, down: torch.Tensor, up: torch.Tensor, scale: float,
-                   tile: int = 0):
+                   tile: int = 0, g_heads: Heads = None, dx_heads: Heads = None):
     """(dX [M,K], Gt [M,r] f32): dX = G W + scale (G up) down, Gt = scale G up, ONE launch of the same MFMA kernel on
-    the resident transposed weight ``weight_t`` [K, N] (factors read in place: up [N,r] k-major, down [r,K])."""
-    return linear_gemm_fwd(g, weight_t, None, up, down, scale, tile, t_scale=scale, factor_layout=3)
+    the resident transposed weight ``weight_t`` [K, N] (factors read in place: up [N,r] k-major, down [r,K]).
+    ``g_heads``: G arrives head-padded (the site's output was); ``dx_heads``: dX is written head-padded (its input was)."""
+    return linear_gemm_fwd(g, weight_t, None, up, down, scale, tile, t_scale=scale, factor_layout=3,
+                           x_heads=g_heads, y_heads=dx_heads)
+
+
+def heads_tile_ok(lay: Heads) -> bool:
+    """Output head layouts the fused kernel can write: an output tile (160 or 320 columns) must own whole heads."""
+    return lay is None or (lay[1] % 8 == 0 and lay[2] % 8 == 0 and 160 % lay[1] == 0)
 
 
 GEMM_TILES = (22, 23, 24, 21)  # stages*10 + shape (see lora_amd_linear_gemm_fwd)
@@ -811,6 +860,27 @@ def gemm_choice(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 _wt_cache = {}
+
+
+def gemm_choice_cached(M: int, K: int, N: int, r: int, dtype: torch.dtype, has_bias: bool) -> Optional[int]:
+    """The forward tile :func:`gemm_choice` settled on for this shape, or None if it has not been timed yet."""
+    env = os.environ.get("LORA_AMD_GEMM")
+    if env is not None:
+        return int(env)
+    c = _gemm_choice.get(repr((M, K, N, r, str(dtype), has_bias)))
+    if c is None and not AUTOTUNE:  # deterministic policy: the head-padded layouts live in the LDS-ring kernel only
+        c = static_fwd_choice(M, K, N, False, K % 64 == 0 and N % 8 == 0 and r <= 16)
+    return None if c == WS_TILE else c
+
+
+def gemm_choice_bwd_cached(M: int, K: int, N: int, r: int, dtype: torch.dtype) -> Optional[int]:
+    env = os.environ.get("LORA_AMD_GEMM_BWD", os.environ.get("LORA_AMD_GEMM"))
+    if env is not None:
+        return int(env)
+    c = _gemm_choice_bwd.get(repr((M, K, N, r, str(dtype))))
+    if c is None and not AUTOTUNE:
+        c = 22 if (N in (320, 640) and M >= 2048) else 0  # the shapes static_bwd_choice fuses, on the LDS-ring kernel
+    return None if c == WS_TILE else c
 
 
 def weight_t(weight: torch.Tensor) -> torch.Tensor:
@@ -1074,4 +1144,79 @@ def layernorm_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, stat
     _check(require().lora_amd_layernorm_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
                                             dx.data_ptr(), x.numel() // K, K, dtype_code(x.dtype), _stream()),
            "lora_amd_layernorm_bwd")
+    return dx
+
+
+_gn_nhwc_ws_cache: Dict[Tuple[int, int, int, int], int] = {}
+
+
+def groupnorm_nhwc_workspace(B: int, C_: int, HW: int, groups: int) -> int:
+    key = (B, C_, HW, groups)
+    n = _gn_nhwc_ws_cache.get(key)
+    if n is None:
+        n = _gn_nhwc_ws_cache[key] = int(require().lora_amd_groupnorm_nhwc_workspace(B, C_, HW, groups))
+    return n
+
+
+def groupnorm_nhwc_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                       act: bool, addend: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GroupNorm (+SiLU) of a channels_last x [B, C, H, W] (+ addend [B, C] f32 before the normalisation); returns
+    (y channels_last, aff [B, 4, C] f32)."""
+    _dev_check(x, gamma, beta, addend)
+    if addend is not None and (addend.dtype != torch.float32 or not addend.is_contiguous()
+                               or tuple(addend.shape) != (x.shape[0], x.shape[1])):
+        raise ValueError("groupnorm_nhwc_fwd: addend must be a contiguous float32 [B, C] tensor")
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_nhwc_workspace(B, C_, HW, groups)
+    if nbytes == 0:
+        raise ValueError(f"lora_amd_groupnorm_nhwc: geometry {tuple(x.shape)} / {groups} groups not supported")
+    y = torch.empty_like(x)  # preserves the channels_last strides
+    aff = torch.empty(B, 4, C_, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_nhwc_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(addend),
+                                                 y.data_ptr(), aff.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups, eps,
+                                                 1 if act else 0, dtype_code(x.dtype), _stream()),
+           "lora_amd_groupnorm_nhwc_fwd")
+    return y, aff
+
+
+def groupnorm_nhwc_bwd(x: torch.Tensor, gout: torch.Tensor, gamma: torch.Tensor, aff: torch.Tensor, groups: int,
+                       act: bool) -> torch.Tensor:
+    _dev_check(x, gout, gamma, aff)
+    B, C_ = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C_)
+    nbytes = groupnorm_nhwc_workspace(B, C_, HW, groups)
+    dx = torch.empty_like(x)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_groupnorm_nhwc_bwd(x.data_ptr(), gout.data_ptr(), gamma.data_ptr(), aff.data_ptr(),
+                                                 dx.data_ptr(), ws.data_ptr(), nbytes, B, C_, HW, groups,
+                                                 1 if act else 0, dtype_code(x.dtype), _stream()),
+           "lora_amd_groupnorm_nhwc_bwd")
+    return dx
+
+
+def add_layernorm_fwd(x: torch.Tensor, res: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                      eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(x + res, layernorm(x + res), stats) in one pass over contiguous x / res of the same shape."""
+    _dev_check(x, res, gamma, beta)
+    K = x.shape[-1]
+    M = x.numel() // K
+    s, y = torch.empty_like(x), torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_add_layernorm_fwd(x.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                s.data_ptr(), y.data_ptr(), stats.data_ptr(), M, K, eps,
+                                                dtype_code(x.dtype), _stream()), "lora_amd_add_layernorm_fwd")
+    return s, y, stats
+
+
+def add_layernorm_bwd(s: torch.Tensor, gout: torch.Tensor, gsum: Optional[torch.Tensor], gamma: torch.Tensor,
+                      stats: torch.Tensor) -> torch.Tensor:
+    """Gradient of both addends: layernorm backward at the saved sum + the gradient of the residual stream."""
+    _dev_check(s, gout, gsum, gamma, stats)
+    K = s.shape[-1]
+    dx = torch.empty_like(s)
+    _check(require().lora_amd_add_layernorm_bwd(s.data_ptr(), gout.data_ptr(), _ptr(gsum), gamma.data_ptr(),
+                                                stats.data_ptr(), dx.data_ptr(), s.numel() // K, K,
+                                                dtype_code(s.dtype), _stream()), "lora_amd_add_layernorm_bwd")
     return dx

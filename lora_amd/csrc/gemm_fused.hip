@@ -47,15 +47,20 @@ __device__ inline void glds16(const void *gsrc, void *lds_wave_base) {
 // One [rows][64] slab HBM -> LDS: wave-instruction q covers rows [8q, 8q+8); lane l lands at 8q*128 + l*16 and
 // fetches chunk (l & 7) ^ (row & 7) of its row (the swizzle lives on the source side).  Rows past `limit` re-read the
 // last valid row (their results are never stored).
+// Head-padded operands: a tensor whose logical row is `heads` runs of d elements may be stored with every run padded
+// to D elements (what the attention kernels want for d = 40 / 80).  hc = d / 8 and hp = D / 8 chunks; logical 16-byte
+// chunk c lives at physical chunk (c / hc) * hp + c % hc.  hc == 0: dense rows.
+__device__ inline int head_chunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
+
 template <class S>
 __device__ inline void stage_slab(const S *g, int64_t ld, int64_t row0, int64_t limit, int k0, char *lds, int nrows,
-                                  int wave, int lane) {
+                                  int wave, int lane, int hc = 0, int hp = 0) {
   for (int q = wave; q * 8 < nrows; q += 4) {
     const int rl = q * 8 + (lane >> 3);
     int64_t row = row0 + rl;
     if (row >= limit) row = limit - 1;
     const int c = (lane & 7) ^ (rl & 7);
-    glds16(g + row * ld + k0 + c * 8, lds + q * 1024);
+    glds16(g + row * ld + head_chunk((k0 >> 3) + c, hc, hp) * 8, lds + q * 1024);
   }
 }
 
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
     const typename E::storage *__restrict__ x, int64_t ldx, const typename E::storage *__restrict__ w, int64_t ldw,
     const typename E::storage *__restrict__ bias, typename E::storage *__restrict__ y, int64_t ldy,
     const float *__restrict__ down, const float *__restrict__ up, float *__restrict__ t_out, int64_t M, int K, int N,
-    int r, float scale, float t_scale, int flayout) {
+    int r, float scale, float t_scale, int flayout, int xhc, int xhp, int yhc, int yhp) {
   using S = typename E::storage;
   using F = typename MfmaT<E>::frag;
   constexpr int BM = 32 * RS, BN = 32 * CS;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
 #define ISSUE(step, slot)                                                               \
   do {                                                                                  \
     char *xs_ = smem + (slot) * SB, *ws_ = xs_ + XB, *ds_ = ws_ + WB;                   \
-    stage_slab<S>(x, ldx, m0, M, (step) * kBK, xs_, BM, wave, lane);                    \
+    stage_slab<S>(x, ldx, m0, M, (step) * kBK, xs_, BM, wave, lane, xhc, xhp);          \
     stage_slab<S>(w, ldw, n0, N, (step) * kBK, ws_, BN, wave, lane);                    \
     glds16(dn_src + (step) * dn_step, ds_ + dn_w * 1024);                               \
   } while (0)
@@ -288,8 +293,21 @@ __global__ __launch_bounds__(kGT) void linear_gemm_fwd_kernel(
   for (int id = tid; id < BM * CH; id += kGT) {
     const int rl = id / CH, cc = id - rl * CH;
     if (m0 + rl < M && n0 + cc * 8 < N)
-      *reinterpret_cast<Chunk8<E> *>(y + (m0 + rl) * ldy + n0 + cc * 8) =
+      *reinterpret_cast<Chunk8<E> *>(y + (m0 + rl) * ldy + head_chunk((n0 >> 3) + cc, yhc, yhp) * 8) =
           *reinterpret_cast<const Chunk8<E> *>(os + rl * OUT_LD + cc * 8);
+  }
+  if (yhc) {  // head-padded output: this block owns whole heads (host checks CH % yhc == 0): zero their pad chunks
+    const int head0 = (n0 >> 3) / yhc;
+    const int nheads = min(CH / yhc, (N >> 3) / yhc - head0), padc = yhp - yhc;
+    Chunk8<E> z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z.v[i] = E::from_f(0.f);
+    for (int id = tid; id < BM * nheads * padc; id += kGT) {
+      const int rl = id / (nheads * padc), rem = id - rl * (nheads * padc);
+      const int hh = rem / padc, pc = rem - hh * padc;
+      if (m0 + rl < M)
+        *reinterpret_cast<Chunk8<E> *>(y + (m0 + rl) * ldy + ((head0 + hh) * yhp + yhc + pc) * 8) = z;
+    }
   }
 }
 
@@ -306,8 +324,27 @@ extern "C" int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *
                                         void *y, int64_t ldy, const float *down, const float *up, float *t_out,
                                         int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
                                         float t_scale, int32_t factor_layout, int32_t tile, void *stream) {
+  return lora_amd_linear_gemm_fwd_heads(x, ldx, w, ldw, bias, y, ldy, down, up, t_out, M, K, N, r, act_dtype, scale,
+                                        t_scale, factor_layout, tile, 0, 0, 0, 0, stream);
+}
+
+extern "C" int lora_amd_linear_gemm_fwd_heads(const void *x, int64_t ldx, const void *w, int64_t ldw,
+                                              const void *bias, void *y, int64_t ldy, const float *down,
+                                              const float *up, float *t_out, int64_t M, int32_t K, int32_t N,
+                                              int32_t r, int32_t act_dtype, float scale, float t_scale,
+                                              int32_t factor_layout, int32_t tile, int32_t x_head_dim,
+                                              int32_t x_head_pad, int32_t y_head_dim, int32_t y_head_pad,
+                                              void *stream) {
   LORA_AMD_CHECK(lora_amd_linear_gemm_supported(M, K, N, r, act_dtype), LORA_AMD_EINVAL,
                  "linear_gemm_fwd: needs bf16/f16 activations, K %% 64 == 0, N %% 8 == 0, rank <= 16");
+  auto heads_ok = [](int d, int D, int cols, int64_t ld) {
+    return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
+  };
+  LORA_AMD_CHECK(heads_ok(x_head_dim, x_head_pad, K, ldx) && heads_ok(y_head_dim, y_head_pad, N, ldy) &&
+                     (y_head_dim == 0 || 160 % y_head_dim == 0),
+                 LORA_AMD_EINVAL, "linear_gemm_fwd: head layout (d=%d D=%d | d=%d D=%d) not supported for K=%d N=%d",
+                 x_head_dim, x_head_pad, y_head_dim, y_head_pad, K, N);
+  const int xhc = x_head_dim / 8, xhp = x_head_pad / 8, yhc = y_head_dim / 8, yhp = y_head_pad / 8;
   LORA_AMD_CHECK(x && w && y && down && up && t_out, LORA_AMD_EINVAL, "linear_gemm_fwd: null pointer");
   auto al = [](const void *p, int64_t ld) { return ((uintptr_t)p % 16) == 0 && ld % 8 == 0; };
   LORA_AMD_CHECK(al(x, ldx) && al(w, ldw) && al(y, ldy) && ((uintptr_t)down % 16) == 0, LORA_AMD_EINVAL,
@@ -328,7 +365,7 @@ extern "C" int lora_amd_linear_gemm_fwd(const void *x, int64_t ldx, const void *
                      dim3(kGT), 0, st, reinterpret_cast<const typename E::storage *>(x), ldx,                      \
                      reinterpret_cast<const typename E::storage *>(w), ldw,                                        \
                      reinterpret_cast<const typename E::storage *>(bias), reinterpret_cast<typename E::storage *>(y), \
-                     ldy, down, up, t_out, M, K, N, r, scale, t_scale, factor_layout)
+                     ldy, down, up, t_out, M, K, N, r, scale, t_scale, factor_layout, xhc, xhp, yhc, yhp)
 #define GF_R(E, RSV, CSV, NSV) do { if (rg == 1) GF(E, RSV, CSV, NSV, 1); else GF(E, RSV, CSV, NSV, 4); } while (0)
 #define GF_S(E, RSV, CSV) do { if (stages == 3) GF_R(E, RSV, CSV, 3); else GF_R(E, RSV, CSV, 2); } while (0)
 #define GF_T(E)                                                                        \

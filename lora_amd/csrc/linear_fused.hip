@@ -507,6 +507,7 @@ struct FactorJob {
   float *part;           // [nrb][RT][C]
   float mult;
   int C, log_ct8, nct, rows_per_block, nblocks;
+  int hc, hp;            // head-padded rows of `data`: logical chunk c lives at (c / hc) * hp + c % hc; hc == 0: dense
 };
 
 template <class E, int RT>
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
   const float mult = first ? a.mult : b.mult;
   const int C = first ? a.C : b.C, log_ct8 = first ? a.log_ct8 : b.log_ct8, nct = first ? a.nct : b.nct;
   const int rows_per_block = first ? a.rows_per_block : b.rows_per_block;
+  const int hc = first ? a.hc : b.hc, hp = first ? a.hp : b.hp;
 
   const int tid = threadIdx.x;
   const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
@@ -531,7 +533,8 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
   const int ct = (int)(bid - rb * nct);
   const int64_t m0 = rb * rows_per_block;
   const int nrows = (int)min((int64_t)rows_per_block, M - m0);
-  const int col = (ct * ct8 + cl) * 8;
+  const int col = (ct * ct8 + cl) * 8;                                              // logical column (partials)
+  const int pcol = hc ? (((col >> 3) / hc) * hp + ((col >> 3) % hc)) * 8 : col;     // where it lives in `data`
 
   stage_rowvecs<RT>(s_t, rowvec, 1, 0, m0, nrows, r, sel, 1, mult);
   __syncthreads();
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots;
-      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + col, rl < nrows, v[u]);
+      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -784,15 +787,32 @@ extern "C" int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const flo
                                            int64_t ldx, const float *gt, const float *sel, float *down_part,
                                            int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
                                            void *stream) {
+  return lora_amd_linear_bwd_factors_heads(g, ldg, t, up_part, x, ldx, gt, sel, down_part, M, K, N, r, act_dtype,
+                                           scale, 0, 0, 0, 0, stream);
+}
+
+extern "C" int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, const float *t, float *up_part,
+                                                 const void *x, int64_t ldx, const float *gt, const float *sel,
+                                                 float *down_part, int64_t M, int32_t K, int32_t N, int32_t r,
+                                                 int32_t act_dtype, float scale, int32_t g_head_dim,
+                                                 int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad,
+                                                 void *stream) {
   FUSED_COMMON("linear_bwd_factors", act_dtype, LORA_AMD_F32);
+  auto heads_ok = [](int d, int D, int cols, int64_t ld) {
+    return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
+  };
+  LORA_AMD_CHECK(heads_ok(g_head_dim, g_head_pad, N, ldg) && heads_ok(x_head_dim, x_head_pad, K, ldx), LORA_AMD_EINVAL,
+                 "linear_bwd_factors: head layout not supported");
   LORA_AMD_CHECK(g && t && up_part && x && gt && down_part, LORA_AMD_EINVAL, "linear_bwd_factors: null pointer");
   LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4 && aligned_ok(x, ldx, K, act_dtype) &&
                      pow2_divisor(K / 8, 256) >= 4,
                  LORA_AMD_EINVAL, "linear_bwd_factors: shape/alignment not supported (see lora_amd_linear_plan)");
   const int RT = frank_tile(r);
   const BwdGeom qg = bwd_geom(M, N, RT, 64), qx = bwd_geom(M, K, RT, 256);
-  FactorJob a{g, ldg, t, nullptr, up_part, scale, N, qg.log_ct8, qg.nct, qg.rows_per_block, (int)(qg.nrb * qg.nct)};
-  FactorJob b{x, ldx, gt, sel, down_part, 1.0f, K, qx.log_ct8, qx.nct, qx.rows_per_block, (int)(qx.nrb * qx.nct)};
+  FactorJob a{g, ldg, t, nullptr, up_part, scale, N, qg.log_ct8, qg.nct, qg.rows_per_block, (int)(qg.nrb * qg.nct),
+              g_head_dim / 8, g_head_pad / 8};
+  FactorJob b{x, ldx, gt, sel, down_part, 1.0f, K, qx.log_ct8, qx.nct, qx.rows_per_block, (int)(qx.nrb * qx.nct),
+              x_head_dim / 8, x_head_pad / 8};
   const unsigned grid = (unsigned)(a.nblocks + b.nblocks);
   hipStream_t st = (hipStream_t)stream;
 #define BF(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a, b, M, r)

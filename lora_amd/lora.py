@@ -141,7 +141,7 @@ class LoraInjectedLinear(_Adapter):
         low = self.lora_up(self.selector(self.lora_down(input)))
         return self.linear(input) + self.dropout(low) * self.scale
 
-    def _forward_device(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_device(self, x: torch.Tensor, in_heads=None, out_heads=None) -> torch.Tensor:
         w, b = self.linear.weight, self.linear.bias
         dt = _autocast_dtype(x, w)
         xc = x if x.dtype == dt else x.to(dt)
@@ -149,7 +149,17 @@ class LoraInjectedLinear(_Adapter):
         with torch.autocast(device_type=x.device.type, enabled=False):
             return ops.lora_linear(xc, wc, bc, self.lora_down.weight, self.lora_up.weight,
                                    self._selector_matrix(), self.scale, self._dropout_p(),
-                                   self.__dict__.get("_grad_sink"))
+                                   self.__dict__.get("_grad_sink"), in_heads, out_heads)
+
+    def forward_heads(self, input, in_heads=None, out_heads=None):
+        """``forward`` for head-padded activations (not in the reference): ``in_heads`` / ``out_heads`` = (heads, d, D)
+        say that the input arrives / the output leaves with every head's d columns padded to D, the layout the
+        attention kernels want for head sizes 40 / 80.  On the device the fused kernels read and write that layout
+        themselves (no pad / slice copies); everywhere else this is unpack -> forward -> pack."""
+        if input.is_cuda:
+            return self._forward_device(input, in_heads, out_heads)
+        y = self.forward(ops.unpack_heads(input, in_heads) if in_heads else input)
+        return ops.pack_heads(y, out_heads) if out_heads else y
 
     def set_selector_from_diag(self, diag: torch.Tensor):  # ref:63-70
         assert diag.shape == (self.r,)

@@ -270,10 +270,118 @@ class LoraLinearFunction(torch.autograd.Function):
         return dx, dw, db, d_down, d_up, None, None, None, None
 
 
+def pack_heads(y: torch.Tensor, lay) -> torch.Tensor:
+    """[..., heads*d] -> [..., heads*D]: every head's d columns followed by D-d zeros (the layout the attention kernels
+    want for head sizes 40 / 80)."""
+    h, d, D = lay
+    return F.pad(y.unflatten(-1, (h, d)), (0, D - d)).flatten(-2)
+
+
+def unpack_heads(x: torch.Tensor, lay) -> torch.Tensor:
+    """[..., heads*D] -> [..., heads*d] (a copy)."""
+    h, d, D = lay
+    return x.unflatten(-1, (h, D))[..., :d].flatten(-2)
+
+
+class LoraLinearHeadsFunction(torch.autograd.Function):
+    """:class:`LoraLinearFunction` for head-padded activations on the fused MFMA kernels: the X operand and / or the
+    output (and, in the backward, G and / or dX) are read and written in the padded layout by the kernel itself, so the
+    pad / slice copies around the attention core disappear.  Only entered when the forward tile for the shape is known;
+    a backward whose fused tile is not known (yet) detours through dense copies and the regular backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, down, up, scale, sink, in_heads, out_heads, tile):
+        _C.require()
+        N, K = weight.shape
+        x2 = _rows2d(x, _C.heads_width(K, in_heads))
+        y, t = _C.linear_gemm_fwd(x2, weight, bias, down.contiguous(), up.contiguous(), scale, tile,
+                                  x_heads=in_heads, y_heads=out_heads)
+        ctx.save_for_backward(x2, weight, down, up, t)
+        ctx.scale, ctx.has_bias, ctx.x_shape, ctx.sink = float(scale), bias is not None, x.shape, sink
+        ctx.in_heads, ctx.out_heads = in_heads, out_heads
+        return y.view(*x.shape[:-1], y.shape[1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x2, weight, down, up, t = ctx.saved_tensors
+        N, K = weight.shape
+        r, M = down.shape[0], x2.shape[0]
+        g2 = _rows2d(g, _C.heads_width(N, ctx.out_heads))
+        need_x, need_w, need_b, need_down, need_up = ctx.needs_input_grad[:5]
+        s, sink = ctx.scale, ctx.sink
+        plan = _C.linear_plan(M, K, N, r)
+        tile = _C.gemm_choice_bwd_cached(M, K, N, r, g2.dtype)
+        if not (tile and plan.fused and _C._rows_ok(g2) and weight.is_contiguous() and _C.heads_tile_ok(ctx.in_heads)
+                and not need_w):
+            # dense detour: unpacked copies through the regular backward (which also times the fused candidates, so the
+            # next backward of this shape stays in the padded layout)
+            from types import SimpleNamespace
+
+            x_log = unpack_heads(x2, ctx.in_heads) if ctx.in_heads else x2
+            g_log = unpack_heads(g2, ctx.out_heads) if ctx.out_heads else g2
+            fake = SimpleNamespace(saved_tensors=(x_log, weight, down, up, t, None),
+                                   needs_input_grad=tuple(ctx.needs_input_grad[:5]) + (False,) * 4, scale=s, p=0.0,
+                                   seed=0, off=0, sink=sink, fused=_C.fused_ok(x_log, N, r), has_bias=ctx.has_bias,
+                                   x_shape=x_log.shape)
+            dx, dw, db, d_down, d_up = LoraLinearFunction.backward(fake, g_log)[:5]
+            if dx is not None:
+                if ctx.in_heads:
+                    dx = pack_heads(dx, ctx.in_heads)
+                dx = dx.view(*ctx.x_shape[:-1], dx.shape[-1])
+            return dx, dw, db, d_down, d_up, None, None, None, None, None
+        key = (M, K, N, r)
+        if sink is not None:
+            if sink.pending is not None:
+                sink.flush()
+            _, up_part, down_part = sink.workspace(key, plan, g2.device)
+        else:
+            up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
+                                  for n in (plan.up_part_floats, plan.down_part_floats))
+        down_c, up_c = down.contiguous(), up.contiguous()
+        dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile, g_heads=ctx.out_heads,
+                                    dx_heads=ctx.in_heads)
+        _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, None, g_heads=ctx.out_heads,
+                              x_heads=ctx.in_heads)
+        dx = dx2.view(*ctx.x_shape[:-1], dx2.shape[1]) if need_x else None
+        d_up = d_down = None
+        if sink is not None:
+            sink.pending = key
+        else:
+            d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+            d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+            rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                    (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+            table, n, total = _C.make_reduce_table(rows, g2.device)
+            _C.reduce_batched(table, n, total)
+            d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+        db = None
+        if ctx.has_bias and need_b:
+            db = (unpack_heads(g2, ctx.out_heads) if ctx.out_heads else g2).sum(0)
+        return dx, None, db, d_down, d_up, None, None, None, None, None
+
+
 def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
                 up: torch.Tensor, sel: Optional[torch.Tensor], scale: float, dropout_p: float,
-                sink: Optional[GradSink] = None) -> torch.Tensor:
-    return LoraLinearFunction.apply(x, weight, bias, down, up, sel, float(scale), float(dropout_p), sink)
+                sink: Optional[GradSink] = None, in_heads=None, out_heads=None) -> torch.Tensor:
+    """``in_heads`` / ``out_heads`` = (heads, d, D): x arrives / y leaves with every head's d columns padded to D."""
+    if in_heads is None and out_heads is None:
+        return LoraLinearFunction.apply(x, weight, bias, down, up, sel, float(scale), float(dropout_p), sink)
+    N, K = weight.shape
+    r = down.shape[0]
+    M = x.numel() // _C.heads_width(K, in_heads)
+    tile = 0
+    if (x.is_cuda and dropout_p == 0.0 and sel is None and down.dtype == torch.float32 and up.dtype == torch.float32
+            and x.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x.dtype and weight.is_contiguous()
+            and _C.heads_tile_ok(out_heads) and (in_heads is None or in_heads[1] % 8 == 0)):
+        tile = _C.gemm_choice_cached(M, K, N, r, x.dtype, bias is not None) or 0
+    if tile:
+        return LoraLinearHeadsFunction.apply(x, weight, bias, down, up, float(scale), sink, in_heads, out_heads, tile)
+    # dense detour (CPU tensors, shapes the fused kernel does not take, or a shape not timed yet: the regular function
+    # times it, so the next call stays in the padded layout)
+    y = LoraLinearFunction.apply(unpack_heads(x, in_heads) if in_heads else x, weight, bias, down, up, sel,
+                                 float(scale), float(dropout_p), sink)
+    return pack_heads(y, out_heads) if out_heads else y
 
 
 class LoraLinearGroupFunction(torch.autograd.Function):

@@ -31,44 +31,57 @@ def _padded(d: int) -> int:
     return 64 if d <= 64 else 128 if d <= 128 else 256 if d <= 256 else d
 
 
-def _run(q, k, v, backend: Optional[str], pad_to: int):
+def _run(q, k, v, backend: Optional[str], pad_to: int, pad_v: bool = True):
+    """``pad_to`` > d zero-pads the head dimension of q and k (and of v when ``pad_v``; with v left as is the output
+    comes back unpadded — one pad and one slice copy fewer each way — where the kernel accepts Dv != Dk)."""
     d = q.shape[-1]
     scale = d ** -0.5
     if pad_to > d:
-        q, k, v = (F.pad(t, (0, pad_to - d)) for t in (q, k, v))
+        q, k = F.pad(q, (0, pad_to - d)), F.pad(k, (0, pad_to - d))
+        if pad_v:
+            v = F.pad(v, (0, pad_to - d))
     if backend is None or sdpa_kernel is None:
         o = F.scaled_dot_product_attention(q, k, v, scale=scale)
     else:
         with sdpa_kernel(getattr(SDPBackend, backend)):
             o = F.scaled_dot_product_attention(q, k, v, scale=scale)
-    return o[..., :d] if pad_to > d else o
+    return o[..., :d] if (pad_to > d and pad_v) else o
+
+
+def _pad_candidates(d: int):
+    """Head sizes worth timing: as is, and the next multiples of 16 / 32 / 64-128-256 (what the library kernels are
+    specialised for: 40 -> 48, 64; 80 -> 96, 128).  LORA_AMD_SDPA_PADS=0 keeps only the 64/128/256 step."""
+    if os.environ.get("LORA_AMD_SDPA_PADS", "1") == "0":
+        return sorted({d, _padded(d)})
+    return sorted({d, -(-d // 16) * 16, -(-d // 32) * 32, _padded(d)})
 
 
 def _tune(q, k, v) -> Tuple[Optional[str], int]:
     d = q.shape[-1]
     cands = [(None, d), ("EFFICIENT_ATTENTION", d)]
-    if _padded(d) > d:
-        cands += [("EFFICIENT_ATTENTION", _padded(d)), ("FLASH_ATTENTION", _padded(d))]
+    for pad in _pad_candidates(d):
+        if pad > d:
+            cands += [("EFFICIENT_ATTENTION", pad), ("FLASH_ATTENTION", pad), ("EFFICIENT_ATTENTION", pad, False)]
     best, best_t = (None, d), float("inf")
-    for be, pad in cands:
+    for cand in cands:
         try:
             qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
             go = torch.randn_like(q)
-            _run(qq, kk, vv, be, pad).backward(go)  # warm: lazy kernel loading / JIT is not what is compared
+            _run(qq, kk, vv, *cand).backward(go)  # warm: lazy kernel loading / JIT is not what is compared
             t = float("inf")
             for _ in range(3):  # minimum over repeats: one stall must not pick the wrong kernel for the whole run
                 torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(2):
-                    _run(qq, kk, vv, be, pad).backward(go)
+                    _run(qq, kk, vv, *cand).backward(go)
                 b.record()
                 torch.cuda.synchronize()
                 t = min(t, a.elapsed_time(b))
         except Exception:  # noqa: BLE001 - a backend that rejects the shape is simply not a candidate
             continue
         if t < best_t:
-            best, best_t = (be, pad), t
+            best, best_t = tuple(cand), t
     return best
 
 
@@ -89,6 +102,31 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         else:
             choice = (None, q.shape[-1])
     return _run(q, k, v, *choice)
+
+
+FORCE_PAD: Optional[int] = None  # tests: take the padded-layout path with this head size, on any device
+
+
+def padded_choice(B: int, H: int, Sq: int, Sk: int, d: int, dtype, grad: bool):
+    """(backend, D) if the kernel chosen for this shape runs on q, k, v all zero-padded to head size D > d, else None.
+    Only a choice that has already been made counts (the first call of a shape goes through :func:`sdpa`, which times
+    the candidates); callers that can produce / consume the padded layout directly then skip the pad and slice copies."""
+    if FORCE_PAD is not None:
+        return (None, FORCE_PAD) if FORCE_PAD > d else None
+    c = _CHOICE.get(repr((B, H, Sq, Sk, d, str(dtype), grad)))
+    if c is None or c[1] <= d or (len(c) > 2 and not c[2]):
+        return None
+    return c[0], c[1]
+
+
+def sdpa_padded(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, d: int, backend: Optional[str]) -> torch.Tensor:
+    """The attention core on tensors that already carry the padded head size (pad columns zero); ``d`` is the true
+    head size (softmax scale)."""
+    scale = d ** -0.5
+    if backend is None or sdpa_kernel is None or not q.is_cuda:
+        return F.scaled_dot_product_attention(q, k, v, scale=scale)
+    with sdpa_kernel(getattr(SDPBackend, backend)):
+        return F.scaled_dot_product_attention(q, k, v, scale=scale)
 
 
 def choices():

@@ -19,8 +19,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import attention
 from .attention import sdpa
-from .fused import geglu, group_norm_act, layer_norm
+from .fused import add_layer_norm, geglu, group_norm_act, layer_norm
 from torch.utils.checkpoint import checkpoint
 
 
@@ -83,7 +84,7 @@ class CrossAttention(nn.Module):
         super().__init__()
         inner = heads * dim_head
         ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
-        self.heads = heads
+        self.heads, self.dim_head = heads, dim_head
         self.to_q = nn.Linear(query_dim, inner, bias=False)
         self.to_k = nn.Linear(ctx, inner, bias=False)
         self.to_v = nn.Linear(ctx, inner, bias=False)
@@ -93,6 +94,22 @@ class CrossAttention(nn.Module):
         ctx = x if context is None else context
         B, T, _ = x.shape
         h = self.heads
+        d = self.dim_head
+        grad = torch.is_grad_enabled() and (x.requires_grad or ctx.requires_grad or _trains(self))
+        # opt-in (LORA_AMD_HEAD_PAD=1; round-1 design, LDS-ring kernel): the projections write / read the padded head
+        # layout of the chosen attention kernel.  Default: q/k/v as one weight-stationary launch (project_qkv)
+        pad = attention.padded_choice(B, h, T, ctx.shape[1], d, x.dtype, grad) \
+            if (os.environ.get("LORA_AMD_HEAD_PAD", "0") == "1" or attention.FORCE_PAD is not None) else None
+        if pad is not None:
+            # the chosen attention kernel wants head size D > d: the projections write / read that layout themselves
+            # (fused GEMM epilogue and operand remap, ops.lora_linear) instead of pad + slice copies around the core
+            backend, D = pad
+            lay = (h, d, D)
+            q = _project(self.to_q, x, None, lay).view(B, T, h, D).transpose(1, 2)
+            k = _project(self.to_k, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+            v = _project(self.to_v, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+            o = attention.sdpa_padded(q, k, v, d, backend).transpose(1, 2).reshape(B, T, h * D)
+            return self.to_out[1](_project(self.to_out[0], o, lay, None))
         q, k, v = project_qkv(self, x, context)
         q = q.view(B, T, h, -1).transpose(1, 2)
         k = k.view(B, ctx.shape[1], h, -1).transpose(1, 2)
@@ -100,6 +117,21 @@ class CrossAttention(nn.Module):
         o = sdpa(q, k, v)  # dense contraction: library MFMA flash kernels, fastest variant per shape (attention.py)
         o = o.transpose(1, 2).reshape(B, T, -1)
         return self.to_out[1](self.to_out[0](o))
+
+
+def _trains(module: nn.Module) -> bool:
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _project(lin: nn.Module, x: torch.Tensor, in_heads, out_heads) -> torch.Tensor:
+    """A q / k / v / out projection on head-padded activations: adapters handle the layout themselves
+    (``forward_heads``), a plain Linear gets dense copies around it."""
+    if hasattr(lin, "forward_heads"):
+        return lin.forward_heads(x, in_heads, out_heads)
+    from ..ops import pack_heads, unpack_heads
+
+    y = lin(unpack_heads(x, in_heads) if in_heads else x)
+    return pack_heads(y, out_heads) if out_heads else y
 
 
 class GEGLU(nn.Module):
@@ -134,9 +166,10 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
 
     def forward(self, x, context):
-        x = self.attn1(layer_norm(x, self.norm1)) + x
-        x = self.attn2(layer_norm(x, self.norm2), context) + x
-        return self.ff(layer_norm(x, self.norm3)) + x
+        # each residual add runs inside the LayerNorm pass that follows it (fused.add_layer_norm)
+        x, n = add_layer_norm(self.attn1(layer_norm(x, self.norm1)), x, self.norm2)
+        x, n = add_layer_norm(self.attn2(n, context), x, self.norm3)
+        return self.ff(n) + x
 
 
 class Transformer2DModel(nn.Module):
@@ -152,22 +185,23 @@ class Transformer2DModel(nn.Module):
         B, C, H, W = x.shape
         n = group_norm_act(x, self.norm, act=False)
         nhwc = n.is_contiguous(memory_format=torch.channels_last) and not n.is_contiguous()
-        # A 1x1 convolution IS the token-major linear map.  On NCHW activations run it there: one library GEMM with
-        # the bias in its epilogue instead of a MIOpen call wrapped in NCHW<->NHWC transposes plus a strided bias add
-        # (proj_in / proj_out are not adapter sites of the reference's target classes; if they have been replaced,
-        # or the activations are channels_last, keep the convolution).
-        as_linear = (not nhwc and type(self.proj_in) is nn.Conv2d and type(self.proj_out) is nn.Conv2d
+        # A 1x1 convolution IS the token-major linear map: one library GEMM with the bias in its epilogue instead of a
+        # MIOpen call (on NCHW activations wrapped in NCHW<->NHWC transposes) plus a strided bias add.  On channels_last
+        # activations the token view is free in both directions (proj_in / proj_out are not adapter sites of the
+        # reference's target classes; if they have been replaced, keep the module call).
+        as_linear = (type(self.proj_in) is nn.Conv2d and type(self.proj_out) is nn.Conv2d
                      and self.proj_in.kernel_size == (1, 1) and self.proj_out.kernel_size == (1, 1))
         if as_linear:
-            h = n.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = n.permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when the activations are NHWC, else one copy
             h = F.linear(h, self.proj_in.weight.view(C, C), self.proj_in.bias)
         else:
-            h = self.proj_in(n).permute(0, 2, 3, 1).reshape(B, H * W, C)  # a view when activations are NHWC
+            h = self.proj_in(n).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         if as_linear:
             h = F.linear(h, self.proj_out.weight.view(C, C), self.proj_out.bias)
-            return h.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous() + x
+            h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)  # channels_last strides
+            return (h if nhwc else h.contiguous()) + x
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         if not nhwc:
             h = h.contiguous()
@@ -188,9 +222,17 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
-        h = self.conv1(group_norm_act(x, self.norm1))  # GroupNorm + SiLU: two launches each way (fused.py)
-        h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(group_norm_act(h, self.norm2)))
+        n1 = group_norm_act(x, self.norm1)  # GroupNorm + SiLU as HIP passes (fused.py)
+        t = self.time_emb_proj(self.nonlinearity(temb))  # [B, C_out]
+        if type(self.conv1) is nn.Conv2d and self.conv1.bias is not None:
+            # the convolution's bias and the time embedding are both per-(sample, channel) terms in front of norm2:
+            # one small [B, C] add instead of two passes over the activation (none at all on channels_last)
+            c1 = self.conv1
+            h = F.conv2d(n1, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups)
+            t = t + c1.bias
+        else:
+            h = self.conv1(n1)
+        h = self.conv2(self.dropout(group_norm_act(h, self.norm2, addend=t)))
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 

@@ -53,6 +53,68 @@ def test_groupnorm_act_forward_backward(B, C, H, W, G, dt, act):
     _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
 
 
+NHWC_SHAPES = [(4, 320, 64, 64, 32), (2, 640, 32, 32, 32), (2, 1280, 8, 8, 32), (1, 960, 16, 16, 32), (3, 64, 4, 6, 8),
+               (2, 32, 8, 8, 32), (1, 1920, 24, 24, 32), (2, 96, 3, 5, 3), (2, 2560, 8, 8, 32), (1, 88, 5, 7, 11)]
+
+
+@pytest.mark.parametrize("B,C,H,W,G", NHWC_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_act_channels_last_forward_backward(B, C, H, W, G, dt, act):
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + torch.randn(1, C, 1, 1, generator=g) * 3.0).to(dt).to(DEV)
+    x = x.contiguous(memory_format=torch.channels_last)
+    norm = nn.GroupNorm(G, C, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(B, C, H, W, generator=g).to(dt).to(DEV)  # NCHW-contiguous on purpose: converted inside
+    assert fused._gn_native_nhwc(x, norm) and not fused._gn_native(x, norm)
+
+    xg = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    y = fused.group_norm_act(xg, norm, act)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gout)
+    assert xg.grad.shape == x.shape
+
+    xr = x.float().contiguous().requires_grad_(True)
+    yr = F.group_norm(xr, G, norm.weight.float(), norm.bias.float(), norm.eps)
+    if act:
+        yr = F.silu(yr)
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(4, 320, 32, 32, 32), (2, 1280, 8, 8, 32), (3, 64, 4, 6, 8)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+def test_groupnorm_addend_is_x_plus_broadcast(B, C, H, W, G, dt, layout):
+    """group_norm_act(x, addend=t) == group_norm_act(x + t[:, :, None, None]) incl. gradients w.r.t. x and t (the
+    channels_last kernels fold t into the statistics / affine; NCHW adds it first)."""
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5).to(dt).to(DEV)
+    t = (torch.randn(B, C, generator=g) * 2.0).to(dt).to(DEV)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    norm = nn.GroupNorm(G, C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gout = torch.randn(B, C, H, W, generator=g).to(dt).to(DEV)
+    xg, tg = x.clone(memory_format=torch.preserve_format).requires_grad_(True), t.clone().requires_grad_(True)
+    y = fused.group_norm_act(xg, norm, True, addend=tg)
+    y.backward(gout)
+    xr, tr = x.float().contiguous().requires_grad_(True), t.float().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr + tr[:, :, None, None], G, norm.weight.float(), norm.bias.float(), norm.eps))
+    yr.backward(gout.float())
+    _close(y, yr, dt, msg="forward")
+    _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="dx")
+    _close(tg.grad, tr.grad, dt, scale=float(tr.grad.abs().max()) + 1e-6, msg="d addend")
+
+
 def test_groupnorm_statistics_and_fallbacks():
     x = torch.randn(2, 64, 8, 8, device=DEV) * 2 + 5
     norm = nn.GroupNorm(8, 64).to(DEV).requires_grad_(False)
@@ -115,6 +177,33 @@ def test_layernorm_forward_backward(shape, dt):
     yr.backward(gout.float())
     _close(y, yr, dt, msg="forward")
     _close(xg.grad, xr.grad, dt, scale=float(xr.grad.abs().max()) + 1e-6, msg="input gradient")
+
+
+@pytest.mark.parametrize("shape", [(4, 4096, 320), (2, 256, 1280), (3, 77, 768), (1, 5, 8)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_add_layernorm_equals_add_then_layernorm(shape, dt):
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    a = (torch.randn(*shape, generator=g) * 1.5).to(dt).to(DEV)
+    b = (torch.randn(*shape, generator=g) * 1.5 + torch.randn(shape[-1], generator=g)).to(dt).to(DEV)
+    norm = nn.LayerNorm(shape[-1]).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(shape[-1], generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(shape[-1], generator=g) * 0.3)
+    norm = norm.to(dt).requires_grad_(False)
+    gs, gy = torch.randn(*shape, generator=g).to(dt).to(DEV), torch.randn(*shape, generator=g).to(dt).to(DEV)
+    ag, bg = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    s, y = fused.add_layer_norm(ag, bg, norm)
+    assert type(y.grad_fn).__name__ == "_AddLayerNormBackward"
+    torch.autograd.backward([s, y], [gs, gy])
+    assert torch.equal(s, a + b), "the sum must be exactly what the separate add produces"
+    ar, br = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    sr = (ar + br).to(dt).float() if dt != torch.float32 else ar + br  # the norm sees the rounded sum
+    sr_ = (ar + br)
+    yr = F.layer_norm(sr_ + (sr - sr_).detach(), (shape[-1],), norm.weight.float(), norm.bias.float(), norm.eps)
+    torch.autograd.backward([sr_, yr], [gs.float(), gy.float()])
+    _close(y, yr, dt, msg="norm output")
+    _close(ag.grad, ar.grad, dt, scale=float(ar.grad.abs().max()) + 1e-6, msg="gradient of a")
+    assert torch.equal(ag.grad, bg.grad)
 
 
 def test_layernorm_fallbacks():

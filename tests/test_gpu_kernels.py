@@ -773,6 +773,79 @@ def test_fused_gemm_input_gradient(M, K, N, r, tile):
         assert torch.equal(up_part2, up_part) and torch.equal(down_part2, down_part)
 
 
+@pytest.mark.parametrize("M,K,N,r,d,D", [(4096, 320, 320, 4, 40, 64), (1000, 640, 640, 8, 80, 128), (300, 320, 320, 4, 40, 48),
+                                         (260, 1280, 1280, 16, 160, 192), (77, 320, 640, 3, 40, 64)])
+@pytest.mark.parametrize("tile", [22, 24, 21, 33])
+def test_fused_gemm_head_padded_layouts(M, K, N, r, d, D, tile):
+    """Head-padded operands of the fused kernel: the padded output is exactly pack(dense output) with a zero pad, a
+    padded input gives exactly the dense result whatever sits in its pad columns (NaN here), in both directions."""
+    dt, s = "bf16", 0.7
+    x, w, b = rnd((M, K), dt, 1.0, seed=1), rnd((N, K), dt, 0.05, seed=2), rnd((N,), dt, 0.5, seed=3)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
+    lay_n, lay_k = (N // d, d, D), (K // d, d, D)
+
+    def nan_pad(t, lay):
+        p = ops.pack_heads(t, lay)
+        p.view(t.shape[0], lay[0], lay[2])[..., lay[1]:] = float("nan")
+        return p
+
+    y, t = _C.linear_gemm_fwd(x, w, b, down, up, s, tile)
+    yp, tp = _C.linear_gemm_fwd(x, w, b, down, up, s, tile, y_heads=lay_n)
+    assert torch.equal(yp, ops.pack_heads(y, lay_n)) and torch.equal(tp, t)
+    y2, t2 = _C.linear_gemm_fwd(nan_pad(x, lay_k), w, b, down, up, s, tile, x_heads=lay_k)
+    assert torch.equal(y2, y) and torch.equal(t2, t)
+    y3, _ = _C.linear_gemm_fwd(nan_pad(x, lay_k), w, b, down, up, s, tile, x_heads=lay_k, y_heads=lay_n)
+    assert torch.equal(y3, ops.pack_heads(y, lay_n))
+    # input-gradient direction: G padded in, dX padded out
+    g = rnd((M, N), dt, 1.0, seed=6)
+    wt = _C.weight_t(w)
+    dx, gt = _C.linear_gemm_dx(g, wt, down, up, s, tile)
+    dxp, gtp = _C.linear_gemm_dx(nan_pad(g, lay_n), wt, down, up, s, tile, g_heads=lay_n, dx_heads=lay_k)
+    assert torch.equal(dxp, ops.pack_heads(dx, lay_k)) and torch.equal(gtp, gt)
+    # both factor-gradient partials from padded G and X
+    plan = _C.linear_plan(M, K, N, r)
+    if plan.fused:
+        up_part, down_part = torch.zeros(plan.up_part_floats, device=DEV), torch.zeros(plan.down_part_floats, device=DEV)
+        up_part2, down_part2 = torch.zeros_like(up_part), torch.zeros_like(down_part)
+        _C.linear_bwd_factors(g, t, up_part, x, gt, down_part, r, s)
+        _C.linear_bwd_factors(nan_pad(g, lay_n), t, up_part2, nan_pad(x, lay_k), gt, down_part2, r, s, None,
+                              g_heads=lay_n, x_heads=lay_k)
+        assert torch.equal(up_part2, up_part) and torch.equal(down_part2, down_part)
+
+
+def test_attention_block_in_padded_head_layout_equals_regular_path(monkeypatch):
+    """CrossAttention with adapters: q/k/v written and the attention output read in the padded head layout by the fused
+    kernels (forward and backward) vs the regular pad-and-slice path."""
+    import torch.nn as nn
+
+    from lora_amd.standin import attention
+    from lora_amd.standin.unet import CrossAttention
+
+    torch.manual_seed(0)
+    att = CrossAttention(320, None, heads=8, dim_head=40).to(DEV).to(torch.bfloat16).requires_grad_(False)
+    L.inject_trainable_lora(att, target_replace_module={"CrossAttention"}, r=4)
+    for m in att.modules():
+        if type(m).__name__ == "LoraInjectedLinear":
+            nn.init.normal_(m.lora_up.weight, std=0.05)
+            m.lora_up.weight.data = m.lora_up.weight.data.float()
+            m.lora_down.weight.data = m.lora_down.weight.data.float()
+    x = (torch.randn(2, 1024, 320, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    params = [p for p in att.parameters() if p.requires_grad]
+
+    def run():
+        y = att(x)
+        return y, torch.autograd.grad(y.float().square().mean(), [x] + params)
+
+    monkeypatch.setenv("LORA_AMD_GEMM", "22")      # fused tiles both ways (what the tuner picks for these sites)
+    monkeypatch.setenv("LORA_AMD_GEMM_BWD", "22")
+    y0, g0 = run()
+    monkeypatch.setattr(attention, "FORCE_PAD", 64)
+    y1, g1 = run()
+    torch.testing.assert_close(y1.float(), y0.float(), rtol=2e-2, atol=2e-2 * float(y0.float().abs().max()))
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a.float(), b.float(), rtol=5e-2, atol=3e-2 * float(b.float().abs().max()) + 1e-8)
+
+
 def test_fused_gemm_random_shapes_against_device_torch():
     """40 seeded random (M, K, N, r, dtype, tile) draws incl. ragged M / N tails: fused kernel vs torch on the device."""
     rng = np.random.default_rng(0)

@@ -111,14 +111,28 @@ def test_transformer2d_token_major_projection_equals_the_1x1_convolutions():
     ctx = torch.randn(2, 5, 16)
     y1 = m(x, ctx)
     (g1,) = torch.autograd.grad(y1.square().sum(), x)
-    y0 = m(x.contiguous(memory_format=torch.channels_last), ctx)
+    yc = m(x.contiguous(memory_format=torch.channels_last), ctx)  # token view is free on NHWC activations
+    assert yc.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1, yc.contiguous(), rtol=1e-5, atol=1e-5)
+
+    class Conv1x1(nn.Conv2d):  # any subclass keeps the module call (what an injected adapter looks like)
+        pass
+
+    for name in ("proj_in", "proj_out"):
+        old = getattr(m, name)
+        new = Conv1x1(32, 32, 1)
+        new.load_state_dict(old.state_dict())
+        setattr(m, name, new)
+    y0 = m(x, ctx)
     (g0,) = torch.autograd.grad(y0.square().sum(), x)
-    torch.testing.assert_close(y1, y0.contiguous(), rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(g1, g0.contiguous(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     # an adapter injected into the projection (custom target class) keeps the module call
-    L.inject_trainable_lora_extended(m, target_replace_module={"Transformer2DModel"}, r=2)
-    assert type(m.proj_in).__name__ == "LoraInjectedConv2d"
-    y2 = m(x, ctx)  # lora_up is zero-initialised: same output through the module path
+    torch.manual_seed(0)
+    m2 = Transformer2DModel(32, 2, 16, groups=8)
+    L.inject_trainable_lora_extended(m2, target_replace_module={"Transformer2DModel"}, r=2)
+    assert type(m2.proj_in).__name__ == "LoraInjectedConv2d"
+    y2 = m2(x, ctx)  # same seed, lora_up zero-initialised: same output through the module path
     torch.testing.assert_close(y2, y1, rtol=1e-5, atol=1e-5)
     del F
 
@@ -137,3 +151,81 @@ def test_fused_host_passes_fall_back_to_aten_on_cpu():
     y = torch.randn(3, 5, 32)
     h, g = y.chunk(2, dim=-1)
     torch.testing.assert_close(fused.geglu(y), h * F.gelu(g))
+
+
+def test_resnet_block_folds_conv_bias_and_time_embedding_into_one_addend():
+    import torch.nn.functional as F
+    from lora_amd.standin.unet import ResnetBlock2D
+
+    torch.manual_seed(0)
+    blk = ResnetBlock2D(16, 32, temb_channels=24, groups=4)
+    x, temb = torch.randn(2, 16, 6, 6, requires_grad=True), torch.randn(2, 24)
+    y = blk(x, temb)
+    h = blk.conv1(F.silu(blk.norm1(x)))  # the reference order of operations (diffusers ResnetBlock2D)
+    h = h + blk.time_emb_proj(F.silu(temb))[:, :, None, None]
+    h = blk.conv2(F.silu(blk.norm2(h)))
+    want = blk.conv_shortcut(x) + h
+    torch.testing.assert_close(y, want, rtol=1e-5, atol=1e-5)
+    (g1,) = torch.autograd.grad(y.square().sum(), x, retain_graph=True)
+    (g0,) = torch.autograd.grad(want.square().sum(), x)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
+    # channels_last input: same numbers (ATen fallbacks on CPU)
+    yc = blk(x.contiguous(memory_format=torch.channels_last), temb)
+    torch.testing.assert_close(yc.contiguous(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_attention_padded_head_layout_plumbing_equals_regular_path():
+    """The padded-head-layout route through CrossAttention (projections via ``forward_heads``, core on padded tensors)
+    gives the regular route's output and gradients; on CPU the layout conversions are dense copies."""
+    from lora_amd import ops
+    from lora_amd.standin import attention
+    from lora_amd.standin.unet import CrossAttention
+
+    torch.manual_seed(0)
+    y = torch.randn(2, 5, 8 * 40)
+    p = ops.pack_heads(y, (8, 40, 64))
+    assert p.shape == (2, 5, 512) and torch.equal(ops.unpack_heads(p, (8, 40, 64)), y)
+    assert float(p.view(2, 5, 8, 64)[..., 40:].abs().max()) == 0
+    for ctx_dim, inject in ((None, True), (48, True), (None, False)):
+        att = CrossAttention(64, ctx_dim, heads=4, dim_head=24)
+        if inject:
+            L.inject_trainable_lora(att, target_replace_module={"CrossAttention"}, r=4)
+            for m in att.modules():
+                if type(m).__name__ == "LoraInjectedLinear":
+                    nn.init.normal_(m.lora_up.weight, std=0.1)
+        x = torch.randn(2, 9, 64, requires_grad=True)
+        c = None if ctx_dim is None else torch.randn(2, 7, 48)
+        leaves = [x] + [q for q in att.parameters() if q.requires_grad]
+        try:
+            attention.FORCE_PAD = None
+            y0 = att(x, c)
+            g0 = torch.autograd.grad(y0.square().sum(), leaves)
+            attention.FORCE_PAD = 32
+            y1 = att(x, c)
+            g1 = torch.autograd.grad(y1.square().sum(), leaves)
+        finally:
+            attention.FORCE_PAD = None
+        torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
+        for a, b in zip(g1, g0):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_unet_channels_last_equals_nchw():
+    """The whole stand-in UNet on channels_last activations (token views instead of copies in Transformer2DModel,
+    GroupNorm addend, add+LayerNorm) computes what it computes on NCHW; on CPU every fused pass is its ATen fallback."""
+    torch.manual_seed(0)
+    unet = tiny_unet()
+    L.inject_trainable_lora(unet, r=2)
+    for m in unet.modules():
+        if type(m).__name__ == "LoraInjectedLinear":
+            nn.init.normal_(m.lora_up.weight, std=0.05)
+    lat, t, ctx = torch.randn(2, 4, 16, 16), torch.tensor([3, 700]), torch.randn(2, 7, 32)
+    leaves = [p for p in unet.parameters() if p.requires_grad]
+    y0 = unet(lat, t, ctx).sample
+    g0 = torch.autograd.grad(y0.square().mean(), leaves)
+    unet.to(memory_format=torch.channels_last)
+    y1 = unet(lat.contiguous(memory_format=torch.channels_last), t, ctx).sample
+    g1 = torch.autograd.grad(y1.square().mean(), leaves)
+    torch.testing.assert_close(y1.contiguous(), y0, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-6)
