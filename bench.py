@@ -370,7 +370,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (train_batch_size, ref :285-289)")
     ap.add_argument("--rank", type=int, default=4, dest="lora_rank")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
-    ap.add_argument("--channels-last", type=int, default=0, help="NHWC activations/conv weights (MIOpen igemm layout)")
+    ap.add_argument("--channels-last", type=int, default=-1, help="NHWC activations/conv weights (the layout MIOpen's "
+                    "implicit-GEMM convolutions run in; GroupNorm(+SiLU) has an NHWC HIP pass).  -1 = on, except with "
+                    "--extended (the Conv2d adapter kernels are NCHW)")
+    ap.add_argument("--head-pad", type=int, default=1, help="q/k/v/out projections write / read the padded head layout "
+                    "of the chosen attention kernel (LORA_AMD_HEAD_PAD; no pad / slice copies around the attention core)")
     ap.add_argument("--extended", type=int, default=0, help="inject_trainable_lora_extended: + ResnetBlock2D Conv2d "
                     "adapters (BASELINE configs[3] geometry; not the headline workload)")
     ap.add_argument("--text-encoder", type=int, default=0, help="also train CLIP text-encoder LoRA (configs[2] geometry)")
@@ -399,6 +403,9 @@ def main():
         return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.channels_last < 0:
+        args.channels_last = 0 if args.extended else 1
+    os.environ.setdefault("LORA_AMD_HEAD_PAD", str(int(bool(args.head_pad))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # one process per GPU; rank 0 of the child job prints the JSON line
     torch.backends.cudnn.benchmark = bool(args.conv_find)
@@ -531,6 +538,10 @@ def main():
                        "synthetic inputs SURVEY 8d prescribes (cached_latents-style)",
                        "allreduce_us": allreduce_us,
                        "kernel_choices": {"fused_gemm_fwd": dict(_C._gemm_choice), "fused_gemm_bwd": dict(_C._gemm_choice_bwd)},
+                       "host_model_options": {"channels_last": bool(args.channels_last),
+                                              "head_padded_projections": os.environ.get("LORA_AMD_HEAD_PAD") == "1",
+                                              "fused_hostops": os.environ.get("LORA_AMD_HOSTOPS", "1") != "0",
+                                              "grouped_qkv": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0"},
                        "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
                        "(859,520,964 params, random init)", "trainable_params": state.n,
                        "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},

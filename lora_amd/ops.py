@@ -650,6 +650,8 @@ def lora_conv_branch(x, y0, down_w, up_w, sel, stride, padding, dilation, groups
 
     The k x k down-projection to r channels runs as a library conv; the 1x1 up-projection,
     dropout, scale and the add are one fused HIP kernel per sample."""
+    if not y0.is_contiguous():  # channels_last host model: this (rare, non-native geometry) branch works in NCHW
+        y0 = y0.contiguous()
     t = F.conv2d(x, down_w if down_w.dtype == x.dtype else down_w.to(x.dtype), None, stride, padding, dilation,
                  groups)
     if sel is not None:
