@@ -379,8 +379,9 @@ def main():
                     "adapters (BASELINE configs[3] geometry; not the headline workload)")
     ap.add_argument("--text-encoder", type=int, default=0, help="also train CLIP text-encoder LoRA (configs[2] geometry)")
     ap.add_argument("--res", type=int, default=512, help="image resolution (latents are res/8)")
-    ap.add_argument("--conv-find", type=int, default=0, help="torch.backends.cudnn.benchmark: MIOpen Find picks the "
-                    "frozen convs' kernels by timing them once (slow first step)")
+    ap.add_argument("--conv-find", type=int, default=1, help="torch.backends.cudnn.benchmark: MIOpen Find picks the "
+                    "frozen convs' kernels by timing them once, in the warm-up steps before the hipGraph capture "
+                    "(+5 %% steps/s measured; 0 = MIOpen's immediate-mode heuristic)")
     ap.add_argument("--with-prior-preservation", type=int, default=0, help="instance + class-prior batch (2 x --batch "
                     "samples per step, ref :698-702, 855-875); not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -541,7 +542,8 @@ def main():
                        "host_model_options": {"channels_last": bool(args.channels_last),
                                               "head_padded_projections": os.environ.get("LORA_AMD_HEAD_PAD") == "1",
                                               "fused_hostops": os.environ.get("LORA_AMD_HOSTOPS", "1") != "0",
-                                              "grouped_qkv": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0"},
+                                              "grouped_qkv": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
+                                              "miopen_find": bool(args.conv_find)},
                        "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
                        "(859,520,964 params, random init)", "trainable_params": state.n,
                        "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},

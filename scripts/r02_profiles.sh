@@ -3,6 +3,7 @@
 # geometries, kernel trace of the headline step, PMC traffic of the adapter kernels.  Outputs under gpurun_out/.
 set -u
 export TMPDIR=/tmp
+export LORA_AMD_TUNE_CACHE=/tmp/lora_amd_tune_r02.json   # the first run times the attention candidates, every later run (incl. the traced one) re-uses its choices
 OUT=gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/r02_bench_line.json 2> $OUT/r02_bench_line.err
