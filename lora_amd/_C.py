@@ -36,6 +36,8 @@ SYMBOLS = (
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
+    "lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd", "lora_amd_conv3_nhwc_bwd_dx",
+    "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance", "lora_amd_loss_scale_update", "lora_amd_ti_rows_step",
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
@@ -77,6 +79,12 @@ class ConvPlan(C.Structure):
     _fields_ = [("native", C.c_int32), ("cpw_in", C.c_int32), ("ngroups_in", C.c_int32), ("ngroups_out", C.c_int32),
                 ("split_in", C.c_int32), ("split_out", C.c_int32), ("rank_pad", C.c_int32), ("reserved", C.c_int32),
                 ("t_part_floats", C.c_int64), ("gt_part_floats", C.c_int64), ("up_part_floats", C.c_int64),
+                ("down_part_floats", C.c_int64)]
+
+
+class Conv3NhwcPlan(C.Structure):
+    _fields_ = [("native", C.c_int32), ("pt", C.c_int32), ("ks", C.c_int32), ("nsplit", C.c_int32),
+                ("rank_pad", C.c_int32), ("reserved", C.c_int32), ("pf_elems", C.c_int64), ("pd_elems", C.c_int64),
                 ("down_part_floats", C.c_int64)]
 
 
@@ -162,6 +170,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_conv_bwd_g.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
                                         u64, vp, vp]
     lib.lora_amd_conv_bwd_x.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_conv3_nhwc_plan.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Conv3NhwcPlan)]
+    lib.lora_amd_conv3_nhwc_pack.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.lora_amd_conv3_nhwc_down_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_conv3_nhwc_bwd_dx.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_conv3_nhwc_bwd_down.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_sum_parts.argtypes = [vp, i32, i64, vp, i64, vp]
+    for name in ("lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd",
+                 "lora_amd_conv3_nhwc_bwd_dx", "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts"):
+        getattr(lib, name).restype = C.c_int
     lib.lora_amd_groupnorm_workspace.argtypes = [i32, i32, i32, i32]
     lib.lora_amd_groupnorm_workspace.restype = sz
     lib.lora_amd_groupnorm_supported.argtypes = [i32, i32, i32, i32]
@@ -650,6 +667,71 @@ def conv_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt: torch.Tensor, do
     _check(require().lora_amd_conv_bwd_x(x.data_ptr(), _ptr(dx), gt.data_ptr(), down.data_ptr(),
                                          down_part.data_ptr(), B, Ci, H, W, ks, down.shape[0], dtype_code(x.dtype),
                                          dtype_code(down.dtype), _stream()), "lora_amd_conv_bwd_x")
+
+
+# ----------------------------------------------------------------------------- K4, channels-last 3x3 (csrc/conv_nhwc.hip)
+_conv3_nhwc_plan_cache = {}
+
+
+def conv3_nhwc_plan(B: int, C_in: int, H: int, W: int, r: int) -> Conv3NhwcPlan:
+    key = (B, C_in, H, W, r)
+    pl = _conv3_nhwc_plan_cache.get(key)
+    if pl is None:
+        pl = Conv3NhwcPlan()
+        _check(require().lora_amd_conv3_nhwc_plan(B, C_in, H, W, r, C.byref(pl)), "lora_amd_conv3_nhwc_plan")
+        _conv3_nhwc_plan_cache[key] = pl
+    return pl
+
+
+def _nhwc_dims(x: torch.Tensor):
+    """(B, C, H, W) of a logically-NCHW tensor whose memory is [B, H, W, C] contiguous."""
+    B, Ci, H, W = x.shape
+    if x.stride() != (H * W * Ci, 1, W * Ci, Ci) and not (x.numel() == 0):
+        raise ValueError("lora_amd: expected a channels_last-contiguous [B, C, H, W] tensor")
+    return B, Ci, H, W
+
+
+def conv3_nhwc_pack(down: torch.Tensor, act_dtype: torch.dtype, plan: Conv3NhwcPlan) -> Tuple[torch.Tensor, torch.Tensor]:
+    """down [r, C_in, 3, 3] f32 -> (pf, pd): MFMA fragment order, activation dtype (forward / input-gradient operand)."""
+    r, Ci = down.shape[0], down.shape[1]
+    pf = torch.empty(int(plan.pf_elems), dtype=act_dtype, device=down.device)
+    pd = torch.empty(int(plan.pd_elems), dtype=act_dtype, device=down.device)
+    _check(require().lora_amd_conv3_nhwc_pack(down.data_ptr(), r, Ci, dtype_code(act_dtype), pf.data_ptr(),
+                                              pd.data_ptr(), _stream()), "lora_amd_conv3_nhwc_pack")
+    return pf, pd
+
+
+def conv3_nhwc_down_fwd(x: torch.Tensor, pf: torch.Tensor, r: int) -> torch.Tensor:
+    """T [B*H*W, r] f32 = conv3x3(x; down) for a channels_last x."""
+    B, Ci, H, W = _nhwc_dims(x)
+    t = torch.empty((B * H * W, r), dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_conv3_nhwc_down_fwd(x.data_ptr(), pf.data_ptr(), t.data_ptr(), B, Ci, H, W, r,
+                                                  dtype_code(x.dtype), _stream()), "lora_amd_conv3_nhwc_down_fwd")
+    return t
+
+
+def conv3_nhwc_bwd_dx_(dx: torch.Tensor, gt: torch.Tensor, pd: torch.Tensor) -> torch.Tensor:
+    """dx (channels_last, in place) += conv_transpose3x3(gt; down)."""
+    B, Ci, H, W = _nhwc_dims(dx)
+    _check(require().lora_amd_conv3_nhwc_bwd_dx(dx.data_ptr(), gt.data_ptr(), pd.data_ptr(), B, Ci, H, W, gt.shape[1],
+                                                dtype_code(dx.dtype), _stream()), "lora_amd_conv3_nhwc_bwd_dx")
+    return dx
+
+
+def conv3_nhwc_bwd_down(x: torch.Tensor, gt: torch.Tensor, down_part: torch.Tensor) -> None:
+    B, Ci, H, W = _nhwc_dims(x)
+    _check(require().lora_amd_conv3_nhwc_bwd_down(x.data_ptr(), gt.data_ptr(), down_part.data_ptr(), B, Ci, H, W,
+                                                  gt.shape[1], dtype_code(x.dtype), _stream()),
+           "lora_amd_conv3_nhwc_bwd_down")
+
+
+def sum_parts(part: torch.Tensor, nparts: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n] = sum of the `nparts` consecutive length-n slices of `part` (f32)."""
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=part.device)
+    _check(require().lora_amd_sum_parts(part.data_ptr(), int(nparts), int(n), out.data_ptr(), int(n), _stream()),
+           "lora_amd_sum_parts")
+    return out
 
 
 # ----------------------------------------------------------------------------- K1 fully fused (MFMA GEMM + LoRA)

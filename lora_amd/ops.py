@@ -72,6 +72,15 @@ class GradSink:
             self._new(key, w, conv_reduce_rows(w, plan, Ci, Co, ks, r, self.up_grad, self.down_grad, 1.0))
         return w
 
+    def conv3_nhwc_workspace(self, key, lplan, cplan, device):
+        """Channels-last 3x3 site, key = ("conv3n", B, Ci, Co, H, W, r): (gt_part, up_part, gt, down_part)."""
+        w = self.ws.get(key)
+        if w is None:
+            _, B, Ci, Co, H, W, r = key
+            w = conv3_nhwc_buffers(lplan, cplan, B * H * W, r, device)
+            self._new(key, w, conv3_nhwc_reduce_rows(w, lplan, cplan, Ci, Co, r, self.up_grad, self.down_grad, 1.0))
+        return w
+
     def reduce_rows(self, key, plan=None):
         return self.rows[key]
 
@@ -93,6 +102,16 @@ def conv_buffers(plan, B: int, r: int, HW: int, device):
 def conv_reduce_rows(w, plan, Ci, Co, ks, r, up_grad, down_grad, beta):
     return [(w[3], up_grad, plan.ngroups_out, plan.rank_pad, Co, r, _C.FACTOR_KR, 1.0, beta),
             (w[4], down_grad, plan.ngroups_in, plan.rank_pad, Ci * ks * ks, r, _C.FACTOR_RK, 1.0, beta)]
+
+
+def conv3_nhwc_buffers(lplan, cplan, M: int, r: int, device):
+    f = lambda n: torch.empty(max(int(n), 4), dtype=torch.float32, device=device)  # noqa: E731
+    return (f(lplan.gt_part_floats), f(lplan.up_part_floats), f(M * r), f(cplan.down_part_floats))
+
+
+def conv3_nhwc_reduce_rows(w, lplan, cplan, Ci, Co, r, up_grad, down_grad, beta):
+    return [(w[1], up_grad, lplan.nparts_up, lplan.rank_tile, Co, r, _C.FACTOR_KR, 1.0, beta),
+            (w[3], down_grad, cplan.nsplit, cplan.rank_pad, Ci * 9, r, _C.FACTOR_RK, 1.0, beta)]
 
 
 def _rows2d(t: torch.Tensor, cols: int) -> torch.Tensor:
@@ -623,6 +642,131 @@ class LoraConvFunction(torch.autograd.Function):
         return dx, dw, db, d_down, d_up, None, None, None, None, None
 
 
+class LoraConv3NhwcFunction(torch.autograd.Function):
+    """The same site (lora.py:130-135, 3x3 / padding 1 / stride 1) for channels_last activations: csrc/conv_nhwc.hip.
+
+    In [B, H, W, C] memory the up-projection, its gradient pass over G and dUp are the Linear adapter's kernels on the
+    [B*H*W, C] rows (``rank_update``, ``linear_bwd_g``); the three 3x3 contractions (T, dX, dDown) are MFMA kernels that
+    touch X / dX exactly once, with no partial buffers but the `nsplit` dDown partials.  The frozen convolution and its
+    input gradient stay MIOpen (NHWC).  Saves X, T [B*H*W, r] f32 and the packed factor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, down, up, sel, scale, dropout_p, sink):
+        _C.require()
+        B, Ci, H, W = x.shape
+        Co, r = weight.shape[0], down.shape[0]
+        M = B * H * W
+        y = F.conv2d(x, weight, bias, 1, 1)  # frozen dense conv (MIOpen, MFMA)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        plan = _C.conv3_nhwc_plan(B, Ci, H, W, r)
+        down_c = down.float().contiguous()  # f32 masters: no-ops in training
+        up2 = up.reshape(Co, r).float().contiguous()
+        pf, pd = _C.conv3_nhwc_pack(down_c, x.dtype, plan)
+        t = _C.conv3_nhwc_down_fwd(x, pf, r)
+        sel_c = sel.to(torch.float32).contiguous() if sel is not None else None
+        if sel_c is not None:  # rare (set_lora_diag): T' = T S^T on the [M, r] rows
+            t = (t @ sel_c.t()).contiguous()
+        seed = off = 0
+        if dropout_p > 0.0:
+            seed, off = next_dropout_stream(x.device)
+        _C.rank_update_(y.permute(0, 2, 3, 1).view(M, Co), t, up2, _C.FACTOR_KR, scale, dropout_p, seed, off)
+        ctx.save_for_backward(x, weight, down, up, t, sel_c, pd)
+        ctx.scale, ctx.p, ctx.seed, ctx.off, ctx.sink = float(scale), float(dropout_p), seed, off, sink
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight, down, up, t, sel, pd = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co, r = weight.shape[0], down.shape[0]
+        M = B * H * W
+        need_x, need_w, need_b, need_down, need_up = ctx.needs_input_grad[:5]
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        g2 = g.permute(0, 2, 3, 1).view(M, Co)
+        cplan = _C.conv3_nhwc_plan(B, Ci, H, W, r)
+        lplan = _C.linear_plan(M, Ci, Co, r)
+        key = ("conv3n", B, Ci, Co, H, W, r)
+        sink = ctx.sink
+        if sink is not None:
+            if sink.pending is not None:
+                sink.flush()
+            bufs = sink.conv3_nhwc_workspace(key, lplan, cplan, g.device)
+        else:
+            bufs = conv3_nhwc_buffers(lplan, cplan, M, r, g.device)
+        gt_part, up_part, gt_buf, down_part = bufs
+        up2 = up.reshape(Co, r).float().contiguous()
+        s, p, seed, off = ctx.scale, ctx.p, ctx.seed, ctx.off
+        fused_g = bool(lplan.fused) and _C._rows_ok(g2)
+        d_up_direct = None
+        if fused_g:
+            # one pass over G: Gt column-tile partials + dUp row-block partials; the partials of Gt are then folded
+            _C.linear_bwd_g(g2, t, up2, gt_part, up_part, s, p, seed, off)
+            gt = _C.sum_parts(gt_part, lplan.nct_g, M * r, out=gt_buf[:M * r]).view(M, r)
+        else:  # C_out without 16-byte rows: the primitives (two passes over G)
+            gt = rowdot_any(g2, up2, _C.FACTOR_KR, s, None, False, p, seed, off)
+            d_up_direct = colreduce_any(g2, t, _C.FACTOR_KR, s, p=p, seed=seed, off=off)
+        if sel is not None:
+            gt = (gt @ sel).contiguous()
+        dx = None
+        if need_x:  # frozen dense conv's input gradient (MIOpen), then the low-rank term is added in place
+            dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+            if not dx.is_contiguous(memory_format=torch.channels_last):
+                dx = dx.contiguous(memory_format=torch.channels_last)
+            _C.conv3_nhwc_bwd_dx_(dx, gt, pd)
+        _C.conv3_nhwc_bwd_down(x, gt, down_part)
+        d_down = d_up = None
+        if sink is not None and fused_g:
+            sink.pending = key  # both partial sets are folded by the trainer's batched reduce
+        else:
+            to_sink = sink is not None
+            up_t = sink.up_grad if to_sink else torch.empty(up.shape, dtype=torch.float32, device=g.device)
+            down_t = sink.down_grad if to_sink else torch.empty(down.shape, dtype=torch.float32, device=g.device)
+            rows = conv3_nhwc_reduce_rows(bufs, lplan, cplan, Ci, Co, r, up_t, down_t, 1.0 if to_sink else 0.0)
+            if d_up_direct is not None:
+                rows = rows[1:]
+                if to_sink:
+                    up_t.add_(d_up_direct.view_as(up_t))
+                else:
+                    up_t = d_up_direct.view(up.shape)
+            table, n, total = _C.make_reduce_table(rows, g.device)
+            _C.reduce_batched(table, n, total)
+            if not to_sink:
+                d_up, d_down = up_t.to(up.dtype), down_t.to(down.dtype)
+        dw = db = None
+        if need_w:
+            dw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if ctx.has_bias and need_b:
+            db = g.sum((0, 2, 3))
+        return dx, dw, db, d_down, d_up, None, None, None, None
+
+
+def _channels_last_only(x: torch.Tensor) -> bool:
+    """Memory is [B, H, W, C] and NOT also plain NCHW-contiguous (C == 1 or H == W == 1 are both)."""
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def conv_nhwc_ok(x: torch.Tensor, weight: torch.Tensor, r: int, stride, padding, dilation, groups) -> bool:
+    """Channels-last activations at a site the NHWC forms cover: 1x1 (= the Linear adapter on the pixel rows) or
+    3x3 / padding 1 with a geometry ``_C.conv3_nhwc_plan`` accepts; stride 1, 16-bit activations."""
+    if not _channels_last_only(x) or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1):
+        return False
+    kh, kw = weight.shape[2], weight.shape[3]
+    if kh != kw or kh not in (1, 3) or tuple(padding) != ((kh - 1) // 2,) * 2:
+        return False
+    if x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != x.dtype:
+        return False
+    if kh == 1:
+        return True
+    B, Ci, H, W = x.shape
+    return bool(_C.conv3_nhwc_plan(B, Ci, H, W, r).native)
+
+
 def conv_native_ok(x: torch.Tensor, weight: torch.Tensor, r: int, stride, padding, dilation, groups) -> bool:
     if x.dim() != 4 or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1):
         return False
@@ -637,6 +781,14 @@ def lora_conv(x, weight, bias, down_w, up_w, sel, stride, padding, dilation, gro
     """LoraInjectedConv2d forward on device tensors: the native kernels when the geometry qualifies, else the frozen
     conv + ``lora_conv_branch`` (library conv for the k x k down-projection, HIP kernel for the rest)."""
     r = down_w.shape[0]
+    if down_w.dtype == up_w.dtype and conv_nhwc_ok(x, weight, r, stride, padding, dilation, groups):
+        Co, Ci = weight.shape[0], weight.shape[1]
+        if weight.shape[2] == 1:
+            # a 1x1 convolution of channels-last pixels IS the Linear site on the [B*H*W, C] rows (zero-copy views)
+            y = LoraLinearFunction.apply(x.permute(0, 2, 3, 1), weight.reshape(Co, Ci), bias, down_w.reshape(r, Ci),
+                                         up_w.reshape(Co, r), sel, float(scale), float(dropout_p), sink)
+            return y.permute(0, 3, 1, 2)
+        return LoraConv3NhwcFunction.apply(x, weight, bias, down_w, up_w, sel, float(scale), float(dropout_p), sink)
     if down_w.dtype == up_w.dtype and conv_native_ok(x, weight, r, stride, padding, dilation, groups):
         return LoraConvFunction.apply(x, weight, bias, down_w, up_w, sel, int(weight.shape[2]), float(scale),
                                       float(dropout_p), sink)

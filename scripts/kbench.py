@@ -233,6 +233,44 @@ def bench_conv(args):
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
+def bench_nhwc(args):
+    """K4 in both layouts at the same 3x3 sites: csrc/conv_nhwc.hip (MFMA, channels-last) next to csrc/conv.hip (NCHW).
+    GB/s = algorithmic bytes (X once; dX read + write; X once) over the kernel time."""
+    from lora_amd import ops
+
+    for (B, C, Hh, r) in ((4, 320, 64, 4), (4, 320, 64, 16), (4, 640, 32, 16), (4, 1280, 16, 16), (4, 1280, 8, 16),
+                          (1, 320, 96, 16), (1, 640, 48, 16), (1, 1280, 24, 16), (1, 2560, 24, 16), (1, 1280, 12, 16)):
+        x = torch.randn(B, C, Hh, Hh, device=DEV).to(torch.bfloat16)
+        xl = x.contiguous(memory_format=torch.channels_last)
+        dxl = torch.randn(B, C, Hh, Hh, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        down = torch.randn(r, C, 3, 3, device=DEV) * 0.1
+        M = B * Hh * Hh
+        gt = torch.randn(M, r, device=DEV)
+        plan = _C.conv3_nhwc_plan(B, C, Hh, Hh, r)
+        pf, pd = _C.conv3_nhwc_pack(down, torch.bfloat16, plan)
+        part = torch.empty(int(plan.down_part_floats), device=DEV)
+        ex = B * C * Hh * Hh * 2
+        res = dict(B=B, C=C, HW=Hh, r=r, pt=plan.pt, nsplit=plan.nsplit)
+        med, _ = timeit(lambda: _C.conv3_nhwc_pack(down, torch.bfloat16, plan), args.iters)
+        res["pack_us"] = med * 1e6
+        med, _ = timeit(lambda: _C.conv3_nhwc_down_fwd(xl, pf, r), args.iters)
+        res["T_us"], res["T_GBs"] = med * 1e6, ex / med / 1e9
+        med, _ = timeit(lambda: _C.conv3_nhwc_bwd_dx_(dxl, gt, pd), args.iters)
+        res["dx_us"], res["dx_GBs"] = med * 1e6, 2 * ex / med / 1e9
+        med, _ = timeit(lambda: _C.conv3_nhwc_bwd_down(xl, gt, part), args.iters)
+        res["ddown_us"], res["ddown_GBs"] = med * 1e6, ex / med / 1e9
+        cplan = _C.conv_plan(B, C, C, Hh, Hh, 3, r)
+        if cplan.native:
+            t_part, gt_part, gtn, up_part, down_part = ops.conv_buffers(cplan, B, r, Hh * Hh, DEV)
+            t = torch.empty(B, r, Hh, Hh, device=DEV)
+            dx = torch.randn(B, C, Hh, Hh, device=DEV).to(torch.bfloat16)
+            med, _ = timeit(lambda: _C.conv_down_fwd(x, down, None, t_part, t, 3), args.iters)
+            res["nchw_T_us"] = med * 1e6
+            med, _ = timeit(lambda: _C.conv_bwd_x(x, dx, gtn, down, down_part, 3), args.iters)
+            res["nchw_dx_ddown_us"] = med * 1e6
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+
+
 def bench_hostops(args):
     """GroupNorm(+SiLU), LayerNorm and the GEGLU gate of the frozen UNet: HIP passes vs the ATen sequences (bf16)."""
     import torch.nn as nn
@@ -293,5 +331,7 @@ if __name__ == "__main__":
         bench_ws(a)
     if "conv" in a.what:
         bench_conv(a)
+    if "nhwc" in a.what:
+        bench_nhwc(a)
     if "hostops" in a.what:
         bench_hostops(a)

@@ -107,3 +107,20 @@ def test_host_pass_geometry_is_pure_host_arithmetic():
     assert lib.lora_amd_geglu_fwd(None, 16, None, 8, 4, 10, _C.BF16, None) != 0
     assert b"inner" in lib.lora_amd_last_error()
     assert lib.lora_amd_layernorm_fwd(None, None, None, None, None, 4, 100, 1e-5, _C.BF16, None) != 0
+
+
+def test_conv3_nhwc_plan_is_pure_host_arithmetic():
+    """Geometry of the channels-last 3x3 kernels (csrc/conv_nhwc.hip): which sites qualify and how they are cut."""
+    assert C.sizeof(_C.Conv3NhwcPlan) == 48 and _C.Conv3NhwcPlan.pf_elems.offset == 24
+    pl = _C.conv3_nhwc_plan(4, 320, 64, 64, 16)  # SD1.5 ResnetBlock2D conv at 512^2, batch 4, extended LoRA rank 16
+    assert pl.native == 1 and pl.pt == 4 and pl.ks == 5 and pl.rank_pad == 16
+    assert pl.pf_elems == 9 * 320 * 16 and pl.pd_elems == 320 * 5 * 32
+    assert 1 <= pl.nsplit <= 16 and pl.down_part_floats == pl.nsplit * 16 * 320 * 9
+    # dDown partials stay under ~15 % of the X stream
+    assert pl.nsplit * 16 * 320 * 9 * 4 <= 0.16 * (4 * 64 * 64 * 320 * 2)
+    pl = _C.conv3_nhwc_plan(1, 1280, 12, 12, 4)  # the 12x12 maps of 768^2 images: native here (masked tile edges)
+    assert pl.native == 1 and pl.pt == 1 and pl.ks == 2 and pl.rank_pad == 4
+    for bad in [(4, 320, 64, 64, 3), (4, 320, 64, 64, 20), (4, 100, 64, 64, 4), (64, 2560, 256, 256, 4)]:
+        assert _C.conv3_nhwc_plan(*bad).native == 0
+    lib = _C.require()
+    assert lib.lora_amd_conv3_nhwc_plan(1, 64, 8, 8, 65, C.byref(_C.Conv3NhwcPlan())) == -2
