@@ -363,8 +363,8 @@ int lora_amd_conv_bwd_x(const void *x, void *dx, const float *gt, const void *do
  *     T[p, j]         = sum_{tap, c} down[j, c, tap] X[p + tap, c]
  *     dX[p, c]       += sum_{tap, j} down[j, c, tap] Gt[p - tap, j]
  *     dDown[j, c, tap] = sum_p Gt[p, j] X[p + tap, c]         (per-split partials, folded by lora_amd_reduce_batched)
- * Native geometry: C_in % 64 == 0, rank in {4, 8, 12, 16}, bf16 / f16 activations, B*H*W*C_in < 2^31; any H, W
- * (pixel tiles are 16 columns x pt rows with masked edges, so the 12x12 maps qualify too).
+ * Native geometry: C_in % 64 == 0, rank in {4, 8, 12, 16}, bf16 / f16 activations, B*H*W*C_in < 2^31, W <= 128;
+ * any H (pixel tiles are 16 columns x pt rows with masked edges, so the 12x12 maps qualify too).
  * `down` is [r, C_in, 3, 3] f32; lora_amd_conv3_nhwc_pack rewrites it per call into MFMA fragment order in the
  * activation dtype: pf for the forward (at rank <= 8 the spare fragment rows carry the low 16-bit parts of the f32
  * values, T is then as precise as with f32 factors; at rank 12 / 16 the factor is rounded to the activation dtype,
@@ -373,11 +373,14 @@ int lora_amd_conv_bwd_x(const void *x, void *dx, const float *gt, const void *do
 typedef struct lora_amd_conv3_nhwc_plan_t {
   int32_t native;   /* 1: the entry points below accept this geometry */
   int32_t pt;       /* image rows of a forward pixel tile (tile = 16 columns x pt rows) */
+  int32_t ksplit;   /* forward: channel shares per pixel tile (small maps); > 1 = that many T partials in t_part */
+  int32_t csplit;   /* input gradient: shares of the 64-channel blocks per pixel tile */
   int32_t ks;       /* 32-slot steps of the (tap, rank) contraction = ceil(9 r / 32) */
-  int32_t nsplit;   /* pixel splits of the dDown pass = number of dDown partials */
+  int32_t pr;       /* factor gradient: image rows per LDS-staged strip */
+  int32_t nsplit;   /* factor gradient: workgroups per 64-channel chunk = number of dDown partials */
   int32_t rank_pad; /* rows of one dDown partial (r rounded up to 4 / 8 / 16) */
-  int32_t reserved;
   int64_t pf_elems, pd_elems; /* packed factor sizes in activation-dtype elements */
+  int64_t t_part_floats;      /* ksplit > 1: ksplit * B*H*W * r, else 0 */
   int64_t down_part_floats;   /* nsplit * rank_pad * C_in * 9 */
 } lora_amd_conv3_nhwc_plan_t;
 
@@ -385,13 +388,14 @@ int lora_amd_conv3_nhwc_plan(int32_t B, int32_t C_in, int32_t H, int32_t W, int3
                              lora_amd_conv3_nhwc_plan_t *out);
 int lora_amd_conv3_nhwc_pack(const float *down, int32_t r, int32_t C_in, int32_t act_dtype, void *pf, void *pd,
                              void *stream);
-/* t_out [B*H*W, r] f32 = conv3x3(X; down), X [B, H, W, C_in] contiguous. */
-int lora_amd_conv3_nhwc_down_fwd(const void *x, const void *pf, float *t_out, int32_t B, int32_t C_in, int32_t H,
-                                 int32_t W, int32_t r, int32_t act_dtype, void *stream);
+/* t_out [B*H*W, r] f32 = conv3x3(X; down), X [B, H, W, C_in] contiguous.  t_part: plan.t_part_floats floats
+ * (may be NULL when plan.ksplit == 1). */
+int lora_amd_conv3_nhwc_down_fwd(const void *x, const void *pf, float *t_part, float *t_out, int32_t B, int32_t C_in,
+                                 int32_t H, int32_t W, int32_t r, int32_t act_dtype, void *stream);
 /* dX [B, H, W, C_in] (in place; holds the frozen conv's input gradient) += conv_transpose3x3(Gt; down). */
 int lora_amd_conv3_nhwc_bwd_dx(void *dx, const float *gt, const void *pd, int32_t B, int32_t C_in, int32_t H,
                                int32_t W, int32_t r, int32_t act_dtype, void *stream);
-/* down_part [nsplit][rank_pad][C_in * 9] f32: per-split partial sums of dDown (rows >= r are not written). */
+/* down_part [nsplit][rank_pad][C_in * 9] f32: per-workgroup partial sums of dDown (rows >= r are not written). */
 int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, float *down_part, int32_t B, int32_t C_in,
                                  int32_t H, int32_t W, int32_t r, int32_t act_dtype, void *stream);
 /* out[n] = sum_p part[p * stride + i]: folds the column-tile partials of lora_amd_linear_bwd_g into one Gt. */

@@ -83,8 +83,9 @@ class ConvPlan(C.Structure):
 
 
 class Conv3NhwcPlan(C.Structure):
-    _fields_ = [("native", C.c_int32), ("pt", C.c_int32), ("ks", C.c_int32), ("nsplit", C.c_int32),
-                ("rank_pad", C.c_int32), ("reserved", C.c_int32), ("pf_elems", C.c_int64), ("pd_elems", C.c_int64),
+    _fields_ = [("native", C.c_int32), ("pt", C.c_int32), ("ksplit", C.c_int32), ("csplit", C.c_int32),
+                ("ks", C.c_int32), ("pr", C.c_int32), ("nsplit", C.c_int32), ("rank_pad", C.c_int32),
+                ("pf_elems", C.c_int64), ("pd_elems", C.c_int64), ("t_part_floats", C.c_int64),
                 ("down_part_floats", C.c_int64)]
 
 
@@ -172,7 +173,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_conv_bwd_x.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv3_nhwc_plan.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Conv3NhwcPlan)]
     lib.lora_amd_conv3_nhwc_pack.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    lib.lora_amd_conv3_nhwc_down_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.lora_amd_conv3_nhwc_down_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv3_nhwc_bwd_dx.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv3_nhwc_bwd_down.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_sum_parts.argtypes = [vp, i32, i64, vp, i64, vp]
@@ -701,12 +702,17 @@ def conv3_nhwc_pack(down: torch.Tensor, act_dtype: torch.dtype, plan: Conv3NhwcP
     return pf, pd
 
 
-def conv3_nhwc_down_fwd(x: torch.Tensor, pf: torch.Tensor, r: int) -> torch.Tensor:
-    """T [B*H*W, r] f32 = conv3x3(x; down) for a channels_last x."""
+def conv3_nhwc_down_fwd(x: torch.Tensor, pf: torch.Tensor, r: int, t_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T [B*H*W, r] f32 = conv3x3(x; down) for a channels_last x (``t_part``: plan.t_part_floats floats of workspace,
+    allocated here when the geometry needs it and none is given)."""
     B, Ci, H, W = _nhwc_dims(x)
     t = torch.empty((B * H * W, r), dtype=torch.float32, device=x.device)
-    _check(require().lora_amd_conv3_nhwc_down_fwd(x.data_ptr(), pf.data_ptr(), t.data_ptr(), B, Ci, H, W, r,
-                                                  dtype_code(x.dtype), _stream()), "lora_amd_conv3_nhwc_down_fwd")
+    need = int(conv3_nhwc_plan(B, Ci, H, W, r).t_part_floats)
+    if need and (t_part is None or t_part.numel() < need):
+        t_part = torch.empty(need, dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_conv3_nhwc_down_fwd(x.data_ptr(), pf.data_ptr(), _ptr(t_part) if need else None,
+                                                  t.data_ptr(), B, Ci, H, W, r, dtype_code(x.dtype), _stream()),
+           "lora_amd_conv3_nhwc_down_fwd")
     return t
 
 

@@ -21,9 +21,9 @@
 //   * `down` is re-packed per call into MFMA fragment order in the activation dtype (conv3_pack_kernel; 9*C*16
 //     elements, 92 KB at C = 320) so that a wave fetches a fragment with one coalesced 1 KB load; at r <= 8 the spare
 //     fragment rows carry the low 16-bit parts of the f32 masters, so T is as precise as f32 factors at no cost;
-//   * dDown contracts over PIXELS, which are strided in NHWC: the X^T fragment is gathered with 2-byte loads (a lane =
-//     one channel x 8 pixels), the shifted-Gt fragment with 4-byte loads (Gt is r/C of the stream); the pixel range is
-//     split over `nsplit` workgroups x 4 waves, the waves meet in LDS, and the `nsplit` partials are folded by the
+//   * dDown contracts over PIXELS, which are strided in NHWC: image-row strips of X (with zero margins, so that a tap
+//     is a pure shift) and the transposed Gt are staged in LDS, the X^T fragments are gathered from there with 2-byte
+//     reads; the strips are dealt to `nsplit` workgroups per 64-channel chunk, whose partials are folded by the
 //     trainer's batched reduce (same [parts][rank_pad][C*9] layout as conv.hip's).
 // Algorithmic bytes per site: forward B*H*W*C*e (X once); backward 2*B*H*W*C*e (dX read + write) + B*H*W*C*e (X once);
 // the [B*H*W, r] f32 tensors are 2r/C of that.  All three are HBM/L2-stream bound (9*r*2 flop per 2-byte element is
@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float *__restrict
 }
 
 // ============================================================================ T = conv3x3(X; down), [B*H*W, r] f32
-// grid = B * nrg * ntc workgroups; workgroup = pixel tile (PT rows x 16 columns); wave w takes the 32-channel k-steps
-// kc = w, w + 4, ...  Per k-step and column shift dx: 3 weight fragments (dy = -1, 0, 1) and the PT + 2 input rows the
+// grid = (B * nrg * ntc, ksplit); workgroup = pixel tile (PT rows x 16 columns) x channel share kz; wave w takes the
+// 32-channel k-steps kc = kz*4 + w, + 4*ksplit, ...  (small maps: the packed factor a workgroup pulls, 9*C*16 elements,
+// outweighs its 16*PT pixels of X, so the channels are split over `ksplit` workgroups as well; each then writes its own
+// partial T and lora_amd_sum_parts folds them).  Per k-step and column shift dx: 3 weight fragments and the PT + 2 input rows the
 // tile's taps touch, each row fragment feeding up to 3 MFMAs (one per dy).  Out-of-image taps: clamped address, value
 // ANDed to zero (no branch, no load behind a branch).
 template <class E, int PT>
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(kNhThreads) void conv3_down_nhwc_kernel(const typen
 #pragma unroll
   for (int t = 0; t < PT; ++t) acc[t] = (nf32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = wave; kc < KC; kc += 4) {
+  const int ksplit = gridDim.y;
+  t_out += (int64_t)blockIdx.y * ((int64_t)g.B * H * W * g.r);  // this share's partial (the output itself at ksplit 1)
+  for (int kc = blockIdx.y * 4 + wave; kc < KC; kc += 4 * ksplit) {
     const S *xk = x + kc * 32;
     const S *pk = pf + ((int64_t)kc * 64 + lane) * 8;
 #pragma unroll
@@ -211,9 +215,10 @@ __global__ __launch_bounds__(kNhThreads) void conv3_down_nhwc_kernel(const typen
 
 // ============================================================================ dX += conv_transpose3x3(Gt; down)
 // Same pixel tiles.  The (tap, rank) contraction has 9r slots = KS k-steps of 32; the tile's Gt fragments (shifted by
-// the tap of each slot group, zero outside the image) are built once and stay in registers; the waves walk disjoint
-// 64-channel blocks: per 16-channel subtile KS weight fragments, KS MFMAs per tile row, one 8-byte read-modify-write of
-// dX per lane (a lane owns 4 consecutive channels of one pixel; the 4 subtiles of a block cover the pixel's 128-byte line).
+// the tap of each slot group, zero outside the image) are built once and stay in registers; workgroup (tile, cz) walks
+// the 64-channel blocks cz, cz + csplit, ..., wave w owning subtile w of each: KS weight fragments, KS MFMAs per tile
+// row, one 8-byte read-modify-write of dX per lane (a lane owns 4 consecutive channels of one pixel; the four waves
+// together cover the pixel's 128-byte line).
 template <class E, int PT, int KS>
 __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::storage *__restrict__ dx,
                                                                    const float *__restrict__ gt,
@@ -265,7 +270,10 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
         const unsigned m = gmask[t][ks][h];
         const nu32x4 q = graw[t][ks][h] & (nu32x4){m, m, m, m};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[h * 4 + e] = __builtin_bit_cast(float, q[e]);
+        for (int e = 0; e < 4; ++e) {
+          const unsigned qe = q[e];  // (a __builtin_bit_cast applied to q[e] itself reads element 0 for every e)
+          v[h * 4 + e] = __builtin_bit_cast(float, qe);
+        }
       }
       bg[t][ks] = nh_frag<E>(v);
     }
@@ -279,10 +287,9 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
     poff[t] = ((b * H + nh_clamp(yy, H - 1)) * W + nh_clamp(xx, W - 1)) * C + lg * 4;
   }
   const int NCB = C >> 6;
-  for (int cb = wave; cb < NCB; cb += 4) {
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      const int ct = cb * 4 + sub;
+  for (int cb = blockIdx.y; cb < NCB; cb += gridDim.y) {
+    {
+      const int ct = cb * 4 + wave;  // the four waves cover the pixel's 128-byte line of this block
       F pa[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) pa[ks] = *reinterpret_cast<const F *>(pd + (((int64_t)ct * KS + ks) * 64 + lane) * 8);
@@ -305,128 +312,166 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
 }
 
 // ============================================================================ dDown partials
-// grid (C / 32, nsplit).  Workgroup (cg, sp): channels cg*32 .. +31, pixel blocks (32 consecutive flat pixels = one
-// k-step) sp*4 + wave, + 4*nsplit, ...  A = X^T (rows = channels; a lane gathers one channel of 8 consecutive pixels
-// with 2-byte loads), B = Gt shifted by the slot's tap (columns = (tap, rank) slots, NT tiles of 16).  The waves meet in
-// LDS; wave 0 writes part[sp][j][c*9 + tap].
-template <class E, int NT>
-__global__ __launch_bounds__(kNhThreads) void conv3_ddown_nhwc_kernel(const typename E::storage *__restrict__ x,
-                                                                      const float *__restrict__ gt,
-                                                                      float *__restrict__ part, const NhGeom g,
-                                                                      int nblk, int nsplit, int rank_pad) {
+// dDown[j, c, tap] = sum_p Gt[p, j] X[p + tap, c] contracts over PIXELS, which are strided in NHWC, so both operands
+// are staged through LDS:
+//   * a workgroup owns a 64-channel chunk `cc` and walks image-row strips s = sid, sid + nsplit, ... (PR rows each);
+//     a strip's X rows y0-1 .. y0+PR (64 channels = one 128-byte line per pixel, coalesced 16-byte loads) are written
+//     [pixel][136 B] with a zero pixel left and right of every row and zero rows outside the image, so that a tap is a
+//     PURE SHIFT of the flat staged index (dy*(W+2) + dx) and the zero padding of the convolution needs no mask;
+//   * Gt of the strip is staged transposed and in the activation dtype, gT[rank][padded pixel] (zero at the padding
+//     positions), so the A operand (rows = ranks, k = 8 consecutive pixels) is one 16-byte LDS read per k-step;
+//   * the B operand X^T (columns = channels, k = 8 consecutive pixels) is gathered from LDS with 2-byte reads at
+//     compile-time offsets i*136 (the 4 lane groups are 8 pixels = 1088 B apart: disjoint bank groups); the 10 values
+//     pixel-1 .. pixel+8 serve the three dx shifts of a row (two direct, one by v_alignbit);
+//   * wave w owns channels w*16 .. +15 of the chunk: 9 accumulators (one per tap) live in registers across ALL strips
+//     of the workgroup, no cross-wave reduction; the next strip's global loads are issued before the current one is
+//     multiplied.
+// Output: part[sid][j][c*9 + tap] (the trainer's batched reduce folds the nsplit partials).
+constexpr int kDdRowB = 136;    // bytes per staged pixel
+constexpr int kDdMaxPix = 432;  // (PR + 2) * (W + 2) staged pixels at most
+constexpr int kDdTail = 41;     // front margin pixel + k-step overrun behind the last row (zero)
+constexpr int kDdGRow = 456;    // gT row length in elements (>= padded strip pixels rounded up to 32; multiple of 8)
+constexpr int kDdNld = 12;      // 16-byte chunks of X per thread and strip: (PR + 2) * W * 8 <= 12 * 256
+
+template <class E, int RQ>
+__global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const typename E::storage *__restrict__ x,
+                                                                         const float *__restrict__ gt,
+                                                                         float *__restrict__ part, const NhGeom g,
+                                                                         int PR, int nsplit, int rank_pad) {
+  using S = typename E::storage;
   using F = typename NhMfma<E>::frag;
-  constexpr int CT = 2;
-  __shared__ __attribute__((aligned(16))) float red[3 * CT * NT * 64 * 4];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) unsigned char xs[(kDdMaxPix + kDdTail) * kDdRowB];
+  __shared__ __attribute__((aligned(16))) unsigned short gT[16 * kDdGRow];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  const int cg = blockIdx.x, sp = blockIdx.y;
-  const int H = g.H, W = g.W, C = g.C, r = g.r, HW = H * W;
-  const int M = g.B * HW;
-  const unsigned short *xs16 = reinterpret_cast<const unsigned short *>(x);
+  const int cc = blockIdx.x, sid = blockIdx.y;
+  const int H = g.H, W = g.W, C = g.C, r = g.r, WP = W + 2;
+  const int spi = (H + PR - 1) / PR, nstrips = g.B * spi;
+  const int SPP = PR * WP, KSP = (SPP + 31) >> 5;
+  const int nchunks = (PR + 2) * W * 8;
 
-  int s_dy[NT], s_dx[NT], s_off[NT], s_j[NT], s_tap[NT];
-  bool s_live[NT];
+  // everything that is never written below stays zero: the pixel margins of every staged row, the tail, ranks >= r
+  for (int i = tid; i < (int)(sizeof(xs) / 16); i += kNhThreads) reinterpret_cast<nu32x4 *>(xs)[i] = (nu32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < (int)(sizeof(gT) / 16); i += kNhThreads) reinterpret_cast<nu32x4 *>(gT)[i] = (nu32x4){0u, 0u, 0u, 0u};
+
+  // strip-independent descriptors of this thread's X chunks and Gt pixels
+  int xrel[kDdNld], xlds[kDdNld], xry[kDdNld];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int s = nt * 16 + l15;
-    s_live[nt] = s < 9 * r;
-    const int tap = s_live[nt] ? s / r : 0;
-    s_tap[nt] = tap;
-    s_j[nt] = s_live[nt] ? s - tap * r : 0;
-    s_dy[nt] = tap / 3 - 1;
-    s_dx[nt] = tap % 3 - 1;
-    s_off[nt] = -(s_dy[nt] * W + s_dx[nt]) * r + s_j[nt];  // Gt index of pixel p shifted by -tap: p*r + s_off
+  for (int u = 0; u < kDdNld; ++u) {
+    const int q = tid + kNhThreads * u;
+    const bool live = q < nchunks;
+    const int f = live ? q >> 3 : 0, c16 = q & 7;
+    const int ryp = f / W, xq = f - ryp * W;  // staged row 0 .. PR+1 (image row y0 - 1 + ryp), column
+    xry[u] = live ? ryp - 1 : (1 << 20);      // a dead chunk is "outside the image" for every strip
+    xrel[u] = ((ryp - 1) * W + xq) * C + cc * 64 + c16 * 8;
+    xlds[u] = (ryp * WP + xq + 2) * kDdRowB + c16 * 16;  // + 1 column margin + 1 front pixel
+  }
+  int grel[2], gry[2];
+  bool gin[2], gst[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int sp = tid + kNhThreads * v;
+    gin[v] = sp < KSP * 32;
+    const int ry = sp / WP, xx = sp - ry * WP;
+    gst[v] = sp < SPP && xx >= 1 && xx <= W;
+    gry[v] = ry;
+    grel[v] = (ry * W + xx - 1) * r;
   }
 
-  nf32x4 acc[CT][NT];
+  nu32x4 xr[kDdNld];
+  nf32x4 gr[2][RQ];
+  auto prefetch = [&](int s) {
+    const int b = s / spi, y0 = (s - b * spi) * PR;
+    const int rows_valid = min(PR, H - y0);
+    const S *xb = x + ((int64_t)(b * H + y0) * W) * C;
+    const float *gb = gt + ((int64_t)(b * H + y0) * W) * r;
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[ct][nt] = (nf32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int blk = sp * 4 + wave; blk < nblk; blk += nsplit * 4) {
-    const int p0 = blk * 32 + lg * 8;
-    int py[8], px[8];
-    bool pv[8];
-    {
-      const int pc = p0 < M ? p0 : 0;
-      const int rem = pc % HW;
-      int y = rem / W, xq = rem - y * W;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        pv[e] = p0 + e < M;
-        py[e] = y;
-        px[e] = xq;
-        if (++xq == W) { xq = 0; if (++y == H) y = 0; }
-      }
-    }
-    // X^T fragments: raw 2-byte gathers (clamped rows), zeroed past M
-    unsigned short xraw[CT][8];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int p = pv[e] ? p0 + e : M - 1;
-        xraw[ct][e] = xs16[(int64_t)p * C + cg * 32 + ct * 16 + l15];
-      }
-    F xa[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      union { F f; unsigned short s[8]; } u;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) u.s[e] = pv[e] ? xraw[ct][e] : (unsigned short)0;
-      xa[ct] = u.f;
+    for (int u = 0; u < kDdNld; ++u) {
+      const int y = y0 + xry[u];
+      const bool ok = y >= 0 && y < H;
+      xr[u] = *reinterpret_cast<const nu32x4 *>(xb + (ok ? xrel[u] : cc * 64 + (tid & 7) * 8));
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float graw[8];
-      bool ok[8];
+    for (int v = 0; v < 2; ++v) {
+      const bool ok = gst[v] && gry[v] < rows_valid;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ys = py[e] - s_dy[nt], xs = px[e] - s_dx[nt];
-        ok[e] = s_live[nt] && pv[e] && ys >= 0 && ys < H && xs >= 0 && xs < W;
-        const int64_t idx = ok[e] ? (int64_t)(p0 + e) * r + s_off[nt] : 0;
-        graw[e] = gt[idx];
+      for (int qd = 0; qd < RQ; ++qd) gr[v][qd] = *reinterpret_cast<const nf32x4 *>(gb + (ok ? grel[v] : 0) + 4 * qd);
+    }
+  };
+
+  nf32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (nf32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned short *xs16 = reinterpret_cast<const unsigned short *>(xs);
+  const int col = wave * 16 + l15;  // this lane's channel inside the chunk
+
+  if (sid < nstrips) prefetch(sid);
+  for (int s = sid; s < nstrips; s += nsplit) {
+    const int b = s / spi, y0 = (s - b * spi) * PR;
+    const int rows_valid = min(PR, H - y0);
+    __syncthreads();  // the previous strip has been multiplied (first trip: the zero fill is complete)
+#pragma unroll
+    for (int u = 0; u < kDdNld; ++u) {
+      const int y = y0 + xry[u];
+      const unsigned m = (y >= 0 && y < H) ? 0xFFFFFFFFu : 0u;
+      const nu32x4 v = xr[u] & (nu32x4){m, m, m, m};
+      if (tid + kNhThreads * u < nchunks) {
+        *reinterpret_cast<nu32x2 *>(xs + xlds[u]) = (nu32x2){v[0], v[1]};
+        *reinterpret_cast<nu32x2 *>(xs + xlds[u] + 8) = (nu32x2){v[2], v[3]};
       }
-      float v[8];
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float q = graw[e];
-        asm volatile("" : "+v"(q));  // keep the load where it is: a select, not a load behind a branch
-        v[e] = ok[e] ? q : 0.f;
+    for (int v = 0; v < 2; ++v) {
+      if (gin[v]) {
+        const bool ok = gst[v] && gry[v] < rows_valid;
+        const int sp = tid + kNhThreads * v;
+#pragma unroll
+        for (int qd = 0; qd < RQ; ++qd)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            union { S s; unsigned short u; } cv;
+            cv.s = E::from_f(ok ? gr[v][qd][e] : 0.f);
+            gT[(qd * 4 + e) * kDdGRow + sp] = cv.u;
+          }
       }
-      const F bq = nh_frag<E>(v);
+    }
+    __syncthreads();
+    if (s + nsplit < nstrips) prefetch(s + nsplit);  // in flight while this strip is multiplied
+
+    for (int ks = 0; ks < KSP; ++ks) {
+      const int sp0 = ks * 32 + lg * 8;
+      const F ga = nh_frag_bits<E>(*reinterpret_cast<const nu32x4 *>(gT + l15 * kDdGRow + sp0));
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[ct][nt] = NhMfma<E>::mma(xa[ct], bq, acc[ct][nt]);
+      for (int d = 0; d < 3; ++d) {
+        const unsigned short *src = xs16 + (sp0 + WP * d) * (kDdRowB / 2) + col;  // pixel (row + d - 1, column - 1)
+        unsigned v[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) v[i] = src[i * (kDdRowB / 2)];
+        unsigned P[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) P[k] = v[2 * k] | (v[2 * k + 1] << 16);
+        const nu32x4 fm = (nu32x4){P[0], P[1], P[2], P[3]};
+        const nu32x4 fp = (nu32x4){P[1], P[2], P[3], P[4]};
+        const nu32x4 f0 = (nu32x4){(P[0] >> 16) | (P[1] << 16), (P[1] >> 16) | (P[2] << 16),
+                                   (P[2] >> 16) | (P[3] << 16), (P[3] >> 16) | (P[4] << 16)};
+        acc[d * 3 + 0] = NhMfma<E>::mma(ga, nh_frag_bits<E>(fm), acc[d * 3 + 0]);
+        acc[d * 3 + 1] = NhMfma<E>::mma(ga, nh_frag_bits<E>(f0), acc[d * 3 + 1]);
+        acc[d * 3 + 2] = NhMfma<E>::mma(ga, nh_frag_bits<E>(fp), acc[d * 3 + 2]);
+      }
     }
   }
 
-  if (wave > 0) {
+  // acc[tap][e] = dDown[rank lg*4 + e][channel cc*64 + wave*16 + l15][tap]
+  const int64_t row_len = (int64_t)C * 9;
+  const int c = cc * 64 + wave * 16 + l15;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        *reinterpret_cast<nf32x4 *>(red + ((((wave - 1) * CT + ct) * NT + nt) * 64 + lane) * 4) = acc[ct][nt];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const int64_t row_len = (int64_t)C * 9;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        nf32x4 v = acc[ct][nt];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const nf32x4 *>(red + (((w * CT + ct) * NT + nt) * 64 + lane) * 4);
-        // v[e] = dDown^T[channel cg*32 + ct*16 + lg*4 + e][slot nt*16 + l15]
-        if (s_live[nt]) {
-          float *dst = part + ((int64_t)sp * rank_pad + s_j[nt]) * row_len + (int64_t)(cg * 32 + ct * 16 + lg * 4) * 9 + s_tap[nt];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dst[e * 9] = v[e];
-        }
-      }
-  }
+    for (int e = 0; e < 4; ++e) {
+      const int j = lg * 4 + e;
+      if (j < r) part[((int64_t)sid * rank_pad + j) * row_len + (int64_t)c * 9 + t] = acc[t][e];
+    }
 }
 
 // ============================================================================ out = sum_p part[p]  (Gt column-tile partials)
@@ -446,6 +491,7 @@ static inline int nh_env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
+static inline int64_t nh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static int nh_pick_pt(int B, int H, int W) {
   const int forced = nh_env_int("LORA_AMD_NHWC_PT", 0);
   if (forced == 1 || forced == 2 || forced == 4) return forced;
@@ -455,19 +501,47 @@ static int nh_pick_pt(int B, int H, int W) {
   if (t2 >= 100) return 2;
   return 1;
 }
+// image rows per dDown strip: as many as the staging budget holds ((PR+2)*W*8 chunks over 256 threads x kDdNld,
+// (PR+2)*(W+2) staged pixels); 0 = the map is too wide
+static int nh_pick_pr(int H, int W) {
+  int pr = 0;
+  for (int p = 1; p <= H; ++p)
+    if ((p + 2) * W * 8 <= kDdNld * kNhThreads && (p + 2) * (W + 2) <= kDdMaxPix &&
+        ((p * (W + 2) + 31) / 32) * 32 <= kDdGRow)
+      pr = p;
+  return pr;
+}
 static inline bool nh_native(int B, int C, int H, int W, int r) {
   return B >= 1 && H >= 1 && W >= 1 && C >= 64 && C % 64 == 0 && r >= 4 && r <= 16 && r % 4 == 0 &&
-         (int64_t)B * H * W * C < ((int64_t)1 << 31);
+         (int64_t)B * H * W * C < ((int64_t)1 << 31) && nh_pick_pr(H, W) >= 1;
 }
-static int nh_pick_split(int64_t M, int C, int r) {
-  const int forced = nh_env_int("LORA_AMD_NHWC_SPLIT", 0);
-  const int64_t nblk = (M + 31) / 32;
-  int64_t s = forced > 0 ? forced : (256 + C / 32 - 1) / (C / 32);
-  // partials are nsplit * 18 r / M of the X stream: keep them under ~15 %
-  const int64_t cap_bytes = std::max<int64_t>(1, (int64_t)(0.15 * (double)M / (18.0 * r)));
-  if (forced <= 0) s = std::min<int64_t>(s, std::min<int64_t>(16, cap_bytes));
-  s = std::min<int64_t>(s, std::max<int64_t>(1, nblk / 4));
-  return (int)std::max<int64_t>(1, s);
+struct NhCuts { int pt, ksplit, pt_dx, csplit, pr, nsplit; };
+static NhCuts nh_cuts(int B, int C, int H, int W, int r) {
+  NhCuts q;
+  const int64_t ntc = (W + 15) / 16, M = (int64_t)B * H * W;
+  q.pt = nh_pick_pt(B, H, W);
+  // forward: few pixel tiles (small maps) -> also split the channel k-steps (C/32; >= 4 per share, one per wave)
+  const int64_t tiles = (int64_t)B * nh_cdiv(H, q.pt) * ntc;
+  int ks = nh_env_int("LORA_AMD_NHWC_KSPLIT", 0);
+  if (ks <= 0) ks = tiles >= 192 ? 1 : (int)nh_cdiv(256, tiles);
+  q.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(ks, (C / 32) / 4));
+  // input gradient: PT * KS Gt fragments stay in registers -> at most 2 tile rows; channel blocks (C/64) over grid.y
+  q.pt_dx = std::min(q.pt, 2);
+  const int64_t tiles_dx = (int64_t)B * nh_cdiv(H, q.pt_dx) * ntc;
+  int cs = nh_env_int("LORA_AMD_NHWC_CSPLIT", 0);
+  if (cs <= 0) cs = tiles_dx >= 192 ? 1 : (int)nh_cdiv(256, tiles_dx);
+  q.csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cs, C / 64));
+  // factor gradient: strips of PR rows, dealt to nsplit workgroups per 64-channel chunk; the nsplit partials are
+  // nsplit * 18 r / M of the X stream: at most ~30 % of it, and ~256 workgroups in all
+  q.pr = nh_pick_pr(H, W);
+  const int64_t nstrips = (int64_t)B * nh_cdiv(H, std::max(q.pr, 1));
+  int ns = nh_env_int("LORA_AMD_NHWC_SPLIT", 0);
+  if (ns <= 0) {
+    const int64_t cap = std::max<int64_t>(1, (int64_t)(0.30 * (double)M / (18.0 * r)));
+    ns = (int)std::min<int64_t>(nh_cdiv(256, C / 64), cap);
+  }
+  q.nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, nstrips));
+  return q;
 }
 static inline NhGeom nh_geom(int B, int C, int H, int W, int r, int pt) {
   NhGeom g;
@@ -489,14 +563,20 @@ extern "C" int lora_amd_conv3_nhwc_plan(int32_t B, int32_t C_in, int32_t H, int3
                  LORA_AMD_MAX_RANK);
   memset(out, 0, sizeof(*out));
   if (!nh_native(B, C_in, H, W, r)) return LORA_AMD_OK;
+  const NhCuts q = nh_cuts(B, C_in, H, W, r);
+  const int64_t M = (int64_t)B * H * W;
   out->native = 1;
-  out->pt = nh_pick_pt(B, H, W);
+  out->pt = q.pt;
+  out->ksplit = q.ksplit;
+  out->csplit = q.csplit;
   out->ks = (9 * r + 31) / 32;
+  out->pr = q.pr;
+  out->nsplit = q.nsplit;
   out->rank_pad = nh_rank_pad(r);
-  out->nsplit = nh_pick_split((int64_t)B * H * W, C_in, r);
   out->pf_elems = (int64_t)9 * C_in * 16;
   out->pd_elems = (int64_t)C_in * out->ks * 32;
-  out->down_part_floats = (int64_t)out->nsplit * out->rank_pad * C_in * 9;
+  out->t_part_floats = q.ksplit > 1 ? q.ksplit * M * r : 0;
+  out->down_part_floats = (int64_t)q.nsplit * out->rank_pad * C_in * 9;
   return LORA_AMD_OK;
 }
 
@@ -505,7 +585,8 @@ extern "C" int lora_amd_conv3_nhwc_plan(int32_t B, int32_t C_in, int32_t H, int3
                  name ": activations must be bf16 or f16");                                                       \
   LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, name ": rank %d outside [1,16]", r);                          \
   LORA_AMD_CHECK(nh_native(B, C_in, H, W, r), LORA_AMD_EINVAL,                                                    \
-                 name ": needs C_in %% 64 == 0, rank in {4, 8, 12, 16}, B*H*W*C_in < 2^31 (lora_amd_conv3_nhwc_plan)")
+                 name ": needs C_in %% 64 == 0, rank in {4, 8, 12, 16}, W <= 128, B*H*W*C_in < 2^31 "            \
+                      "(lora_amd_conv3_nhwc_plan)")
 
 extern "C" int lora_amd_conv3_nhwc_pack(const float *down, int32_t r, int32_t C_in, int32_t act_dtype, void *pf,
                                         void *pd, void *stream) {
@@ -528,26 +609,42 @@ extern "C" int lora_amd_conv3_nhwc_pack(const float *down, int32_t r, int32_t C_
   if (act_dtype == LORA_AMD_BF16) { LAUNCH(bf16_t) } \
   else { LAUNCH(f16_t) }
 
-extern "C" int lora_amd_conv3_nhwc_down_fwd(const void *x, const void *pf, float *t_out, int32_t B, int32_t C_in,
-                                            int32_t H, int32_t W, int32_t r, int32_t act_dtype, void *stream) {
+static int nh_launch_sum(const float *part, int nparts, int64_t n, float *out, void *stream) {
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(nh_sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     nparts, n4, out, n4);
+  return check_launch("lora_amd_sum_parts");
+}
+
+extern "C" int lora_amd_conv3_nhwc_down_fwd(const void *x, const void *pf, float *t_part, float *t_out, int32_t B,
+                                            int32_t C_in, int32_t H, int32_t W, int32_t r, int32_t act_dtype,
+                                            void *stream) {
   NH_COMMON("conv3_nhwc_down_fwd");
   LORA_AMD_CHECK(x && pf && t_out, LORA_AMD_EINVAL, "conv3_nhwc_down_fwd: null pointer");
-  LORA_AMD_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)pf % 16) == 0 && ((uintptr_t)t_out % 16) == 0, LORA_AMD_EINVAL,
-                 "conv3_nhwc_down_fwd: 16-byte aligned buffers");
-  const int pt = nh_pick_pt(B, H, W);
+  LORA_AMD_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)pf % 16) == 0 && ((uintptr_t)t_out % 16) == 0 &&
+                     ((uintptr_t)t_part % 16) == 0,
+                 LORA_AMD_EINVAL, "conv3_nhwc_down_fwd: 16-byte aligned buffers");
+  const NhCuts q = nh_cuts(B, C_in, H, W, r);
+  LORA_AMD_CHECK(q.ksplit == 1 || t_part != nullptr, LORA_AMD_EWORKSPACE,
+                 "conv3_nhwc_down_fwd: this geometry splits the channels over %d workgroups and needs t_part "
+                 "(plan.t_part_floats)", q.ksplit);
+  const int pt = q.pt;
   const NhGeom g = nh_geom(B, C_in, H, W, r, pt);
-  const unsigned grid = (unsigned)((int64_t)B * g.nrg * g.ntc);
+  const dim3 grid((unsigned)((int64_t)B * g.nrg * g.ntc), (unsigned)q.ksplit);
+  float *dst = q.ksplit > 1 ? t_part : t_out;
 #define NH_LAUNCH_T(E)                                                                                         \
   using S = typename E::storage;                                                                               \
-  if (pt == 4) hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 4>), dim3(grid), dim3(kNhThreads), 0,            \
-                                  (hipStream_t)stream, (const S *)x, (const S *)pf, t_out, g);                 \
-  else if (pt == 2) hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 2>), dim3(grid), dim3(kNhThreads), 0,       \
-                                       (hipStream_t)stream, (const S *)x, (const S *)pf, t_out, g);            \
-  else hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 1>), dim3(grid), dim3(kNhThreads), 0, (hipStream_t)stream, \
-                          (const S *)x, (const S *)pf, t_out, g);
+  if (pt == 4) hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 4>), grid, dim3(kNhThreads), 0,                  \
+                                  (hipStream_t)stream, (const S *)x, (const S *)pf, dst, g);                   \
+  else if (pt == 2) hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 2>), grid, dim3(kNhThreads), 0,             \
+                                       (hipStream_t)stream, (const S *)x, (const S *)pf, dst, g);              \
+  else hipLaunchKernelGGL((conv3_down_nhwc_kernel<E, 1>), grid, dim3(kNhThreads), 0, (hipStream_t)stream,     \
+                          (const S *)x, (const S *)pf, dst, g);
   NH_BY_DTYPE(NH_LAUNCH_T)
 #undef NH_LAUNCH_T
-  return check_launch("lora_amd_conv3_nhwc_down_fwd");
+  const int rc = check_launch("lora_amd_conv3_nhwc_down_fwd");
+  if (rc != LORA_AMD_OK || q.ksplit == 1) return rc;
+  return nh_launch_sum(t_part, q.ksplit, (int64_t)B * H * W * r, t_out, stream);
 }
 
 extern "C" int lora_amd_conv3_nhwc_bwd_dx(void *dx, const float *gt, const void *pd, int32_t B, int32_t C_in,
@@ -556,12 +653,13 @@ extern "C" int lora_amd_conv3_nhwc_bwd_dx(void *dx, const float *gt, const void 
   LORA_AMD_CHECK(dx && gt && pd, LORA_AMD_EINVAL, "conv3_nhwc_bwd_dx: null pointer");
   LORA_AMD_CHECK(((uintptr_t)dx % 16) == 0 && ((uintptr_t)pd % 16) == 0 && ((uintptr_t)gt % 16) == 0, LORA_AMD_EINVAL,
                  "conv3_nhwc_bwd_dx: 16-byte aligned buffers");
-  const int pt = std::min(nh_pick_pt(B, H, W), 2);  // PT * KS Gt fragments stay in registers
+  const NhCuts q = nh_cuts(B, C_in, H, W, r);
+  const int pt = q.pt_dx;
   const NhGeom g = nh_geom(B, C_in, H, W, r, pt);
-  const unsigned grid = (unsigned)((int64_t)B * g.nrg * g.ntc);
+  const dim3 grid((unsigned)((int64_t)B * g.nrg * g.ntc), (unsigned)q.csplit);
   const int KS = (9 * r + 31) / 32;
 #define NH_LAUNCH_DX2(E, PT_, KS_)                                                                      \
-  hipLaunchKernelGGL((conv3_dx_nhwc_kernel<E, PT_, KS_>), dim3(grid), dim3(kNhThreads), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((conv3_dx_nhwc_kernel<E, PT_, KS_>), grid, dim3(kNhThreads), 0, (hipStream_t)stream, \
                      (typename E::storage *)dx, gt, (const typename E::storage *)pd, g);
 #define NH_LAUNCH_DX(E)                                                         \
   if (pt == 2) {                                                                \
@@ -589,21 +687,21 @@ extern "C" int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, floa
                                             int32_t H, int32_t W, int32_t r, int32_t act_dtype, void *stream) {
   NH_COMMON("conv3_nhwc_bwd_down");
   LORA_AMD_CHECK(x && gt && down_part, LORA_AMD_EINVAL, "conv3_nhwc_bwd_down: null pointer");
-  const int64_t M = (int64_t)B * H * W;
+  LORA_AMD_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)gt % 16) == 0, LORA_AMD_EINVAL,
+                 "conv3_nhwc_bwd_down: 16-byte aligned buffers");
+  const NhCuts q = nh_cuts(B, C_in, H, W, r);
   const NhGeom g = nh_geom(B, C_in, H, W, r, 1);
-  const int nblk = (int)((M + 31) / 32);
-  const int nsplit = nh_pick_split(M, C_in, r), rank_pad = nh_rank_pad(r);
-  const dim3 grid((unsigned)(C_in / 32), (unsigned)nsplit);
-  const int NT = (9 * r + 15) / 16;  // r = 4: 3, 8: 5, 12: 7, 16: 9
-#define NH_LAUNCH_DD2(E, NT_)                                                                                   \
-  hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, NT_>), grid, dim3(kNhThreads), 0, (hipStream_t)stream,        \
-                     (const typename E::storage *)x, gt, down_part, g, nblk, nsplit, rank_pad);
+  const int rank_pad = nh_rank_pad(r);
+  const dim3 grid((unsigned)(C_in / 64), (unsigned)q.nsplit);
+#define NH_LAUNCH_DD2(E, RQ_)                                                                                   \
+  hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kNhThreads), 0, (hipStream_t)stream,        \
+                     (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad);
 #define NH_LAUNCH_DD(E)                    \
-  switch (NT) {                            \
+  switch (r / 4) {                         \
+    case 1: NH_LAUNCH_DD2(E, 1) break;     \
+    case 2: NH_LAUNCH_DD2(E, 2) break;     \
     case 3: NH_LAUNCH_DD2(E, 3) break;     \
-    case 5: NH_LAUNCH_DD2(E, 5) break;     \
-    case 7: NH_LAUNCH_DD2(E, 7) break;     \
-    default: NH_LAUNCH_DD2(E, 9) break;    \
+    default: NH_LAUNCH_DD2(E, 4) break;    \
   }
   NH_BY_DTYPE(NH_LAUNCH_DD)
 #undef NH_LAUNCH_DD

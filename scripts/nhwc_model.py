@@ -64,13 +64,14 @@ def pack(down, r, C, lo_model=False):
     return pf, pd
 
 
-def down_fwd(x, pf, B, H, W, C, r, PT):
-    """conv3_down_nhwc_kernel.  x [B, H, W, C] -> T [B*H*W, r]."""
+def down_fwd(x, pf, B, H, W, C, r, PT, ksplit=1):
+    """conv3_down_nhwc_kernel (+ the sum over the `ksplit` channel shares).  x [B, H, W, C] -> T [B*H*W, r]."""
     KC = C // 32
     ntc, nrg = (W + 15) // 16, (H + PT - 1) // PT
     xf = x.reshape(-1)
-    T = np.full((B * H * W, r), np.nan)
-    for bid in range(B * nrg * ntc):
+    Tp = np.full((ksplit, B * H * W, r), np.nan)
+    for bid, kz in ((bb, kk) for bb in range(B * nrg * ntc) for kk in range(ksplit)):
+        T = Tp[kz]
         tc = bid % ntc
         rgi = (bid // ntc) % nrg
         b = bid // ntc // nrg
@@ -82,7 +83,7 @@ def down_fwd(x, pf, B, H, W, C, r, PT):
             coloff = [clamp(xx + d - 1, W - 1) * C + LG * 8 for d in range(3)]
             colmask = [(xx + d - 1 >= 0) & (xx + d - 1 < W) for d in range(3)]
             acc = [np.zeros((64, 4)) for _ in range(PT)]
-            for kc in range(wave, KC, 4):
+            for kc in range(kz * 4 + wave, KC, 4 * ksplit):
                 for d in range(3):
                     pa = [pf[dy * 3 + d, kc] for dy in range(3)]
                     xr = []
@@ -110,10 +111,10 @@ def down_fwd(x, pf, B, H, W, C, r, PT):
                         for e in range(4):
                             if LG[l] * 4 + e < r:
                                 T[p, LG[l] * 4 + e] = v[l, e]
-    return T
+    return Tp.sum(0)
 
 
-def bwd_dx(dx, gt, pd, B, H, W, C, r, PT):
+def bwd_dx(dx, gt, pd, B, H, W, C, r, PT, csplit=1):
     """conv3_dx_nhwc_kernel.  dx [B, H, W, C] (modified in place), gt [B*H*W, r]."""
     KS = (9 * r + 31) // 32
     ntc, nrg = (W + 15) // 16, (H + PT - 1) // PT
@@ -144,10 +145,10 @@ def bwd_dx(dx, gt, pd, B, H, W, C, r, PT):
                     halves[t][h] = np.where(m, v, 0.0)
             for t in range(PT):
                 bg[t][ks] = np.concatenate(halves[t], axis=1)
-        for wave in range(4):
-            for cb in range(wave, C // 64, 4):
-                for sub in range(4):
-                    ct = cb * 4 + sub
+        for wave, cz in ((w, z) for w in range(4) for z in range(csplit)):
+            for cb in range(cz, C // 64, csplit):
+                if True:
+                    ct = cb * 4 + wave
                     for t in range(PT):
                         yy = y0 + t
                         a = np.zeros((64, 4))
@@ -160,71 +161,70 @@ def bwd_dx(dx, gt, pd, B, H, W, C, r, PT):
     return dx
 
 
-def bwd_down(x, gt, B, H, W, C, r, nsplit):
+def pick_pr(H, W):
+    """nh_pick_pr: image rows per dDown strip."""
+    pr = 0
+    for p in range(1, H + 1):
+        if (p + 2) * W * 8 <= 12 * 256 and (p + 2) * (W + 2) <= 432 and ((p * (W + 2) + 31) // 32) * 32 <= 456:
+            pr = p
+    return pr
+
+
+def bwd_down(x, gt, B, H, W, C, r, nsplit, PR=None):
     """conv3_ddown_nhwc_kernel.  Returns part [nsplit, rank_pad, C*9]."""
-    NT, CT = (9 * r + 15) // 16, 2
+    PR = PR or pick_pr(H, W)
     rank_pad = 4 if r <= 4 else 8 if r <= 8 else 16
-    HW = H * W
-    M = B * HW
-    nblk = (M + 31) // 32
-    xf, gf = x.reshape(-1), gt.reshape(-1)
+    WP = W + 2
+    spi = (H + PR - 1) // PR
+    nstrips = B * spi
+    SPP = PR * WP
+    KSP = (SPP + 31) // 32
+    nsplit = min(nsplit, nstrips)
     part = np.full((nsplit, rank_pad, C * 9), np.nan)
-    s_all = [nt * 16 + L15 for nt in range(NT)]
-    for cg in range(C // 32):
-        for sp in range(nsplit):
-            tot = [[np.zeros((64, 4)) for _ in range(NT)] for _ in range(CT)]
+    for cc in range(C // 64):
+        for sid in range(nsplit):
+            acc = [[np.zeros((64, 4)) for _ in range(9)] for _ in range(4)]
+            xs = np.zeros((432 + 41, 64))  # zeroed once: margins and tail are never written
+            gT = np.zeros((16, 456))
+            for s in range(sid, nstrips, nsplit):
+                b = s // spi
+                y0 = (s - b * spi) * PR
+                rows_valid = min(PR, H - y0)
+                for q in range((PR + 2) * W * 8):
+                    f, c16 = q >> 3, q & 7
+                    ryp = f // W
+                    xq = f - ryp * W
+                    y = y0 + ryp - 1
+                    val = x[b, y, xq, cc * 64 + c16 * 8: cc * 64 + c16 * 8 + 8] if 0 <= y < H else 0.0
+                    xs[ryp * WP + xq + 2, c16 * 8: c16 * 8 + 8] = val
+                for sp in range(KSP * 32):
+                    ry = sp // WP
+                    xx = sp - ry * WP
+                    ok = sp < SPP and 1 <= xx <= W and ry < rows_valid
+                    for j in range(r):
+                        gT[j, sp] = gt[(b * H + y0) * W + ry * W + xx - 1, j] if ok else 0.0
+                for wave in range(4):
+                    col = wave * 16 + L15
+                    for ks in range(KSP):
+                        sp0 = ks * 32 + LG * 8
+                        ga = np.stack([gT[L15[l], sp0[l]:sp0[l] + 8] for l in range(64)])
+                        for d in range(3):
+                            v = np.stack([xs[sp0 + WP * d + i, col] for i in range(10)], axis=1)  # [64, 10]
+                            acc[wave][d * 3 + 0] = mfma(ga, v[:, 0:8], acc[wave][d * 3 + 0])
+                            acc[wave][d * 3 + 1] = mfma(ga, v[:, 1:9], acc[wave][d * 3 + 1])
+                            acc[wave][d * 3 + 2] = mfma(ga, v[:, 2:10], acc[wave][d * 3 + 2])
             for wave in range(4):
-                for blk in range(sp * 4 + wave, nblk, nsplit * 4):
-                    p0 = blk * 32 + LG * 8
-                    pc = np.where(p0 < M, p0, 0)
-                    rem = pc % HW
-                    y, xq = rem // W, rem % W
-                    py, px, pv = [], [], []
-                    for e in range(8):
-                        pv.append(p0 + e < M)
-                        py.append(y.copy())
-                        px.append(xq.copy())
-                        xq = xq + 1
-                        wrap = xq == W
-                        xq = np.where(wrap, 0, xq)
-                        y = np.where(wrap, y + 1, y)
-                        y = np.where(y == H, 0, y)
-                    xa = []
-                    for ct in range(CT):
-                        v = np.zeros((64, 8))
-                        for e in range(8):
-                            p = np.where(pv[e], p0 + e, M - 1)
-                            raw = xf[p * C + cg * 32 + ct * 16 + L15]
-                            v[:, e] = np.where(pv[e], raw, 0.0)
-                        xa.append(v)
-                    for nt in range(NT):
-                        s = s_all[nt]
-                        live = s < 9 * r
-                        tap = np.where(live, s // r, 0)
-                        j = np.where(live, s - tap * r, 0)
-                        dy, dxx = tap // 3 - 1, tap % 3 - 1
-                        off = -(dy * W + dxx) * r + j
-                        v = np.zeros((64, 8))
-                        for e in range(8):
-                            ys, xs = py[e] - dy, px[e] - dxx
-                            ok = live & pv[e] & (ys >= 0) & (ys < H) & (xs >= 0) & (xs < W)
-                            idx = np.where(ok, (p0 + e) * r + off, 0)
-                            v[:, e] = np.where(ok, gf[idx], 0.0)
-                        for ct in range(CT):
-                            tot[ct][nt] = mfma(xa[ct], v, tot[ct][nt])
-            for ct in range(CT):
-                for nt in range(NT):
-                    s = s_all[nt]
+                for t in range(9):
                     for l in range(64):
-                        if s[l] < 9 * r:
-                            tap, j = s[l] // r, s[l] % r
-                            for e in range(4):
-                                c = cg * 32 + ct * 16 + LG[l] * 4 + e
-                                part[sp, j, c * 9 + tap] = tot[ct][nt][l, e]
+                        c = cc * 64 + wave * 16 + L15[l]
+                        for e in range(4):
+                            j = LG[l] * 4 + e
+                            if j < r:
+                                part[sid, j, c * 9 + t] = acc[wave][t][l, e]
     return part
 
 
-def check(B, H, W, C, r, PT, nsplit, seed=0):
+def check(B, H, W, C, r, PT, nsplit, seed=0, ksplit=1, csplit=1):
     import torch
     import torch.nn.functional as F
 
@@ -237,10 +237,10 @@ def check(B, H, W, C, r, PT, nsplit, seed=0):
     x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous().numpy()
     gt_rows = gt.permute(0, 2, 3, 1).reshape(-1, r).contiguous().numpy()
     pf, pd = pack(down.detach().numpy(), r, C)
-    T = down_fwd(x_nhwc, pf, B, H, W, C, r, PT)
+    T = down_fwd(x_nhwc, pf, B, H, W, C, r, PT, ksplit)
     e_t = np.abs(T - t.detach().permute(0, 2, 3, 1).reshape(-1, r).numpy()).max()
     dx = np.zeros((B, H, W, C))
-    bwd_dx(dx, gt_rows, pd, B, H, W, C, r, min(PT, 2))
+    bwd_dx(dx, gt_rows, pd, B, H, W, C, r, min(PT, 2), csplit)
     e_dx = np.abs(dx - x.grad.permute(0, 2, 3, 1).numpy()).max()
     part = bwd_down(x_nhwc, gt_rows, B, H, W, C, r, nsplit)
     dd = part[:, :r].sum(0).reshape(r, C, 3, 3)
@@ -249,8 +249,8 @@ def check(B, H, W, C, r, PT, nsplit, seed=0):
 
 
 if __name__ == "__main__":
-    for cfg in [(1, 5, 20, 64, 4, 2, 1), (2, 4, 7, 64, 8, 1, 2), (1, 3, 3, 64, 16, 4, 1), (1, 6, 16, 128, 12, 2, 1)]:
-        errs = check(*cfg)
+    for cfg in [(1, 5, 20, 64, 4, 2, 1), (2, 4, 7, 64, 8, 1, 2), (1, 3, 3, 64, 16, 4, 1), (1, 6, 16, 128, 12, 2, 3)]:
+        errs = check(*cfg, ksplit=1 if cfg[3] == 64 else 2, csplit=1 if cfg[3] == 64 else 2)
         print(cfg, ["%.2e" % e for e in errs])
         assert max(errs) < 1e-9, errs
     print("ok")

@@ -111,16 +111,21 @@ def test_host_pass_geometry_is_pure_host_arithmetic():
 
 def test_conv3_nhwc_plan_is_pure_host_arithmetic():
     """Geometry of the channels-last 3x3 kernels (csrc/conv_nhwc.hip): which sites qualify and how they are cut."""
-    assert C.sizeof(_C.Conv3NhwcPlan) == 48 and _C.Conv3NhwcPlan.pf_elems.offset == 24
+    assert C.sizeof(_C.Conv3NhwcPlan) == 64 and _C.Conv3NhwcPlan.pf_elems.offset == 32
     pl = _C.conv3_nhwc_plan(4, 320, 64, 64, 16)  # SD1.5 ResnetBlock2D conv at 512^2, batch 4, extended LoRA rank 16
     assert pl.native == 1 and pl.pt == 4 and pl.ks == 5 and pl.rank_pad == 16
+    assert pl.ksplit == 1 and pl.csplit == 1 and pl.t_part_floats == 0  # 256 / 512 pixel tiles fill the chip
     assert pl.pf_elems == 9 * 320 * 16 and pl.pd_elems == 320 * 5 * 32
-    assert 1 <= pl.nsplit <= 16 and pl.down_part_floats == pl.nsplit * 16 * 320 * 9
-    # dDown partials stay under ~15 % of the X stream
-    assert pl.nsplit * 16 * 320 * 9 * 4 <= 0.16 * (4 * 64 * 64 * 320 * 2)
+    assert pl.pr == 4 and (pl.pr + 2) * 64 * 8 <= 12 * 256  # strip of 4 rows (+2 halo rows) = 12 chunks per thread
+    assert 1 <= pl.nsplit <= 4 * 16 and pl.down_part_floats == pl.nsplit * 16 * 320 * 9
+    # dDown partials stay under ~30 % of the X stream
+    assert pl.nsplit * 16 * 320 * 9 * 4 <= 0.31 * (4 * 64 * 64 * 320 * 2)
     pl = _C.conv3_nhwc_plan(1, 1280, 12, 12, 4)  # the 12x12 maps of 768^2 images: native here (masked tile edges)
-    assert pl.native == 1 and pl.pt == 1 and pl.ks == 2 and pl.rank_pad == 4
-    for bad in [(4, 320, 64, 64, 3), (4, 320, 64, 64, 20), (4, 100, 64, 64, 4), (64, 2560, 256, 256, 4)]:
+    assert pl.native == 1 and pl.pt == 1 and pl.ks == 2 and pl.rank_pad == 4 and pl.pr == 12 and pl.nsplit == 1
+    assert pl.ksplit == 10 and pl.t_part_floats == 10 * 144 * 4  # 12 pixel tiles: the channels are split as well
+    assert 1 < pl.csplit <= 1280 // 64
+    for bad in [(4, 320, 64, 64, 3), (4, 320, 64, 64, 20), (4, 100, 64, 64, 4), (64, 2560, 256, 256, 4),
+                (1, 64, 8, 200, 4)]:
         assert _C.conv3_nhwc_plan(*bad).native == 0
     lib = _C.require()
     assert lib.lora_amd_conv3_nhwc_plan(1, 64, 8, 8, 65, C.byref(_C.Conv3NhwcPlan())) == -2
