@@ -408,6 +408,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # one process per GPU; rank 0 of the child job prints the JSON line
     torch.backends.cudnn.benchmark = bool(args.conv_find)
+    if args.conv_find:
+        # Find times every applicable solver once per convolution geometry; MIOpen's naive reference solvers
+        # (naive_conv_*: 150-260 ms per call at 768^2 NHWC, never the pick) would turn that into minutes of warm-up
+        for k in ("FWD", "BWD", "WRW"):
+            os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
     _C.require()
     rank, local, world = T.init_distributed("cuda")
     if world != args.gpus:

@@ -687,7 +687,7 @@ def conv3_nhwc_plan(B: int, C_in: int, H: int, W: int, r: int) -> Conv3NhwcPlan:
 def _nhwc_dims(x: torch.Tensor):
     """(B, C, H, W) of a logically-NCHW tensor whose memory is [B, H, W, C] contiguous."""
     B, Ci, H, W = x.shape
-    if x.stride() != (H * W * Ci, 1, W * Ci, Ci) and not (x.numel() == 0):
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):  # (size-1 dims may carry any stride)
         raise ValueError("lora_amd: expected a channels_last-contiguous [B, C, H, W] tensor")
     return B, Ci, H, W
 

@@ -323,28 +323,31 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
 //   * the B operand X^T (columns = channels, k = 8 consecutive pixels) is gathered from LDS with 2-byte reads at
 //     compile-time offsets i*136 (the 4 lane groups are 8 pixels = 1088 B apart: disjoint bank groups); the 10 values
 //     pixel-1 .. pixel+8 serve the three dx shifts of a row (two direct, one by v_alignbit);
-//   * wave w owns channels w*16 .. +15 of the chunk: 9 accumulators (one per tap) live in registers across ALL strips
-//     of the workgroup, no cross-wave reduction; the next strip's global loads are issued before the current one is
-//     multiplied.
+//   * 8 waves: wave w owns channels (w & 3)*16 .. +15 of the chunk and the k-steps of parity w >> 2; its 9 accumulators
+//     (one per tap) live in registers across ALL strips of the workgroup and the two parities meet once, at the end;
+//     the next strip's global loads and the next k-step's LDS reads are issued before the current MFMAs.
 // Output: part[sid][j][c*9 + tap] (the trainer's batched reduce folds the nsplit partials).
-constexpr int kDdRowB = 136;    // bytes per staged pixel
-constexpr int kDdMaxPix = 432;  // (PR + 2) * (W + 2) staged pixels at most
-constexpr int kDdTail = 41;     // front margin pixel + k-step overrun behind the last row (zero)
-constexpr int kDdGRow = 456;    // gT row length in elements (>= padded strip pixels rounded up to 32; multiple of 8)
-constexpr int kDdNld = 12;      // 16-byte chunks of X per thread and strip: (PR + 2) * W * 8 <= 12 * 256
+constexpr int kDdRowB = 136;      // bytes per staged pixel
+constexpr int kDdMaxPix = 432;    // (PR + 2) * (W + 2) staged pixels at most
+constexpr int kDdTail = 41;       // front margin pixel + k-step overrun behind the last row (zero)
+constexpr int kDdGRow = 456;      // gT row length in elements (>= padded strip pixels rounded up to 32; multiple of 8)
+constexpr int kDdThreads = 512;   // 8 waves: wave w owns channel tile (w & 3) and the k-steps of parity (w >> 2)
+constexpr int kDdNld = 6;         // 16-byte chunks of X per thread and strip: (PR + 2) * W * 8 <= 6 * 512
 
 template <class E, int RQ>
-__global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const typename E::storage *__restrict__ x,
-                                                                         const float *__restrict__ gt,
-                                                                         float *__restrict__ part, const NhGeom g,
-                                                                         int PR, int nsplit, int rank_pad) {
+__global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const typename E::storage *__restrict__ x,
+                                                                      const float *__restrict__ gt,
+                                                                      float *__restrict__ part, const NhGeom g,
+                                                                      int PR, int nsplit, int rank_pad) {
   using S = typename E::storage;
   using F = typename NhMfma<E>::frag;
   __shared__ __attribute__((aligned(16))) unsigned char xs[(kDdMaxPix + kDdTail) * kDdRowB];
   __shared__ __attribute__((aligned(16))) unsigned short gT[16 * kDdGRow];
+  static_assert(sizeof(xs) >= 4 * 9 * 64 * 16, "the cross-group reduction reuses the staging area");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
+  const int ctw = wave & 3, kg = wave >> 2;
   const int cc = blockIdx.x, sid = blockIdx.y;
   const int H = g.H, W = g.W, C = g.C, r = g.r, WP = W + 2;
   const int spi = (H + PR - 1) / PR, nstrips = g.B * spi;
@@ -352,14 +355,14 @@ __global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const t
   const int nchunks = (PR + 2) * W * 8;
 
   // everything that is never written below stays zero: the pixel margins of every staged row, the tail, ranks >= r
-  for (int i = tid; i < (int)(sizeof(xs) / 16); i += kNhThreads) reinterpret_cast<nu32x4 *>(xs)[i] = (nu32x4){0u, 0u, 0u, 0u};
-  for (int i = tid; i < (int)(sizeof(gT) / 16); i += kNhThreads) reinterpret_cast<nu32x4 *>(gT)[i] = (nu32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < (int)(sizeof(xs) / 16); i += kDdThreads) reinterpret_cast<nu32x4 *>(xs)[i] = (nu32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < (int)(sizeof(gT) / 16); i += kDdThreads) reinterpret_cast<nu32x4 *>(gT)[i] = (nu32x4){0u, 0u, 0u, 0u};
 
-  // strip-independent descriptors of this thread's X chunks and Gt pixels
+  // strip-independent descriptors of this thread's X chunks and of its Gt pixel
   int xrel[kDdNld], xlds[kDdNld], xry[kDdNld];
 #pragma unroll
   for (int u = 0; u < kDdNld; ++u) {
-    const int q = tid + kNhThreads * u;
+    const int q = tid + kDdThreads * u;
     const bool live = q < nchunks;
     const int f = live ? q >> 3 : 0, c16 = q & 7;
     const int ryp = f / W, xq = f - ryp * W;  // staged row 0 .. PR+1 (image row y0 - 1 + ryp), column
@@ -367,20 +370,14 @@ __global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const t
     xrel[u] = ((ryp - 1) * W + xq) * C + cc * 64 + c16 * 8;
     xlds[u] = (ryp * WP + xq + 2) * kDdRowB + c16 * 16;  // + 1 column margin + 1 front pixel
   }
-  int grel[2], gry[2];
-  bool gin[2], gst[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int sp = tid + kNhThreads * v;
-    gin[v] = sp < KSP * 32;
-    const int ry = sp / WP, xx = sp - ry * WP;
-    gst[v] = sp < SPP && xx >= 1 && xx <= W;
-    gry[v] = ry;
-    grel[v] = (ry * W + xx - 1) * r;
-  }
+  const int gsp = tid;  // padded strip pixel whose Gt row this thread stages (KSP * 32 <= 456 < 512)
+  const bool gin = gsp < KSP * 32;
+  const int gry = gsp / WP, gxx = gsp - gry * WP;
+  const bool gst = gsp < SPP && gxx >= 1 && gxx <= W;
+  const int grel = (gry * W + gxx - 1) * r;
 
   nu32x4 xr[kDdNld];
-  nf32x4 gr[2][RQ];
+  nf32x4 gr[RQ];
   auto prefetch = [&](int s) {
     const int b = s / spi, y0 = (s - b * spi) * PR;
     const int rows_valid = min(PR, H - y0);
@@ -392,19 +389,16 @@ __global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const t
       const bool ok = y >= 0 && y < H;
       xr[u] = *reinterpret_cast<const nu32x4 *>(xb + (ok ? xrel[u] : cc * 64 + (tid & 7) * 8));
     }
+    const bool ok = gst && gry < rows_valid;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const bool ok = gst[v] && gry[v] < rows_valid;
-#pragma unroll
-      for (int qd = 0; qd < RQ; ++qd) gr[v][qd] = *reinterpret_cast<const nf32x4 *>(gb + (ok ? grel[v] : 0) + 4 * qd);
-    }
+    for (int qd = 0; qd < RQ; ++qd) gr[qd] = *reinterpret_cast<const nf32x4 *>(gb + (ok ? grel : 0) + 4 * qd);
   };
 
   nf32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = (nf32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned short *xs16 = reinterpret_cast<const unsigned short *>(xs);
-  const int col = wave * 16 + l15;  // this lane's channel inside the chunk
+  const int col = ctw * 16 + l15;  // this lane's channel inside the chunk
 
   if (sid < nstrips) prefetch(sid);
   for (int s = sid; s < nstrips; s += nsplit) {
@@ -416,45 +410,54 @@ __global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const t
       const int y = y0 + xry[u];
       const unsigned m = (y >= 0 && y < H) ? 0xFFFFFFFFu : 0u;
       const nu32x4 v = xr[u] & (nu32x4){m, m, m, m};
-      if (tid + kNhThreads * u < nchunks) {
+      if (tid + kDdThreads * u < nchunks) {
         *reinterpret_cast<nu32x2 *>(xs + xlds[u]) = (nu32x2){v[0], v[1]};
         *reinterpret_cast<nu32x2 *>(xs + xlds[u] + 8) = (nu32x2){v[2], v[3]};
       }
     }
+    if (gin) {
+      const bool ok = gst && gry < rows_valid;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      if (gin[v]) {
-        const bool ok = gst[v] && gry[v] < rows_valid;
-        const int sp = tid + kNhThreads * v;
+      for (int qd = 0; qd < RQ; ++qd)
 #pragma unroll
-        for (int qd = 0; qd < RQ; ++qd)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            union { S s; unsigned short u; } cv;
-            cv.s = E::from_f(ok ? gr[v][qd][e] : 0.f);
-            gT[(qd * 4 + e) * kDdGRow + sp] = cv.u;
-          }
-      }
+        for (int e = 0; e < 4; ++e) {
+          union { S s; unsigned short u; } cv;
+          cv.s = E::from_f(ok ? gr[qd][e] : 0.f);
+          gT[(qd * 4 + e) * kDdGRow + gsp] = cv.u;
+        }
     }
     __syncthreads();
     if (s + nsplit < nstrips) prefetch(s + nsplit);  // in flight while this strip is multiplied
 
-    for (int ks = 0; ks < KSP; ++ks) {
+    // k-steps ks = kg, kg + 2, ...: the LDS reads of the next one are issued before the MFMAs of the current one
+    unsigned v[3][10];
+    nu32x4 gaw;
+    auto fetch = [&](int ks) {
       const int sp0 = ks * 32 + lg * 8;
-      const F ga = nh_frag_bits<E>(*reinterpret_cast<const nu32x4 *>(gT + l15 * kDdGRow + sp0));
+      gaw = *reinterpret_cast<const nu32x4 *>(gT + l15 * kDdGRow + sp0);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const unsigned short *src = xs16 + (sp0 + WP * d) * (kDdRowB / 2) + col;  // pixel (row + d - 1, column - 1)
-        unsigned v[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) v[i] = src[i * (kDdRowB / 2)];
-        unsigned P[5];
+        for (int i = 0; i < 10; ++i) v[d][i] = src[i * (kDdRowB / 2)];
+      }
+    };
+    int ks = kg;
+    if (ks < KSP) fetch(ks);
+    for (; ks < KSP; ks += 2) {
+      unsigned P[3][5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) P[k] = v[2 * k] | (v[2 * k + 1] << 16);
-        const nu32x4 fm = (nu32x4){P[0], P[1], P[2], P[3]};
-        const nu32x4 fp = (nu32x4){P[1], P[2], P[3], P[4]};
-        const nu32x4 f0 = (nu32x4){(P[0] >> 16) | (P[1] << 16), (P[1] >> 16) | (P[2] << 16),
-                                   (P[2] >> 16) | (P[3] << 16), (P[3] >> 16) | (P[4] << 16)};
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) P[d][k] = v[d][2 * k] | (v[d][2 * k + 1] << 16);
+      const F ga = nh_frag_bits<E>(gaw);
+      if (ks + 2 < KSP) fetch(ks + 2);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const nu32x4 fm = (nu32x4){P[d][0], P[d][1], P[d][2], P[d][3]};
+        const nu32x4 fp = (nu32x4){P[d][1], P[d][2], P[d][3], P[d][4]};
+        const nu32x4 f0 = (nu32x4){(P[d][0] >> 16) | (P[d][1] << 16), (P[d][1] >> 16) | (P[d][2] << 16),
+                                   (P[d][2] >> 16) | (P[d][3] << 16), (P[d][3] >> 16) | (P[d][4] << 16)};
         acc[d * 3 + 0] = NhMfma<E>::mma(ga, nh_frag_bits<E>(fm), acc[d * 3 + 0]);
         acc[d * 3 + 1] = NhMfma<E>::mma(ga, nh_frag_bits<E>(f0), acc[d * 3 + 1]);
         acc[d * 3 + 2] = NhMfma<E>::mma(ga, nh_frag_bits<E>(fp), acc[d * 3 + 2]);
@@ -462,16 +465,28 @@ __global__ __launch_bounds__(kNhThreads, 2) void conv3_ddown_nhwc_kernel(const t
     }
   }
 
-  // acc[tap][e] = dDown[rank lg*4 + e][channel cc*64 + wave*16 + l15][tap]
-  const int64_t row_len = (int64_t)C * 9;
-  const int c = cc * 64 + wave * 16 + l15;
+  // the two k-step groups of a channel tile meet in LDS (the staging area is free now)
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(xs);
+  if (kg == 1) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) *reinterpret_cast<nf32x4 *>(red + ((ctw * 9 + t) * 64 + lane) * 4) = acc[t];
+  }
+  __syncthreads();
+  if (kg == 0) {
+    // acc[tap][e] = dDown[rank lg*4 + e][channel cc*64 + ctw*16 + l15][tap]
+    const int64_t row_len = (int64_t)C * 9;
+    const int c = cc * 64 + ctw * 16 + l15;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = lg * 4 + e;
-      if (j < r) part[((int64_t)sid * rank_pad + j) * row_len + (int64_t)c * 9 + t] = acc[t][e];
+    for (int t = 0; t < 9; ++t) {
+      const nf32x4 o = acc[t] + *reinterpret_cast<const nf32x4 *>(red + ((ctw * 9 + t) * 64 + lane) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = lg * 4 + e;
+        if (j < r) part[((int64_t)sid * rank_pad + j) * row_len + (int64_t)c * 9 + t] = o[e];
+      }
     }
+  }
 }
 
 // ============================================================================ out = sum_p part[p]  (Gt column-tile partials)
@@ -506,7 +521,7 @@ static int nh_pick_pt(int B, int H, int W) {
 static int nh_pick_pr(int H, int W) {
   int pr = 0;
   for (int p = 1; p <= H; ++p)
-    if ((p + 2) * W * 8 <= kDdNld * kNhThreads && (p + 2) * (W + 2) <= kDdMaxPix &&
+    if ((p + 2) * W * 8 <= kDdNld * kDdThreads && (p + 2) * (W + 2) <= kDdMaxPix &&
         ((p * (W + 2) + 31) / 32) * 32 <= kDdGRow)
       pr = p;
   return pr;
@@ -694,7 +709,7 @@ extern "C" int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, floa
   const int rank_pad = nh_rank_pad(r);
   const dim3 grid((unsigned)(C_in / 64), (unsigned)q.nsplit);
 #define NH_LAUNCH_DD2(E, RQ_)                                                                                   \
-  hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kNhThreads), 0, (hipStream_t)stream,        \
+  hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kDdThreads), 0, (hipStream_t)stream,        \
                      (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad);
 #define NH_LAUNCH_DD(E)                    \
   switch (r / 4) {                         \

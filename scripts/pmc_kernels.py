@@ -28,6 +28,14 @@ CASES = {  # name -> algorithmic bytes (bf16 activations, f32 factors, r = 4); M
     "conv_bwd_g_kernel": ("conv G pass: read G", 4 * 320 * 4096 * 2),
     "conv_bwd_down_kernel": ("conv dDown pass: read X", 4 * 320 * 4096 * 2),
     "conv_bwd_dx_kernel": ("conv dX pass: read+write dX", 2 * 4 * 320 * 4096 * 2),
+    # channels-last form (csrc/conv_nhwc.hip), same site at rank 16: X once / dX read + write / X once; the packed
+    # factor (92 KB), T and Gt (1 MB each) are counted in the algorithmic bytes, the dDown partials are not
+    "conv3_down_nhwc_kernel": ("NHWC T = conv3x3(X; down) (4,320,64x64), r16: read X, pf; write T",
+                               4 * 320 * 4096 * 2 + 9 * 320 * 16 * 2 + 16384 * 16 * 4),
+    "conv3_dx_nhwc_kernel": ("NHWC dX += (4,320,64x64), r16: read+write dX, read Gt, pd",
+                             2 * 4 * 320 * 4096 * 2 + 16384 * 16 * 4 + 320 * 5 * 32 * 2),
+    "conv3_ddown_nhwc_kernel": ("NHWC dDown partials (4,320,64x64), r16: read X, Gt",
+                                4 * 320 * 4096 * 2 + 16384 * 16 * 4),
 }
 COPY_ELEMS = 192_634_880
 
@@ -89,6 +97,21 @@ def run():
         _C.conv_bwd_g(gc, tc, up, None, gtp, gt, upp, 1.0, 0.0, 0, 0)
         flush.fill_(4.0)
         _C.conv_bwd_x(xc, dxc, gt, down, dnp, ks)
+    r16 = 16
+    xl = xc.contiguous(memory_format=torch.channels_last)
+    dxl = torch.randn_like(xc).contiguous(memory_format=torch.channels_last)
+    down16 = torch.randn(r16, C, 3, 3, device=DEV) * 0.1
+    gt16 = torch.randn(Bc * Hh * Hh, r16, device=DEV)
+    np_ = _C.conv3_nhwc_plan(Bc, C, Hh, Hh, r16)
+    pf, pd = _C.conv3_nhwc_pack(down16, torch.bfloat16, np_)
+    part = torch.empty(int(np_.down_part_floats), device=DEV)
+    for _ in range(3):
+        flush.fill_(1.0)
+        _C.conv3_nhwc_down_fwd(xl, pf, r16)
+        flush.fill_(2.0)
+        _C.conv3_nhwc_bwd_dx_(dxl, gt16, pd)
+        flush.fill_(3.0)
+        _C.conv3_nhwc_bwd_down(xl, gt16, part)
     torch.cuda.synchronize()
 
 

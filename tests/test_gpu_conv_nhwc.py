@@ -159,7 +159,8 @@ def test_channels_last_module_equals_nchw_module_with_selector_and_sink():
         assert np.abs(a - b).max() <= tol * np.abs(a).max() + 1e-6
 
 
-REAL_SITES = [(1, 320, 96, 96), (1, 640, 48, 48), (1, 2560, 24, 24), (1, 1920, 48, 48), (4, 320, 64, 64), (4, 1280, 8, 8)]
+# (this test's time goes to the numpy oracle's im2col at these sizes: four sites, not every one)
+REAL_SITES = [(1, 320, 96, 96), (1, 2560, 24, 24), (1, 1280, 12, 12), (4, 1280, 8, 8)]
 
 
 @pytest.mark.parametrize("B,C,Hh,Ww", REAL_SITES)
