@@ -165,23 +165,39 @@ __global__ __launch_bounds__(kNhThreads) void conv3_down_nhwc_kernel(const typen
   for (int kc = blockIdx.y * 4 + wave; kc < KC; kc += 4 * ksplit) {
     const S *xk = x + kc * 32;
     const S *pk = pf + ((int64_t)kc * 64 + lane) * 8;
+    // every load of the k-step is issued before the first MFMA (9 weight fragments + 3 x (PT + 2) row fragments):
+    // the waits are then counted ones, in issue order, and the MFMAs start as the data arrives
+    nu32x4 praw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) praw[tap] = *reinterpret_cast<const nu32x4 *>(pk + (int64_t)(tap * KC) * 512);
+    nu32x4 xr[3][PT + 2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < PT + 2; ++q) xr[d][q] = *reinterpret_cast<const nu32x4 *>(xk + rowoff[q] + coloff[d]);
+    // opaque uses in issue order: the scheduler may not sink a load below them (left alone it keeps two loads in
+    // flight and waits for each pair: 14 memory round trips per k-step instead of one)
+    F pa[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("" : "+v"(praw[tap]));
+      pa[tap] = nh_frag_bits<E>(praw[tap]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < PT + 2; ++q) asm volatile("" : "+v"(xr[d][q]));
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      F pa[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) pa[dy] = *reinterpret_cast<const F *>(pk + (int64_t)((dy * 3 + d) * KC) * 512);
-      nu32x4 xr[PT + 2];
-#pragma unroll
-      for (int q = 0; q < PT + 2; ++q) xr[q] = *reinterpret_cast<const nu32x4 *>(xk + rowoff[q] + coloff[d]);
 #pragma unroll
       for (int q = 0; q < PT + 2; ++q) {
         const unsigned m = rowmask[q] & colmask[d];
-        xr[q] = xr[q] & (nu32x4){m, m, m, m};
+        xr[d][q] = xr[d][q] & (nu32x4){m, m, m, m};
       }
 #pragma unroll
       for (int t = 0; t < PT; ++t)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) acc[t] = NhMfma<E>::mma(pa[dy], nh_frag_bits<E>(xr[t + dy]), acc[t]);
+        for (int dy = 0; dy < 3; ++dy) acc[t] = NhMfma<E>::mma(pa[dy * 3 + d], nh_frag_bits<E>(xr[d][t + dy]), acc[t]);
     }
   }
 
@@ -259,6 +275,12 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
         gmask[t][ks][h] = (xok && ys >= 0 && ys < H) ? 0xFFFFFFFFu : 0u;
       }
     }
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(graw[t][ks][h]));  // all PT*KS*2 loads in flight, one wait
   F bg[PT][KS];
 #pragma unroll
   for (int t = 0; t < PT; ++t)
@@ -287,26 +309,37 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
     poff[t] = ((b * H + nh_clamp(yy, H - 1)) * W + nh_clamp(xx, W - 1)) * C + lg * 4;
   }
   const int NCB = C >> 6;
-  for (int cb = blockIdx.y; cb < NCB; cb += gridDim.y) {
-    {
-      const int ct = cb * 4 + wave;  // the four waves cover the pixel's 128-byte line of this block
-      F pa[KS];
+  // block cb + csplit's weight fragments and dX lines are requested before block cb is multiplied
+  F pa[KS];
+  nu32x2 prev[PT];
+  auto fetch = [&](int cb) {
+    const int ct = cb * 4 + wave;  // the four waves cover the pixel's 128-byte line of this block
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) pa[ks] = *reinterpret_cast<const F *>(pd + (((int64_t)ct * KS + ks) * 64 + lane) * 8);
-      nu32x2 prev[PT];
+    for (int ks = 0; ks < KS; ++ks) pa[ks] = *reinterpret_cast<const F *>(pd + (((int64_t)ct * KS + ks) * 64 + lane) * 8);
 #pragma unroll
-      for (int t = 0; t < PT; ++t) prev[t] = *reinterpret_cast<const nu32x2 *>(dx + poff[t] + ct * 16);
+    for (int t = 0; t < PT; ++t) prev[t] = *reinterpret_cast<const nu32x2 *>(dx + poff[t] + ct * 16);
+  };
+  int cb = blockIdx.y;
+  if (cb < NCB) fetch(cb);
+  for (; cb < NCB; cb += gridDim.y) {
+    const int ct = cb * 4 + wave;
+    F pc[KS];
+    nu32x2 pv[PT];
 #pragma unroll
-      for (int t = 0; t < PT; ++t) {
-        nf32x4 a = (nf32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) pc[ks] = pa[ks];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a = NhMfma<E>::mma(pa[ks], bg[t][ks], a);
-        union { nu32x2 v; S s[4]; } o;
-        o.v = prev[t];
+    for (int t = 0; t < PT; ++t) pv[t] = prev[t];
+    if (cb + (int)gridDim.y < NCB) fetch(cb + gridDim.y);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(E::to_f(o.s[e]) + a[e]);
-        if (pok[t]) *reinterpret_cast<nu32x2 *>(dx + poff[t] + ct * 16) = o.v;
-      }
+    for (int t = 0; t < PT; ++t) {
+      nf32x4 a = (nf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a = NhMfma<E>::mma(pc[ks], bg[t][ks], a);
+      union { nu32x2 v; S s[4]; } o;
+      o.v = pv[t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(E::to_f(o.s[e]) + a[e]);
+      if (pok[t]) *reinterpret_cast<nu32x2 *>(dx + poff[t] + ct * 16) = o.v;
     }
   }
 }
