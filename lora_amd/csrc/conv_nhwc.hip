@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kNhThreads) void conv3_down_nhwc_kernel(const typen
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  int bid = blockIdx.x;
+  // consecutive tiles (row groups of one image: they share halo rows) go to the same XCD, i.e. the same L2
+  int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
   const int tc = bid % g.ntc;
   bid /= g.ntc;
   const int rgi = bid % g.nrg, b = bid / g.nrg;
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  int bid = blockIdx.x;
+  // consecutive tiles (row groups of one image: they share halo rows) go to the same XCD, i.e. the same L2
+  int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
   const int tc = bid % g.ntc;
   bid /= g.ntc;
   const int rgi = bid % g.nrg, b = bid / g.nrg;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(kNhThreads) void conv3_dx_nhwc_kernel(typename E::s
 // ============================================================================ dDown partials
 // dDown[j, c, tap] = sum_p Gt[p, j] X[p + tap, c] contracts over PIXELS, which are strided in NHWC, so both operands
 // are staged through LDS:
-//   * a workgroup owns a 64-channel chunk `cc` and walks image-row strips s = sid, sid + nsplit, ... (PR rows each);
+//   * a workgroup owns a 64-channel chunk `cc` and walks a run of consecutive image-row strips (PR rows each);
 //     a strip's X rows y0-1 .. y0+PR (64 channels = one 128-byte line per pixel, coalesced 16-byte loads) are written
 //     [pixel][136 B] with a zero pixel left and right of every row and zero rows outside the image, so that a tap is a
 //     PURE SHIFT of the flat staged index (dy*(W+2) + dx) and the zero padding of the convolution needs no mask;
@@ -433,8 +435,12 @@ __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const type
   const unsigned short *xs16 = reinterpret_cast<const unsigned short *>(xs);
   const int col = ctw * 16 + l15;  // this lane's channel inside the chunk
 
-  if (sid < nstrips) prefetch(sid);
-  for (int s = sid; s < nstrips; s += nsplit) {
+  // this workgroup's strips are CONSECUTIVE ones (the halo rows two neighbours share are then re-read by the same
+  // workgroup a moment later: an L2 hit instead of a second trip to HBM)
+  const int per = (nstrips + nsplit - 1) / nsplit;
+  const int s_begin = sid * per, s_end = min(nstrips, s_begin + per);
+  if (s_begin < s_end) prefetch(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
     const int b = s / spi, y0 = (s - b * spi) * PR;
     const int rows_valid = min(PR, H - y0);
     __syncthreads();  // the previous strip has been multiplied (first trip: the zero fill is complete)
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const type
         }
     }
     __syncthreads();
-    if (s + nsplit < nstrips) prefetch(s + nsplit);  // in flight while this strip is multiplied
+    if (s + 1 < s_end) prefetch(s + 1);  // in flight while this strip is multiplied
 
     // k-steps ks = kg, kg + 2, ...: the LDS reads of the next one are issued before the MFMAs of the current one
     unsigned v[3][10];

@@ -186,7 +186,8 @@ def bwd_down(x, gt, B, H, W, C, r, nsplit, PR=None):
             acc = [[np.zeros((64, 4)) for _ in range(9)] for _ in range(4)]
             xs = np.zeros((432 + 41, 64))  # zeroed once: margins and tail are never written
             gT = np.zeros((16, 456))
-            for s in range(sid, nstrips, nsplit):
+            per = (nstrips + nsplit - 1) // nsplit
+            for s in range(sid * per, min(nstrips, sid * per + per)):
                 b = s // spi
                 y0 = (s - b * spi) * PR
                 rows_valid = min(PR, H - y0)
