@@ -383,7 +383,10 @@ __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const type
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const int ctw = wave & 3, kg = wave >> 2;
-  const int cc = blockIdx.x, sid = blockIdx.y;
+  // 1-D grid, XCD-aware: the C/64 chunk workgroups of one strip run (they read the same Gt rows) share an L2
+  const int nch = g.C >> 6;
+  const int logical = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int cc = logical % nch, sid = logical / nch;
   const int H = g.H, W = g.W, C = g.C, r = g.r, WP = W + 2;
   const int spi = (H + PR - 1) / PR, nstrips = g.B * spi;
   const int SPP = PR * WP, KSP = (SPP + 31) >> 5;
@@ -746,7 +749,7 @@ extern "C" int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, floa
   const NhCuts q = nh_cuts(B, C_in, H, W, r);
   const NhGeom g = nh_geom(B, C_in, H, W, r, 1);
   const int rank_pad = nh_rank_pad(r);
-  const dim3 grid((unsigned)(C_in / 64), (unsigned)q.nsplit);
+  const dim3 grid((unsigned)((C_in / 64) * q.nsplit));
 #define NH_LAUNCH_DD2(E, RQ_)                                                                                   \
   hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kDdThreads), 0, (hipStream_t)stream,        \
                      (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad);
