@@ -440,8 +440,8 @@ __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const type
 
   // this workgroup's strips are CONSECUTIVE ones (the halo rows two neighbours share are then re-read by the same
   // workgroup a moment later: an L2 hit instead of a second trip to HBM)
-  const int per = (nstrips + nsplit - 1) / nsplit;
-  const int s_begin = sid * per, s_end = min(nstrips, s_begin + per);
+  const int per = nstrips / nsplit, extra = nstrips - per * nsplit;  // the first `extra` workgroups take one more
+  const int s_begin = sid * per + min(sid, extra), s_end = s_begin + per + (sid < extra ? 1 : 0);
   if (s_begin < s_end) prefetch(s_begin);
   for (int s = s_begin; s < s_end; ++s) {
     const int b = s / spi, y0 = (s - b * spi) * PR;

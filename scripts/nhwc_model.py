@@ -186,8 +186,9 @@ def bwd_down(x, gt, B, H, W, C, r, nsplit, PR=None):
             acc = [[np.zeros((64, 4)) for _ in range(9)] for _ in range(4)]
             xs = np.zeros((432 + 41, 64))  # zeroed once: margins and tail are never written
             gT = np.zeros((16, 456))
-            per = (nstrips + nsplit - 1) // nsplit
-            for s in range(sid * per, min(nstrips, sid * per + per)):
+            per, extra = divmod(nstrips, nsplit)
+            s_begin = sid * per + min(sid, extra)
+            for s in range(s_begin, s_begin + per + (1 if sid < extra else 0)):
                 b = s // spi
                 y0 = (s - b * spi) * PR
                 rows_valid = min(PR, H - y0)
