@@ -373,7 +373,7 @@ template <class E, int RQ>
 __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const typename E::storage *__restrict__ x,
                                                                       const float *__restrict__ gt,
                                                                       float *__restrict__ part, const NhGeom g,
-                                                                      int PR, int nsplit, int rank_pad) {
+                                                                      int PR, int nsplit, int rank_pad, int xcd_aware) {
   using S = typename E::storage;
   using F = typename NhMfma<E>::frag;
   __shared__ __attribute__((aligned(16))) unsigned char xs[(kDdMaxPix + kDdTail) * kDdRowB];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kDdThreads) void conv3_ddown_nhwc_kernel(const type
   const int ctw = wave & 3, kg = wave >> 2;
   // 1-D grid, XCD-aware: the C/64 chunk workgroups of one strip run (they read the same Gt rows) share an L2
   const int nch = g.C >> 6;
-  const int logical = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_aware ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int cc = logical % nch, sid = logical / nch;
   const int H = g.H, W = g.W, C = g.C, r = g.r, WP = W + 2;
   const int spi = (H + PR - 1) / PR, nstrips = g.B * spi;
@@ -589,13 +589,17 @@ static NhCuts nh_cuts(int B, int C, int H, int W, int r) {
   if (cs <= 0) cs = tiles_dx >= 192 ? 1 : (int)nh_cdiv(256, tiles_dx);
   q.csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cs, C / 64));
   // factor gradient: strips of PR rows, dealt to nsplit workgroups per 64-channel chunk; the nsplit partials are
-  // nsplit * 18 r / M of the X stream: at most ~30 % of it, and ~256 workgroups in all
+  // nsplit * 18 r / M of the X stream: at most ~30 % of it (or 4 MB, whichever is more), <= 256 workgroups in all
   q.pr = nh_pick_pr(H, W);
   const int64_t nstrips = (int64_t)B * nh_cdiv(H, std::max(q.pr, 1));
   int ns = nh_env_int("LORA_AMD_NHWC_SPLIT", 0);
   if (ns <= 0) {
-    const int64_t cap = std::max<int64_t>(1, (int64_t)(0.30 * (double)M / (18.0 * r)));
-    ns = (int)std::min<int64_t>(nh_cdiv(256, C / 64), cap);
+    // at most one workgroup per CU (a 257th would share a CU with another one and double the critical path), the cap
+    // on the partial bytes, and then EQUAL shares: strips per workgroup = ceil(nstrips / that bound)
+    const int64_t cap = std::max<int64_t>((int64_t)(0.30 * (double)M / (18.0 * r)),
+                                          std::max<int64_t>(1, ((int64_t)4 << 20) / ((int64_t)nh_rank_pad(r) * C * 36)));
+    const int64_t bound = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256 / (C / 64), cap), nstrips));
+    ns = (int)nh_cdiv(nstrips, nh_cdiv(nstrips, bound));
   }
   q.nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ns, nstrips));
   return q;
@@ -752,7 +756,8 @@ extern "C" int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, floa
   const dim3 grid((unsigned)((C_in / 64) * q.nsplit));
 #define NH_LAUNCH_DD2(E, RQ_)                                                                                   \
   hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kDdThreads), 0, (hipStream_t)stream,        \
-                     (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad);
+                     (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad,          \
+                     nh_env_int("LORA_AMD_NHWC_DD_XCD", 1));
 #define NH_LAUNCH_DD(E)                    \
   switch (r / 4) {                         \
     case 1: NH_LAUNCH_DD2(E, 1) break;     \

@@ -118,8 +118,8 @@ def test_conv3_nhwc_plan_is_pure_host_arithmetic():
     assert pl.pf_elems == 9 * 320 * 16 and pl.pd_elems == 320 * 5 * 32
     assert pl.pr == 4 and (pl.pr + 2) * 64 * 8 <= 12 * 256  # strip of 4 rows (+2 halo rows) = 12 chunks per thread
     assert 1 <= pl.nsplit <= 4 * 16 and pl.down_part_floats == pl.nsplit * 16 * 320 * 9
-    # dDown partials stay under ~30 % of the X stream
-    assert pl.nsplit * 16 * 320 * 9 * 4 <= 0.31 * (4 * 64 * 64 * 320 * 2)
+    # dDown partials stay under ~30 % of the X stream or 4 MB, and one workgroup per CU at most
+    assert pl.nsplit * 16 * 320 * 9 * 4 <= max(0.31 * (4 * 64 * 64 * 320 * 2), 4 << 20) and pl.nsplit * (320 // 64) <= 256
     pl = _C.conv3_nhwc_plan(1, 1280, 12, 12, 4)  # the 12x12 maps of 768^2 images: native here (masked tile edges)
     assert pl.native == 1 and pl.pt == 1 and pl.ks == 2 and pl.rank_pad == 4 and pl.pr == 12 and pl.nsplit == 1
     assert pl.ksplit == 10 and pl.t_part_floats == 10 * 144 * 4  # 12 pixel tiles: the channels are split as well
