@@ -214,6 +214,13 @@ int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, co
 int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
                                 int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
                                 int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, void *stream);
+/* The same for a site whose branch had nn.Dropout (lora.py:45, 56): the G pass sees mask * G, the mask regenerated
+ * from (seed, offset [+ *offset_dev]) as lora_amd_linear_fwd indexed it.  Pairs with the dropout fields of
+ * lora_amd_ws_site (forward and input-gradient calls). */
+int lora_amd_linear_bwd_factors_drop(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
+                                     int64_t ldx, const float *gt, const float *sel, float *down_part, int64_t M,
+                                     int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale, float dropout_p,
+                                     uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
 /* The same for head-padded G and / or X rows (see lora_amd_linear_gemm_fwd_heads): g_head_* describe G [M, heads*D],
  * x_head_* describe X; the partials stay dense. */
 int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
@@ -262,6 +269,13 @@ typedef struct lora_amd_ws_site {
   int64_t ldy;
   int32_t N, r, panel_begin /* filled by the launcher */, flayout;
   float scale, t_scale;
+  /* nn.Dropout on the low-rank branch (lora.py:45, 56); 0 = off.  Mask indexing as lora_amd_linear_fwd /
+   * lora_amd_linear_bwd_g: element (m, n) of the site's [M, N] output (forward) resp. of G (input-gradient call, where
+   * the launch's contraction length K is that N).  Needs N % 8 == 0. */
+  float dropout_p;
+  int32_t reserved;
+  uint64_t seed, offset;
+  const uint64_t *offset_dev; /* device int64 added to `offset` (graph replay / checkpoint recompute), or NULL */
 } lora_amd_ws_site;
 
 int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);

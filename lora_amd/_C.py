@@ -32,7 +32,8 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
-    "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_heads", "lora_amd_linear_gemm_fwd_heads",
+    "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
+    "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
@@ -95,7 +96,9 @@ WS_MAX_SITES = 4
 class WsSite(C.Structure):
     _fields_ = [("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
                 ("t_out", C.c_void_p), ("ldy", C.c_int64), ("N", C.c_int32), ("r", C.c_int32),
-                ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float)]
+                ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float),
+                ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("offset_dev", C.c_void_p)]
 
 
 class ReduceDesc(C.Structure):
@@ -148,6 +151,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_x.argtypes = [vp, i64, vp, i64, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]
     lib.lora_amd_linear_bwd_factors.restype = C.c_int
+    lib.lora_amd_linear_bwd_factors_drop.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32,
+                                                     f32, u64, u64, vp, vp]
+    lib.lora_amd_linear_bwd_factors_drop.restype = C.c_int
     lib.lora_amd_linear_bwd_factors_heads.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32,
                                                       i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors_heads.restype = C.c_int
@@ -584,10 +590,21 @@ def linear_bwd_x(x: torch.Tensor, dx: Optional[torch.Tensor], gt_part: torch.Ten
 
 def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, x: torch.Tensor, gt: torch.Tensor,
                        down_part: torch.Tensor, r: int, scale: float, sel: Optional[torch.Tensor] = None,
-                       g_heads=None, x_heads=None) -> None:
+                       g_heads=None, x_heads=None, dropout=None) -> None:
     """dUp and dDown partials of a site in ONE launch (Gt already known: the fused MFMA backward produced it).
-    ``g_heads`` / ``x_heads`` = (heads, d, D) when G / X rows are head-padded (logical N / K = heads * d)."""
+    ``g_heads`` / ``x_heads`` = (heads, d, D) when G / X rows are head-padded (logical N / K = heads * d);
+    ``dropout`` = (p, seed, off) of the forward when the branch had nn.Dropout (dense rows only)."""
     _dev_check(g, t, up_part, x, gt, down_part, sel)
+    if dropout is not None and dropout[0] > 0.0:
+        if g_heads or x_heads:
+            raise ValueError("linear_bwd_factors: dropout with head-padded rows is not supported")
+        _check(require().lora_amd_linear_bwd_factors_drop(g.data_ptr(), g.stride(0), t.data_ptr(), up_part.data_ptr(),
+                                                          x.data_ptr(), x.stride(0), gt.data_ptr(), _ptr(sel),
+                                                          down_part.data_ptr(), g.shape[0], x.shape[1], g.shape[1], r,
+                                                          dtype_code(g.dtype), float(scale), float(dropout[0]),
+                                                          int(dropout[1]), *_off(dropout[2]), _stream()),
+               "lora_amd_linear_bwd_factors_drop")
+        return
     N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
     K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
     gd, gD = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
@@ -1036,7 +1053,8 @@ def ws_pack(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
 def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
     """One launch for every site in ``sites`` (all reading ``x`` [M, K]); each site is a dict with ``wp`` (packed
     weight), ``N``, ``down``, ``up``, ``scale`` and optionally ``bias``, ``y`` (output buffer, allocated if absent),
-    ``want_t`` (default True), ``t_scale``, ``flayout``.  Returns [(y, t), ...]."""
+    ``want_t`` (default True), ``t_scale``, ``flayout``, and ``p`` / ``seed`` / ``off`` for nn.Dropout on the branch (every
+    site of a launch or none; ``off`` an int or a 1-element int64 device tensor).  Returns [(y, t), ...]."""
     lib = require()
     M, K = x.shape
     if not 1 <= len(sites) <= WS_MAX_SITES:
@@ -1058,6 +1076,8 @@ def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
                                                     up.data_ptr(), _ptr(t))
         d.ldy, d.N, d.r, d.panel_begin, d.flayout = y.stride(0), N, r, 0, fl
         d.scale, d.t_scale = float(s["scale"]), float(s.get("t_scale", 1.0))
+        off_s, off_p = _off(s.get("off", 0))
+        d.dropout_p, d.seed, d.offset, d.offset_dev = float(s.get("p", 0.0)), int(s.get("seed", 0)), off_s, off_p
         outs.append((y, t))
         keep.append((down, up, bias))
     _check(lib.lora_amd_linear_ws(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), arr, len(sites), int(row_groups),
@@ -1065,16 +1085,18 @@ def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
     return outs
 
 
-def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0):
-    """(y, t) of ONE site through the weight-stationary kernel (same contract as :func:`linear_gemm_fwd`)."""
-    return linear_ws(x, [dict(wp=ws_pack(weight), N=weight.shape[0], bias=bias, down=down, up=up, scale=scale)],
-                     row_groups)[0]
+def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0):
+    """(y, t) of ONE site through the weight-stationary kernel (same contract as :func:`linear_gemm_fwd`);
+    ``p`` > 0: nn.Dropout on the low-rank branch, mask indexed as :func:`linear_fwd_` does."""
+    return linear_ws(x, [dict(wp=ws_pack(weight), N=weight.shape[0], bias=bias, down=down, up=up, scale=scale, p=p,
+                              seed=seed, off=off)], row_groups)[0]
 
 
-def linear_ws_dx(g, weight, down, up, scale, row_groups: int = 0):
-    """(dX [M,K], Gt [M,r] f32) = (G W + scale (G up) down, scale G up) of one site, weight-stationary on W^T."""
+def linear_ws_dx(g, weight, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0):
+    """(dX [M,K], Gt [M,r] f32) = (G W + scale ((mask*G) up) down, scale (mask*G) up) of one site, weight-stationary on
+    W^T (mask = the forward's dropout mask when ``p`` > 0, all ones otherwise)."""
     return linear_ws(g, [dict(wp=ws_pack(weight, True), N=weight.shape[1], down=up, up=down, scale=scale,
-                              t_scale=scale, flayout=3)], row_groups)[0]
+                              t_scale=scale, flayout=3, p=p, seed=seed, off=off)], row_groups)[0]
 
 
 _gemm_choice_bwd = _TuneCache("gemm_bwd")

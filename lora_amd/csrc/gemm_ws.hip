@@ -93,7 +93,12 @@ __device__ inline float ws_pin(float v) { asm volatile("" : "+v"(v)); return v; 
 // FL = factor layout of every site of the launch (0: down [r,K], up [N,r]; 3: down [K,r], up [r,N] — the input-gradient
 // call); RM = how a column's ranks are fetched from `up` when FL = 0: 1: r == 4 (one 16-byte load), 2: r % 4 == 0 (two),
 // 0: element by element.  Compile-time so that no load sits behind a branch whose join would drain the queue.
-template <class E, int KF, int CS, int RS, int FL, int RM>
+// DROP: nn.Dropout on the low-rank branch (lora.py:45, 56), mask regenerated from (seed, offset) exactly as
+// lora_amd_linear_fwd / lora_amd_linear_bwd_g index it (Philox chunk = 8 consecutive columns of a row of the [M, N] output):
+//   forward  — the rank-r term goes through its own MFMA, is multiplied by the lane's 4 mask values and added;
+//   backward — the G fragments that feed Gt = scale (mask*G) up are ANDed with the mask bits (one Philox call per
+//              fragment: its 8 k-slots are one chunk), 1/(1-p) is applied to T; the frozen product G W reads G unmasked.
+template <class E, int KF, int CS, int RS, int FL, int RM, bool DROP>
 __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a) {
   using S = typename E::storage;
   using F = typename WsMfma<E>::frag;
@@ -155,6 +160,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
   // their layout allows — forward layouts take 16-byte / 8-byte loads (16 instructions, 54 registers at r = 4)
   constexpr bool dn_kr = FL & 1, up_rk = FL & 2;
   const float scale = st.scale, t_scale = st.t_scale;
+  const Philox ph(st.seed);
+  const uint64_t doff = DROP ? dropout_offset(st.offset, st.offset_dev) : 0;
+  const uint32_t dthr = (uint32_t)(st.dropout_p * 65536.0f + 0.5f);
+  const float dkeep = 1.0f / (1.0f - st.dropout_p);
   const float *downp = st.down, *upp = st.up;
   float *t_out = st.t_out;
   constexpr bool up_vec = !up_rk && RM != 0;  // ranks of one column are contiguous 16-byte groups
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
     ws_barrier();  // ... and for every wave
     const char *xs = smem + (it % kWsSlots) * SLOT;
     f32x4 acc[RS][CS];
+    f32x4 lr[DROP && FL == 0 ? RS : 1][DROP && FL == 0 ? CS : 1];
 #pragma unroll
     for (int i = 0; i < RS; ++i)
 #pragma unroll
@@ -294,7 +304,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
           const int row = i * 16 + l15, c = (kf & 1) * 4 + lg;
-          const F xf = *reinterpret_cast<const F *>(xs + ((kf >> 1) * BM + row) * 128 + ((c ^ (row & 7)) << 4));
+          F xf = *reinterpret_cast<const F *>(xs + ((kf >> 1) * BM + row) * 128 + ((c ^ (row & 7)) << 4));
+          if (DROP && FL == 3) {  // Gt = scale (mask * G) up: the fragment's 8 columns are one Philox chunk
+            uint32_t rr[4];
+            ph((uint64_t)(((m0 + row) * (int64_t)K + kf * 32 + lg * 8) >> 3), doff, rr);
+            union { F f; u32x4 u; } mx;
+            mx.f = xf;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+              mx.u[w] &= ((rr[w] & 0xFFFFu) >= dthr ? 0x0000FFFFu : 0u) | ((rr[w] >> 16) >= dthr ? 0xFFFF0000u : 0u);
+            xf = mx.f;
+          }
           tacc[i] = WsMfma<E>::mma(dhi[q], xf, tacc[i]);
           tacc[i] = WsMfma<E>::mma(dlo[q], xf, tacc[i]);
         }
@@ -320,6 +340,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
           }
         }
       }
+      if (DROP && FL == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] *= dkeep;
+      }
       // T (f32) for the backward: row m0 + i*16 + l15; written by wave i % 4 of the site's first panel
       if (t_writer && (i & 3) == wave) {
         const int64_t m = m0 + i * 16 + l15;
@@ -333,9 +357,29 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
         }
       }
       const F tb = ws_make_frag<E>(tv);  // rounded to the activation dtype, as the reference's autocast does
+      if (DROP && FL == 0) {
+        // the rank-r term keeps its own accumulators (AGPRs, like acc): the mask is applied in the epilogue, where
+        // the values pass through VGPRs anyway (VALU updates of acc here would pull all of it out of the AGPRs: spills)
 #pragma unroll
-      for (int j = 0; j < CS; ++j) acc[i][j] = WsMfma<E>::mma(ub[j], tb, acc[i][j]);
+        for (int j = 0; j < CS; ++j) lr[i][j] = WsMfma<E>::mma(ub[j], tb, (f32x4){0.f, 0.f, 0.f, 0.f});
+      } else {
+#pragma unroll
+        for (int j = 0; j < CS; ++j) acc[i][j] = WsMfma<E>::mma(ub[j], tb, acc[i][j]);
+      }
     }
+    // mask * rank-r term of accumulator (i, j): the lane's 4 consecutive columns are half a Philox chunk
+    auto dropped = [&](int i, int j) -> f32x4 {
+      const int n0 = n_wave + j * 16 + lg * 4;
+      uint32_t rr[4];
+      ph((uint64_t)(((m0 + i * 16 + l15) * (int64_t)N + n0) >> 3), doff, rr);
+      const uint32_t ra = (n0 & 4) ? rr[2] : rr[0], rb = (n0 & 4) ? rr[3] : rr[1];
+      f32x4 o;
+      o[0] = ((ra & 0xFFFFu) >= dthr ? dkeep : 0.f) * lr[i][j][0];
+      o[1] = ((ra >> 16) >= dthr ? dkeep : 0.f) * lr[i][j][1];
+      o[2] = ((rb & 0xFFFFu) >= dthr ? dkeep : 0.f) * lr[i][j][2];
+      o[3] = ((rb >> 16) >= dthr ? dkeep : 0.f) * lr[i][j][3];
+      return o;
+    };
     // ---- epilogue: lane holds OUT[m = i*16 + l15][n_wave + j*16 + lg*4 + 0..3]
     if (a.debug & 1) {
     } else if (cols8 && !accum) {  // the common case, branch-free: 8-byte stores, always issued (rows past M -> trash line)
@@ -347,8 +391,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
 #pragma unroll
         for (int j = 0; j < CS; ++j) {
           union { u32x2 v; S s[4]; } o;
+          f32x4 val = acc[i][j];
+          if (DROP && FL == 0) val += dropped(i, j);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(acc[i][j][e] + bv[j][e]);
+          for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(val[e] + bv[j][e]);
           *reinterpret_cast<u32x2 *>(yr + j * jstep) = o.v;
         }
       }
@@ -373,8 +419,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
                 if (n_wave + j * 16 + lg * 4 + e < N) add[e] = E::to_f(yr[j * 16 + e]);
             }
           }
+          f32x4 val = acc[i][j];
+          if (DROP && FL == 0) val += dropped(i, j);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(acc[i][j][e] + bv[j][e] + add[e]);
+          for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(val[e] + bv[j][e] + add[e]);
           if (cols8) {  // always issued: exactly NY stores per tile
             u32x2 *dst = row_ok ? reinterpret_cast<u32x2 *>(yr + j * 16) : reinterpret_cast<u32x2 *>(g_ws_trash);
             *dst = o.v;
@@ -472,6 +520,16 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
                  "linear_ws: bad argument (1..%d sites)", LORA_AMD_WS_MAX_SITES);
   LORA_AMD_CHECK(((uintptr_t)x % 16) == 0 && ldx % 8 == 0 && ldx >= K, LORA_AMD_EINVAL,
                  "linear_ws: input rows must be 16-byte aligned");
+  bool drop = false;
+  for (int s = 0; s < nsites; ++s) {
+    LORA_AMD_CHECK(sites[s].dropout_p >= 0.f && sites[s].dropout_p < 1.f, LORA_AMD_EINVAL,
+                   "linear_ws: site %d: dropout p=%f", s, sites[s].dropout_p);
+    drop = drop || sites[s].dropout_p > 0.f;  // all sites of a launch or none (p = 0 sites would pay the Philox calls)
+  }
+  // forward with dropout at K = 320: the masked rank-r term keeps its own accumulators, which the 64-row tile has no
+  // registers left for (495 of 512 in use) -> 32-row tiles
+  const bool half_rows = drop && (sites[0].flayout & 3) == 0 && K == 320;
+  if (half_rows) c.RS = 2;
   const int BN = c.CS * 64, BM = c.RS * 16;
   WsArgs a;
   a.x = x; a.ldx = ldx; a.M = M; a.nsites = nsites;
@@ -517,16 +575,26 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
     rm = m == 0 ? 0 : (rm == 0 ? 0 : std::max(rm, m));
   }
   if (fl == 3) rm = 0;
-#define WS(E, KFV, CSV, RSV)                                                                                       \
+  for (int s = 0; s < nsites; ++s)
+    LORA_AMD_CHECK(!drop || sites[s].N % 8 == 0, LORA_AMD_EINVAL,
+                   "linear_ws: site %d: dropout needs N %% 8 == 0 (mask chunks of 8 columns)", s);
+#define WS_D(E, KFV, CSV, RSV, DV)                                                                                 \
   do {                                                                                                             \
-    if (fl == 3) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 3, 0>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else if (rm == 1) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 1>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else if (rm == 2) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 2>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 0>), dim3(grid), dim3(kWsThreads), 0, st, a);   \
+    if (fl == 3) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 3, 0, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+    else if (rm == 1) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 1, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+    else if (rm == 2) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 2, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+    else hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 0, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+  } while (0)
+#define WS(E, KFV, CSV, RSV)                                  \
+  do {                                                        \
+    if (drop) WS_D(E, KFV, CSV, RSV, true);                   \
+    else WS_D(E, KFV, CSV, RSV, false);                       \
   } while (0)
 #define WS_K(E)                                  \
   do {                                           \
-    if (K == 320) WS(E, 10, 5, 4);               \
+    if (K == 320 && half_rows) WS_D(E, 10, 5, 2, true); \
+    else if (K == 320 && drop) /* input gradient */ hipLaunchKernelGGL((linear_ws_kernel<E, 10, 5, 4, 3, 0, true>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+    else if (K == 320) WS_D(E, 10, 5, 4, false); \
     else if (K == 640) WS(E, 20, 2, 2);          \
     else if (K == 768) WS(E, 24, 2, 2);          \
     else WS(E, 40, 1, 1);                        \
@@ -534,5 +602,6 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
   if (act_dtype == LORA_AMD_BF16) WS_K(bf16_t); else WS_K(f16_t);
 #undef WS_K
 #undef WS
+#undef WS_D
   return check_launch("lora_amd_linear_ws");
 }

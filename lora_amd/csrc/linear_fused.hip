@@ -508,6 +508,9 @@ struct FactorJob {
   float mult;
   int C, log_ct8, nct, rows_per_block, nblocks;
   int hc, hp;            // head-padded rows of `data`: logical chunk c lives at (c / hc) * hp + c % hc; hc == 0: dense
+  float p;               // dropout on `data` (the G job of a site whose branch had nn.Dropout): mask chunk = (row*C + col) / 8
+  uint64_t seed, offset;
+  const uint64_t *offset_dev;
 };
 
 template <class E, int RT>
@@ -525,6 +528,9 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
   const int C = first ? a.C : b.C, log_ct8 = first ? a.log_ct8 : b.log_ct8, nct = first ? a.nct : b.nct;
   const int rows_per_block = first ? a.rows_per_block : b.rows_per_block;
   const int hc = first ? a.hc : b.hc, hp = first ? a.hp : b.hp;
+  const float dp = first ? a.p : b.p;  // block-uniform
+  const uint64_t dseed = first ? a.seed : b.seed;
+  const uint64_t doff = dp > 0.f ? dropout_offset(first ? a.offset : b.offset, first ? a.offset_dev : b.offset_dev) : 0;
 
   const int tid = threadIdx.x;
   const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
@@ -552,6 +558,16 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots;
       load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
+    }
+    if (dp > 0.f) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float mk[8];
+        const int64_t e = (m0 + rb0 + u * nslots) * (int64_t)C + col;
+        dropout_mult8(dseed, doff, (uint64_t)(e >> 3), dp, mk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] *= mk[i];
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -783,12 +799,27 @@ extern "C" int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64
   return check_launch("lora_amd_linear_bwd_x");
 }
 
+static int bwd_factors_impl(const void *g, int64_t ldg, const float *t, float *up_part, const void *x, int64_t ldx,
+                            const float *gt, const float *sel, float *down_part, int64_t M, int32_t K, int32_t N,
+                            int32_t r, int32_t act_dtype, float scale, int32_t g_head_dim, int32_t g_head_pad,
+                            int32_t x_head_dim, int32_t x_head_pad, float dropout_p, uint64_t seed, uint64_t offset,
+                            const uint64_t *offset_dev, void *stream);
+
 extern "C" int lora_amd_linear_bwd_factors(const void *g, int64_t ldg, const float *t, float *up_part, const void *x,
                                            int64_t ldx, const float *gt, const float *sel, float *down_part,
                                            int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, float scale,
                                            void *stream) {
-  return lora_amd_linear_bwd_factors_heads(g, ldg, t, up_part, x, ldx, gt, sel, down_part, M, K, N, r, act_dtype,
-                                           scale, 0, 0, 0, 0, stream);
+  return bwd_factors_impl(g, ldg, t, up_part, x, ldx, gt, sel, down_part, M, K, N, r, act_dtype, scale, 0, 0, 0, 0,
+                          0.f, 0, 0, nullptr, stream);
+}
+
+extern "C" int lora_amd_linear_bwd_factors_drop(const void *g, int64_t ldg, const float *t, float *up_part,
+                                                const void *x, int64_t ldx, const float *gt, const float *sel,
+                                                float *down_part, int64_t M, int32_t K, int32_t N, int32_t r,
+                                                int32_t act_dtype, float scale, float dropout_p, uint64_t seed,
+                                                uint64_t offset, const uint64_t *offset_dev, void *stream) {
+  return bwd_factors_impl(g, ldg, t, up_part, x, ldx, gt, sel, down_part, M, K, N, r, act_dtype, scale, 0, 0, 0, 0,
+                          dropout_p, seed, offset, offset_dev, stream);
 }
 
 extern "C" int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, const float *t, float *up_part,
@@ -797,7 +828,18 @@ extern "C" int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, con
                                                  int32_t act_dtype, float scale, int32_t g_head_dim,
                                                  int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad,
                                                  void *stream) {
+  return bwd_factors_impl(g, ldg, t, up_part, x, ldx, gt, sel, down_part, M, K, N, r, act_dtype, scale, g_head_dim,
+                          g_head_pad, x_head_dim, x_head_pad, 0.f, 0, 0, nullptr, stream);
+}
+
+static int bwd_factors_impl(const void *g, int64_t ldg, const float *t, float *up_part, const void *x, int64_t ldx,
+                            const float *gt, const float *sel, float *down_part, int64_t M, int32_t K, int32_t N,
+                            int32_t r, int32_t act_dtype, float scale, int32_t g_head_dim, int32_t g_head_pad,
+                            int32_t x_head_dim, int32_t x_head_pad, float dropout_p, uint64_t seed, uint64_t offset,
+                            const uint64_t *offset_dev, void *stream) {
   FUSED_COMMON("linear_bwd_factors", act_dtype, LORA_AMD_F32);
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || g_head_dim == 0), LORA_AMD_EINVAL,
+                 "linear_bwd_factors: dropout p=%f (dense G rows only)", dropout_p);
   auto heads_ok = [](int d, int D, int cols, int64_t ld) {
     return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
   };
@@ -810,9 +852,9 @@ extern "C" int lora_amd_linear_bwd_factors_heads(const void *g, int64_t ldg, con
   const int RT = frank_tile(r);
   const BwdGeom qg = bwd_geom(M, N, RT, 64), qx = bwd_geom(M, K, RT, 256);
   FactorJob a{g, ldg, t, nullptr, up_part, scale, N, qg.log_ct8, qg.nct, qg.rows_per_block, (int)(qg.nrb * qg.nct),
-              g_head_dim / 8, g_head_pad / 8};
+              g_head_dim / 8, g_head_pad / 8, dropout_p, seed, offset, offset_dev};
   FactorJob b{x, ldx, gt, sel, down_part, 1.0f, K, qx.log_ct8, qx.nct, qx.rows_per_block, (int)(qx.nrb * qx.nct),
-              x_head_dim / 8, x_head_pad / 8};
+              x_head_dim / 8, x_head_pad / 8, 0.f, 0, 0, nullptr};
   const unsigned grid = (unsigned)(a.nblocks + b.nblocks);
   hipStream_t st = (hipStream_t)stream;
 #define BF(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a, b, M, r)

@@ -186,12 +186,14 @@ class LoraLinearFunction(torch.autograd.Function):
             seed, off = next_dropout_stream(x.device)
         down_c, up_c = down.contiguous(), up.contiguous()
         tile = 0
-        if (dropout_p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
+        if (sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
                 and x2.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x2.dtype):
             # ONE launch on the matrix cores (frozen GEMM + low-rank branch): which kernel is a fixed function of the shape
             tile = _C.gemm_choice(x2, weight, bias, down_c, up_c, scale)
+            if dropout_p > 0.0 and (tile != _C.WS_TILE or N % 8):
+                tile = 0  # nn.Dropout on the branch: only the weight-stationary kernel regenerates the mask
         if tile == _C.WS_TILE:
-            y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale)
+            y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale, 0, dropout_p, seed, off)
             fused = _C.fused_ok(x2, N, r)
         elif tile:
             y, t = _C.linear_gemm_fwd(x2, weight, bias, down_c, up_c, scale, tile)
@@ -235,19 +237,21 @@ class LoraLinearFunction(torch.autograd.Function):
                                                for n in (plan.gt_part_floats, plan.up_part_floats,
                                                          plan.down_part_floats))
             tile = 0
-            if (need_x and p == 0.0 and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
+            if (need_x and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
                     and weight.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float16)
                     and weight.dtype == g2.dtype):
                 tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
+                if p > 0.0 and tile != _C.WS_TILE:
+                    tile = 0  # the mask of the forward: weight-stationary kernel or the three-launch path
             if tile:
                 # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch (weight-stationary on W^T packed in
                 # fragment order, or the LDS-ring kernel on the resident W^T); what remains are the parameter-gradient
                 # partials (G^T T and Gt^T X), both in one more launch
                 if tile == _C.WS_TILE:
-                    dx2, gt = _C.linear_ws_dx(g2, weight, down_c, up_c, s)
+                    dx2, gt = _C.linear_ws_dx(g2, weight, down_c, up_c, s, 0, p, seed, off)
                 else:
                     dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
-                _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s)
+                _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
             else:
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
                 dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM

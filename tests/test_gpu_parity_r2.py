@@ -794,3 +794,84 @@ def test_rank_beyond_kernel_limit_is_chunked_not_refused():
     quiet(L.collapse_lora, holder, 0.5)
     want = w0 + 0.5 * (m.lora_up.weight.detach() @ m.lora_down.weight.detach())
     assert torch.allclose(m.linear.weight.detach(), want, rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- nn.Dropout inside the fused MFMA kernels
+@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2048, 640, 640, 4, 0.25), (308, 768, 320, 8, 0.1),
+                                       (1000, 320, 2560, 16, 0.1)])
+def test_ws_kernel_dropout_forward_equals_two_launch_path(M, K, N, r, p):
+    """lora.py:45, 56 on the weight-stationary kernel: same (seed, offset) -> the SAME mask as lora_amd_linear_fwd
+    (Philox chunk = 8 consecutive columns of a row), so the fused output equals frozen GEMM + masked branch up to the
+    one extra rounding of the two-launch path."""
+    x, w, b = rnd((M, K), "bf16", seed=1), rnd((N, K), "bf16", 0.05, seed=2), rnd((N,), "bf16", seed=3)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.5, seed=5)
+    seed, s = 4321, 0.9
+    off = torch.tensor([977], dtype=torch.int64, device=DEV)
+    y_ws, t_ws = _C.linear_ws_fwd(x, w, b, down, up, s, 0, p, seed, off)
+    y_ref = F.linear(x, w, b)
+    base = y_ref.clone()
+    t_ref = _C.linear_fwd_(x, y_ref, down, up, s, None, p, seed, off)
+    branch = (y_ref.float() - base.float()).abs()
+    assert float(branch.max()) > 0.5 and 0.5 * p < float((branch == 0).float().mean()) < 2 * p + 0.02  # a real mask
+    e = 2.0 ** -8
+    tol = 3 * e * (y_ref.float().abs() + branch) + 2 * e * branch.max()  # T is rounded to bf16 before the up-projection
+    assert bool(((y_ws.float() - y_ref.float()).abs() <= tol).all()), float((y_ws.float() - y_ref.float()).abs().max())
+    np.testing.assert_allclose(n(t_ws), n(t_ref), rtol=1e-4, atol=1e-4 * float(t_ref.abs().max()))
+    # another offset -> another mask
+    y_2, _ = _C.linear_ws_fwd(x, w, b, down, up, s, 0, p, seed, 12345)
+    assert float((y_2.float() - y_ws.float()).abs().max()) > 0.5
+
+
+@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2048, 1280, 640, 4, 0.25)])
+def test_ws_kernel_dropout_input_gradient_and_factor_partials(M, K, N, r, p):
+    """Backward of the same site: Gt = s (mask*G) up and dX = G W + Gt down from the weight-stationary kernel, dUp
+    from lora_amd_linear_bwd_factors_drop — against the masked primitives (rowdot_masked / colreduce) with the same
+    (seed, offset)."""
+    g, x = rnd((M, N), "bf16", seed=1), rnd((M, K), "bf16", seed=6)
+    w = rnd((N, K), "bf16", 0.05, seed=2)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
+    t = rnd((M, r), "f32", 1.0, seed=7)
+    seed, off, s = 99, 31337, 0.8
+    dx, gt = _C.linear_ws_dx(g, w, down, up, s, 0, p, seed, off)
+    gt_ref = _C.rowdot(g, up, _C.FACTOR_KR, s, None, False, p, seed, off)
+    bound = s / (1 - p) * (n(g).__abs__() @ np.abs(n(up)))
+    close(n(gt), n(gt_ref), bound, "f32", k=2e-5, msg="Gt")  # mask bits exact, bf16 G exact, f32-accurate factor (hi+lo)
+    dx_ref = g.float() @ w.float() + gt_ref @ down
+    e = 2.0 ** -8
+    assert float((dx.float() - dx_ref).abs().max()) <= 4 * e * float(dx_ref.abs().max())
+    plan = _C.linear_plan(M, K, N, r)
+    up_part, down_part = (torch.empty(max(int(k), 1), device=DEV) for k in (plan.up_part_floats, plan.down_part_floats))
+    _C.linear_bwd_factors(g, t, up_part, x, gt_ref, down_part, r, s, dropout=(p, seed, off))
+    d_up, d_down = torch.empty((N, r), device=DEV), torch.empty((r, K), device=DEV)
+    rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+            (down_part, d_down, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    table, nn_, total = _C.make_reduce_table(rows, DEV)
+    _C.reduce_batched(table, nn_, total)
+    d_up_ref = _C.colreduce(g, t, _C.FACTOR_KR, s, dropout_p=p, seed=seed, offset=off)
+    d_down_ref = _C.colreduce(x, gt_ref, _C.FACTOR_RK, 1.0)
+    np.testing.assert_allclose(n(d_up), n(d_up_ref), rtol=2e-3, atol=2e-4 * float(d_up_ref.abs().max()))
+    np.testing.assert_allclose(n(d_down), n(d_down_ref), rtol=2e-3, atol=2e-4 * float(d_down_ref.abs().max()))
+
+
+def test_module_with_dropout_takes_the_fused_kernels_and_matches_the_three_launch_path(monkeypatch):
+    """LoraInjectedLinear in train mode with dropout 0.1 (what inject_trainable_lora_extended leaves on every site):
+    the fused path (weight-stationary forward and input gradient) against LORA_AMD_GEMM=0 (library GEMM + streaming
+    kernels) under the same torch seed, i.e. the same masks."""
+    res = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("LORA_AMD_GEMM", "0")
+        torch.manual_seed(11)
+        m = L.LoraInjectedLinear(320, 320, True, r=16, dropout_p=0.1, scale=1.0)
+        m.lora_up.weight.data.normal_(0, 0.2)
+        m.to(DEV)
+        m.linear.to(torch.bfloat16)
+        m.train()
+        x = torch.randn(4096, 320, device=DEV).to(torch.bfloat16).requires_grad_(True)
+        gy = torch.randn(4096, 320, device=DEV).to(torch.bfloat16)
+        torch.manual_seed(5)
+        y = m(x)
+        y.backward(gy)
+        res[mode] = [n(y), n(x.grad), n(m.lora_up.weight.grad), n(m.lora_down.weight.grad)]
+    for a, b, tol in zip(res["fused"], res["unfused"], (2.0 ** -6, 2.0 ** -6, 3e-3, 3e-3)):
+        assert np.abs(a - b).max() <= tol * np.abs(b).max() + 1e-6, np.abs(a - b).max() / np.abs(b).max()
