@@ -8,6 +8,8 @@ are the hand-written kernels of ``csrc/linear.hip``.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -30,6 +32,10 @@ def next_dropout_stream(device) -> tuple:
     The backward regenerates the mask from the same pair: no [M, N] mask tensor ever exists in HBM."""
     off = torch.empty(1, dtype=torch.int64, device=device).random_(0, 1 << 62)
     return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, off
+
+
+# nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
+WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "1") != "0"
 
 
 class GradSink:
@@ -190,7 +196,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 and x2.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x2.dtype):
             # ONE launch on the matrix cores (frozen GEMM + low-rank branch): which kernel is a fixed function of the shape
             tile = _C.gemm_choice(x2, weight, bias, down_c, up_c, scale)
-            if dropout_p > 0.0 and (tile != _C.WS_TILE or N % 8):
+            if dropout_p > 0.0 and (tile != _C.WS_TILE or N % 8 or not WS_DROPOUT):
                 tile = 0  # nn.Dropout on the branch: only the weight-stationary kernel regenerates the mask
         if tile == _C.WS_TILE:
             y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale, 0, dropout_p, seed, off)
@@ -241,7 +247,7 @@ class LoraLinearFunction(torch.autograd.Function):
                     and weight.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float16)
                     and weight.dtype == g2.dtype):
                 tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
-                if p > 0.0 and tile != _C.WS_TILE:
+                if p > 0.0 and (tile != _C.WS_TILE or not WS_DROPOUT):
                     tile = 0  # the mask of the forward: weight-stationary kernel or the three-launch path
             if tile:
                 # dX = G W + s (G up) down and Gt = s G up in ONE MFMA launch (weight-stationary on W^T packed in
