@@ -36,6 +36,7 @@ def next_dropout_stream(device) -> tuple:
 
 # nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
 WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "1") != "0"
+WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "1") == "2"
 
 
 class GradSink:
@@ -196,8 +197,14 @@ class LoraLinearFunction(torch.autograd.Function):
                 and x2.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x2.dtype):
             # ONE launch on the matrix cores (frozen GEMM + low-rank branch): which kernel is a fixed function of the shape
             tile = _C.gemm_choice(x2, weight, bias, down_c, up_c, scale)
-            if dropout_p > 0.0 and (tile != _C.WS_TILE or N % 8 or not WS_DROPOUT):
-                tile = 0  # nn.Dropout on the branch: only the weight-stationary kernel regenerates the mask
+            if dropout_p > 0.0:
+                # nn.Dropout on the branch: only the weight-stationary kernel regenerates the mask; with WS_DROPOUT_WIDE it
+                # also takes the shapes whose p = 0 choice is another kernel (the alternative here is the rank-16 VALU
+                # kernel on top of the library GEMM), except the 1280-deep GEGLU projections
+                if WS_DROPOUT_WIDE and tile != _C.WS_TILE and _C.ws_supported(x2, K, N, r) and not (K == 1280 and N >= 4 * K):
+                    tile = _C.WS_TILE
+                if tile != _C.WS_TILE or N % 8 or not WS_DROPOUT:
+                    tile = 0
         if tile == _C.WS_TILE:
             y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale, 0, dropout_p, seed, off)
             fused = _C.fused_ok(x2, N, r)
