@@ -35,8 +35,11 @@ def next_dropout_stream(device) -> tuple:
 
 
 # nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
-WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "1") != "0"
-WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "1") == "2"
+WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "2") != "0"
+# 2 (default): under dropout the weight-stationary forward also takes the shapes whose p = 0 choice is another kernel
+# (configs[3], same box: 21.26 -> 22.20 steps/s); 1: only the shapes of the p = 0 table; 3: the backward as well
+WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "2") in ("2", "3")
+WS_DROPOUT_WIDE_BWD = os.environ.get("LORA_AMD_WS_DROPOUT", "2") == "3"
 
 
 class GradSink:
@@ -254,6 +257,9 @@ class LoraLinearFunction(torch.autograd.Function):
                     and weight.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float16)
                     and weight.dtype == g2.dtype):
                 tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
+                if (p > 0.0 and WS_DROPOUT_WIDE_BWD and tile != _C.WS_TILE and M >= 256
+                        and _C.ws_supported(g2, N, K, r) and K % 8 == 0):
+                    tile = _C.WS_TILE
                 if p > 0.0 and (tile != _C.WS_TILE or not WS_DROPOUT):
                     tile = 0  # the mask of the forward: weight-stationary kernel or the three-launch path
             if tile:
