@@ -372,9 +372,7 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--channels-last", type=int, default=-1, help="NHWC activations/conv weights (the layout MIOpen's "
                     "implicit-GEMM convolutions run in; GroupNorm(+SiLU) has an NHWC HIP pass, and with --extended the "
-                    "Conv2d adapters take the channels-last MFMA kernels of csrc/conv_nhwc.hip).  0 = NCHW; -1 = on, "
-                    "except with --extended at batch 1 768^2, where the same box measured 18.47 (NCHW) vs 18.04 (NHWC) "
-                    "steps/s (profiles/r02_bench_cfg3*.json)")
+                    "Conv2d adapters take the channels-last MFMA kernels of csrc/conv_nhwc.hip).  0 = NCHW; -1 = on")
     ap.add_argument("--head-pad", type=int, default=1, help="q/k/v/out projections write / read the padded head layout "
                     "of the chosen attention kernel (LORA_AMD_HEAD_PAD; no pad / slice copies around the attention core)")
     ap.add_argument("--extended", type=int, default=0, help="inject_trainable_lora_extended: + ResnetBlock2D Conv2d "
@@ -407,7 +405,7 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.channels_last < 0:
-        args.channels_last = 0 if args.extended else 1
+        args.channels_last = 1
     os.environ.setdefault("LORA_AMD_HEAD_PAD", str(int(bool(args.head_pad))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # one process per GPU; rank 0 of the child job prints the JSON line

@@ -35,11 +35,12 @@ def next_dropout_stream(device) -> tuple:
 
 
 # nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
-WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "2") != "0"
-# 2 (default): under dropout the weight-stationary forward also takes the shapes whose p = 0 choice is another kernel
-# (configs[3], same box: 21.26 -> 22.20 steps/s); 1: only the shapes of the p = 0 table; 3: the backward as well
-WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "2") in ("2", "3")
-WS_DROPOUT_WIDE_BWD = os.environ.get("LORA_AMD_WS_DROPOUT", "2") == "3"
+WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "3") != "0"
+# 1: only the shapes of the p = 0 table (_C.static_fwd_choice / static_bwd_choice); 2: under dropout the forward also
+# takes the shapes whose p = 0 choice is another kernel (there the alternative is the rank-16 VALU kernel on top of the
+# library GEMM; configs[3], same box: 21.26 -> 22.20 steps/s); 3 (default): the backward as well (22.20 -> 22.44)
+WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "3") in ("2", "3")
+WS_DROPOUT_WIDE_BWD = os.environ.get("LORA_AMD_WS_DROPOUT", "3") == "3"
 
 
 class GradSink:

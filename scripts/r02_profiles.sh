@@ -8,8 +8,9 @@ OUT=gpurun_out
 mkdir -p $OUT
 timeout 400 python bench.py > $OUT/r02_bench_line.json 2> $OUT/r02_bench_line.err
 timeout 300 python bench.py --text-encoder 1 --rank 8 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg2.json 2> /dev/null
-timeout 400 python bench.py --extended 1 --rank 16 --res 768 --batch 1 --channels-last 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3_nhwc.json 2> $OUT/r02_bench_cfg3.err
-timeout 300 python bench.py --extended 1 --rank 16 --res 768 --batch 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3.json 2> /dev/null
+timeout 400 python bench.py --extended 1 --rank 16 --res 768 --batch 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3.json 2> $OUT/r02_bench_cfg3.err
+timeout 300 python bench.py --extended 1 --rank 16 --res 768 --batch 1 --channels-last 0 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3_nchw.json 2> /dev/null
+LORA_AMD_WS_DROPOUT=0 timeout 300 python bench.py --extended 1 --rank 16 --res 768 --batch 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_cfg3_unfused_dropout.json 2> /dev/null
 timeout 300 python bench.py --with-prior-preservation 1 --no-cpu-baseline --no-roofline > $OUT/r02_bench_prior.json 2> /dev/null
 timeout 200 python bench.py --svd --warmup 1 > $OUT/r02_bench_svd.json 2> /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r02_trace -o bench -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/r02_bench_traced.json 2> $OUT/r02_bench_traced.err
@@ -20,7 +21,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 python scripts/pmc_kernels.py reduce $OUT/r02_pmc_f $OUT/r02_pmc_w > $OUT/r02_adapter_pmc.json 2> $OUT/r02_pmc_reduce.err
 rm -rf $OUT/r02_pmc_f $OUT/r02_pmc_w
 timeout 120 python scripts/kbench.py --what nhwc > $OUT/r02_kbench_nhwc.log 2>&1
-for f in r02_bench_line r02_bench_cfg2 r02_bench_cfg3 r02_bench_cfg3_nhwc r02_bench_prior r02_bench_svd; do python - <<PY
+for f in r02_bench_line r02_bench_cfg2 r02_bench_cfg3 r02_bench_cfg3_nchw r02_bench_cfg3_unfused_dropout r02_bench_prior r02_bench_svd; do python - <<PY
 import json
 try:
     d = json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1]); print("$f", d["value"], d["unit"], d.get("ms_per_step"))

@@ -822,7 +822,7 @@ def test_ws_kernel_dropout_forward_equals_two_launch_path(M, K, N, r, p):
     assert float((y_2.float() - y_ws.float()).abs().max()) > 0.5
 
 
-@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2048, 1280, 640, 4, 0.25)])
+@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2048, 1280, 640, 4, 0.25), (576, 320, 1280, 16, 0.1)])
 def test_ws_kernel_dropout_input_gradient_and_factor_partials(M, K, N, r, p):
     """Backward of the same site: Gt = s (mask*G) up and dX = G W + Gt down from the weight-stationary kernel, dUp
     from lora_amd_linear_bwd_factors_drop — against the masked primitives (rowdot_masked / colreduce) with the same
