@@ -16,11 +16,13 @@ timeout 200 python bench.py --svd --warmup 1 > $OUT/r02_bench_svd.json 2> /dev/n
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r02_trace -o bench -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/r02_bench_traced.json 2> $OUT/r02_bench_traced.err
 python scripts/prof_summary.py $(find $OUT/r02_trace -name "*kernel_trace.csv" | head -1) 60 > $OUT/r02_bench_kernel_trace_summary.txt
 rm -rf $OUT/r02_trace
+if [ "${SKIP_PMC:-0}" != "1" ]; then
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/r02_pmc_f -o p -- python scripts/pmc_kernels.py run > /dev/null 2> $OUT/r02_pmc_f.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/r02_pmc_w -o p -- python scripts/pmc_kernels.py run > /dev/null 2> $OUT/r02_pmc_w.err
 python scripts/pmc_kernels.py reduce $OUT/r02_pmc_f $OUT/r02_pmc_w > $OUT/r02_adapter_pmc.json 2> $OUT/r02_pmc_reduce.err
 rm -rf $OUT/r02_pmc_f $OUT/r02_pmc_w
 timeout 120 python scripts/kbench.py --what nhwc > $OUT/r02_kbench_nhwc.log 2>&1
+fi
 for f in r02_bench_line r02_bench_cfg2 r02_bench_cfg3 r02_bench_cfg3_nchw r02_bench_cfg3_unfused_dropout r02_bench_prior r02_bench_svd; do python - <<PY
 import json
 try:
@@ -28,4 +30,4 @@ try:
 except Exception as e: print("$f FAILED", e)
 PY
 done
-head -c 1800 $OUT/r02_adapter_pmc.json
+
