@@ -188,3 +188,24 @@ def test_load_host_models_real_branch_with_fake_diffusers(tmp_path, monkeypatch)
     L.inject_trainable_lora(unet, r=2)
     assert isinstance(unet.attn1.to_q, L.LoraInjectedLinear)
     assert torch.allclose(unet.attn1(x), ref(unet.attn1, x, x), atol=1e-5)
+
+
+def test_conv_layout_routing_is_decided_from_strides_only():
+    """ops.lora_conv picks the channels-last kernels from the memory format (no device needed to decide): NHWC-only
+    tensors at 1x1 / 3x3 stride-1 sites in 16-bit; everything else keeps the NCHW kernels or the library-conv branch."""
+    import torch
+    from lora_amd import ops
+
+    x = torch.zeros(2, 64, 8, 8, dtype=torch.bfloat16)
+    xl = x.contiguous(memory_format=torch.channels_last)
+    w3, w1 = torch.zeros(32, 64, 3, 3, dtype=torch.bfloat16), torch.zeros(32, 64, 1, 1, dtype=torch.bfloat16)
+    geom3, geom1 = ((1, 1), (1, 1), (1, 1), 1), ((1, 1), (0, 0), (1, 1), 1)
+    assert not ops.conv_nhwc_ok(x, w3, 4, *geom3)  # plain NCHW
+    assert ops.conv_nhwc_ok(xl, w3, 4, *geom3) and ops.conv_nhwc_ok(xl, w1, 4, *geom1)
+    assert not ops.conv_nhwc_ok(xl, w3, 3, *geom3)  # rank 3: not a multiple of 4 -> NCHW kernels
+    assert ops.conv_nhwc_ok(xl, w1, 3, *geom1)      # 1x1 = the Linear adapter: any rank
+    assert not ops.conv_nhwc_ok(xl, w3, 4, (2, 2), (1, 1), (1, 1), 1)  # strided (Downsample2D)
+    assert not ops.conv_nhwc_ok(xl.float(), w3.float(), 4, *geom3)     # f32 activations
+    one = torch.zeros(2, 64, 1, 1, dtype=torch.bfloat16)  # H = W = 1: both formats at once -> NCHW path
+    assert not ops.conv_nhwc_ok(one, w1, 4, *geom1)
+    assert ops.WS_DROPOUT and ops.WS_DROPOUT_WIDE and ops.WS_DROPOUT_WIDE_BWD  # defaults (LORA_AMD_WS_DROPOUT unset)
