@@ -4,8 +4,10 @@ Every public name, signature, return shape, on-disk layout and quirk of the
 reference module (``/root/reference/lora_diffusion/lora.py``, cited per item as
 ``ref:LINE``) is kept; what changes is *how* the hot operations run:
 
-* adapter forward/backward on device tensors -> ``ops.lora_linear`` / ``ops.lora_conv_up``
-  (rowdot / rank_update / colreduce kernels) instead of 6 ATen launches per site;
+* adapter forward/backward on device tensors -> ``ops.lora_linear`` / ``ops.lora_linear_group`` / ``ops.lora_conv``:
+  one fused MFMA launch per site (or per q/k/v group) where the shape table says so, the streaming kernels
+  (rowdot / rank_update / colreduce) otherwise, NCHW or channels-last convolution kernels by memory format —
+  instead of 6 ATen launches per site;
 * ``collapse_lora`` on device tensors -> ONE batched launch of the fused
   ``W + alpha * up @ down`` kernel over all sites instead of 3 passes per site.
 

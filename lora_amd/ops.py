@@ -2,9 +2,12 @@
 
 Device tensors only: everything here ends in a call through the C-ABI
 (``_C.require()`` raises if the library is missing).  The frozen dense
-contractions (``X @ W^T``, ``G @ W``) are plain library GEMMs on MFMA
-(hipBLASLt via ``F.linear``/``matmul``); the low-rank branch and its gradients
-are the hand-written kernels of ``csrc/linear.hip``.
+contractions (``X @ W^T``, ``G @ W``) are either part of the fused MFMA kernels
+(``csrc/gemm_ws.hip``, ``csrc/gemm_fused.hip``: one launch for frozen product + low-rank
+branch, dropout included) or plain library GEMMs (hipBLASLt via ``F.linear``/``matmul``)
+followed by the streaming kernels of ``csrc/linear_fused.hip`` / ``csrc/linear.hip``;
+which one a site gets is a fixed function of its shape (``_C.static_fwd_choice``).
+Convolution sites: ``csrc/conv.hip`` (NCHW) or ``csrc/conv_nhwc.hip`` (channels_last).
 """
 from __future__ import annotations
 
