@@ -121,3 +121,30 @@ def dreambooth_step(unet, params, optimizer, latents, noise, timesteps, ehs, alp
     optimizer.step()
     optimizer.zero_grad()
     return loss.detach()
+
+
+def pti_loss_step(unet, latents, noise, timesteps, ehs, alphas_cumprod, mask=None, mask_temperature=1.0,
+                  prediction_type="epsilon"):
+    """ref: lora_diffusion/cli_lora_pti.py:260-370 (``loss_step``) with the random draws (noise :296, timesteps
+    :299-305) and the text-encoder output (:317-319 / :327-329) given, VAE skipped as under ``cached_latents``
+    (:288-289): add_noise (:307) -> unet (:331) -> target by prediction type (:333-338) -> optional mask: reshape to
+    the image grid (:342-349), nearest resize to the prediction's grid (:351-355), ``(mask + 0.01) ** temperature``
+    (:357), divide by its max (:359), multiply prediction AND target (:361-363) -> per-sample MSE, mean over the
+    batch (:365-369).  ``unet(noisy, t, ehs)`` returns the prediction tensor."""
+    a = alphas_cumprod[timesteps].to(latents.dtype)
+    sa, sb = a.sqrt().view(-1, 1, 1, 1), (1 - a).sqrt().view(-1, 1, 1, 1)
+    noisy = sa * latents + sb * noise
+    pred = unet(noisy, timesteps, ehs)
+    if prediction_type == "epsilon":
+        target = noise
+    elif prediction_type == "v_prediction":
+        target = sa * noise - sb * latents
+    else:
+        raise ValueError(f"Unknown prediction type {prediction_type}")
+    if mask is not None:
+        m = mask.to(pred.device).reshape(pred.shape[0], 1, pred.shape[2] * 8, pred.shape[3] * 8)
+        m = F.interpolate(m.float(), size=pred.shape[-2:], mode="nearest")
+        m = (m + 0.01).pow(mask_temperature)
+        m = m / m.max()
+        pred, target = pred * m, target * m
+    return F.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3]).mean()

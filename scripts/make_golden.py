@@ -289,6 +289,73 @@ def hostops_cases():
     np.savez(os.path.join(OUT, "hostops_cases.npz"), **out)
 
 
+def _reference_function(path: str, name: str, namespace: dict):
+    """Compile ONE top-level function of a reference file whose module cannot be imported here (its imports need
+    diffusers / fire) and return it, executed in ``namespace`` — the reference's own code object, nothing restated."""
+    import ast
+
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace[name]
+
+
+def pti_loss_cases():
+    """``loss_step`` of the reference's cli_lora_pti.py (:260-370), executed from its own source: the t_mutliplier
+    range of the timestep draw, both prediction types, the masked-MSE branch with a temperature, gradients w.r.t. the
+    toy UNet's parameters.  The draws are recovered by re-seeding and repeating the two calls loss_step makes."""
+    import torch.nn.functional as F
+    from lora_amd.standin import DDPMScheduler
+
+    loss_step = _reference_function("/root/reference/lora_diffusion/cli_lora_pti.py", "loss_step", {"torch": torch, "F": F})
+    torch.manual_seed(77)
+    unet, text = H.PtiToyUNet(), H.PtiToyText()
+    out = {f"unet_{k.replace('.', '_')}": H.t2n(v) for k, v in unet.state_dict().items()}
+    out["text_emb"] = H.t2n(text.emb.weight)
+    cases = [("plain", "epsilon", 1.0, False, 1.0), ("tmul", "epsilon", 0.8, False, 1.0),
+             ("mask", "epsilon", 0.8, True, 1.0), ("mask_temp", "epsilon", 0.8, True, 2.5),
+             ("vpred_mask", "v_prediction", 0.8, True, 0.5)]
+    g = torch.Generator().manual_seed(5)
+    for i, (tag, ptype, tmul, masked, temp) in enumerate(cases):
+        B, hw = 3, 6
+        sched = DDPMScheduler(prediction_type=ptype)
+        batch = {"pixel_values": torch.randn(B, 4, hw, hw, generator=g) * 0.18215,
+                 "input_ids": torch.randint(0, 20, (B, 5), generator=g)}
+        if masked:  # face-segmentation style: [B, H*8, W*8] with a soft blob, values in [0, 1]
+            m = torch.rand(B, hw * 8, hw * 8, generator=g)
+            m[:, : hw * 4] *= 0.1
+            batch["mask"] = m
+        unet.zero_grad()
+        torch.manual_seed(1000 + i)
+        loss = loss_step(batch, unet, None, text, sched, t_mutliplier=tmul, mask_temperature=temp, cached_latents=True)
+        loss.backward()
+        torch.manual_seed(1000 + i)  # the same two draws, in loss_step's order (:296, :299-305)
+        noise = torch.randn_like(batch["pixel_values"])
+        ts = torch.randint(0, int(1000 * tmul), (B,)).long()
+        assert int(ts.max()) < int(1000 * tmul)
+        out.update({f"{tag}_latents": H.t2n(batch["pixel_values"]), f"{tag}_ids": batch["input_ids"].numpy(),
+                    f"{tag}_noise": H.t2n(noise), f"{tag}_t": ts.numpy(), f"{tag}_loss": H.t2n(loss),
+                    f"{tag}_dconv": H.t2n(unet.conv.weight.grad), f"{tag}_dctx": H.t2n(unet.ctx.weight.grad),
+                    f"{tag}_meta": np.array([tmul, temp, float(ptype == "v_prediction"), 1000 + i], dtype=np.float64)})
+        if masked:
+            out[f"{tag}_mask"] = H.t2n(batch["mask"])
+    # non-cached branch (:272-277): a deterministic toy VAE (latent_dist.sample() returns the mean)
+    import types
+
+    class ToyVAE:
+        def encode(self, px):
+            lat = F.avg_pool2d(px, 8)[:, [0, 1, 2, 0]] * torch.tensor([1.0, -0.5, 0.25, 2.0]).view(1, 4, 1, 1)
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: lat))
+
+    px = torch.rand(2, 3, 48, 48, generator=g) * 2 - 1
+    batch = {"pixel_values": px, "input_ids": torch.randint(0, 20, (2, 5), generator=g)}
+    torch.manual_seed(2000)
+    loss = loss_step(batch, unet, ToyVAE(), text, DDPMScheduler(), t_mutliplier=1.0, cached_latents=False)
+    out.update({"vae_pixels": H.t2n(px), "vae_ids": batch["input_ids"].numpy(), "vae_loss": H.t2n(loss)})
+    np.savez(os.path.join(OUT, "pti_loss_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:  # regenerate only the named fixture sets, e.g. `make_golden.py conv_native_cases`
@@ -304,6 +371,7 @@ if __name__ == "__main__":
     example_lora_manifest()
     optimizer_cases()
     hostops_cases()
+    pti_loss_cases()
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn:40s} {os.path.getsize(os.path.join(OUT, fn)):>9d} B")

@@ -151,3 +151,42 @@ def nested_spec():
                                                     ["c", {"cls": "LoraInjectedConv2d", "kind": "lora_conv"}]]}],
         ["plain", _lin()],
     ]}
+
+
+# ---- toy models with the call contract of cli_lora_pti.loss_step (scripts/make_golden.py::pti_loss_cases)
+class PtiToyUNet(nn.Module):
+    """A few-parameter stand-in with the call contract loss_step uses: ``unet(x, t, ehs).sample`` and ``.device``."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(4, 4, 3, padding=1)
+        self.temb = nn.Linear(1, 4)
+        self.ctx = nn.Linear(12, 4)
+
+    @property
+    def device(self):
+        return self.conv.weight.device
+
+    @property
+    def dtype(self):
+        return self.conv.weight.dtype
+
+    def forward(self, x, t, ehs):
+        import types
+
+        h = self.conv(x) + self.temb(t.to(x.dtype).view(-1, 1) / 1000.0).view(-1, 4, 1, 1) \
+            + self.ctx(ehs.mean(1)).view(-1, 4, 1, 1)
+        return types.SimpleNamespace(sample=torch.tanh(h))
+
+
+class PtiToyText(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.emb = nn.Embedding(20, 12)
+
+    @property
+    def device(self):
+        return self.emb.weight.device
+
+    def forward(self, ids):
+        return (self.emb(ids),)
