@@ -78,7 +78,7 @@ def merge_roofline(unet, iters=30):
     avg_s = sum(a.elapsed_time(b) for a, b in evs) / (iters * inner) * 1e-3
     ach = plan.bytes_algorithmic / avg_s / 1e9
     traffic, traffic_src = None, None
-    pmc = next((p for p in (os.path.join(REPO, "profiles", f) for f in ("r02_merge_pmc.json", "r01_merge_pmc.json"))
+    pmc = next((p for p in (os.path.join(REPO, "profiles", f) for f in ("r03_merge_pmc.json", "r02_merge_pmc.json", "r01_merge_pmc.json"))
                 if os.path.exists(p)), "")  # offline rocprofv3 --pmc passes (scripts/profile_bench.sh)
     if os.path.exists(pmc):
         try:
@@ -244,13 +244,150 @@ def cpu_baseline(rank_r=4):
             "sample": "no bounded sample finished: " + "; ".join(errs)}
 
 
+# ----------------------------------------------------------------------------- adapter-path evidence
+def _site_bytes(phase: str, path: str, M: int, K: int, N: int, r: int, e: int = 2) -> int:
+    """Algorithmic HBM bytes of one adapter site.  A site whose frozen product runs INSIDE our launch is
+    priced with the fused formula (W, X, Y / G, X, dX, W once each); a site whose frozen product stays a library GEMM is
+    priced with the branch-only bound (read X + read-modify-write Y; backward: read G, read X, read-modify-write dX) —
+    the library GEMM's own time and bytes are then not the adapter path's."""
+    ab = (N + K) * r * 4
+    fused = not (path.startswith("lib") or path.startswith("g+lib") or path == "primitives")
+    if phase == "fwd":
+        return ((N * K + M * K + M * N) * e + ab) if fused else (M * K * e + 2 * M * N * e + ab)
+    return ((2 * M * K + M * N + N * K) * e + 2 * ab) if fused else (M * N * e + 3 * M * K * e + 2 * ab)
+
+
+def adapter_path_profile(step_fn, state) -> dict:
+    """One EAGER step under torch.profiler (kineto's device-side kernel records, i.e. kernel durations without launch
+    gaps): which kernel ran which adapter site (ops.PATH_LOG), device time of every lora_amd:: kernel, and the adapter
+    path's algorithmic bytes -> fraction of the HBM roof.  Adapter kernels = the Linear / Conv2d adapter launches, the
+    partial reduce and the flat-buffer optimiser; the frozen-UNet passes of csrc/hostops.hip are listed separately."""
+    from collections import Counter
+
+    from torch.profiler import ProfilerActivity, profile
+
+    from lora_amd import ops
+
+    step_fn()  # warm (lazy workspaces, tuning)
+    state.zero_grad()
+    torch.cuda.synchronize()
+    ops.PATH_LOG = []
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step_fn()
+            torch.cuda.synchronize()
+    finally:
+        log_, ops.PATH_LOG = ops.PATH_LOG, None
+    state.zero_grad()
+    host_pref = ("gn_", "ln_", "geglu_", "add_ln", "groupnorm", "layernorm")
+    kern, total_us, ours_us, host_us = {}, 0.0, 0.0, 0.0
+    for ev in prof.events():
+        if getattr(ev, "device_type", None) is None or "cuda" not in str(ev.device_type).lower():
+            continue
+        dur = float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
+        total_us += dur
+        name = ev.name
+        if "lora_amd::" not in name:
+            continue
+        short = name.split("lora_amd::", 1)[1].split("(")[0]
+        k = kern.setdefault(short, [0, 0.0])
+        k[0] += 1
+        k[1] += dur
+        if short.startswith(host_pref):
+            host_us += dur
+        else:
+            ours_us += dur
+    choices = Counter((ph, path) for ph, path, *_ in log_)
+    byts = sum(_site_bytes(*rec) for rec in log_)
+    fused_sites = sum(1 for ph, path, *_ in log_ if ph == "fwd" and not path.startswith("lib"))
+    out = {"how": "one eager step under torch.profiler (device-side kernel durations); bytes per SURVEY 8d: fused "
+                  "formula where the frozen product is inside our launch, branch-only bound where it is a library GEMM",
+           "gpu_ms_per_step": round(ours_us / 1e3, 3), "algorithmic_bytes_per_step": int(byts),
+           "frac": round(byts / (ours_us * 1e-6) / HBM_PEAK, 4) if ours_us else None, "bound": "hbm",
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": round(byts / (ours_us * 1e-6) / 1e9, 1) if ours_us else None,
+           "hostops_gpu_ms_per_step": round(host_us / 1e3, 3), "all_kernels_gpu_ms_per_step": round(total_us / 1e3, 3),
+           "sites_fwd_fused": fused_sites, "sites_fwd_total": sum(1 for ph, *_ in log_ if ph == "fwd"),
+           "kernels": {k: {"calls": v[0], "us": round(v[1], 1)} for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
+    return out, {f"{ph}:{path}": c for (ph, path), c in sorted(choices.items())}
+
+
+class AtenLoraLinear(torch.nn.Module):
+    """The reference's op sequence for one adapter (lora.py:53-58: linear, linear, linear, dropout, mul, add) as stock
+    ATen launches on the GPU — the `--adapters aten` comparison leg of bench.py only (what the same host model costs
+    with the reference's adapters instead of the HIP kernels).  Factors are cast to the compute dtype per call, as
+    autocast does."""
+
+    def __init__(self, src):
+        super().__init__()
+        self.linear, self.lora_down, self.lora_up = src.linear, src.lora_down, src.lora_up
+        self.dropout, self.scale = src.dropout, src.scale
+
+    def forward(self, x):
+        dt = x.dtype
+        low = torch.nn.functional.linear(torch.nn.functional.linear(x, self.lora_down.weight.to(dt)),
+                                         self.lora_up.weight.to(dt))
+        return self.linear(x) + self.dropout(low) * self.scale
+
+
+def swap_in_aten_adapters(model) -> int:
+    n = 0
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            if isinstance(child, L.LoraInjectedLinear):
+                parent._modules[name] = AtenLoraLinear(child)
+                n += 1
+    return n
+
+
+SECONDARY = [  # (tag, extra argv, env, timeout s): driver-observed lines for the other BASELINE geometries, short runs
+    ("host_options_off", ["--channels-last", "0", "--head-pad", "0", "--conv-find", "0"], {"LORA_AMD_HOSTOPS": "0"}, 150),
+    ("aten_adapters", ["--adapters", "aten"], {}, 150),
+    ("configs[2] UNet+CLIP rank 8", ["--text-encoder", "1", "--rank", "8"], {}, 150),
+    ("configs[3] extended rank 16 768^2 batch 1", ["--extended", "1", "--rank", "16", "--res", "768", "--batch", "1"], {}, 240),
+    ("prior preservation (8 samples/step)", ["--with-prior-preservation", "1"], {}, 150),
+    ("configs[4] cli_svd 224 sites rank 8", ["--svd", "--warmup", "1", "--no-cpu-baseline"], {}, 120),
+]
+
+
+def run_secondaries(budget_s: float, steps: int) -> list:
+    """Each secondary line is its own `python bench.py ...` child (fresh process, GPU shared sequentially), bounded by a
+    timeout and by the remaining budget; what does not fit is reported as skipped, never silently dropped."""
+    import subprocess
+
+    out, t_begin = [], time.perf_counter()
+    for tag, extra, env, tmo in SECONDARY:
+        left = budget_s - (time.perf_counter() - t_begin)
+        rec = {"tag": tag, "argv": " ".join(extra), "env": env}
+        if left < 30:
+            rec["skipped"] = "time budget of the default run spent"
+            out.append(rec)
+            continue
+        argv = [sys.executable, os.path.abspath(__file__)] + extra
+        if "--svd" not in extra:
+            argv += ["--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=min(tmo, left), env={**os.environ, **env})
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            rec.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
+                        "workload": d["config"].get("workload"), "wall_s": round(time.perf_counter() - t0, 1)})
+            if "roofline" in d:
+                rec["roofline_frac"] = d["roofline"].get("frac")
+        except subprocess.TimeoutExpired:
+            rec["skipped"] = f"did not finish in {min(tmo, left):.0f} s"
+        except Exception as e:  # noqa: BLE001
+            rec["skipped"] = f"{type(e).__name__}: {e}"
+        out.append(rec)
+    return out
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start one process per GPU ourselves, the way
     the driver's documented command does (torch.distributed.run, 127.0.0.1 rendezvous), and relay rank 0's JSON line."""
     import socket
     import subprocess
 
-    have = torch.cuda.device_count()
+    have = torch.cuda.device_count() if args.device == "cuda" else args.gpus
     if have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node")
     with socket.socket() as sk:
@@ -384,8 +521,17 @@ def main():
                     "(+5 %% steps/s measured; 0 = MIOpen's immediate-mode heuristic)")
     ap.add_argument("--with-prior-preservation", type=int, default=0, help="instance + class-prior batch (2 x --batch "
                     "samples per step, ref :698-702, 855-875); not the headline workload")
+    ap.add_argument("--adapters", choices=["hip", "aten"], default="hip", help="aten: the reference's op sequence "
+                    "(lora.py:53-58 as stock ATen launches) in place of the HIP adapter kernels, same host model: the "
+                    "comparison leg behind `secondary[aten_adapters]`")
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda", help="cpu: BASELINE configs[0]-style plumbing "
+                    "run (gloo for --gpus N > 1, f32, eager, no roofline); what the multi-rank CPU test drives")
+    ap.add_argument("--standin", choices=["sd15", "tiny"], default="sd15", help="tiny: 4-level miniature UNet (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary lines (other BASELINE "
+                    "geometries, host options off, ATen adapters) the default 1-GPU run appends under `secondary`")
+    ap.add_argument("--secondary-budget", type=float, default=420.0, help="seconds all secondary lines may take together")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--svd", action="store_true", help="time BASELINE configs[4] (cli_svd distillation, 224 sites) "
                     "instead of the training step; prints its own JSON line")
@@ -403,27 +549,41 @@ def main():
         print(json.dumps(svd_bench(args)), flush=True)
         return
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (use --device cpu for the plumbing run)"
     if args.channels_last < 0:
-        args.channels_last = 1
-    os.environ.setdefault("LORA_AMD_HEAD_PAD", str(int(bool(args.head_pad))))
+        args.channels_last = 1 if on_gpu else 0
+    os.environ.setdefault("LORA_AMD_HEAD_PAD", str(int(bool(args.head_pad and on_gpu))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # one process per GPU; rank 0 of the child job prints the JSON line
-    torch.backends.cudnn.benchmark = bool(args.conv_find)
-    if args.conv_find:
-        # Find times every applicable solver once per convolution geometry; MIOpen's naive reference solvers
-        # (naive_conv_*: 150-260 ms per call at 768^2 NHWC, never the pick) would turn that into minutes of warm-up
-        for k in ("FWD", "BWD", "WRW"):
-            os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
-    _C.require()
-    rank, local, world = T.init_distributed("cuda")
+    if on_gpu:
+        torch.backends.cudnn.benchmark = bool(args.conv_find)
+        if args.conv_find:
+            # Find times every applicable solver once per convolution geometry; MIOpen's naive reference solvers
+            # (naive_conv_*: 150-260 ms per call at 768^2 NHWC, never the pick) would turn that into minutes of warm-up
+            for k in ("FWD", "BWD", "WRW"):
+                os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
+        _C.require()
+    rank, local, world = T.init_distributed(args.device)
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    if on_gpu:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+        args.mode = "eager"
     torch.manual_seed(0)
+    cdt = torch.bfloat16 if on_gpu else torch.float32
 
-    unet = build_unet(dev, torch.bfloat16, seed=0)
+    if args.standin == "tiny":
+        from lora_amd.standin import tiny_unet
+
+        unet = tiny_unet(cross_attention_dim=768).to(dev).to(cdt)
+        unet.requires_grad_(False)
+    else:
+        unet = build_unet(dev, cdt, seed=0)
     if args.channels_last:
         unet.to(memory_format=torch.channels_last)
     if args.extended:
@@ -437,14 +597,19 @@ def main():
     if args.text_encoder:
         from lora_amd.standin import clip_text_model
 
-        text_encoder = clip_text_model().to(dev).to(torch.bfloat16)
+        text_encoder = clip_text_model().to(dev).to(cdt)
         text_encoder.requires_grad_(False)
         L.inject_trainable_lora(text_encoder, target_replace_module=["CLIPAttention"], r=args.lora_rank)
         T.promote_lora_to_fp32(text_encoder)
         text_encoder.train()
         groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
-    n_sites = state.attach_direct_grads(unet, *([text_encoder] if text_encoder is not None else []))
+    if args.adapters == "aten":
+        n_sites = swap_in_aten_adapters(unet) + (swap_in_aten_adapters(text_encoder) if text_encoder is not None else 0)
+    elif on_gpu:
+        n_sites = state.attach_direct_grads(unet, *([text_encoder] if text_encoder is not None else []))
+    else:
+        n_sites = sum(isinstance(m, (L.LoraInjectedLinear, L.LoraInjectedConv2d)) for m in unet.modules())
     sched = DDPMScheduler()
     cfg = T.StepConfig(with_prior_preservation=bool(args.with_prior_preservation))
     if args.with_prior_preservation:
@@ -452,16 +617,36 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank data shard
     hw = args.res // 8
-    latents = (torch.randn(args.batch, 4, hw, hw, device=dev, generator=g) * 0.18215).to(torch.bfloat16)
+    latents = (torch.randn(args.batch, 4, hw, hw, device=dev, generator=g) * 0.18215).to(cdt)
     if args.channels_last:
         latents = latents.contiguous(memory_format=torch.channels_last)
     if text_encoder is not None:
         ehs = torch.randint(0, 49408, (args.batch, 77), device=dev, generator=g)
     else:
-        ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(torch.bfloat16)
+        ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(cdt)
 
     def fwd_bwd(lat, cond):
         return T.forward_backward(unet, sched, lat, cond, cfg, text_encoder=text_encoder)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    # which kernel runs which site, device time of the adapter kernels, adapter-path bytes: one eager profiled step,
+    # BEFORE the capture (rank 0 of a 1-GPU run; its attention / MIOpen choices are the ones the graph then bakes in)
+    adapter_path, kernel_choices = None, {}
+    if on_gpu and rank == 0 and args.adapters == "hip" and not args.no_roofline:
+        def eager_step():
+            fwd_bwd(latents, ehs)
+            state.step(state.all_reduce())
+        try:
+            eager_step()  # first touch: attention candidates and MIOpen Find are timed here, not under the profiler
+            adapter_path, kernel_choices = adapter_path_profile(eager_step, state)
+        except Exception as e:  # noqa: BLE001 - the profiler is evidence, not the product: say so and go on
+            log(f"[bench] adapter-path profile failed: {type(e).__name__}: {e}")
+    barrier()
 
     mode = args.mode
     runner = fwd_bwd
@@ -479,20 +664,14 @@ def main():
         state.step(scale)
         return loss
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     barrier()
-    if rank == 0:  # which kernels the per-shape tuning settled on (stderr; the JSON line stays alone on stdout)
+    if rank == 0 and on_gpu:  # which kernels the per-shape tuning settled on (stderr; the JSON line stays alone on stdout)
         from lora_amd.standin import attention as _att
 
         log("[bench] attention kernels:", {k: v for k, v in _att.choices().items()})
-        log("[bench] fused-GEMM forward tiles:", dict(_C._gemm_choice))
-        log("[bench] fused-GEMM backward tiles:", dict(_C._gemm_choice_bwd))
+        log("[bench] adapter kernels per step:", kernel_choices)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -503,37 +682,48 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss_v = float(loss.item())
-    # the step's one collective on its real payload, timed on its own (HIP events, RCCL's stream ordering)
+    # the step's one collective on its real payload, timed on its own (HIP events, RCCL's stream ordering; host clock
+    # around gloo on CPU)
     allreduce_us = None
     if world > 1:
         buf = torch.zeros_like(state.flat_g)
         for _ in range(3):
             dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(20):
-            dist.all_reduce(buf)
-        b.record()
-        torch.cuda.synchronize()
-        allreduce_us = round(a.elapsed_time(b) / 20 * 1e3, 1)
-        log(f"[bench] RCCL ranks: {dist.get_world_size()} (backend {dist.get_backend()}); all-reduce of "
+        barrier()
+        if on_gpu:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                dist.all_reduce(buf)
+            b.record()
+            torch.cuda.synchronize()
+            allreduce_us = round(a.elapsed_time(b) / 20 * 1e3, 1)
+        else:
+            ta = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(buf)
+            allreduce_us = round((time.perf_counter() - ta) / 20 * 1e6, 1)
+        log(f"[bench] ranks: {dist.get_world_size()} (backend {dist.get_backend()}); all-reduce of "
             f"{state.payload_bytes} B: {allreduce_us} us")
 
     if rank == 0:
+        headline = not (args.extended or args.text_encoder or args.res != 512 or args.with_prior_preservation
+                        or args.standin != "sd15" or not on_gpu or args.adapters != "hip")
+        host_model = ("stand-in UNet2DConditionModel (859,520,964 params, random init)" if args.standin == "sd15"
+                      else "tiny stand-in UNet (plumbing)")
         out = {
             "metric": "train steps/sec SD1.5 rank-4 512^2 (train_lora_dreambooth.py step)",
             "value": round(args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if on_gpu else "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
                                     "latents), reference-default injection (%d Linear sites: Q/K/V/O + GEGLU), f32 LoRA "
                                     "masters, DDPM+MSE+clip(1.0)+AdamW" % (args.lora_rank, args.batch, n_sites))
-                       if not (args.extended or args.text_encoder or args.res != 512 or args.with_prior_preservation) else
-                       ("non-headline variant: rank %d, batch %d/GPU, %dx%d, extended=%d, text_encoder=%d, "
-                        "prior_preservation=%d, %d adapter sites" % (args.lora_rank, args.batch, args.res, args.res,
-                                                                   args.extended, args.text_encoder,
-                                                                   args.with_prior_preservation, n_sites)),
+                       if headline else
+                       ("non-headline variant: rank %d, batch %d/%s, %dx%d, extended=%d, text_encoder=%d, "
+                        "prior_preservation=%d, adapters=%s, host=%s, %d adapter sites"
+                        % (args.lora_rank, args.batch, "GPU" if on_gpu else "CPU rank", args.res, args.res, args.extended,
+                           args.text_encoder, args.with_prior_preservation, args.adapters, args.standin, n_sites)),
                        "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
                        "parallelism": f"dp{world}",
                        "value_counts": "optimizer updates per second of the whole job (train_lora_dreambooth.py's global step: "
@@ -543,22 +733,56 @@ def main():
                        "VAE encode and CLIP forward (ref :818-840) are outside it: latents and text states are the "
                        "synthetic inputs SURVEY 8d prescribes (cached_latents-style)",
                        "allreduce_us": allreduce_us,
-                       "kernel_choices": {"fused_gemm_fwd": dict(_C._gemm_choice), "fused_gemm_bwd": dict(_C._gemm_choice_bwd)},
+                       "kernel_choices": kernel_choices,
+                       "adapter_options": {"grouped_qkv_one_launch": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
+                                           "adapters": args.adapters},
                        "host_model_options": {"channels_last": bool(args.channels_last),
                                               "head_padded_projections": os.environ.get("LORA_AMD_HEAD_PAD") == "1",
                                               "fused_hostops": os.environ.get("LORA_AMD_HOSTOPS", "1") != "0",
-                                              "grouped_qkv": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
-                                              "miopen_find": bool(args.conv_find)},
-                       "execution": mode, "channels_last": bool(args.channels_last), "host_model": "stand-in UNet2DConditionModel "
-                       "(859,520,964 params, random init)", "trainable_params": state.n,
+                                              "miopen_find": bool(args.conv_find and on_gpu),
+                                              "scope": "stand-in UNet only (lora_amd/standin); a diffusers host gets the "
+                                                       "grouped q/k/v processor of diffusers_glue.py and nothing else"},
+                       "execution": mode, "channels_last": bool(args.channels_last), "host_model": host_model,
+                       "device": args.device, "trainable_params": state.n,
                        "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},
         }
         out["samples_per_s"] = out["config"]["samples_per_s"]
-        if not args.no_roofline:
+        if adapter_path is not None:
+            adapter_path["frac_of_step_time"] = round(adapter_path["gpu_ms_per_step"] / out["ms_per_step"], 4)
+            out["adapter_path"] = adapter_path
+            # the step against the byte roof: the time the adapter path's algorithmic bytes need at 8 TB/s over the
+            # measured step time (the rest of the step is the frozen UNet's library MFMA work, left to PyTorch)
+            out["step_hbm"] = {"adapter_algorithmic_bytes_per_step": adapter_path["algorithmic_bytes_per_step"],
+                               "floor_ms_at_peak": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK * 1e3, 4),
+                               "frac_of_step": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK
+                                                     / (out["ms_per_step"] * 1e-3), 5)}
+            pmc = os.path.join(REPO, "profiles", "r03_step_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    m = json.load(open(pmc))
+                    out["step_hbm"].update({"measured_hbm_bytes_per_step": m["hbm_bytes_per_step"],
+                                            "measured_GBs_at_this_step_time": round(m["hbm_bytes_per_step"] /
+                                                                                    (out["ms_per_step"] * 1e-3) / 1e9, 1),
+                                            "measured_frac_of_peak": round(m["hbm_bytes_per_step"] /
+                                                                           (out["ms_per_step"] * 1e-3) / HBM_PEAK, 4),
+                                            "source": "profiles/r03_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                      "summed over every dispatch of a step, separate passes)"})
+                    if "mfma" in m:
+                        out["mfma_util"] = m["mfma"]
+                except (KeyError, ValueError):
+                    pass
+        if on_gpu and not args.no_roofline:
             out["roofline"] = merge_roofline(unet)
             out["roofline_fused_gemm"] = gemm_roofline()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and on_gpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.lora_rank)
+        if world == 1 and on_gpu and headline and not args.no_secondary:
+            out["secondary"] = run_secondaries(args.secondary_budget, steps=10)
+            for rec in out["secondary"]:
+                if rec["tag"] == "host_options_off" and "value" in rec:
+                    out["value_host_options_off"] = rec["value"]
+                if rec["tag"] == "aten_adapters" and "value" in rec:
+                    out["value_aten_adapters"] = rec["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -988,6 +988,15 @@ def gemm_choice_bwd_cached(M: int, K: int, N: int, r: int, dtype: torch.dtype) -
     return None if c == WS_TILE else c
 
 
+def _tensor_version(t: torch.Tensor) -> int:
+    """``t._version``, or 0 for inference tensors (created under ``torch.inference_mode()``: they do not track one and
+    reading it raises; such a tensor cannot be modified in place outside inference mode either)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 def weight_t(weight: torch.Tensor) -> torch.Tensor:
     """Resident transposed copy [K, N] of a frozen [N, K] weight (the fused dX kernel contracts over N and wants it
     contiguous); built once per weight — frozen weights do not change during training, 288 GB of HBM make the second
@@ -998,7 +1007,7 @@ def weight_t(weight: torch.Tensor) -> torch.Tensor:
     the address alone could return another site's transpose after a free + re-allocation).  In-place edits through
     ``.data`` do not bump ``_version``; code that rewrites a frozen weight in place must call
     :func:`invalidate_weight_caches` (``collapse_lora``, ``monkeypatch_*`` and ``Module._apply`` of the adapters do)."""
-    key = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape))
+    key = (weight.data_ptr(), _tensor_version(weight), weight.dtype, tuple(weight.shape))
     hit = _wt_cache.get(key)
     if hit is None:
         if len(_wt_cache) >= 2048:
@@ -1009,7 +1018,10 @@ def weight_t(weight: torch.Tensor) -> torch.Tensor:
 
 
 def invalidate_weight_caches() -> None:
-    """Drop every derived layout of frozen weights (transposes and fragment-order packs for the fused kernels)."""
+    """Drop every derived layout of frozen weights (transposes and fragment-order packs for the fused kernels).
+    A captured hipGraph (``trainer.GraphedForwardBackward``) holds raw pointers into these buffers: re-capture after
+    anything that calls this (``collapse_lora``, ``monkeypatch_*``, ``Module.to``) — frozen weights do not change while
+    a training graph is alive, which is the only place graphs are used."""
     _wt_cache.clear()
     _ws_cache.clear()
 
@@ -1029,7 +1041,8 @@ def ws_pack(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """Frozen weight [N, K] in MFMA fragment order (``lora_amd_ws_pack``), built once and kept resident like
     :func:`weight_t` (same keep-the-source-alive cache discipline).  ``transposed``: pack W^T — the operand of the
     input gradient dX = G W (contraction over N) — straight from the [N, K] storage."""
-    key = (weight.data_ptr(), weight._version, weight.dtype, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
+    key = (weight.data_ptr(), _tensor_version(weight), weight.dtype, tuple(weight.shape), tuple(weight.stride()),
+           bool(transposed))
     hit = _ws_cache.get(key)
     if hit is None:
         if len(_ws_cache) >= 4096:

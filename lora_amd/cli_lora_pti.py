@@ -153,8 +153,8 @@ class PlaceholderRows:
         self.t += 1
         lam = min(1.0, 100 * lr) if clip_ti_decay and len(self.ids) else -1.0
         grad = self.emb.grad
-        if inv_scale is not None:  # fp16 loss scaling: the table gradient carries the scale of this backward; a
-            # non-finite row gradient (the LoRA step of the same batch was skipped) leaves the rows where they are
+        if inv_scale is not None:  # fp16 loss scaling: the table gradient carries the scale of this backward (the
+            # caller skips the whole step when the batch overflowed: PlaceholderRows.skip)
             grad = torch.nan_to_num(grad.float() * inv_scale, nan=0.0, posinf=0.0, neginf=0.0).to(grad.dtype)
             self.emb.grad = grad
         if world > 1:
@@ -180,6 +180,10 @@ class PlaceholderRows:
             self.emb.data[self.ids] = self.rows.to(self.emb.dtype)
         self.emb.grad = None
         return self.rows.norm(dim=-1)
+
+    def skip(self) -> None:
+        """An overflowed fp16 batch: drop the table gradient, leave rows, moments and the step count untouched."""
+        self.emb.grad = None
 
 
 def _freeze_all_but_token_embedding(text_encoder):
@@ -233,8 +237,15 @@ def perform_tuning(unet, vae, text_encoder, dataloader, num_steps, scheduler, st
                              mask_temperature=mask_temperature, cached_latents=cached_latents)
             (loss * state.loss_scale if state.loss_scale is not None else loss).backward()
             state.step(state.all_reduce())
+            applied = True
             if rows is not None:  # continue_inversion
-                rows.step(rows_lr * mult, world, False, inv_scale=state.scaler[2] if state.scaler is not None else None)
+                # GradScaler.step skips EVERY parameter of the optimiser on an overflowed batch (the placeholder rows
+                # sit in the same AdamW as the LoRA factors, ref :960-997): no moment update, no weight decay
+                applied = state.scaler is None or bool(state.scaler[3].item() > 0)
+                if applied:
+                    rows.step(rows_lr * mult, world, False, inv_scale=state.scaler[2] if state.scaler is not None else None)
+                else:
+                    rows.skip()
             global_step += 1
             if is_main and global_step % 10 == 0:
                 print(f"tuning step {global_step}/{num_steps} loss {loss.item():.5f} lr {state.lrs[0]:.3e}")
@@ -377,7 +388,9 @@ def train(instance_data_dir: str, pretrained_model_name_or_path: str, output_dir
     if wdt == torch.float16:
         state.enable_loss_scaling()
     perform_tuning(unet, vae, text_encoder, dataloader, max_train_steps_tuning, noise_scheduler, state, list(state.lrs),
-                   T.get_lr_lambda(lr_scheduler_lora, lr_warmup_steps_lora, max_train_steps_tuning, lr_init=unet_lr), save_steps,
+                   # the reference builds optim.AdamW(params_to_optimize, weight_decay=...) WITHOUT an lr (ref :997), so
+                   # diffusers' polynomial schedule reads lr_init = optimizer.defaults["lr"] = AdamW's 1e-3, not unet_lr
+                   T.get_lr_lambda(lr_scheduler_lora, lr_warmup_steps_lora, max_train_steps_tuning, lr_init=1e-3), save_steps,
                    placeholder_token_ids, placeholder_tokens, output_dir, lora_unet_target_modules,
                    lora_clip_target_modules, mask_temperature, out_name, cached_latents, rows, rows_lr, world, is_main)
     if world > 1:

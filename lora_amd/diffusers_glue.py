@@ -25,7 +25,12 @@ class LoraAmdAttnProcessor:
         plain = (hidden_states.dim() == 3 and attention_mask is None and getattr(attn, "norm_cross", None) is None
                  and getattr(attn, "group_norm", None) is None and getattr(attn, "spatial_norm", None) is None
                  and not getattr(attn, "residual_connection", False)
-                 and getattr(attn, "added_kv_proj_dim", None) is None)
+                 and getattr(attn, "added_kv_proj_dim", None) is None
+                 # qk-norm, fp32-upcast attention / softmax and fused q|k|v projections change what the block computes:
+                 # never approximate them, hand the call back
+                 and getattr(attn, "norm_q", None) is None and getattr(attn, "norm_k", None) is None
+                 and not getattr(attn, "upcast_attention", False) and not getattr(attn, "upcast_softmax", False)
+                 and not getattr(attn, "fused_projections", False))
         if not plain:
             if self.fallback is None:
                 raise NotImplementedError("LoraAmdAttnProcessor: attention variant outside the SD1.x pattern")

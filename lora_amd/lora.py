@@ -94,10 +94,10 @@ class _Adapter(nn.Module):
             return t.to(dt)
         cache = self.__dict__.setdefault("_shadow_cache", {})
         hit = cache.get(slot)
-        if hit is not None and hit[0] is t and hit[1] == (t.data_ptr(), t._version, dt):
+        if hit is not None and hit[0] is t and hit[1] == (t.data_ptr(), _C._tensor_version(t), dt):
             return hit[2]
         c = t.detach().to(dt)
-        cache[slot] = (t, (t.data_ptr(), t._version, dt), c)
+        cache[slot] = (t, (t.data_ptr(), _C._tensor_version(t), dt), c)
         return c
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .half(): every derived layout is stale

@@ -46,6 +46,16 @@ WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "3") in ("2", "3")
 WS_DROPOUT_WIDE_BWD = os.environ.get("LORA_AMD_WS_DROPOUT", "3") == "3"
 
 
+# When a list: every adapter forward / backward appends (phase, kernel path, M, K, N, r) — what bench.py turns into
+# ``config.kernel_choices`` and the adapter-path byte count.  None (default): nothing is recorded.
+PATH_LOG: Optional[list] = None
+
+
+def _log(phase: str, path: str, M: int, K: int, N: int, r: int) -> None:
+    if PATH_LOG is not None:
+        PATH_LOG.append((phase, path, int(M), int(K), int(N), int(r)))
+
+
 class GradSink:
     """Where one adapter's backward leaves its parameter gradients when a trainer owns them:
     views into the flat gradient buffer + persistent partial-sum workspaces.  The partials are summed
@@ -162,8 +172,18 @@ def rank_update_any_(y, t, f, layout, scale=1.0, p=0.0, seed=0, off=0):
     r = t.shape[1]
     if r <= _C.MAX_RANK:
         return _C.rank_update_(y, t, f, layout, scale, p, seed, off)
-    if p > 0.0:  # the mask belongs to the SUM over ranks: one masked update with the full product is needed
-        raise ValueError(f"lora_amd: dropout with rank {r} > {_C.MAX_RANK} is not supported on device")
+    if p > 0.0:
+        # the mask belongs to the SUM over ranks, so the chunks cannot be masked one by one: draw the mask itself with a
+        # rank-1 launch of the same kernel (ones x ones -> 0 or 1/(1-p) per element, indexed by (row, column) of the
+        # [M, N] output exactly as the backward's rowdot / colreduce regenerate it), then apply it to the full product
+        M, N = y.shape
+        one_t = torch.ones((M, 1), dtype=torch.float32, device=y.device)
+        one_f = torch.ones((1, N) if layout == _C.FACTOR_RK else (N, 1), dtype=torch.float32, device=y.device)
+        mask = _C.rank_update_(torch.zeros((M, N), dtype=torch.float32, device=y.device), one_t, one_f, layout, 1.0, p,
+                               seed, off)
+        ff = f.float()
+        y.add_((mask * (t @ (ff if layout == _C.FACTOR_RK else ff.t()))).mul_(scale).to(y.dtype))
+        return y
     for a, b in _rank_chunks(r):
         _C.rank_update_(y, t[:, a:b].contiguous(), _slice_factor(f, layout, a, b), layout, scale, 0.0, 0, 0)
     return y
@@ -215,17 +235,21 @@ class LoraLinearFunction(torch.autograd.Function):
         if tile == _C.WS_TILE:
             y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale, 0, dropout_p, seed, off)
             fused = _C.fused_ok(x2, N, r)
+            _log("fwd", "ws", x2.shape[0], K, N, r)
         elif tile:
             y, t = _C.linear_gemm_fwd(x2, weight, bias, down_c, up_c, scale, tile)
             fused = _C.fused_ok(x2, N, r)
+            _log("fwd", f"ring{tile}", x2.shape[0], K, N, r)
         else:
             y = F.linear(x2, weight, bias)  # frozen dense GEMM (MFMA, hipBLASLt)
             fused = down_c.dtype == up_c.dtype and _C.fused_ok(x2, N, r) and _C._rows_ok(y)
             if fused:
                 t = _C.linear_fwd_(x2, y, down_c, up_c, scale, sel, dropout_p, seed, off)
+                _log("fwd", "lib+linear_fwd", x2.shape[0], K, N, r)
             else:
                 t = rowdot_any(x2, down_c, _C.FACTOR_RK, 1.0, sel, False)
                 rank_update_any_(y, t, up_c, _C.FACTOR_KR, scale, dropout_p, seed, off)
+                _log("fwd", "lib+primitives", x2.shape[0], K, N, r)
         ctx.save_for_backward(x2, weight, down, up, t, sel)
         ctx.scale, ctx.p, ctx.seed, ctx.off = float(scale), float(dropout_p), seed, off
         ctx.has_bias, ctx.x_shape, ctx.sink, ctx.fused = bias is not None, x.shape, sink, fused
@@ -275,7 +299,9 @@ class LoraLinearFunction(torch.autograd.Function):
                 else:
                     dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
                 _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
+                _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors", M, K, N, r)
             else:
+                _log("bwd", "g+lib+x", M, K, N, r)
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
                 dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM
                 if dx2 is not None and not _C._rows_ok(dx2):
@@ -295,6 +321,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
         else:
             gt = None
+            _log("bwd", "primitives", M, K, N, r)
             if need_x or need_down:
                 gt = rowdot_any(g2, up_c, _C.FACTOR_KR, s, sel, True, p, seed, off)  # dT = s*(G.*mask) @ B @ S
             if need_up:
@@ -342,6 +369,7 @@ class LoraLinearHeadsFunction(torch.autograd.Function):
         x2 = _rows2d(x, _C.heads_width(K, in_heads))
         y, t = _C.linear_gemm_fwd(x2, weight, bias, down.contiguous(), up.contiguous(), scale, tile,
                                   x_heads=in_heads, y_heads=out_heads)
+        _log("fwd", f"ring{tile}_heads", x2.shape[0], K, N, down.shape[0])
         ctx.save_for_backward(x2, weight, down, up, t)
         ctx.scale, ctx.has_bias, ctx.x_shape, ctx.sink = float(scale), bias is not None, x.shape, sink
         ctx.in_heads, ctx.out_heads = in_heads, out_heads
@@ -387,6 +415,7 @@ class LoraLinearHeadsFunction(torch.autograd.Function):
         down_c, up_c = down.contiguous(), up.contiguous()
         dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile, g_heads=ctx.out_heads,
                                     dx_heads=ctx.in_heads)
+        _log("bwd", f"ring{tile}_heads_dx+factors", M, K, N, r)
         _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, None, g_heads=ctx.out_heads,
                               x_heads=ctx.in_heads)
         dx = dx2.view(*ctx.x_shape[:-1], dx2.shape[1]) if need_x else None
@@ -448,6 +477,8 @@ class LoraLinearGroupFunction(torch.autograd.Function):
         descs = [dict(wp=_C.ws_pack(w), N=w.shape[0], bias=b, down=d.contiguous(), up=u.contiguous(), scale=float(sc))
                  for (w, b, d, u, sc, _) in sites]
         outs = _C.linear_ws(x2, descs)
+        for d_ in descs:
+            _log("fwd", f"ws_group{n}", x2.shape[0], K, d_["N"], d_["down"].shape[0])
         ctx.save_for_backward(x2, *[t for _, t in outs], *[a for s_ in sites for a in (s_[0], s_[2], s_[3])])
         ctx.n, ctx.x_shape = n, x.shape
         ctx.meta = [(float(sc), sink, b is not None) for (_, b, _, _, sc, sink) in sites]
@@ -494,6 +525,7 @@ class LoraLinearGroupFunction(torch.autograd.Function):
                 (_, gt), = _C.linear_ws(g2, [dict(wp=_C.ws_pack(weight, True), N=K, down=up_c, up=down_c, scale=scale,
                                                   t_scale=scale, flayout=3 if first else 7, y=dx2)])
                 _C.linear_bwd_factors(g2, ts[i], up_part, x2, gt, down_part, r, scale)
+                _log("bwd", "ws_dx+factors", M, K, N, r)
                 if sink is not None:
                     sink.pending = key
                 else:
@@ -555,8 +587,8 @@ class LoraConvUpFunction(torch.autograd.Function):
             if dropout_p > 0.0:
                 seed, off = next_dropout_stream(y0.device)
             streams.append((seed, off))
-            _C.rank_update_(y0[b].view(Co, H * W), up2, t[b].view(r, H * W), _C.FACTOR_RK, scale, dropout_p,
-                            seed, off)
+            rank_update_any_(y0[b].view(Co, H * W), up2, t[b].view(r, H * W), _C.FACTOR_RK, scale, dropout_p,
+                             seed, off)
         ctx.mark_dirty(y0)
         ctx.save_for_backward(t, up2)
         ctx.scale, ctx.p, ctx.streams = float(scale), float(dropout_p), streams
@@ -577,10 +609,9 @@ class LoraConvUpFunction(torch.autograd.Function):
             seed, off = ctx.streams[b]
             gb = g[b].view(Co, H * W)
             if need_t:  # dT_b = scale * up^T @ (G_b .* mask)
-                _C.colreduce(gb, up2, _C.FACTOR_RK, ctx.scale, out=dt[b], beta=0.0, dropout_p=ctx.p, seed=seed,
-                             offset=off)
+                colreduce_any(gb, up2, _C.FACTOR_RK, ctx.scale, out=dt[b], beta=0.0, p=ctx.p, seed=seed, off=off)
             if need_up:  # dUp += scale * (G_b .* mask) @ T_b^T
-                part = _C.rowdot(gb, t[b].view(r, H * W), _C.FACTOR_RK, ctx.scale, None, False, ctx.p, seed, off)
+                part = rowdot_any(gb, t[b].view(r, H * W), _C.FACTOR_RK, ctx.scale, None, False, ctx.p, seed, off)
                 dup = part if dup is None else dup + part
         dt_out = dt.view(B, r, H, W).to(t.dtype) if need_t else None
         dup_out = dup.view(ctx.up_shape).to(ctx.up_dtype) if need_up else None

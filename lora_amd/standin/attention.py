@@ -14,6 +14,7 @@ import os
 from typing import Optional, Tuple
 
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
 try:
@@ -24,6 +25,7 @@ except ImportError:  # pragma: no cover
 from .._C import _TuneCache  # noqa: E402  (shared JSON cache of per-shape choices, LORA_AMD_TUNE_CACHE)
 
 _CHOICE = _TuneCache("sdpa")
+_AGREED = set()  # shapes whose kernel choice has been agreed across the ranks of a data-parallel job
 _TUNE = os.environ.get("LORA_AMD_SDPA_TUNE", "1") != "0"
 
 
@@ -94,13 +96,23 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     choice = _CHOICE.get(key)
     if choice is not None:
         choice = tuple(choice)
-    if choice is None:
-        if _TUNE and q.dtype in (torch.bfloat16, torch.float16) and not torch.cuda.is_current_stream_capturing():
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if (choice is None or (multi and key not in _AGREED)) and not torch.cuda.is_current_stream_capturing():
+        if choice is None and _TUNE and q.dtype in (torch.bfloat16, torch.float16):
             with torch.enable_grad():
                 choice = _tune(q, k, v)
+        if multi:
+            # data-parallel replicas run the same kernels: every rank adopts rank 0's pick the first time it meets a
+            # shape (all ranks meet the shapes in the same order — same model, same step), instead of each timing the
+            # candidates on its own GPU and possibly settling on different ones (noisy per-rank step times)
+            box = [list(choice) if choice is not None else None]
+            dist.broadcast_object_list(box, src=0)
+            choice = tuple(box[0]) if box[0] is not None else None
+            _AGREED.add(key)
+        if choice is not None:
             _CHOICE[key] = list(choice)
-        else:
-            choice = (None, q.shape[-1])
+    if choice is None:
+        choice = (None, q.shape[-1])
     return _run(q, k, v, *choice)
 
 

@@ -62,4 +62,33 @@ def test_bench_self_launch_fails_loudly_without_enough_gpus():
     if torch.cuda.device_count() >= 2:
         pytest.skip("this box could actually launch 2 ranks")
     with pytest.raises(SystemExit, match="--gpus 2 requested"):
-        bench.self_launch(argparse.Namespace(gpus=2))
+        bench.self_launch(argparse.Namespace(gpus=2, device="cuda"))
+
+
+def test_bench_self_launch_runs_two_gloo_ranks_end_to_end():
+    """`python bench.py --gpus 2` with no launcher environment must start its own ranks
+    (torch.distributed.run, 127.0.0.1), shard the batch, all-reduce the flat gradient and have rank 0 print ONE JSON line
+    with n_gpus 2 — driven here on the CPU (`--device cpu`: gloo, tiny stand-in UNet), the same code path the GPU run
+    takes with backend nccl."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests import helpers as H
+
+    env = {**os.environ, "OMP_NUM_THREADS": "2"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--device", "cpu", "--standin", "tiny",
+                        "--steps", "2", "--warmup", "1", "--res", "128", "--batch", "1"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=H.REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
+    assert d["config"]["allreduce_us"] and d["config"]["allreduce_us"] > 0
+    assert d["config"]["allreduce_payload_bytes"] == 4 * d["config"]["trainable_params"]
+    assert d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
+    assert "backend gloo" in r.stderr

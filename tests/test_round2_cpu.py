@@ -209,3 +209,39 @@ def test_conv_layout_routing_is_decided_from_strides_only():
     one = torch.zeros(2, 64, 1, 1, dtype=torch.bfloat16)  # H = W = 1: both formats at once -> NCHW path
     assert not ops.conv_nhwc_ok(one, w1, 4, *geom1)
     assert ops.WS_DROPOUT and ops.WS_DROPOUT_WIDE and ops.WS_DROPOUT_WIDE_BWD  # defaults (LORA_AMD_WS_DROPOUT unset)
+
+
+def test_weight_cache_keys_accept_inference_tensors():
+    """tensors created under torch.inference_mode() do not track a version counter (reading ``_version``
+    raises); the layout caches must key them anyway."""
+    from lora_amd import _C
+
+    with torch.inference_mode():
+        w = torch.randn(8, 8)
+        assert _C._tensor_version(w) == 0
+    assert _C._tensor_version(torch.randn(2, 2)) == 0
+    v = torch.randn(2, 2)
+    v.add_(1)
+    assert _C._tensor_version(v) == 1
+    import lora_amd as L
+
+    m = L.LoraInjectedLinear(8, 8, r=2)
+    with torch.inference_mode():
+        sh = m._shadow(torch.randn(8, 8), torch.bfloat16, "w")  # shadow built from an inference tensor
+        assert sh.dtype == torch.bfloat16
+
+
+def test_diffusers_processor_hands_back_variants_it_does_not_model():
+    """qk-norm / upcast / fused-projection attention blocks must go to the previous processor, never be approximated."""
+    import types
+
+    from lora_amd.diffusers_glue import LoraAmdAttnProcessor
+
+    calls = []
+    proc = LoraAmdAttnProcessor(lambda *a, **k: calls.append(1) or "fallback")
+    x = torch.randn(1, 3, 8)
+    for extra in ({"norm_q": torch.nn.LayerNorm(4)}, {"upcast_softmax": True}, {"fused_projections": True},
+                  {"upcast_attention": True}, {"norm_k": torch.nn.LayerNorm(4)}):
+        attn = types.SimpleNamespace(heads=2, **extra)
+        assert proc(attn, x) == "fallback"
+    assert len(calls) == 5

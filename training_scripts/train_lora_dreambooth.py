@@ -95,7 +95,8 @@ def parse_args(input_args=None):
     a("--device", type=str, default=None, help="cuda | cpu (default: cuda if available).")
     a("--hip_graph", type=int, default=0, help="Capture forward+backward into a hipGraph (fixed batch shape).")
     a("--channels_last", type=int, default=0, help="Run the UNet in NHWC (the layout MIOpen's convolutions use on "
-      "MI355X; +5 %% steps/s on the SD1.5 stand-in).  Linear-adapter training only: the Conv2d adapter kernels are NCHW.")
+      "MI355X; +5 %% steps/s on the SD1.5 stand-in).  Linear sites run as they are; Conv2d adapter sites take the "
+      "channels-last MFMA kernels of csrc/conv_nhwc.hip (3x3) or the Linear kernels on the pixel rows (1x1).")
     args = p.parse_args(input_args) if input_args is not None else p.parse_args()
 
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
