@@ -15,6 +15,8 @@ bench)
 benchshort)
   timeout 400 python bench.py --no-secondary --no-cpu-baseline > $OUT/r03_bench_short.json 2> $OUT/r03_bench_short.err ;;
 trace)
+  # MIOpen's find cache and the tune cache do not survive between boxes: fill them first, or the trace holds the find pass
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline > /dev/null 2> $OUT/r03_trace_warm.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_trace -o bench -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/r03_bench_traced.json 2> $OUT/r03_bench_traced.err
   python scripts/prof_summary.py $(find $OUT/r03_trace -name "*kernel_trace.csv" | head -1) 70 > $OUT/r03_bench_kernel_trace_summary.txt
   rm -rf $OUT/r03_trace ;;
