@@ -451,10 +451,12 @@ def svd_bench(args) -> dict:
 
     def step():
         gen = torch.Generator(device=dev).manual_seed(1)
-        last = None
-        for tuned, base in groups:
-            last = S.distill_group(tuned, base, rank, 0.99, gen, n_iter=n_iter)
-        return last
+        if os.environ.get("LORA_AMD_SVD_PER_GROUP", "0") == "1":  # A/B: one batched iteration per shape group (round 2)
+            last = None
+            for tuned, base in groups:
+                last = S.distill_group(tuned, base, rank, 0.99, gen, n_iter=n_iter)
+            return last
+        return S.distill_model(groups, rank, 0.99, gen, n_iter=n_iter)[-1]
 
     for _ in range(args.warmup):
         step()
@@ -471,8 +473,9 @@ def svd_bench(args) -> dict:
            "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 "
-                                  "sites (31 shape groups, 730 M weight elements), randomized subspace iteration n_iter=4 "
-                                  "batched per shape group on the HIP rowdot/colreduce passes, on-device CholeskyQR3",
+                                  "sites (31 shape groups, 730 M weight elements), randomized subspace iteration n_iter=4, "
+                                  "every step ONE ragged launch over all shape groups (lora_amd_colreduce_ragged / "
+                                  "rowdot_ragged descriptor tables), on-device CholeskyQR3",
                       "sites": n_sites, "groups": len(groups), "weight_elements": elems},
            "roofline": {"kernel": "lora_amd::rowdot_kernel / colreduce_stage1_kernel <f32> (batched residual passes)",
                         "bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

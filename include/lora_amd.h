@@ -169,6 +169,38 @@ int lora_amd_colreduce_batched(const void *x, int64_t ldx, int64_t stride_x, con
                                size_t workspace_bytes, void *stream);
 int lora_amd_chol_inverse_batched(const float *gram, float *out, int32_t l, int32_t batch, float shift_rel,
                                   void *stream);
+
+/* Ragged forms: the same passes over a TABLE of stacks of different shapes in one launch (cli_svd.py:24-92 walks 224
+ * sites of 31 shapes; one table entry per shape group).  f32 matrices and factors; the rank r is common to the table.
+ * The caller fills the first block of fields, lora_amd_ragged_plan fills the second (host side) and returns the grid
+ * sizes; the table is then copied to the device once and reused by every launch on the same buffers.
+ *   rowdot_ragged:    out_g[b] [M, r] = scale * x_g[b] [M, K] @ f_g[b]^T          (f [r, K] or [K, r] per `layout`)
+ *   colreduce_ragged: out_g[b] ([r, K] or [K, r]) = scale * f_g[b]^T @ x_g[b]    (f = T [M, r]; partial: workspace of
+ *                     batch * lora_amd_colreduce_workspace(M, K, r) bytes per group)
+ *   sub_ragged:       out = (f32) a - (f32) b over a table of flat arrays (the residuals W_tuned - W_base, ref :30-32) */
+typedef struct lora_amd_ragged_desc {
+  const void *x;          /* stack of `batch` [M, K] matrices: row stride ldx, matrix stride stride_x (elements) */
+  const void *f;          /* rowdot: factor stack; colreduce: T stack [M, r]; matrix stride stride_f (elements) */
+  float *out;             /* matrix stride stride_out (elements) */
+  float *partial;         /* colreduce only */
+  int64_t ldx, stride_x, stride_f, stride_out, M;
+  int32_t K, batch;
+  /* filled by lora_amd_ragged_plan */
+  int64_t stride_partial, begin1, begin2;
+  int32_t blocks1, blocks2, col_tiles, kt_cols, logL, rows_per_block;
+} lora_amd_ragged_desc;
+enum { LORA_AMD_RAGGED_ROWDOT = 0, LORA_AMD_RAGGED_COLREDUCE = 1 };
+int lora_amd_ragged_plan(int32_t op, lora_amd_ragged_desc *descs, int32_t n, int32_t r, int64_t *grid1, int64_t *grid2);
+int lora_amd_rowdot_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int64_t grid1, int32_t r,
+                           int32_t factor_layout, float scale, void *stream);
+int lora_amd_colreduce_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int64_t grid1, int64_t grid2, int32_t r,
+                              int32_t out_layout, float scale, void *stream);
+typedef struct lora_amd_sub_desc {
+  const void *a, *b;
+  float *out;
+  int64_t n, begin;       /* elements; begin: running count of 4096-element blocks (filled by the caller) */
+} lora_amd_sub_desc;
+int lora_amd_sub_ragged(const lora_amd_sub_desc *descs_dev, int32_t n, int64_t blocks, int32_t in_dtype, void *stream);
 /* ------------------------------------------------------------------------
  * K1/K2 fused: one launch forward, two backward, one batched reduction per step.
  * These are what LoraInjectedLinear runs for 16-byte-friendly shapes (K%8==0, N%8==0,

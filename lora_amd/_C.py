@@ -31,6 +31,7 @@ SYMBOLS = (
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
+    "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_gemm_fwd_heads",
@@ -51,6 +52,22 @@ SYMBOLS = (
 
 class HipExtensionMissing(RuntimeError):
     pass
+
+
+class RaggedDesc(C.Structure):
+    """lora_amd_ragged_desc (include/lora_amd.h): one stack of same-shape matrices of a ragged launch."""
+    _fields_ = [
+        ("x", C.c_void_p), ("f", C.c_void_p), ("out", C.c_void_p), ("partial", C.c_void_p),
+        ("ldx", C.c_int64), ("stride_x", C.c_int64), ("stride_f", C.c_int64), ("stride_out", C.c_int64), ("M", C.c_int64),
+        ("K", C.c_int32), ("batch", C.c_int32),
+        ("stride_partial", C.c_int64), ("begin1", C.c_int64), ("begin2", C.c_int64),
+        ("blocks1", C.c_int32), ("blocks2", C.c_int32), ("col_tiles", C.c_int32), ("kt_cols", C.c_int32),
+        ("logL", C.c_int32), ("rows_per_block", C.c_int32),
+    ]
+
+
+class SubDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("begin", C.c_int64)]
 
 
 class MergeSite(C.Structure):
@@ -132,6 +149,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_chol_inverse_batched.argtypes = [vp, vp, i32, i32, f32, vp]
     lib.lora_amd_rowdot_batched.restype = lib.lora_amd_colreduce_batched.restype = C.c_int
     lib.lora_amd_chol_inverse_batched.restype = C.c_int
+    lib.lora_amd_ragged_plan.argtypes = [i32, vp, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.lora_amd_rowdot_ragged.argtypes = [vp, i32, i64, i32, i32, f32, vp]
+    lib.lora_amd_colreduce_ragged.argtypes = [vp, i32, i64, i64, i32, i32, f32, vp]
+    lib.lora_amd_sub_ragged.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_ragged_plan.restype = lib.lora_amd_rowdot_ragged.restype = C.c_int
+    lib.lora_amd_colreduce_ragged.restype = lib.lora_amd_sub_ragged.restype = C.c_int
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
     lib.lora_amd_sumsq_workspace.restype = sz
     lib.lora_amd_sumsq.argtypes = [vp, i64, vp, vp, sz, vp]
@@ -449,16 +472,96 @@ def colreduce_batched(x: torch.Tensor, t: torch.Tensor, layout: int = FACTOR_RK,
     return out
 
 
-def chol_inverse_batched(gram: torch.Tensor, shift_rel: float = 0.0) -> torch.Tensor:
+def chol_inverse_batched(gram: torch.Tensor, shift_rel: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """L^{-1} [B, l, l] for G + shift_rel * tr(G)/l * I = L L^T (l <= 32): the small dense step of CholeskyQR."""
     lib = require()
     _dev_check(gram)
     if gram.dim() != 3 or gram.shape[1] != gram.shape[2] or gram.dtype != torch.float32 or not gram.is_contiguous():
         raise ValueError("chol_inverse_batched: contiguous f32 [B, l, l] expected")
-    out = torch.empty_like(gram)
+    if out is None:
+        out = torch.empty_like(gram)
+    elif out.shape != gram.shape or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError("chol_inverse_batched: out must match gram")
     _check(lib.lora_amd_chol_inverse_batched(gram.data_ptr(), out.data_ptr(), gram.shape[1], gram.shape[0],
                                              float(shift_rel), _stream()), "lora_amd_chol_inverse_batched")
     return out
+
+
+RAGGED_ROWDOT, RAGGED_COLREDUCE = 0, 1
+
+
+class RaggedProgram:
+    """Descriptor tables of a sequence of ragged launches over persistent buffers (``cli_svd.distill_model``): every
+    table is planned on the host as it is declared, ALL of them go to the device in one copy (``upload``), and a launch
+    is then one C call with a pointer into that buffer — no per-launch allocation, planning or host-to-device traffic."""
+
+    def __init__(self, device):
+        self.device = device
+        self._blobs, self._meta, self._size = [], [], 0
+        self._dev = None
+
+    def table(self, op: int, r: int, rows) -> int:
+        """rows: per stack (x [B, M, K], f [B, ...], out [B, ...], partial or None).  Returns the table's handle."""
+        lib = require()
+        arr = (RaggedDesc * len(rows))()
+        for d, (x, f, out, partial) in zip(arr, rows):
+            B, M, K = x.shape
+            if x.dtype != torch.float32 or f.dtype != torch.float32 or out.dtype != torch.float32:
+                raise TypeError("ragged launches take f32 stacks")
+            if not (x.is_contiguous() and f.is_contiguous() and out.is_contiguous()):
+                raise ValueError("ragged launches take contiguous stacks")
+            d.x, d.f, d.out = x.data_ptr(), f.data_ptr(), out.data_ptr()
+            d.partial = partial.data_ptr() if partial is not None else None
+            d.ldx, d.stride_x, d.M, d.K, d.batch = K, M * K, M, K, B
+            d.stride_f, d.stride_out = f[0].numel(), out[0].numel()
+            if partial is not None and partial.numel() * 4 < lib.lora_amd_colreduce_workspace(M, K, r) * B:
+                raise ValueError("ragged colreduce: workspace too small")
+        g1, g2 = C.c_int64(0), C.c_int64(0)
+        _check(lib.lora_amd_ragged_plan(op, arr, len(rows), r, C.byref(g1), C.byref(g2)), "lora_amd_ragged_plan")
+        off = self._size
+        blob = bytes(arr)
+        pad = (-len(blob)) % 64
+        self._blobs.append(blob + b"\0" * pad)
+        self._size += len(blob) + pad
+        self._meta.append((op, r, len(rows), off, g1.value, g2.value))
+        return len(self._meta) - 1
+
+    def upload(self):
+        self._dev = torch.frombuffer(bytearray(b"".join(self._blobs)), dtype=torch.uint8).to(self.device)
+
+    def run(self, handle: int, layout: int, scale: float = 1.0) -> None:
+        lib = require()
+        op, r, n, off, g1, g2 = self._meta[handle]
+        ptr = self._dev.data_ptr() + off
+        if op == RAGGED_ROWDOT:
+            _check(lib.lora_amd_rowdot_ragged(ptr, n, g1, r, layout, float(scale), _stream()), "lora_amd_rowdot_ragged")
+        else:
+            _check(lib.lora_amd_colreduce_ragged(ptr, n, g1, g2, r, layout, float(scale), _stream()),
+                   "lora_amd_colreduce_ragged")
+
+
+def colreduce_workspace_floats(M: int, K: int, r: int) -> int:
+    return require().lora_amd_colreduce_workspace(M, K, r) // 4
+
+
+def sub_ragged(pairs, outs) -> None:
+    """outs[i] (f32, flat) = float(a_i) - float(b_i) for every (a_i, b_i) of ``pairs`` (same dtype) in ONE launch."""
+    lib = require()
+    arr = (SubDesc * len(pairs))()
+    blocks = 0
+    dt = pairs[0][0].dtype
+    for d, (a, b), o in zip(arr, pairs, outs):
+        _dev_check(a, b, o)
+        if a.dtype != dt or b.dtype != dt or o.dtype != torch.float32 or a.numel() != b.numel() or a.numel() != o.numel():
+            raise ValueError("sub_ragged: one input dtype, f32 outputs, matching sizes")
+        if not (a.is_contiguous() and b.is_contiguous() and o.is_contiguous()):
+            raise ValueError("sub_ragged: contiguous tensors expected")
+        d.a, d.b, d.out, d.n, d.begin = a.data_ptr(), b.data_ptr(), o.data_ptr(), a.numel(), blocks
+        blocks += (a.numel() + 4095) // 4096
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(outs[0].device)
+    _check(lib.lora_amd_sub_ragged(dev.data_ptr(), len(pairs), blocks, dtype_code(dt), _stream()), "lora_amd_sub_ragged")
+    # `dev` goes back to the caching allocator on return; the pool hands it out again only to work that is ordered after
+    # this launch on the same stream
 
 
 # ----------------------------------------------------------------------------- optimiser (C2/K6)

@@ -149,6 +149,136 @@ def distill_group(w_tuned, w_base, rank: int, clamp_quantile: float = 0.99,
     return _clamp_pairs(U * S[:, None, :], Vh, clamp_quantile)
 
 
+def _flat_stacks(shapes, device):
+    """One f32 allocation holding a [B, R, C] stack per entry of ``shapes``; every stack starts on a 256-byte boundary."""
+    offs, total = [], 0
+    for B, R, Cc in shapes:
+        offs.append(total)
+        total += -(-(B * R * Cc) // 64) * 64
+    flat = torch.empty(max(total, 64), dtype=torch.float32, device=device)
+    return flat, [flat[o:o + B * R * Cc].view(B, R, Cc) for o, (B, R, Cc) in zip(offs, shapes)]
+
+
+def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
+                    generator: Optional[torch.Generator] = None):
+    """``topr_svd_batched`` for a LIST of stacks of different shapes ([B_g, N_g, K_g] f32, contiguous) run in lock-step:
+    every step of the iteration is ONE launch (pair) for the whole model — ``lora_amd_colreduce_ragged`` /
+    ``lora_amd_rowdot_ragged`` over a descriptor table with one entry per shape group, ``chol_inverse_batched`` and the
+    l x l core SVD over the concatenation of all groups.  SD1.5 extended (224 sites, 31 shapes): ~110 launches instead
+    of ~3100.  Returns per group (U [B,N,r], S [B,r], Vh [B,r,K]) with the deterministic sign rule of the batched path."""
+    _C.require()
+    dev = deltas[0].device
+    dims = [tuple(d.shape) for d in deltas]
+    l = _sketch_width(rank, oversample, dims[0][1], dims[0][2])
+    for (B, N, K) in dims:
+        if not group_supported(N, K, rank, oversample) or _sketch_width(rank, oversample, N, K) != l:
+            raise ValueError(f"topr_svd_ragged: shape {N}x{K} rank {rank} is outside the batched device path")
+    nb = sum(B for B, _, _ in dims)
+    delta_t = [d.transpose(1, 2).contiguous() for d in deltas]      # second resident layout of the residuals
+    yshape = [(B, N, l) for B, N, K in dims]
+    zshape = [(B, K, l) for B, N, K in dims]
+    _ya, Ya = _flat_stacks(yshape, dev)
+    _yb, Yb = _flat_stacks(yshape, dev)
+    _za, Za = _flat_stacks(zshape, dev)
+    _zb, Zb = _flat_stacks(zshape, dev)
+    zc_flat, Zc = _flat_stacks(zshape, dev)
+    _u, Uo = _flat_stacks([(B, N, rank) for B, N, K in dims], dev)
+    _v, Vo = _flat_stacks([(B, K, rank) for B, N, K in dims], dev)
+    gram = torch.empty(nb, l, l, dtype=torch.float32, device=dev)
+    linv = torch.empty(nb, l, l, dtype=torch.float32, device=dev)
+    core = torch.empty(nb, l, l, dtype=torch.float32, device=dev)
+    ubt = torch.empty(nb, rank, l, dtype=torch.float32, device=dev)
+    vb = torch.empty(nb, rank, l, dtype=torch.float32, device=dev)
+    boffs, o = [], 0
+    for B, _, _ in dims:
+        boffs.append(o)
+        o += B
+    per = lambda t: [t[o:o + B] for o, (B, _, _) in zip(boffs, dims)]  # noqa: E731
+    G, L, Cr, Ub, Vb = per(gram), per(linv), per(core), per(ubt), per(vb)
+    ws = [torch.empty(B * max(_C.colreduce_workspace_floats(N, K, l), _C.colreduce_workspace_floats(K, N, l)),
+                      dtype=torch.float32, device=dev) for B, N, K in dims]
+
+    prog = _C.RaggedProgram(dev)
+    cr = lambda xs, fs, outs: prog.table(_C.RAGGED_COLREDUCE, l, list(zip(xs, fs, outs, ws)))  # noqa: E731
+    rd = lambda xs, fs, outs, r=l: prog.table(_C.RAGGED_ROWDOT, r, [(x, f, o_, None) for x, f, o_ in zip(xs, fs, outs)])  # noqa: E731
+    t_sketch = cr(delta_t, Zc, Ya)          # Y = dW Omega
+    t_fwd = cr(deltas, Yb, Za)              # Z = dW^T Q
+    t_back = cr(delta_t, Zb, Ya)            # Y = dW Qz
+    t_b = cr(deltas, Yb, Zc)                # b^T = dW^T Q
+    t_core = cr(Za, Zc, Cr)                 # b Qb  [l, l]
+    gram_of = {id(t[0]): cr(t, t, G) for t in (Ya, Yb, Za, Zb, Zc)}
+    apply_l = {(id(a[0]), id(b[0])): rd(a, L, b) for a, b in ((Ya, Yb), (Yb, Ya), (Za, Zb), (Zb, Za), (Zc, Za))}
+    t_u = rd(Yb, Ub, Uo, rank)
+    t_v = rd(Za, Vb, Vo, rank)
+    prog.upload()
+    lib_chol = _C.chol_inverse_batched
+
+    def orth(chain):
+        """CholeskyQR3 along ``chain`` = (src, tmp, ..., dst): shifted first pass, two clean ones (see ``_orth``)."""
+        for shift, (a, b) in zip((1e-4, 0.0, 0.0), zip(chain[:-1], chain[1:])):
+            prog.run(gram_of[id(a[0])], _C.FACTOR_RK)
+            lib_chol(gram, shift, out=linv)
+            prog.run(apply_l[(id(a[0]), id(b[0]))], _C.FACTOR_RK)
+
+    zc_flat.normal_(generator=generator)                          # Omega, every group at once
+    prog.run(t_sketch, _C.FACTOR_KR)
+    orth((Ya, Yb, Ya, Yb))                                        # q in Yb
+    for _ in range(n_iter):
+        prog.run(t_fwd, _C.FACTOR_KR)
+        orth((Za, Zb, Za, Zb))                                    # qz in Zb
+        prog.run(t_back, _C.FACTOR_KR)
+        orth((Ya, Yb, Ya, Yb))
+    prog.run(t_b, _C.FACTOR_KR)                                   # b^T [K, l] in Zc
+    orth((Zc, Za, Zb, Za))                                        # qb in Za
+    prog.run(t_core, _C.FACTOR_RK)
+    ub, s, vbh = torch.linalg.svd(core, full_matrices=False)      # [sum B, l, l]: one batched call for the model
+    ubt.copy_(ub[:, :, :rank].transpose(1, 2))
+    vb.copy_(vbh[:, :rank])
+    prog.run(t_u, _C.FACTOR_RK)                                   # U = Q Ub[:, :r]
+    prog.run(t_v, _C.FACTOR_RK)                                   # Vh^T = Qb Vb[:r]^T
+    out = []
+    for (o, (B, N, K)), u, vt in zip(zip(boffs, dims), Uo, Vo):
+        idx = vt.abs().argmax(dim=1, keepdim=True)                # [B, 1, r]: the largest-magnitude entry of each down row
+        sgn = torch.sign(vt.gather(1, idx))
+        sgn = torch.where(sgn == 0, torch.ones_like(sgn), sgn)
+        out.append((u * sgn, s[o:o + B, :rank], (vt * sgn).transpose(1, 2).contiguous()))
+    return out
+
+
+def distill_model(groups, rank: int, clamp_quantile: float = 0.99, generator: Optional[torch.Generator] = None,
+                  **svd_kw):
+    """``distill_group`` for every shape group of a model at once: ``groups`` = [(tuned weights, base weights), ...],
+    one entry per shape.  Device groups of supported shapes share ONE ragged iteration (``topr_svd_ragged``), with the
+    residuals of all sites formed by one launch; anything else falls back to ``distill_group``.  Returns a list of
+    (up [B, N, r], down [B, r, K]) in the order of ``groups``."""
+    over = svd_kw.get("oversample", 8)
+    fast, results = [], [None] * len(groups)
+    for gi, (tuned, base) in enumerate(groups):
+        N = tuned[0].shape[0]
+        K = tuned[0].numel() // N
+        if (tuned[0].is_cuda and group_supported(N, K, rank, over) and tuned[0].dtype == base[0].dtype
+                and all(t.is_contiguous() for t in tuned) and all(b.is_contiguous() for b in base)):
+            fast.append((gi, len(tuned), N, K))
+        else:
+            results[gi] = distill_group(tuned, base, rank, clamp_quantile, generator, **svd_kw)
+    by_dtype = {}
+    for ent in fast:
+        by_dtype.setdefault(groups[ent[0]][0][0].dtype, []).append(ent)
+    for dt, ents in by_dtype.items():
+        dev = groups[ents[0][0]][0][0].device
+        _, deltas = _flat_stacks([(B, N, K) for _, B, N, K in ents], dev)
+        pairs, outs = [], []
+        for (gi, B, N, K), d in zip(ents, deltas):
+            for i, (t, b) in enumerate(zip(*groups[gi])):
+                pairs.append((t, b))
+                outs.append(d[i])
+        _C.sub_ragged(pairs, outs)                                 # every residual W_tuned - W_base: one launch
+        trip = topr_svd_ragged(deltas, rank, generator=generator, **svd_kw)
+        for (gi, _, _, _), (U, S, Vh) in zip(ents, trip):
+            results[gi] = _clamp_pairs(U * S[:, None, :], Vh, clamp_quantile)
+    return results
+
+
 def distill_pair(w_tuned: torch.Tensor, w_base: torch.Tensor, rank: int, clamp_quantile: float = 0.99,
                  generator: Optional[torch.Generator] = None, **svd_kw) -> Tuple[torch.Tensor, torch.Tensor]:
     """(up [N, r], down [r, K]) of one site from its tuned / base weights flattened to 2-D (ref :30-47, :57-74)."""
@@ -167,11 +297,18 @@ def overwrite_base(base_model, tuned_model, rank, clamp_quantile, seed: int = 0,
               tuple(fb.weight.shape))
         key = (type(lor_base).__name__, tuple(fb.weight.shape), fb.weight.device, fb.weight.dtype)
         groups.setdefault(key, []).append((lor_base, fb, ft))
-    for (kind, shape, dev, dtype), sites in groups.items():
+    by_dev = {}
+    for key in groups:
+        by_dev.setdefault(key[2], []).append(key)
+    done = {}
+    for dev, keys in by_dev.items():
         if dev.type == "cuda" and dev not in gens:
             gens[dev] = torch.Generator(device=dev).manual_seed(seed)
-        ups, downs = distill_group([ft.weight.data for _, _, ft in sites], [fb.weight.data for _, fb, _ in sites],
-                                   rank, clamp_quantile, gens.get(dev), **svd_kw)
+        res = distill_model([([ft.weight.data for _, _, ft in groups[k]], [fb.weight.data for _, fb, _ in groups[k]])
+                             for k in keys], rank, clamp_quantile, gens.get(dev), **svd_kw)
+        done.update(zip(keys, res))
+    for (kind, shape, dev, dtype), sites in groups.items():
+        ups, downs = done[(kind, shape, dev, dtype)]
         for (lor_base, fb, _), up, down in zip(sites, ups, downs):
             if isinstance(lor_base, LoraInjectedConv2d):
                 up = up.reshape(up.shape[0], up.shape[1], 1, 1)

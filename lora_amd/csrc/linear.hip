@@ -71,21 +71,19 @@ __device__ inline void fma_chunk(const float *s_f, int c8, int cc, const float (
 // finishes with logL xor-shuffles.  Lane 0 of each group applies scale/selector
 // and writes the r outputs.
 // ---------------------------------------------------------------------------
+// `bx` = row block of the matrix; the pointers already address the matrix (batched and ragged launches offset them).
 template <class EX, int RT, bool MASKED>
-__global__ __launch_bounds__(kThreads) void rowdot_kernel(
+__device__ inline void rowdot_body(
     const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
     int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
     int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
-    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int64_t bx) {
   __shared__ __attribute__((aligned(16))) float s_f[kFactorLdsFloats];
   __shared__ float s_sel[RT * RT];
-  x += blockIdx.y * bs.x;
-  f = reinterpret_cast<const char *>(f) + blockIdx.y * bs.f_bytes;
-  t_out += blockIdx.y * bs.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = 1 << logL, G = 64 >> logL;  // lanes per row, rows per wave-iteration
   const int l = lane & (L - 1), g = lane >> logL;
-  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t m0 = bx * rows_per_block;
   const int64_t m1 = min(M, m0 + rows_per_block);
   const int rows_iter = G * (kThreads / 64);
   const int niter = (int)((m1 - m0 + rows_iter - 1) / rows_iter);
@@ -169,6 +167,43 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
         if (j < r) tr[j] = o[j];
     }
   }
+}
+
+template <class EX, int RT, bool MASKED>
+__global__ __launch_bounds__(kThreads) void rowdot_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
+    int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
+    int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
+  rowdot_body<EX, RT, MASKED>(x + blockIdx.y * bs.x, ldx, reinterpret_cast<const char *>(f) + blockIdx.y * bs.f_bytes, fdt,
+                              layout, t_out + blockIdx.y * bs.t, M, K, r, kt_cols, logL, rows_per_block, scale, sel,
+                              sel_transposed, p, seed, offset, offset_dev, blockIdx.x);
+}
+
+// ---- ragged launches (cli_svd.py: every shape group of a model in ONE launch) -----------------------------------
+// A table of jobs, one per stack of same-shape matrices; blocks are numbered through the table (begin1 / begin2 are the
+// running block counts of the two launch kinds, filled by lora_amd_ragged_plan).  Uniform per workgroup: the lookup is
+// a binary search on scalar loads.
+__device__ inline int ragged_find(const lora_amd_ragged_desc *__restrict__ d, int n, int64_t b, bool second) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((second ? d[mid].begin2 : d[mid].begin1) <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void rowdot_ragged_kernel(const lora_amd_ragged_desc *__restrict__ descs, int n,
+                                                                 int r, int layout, float scale) {
+  const int g = ragged_find(descs, n, blockIdx.x, false);
+  const lora_amd_ragged_desc d = descs[g];
+  const int64_t local = (int64_t)blockIdx.x - d.begin1;
+  const int64_t by = local / d.blocks1, bx = local - by * d.blocks1;
+  rowdot_body<f32_t, RT, false>(reinterpret_cast<const float *>(d.x) + by * d.stride_x, d.ldx,
+                                reinterpret_cast<const float *>(d.f) + by * d.stride_f, LORA_AMD_F32, layout,
+                                d.out + by * d.stride_out, d.M, d.K, r, d.kt_cols, d.logL, d.rows_per_block, scale,
+                                nullptr, 0, 0.f, 0, 0, nullptr, bx);
 }
 
 // Any K / any alignment: one wave per row, scalar lanes.
@@ -316,19 +351,16 @@ constexpr int kColRowsPerBlock = 64;
 constexpr int kColMaxChunks = 64;
 
 template <class EX, int RT, bool MASKED>
-__global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
+__device__ inline void colreduce_stage1_body(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
-    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
-  x += blockIdx.y * bs.x;
-  t += blockIdx.y * bs.t;
-  partial += blockIdx.y * bs.partial;
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int64_t bx) {
   // s_red doubles as the slot-reduction buffer: [slot][c8*8][4 ranks]
   __shared__ __attribute__((aligned(16))) float s_red[kThreads * 8 * 4];
   __shared__ float s_t[kColRowsPerBlock * RT];
   const int tid = threadIdx.x;
-  const int64_t rb = blockIdx.x / col_tiles;
-  const int ct = (int)(blockIdx.x - rb * col_tiles);
+  const int64_t rb = bx / col_tiles;
+  const int ct = (int)(bx - rb * col_tiles);
   const int col0 = ct * kColMaxChunks * 8;
   const int ncols = min(kColMaxChunks * 8, K - col0);
   const int c8 = ncols >> 3;
@@ -408,18 +440,38 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
   }
 }
 
+template <class EX, int RT, bool MASKED>
+__global__ __launch_bounds__(kThreads) void colreduce_stage1_kernel(
+    const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
+    float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
+    uint64_t seed, uint64_t offset, const uint64_t *offset_dev, BatchStride bs) {
+  colreduce_stage1_body<EX, RT, MASKED>(x + blockIdx.y * bs.x, ldx, t + blockIdx.y * bs.t, partial + blockIdx.y * bs.partial,
+                                        M, K, r, rank0, col_tiles, p, seed, offset, offset_dev, blockIdx.x);
+}
+
+template <int RT>
+__global__ __launch_bounds__(kThreads) void colreduce_stage1_ragged_kernel(const lora_amd_ragged_desc *__restrict__ descs,
+                                                                           int n, int r, int rank0) {
+  const int g = ragged_find(descs, n, blockIdx.x, false);
+  const lora_amd_ragged_desc d = descs[g];
+  const int64_t local = (int64_t)blockIdx.x - d.begin1;
+  const int64_t by = local / d.blocks1, bx = local - by * d.blocks1;
+  colreduce_stage1_body<f32_t, RT, false>(reinterpret_cast<const float *>(d.x) + by * d.stride_x, d.ldx,
+                                          reinterpret_cast<const float *>(d.f) + by * d.stride_f,
+                                          d.partial + by * d.stride_partial, d.M, d.K, r, rank0, d.col_tiles, 0.f, 0, 0,
+                                          nullptr, bx);
+}
+
 // stage 2: D[j,k] = beta*D + scale * sum_b partial[b][j][k]  (j in [rank0, rank0+RT)).
 // Block = 64 consecutive (j,k) elements x 4 waves; wave w sums row blocks w, w+4, ... (8 loads in
 // flight per lane), the four wave sums meet in LDS.
-__global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
+__device__ inline void colreduce_stage2_body(
     const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
-    int RT, int rank0, int out_layout, float scale, float beta, BatchStride bs) {
+    int RT, int rank0, int out_layout, float scale, float beta, int64_t bx) {
   __shared__ float s_sum[kThreads];
-  partial += blockIdx.y * bs.partial;
-  d += blockIdx.y * bs.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t total = (int64_t)RT * K;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t i = bx * 64 + lane;
   const int64_t ic = i < total ? i : total - 1;
   const int64_t stride = total;  // floats between consecutive row blocks
   constexpr int U = 8;
@@ -446,6 +498,25 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
       d[o] = (beta == 0.f ? 0.f : beta * d[o]) + scale * sum;
     }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void colreduce_stage2_kernel(
+    const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
+    int RT, int rank0, int out_layout, float scale, float beta, BatchStride bs) {
+  colreduce_stage2_body(partial + blockIdx.y * bs.partial, d + blockIdx.y * bs.d, nblocks, K, r, RT, rank0, out_layout,
+                        scale, beta, blockIdx.x);
+}
+
+__global__ __launch_bounds__(kThreads) void colreduce_stage2_ragged_kernel(const lora_amd_ragged_desc *__restrict__ descs,
+                                                                           int n, int r, int RT, int rank0, int out_layout,
+                                                                           float scale) {
+  const int g = ragged_find(descs, n, blockIdx.x, true);
+  const lora_amd_ragged_desc d = descs[g];
+  const int64_t local = (int64_t)blockIdx.x - d.begin2;
+  const int64_t by = local / d.blocks2, bx = local - by * d.blocks2;
+  const int64_t nrb = (d.M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  colreduce_stage2_body(d.partial + by * d.stride_partial, d.out + by * d.stride_out, nrb, d.K, r, RT, rank0, out_layout,
+                        scale, 0.f, bx);
 }
 
 template <class EX, bool MASKED>
@@ -750,6 +821,131 @@ extern "C" int lora_amd_colreduce_batched(const void *x, int64_t ldx, int64_t st
     default: GO(bf16_t);
   }
 #undef GO
+}
+
+// ---- ragged forms (cli_svd.py: every shape group of a model in one launch) ---------------------------------------
+extern "C" int lora_amd_ragged_plan(int32_t op, lora_amd_ragged_desc *descs, int32_t n, int32_t r, int64_t *grid1,
+                                    int64_t *grid2) {
+  LORA_AMD_CHECK(descs && n >= 1 && grid1 && grid2, LORA_AMD_EINVAL, "ragged_plan: bad argument");
+  LORA_AMD_CHECK(op == LORA_AMD_RAGGED_ROWDOT || op == LORA_AMD_RAGGED_COLREDUCE, LORA_AMD_EINVAL, "ragged_plan: op %d", op);
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "ragged_plan: rank %d outside [1,%d]", r, LORA_AMD_MAX_RANK);
+  int64_t b1 = 0, b2 = 0;
+  for (int i = 0; i < n; ++i) {
+    lora_amd_ragged_desc &d = descs[i];
+    LORA_AMD_CHECK(d.x && d.f && d.out && d.M > 0 && d.K > 0 && d.batch >= 1 && d.ldx >= d.K, LORA_AMD_EINVAL,
+                   "ragged_plan: group %d: bad shape or null pointer", i);
+    LORA_AMD_CHECK(vec_ok(d.x, d.ldx, d.K, LORA_AMD_F32) && d.stride_x % 8 == 0, LORA_AMD_EINVAL,
+                   "ragged_plan: group %d: rows must be 32-byte aligned with K %% 8 == 0", i);
+    d.begin1 = b1; d.begin2 = b2;
+    d.blocks2 = 0; d.col_tiles = 0; d.kt_cols = 0; d.logL = 0; d.rows_per_block = 0; d.stride_partial = 0;
+    if (op == LORA_AMD_RAGGED_ROWDOT) {
+      const int RT = rank_tile(r);
+      int kt_cols = (kFactorLdsFloats / RT) & ~7;
+      if (kt_cols > d.K) kt_cols = d.K;
+      const int logL = pick_logL(kt_cols >> 3);
+      const int rows_iter = (64 >> logL) * (kThreads / 64);
+      int64_t rows_per_block = (d.M + 1023) / 1024;
+      rows_per_block = ((rows_per_block + rows_iter - 1) / rows_iter) * rows_iter;
+      d.kt_cols = kt_cols; d.logL = logL; d.rows_per_block = (int32_t)rows_per_block;
+      d.blocks1 = (int32_t)((d.M + rows_per_block - 1) / rows_per_block);
+    } else {
+      LORA_AMD_CHECK(d.partial, LORA_AMD_EWORKSPACE, "ragged_plan: group %d: colreduce needs a workspace", i);
+      const int64_t nrb = (d.M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+      d.col_tiles = (d.K + kColMaxChunks * 8 - 1) / (kColMaxChunks * 8);
+      d.blocks1 = (int32_t)(nrb * d.col_tiles);
+      d.blocks2 = (int32_t)(((int64_t)col_rank_tile(r) * d.K + 63) / 64);
+      d.stride_partial = (int64_t)(lora_amd_colreduce_workspace(d.M, d.K, r) / sizeof(float));
+    }
+    b1 += (int64_t)d.blocks1 * d.batch;
+    b2 += (int64_t)d.blocks2 * d.batch;
+  }
+  LORA_AMD_CHECK(b1 < (1ll << 31) && b2 < (1ll << 31), LORA_AMD_EINVAL, "ragged_plan: too many blocks");
+  *grid1 = b1; *grid2 = b2;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_rowdot_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int64_t grid1, int32_t r,
+                                      int32_t factor_layout, float scale, void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && grid1 >= 1 && grid1 < (1ll << 31), LORA_AMD_EINVAL, "rowdot_ragged: bad argument");
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "rowdot_ragged: rank %d outside [1,%d]", r, LORA_AMD_MAX_RANK);
+  hipStream_t st = (hipStream_t)stream;
+#define RD(RTV) hipLaunchKernelGGL((rowdot_ragged_kernel<RTV>), dim3((unsigned)grid1), dim3(kThreads), 0, st, descs_dev, n, r, factor_layout, scale)
+  switch (rank_tile(r)) {
+    case 4: RD(4); break;
+    case 8: RD(8); break;
+    case 16: RD(16); break;
+    case 32: RD(32); break;
+    default: RD(64); break;
+  }
+#undef RD
+  return check_launch("lora_amd_rowdot_ragged");
+}
+
+extern "C" int lora_amd_colreduce_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int64_t grid1, int64_t grid2,
+                                         int32_t r, int32_t out_layout, float scale, void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && grid1 >= 1 && grid2 >= 1 && grid1 < (1ll << 31) && grid2 < (1ll << 31),
+                 LORA_AMD_EINVAL, "colreduce_ragged: bad argument");
+  LORA_AMD_CHECK(r >= 1 && r <= LORA_AMD_MAX_RANK, LORA_AMD_ERANK, "colreduce_ragged: rank %d outside [1,%d]", r, LORA_AMD_MAX_RANK);
+  hipStream_t st = (hipStream_t)stream;
+  const int RT = col_rank_tile(r);
+  for (int rank0 = 0; rank0 < r; rank0 += RT) {  // ranks beyond 16 take extra passes over X
+#define CR(RTV) hipLaunchKernelGGL((colreduce_stage1_ragged_kernel<RTV>), dim3((unsigned)grid1), dim3(kThreads), 0, st, descs_dev, n, r, rank0)
+    switch (RT) {
+      case 4: CR(4); break;
+      case 8: CR(8); break;
+      default: CR(16); break;
+    }
+#undef CR
+    hipLaunchKernelGGL(colreduce_stage2_ragged_kernel, dim3((unsigned)grid2), dim3(kThreads), 0, st, descs_dev, n, r, RT,
+                       rank0, out_layout, scale);
+  }
+  return check_launch("lora_amd_colreduce_ragged");
+}
+
+namespace lora_amd {
+// out = (f32) a - (f32) b over a table of flat arrays; one workgroup per 4096 elements (16 per thread, 16-byte accesses
+// when the three pointers allow it).
+template <class E>
+__global__ __launch_bounds__(kThreads) void sub_ragged_kernel(const lora_amd_sub_desc *__restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_sub_desc d = descs[lo];
+  using S = typename E::storage;
+  const S *a = reinterpret_cast<const S *>(d.a), *b = reinterpret_cast<const S *>(d.b);
+  const int64_t e0 = ((int64_t)blockIdx.x - d.begin) * 4096;
+  const bool vec = ((((uintptr_t)d.a | (uintptr_t)d.b) % (8 * sizeof(S))) == 0) && (((uintptr_t)d.out % 32) == 0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int64_t e = e0 + (u * kThreads + threadIdx.x) * 8;
+    if (e >= d.n) continue;
+    if (vec && e + 8 <= d.n) {
+      float av[8], bv[8];
+      load8<E>(a + e, av);
+      load8<E>(b + e, bv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) av[i] -= bv[i];
+      store8<f32_t>(d.out + e, av);
+    } else {
+      for (int i = 0; i < 8 && e + i < d.n; ++i) d.out[e + i] = E::to_f(a[e + i]) - E::to_f(b[e + i]);
+    }
+  }
+}
+}  // namespace lora_amd
+
+extern "C" int lora_amd_sub_ragged(const lora_amd_sub_desc *descs_dev, int32_t n, int64_t blocks, int32_t in_dtype,
+                                   void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && blocks >= 1 && blocks < (1ll << 31) && dtype_ok(in_dtype), LORA_AMD_EINVAL,
+                 "sub_ragged: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  switch (in_dtype) {
+    case LORA_AMD_F32: hipLaunchKernelGGL((sub_ragged_kernel<f32_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, descs_dev, n); break;
+    case LORA_AMD_F16: hipLaunchKernelGGL((sub_ragged_kernel<f16_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, descs_dev, n); break;
+    default: hipLaunchKernelGGL((sub_ragged_kernel<bf16_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, descs_dev, n); break;
+  }
+  return check_launch("lora_amd_sub_ragged");
 }
 
 // Inverse Cholesky factor of a stack of small Gram matrices, for CholeskyQR on the device (cli_svd.py):

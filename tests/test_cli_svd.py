@@ -96,3 +96,15 @@ def test_svd_distill_cli_on_device(tmp_path):
     # adapters it distilled under ResnetBlock2D are not written
     assert all(u.dim() == 2 for u in ups) and all(torch.isfinite(u).all() for u in ups)
     assert max(float(u.abs().max()) for u in ups) > 0
+
+
+def test_distill_model_on_cpu_is_distill_group_per_shape():
+    """The model-level entry (one ragged device iteration for all shape groups) takes the per-group reference path for
+    CPU tensors: same values as ``distill_group``, in the order of the groups."""
+    gs = [([_planted(48, 64, 6, 1e-3, i)[0] for i in range(2)], [_planted(48, 64, 6, 1e-3, i)[1] for i in range(2)]),
+          ([_planted(96, 64, 6, 1e-3, 5)[0]], [_planted(96, 64, 6, 1e-3, 5)[1]])]
+    res = S.distill_model(gs, 4)
+    assert len(res) == 2
+    for (t, b), (up, down) in zip(gs, res):
+        up1, down1 = S.distill_group(t, b, 4)
+        assert torch.equal(up, up1) and torch.equal(down, down1)

@@ -181,6 +181,54 @@ def test_distill_largest_conv_site_on_device_vs_reference_recipe():
     assert (prod - prod_ref).norm() <= 0.05 * prod_ref.norm()
 
 
+# ----------------------------------------------------------------------------- f1: every shape group in one launch
+def test_ragged_svd_of_several_shape_groups_vs_exact_svd():
+    """cli_svd.py:24-92 over a model = sites of several shapes.  ``topr_svd_ragged`` (one descriptor-table launch per
+    step of the iteration for ALL groups) vs the exact SVD of every matrix: sign-free rank-r product, aligned vectors,
+    singular values; then ``distill_model`` (one-launch residuals, f16 weights included) vs ``distill_group``."""
+    from lora_amd import cli_svd as S
+    from tests.test_cli_svd import _planted
+
+    r = 8
+    shapes = [(3, 320, 320), (1, 1280, 2880), (2, 640, 1280), (2, 2560, 320)]  # (sites, N, K); K = 2880: a 3x3 conv
+    tuned, base = [], []
+    for gi, (B, N, K) in enumerate(shapes):
+        tb = [_planted(N, K, r + 4, 2e-3 / (N ** 0.5 + K ** 0.5), 10 * gi + i, "cpu") for i in range(B)]
+        tuned.append([t.to(DEV) for t, _ in tb])
+        base.append([b.to(DEV) for _, b in tb])
+    deltas = [torch.stack([t - b for t, b in zip(ts, bs)]) for ts, bs in zip(tuned, base)]
+    trip = S.topr_svd_ragged(deltas, r, generator=torch.Generator(device=DEV).manual_seed(0))
+    assert len(trip) == len(shapes)
+    for (B, N, K), d, (U, Sg, Vh) in zip(shapes, deltas, trip):
+        assert U.shape == (B, N, r) and Sg.shape == (B, r) and Vh.shape == (B, r, K)
+        for i in range(B):
+            Ue, Se, Vhe = torch.linalg.svd(d[i].double().cpu(), full_matrices=False)
+            ref = (Ue[:, :r] * Se[:r]) @ Vhe[:r]
+            got = ((U[i] * Sg[i]) @ Vh[i]).double().cpu()
+            assert (got - ref).norm() <= 2e-4 * ref.norm(), ((N, K, i), float((got - ref).norm() / ref.norm()))
+            assert (Sg[i].double().cpu() - Se[:r]).abs().max() <= 1e-4 * float(Se[0])
+            sgn = torch.sign((Vh[i].double().cpu() * Vhe[:r]).sum(1))
+            assert (Vh[i].double().cpu() * sgn[:, None] - Vhe[:r]).abs().max() <= 5e-3 * float(Vhe[:r].abs().max())
+            # the sign rule: the largest-magnitude entry of every down row is positive
+            j = Vh[i].abs().argmax(dim=1)
+            assert bool((Vh[i][torch.arange(r), j] > 0).all())
+    # the model-level entry: grouped inputs, residuals formed by sub_ragged, clamp per site — vs the per-group path
+    groups = list(zip(tuned, base))
+    res = S.distill_model(groups, r, 0.99, torch.Generator(device=DEV).manual_seed(1))
+    for (ts, bs), (up, down) in zip(groups, res):
+        up1, down1 = S.distill_group(ts, bs, r, 0.99, torch.Generator(device=DEV).manual_seed(2))
+        assert up.shape == up1.shape and down.shape == down1.shape
+        assert (up - up1).abs().max() <= 2e-3 * up1.abs().max()
+        assert (down - down1).abs().max() <= 2e-3 * down1.abs().max()
+    # f16 weights of odd sizes through the one-launch subtraction
+    a = [torch.randn(n_, device=DEV).half() for n_ in (4096 * 3 + 5, 8, 100000)]
+    b = [torch.randn(n_, device=DEV).half() for n_ in (4096 * 3 + 5, 8, 100000)]
+    o = [torch.empty(t.numel(), device=DEV) for t in a]
+    _C.sub_ragged(list(zip(a, b)), o)
+    for x, y, z in zip(a, b, o):
+        assert torch.equal(z, x.float() - y.float())
+
+
 # ----------------------------------------------------------------------------- the benchmarked configuration vs the oracle
 def _sd15_twins(r=4):
     """SD1.5-size UNet twice: bf16 on the device exactly as bench.py builds it, f32 on the host with the same
