@@ -273,7 +273,9 @@ def adapter_path_profile(step_fn, state) -> dict:
     torch.cuda.synchronize()
     ops.PATH_LOG = []
     try:
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        # CPU activity too: the frozen GEMMs of the merged-weight sites are library kernels; their device time is
+        # attributed through the record_function range ops.LoraLinearMergedFunction opens around them
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             step_fn()
             torch.cuda.synchronize()
     finally:
@@ -297,8 +299,19 @@ def adapter_path_profile(step_fn, state) -> dict:
             host_us += dur
         else:
             ours_us += dur
+    merged_gemm_us, merged_gemm_calls = 0.0, 0
+    for ka in prof.key_averages():
+        if ka.key == "lora_amd::merged_gemm":
+            merged_gemm_us = float(getattr(ka, "device_time_total", 0.0) or getattr(ka, "cuda_time_total", 0.0) or 0.0)
+            merged_gemm_calls = int(ka.count)
+    if merged_gemm_calls:
+        kern["(library GEMM) X W_eff^T / G W_eff of the merged-weight sites"] = [merged_gemm_calls, merged_gemm_us]
+        ours_us += merged_gemm_us
     choices = Counter((ph, path) for ph, path, *_ in log_)
     byts = sum(_site_bytes(*rec) for rec in log_)
+    mw = getattr(state, "merged", None)
+    if mw is not None:
+        byts += mw.bytes_algorithmic  # the step's one merge launch: read W, write W_eff, read the factors
     fused_sites = sum(1 for ph, path, *_ in log_ if ph == "fwd" and not path.startswith("lib"))
     out = {"how": "one eager step under torch.profiler (device-side kernel durations); bytes per SURVEY 8d: fused "
                   "formula where the frozen product is inside our launch, branch-only bound where it is a library GEMM",
@@ -342,6 +355,7 @@ def swap_in_aten_adapters(model) -> int:
 SECONDARY = [  # (tag, extra argv, env, timeout s): driver-observed lines for the other BASELINE geometries, short runs
     ("host_options_off", ["--channels-last", "0", "--head-pad", "0", "--conv-find", "0"], {"LORA_AMD_HOSTOPS": "0"}, 150),
     ("aten_adapters", ["--adapters", "aten"], {}, 150),
+    ("fused_per_site_kernels (--merged 0)", ["--merged", "0"], {}, 150),
     ("configs[2] UNet+CLIP rank 8", ["--text-encoder", "1", "--rank", "8"], {}, 150),
     ("configs[3] extended rank 16 768^2 batch 1", ["--extended", "1", "--rank", "16", "--res", "768", "--batch", "1"], {}, 240),
     ("prior preservation (8 samples/step)", ["--with-prior-preservation", "1"], {}, 150),
@@ -524,6 +538,9 @@ def main():
                     "(+5 %% steps/s measured; 0 = MIOpen's immediate-mode heuristic)")
     ap.add_argument("--with-prior-preservation", type=int, default=0, help="instance + class-prior batch (2 x --batch "
                     "samples per step, ref :698-702, 855-875); not the headline workload")
+    ap.add_argument("--merged", type=int, default=1, help="1: the maskless Linear adapters run on the step's merged weight "
+                    "W + scale up down (one K3 merge launch per step, frozen GEMMs forward / input gradient, one launch for "
+                    "both factor gradients); 0: the fused per-site MFMA kernels of rounds 1-2 (A/B)")
     ap.add_argument("--adapters", choices=["hip", "aten"], default="hip", help="aten: the reference's op sequence "
                     "(lora.py:53-58 as stock ATen launches) in place of the HIP adapter kernels, same host model: the "
                     "comparison leg behind `secondary[aten_adapters]`")
@@ -607,10 +624,13 @@ def main():
         text_encoder.train()
         groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
+    merged = None
     if args.adapters == "aten":
         n_sites = swap_in_aten_adapters(unet) + (swap_in_aten_adapters(text_encoder) if text_encoder is not None else 0)
     elif on_gpu:
         n_sites = state.attach_direct_grads(unet, *([text_encoder] if text_encoder is not None else []))
+        if args.merged:
+            merged = state.enable_merged_weights(unet, *([text_encoder] if text_encoder is not None else []))
     else:
         n_sites = sum(isinstance(m, (L.LoraInjectedLinear, L.LoraInjectedConv2d)) for m in unet.modules())
     sched = DDPMScheduler()
@@ -629,7 +649,7 @@ def main():
         ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(cdt)
 
     def fwd_bwd(lat, cond):
-        return T.forward_backward(unet, sched, lat, cond, cfg, text_encoder=text_encoder)
+        return T.forward_backward(unet, sched, lat, cond, cfg, text_encoder=text_encoder, merged=merged)
 
     def barrier():
         if world > 1:
@@ -738,7 +758,13 @@ def main():
                        "allreduce_us": allreduce_us,
                        "kernel_choices": kernel_choices,
                        "adapter_options": {"grouped_qkv_one_launch": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
-                                           "adapters": args.adapters},
+                                           "adapters": args.adapters,
+                                           "merged_weights": None if merged is None else {
+                                               "sites": len(merged.entries), "merge_launches_per_step": len(merged._plans or []),
+                                               "merge_bytes_per_step": merged.bytes_algorithmic,
+                                               "what": "W_eff = W + scale up down for every maskless Linear adapter, one K3 "
+                                                       "launch per step inside the timed region; forward / input gradient = "
+                                                       "frozen GEMM on W_eff, factor gradients = linear_bwd_factors_self"}},
                        "host_model_options": {"channels_last": bool(args.channels_last),
                                               "head_padded_projections": os.environ.get("LORA_AMD_HEAD_PAD") == "1",
                                               "fused_hostops": os.environ.get("LORA_AMD_HOSTOPS", "1") != "0",
@@ -786,6 +812,8 @@ def main():
                     out["value_host_options_off"] = rec["value"]
                 if rec["tag"] == "aten_adapters" and "value" in rec:
                     out["value_aten_adapters"] = rec["value"]
+                if rec["tag"].startswith("fused_per_site_kernels") and "value" in rec:
+                    out["value_fused_per_site_kernels"] = rec["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -77,7 +77,10 @@ typedef struct lora_amd_merge_site {
                             (K % 8 == 0 and w_in/w_out 16-byte aligned);
                             bit 1: column-owner kernel (rank <= 16, K/8 has a
                             power-of-two factor >= 4)                        */
-  int32_t reserved;
+  int32_t out_heads;     /* caller: 0 = w_out rows are dense [K]; d | (D << 16): w_out is the head-padded layout of a
+                            weight whose INPUT is head-padded — row stride (K/d)*D, logical column k at
+                            (k/d)*D + k%d (d, D multiples of 8, K % d == 0; pad columns are never written: zero them
+                            once).  Column-owner sites only (lora_amd_merge_plan refuses it elsewhere)             */
 } lora_amd_merge_site;
 
 typedef struct lora_amd_merge_summary {
@@ -341,6 +344,20 @@ typedef struct lora_amd_reduce_desc {
   float scale, beta;
 } lora_amd_reduce_desc;
 
+/* The parameter gradients of a site on the merged-weight path (no T, no Gt saved or produced by another launch):
+ * up_part[rb][RT][N] = sum_m (s X down^T)[m, j] G[m, n],  down_part[rb][RT][K] = sum_m (s G up)[m, j] X[m, k] per row
+ * block rb, in ONE launch that reads G and X from HBM once (replaces the autograd of lora.py:53-58 for dA, dB when the
+ * forward ran on W + s up down).  f32 factors; G / X rows may be head-padded (d, D as in linear_bwd_factors_heads).
+ * The plan sizes the partial slabs: `nparts` row blocks, folded by lora_amd_reduce_batched. */
+typedef struct lora_amd_factors_self_plan_t {
+  int32_t supported, rank_tile, nparts, reserved;
+  int64_t up_part_floats, down_part_floats;
+} lora_amd_factors_self_plan_t;
+int lora_amd_linear_factors_self_plan(int64_t M, int32_t K, int32_t N, int32_t r, lora_amd_factors_self_plan_t *out);
+int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, const void *x, int64_t ldx, const float *down,
+                                     const float *up, float *up_part, float *down_part, int64_t M, int32_t K,
+                                     int32_t N, int32_t r, int32_t act_dtype, float scale, int32_t g_head_dim,
+                                     int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad, void *stream);
 int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
 
 /* ------------------------------------------------------------------------

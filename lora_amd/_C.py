@@ -34,6 +34,7 @@ SYMBOLS = (
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
+    "lora_amd_linear_factors_self_plan", "lora_amd_linear_bwd_factors_self",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
@@ -52,6 +53,11 @@ SYMBOLS = (
 
 class HipExtensionMissing(RuntimeError):
     pass
+
+
+class FactorsSelfPlan(C.Structure):
+    _fields_ = [("supported", C.c_int32), ("rank_tile", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32),
+                ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64)]
 
 
 class RaggedDesc(C.Structure):
@@ -75,7 +81,7 @@ class MergeSite(C.Structure):
         ("w_in", C.c_void_p), ("w_out", C.c_void_p), ("up", C.c_void_p), ("down", C.c_void_p),
         ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32),
         ("rows_per_tile", C.c_int32), ("cols_per_tile", C.c_int32), ("tiles_k", C.c_int32),
-        ("tile_begin", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("tile_begin", C.c_int64), ("flags", C.c_int32), ("out_heads", C.c_int32),
     ]
 
 
@@ -180,6 +186,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_factors_heads.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32,
                                                       i32, i32, i32, i32, vp]
     lib.lora_amd_linear_bwd_factors_heads.restype = C.c_int
+    lib.lora_amd_linear_factors_self_plan.argtypes = [i64, i32, i32, i32, C.POINTER(FactorsSelfPlan)]
+    lib.lora_amd_linear_bwd_factors_self.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32,
+                                                     i32, i32, i32, i32, vp]
+    lib.lora_amd_linear_factors_self_plan.restype = lib.lora_amd_linear_bwd_factors_self.restype = C.c_int
     lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
                                                    f32, f32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
@@ -324,7 +334,9 @@ class MergePlan:
         arr = (MergeSite * n)()
         self.keep = []  # keep tensors alive as long as the plan
         self.bytes_algorithmic = 0
-        for i, (w_in, w_out, up, down) in enumerate(sites):
+        for i, site in enumerate(sites):
+            w_in, w_out, up, down = site[:4]
+            heads = site[4] if len(site) > 4 else None  # (d, D): w_out is [N, (K/d)*D], input columns head-padded
             _dev_check(w_in, w_out, up, down)
             if w_in.dtype != self.w_dtype or w_out.dtype != self.w_dtype:
                 raise TypeError("MergePlan: mixed weight dtypes in one plan")
@@ -335,12 +347,14 @@ class MergePlan:
             N = w_in.shape[0]
             K = w_in.numel() // N
             r = down.shape[0]
-            if up.shape[0] != N or up.numel() != N * r or down.numel() != r * K or w_out.shape != w_in.shape:
+            ko = K if heads is None else (K // heads[0]) * heads[1]
+            if up.shape[0] != N or up.numel() != N * r or down.numel() != r * K or w_out.numel() != N * ko:
                 raise ValueError(f"MergePlan: site {i} shape mismatch W{tuple(w_in.shape)} up{tuple(up.shape)} "
                                  f"down{tuple(down.shape)}")
             s = arr[i]
             s.w_in, s.w_out, s.up, s.down = w_in.data_ptr(), w_out.data_ptr(), up.data_ptr(), down.data_ptr()
             s.N, s.K, s.r = N, K, r
+            s.out_heads = 0 if heads is None else int(heads[0]) | (int(heads[1]) << 16)
             self.keep.append((w_in, w_out, up, down))
             self.bytes_algorithmic += 2 * N * K * w_in.element_size() + (N + K) * r * up.element_size()
         self.summary = MergeSummary()
@@ -717,6 +731,40 @@ def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, 
                                                        down_part.data_ptr(), g.shape[0], K, N, r,
                                                        dtype_code(g.dtype), float(scale), gd, gD, xd, xD, _stream()),
            "lora_amd_linear_bwd_factors")
+
+
+_self_plan_cache = {}
+
+
+def factors_self_plan(M: int, K: int, N: int, r: int) -> FactorsSelfPlan:
+    key = (M, K, N, r)
+    pl = _self_plan_cache.get(key)
+    if pl is None:
+        pl = FactorsSelfPlan()
+        _check(require().lora_amd_linear_factors_self_plan(M, K, N, r, C.byref(pl)), "lora_amd_linear_factors_self_plan")
+        _self_plan_cache[key] = pl
+    return pl
+
+
+def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor, up: torch.Tensor,
+                            up_part: torch.Tensor, down_part: torch.Tensor, scale: float, g_heads=None,
+                            x_heads=None) -> None:
+    """dUp and dDown partials of a site of the merged-weight path in ONE launch that needs neither T nor Gt:
+    ``up_part[rb] = (s X down^T)^T G``, ``down_part[rb] = (s G up)^T X`` per row block (see include/lora_amd.h).
+    ``g_heads`` / ``x_heads`` = (heads, d, D) when the rows of G / X are head-padded."""
+    _dev_check(g, x, down, up, up_part, down_part)
+    if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
+        raise ValueError("linear_bwd_factors_self: contiguous f32 factors expected")
+    N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
+    K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+    r = down.shape[0]
+    gd, gD = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    _check(require().lora_amd_linear_bwd_factors_self(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
+                                                      down.data_ptr(), up.data_ptr(), up_part.data_ptr(),
+                                                      down_part.data_ptr(), g.shape[0], K, N, r, dtype_code(g.dtype),
+                                                      float(scale), gd, gD, xd, xD, _stream()),
+           "lora_amd_linear_bwd_factors_self")
 
 
 def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, float, float]],

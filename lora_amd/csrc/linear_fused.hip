@@ -584,6 +584,162 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
   slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, part + (int64_t)rb * RT * C, C, ct * ct8 * 8);
 }
 
+// ============================================================================ backward, both factor gradients, self-sufficient
+// The merged-weight training path (ops.LoraLinearMergedFunction: Y = X W_eff^T with W_eff = W + s up down refreshed once
+// per step by the K3 merge launch, dX = G W_eff) leaves the backward with ONLY the parameter gradients, and with neither
+// T = X down^T nor Gt = s G up at hand.  This kernel recomputes both per row block and consumes them in place:
+//   phase A   s_t[m][j]  = s * sum_k X[m, k] down[j, k]          s_gt[m][j] = s * sum_n G[m, n] up[n, j]      (LDS)
+//   phase B   up_part[rb][j][n] = sum_m s_t[m][j] G[m, n]        down_part[rb][j][k] = sum_m s_gt[m][j] X[m, k]
+// so G and X leave HBM once (phase B re-reads the block's rows from L2 / the Infinity Cache: a row block is
+// rows * (N + K) * 2 bytes).  grid = row blocks x `nsplit`; the splits of a row block share out the column tiles of
+// phase B (and each redo phase A: only taken when M is too small to fill the chip with row blocks alone).
+struct SelfArgs {
+  const void *g, *x;
+  int64_t ldg, ldx, M;
+  const float *down, *up;          // f32 masters: [r, K] and [N, r]
+  float *up_part, *down_part;      // [nrb][RT][N], [nrb][RT][K]
+  float scale;
+  int N, K, r, rows_per_block, nsplit;
+  int ghc, ghp, xhc, xhp;          // head-padded rows (16-byte chunks per head: logical, physical); 0 = dense
+  int kt_g, logL_g, kt_x, logL_x;  // phase A: factor columns per LDS stage, lanes per row (log2)
+  int log_ct8_g, nct_g, log_ct8_x, nct_x;  // phase B: column tiles
+};
+
+__device__ inline int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
+
+// s_out[rl * RT + j] = mult * sum_c data[m0 + rl, c] * factor(j, c) for the block's rows; L lanes per row.
+template <class E, int RT>
+__device__ inline void block_rowdots(float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
+                                     int nrows, int C, const float *factor, int layout, int r, int kt_cols, int logL,
+                                     float mult, int hc, int hp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = 1 << logL, G = 64 >> logL;
+  const int l = lane & (L - 1), g = lane >> logL;
+  const int rows_iter = G * (kFT / 64);
+  const int niter = (nrows + rows_iter - 1) / rows_iter;
+  const bool single = kt_cols >= C;
+  if (single) {
+    __syncthreads();
+    stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, 0, C);
+    __syncthreads();
+  }
+  constexpr int U = 4;
+  for (int it = 0; it < niter; ++it) {
+    const int rl = it * rows_iter + wave * G + g;
+    const bool live = rl < nrows;
+    float acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
+    for (int k0 = 0; k0 < C; k0 += kt_cols) {
+      const int ncols = min(kt_cols, C - k0), c8 = ncols >> 3;
+      if (!single) {
+        __syncthreads();
+        stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, k0, ncols);
+        __syncthreads();
+      }
+      if (live) {
+        const typename E::storage *xr = data + (m0 + rl) * ld;
+        const int cbase = k0 >> 3;
+        for (int cb = l; cb < c8; cb += L * U) {
+          float xv[U][8];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int cc = cb + u * L;
+            load8_sel<E>(xr + hchunk(cbase + (cc < c8 ? cc : cb), hc, hp) * 8, cc < c8, xv[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int cc = cb + u * L;
+            if (cc >= c8) continue;
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+              const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
+              const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + cc) * 4]);
+              float a = acc[j];
+              a = fmaf(xv[u][0], d0.x, a); a = fmaf(xv[u][1], d0.y, a); a = fmaf(xv[u][2], d0.z, a);
+              a = fmaf(xv[u][3], d0.w, a); a = fmaf(xv[u][4], d1.x, a); a = fmaf(xv[u][5], d1.y, a);
+              a = fmaf(xv[u][6], d1.z, a); a = fmaf(xv[u][7], d1.w, a);
+              acc[j] = a;
+            }
+          }
+        }
+      }
+    }
+    for (int off = L >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    if (live && l == 0) {
+#pragma unroll
+      for (int j = 0; j < RT; ++j) s_out[rl * RT + j] = acc[j] * mult;
+    }
+  }
+}
+
+// part[j][c] (this block's [RT][C] slab) = sum over the block's rows of s_vec[row][j] * data[row, c], one column tile.
+template <class E, int RT>
+__device__ inline void block_colsums(float *s_red, const float *s_vec, const typename E::storage *data, int64_t ld,
+                                     int64_t m0, int nrows, int C, int log_ct8, int ct, float *part, int hc, int hp) {
+  const int tid = threadIdx.x;
+  const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
+  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
+  const int col = (ct * ct8 + cl) * 8;
+  const int pcol = hchunk(col >> 3, hc, hp) * 8;
+  float acc[RT][8];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+  constexpr int U = 4;
+  for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rl = rb0 + u * nslots;
+      const float *tr = s_vec + (rl < nrows ? rl : 0) * RT;  // rows past the end contribute v = 0
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float tj = tr[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, v[u][i], acc[j][i]);
+      }
+    }
+  }
+  slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, part, C, ct * ct8 * 8);
+}
+
+template <class E, int RT>
+__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const SelfArgs a) {
+  // phase A stages the factor slab, phase B reduces row slots: never live together
+  __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];
+  static_assert(kFT * 8 * 4 >= kFLdsFactor, "shared buffer");
+  using S = typename E::storage;
+  const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
+  const int64_t rb = blockIdx.x / a.nsplit;
+  const int sp = (int)(blockIdx.x - rb * a.nsplit);
+  const int64_t m0 = rb * a.rows_per_block;
+  const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
+  block_rowdots<E, RT>(s_buf, s_t, x, a.ldx, m0, nrows, a.K, a.down, LORA_AMD_FACTOR_RK, a.r, a.kt_x, a.logL_x, a.scale,
+                       a.xhc, a.xhp);
+  block_rowdots<E, RT>(s_buf, s_gt, g, a.ldg, m0, nrows, a.N, a.up, LORA_AMD_FACTOR_KR, a.r, a.kt_g, a.logL_g, a.scale,
+                       a.ghc, a.ghp);
+  __syncthreads();
+  for (int t = sp; t < a.nct_g + a.nct_x; t += a.nsplit) {
+    if (t < a.nct_g)
+      block_colsums<E, RT>(s_buf, s_t, g, a.ldg, m0, nrows, a.N, a.log_ct8_g, t, a.up_part + rb * RT * (int64_t)a.N,
+                           a.ghc, a.ghp);
+    else
+      block_colsums<E, RT>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, a.log_ct8_x, t - a.nct_g,
+                           a.down_part + rb * RT * (int64_t)a.K, a.xhc, a.xhp);
+  }
+}
+
 // ============================================================================ batched partial reduction
 // out (f32; [r,C] or [C,r]) = beta*out + scale * sum_p part[p][j][c].  One launch for every descriptor.
 __global__ __launch_bounds__(kFT) void reduce_batched_kernel(const lora_amd_reduce_desc *__restrict__ descs, int n,
@@ -867,6 +1023,81 @@ static int bwd_factors_impl(const void *g, int64_t ldg, const float *t, float *u
 #undef BF_E
 #undef BF
   return check_launch("lora_amd_linear_bwd_factors");
+}
+
+// Geometry of the self-sufficient factor-gradient launch (also the size of its partial workspaces).
+static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64_t *nrb_out) {
+  if (M <= 0 || r < 1 || r > 16 || K % 8 || N % 8 || pow2_divisor(N / 8, 64) < 4 || pow2_divisor(K / 8, 256) < 4) return false;
+  const int RT = frank_tile(r);
+  // rows per block: one workgroup streams its rows twice (phase A, phase B); enough blocks to give every CU two, at
+  // least 16 rows (the partial slabs are RT*4 / (rows*2) of the stream) and at most what the LDS row vectors hold
+  int64_t rows = (M + 511) / 512;
+  rows = std::max<int64_t>(rows, 16);
+  rows = std::min<int64_t>(rows, std::min<int64_t>(64, kFLdsT / RT));
+  rows = std::min<int64_t>(rows, M);
+  const int64_t nrb = (M + rows - 1) / rows;
+  const int ct8g = pow2_divisor(N / 8, 64), ct8x = pow2_divisor(K / 8, 256);
+  a->log_ct8_g = ilog2(ct8g); a->nct_g = (N / 8) / ct8g;
+  a->log_ct8_x = ilog2(ct8x); a->nct_x = (K / 8) / ct8x;
+  int nsplit = (int)std::min<int64_t>((512 + nrb - 1) / nrb, 4);
+  nsplit = std::max(1, std::min(nsplit, a->nct_g + a->nct_x));
+  a->nsplit = nsplit;
+  a->rows_per_block = (int)rows;
+  const int kt = (kFLdsFactor / RT) & ~7;
+  a->kt_g = std::min(kt, N); a->logL_g = pick_logL(a->kt_g >> 3);
+  a->kt_x = std::min(kt, K); a->logL_x = pick_logL(a->kt_x >> 3);
+  *nrb_out = nrb;
+  return true;
+}
+
+extern "C" int lora_amd_linear_factors_self_plan(int64_t M, int32_t K, int32_t N, int32_t r,
+                                                 lora_amd_factors_self_plan_t *out) {
+  LORA_AMD_CHECK(out != nullptr, LORA_AMD_EINVAL, "factors_self_plan: null output");
+  memset(out, 0, sizeof(*out));
+  SelfArgs a;
+  int64_t nrb = 0;
+  if (!factors_self_geom(M, K, N, r, &a, &nrb)) return LORA_AMD_OK;
+  out->supported = 1;
+  out->rank_tile = frank_tile(r);
+  out->nparts = (int32_t)nrb;
+  out->up_part_floats = nrb * out->rank_tile * (int64_t)N;
+  out->down_part_floats = nrb * out->rank_tile * (int64_t)K;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, const void *x, int64_t ldx,
+                                                const float *down, const float *up, float *up_part, float *down_part,
+                                                int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype,
+                                                float scale, int32_t g_head_dim, int32_t g_head_pad,
+                                                int32_t x_head_dim, int32_t x_head_pad, void *stream) {
+  FUSED_COMMON("linear_bwd_factors_self", act_dtype, LORA_AMD_F32);
+  auto heads_ok = [](int d, int D, int cols, int64_t ld) {
+    return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
+  };
+  LORA_AMD_CHECK(heads_ok(g_head_dim, g_head_pad, N, ldg) && heads_ok(x_head_dim, x_head_pad, K, ldx), LORA_AMD_EINVAL,
+                 "linear_bwd_factors_self: head layout not supported");
+  LORA_AMD_CHECK(g && x && down && up && up_part && down_part, LORA_AMD_EINVAL, "linear_bwd_factors_self: null pointer");
+  SelfArgs a;
+  int64_t nrb = 0;
+  LORA_AMD_CHECK(factors_self_geom(M, K, N, r, &a, &nrb) && aligned_ok(g, ldg, N, act_dtype) &&
+                     aligned_ok(x, ldx, K, act_dtype) && ((uintptr_t)down % 16) == 0 && ((uintptr_t)up % 16) == 0,
+                 LORA_AMD_EINVAL, "linear_bwd_factors_self: shape/alignment not supported (see lora_amd_linear_factors_self_plan)");
+  a.g = g; a.x = x; a.ldg = ldg; a.ldx = ldx; a.M = M; a.down = down; a.up = up; a.up_part = up_part;
+  a.down_part = down_part; a.scale = scale; a.N = N; a.K = K; a.r = r;
+  a.ghc = g_head_dim / 8; a.ghp = g_head_pad / 8; a.xhc = x_head_dim / 8; a.xhp = x_head_pad / 8;
+  const unsigned grid = (unsigned)(nrb * a.nsplit);
+  const int RT = frank_tile(r);
+  hipStream_t st = (hipStream_t)stream;
+#define FS(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a)
+#define FS_E(E) do { if (RT == 4) FS(E, 4); else if (RT == 8) FS(E, 8); else FS(E, 16); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: FS_E(f32_t); break;
+    case LORA_AMD_F16: FS_E(f16_t); break;
+    default: FS_E(bf16_t); break;
+  }
+#undef FS_E
+#undef FS
+  return check_launch("lora_amd_linear_bwd_factors_self");
 }
 
 extern "C" int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total,

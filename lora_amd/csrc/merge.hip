@@ -210,7 +210,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
   __syncthreads();
 
   const SW *win = reinterpret_cast<const SW *>(s.w_in) + (int64_t)row0 * s.K + col;
-  SW *wout = reinterpret_cast<SW *>(s.w_out) + (int64_t)row0 * s.K + col;
+  // head-padded output layout (out_heads = d | D << 16): logical column k lives at (k/d)*D + k%d of a (K/d)*D-wide row
+  const int hd = s.out_heads & 0xFFFF, hD = s.out_heads >> 16;
+  const int64_t ldo = hd ? (int64_t)(s.K / hd) * hD : s.K;
+  const int pcol = hd ? (col / hd) * hD + col % hd : col;
+  SW *wout = reinterpret_cast<SW *>(s.w_out) + (int64_t)row0 * ldo + pcol;
   constexpr int U = kMergeUnroll;
   for (int rb = slot; rb < nrows; rb += nslots * U) {
     float w[U][8];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
       float o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = merge_one<EW, EAB, ROUND>(w[u][i], p[i], alpha);
-      if (NT) store8_nt<EW>(wout + (int64_t)rl * s.K, o); else store8<EW>(wout + (int64_t)rl * s.K, o);
+      if (NT) store8_nt<EW>(wout + (int64_t)rl * ldo, o); else store8<EW>(wout + (int64_t)rl * ldo, o);
     }
   }
 }
@@ -290,7 +294,11 @@ extern "C" int lora_amd_merge_plan(lora_amd_merge_site *sites, int32_t n_sites, 
       const int c8 = s.K / 8;
       while (ct8 < 256 && (c8 % (ct8 * 2)) == 0) ct8 *= 2;
     }
-    s.reserved = 0;
+    const int hd = s.out_heads & 0xFFFF, hD = s.out_heads >> 16;
+    LORA_AMD_CHECK(s.out_heads == 0 || (hd > 0 && hd % 8 == 0 && hD % 8 == 0 && hD >= hd && s.K % hd == 0),
+                   LORA_AMD_EINVAL, "merge_plan: site %d: bad head layout d=%d D=%d for K=%d", i, hd, hD, s.K);
+    LORA_AMD_CHECK(s.out_heads == 0 || (aligned && ab_aligned && ct8 >= 4 && s.r <= 16), LORA_AMD_EINVAL,
+                   "merge_plan: site %d: a head-padded output needs the column-owner kernel (16-byte rows, rank <= 16)", i);
     if (aligned && ab_aligned && s.K % 8 == 0 && ct8 >= 4 && s.r <= 16) {
       // column-owner tiles: (ct8*8) columns x rows_per_tile rows
       const int cols = ct8 * 8;

@@ -149,6 +149,15 @@ class LoraInjectedLinear(_Adapter):
         xc = x if x.dtype == dt else x.to(dt)
         wc, bc = self._shadow(w, dt, "w"), self._shadow(b, dt, "b")
         with torch.autocast(device_type=x.device.type, enabled=False):
+            mw = self.__dict__.get("_merged")
+            if mw is not None and ops.merged_ok(xc, wc, self.lora_down.weight, self.lora_up.weight,
+                                                self._selector_matrix(), self._dropout_p(), in_heads, out_heads):
+                # the step's merged weight W + scale up down (trainer.enable_merged_weights): frozen GEMM forward and
+                # input gradient, one launch for both factor gradients
+                w_eff, b_eff = mw.lookup(self, wc, bc, dt, in_heads, out_heads)
+                return ops.LoraLinearMergedFunction.apply(xc, w_eff, b_eff, self.lora_down.weight, self.lora_up.weight,
+                                                          float(self.scale), self.__dict__.get("_grad_sink"), in_heads,
+                                                          out_heads)
             return ops.lora_linear(xc, wc, bc, self.lora_down.weight, self.lora_up.weight,
                                    self._selector_matrix(), self.scale, self._dropout_p(),
                                    self.__dict__.get("_grad_sink"), in_heads, out_heads)
@@ -179,6 +188,8 @@ def lora_linear_group(adapters, x: torch.Tensor):
     ``forward`` on the fused path (same kernels, same rounding points)."""
     if not x.is_cuda or len(adapters) < 2 or not all(isinstance(a, LoraInjectedLinear) for a in adapters):
         return None
+    if all(a.__dict__.get("_merged") is not None for a in adapters):
+        return None  # merged-weight path: every site is a plain dense GEMM on its own merged weight
     a0 = adapters[0]
     w0 = a0.linear.weight
     dt = _autocast_dtype(x, w0)

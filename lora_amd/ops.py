@@ -33,8 +33,41 @@ def next_dropout_stream(device) -> tuple:
     * ``torch.manual_seed`` makes the whole sequence reproducible.
 
     The backward regenerates the mask from the same pair: no [M, N] mask tensor ever exists in HBM."""
+    seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    pool = _POOL.get("buf")
+    if pool is not None and pool.device == torch.device(device):
+        i = _POOL["next"]
+        if i >= pool.numel():  # more masked sites than the pool holds: one more draw for the next batch of them
+            pool = _POOL["buf"] = torch.empty(_POOL_SIZE, dtype=torch.int64, device=device).random_(0, 1 << 62)
+            i = 0
+        _POOL["next"] = i + 1
+        return seed, pool[i:i + 1]
     off = torch.empty(1, dtype=torch.int64, device=device).random_(0, 1 << 62)
-    return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, off
+    return seed, off
+
+
+# One draw per STEP instead of one per masked site (configs[3]: 224 one-element RNG launches per step): inside
+# ``dropout_pool`` the offsets are consecutive elements of one tensor filled by a single ``random_`` launch.  Only the
+# training step opens it (trainer.forward_backward): the per-site draw above is what keeps activation checkpointing
+# correct for everyone else (the recompute must see the SAME offsets, which torch's restored generator state gives it; a
+# pool would hand the recompute fresh ones).  hipGraph capture: the fill is a captured kernel, every replay refills.
+_POOL = {}
+_POOL_SIZE = 512
+
+
+class dropout_pool:
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        if self.device.type == "cuda":
+            _POOL["buf"] = torch.empty(_POOL_SIZE, dtype=torch.int64, device=self.device).random_(0, 1 << 62)
+            _POOL["next"] = 0
+        return self
+
+    def __exit__(self, *exc):
+        _POOL.pop("buf", None)
+        return False
 
 
 # nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
@@ -85,6 +118,17 @@ class GradSink:
             _, K, N, r = key
             self._new(key, w, [(w[1], self.up_grad, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
                                (w[2], self.down_grad, plan.nparts_down, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)])
+        return w
+
+    def self_workspace(self, key, plan, device):
+        """Merged-weight Linear site, key = ("self", M, K, N, r): (up_part, down_part) of ``linear_bwd_factors_self``."""
+        w = self.ws.get(key)
+        if w is None:
+            w = tuple(torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+                      for n in (plan.up_part_floats, plan.down_part_floats))
+            _, _, K, N, r = key
+            self._new(key, w, [(w[0], self.up_grad, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
+                               (w[1], self.down_grad, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)])
         return w
 
     def conv_workspace(self, key, plan, device):
@@ -341,6 +385,195 @@ class LoraLinearFunction(torch.autograd.Function):
         dw = g2.t() @ x2 if need_w else None
         db = g2.sum(0) if (ctx.has_bias and need_b) else None
         return dx, dw, db, d_down, d_up, None, None, None, None
+
+
+def _gemm_range():
+    """Profiler range around the library GEMMs of the merged-weight path (only while bench.py's adapter-path profile is
+    recording: PATH_LOG is a list), so that their device time can be attributed to the adapter path."""
+    if PATH_LOG is not None:
+        return torch.profiler.record_function("lora_amd::merged_gemm")
+    import contextlib
+
+    return contextlib.nullcontext()
+
+
+class MergedWeights:
+    """The "fused W + alpha up down" path INSIDE the training step (lora.py:635-669's merge used the way lora.py:53-58 is
+    used): once per step ONE K3 launch (``lora_amd_merge_batched``, HBM-bound, every site) writes
+    ``W_eff = W + scale * up @ down`` of every eligible Linear adapter into a scratch buffer; the adapter's forward is then
+    the frozen dense GEMM on ``W_eff`` (``Y = X W_eff^T + b`` = ``X W^T + b + scale (X down^T) up^T``, no dropout), its
+    input gradient the dense GEMM ``G W_eff``, and the parameter gradients one ``linear_bwd_factors_self`` launch.
+    Eligible: device tensors, dropout not in effect, no selector, frozen weight, f32 factors, rank <= 16.
+
+    Head-padded activations (``forward_heads``): the scratch weight is laid out for them — rows of a head-padded OUTPUT
+    are written head by head (pad rows stay zero), columns of a head-padded INPUT through the merge kernel's
+    ``out_heads`` mapping (pad columns stay zero) — so the GEMM itself reads / writes the padded layout.
+
+    ``refresh()`` must run after every optimiser step and before the next forward (``trainer.forward_backward`` does;
+    it is part of the captured hipGraph).  Entries appear lazily on an adapter's first forward in a given layout."""
+
+    def __init__(self, state=None):
+        self.entries = {}    # (id(module), in_heads, out_heads, dtype) -> dict
+        self._plans = None   # [(MergePlan, alpha)]
+        self.refreshes = 0
+        self._state = state  # the optimiser state whose ``step_count`` says when the merged weights went stale
+        self._fresh_at = None
+
+    def lookup(self, module, w, b, dt, in_heads, out_heads):
+        """(w_eff, bias_eff) for this adapter and layout; creates (and fills) the entry on first use."""
+        if (self._state is not None and self._fresh_at != self._state.step_count
+                and not torch.cuda.is_current_stream_capturing()):
+            self.refresh()  # an optimiser step since the last merge (an eager forward outside trainer.forward_backward)
+        key = (id(module), in_heads, out_heads, dt)
+        e = self.entries.get(key)
+        # the factors were re-bound to new storage (FlatLoraState aliases them into its flat buffer), the frozen weight
+        # was replaced, or tune_lora_scale changed the scale: the entry is rebuilt
+        if e is not None and (e["ptrs"] != (module.lora_up.weight.data_ptr(), module.lora_down.weight.data_ptr(),
+                                            w.data_ptr()) or e["scale"] != float(module.scale)):
+            e = None
+        if e is None:
+            e = self._create(module, w, b, in_heads, out_heads)
+            self.entries[key] = e
+        return e["w_eff"], e["b_eff"]
+
+    def _create(self, module, w, b, in_heads, out_heads):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("MergedWeights: a new adapter / layout appeared during hipGraph capture; run the step "
+                               "eagerly once first (GraphedForwardBackward's warm-up does)")
+        N, K = w.shape
+        n_out = out_heads[0] * out_heads[2] if out_heads else N
+        k_out = in_heads[0] * in_heads[2] if in_heads else K
+        w_eff = torch.zeros((n_out, k_out), dtype=w.dtype, device=w.device)   # pad rows / columns stay zero
+        b_eff = None
+        if b is not None:
+            b_eff = pack_heads(b.detach(), out_heads).contiguous() if out_heads else b.detach()
+        up, down = module.lora_up.weight, module.lora_down.weight
+        heads_in = (in_heads[1], in_heads[2]) if in_heads else None
+        sites = []
+        if out_heads:
+            h, d, D = out_heads
+            for i in range(h):
+                sites.append((w.detach()[i * d:(i + 1) * d], w_eff[i * D:i * D + d], up.detach()[i * d:(i + 1) * d],
+                              down.detach()) + ((heads_in,) if heads_in else ()))
+        else:
+            sites.append((w.detach(), w_eff, up.detach(), down.detach()) + ((heads_in,) if heads_in else ()))
+        e = dict(module=module, w_eff=w_eff, b_eff=b_eff, sites=sites, scale=float(module.scale),
+                 ptrs=(up.data_ptr(), down.data_ptr(), w.data_ptr()))
+        _C.MergePlan(sites).launch(float(module.scale), _C.ROUND_ONCE)  # this forward's values; the step plan is rebuilt
+        self._plans = None
+        return e
+
+    def refresh(self) -> None:
+        """ONE merge launch per (weight dtype, scale) group — one in practice — over every registered site."""
+        if self._state is not None:
+            self._fresh_at = self._state.step_count
+        if not self.entries:
+            return
+        if self._plans is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MergedWeights.refresh: the site table must exist before hipGraph capture (run two "
+                                   "eager steps first: the first registers the sites, the second builds the table)")
+            groups = {}
+            for e in self.entries.values():
+                for st in e["sites"]:
+                    groups.setdefault((st[0].dtype, e["scale"]), []).append(st)
+            self._plans = [(_C.MergePlan(sites), alpha) for (_, alpha), sites in groups.items()]
+        for plan, alpha in self._plans:
+            plan.launch(alpha, _C.ROUND_ONCE)
+        self.refreshes += 1
+
+    def invalidate(self) -> None:
+        """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
+        self.entries.clear()
+        self._plans = None
+
+    @property
+    def bytes_algorithmic(self) -> int:
+        return sum(p.bytes_algorithmic for p, _ in (self._plans or []))
+
+
+class LoraLinearMergedFunction(torch.autograd.Function):
+    """lora.py:53-58 (dropout not in effect) on the step's merged weight — see :class:`MergedWeights`.
+    Saves X only.  The factor gradients leave as per-row-block partials for the batched reduce (``sink``) or are
+    reduced here."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, b_eff, down, up, scale, sink, in_heads, out_heads):
+        _C.require()
+        x2 = _rows2d(x, w_eff.shape[1])
+        with _gemm_range():
+            y = F.linear(x2, w_eff, b_eff)  # frozen dense GEMM (MFMA, hipBLASLt) on W + scale up down
+        K = in_heads[0] * in_heads[1] if in_heads else w_eff.shape[1]
+        N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
+        _log("fwd", "merged" + ("_heads" if (in_heads or out_heads) else ""), x2.shape[0], K, N, down.shape[0])
+        ctx.save_for_backward(x2, w_eff, down, up)
+        ctx.scale, ctx.sink, ctx.x_shape = float(scale), sink, x.shape
+        ctx.in_heads, ctx.out_heads, ctx.dims = in_heads, out_heads, (K, N)
+        return y.view(*x.shape[:-1], y.shape[1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x2, w_eff, down, up = ctx.saved_tensors
+        K, N = ctx.dims
+        r, M = down.shape[0], x2.shape[0]
+        g2 = _rows2d(g, w_eff.shape[0])
+        need_x, _, need_b, need_down, need_up = ctx.needs_input_grad[:5]
+        sink = ctx.sink
+        dx = None
+        if need_x:
+            with _gemm_range():
+                dx = (g2 @ w_eff).view(ctx.x_shape)  # frozen dense GEMM; pad columns of a head-padded dX come out zero
+        d_down = d_up = None
+        if need_down or need_up:
+            plan = _C.factors_self_plan(M, K, N, r)
+            key = ("self", M, K, N, r)
+            if sink is not None:
+                if sink.pending is not None:
+                    sink.flush()
+                up_part, down_part = sink.self_workspace(key, plan, g2.device)
+            else:
+                up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
+                                      for n in (plan.up_part_floats, plan.down_part_floats))
+            _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale,
+                                       g_heads=ctx.out_heads, x_heads=ctx.in_heads)
+            _log("bwd", "merged_dx+factors_self", M, K, N, r)
+            if sink is not None:
+                sink.pending = key
+            else:
+                d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+                d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+                rows = [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                        (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+                table, n, total = _C.make_reduce_table(rows, g2.device)
+                _C.reduce_batched(table, n, total)
+                d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+        db = None
+        if need_b:
+            db = (unpack_heads(g2, ctx.out_heads) if ctx.out_heads else g2).sum(0)
+            if ctx.out_heads:
+                db = pack_heads(db, ctx.out_heads)
+        return dx, None, db, d_down, d_up, None, None, None, None
+
+
+def merged_ok(x: torch.Tensor, weight: torch.Tensor, down: torch.Tensor, up: torch.Tensor, sel, dropout_p: float,
+              in_heads, out_heads) -> bool:
+    """Can this call take the merged-weight path?  (device, no dropout / selector, frozen weight, f32 factors, a shape
+    the one-launch factor-gradient kernel covers, 16-bit or f32 activations matching the weight)."""
+    if not x.is_cuda or dropout_p > 0.0 or sel is not None or weight.requires_grad:
+        return False
+    if down.dtype != torch.float32 or up.dtype != torch.float32 or x.dtype != weight.dtype:
+        return False
+    N, K = weight.shape
+    r = down.shape[0]
+    kw = in_heads[0] * in_heads[2] if in_heads else K
+    if x.shape[-1] != kw or x.numel() == 0:
+        return False
+    M = x.numel() // kw
+    for hl in (in_heads, out_heads):
+        if hl is not None and (hl[1] % 8 or hl[2] % 8 or hl[2] < hl[1]):
+            return False
+    return bool(_C.factors_self_plan(M, K, N, r).supported)
 
 
 def pack_heads(y: torch.Tensor, lay) -> torch.Tensor:

@@ -127,6 +127,20 @@ class FlatLoraState:
                     n += 1
         return n
 
+    def enable_merged_weights(self, *models: torch.nn.Module) -> "ops.MergedWeights":
+        """Route every Linear adapter of ``models`` whose low-rank branch is maskless (dropout not in effect, no
+        selector) through the step's merged weight: ONE ``lora_amd_merge_batched`` launch per step writes
+        ``W + scale up down`` for all of them (``ops.MergedWeights``), forward and input gradient become the frozen
+        dense GEMM on it, both factor gradients one launch.  Returns the object whose ``refresh()`` must open every
+        step (``forward_backward(..., merged=...)`` calls it)."""
+        mw = ops.MergedWeights(self)
+        for model in models:
+            for m in model.modules():
+                if isinstance(m, LoraInjectedLinear) and id(m.lora_down.weight) in self.slices:
+                    m.__dict__["_merged"] = mw
+        self.merged = mw
+        return mw
+
     def reduce_pending(self) -> None:
         """Sum every site's backward partials into the flat gradient buffer: ONE launch for all sites."""
         live = [s for s in self._sinks if s.pending is not None]
@@ -255,13 +269,42 @@ def dreambooth_loss(model_pred: torch.Tensor, target: torch.Tensor, cfg: StepCon
     return F.mse_loss(model_pred.float(), target.float(), reduction="mean")
 
 
+_CKPT_CAND = {}
+
+
+def _ckpt_candidates(model):
+    """The modules of ``model`` that carry a ``gradient_checkpointing`` switch (walked once per model)."""
+    c = _CKPT_CAND.get(id(model))
+    if c is None:
+        c = _CKPT_CAND[id(model)] = [m for m in model.modules() if hasattr(m, "gradient_checkpointing")]
+    return c
+
+
+def _dropout_pool(unet, text_encoder, device):
+    """One RNG launch per step for all dropout masks of the adapters (ops.dropout_pool) — unless the step recomputes
+    activations (checkpointing re-runs the forward and must regenerate the SAME masks: per-site draws do, a pool does not)."""
+    import contextlib
+
+    if device.type != "cuda":
+        return contextlib.nullcontext()
+    ckpt = any(getattr(m, "gradient_checkpointing", False) and m.training for mod in (unet, text_encoder)
+               if mod is not None for m in _ckpt_candidates(mod))
+    if ckpt:
+        return contextlib.nullcontext()
+    return ops.dropout_pool(device)
+
+
 def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConfig,
                      text_encoder=None, noise: Optional[torch.Tensor] = None,
-                     timesteps: Optional[torch.Tensor] = None, loss_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     timesteps: Optional[torch.Tensor] = None, loss_scale: Optional[torch.Tensor] = None,
+                     merged: Optional["ops.MergedWeights"] = None) -> torch.Tensor:
     """noise -> add_noise -> (text encoder) -> UNet -> loss -> backward (ref :823-877).
+    ``merged``: the state's ``enable_merged_weights`` object — its one-launch refresh of ``W + scale up down`` opens the step.
     ``cond``: token ids [B, 77] when ``text_encoder`` is given, else encoder hidden states [B, 77, C].
     ``loss_scale``: 0-d tensor the loss is multiplied by before the backward (fp16: ``FlatLoraState.loss_scale``);
     the returned loss is the un-scaled one."""
+    if merged is not None:
+        merged.refresh()
     if noise is None:
         noise = torch.randn_like(latents)
     if timesteps is None:
@@ -270,7 +313,7 @@ def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConf
     noisy = scheduler.add_noise(latents, noise, timesteps)
     ctx = torch.autocast(latents.device.type, dtype=cfg.autocast_dtype) if cfg.autocast_dtype is not None \
         else torch.autocast(latents.device.type, enabled=False)
-    with ctx:
+    with ctx, _dropout_pool(unet, text_encoder, latents.device):
         ehs = text_encoder(cond)[0] if text_encoder is not None else cond
         pred = unet(noisy, timesteps, ehs).sample
     if cfg.prediction_type == "epsilon":

@@ -181,6 +181,97 @@ def test_distill_largest_conv_site_on_device_vs_reference_recipe():
     assert (prod - prod_ref).norm() <= 0.05 * prod_ref.norm()
 
 
+# ----------------------------------------------------------------------------- a1/a2/a4: the merged-weight path
+def _heads_pack(a, lay):
+    h, d, D = lay
+    out = np.zeros(a.shape[:-1] + (h * D,), dtype=a.dtype)
+    out.reshape(a.shape[:-1] + (h, D))[..., :d] = a.reshape(a.shape[:-1] + (h, d))
+    return out
+
+
+@pytest.mark.parametrize("M,K,N,r,dt,gh,xh", [
+    (16384, 320, 320, 4, "bf16", None, None), (4096, 640, 640, 8, "bf16", None, None),
+    (1024, 1280, 1280, 16, "bf16", None, None), (256, 1280, 1280, 4, "f16", None, None),
+    (308, 768, 320, 4, "bf16", None, None), (4096, 320, 2560, 4, "bf16", None, None),
+    (1000, 1280, 10240, 4, "bf16", None, None), (2048, 320, 320, 4, "bf16", (8, 40, 64), None),
+    (2048, 320, 320, 16, "bf16", None, (8, 40, 64)), (777, 64, 96, 4, "f32", None, None)])
+def test_factors_self_kernel_vs_oracle(M, K, N, r, dt, gh, xh):
+    """autograd of lora.py:53-58 for the factors (dB = s G^T (X A^T), dA = (s G B)^T X) through
+    lora_amd_linear_bwd_factors_self — no T, no Gt supplied — vs oracle.lora_linear_backward; head-padded G / X too."""
+    s = 0.7
+    x, g = rnd((M, K), dt, seed=1), rnd((M, N), dt, seed=2)
+    down, up = rnd((r, K), "f32", 0.2, seed=3), rnd((N, r), "f32", 0.3, seed=4)
+    X, G, A, U = n(x), n(g), n(down), n(up)
+    _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s)
+    gd = torch.from_numpy(_heads_pack(G, gh)).to(DEV).to(g.dtype) if gh else g
+    xd = torch.from_numpy(_heads_pack(X, xh)).to(DEV).to(x.dtype) if xh else x
+    if gh:  # pad columns of a real G need not be zero: the kernel must not read them
+        gd.view(M, gh[0], gh[2])[:, :, gh[1]:] = 7.0
+    if xh:
+        xd.view(M, xh[0], xh[2])[:, :, xh[1]:] = -3.0
+    plan = _C.factors_self_plan(M, K, N, r)
+    assert plan.supported
+    up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
+    down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
+    _C.linear_bwd_factors_self(gd, xd, down, up, up_part, down_part, s, g_heads=gh, x_heads=xh)
+    d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+    table, cnt, total = _C.make_reduce_table(
+        [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+         (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)], DEV)
+    _C.reduce_batched(table, cnt, total)
+    T_abs, Gt_abs = np.abs(X) @ np.abs(A).T, s * (np.abs(G) @ np.abs(U))
+    close(n(d_up), duo, s * (np.abs(G).T @ T_abs), "f32", k=1e-4, msg="dUp")
+    close(n(d_down), ddo, Gt_abs.T @ np.abs(X), "f32", k=1e-4, msg="dDown")
+
+
+@pytest.mark.parametrize("in_heads,out_heads,r,bias", [(None, None, 4, True), (None, (8, 40, 64), 4, False),
+                                                       ((8, 40, 64), None, 8, True), (None, None, 16, False)])
+def test_merged_weight_adapter_forward_backward_vs_oracle(in_heads, out_heads, r, bias):
+    """lora.py:53-58 + autograd with the adapter on ops.MergedWeights (K3 merge into the scratch weight, dense GEMMs on
+    it, one launch for both factor gradients) vs oracle.lora_linear_forward / backward; head-padded layouts included:
+    pad columns of the output and of dX must be exactly zero."""
+    from lora_amd import ops
+
+    M, K, N, s = 2048, 320, 320, 0.8
+    torch.manual_seed(0)
+    m = L.LoraInjectedLinear(K, N, bias, r=r, dropout_p=0.0, scale=s).to(DEV).to(torch.bfloat16)
+    m.linear.requires_grad_(False)
+    T.promote_lora_to_fp32(m)
+    m.lora_up.weight.data.normal_(0, 0.05)
+    m.__dict__["_merged"] = mw = ops.MergedWeights()
+    x, gy = rnd((M, K), "bf16", seed=5), rnd((M, N), "bf16", seed=6)
+    X, G = n(x), n(gy)
+    W, A, U = n(m.linear.weight), n(m.lora_down.weight), n(m.lora_up.weight)
+    Bv = n(m.linear.bias) if bias else None
+    xd = (torch.from_numpy(_heads_pack(X, in_heads)).to(DEV).bfloat16() if in_heads else x).requires_grad_(True)
+    gd = torch.from_numpy(_heads_pack(G, out_heads)).to(DEV).bfloat16() if out_heads else gy
+    for rep in range(2):  # second pass: through refresh()'s batched plan instead of the entry's first merge
+        mw.refresh()
+        xd.grad = None
+        m.lora_up.weight.grad = m.lora_down.weight.grad = None
+        y = m.forward_heads(xd, in_heads, out_heads)
+        y.backward(gd)
+        yo, _ = O.lora_linear_forward(X, W, Bv, A, U, s)
+        dxo, ddo, duo, _, _ = O.lora_linear_backward(G, X, W, A, U, s)
+        yv, dxv = n(y), n(xd.grad)
+        if out_heads:
+            h, d, D = out_heads
+            assert np.all(yv.reshape(M, h, D)[:, :, d:] == 0)
+            yv = yv.reshape(M, h, D)[:, :, :d].reshape(M, N)
+        if in_heads:
+            h, d, D = in_heads
+            assert np.all(dxv.reshape(M, h, D)[:, :, d:] == 0)
+            dxv = dxv.reshape(M, h, D)[:, :, :d].reshape(M, K)
+        absy = np.abs(X) @ (np.abs(W) + s * np.abs(U) @ np.abs(A)).T + (np.abs(Bv) if bias else 0.0)
+        # W_eff is rounded to bf16 once (2^-9 relative on W + s U A), the GEMM output once
+        assert np.all(np.abs(yv - yo) <= 2.0 ** -8 * absy + 2.0 ** -8 * np.abs(yo) + 1e-3), rep
+        absdx = np.abs(G) @ (np.abs(W) + s * np.abs(U) @ np.abs(A))
+        assert np.all(np.abs(dxv - dxo) <= 2.0 ** -8 * absdx + 2.0 ** -8 * np.abs(dxo) + 1e-3), rep
+        close(n(m.lora_up.weight.grad), duo, s * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
+        close(n(m.lora_down.weight.grad), ddo, (s * np.abs(G) @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
+    assert mw.refreshes == 2 and len(mw.entries) == 1
+
+
 # ----------------------------------------------------------------------------- f1: every shape group in one launch
 def test_ragged_svd_of_several_shape_groups_vs_exact_svd():
     """cli_svd.py:24-92 over a model = sites of several shapes.  ``topr_svd_ragged`` (one descriptor-table launch per
@@ -304,18 +395,20 @@ def _compare_step(ref, loss_dev, st):
     assert abs(float(np.linalg.norm(flat)) - tot_r) <= 0.02 * tot_r
 
 
-@pytest.mark.parametrize("config", ["bench", "plain"])
+@pytest.mark.parametrize("config", ["bench", "bench_fused_sites", "plain"])
 def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_step, monkeypatch, config):
     """VERDICT r2 item 1a.  "bench": what BENCH_rNN times (bf16, channels_last activations and conv weights, head-padded
     q/k/v/out projections, grouped q/k/v, the hostops passes, the step replayed from a hipGraph); "plain": NCHW, no head
-    padding, one launch per projection, ATen normalisations, eager.  Both vs oracle/torch_ref.dreambooth_step (f32 on
+    padding, one launch per projection, ATen normalisations, eager; "bench" additionally runs the adapters on the step's
+    merged weight (``--merged 1``, bench.py's default since round 3), "bench_fused_sites" on the per-site fused MFMA
+    kernels (``--merged 0``).  All vs oracle/torch_ref.dreambooth_step (f32 on
     the host): loss within 1 %, every LoRA gradient tensor's cosine >= 0.99, norms within 10 %, total norm within 2 %.
     (bf16 compute against f32: the tolerance is the north star's stated fp16-class tolerance on whole-step quantities.)"""
     from lora_amd.standin import fused
 
     ref = sd15_reference_step
     unet = ref["dev_unet"]
-    bench_like = config == "bench"
+    bench_like = config.startswith("bench")
     monkeypatch.setenv("LORA_AMD_HEAD_PAD", "1" if bench_like else "0")
     monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1" if bench_like else "0")
     monkeypatch.setattr(fused, "_ENABLED", bench_like)
@@ -324,6 +417,7 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
     st = T.FlatLoraState([{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}], max_grad_norm=1.0,
                          device=torch.device(DEV))
     st.attach_direct_grads(unet)
+    merged = st.enable_merged_weights(unet) if config == "bench" else None
     sched = DDPMScheduler()
     lat = ref["lat"].to(DEV).to(torch.bfloat16).contiguous(memory_format=fmt)
     ehs = ref["ehs"].to(DEV).to(torch.bfloat16)
@@ -331,7 +425,7 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
     ts = ref["ts"].to(DEV)
 
     def fwd_bwd(l_, c_):
-        return T.forward_backward(unet, sched, l_, c_, T.StepConfig(), noise=noise, timesteps=ts)
+        return T.forward_backward(unet, sched, l_, c_, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
 
     try:
         for _ in range(2):  # attention choices are timed on first use; the padded layout applies from the second call
@@ -345,9 +439,12 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
             loss = float(fwd_bwd(lat, ehs))
             st.reduce_pending()
         _compare_step(ref, loss, st)
+        if merged is not None:  # every one of the 144 sites took the merged path, in the layouts the host model uses
+            assert len({id(e["module"]) for e in merged.entries.values()}) == 144 and merged.refreshes >= 3
     finally:
         for m in unet.modules():
             m.__dict__.pop("_grad_sink", None)
+            m.__dict__.pop("_merged", None)
 
 
 # ----------------------------------------------------------------------------- multi-GPU: 2 RCCL ranks (skips on a 1-GPU box)
