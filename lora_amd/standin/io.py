@@ -243,10 +243,12 @@ def load_host_models(path: str, vae_path: Optional[str], revision: Optional[str]
                                             revision=None if vae_path else revision)
         unet = UNet2DConditionModel.from_pretrained(path, subfolder="unet", revision=revision)
         sched = DDPMScheduler.from_config(path, subfolder="scheduler")
-        from ..diffusers_glue import install_attention_processor
+        from ..diffusers_glue import install_attention_processor, install_host_options
 
         n_attn = install_attention_processor(unet)  # q/k/v of a block in one launch once the adapters are injected
-        return tok, te, vae, unet, sched, f"diffusers checkpoint {path} ({n_attn} attention blocks on LoraAmdAttnProcessor)"
+        bound = install_host_options(unet)  # GroupNorm(+SiLU), add+LayerNorm, GEGLU, attention-kernel choice / head padding
+        return tok, te, vae, unet, sched, (f"diffusers checkpoint {path} ({n_attn} attention blocks on LoraAmdAttnProcessor; "
+                                           f"host passes bound: {bound})")
     from . import DDPMScheduler, clip_text_model, sd15_unet, tiny_unet
 
     if seed is None:

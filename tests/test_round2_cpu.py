@@ -245,3 +245,133 @@ def test_diffusers_processor_hands_back_variants_it_does_not_model():
         attn = types.SimpleNamespace(heads=2, **extra)
         assert proc(attn, x) == "fallback"
     assert len(calls) == 5
+
+
+def test_host_options_bind_into_fake_diffusers_blocks_and_keep_the_maths():
+    """the stand-in's frozen-host passes (GroupNorm+SiLU with the time-embedding addend, residual
+    add + LayerNorm, GEGLU, tuned attention processor) bound into ``diffusers``-shaped blocks by
+    ``diffusers_glue.install_host_options``: same outputs and gradients as the blocks' own forward (CPU: the bound passes
+    take their ATen sequences), unsupported variants keep their original forward."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from lora_amd.diffusers_glue import LoraAmdAttnProcessor, install_host_options
+
+    class Attention(nn.Module):
+        def __init__(self, dim=32, heads=2, ctx=None):
+            super().__init__()
+            self.heads, self.scale = heads, (dim // heads) ** -0.5
+            self.to_q = nn.Linear(dim, dim, bias=False)
+            self.to_k = nn.Linear(ctx or dim, dim, bias=False)
+            self.to_v = nn.Linear(ctx or dim, dim, bias=False)
+            self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+            self.processor = default_processor  # diffusers blocks always carry one (AttnProcessor / AttnProcessor2_0)
+
+        def set_processor(self, p):
+            self.processor = p
+
+        def forward(self, x, encoder_hidden_states=None, attention_mask=None, **kw):
+            return self.processor(self, x, encoder_hidden_states, attention_mask)
+
+    def default_processor(attn, x, encoder_hidden_states=None, attention_mask=None, temb=None, *a, **k):
+        c = x if encoder_hidden_states is None else encoder_hidden_states
+        B, T, _ = x.shape
+        q, k_, v = (t.view(B, t.shape[1], attn.heads, -1).transpose(1, 2) for t in (attn.to_q(x), attn.to_k(c), attn.to_v(c)))
+        s_ = q @ k_.transpose(-1, -2) * attn.scale
+        if attention_mask is not None:
+            s_ = s_ + attention_mask[:, None]
+        return attn.to_out[1](attn.to_out[0]((torch.softmax(s_, -1) @ v).transpose(1, 2).reshape(B, T, -1)))
+
+    class GEGLU(nn.Module):  # diffusers.models.activations.GEGLU
+        def __init__(self, dim_in, dim_out):
+            super().__init__()
+            self.proj = nn.Linear(dim_in, dim_out * 2)
+
+        def forward(self, hidden_states, *a, **k):
+            hidden_states, gate = self.proj(hidden_states).chunk(2, dim=-1)
+            return hidden_states * F.gelu(gate)
+
+    class FeedForward(nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+        def forward(self, x):
+            for m in self.net:
+                x = m(x)
+            return x
+
+    class BasicTransformerBlock(nn.Module):  # diffusers.models.attention.BasicTransformerBlock, SD1.x configuration
+        def __init__(self, dim=32, ctx=16, ada=False):
+            super().__init__()
+            self.norm1, self.attn1 = nn.LayerNorm(dim), Attention(dim)
+            self.norm2, self.attn2 = nn.LayerNorm(dim), Attention(dim, ctx=ctx)
+            self.norm3, self.ff = nn.LayerNorm(dim), FeedForward(dim)
+            self.use_ada_layer_norm, self.only_cross_attention, self.pos_embed, self._chunk_size = ada, False, None, None
+            self.norm_type = "layer_norm"
+
+        def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                    timestep=None, cross_attention_kwargs=None, class_labels=None, added_cond_kwargs=None):
+            x = hidden_states
+            x = self.attn1(self.norm1(x), attention_mask=attention_mask) + x
+            x = self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states) + x
+            return self.ff(self.norm3(x)) + x
+
+    class ResnetBlock2D(nn.Module):  # diffusers.models.resnet.ResnetBlock2D
+        def __init__(self, cin=32, cout=64, temb=24, norm="default", osf=1.0):
+            super().__init__()
+            self.norm1, self.conv1 = nn.GroupNorm(8, cin), nn.Conv2d(cin, cout, 3, padding=1)
+            self.time_emb_proj = nn.Linear(temb, cout)
+            self.norm2, self.dropout, self.conv2 = nn.GroupNorm(8, cout), nn.Dropout(0.0), nn.Conv2d(cout, cout, 3, padding=1)
+            self.nonlinearity = nn.SiLU()
+            self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+            self.time_embedding_norm, self.up, self.down, self.upsample, self.downsample = norm, False, False, None, None
+            self.output_scale_factor = osf
+
+        def forward(self, input_tensor, temb, *a, **k):
+            h = self.conv1(self.nonlinearity(self.norm1(input_tensor)))
+            h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
+            h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+            sc = input_tensor if self.conv_shortcut is None else self.conv_shortcut(input_tensor)
+            return (sc + h) / self.output_scale_factor
+
+    class FakeUNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.res = ResnetBlock2D(osf=2.0)
+            self.res_odd = ResnetBlock2D(norm="scale_shift")
+            self.blk = BasicTransformerBlock()
+            self.blk_ada = BasicTransformerBlock(ada=True)
+
+    torch.manual_seed(0)
+    unet = FakeUNet()
+    x4, temb = torch.randn(2, 32, 6, 6, requires_grad=True), torch.randn(2, 24)
+    xt, ctx = torch.randn(2, 9, 32, requires_grad=True), torch.randn(2, 5, 16)
+
+    def run():
+        outs = [unet.res(x4, temb), unet.blk(xt, encoder_hidden_states=ctx), unet.blk_ada(xt, encoder_hidden_states=ctx),
+                unet.res_odd(x4, temb)]
+        grads = torch.autograd.grad(sum(o.square().sum() for o in outs), [x4, xt])
+        return [o.detach() for o in outs], grads
+
+    want, gwant = run()
+    counts = install_host_options(unet)
+    assert counts == {"attention": 4, "transformer_block": 1, "resnet": 1, "geglu": 2}, counts
+    assert "_lora_amd_forward" in unet.res.__dict__ and "_lora_amd_forward" not in unet.res_odd.__dict__
+    assert "_lora_amd_forward" not in unet.blk_ada.__dict__
+    assert isinstance(unet.blk.attn1.processor, LoraAmdAttnProcessor) and unet.blk.attn1.processor.tuned
+    got, ggot = run()
+    for a, b in zip(want + list(gwant), got + list(ggot)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert install_host_options(unet) == {"attention": 4, "transformer_block": 0, "resnet": 0, "geglu": 0}  # idempotent
+    # a masked call of a bound block goes to the block's own forward
+    m = torch.zeros(2, 9, 9)
+    assert torch.allclose(unet.blk(xt, attention_mask=m, encoder_hidden_states=ctx).detach(),
+                          unet.blk._lora_amd_forward(xt, attention_mask=m, encoder_hidden_states=ctx).detach())
+    # adapters injected afterwards keep working through the bound blocks
+    type(unet.blk.attn1).__name__ = "Attention"
+    L.inject_trainable_lora(unet, r=2)
+    assert isinstance(unet.blk.ff.net[0].proj, L.LoraInjectedLinear)
+    got2, _ = run()
+    for a, b in zip(want, got2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)  # up = 0 at injection: same function
