@@ -327,7 +327,7 @@ class MergePlan:
         lib = require()
         if len(sites) == 0:
             raise ValueError("MergePlan: no sites")
-        w0, _, up0, _ = sites[0]
+        w0, _, up0, _ = sites[0][:4]
         self.w_dtype, self.ab_dtype = w0.dtype, up0.dtype
         self.device = w0.device
         n = len(sites)

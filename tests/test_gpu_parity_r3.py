@@ -269,7 +269,7 @@ def test_merged_weight_adapter_forward_backward_vs_oracle(in_heads, out_heads, r
         assert np.all(np.abs(dxv - dxo) <= 2.0 ** -8 * absdx + 2.0 ** -8 * np.abs(dxo) + 1e-3), rep
         close(n(m.lora_up.weight.grad), duo, s * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
         close(n(m.lora_down.weight.grad), ddo, (s * np.abs(G) @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
-    assert mw.refreshes == 2 and len(mw.entries) == 1
+    assert mw.refreshes == 1 and len(mw.entries) == 1  # the first refresh() found no site yet
 
 
 # ----------------------------------------------------------------------------- f1: every shape group in one launch
