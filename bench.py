@@ -289,7 +289,7 @@ def adapter_path_profile(step_fn, state) -> dict:
         dur = float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
         total_us += dur
         name = ev.name
-        if "lora_amd::" not in name:
+        if "lora_amd::" not in name or name == "lora_amd::merged_gemm":  # the range itself: added below, once
             continue
         short = name.split("lora_amd::", 1)[1].split("(")[0]
         k = kern.setdefault(short, [0, 0.0])

@@ -350,22 +350,26 @@ __global__ __launch_bounds__(kThreads) void rank_update_generic_kernel(
 constexpr int kColRowsPerBlock = 64;
 constexpr int kColMaxChunks = 64;
 
-template <class EX, int RT, bool MASKED>
+// RB = rows per block: 64 for the single / batched launches (many of them are short stacks of activations), 256 for the
+// ragged SVD passes (tall residual stacks: a quarter of the partial slabs and of the slot reductions per byte streamed).
+constexpr int kColRowsRagged = 256;
+
+template <class EX, int RT, bool MASKED, int RB = kColRowsPerBlock>
 __device__ inline void colreduce_stage1_body(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
     uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int64_t bx) {
   // s_red doubles as the slot-reduction buffer: [slot][c8*8][4 ranks]
   __shared__ __attribute__((aligned(16))) float s_red[kThreads * 8 * 4];
-  __shared__ float s_t[kColRowsPerBlock * RT];
+  __shared__ float s_t[RB * RT];
   const int tid = threadIdx.x;
   const int64_t rb = bx / col_tiles;
   const int ct = (int)(bx - rb * col_tiles);
   const int col0 = ct * kColMaxChunks * 8;
   const int ncols = min(kColMaxChunks * 8, K - col0);
   const int c8 = ncols >> 3;
-  const int64_t m0 = rb * kColRowsPerBlock;
-  const int nrows = (int)min((int64_t)kColRowsPerBlock, M - m0);
+  const int64_t m0 = rb * RB;
+  const int nrows = (int)min((int64_t)RB, M - m0);
   const int nslots = kThreads / c8;  // >= 1
   const int slot = tid / c8, cc = tid - slot * c8;
 
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_ragged_kernel(const
   const lora_amd_ragged_desc d = descs[g];
   const int64_t local = (int64_t)blockIdx.x - d.begin1;
   const int64_t by = local / d.blocks1, bx = local - by * d.blocks1;
-  colreduce_stage1_body<f32_t, RT, false>(reinterpret_cast<const float *>(d.x) + by * d.stride_x, d.ldx,
+  colreduce_stage1_body<f32_t, RT, false, kColRowsRagged>(reinterpret_cast<const float *>(d.x) + by * d.stride_x, d.ldx,
                                           reinterpret_cast<const float *>(d.f) + by * d.stride_f,
                                           d.partial + by * d.stride_partial, d.M, d.K, r, rank0, d.col_tiles, 0.f, 0, 0,
                                           nullptr, bx);
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage2_ragged_kernel(const
   const lora_amd_ragged_desc d = descs[g];
   const int64_t local = (int64_t)blockIdx.x - d.begin2;
   const int64_t by = local / d.blocks2, bx = local - by * d.blocks2;
-  const int64_t nrb = (d.M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+  const int64_t nrb = (d.M + kColRowsRagged - 1) / kColRowsRagged;
   colreduce_stage2_body(d.partial + by * d.stride_partial, d.out + by * d.stride_out, nrb, d.K, r, RT, rank0, out_layout,
                         scale, 0.f, bx);
 }
@@ -850,7 +854,7 @@ extern "C" int lora_amd_ragged_plan(int32_t op, lora_amd_ragged_desc *descs, int
       d.blocks1 = (int32_t)((d.M + rows_per_block - 1) / rows_per_block);
     } else {
       LORA_AMD_CHECK(d.partial, LORA_AMD_EWORKSPACE, "ragged_plan: group %d: colreduce needs a workspace", i);
-      const int64_t nrb = (d.M + kColRowsPerBlock - 1) / kColRowsPerBlock;
+      const int64_t nrb = (d.M + kColRowsRagged - 1) / kColRowsRagged;
       d.col_tiles = (d.K + kColMaxChunks * 8 - 1) / (kColMaxChunks * 8);
       d.blocks1 = (int32_t)(nrb * d.col_tiles);
       d.blocks2 = (int32_t)(((int64_t)col_rank_tile(r) * d.K + 63) / 64);

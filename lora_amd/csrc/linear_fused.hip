@@ -602,7 +602,7 @@ struct SelfArgs {
   int N, K, r, rows_per_block, nsplit;
   int ghc, ghp, xhc, xhp;          // head-padded rows (16-byte chunks per head: logical, physical); 0 = dense
   int kt_g, logL_g, kt_x, logL_x;  // phase A: factor columns per LDS stage, lanes per row (log2)
-  int log_ct8_g, nct_g, log_ct8_x, nct_x;  // phase B: column tiles
+  int tile_g, nct_g, tile_x, nct_x;  // phase B: 16-byte chunks per column tile (<= 256), number of tiles
 };
 
 __device__ inline int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
@@ -675,41 +675,77 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
   }
 }
 
-// part[j][c] (this block's [RT][C] slab) = sum over the block's rows of s_vec[row][j] * data[row, c], one column tile.
+// part[j][c] (this block's [RT][C] slab) = sum over the block's rows of s_vec[row][j] * data[row, c] for the column tile
+// [c0, c0 + tc8) (16-byte chunks; tc8 <= 256, any value: slot = tid / tc8, so a 320-wide row is ONE tile of 40 chunks x 6
+// row slots instead of five power-of-two tiles with a slot reduction each).
 template <class E, int RT>
 __device__ inline void block_colsums(float *s_red, const float *s_vec, const typename E::storage *data, int64_t ld,
-                                     int64_t m0, int nrows, int C, int log_ct8, int ct, float *part, int hc, int hp) {
+                                     int64_t m0, int nrows, int C, int c0, int tc8, float *part, int hc, int hp) {
   const int tid = threadIdx.x;
-  const int ct8 = 1 << log_ct8, nslots = kFT >> log_ct8;
-  const int slot = tid >> log_ct8, cl = tid & (ct8 - 1);
-  const int col = (ct * ct8 + cl) * 8;
-  const int pcol = hchunk(col >> 3, hc, hp) * 8;
+  const int nslots = kFT / tc8;
+  const int slot = tid / tc8, cl = tid - slot * tc8;
+  const bool owner = slot < nslots;  // kFT % tc8 threads idle in the streaming part
+  const int col = (c0 + cl) * 8;
+  const int pcol = hchunk(c0 + cl, hc, hp) * 8;
   float acc[RT][8];
 #pragma unroll
   for (int j = 0; j < RT; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
   constexpr int U = 4;
-  for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
-    float v[U][8];
+  if (owner) {
+    for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+      float v[U][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int rl = rb0 + u * nslots;
-      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
-    }
+      for (int u = 0; u < U; ++u) {
+        const int rl = rb0 + u * nslots;
+        load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int rl = rb0 + u * nslots;
-      const float *tr = s_vec + (rl < nrows ? rl : 0) * RT;  // rows past the end contribute v = 0
+      for (int u = 0; u < U; ++u) {
+        const int rl = rb0 + u * nslots;
+        const float *tr = s_vec + (rl < nrows ? rl : 0) * RT;  // rows past the end contribute v = 0
 #pragma unroll
-      for (int j = 0; j < RT; ++j) {
-        const float tj = tr[j];
+        for (int j = 0; j < RT; ++j) {
+          const float tj = tr[j];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, v[u][i], acc[j][i]);
+          for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, v[u][i], acc[j][i]);
+        }
       }
     }
   }
-  slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, part, C, ct * ct8 * 8);
+  if (nslots == 1) {  // a tile of more than 128 chunks: one row slot, every owner holds final column sums
+#pragma unroll
+    for (int j = 0; owner && j < RT; ++j) {
+      *reinterpret_cast<float4 *>(part + (int64_t)j * C + col) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      *reinterpret_cast<float4 *>(part + (int64_t)j * C + col + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+    }
+    return;
+  }
+  // slot reduction through LDS: [4 ranks][slot][col]
+  const int ncols = tc8 * 8;
+#pragma unroll
+  for (int jb = 0; jb < RT; jb += 4) {
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float *dst = &s_red[((jj * nslots + slot) * ncols) + cl * 8];
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[(jb + jj) % RT][0], acc[(jb + jj) % RT][1],
+                                                       acc[(jb + jj) % RT][2], acc[(jb + jj) % RT][3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[(jb + jj) % RT][4], acc[(jb + jj) % RT][5],
+                                                           acc[(jb + jj) % RT][6], acc[(jb + jj) % RT][7]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < ncols * 4; i += kFT) {
+      const int jj = i / ncols, cc = i - jj * ncols;
+      const float *src = &s_red[(jj * nslots) * ncols + cc];
+      float sum = 0.f;
+      for (int q = 0; q < nslots; ++q) sum += src[q * ncols];
+      part[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
+    }
+  }
 }
 
 template <class E, int RT>
@@ -730,13 +766,18 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
   block_rowdots<E, RT>(s_buf, s_gt, g, a.ldg, m0, nrows, a.N, a.up, LORA_AMD_FACTOR_KR, a.r, a.kt_g, a.logL_g, a.scale,
                        a.ghc, a.ghp);
   __syncthreads();
+  // phase B: column tiles of <= 256 chunks, G's first, shared out among the splits of the row block
+  const int c8g = a.N >> 3, c8x = a.K >> 3;
   for (int t = sp; t < a.nct_g + a.nct_x; t += a.nsplit) {
-    if (t < a.nct_g)
-      block_colsums<E, RT>(s_buf, s_t, g, a.ldg, m0, nrows, a.N, a.log_ct8_g, t, a.up_part + rb * RT * (int64_t)a.N,
-                           a.ghc, a.ghp);
-    else
-      block_colsums<E, RT>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, a.log_ct8_x, t - a.nct_g,
+    if (t < a.nct_g) {
+      const int c0 = t * a.tile_g;
+      block_colsums<E, RT>(s_buf, s_t, g, a.ldg, m0, nrows, a.N, c0, min(a.tile_g, c8g - c0),
+                           a.up_part + rb * RT * (int64_t)a.N, a.ghc, a.ghp);
+    } else {
+      const int c0 = (t - a.nct_g) * a.tile_x;
+      block_colsums<E, RT>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, c0, min(a.tile_x, c8x - c0),
                            a.down_part + rb * RT * (int64_t)a.K, a.xhc, a.xhp);
+    }
   }
 }
 
@@ -1027,7 +1068,7 @@ static int bwd_factors_impl(const void *g, int64_t ldg, const float *t, float *u
 
 // Geometry of the self-sufficient factor-gradient launch (also the size of its partial workspaces).
 static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64_t *nrb_out) {
-  if (M <= 0 || r < 1 || r > 16 || K % 8 || N % 8 || pow2_divisor(N / 8, 64) < 4 || pow2_divisor(K / 8, 256) < 4) return false;
+  if (M <= 0 || r < 1 || r > 16 || K % 8 || N % 8 || K < 32 || N < 32) return false;
   const int RT = frank_tile(r);
   // rows per block: one workgroup streams its rows twice (phase A, phase B); enough blocks to give every CU two, at
   // least 16 rows (the partial slabs are RT*4 / (rows*2) of the stream) and at most what the LDS row vectors hold
@@ -1036,9 +1077,10 @@ static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64
   rows = std::min<int64_t>(rows, std::min<int64_t>(64, kFLdsT / RT));
   rows = std::min<int64_t>(rows, M);
   const int64_t nrb = (M + rows - 1) / rows;
-  const int ct8g = pow2_divisor(N / 8, 64), ct8x = pow2_divisor(K / 8, 256);
-  a->log_ct8_g = ilog2(ct8g); a->nct_g = (N / 8) / ct8g;
-  a->log_ct8_x = ilog2(ct8x); a->nct_x = (K / 8) / ct8x;
+  // phase B tiles: the whole row when it has <= 256 chunks, else equal tiles of <= 256 chunks
+  auto tiles = [](int c8, int *tile, int *nct) { *nct = (c8 + 255) / 256; *tile = (c8 + *nct - 1) / *nct; };
+  tiles(N / 8, &a->tile_g, &a->nct_g);
+  tiles(K / 8, &a->tile_x, &a->nct_x);
   int nsplit = (int)std::min<int64_t>((512 + nrb - 1) / nrb, 4);
   nsplit = std::max(1, std::min(nsplit, a->nct_g + a->nct_x));
   a->nsplit = nsplit;
