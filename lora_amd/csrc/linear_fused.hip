@@ -607,7 +607,8 @@ struct SelfArgs {
 
 __device__ inline int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
 
-// s_out[rl * RT + j] = mult * sum_c data[m0 + rl, c] * factor(j, c) for the block's rows; L lanes per row.
+// s_out[rl * RT + j] = mult * sum_c data[m0 + rl, c] * factor(j, c) for the block's rows; L lanes per row.  The factor
+// passes through LDS in slabs of kt_cols columns (outer loop: a slab is staged once per block, not once per row group).
 template <class E, int RT>
 __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
                                      int nrows, int C, const float *factor, int layout, int r, int kt_cols, int logL,
@@ -617,26 +618,18 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
   const int l = lane & (L - 1), g = lane >> logL;
   const int rows_iter = G * (kFT / 64);
   const int niter = (nrows + rows_iter - 1) / rows_iter;
-  const bool single = kt_cols >= C;
-  if (single) {
-    __syncthreads();
-    stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, 0, C);
-    __syncthreads();
-  }
   constexpr int U = 4;
-  for (int it = 0; it < niter; ++it) {
-    const int rl = it * rows_iter + wave * G + g;
-    const bool live = rl < nrows;
-    float acc[RT];
+  for (int k0 = 0; k0 < C; k0 += kt_cols) {
+    const int ncols = min(kt_cols, C - k0), c8 = ncols >> 3;
+    __syncthreads();
+    stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, k0, ncols);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+      const int rl = it * rows_iter + wave * G + g;
+      const bool live = rl < nrows;
+      float acc[RT];
 #pragma unroll
-    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
-    for (int k0 = 0; k0 < C; k0 += kt_cols) {
-      const int ncols = min(kt_cols, C - k0), c8 = ncols >> 3;
-      if (!single) {
-        __syncthreads();
-        stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, k0, ncols);
-        __syncthreads();
-      }
+      for (int j = 0; j < RT; ++j) acc[j] = 0.f;
       if (live) {
         const typename E::storage *xr = data + (m0 + rl) * ld;
         const int cbase = k0 >> 3;
@@ -664,13 +657,13 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
           }
         }
       }
-    }
-    for (int off = L >> 1; off > 0; off >>= 1)
+      for (int off = L >> 1; off > 0; off >>= 1)
 #pragma unroll
-      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-    if (live && l == 0) {
+        for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+      if (live && l == 0) {  // the row belongs to this lane group in every slab: no race on s_out
 #pragma unroll
-      for (int j = 0; j < RT; ++j) s_out[rl * RT + j] = acc[j] * mult;
+        for (int j = 0; j < RT; ++j) s_out[rl * RT + j] = (k0 == 0 ? 0.f : s_out[rl * RT + j]) + acc[j] * mult;
+      }
     }
   }
 }
@@ -777,6 +770,166 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
       const int c0 = (t - a.nct_g) * a.tile_x;
       block_colsums<E, RT>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, c0, min(a.tile_x, c8x - c0),
                            a.down_part + rb * RT * (int64_t)a.K, a.xhc, a.xhp);
+    }
+  }
+}
+
+// ---- the same, wave-specialised: the two halves of the workgroup work on the two tensors at the same time, so a block's
+// critical path is ONE trip to HBM (phase A: waves 0-1 take X rows against `down`, waves 2-3 the G rows against `up`)
+// and ONE to L2 (phase B: waves 0-1 sum G columns weighted by T, waves 2-3 X columns weighted by Gt) instead of four
+// trips in sequence.  Needs both factor slabs in LDS together: RT * (N + K) <= kSelfLdsFloats (every attention site and
+// the smallest GEGLU projection at rank 4; the sequential kernel above takes the rest).
+constexpr int kSelfLdsFloats = 12288;  // 48 KiB: [down slab | up slab] in phase A, the two slot-reduction areas in phase B
+constexpr int kHalf = kFT / 2;
+
+template <class E, int RT>
+__device__ inline void half_rowdots(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
+                                    int nrows, int C, int logL, float mult, int hc, int hp, int hw) {
+  const int lane = threadIdx.x & 63;
+  const int L = 1 << logL, G = 64 >> logL;
+  const int l = lane & (L - 1), g = lane >> logL;
+  const int rows_iter = G * 2, c8 = C >> 3;
+  constexpr int U = 4;
+  for (int rl = hw * G + g; rl < nrows; rl += rows_iter) {
+    float acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
+    const typename E::storage *xr = data + (m0 + rl) * ld;
+    for (int cb = l; cb < c8; cb += L * U) {
+      float xv[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cc = cb + u * L;
+        load8_sel<E>(xr + hchunk(cc < c8 ? cc : cb, hc, hp) * 8, cc < c8, xv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cc = cb + u * L;
+        if (cc >= c8) continue;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
+          const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + cc) * 4]);
+          float a = acc[j];
+          a = fmaf(xv[u][0], d0.x, a); a = fmaf(xv[u][1], d0.y, a); a = fmaf(xv[u][2], d0.z, a);
+          a = fmaf(xv[u][3], d0.w, a); a = fmaf(xv[u][4], d1.x, a); a = fmaf(xv[u][5], d1.y, a);
+          a = fmaf(xv[u][6], d1.z, a); a = fmaf(xv[u][7], d1.w, a);
+          acc[j] = a;
+        }
+      }
+    }
+    for (int off = L >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    if (l == 0) {
+#pragma unroll
+      for (int j = 0; j < RT; ++j) s_out[rl * RT + j] = acc[j] * mult;
+    }
+  }
+}
+
+template <class E, int RT>
+__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_dual_kernel(const SelfArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kSelfLdsFloats];
+  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];
+  using S = typename E::storage;
+  const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
+  const int64_t rb = blockIdx.x;
+  const int64_t m0 = rb * a.rows_per_block;
+  const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool first = wave < 2;  // wave-uniform
+  float *s_fx = s_buf, *s_fg = s_buf + RT * a.K;
+  stage_factor<RT>(s_fx, a.down, LORA_AMD_F32, LORA_AMD_FACTOR_RK, a.r, a.K, 0, a.K);
+  stage_factor<RT>(s_fg, a.up, LORA_AMD_F32, LORA_AMD_FACTOR_KR, a.r, a.N, 0, a.N);
+  __syncthreads();
+  // ---- phase A
+  if (first) half_rowdots<E, RT>(s_fx, s_t, x, a.ldx, m0, nrows, a.K, a.logL_x, a.scale, a.xhc, a.xhp, wave);
+  else half_rowdots<E, RT>(s_fg, s_gt, g, a.ldg, m0, nrows, a.N, a.logL_g, a.scale, a.ghc, a.ghp, wave - 2);
+  __syncthreads();
+  // ---- phase B: this half's tensor, its row vectors, its partial slab and its 16 KiB of the slot-reduction area
+  const S *data = first ? g : x;
+  const int64_t ld = first ? a.ldg : a.ldx;
+  const int C = first ? a.N : a.K, hc = first ? a.ghc : a.xhc, hp = first ? a.ghp : a.xhp;
+  const float *s_vec = first ? s_t : s_gt;
+  float *part = first ? a.up_part + rb * RT * (int64_t)a.N : a.down_part + rb * RT * (int64_t)a.K;
+  float *s_red = s_buf + (first ? 0 : 4096);
+  const int c8 = C >> 3;
+  const int ntile = (c8 + kHalf - 1) / kHalf, tile = (c8 + ntile - 1) / ntile;
+  const int ntile_max = max(((a.N >> 3) + kHalf - 1) / kHalf, ((a.K >> 3) + kHalf - 1) / kHalf);
+  const int ht = tid & (kHalf - 1);
+  for (int t = 0; t < ntile_max; ++t) {  // both halves pass the same barriers
+    const bool have = t < ntile;
+    const int c0 = t * tile, tc8 = have ? min(tile, c8 - c0) : 1;
+    const int nslots = kHalf / tc8;
+    const int slot = ht / tc8, cl = ht - slot * tc8;
+    const bool owner = have && slot < nslots;
+    const int col = (c0 + cl) * 8;
+    float acc[RT][8];
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    constexpr int U = 4;
+    if (owner) {
+      const int pcol = hchunk(c0 + cl, hc, hp) * 8;
+      for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rl = rb0 + u * nslots;
+          load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rl = rb0 + u * nslots;
+          const float *tr = s_vec + (rl < nrows ? rl : 0) * RT;
+#pragma unroll
+          for (int j = 0; j < RT; ++j) {
+            const float tj = tr[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(tj, v[u][i], acc[j][i]);
+          }
+        }
+      }
+    }
+    const int ncols = tc8 * 8;
+#pragma unroll
+    for (int jb = 0; jb < RT; jb += 4) {
+      __syncthreads();  // phase A's factor slabs / the previous round's sums have been read
+      if (owner) {
+        if (nslots == 1) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            float *dst = part + (int64_t)(jb + jj) * C + col;
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[(jb + jj) % RT][0], acc[(jb + jj) % RT][1],
+                                                           acc[(jb + jj) % RT][2], acc[(jb + jj) % RT][3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[(jb + jj) % RT][4], acc[(jb + jj) % RT][5],
+                                                               acc[(jb + jj) % RT][6], acc[(jb + jj) % RT][7]);
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            float *dst = &s_red[((jj * nslots + slot) * ncols) + cl * 8];
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[(jb + jj) % RT][0], acc[(jb + jj) % RT][1],
+                                                           acc[(jb + jj) % RT][2], acc[(jb + jj) % RT][3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[(jb + jj) % RT][4], acc[(jb + jj) % RT][5],
+                                                               acc[(jb + jj) % RT][6], acc[(jb + jj) % RT][7]);
+          }
+        }
+      }
+      __syncthreads();
+      if (have && nslots > 1) {
+        for (int i = ht; i < ncols * 4; i += kHalf) {
+          const int jj = i / ncols, cc = i - jj * ncols;
+          const float *src = &s_red[(jj * nslots) * ncols + cc];
+          float sum = 0.f;
+          for (int q = 0; q < nslots; ++q) sum += src[q * ncols];
+          part[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
+        }
+      }
     }
   }
 }
@@ -1130,7 +1283,14 @@ extern "C" int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, cons
   const unsigned grid = (unsigned)(nrb * a.nsplit);
   const int RT = frank_tile(r);
   hipStream_t st = (hipStream_t)stream;
-#define FS(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a)
+  // both factor slabs in LDS at once -> the wave-specialised kernel (one row block per workgroup, no column splits)
+  static const bool no_dual = getenv("LORA_AMD_SELF_DUAL") && atoi(getenv("LORA_AMD_SELF_DUAL")) == 0;
+  const bool dual = !no_dual && (int64_t)RT * (N + K) <= kSelfLdsFloats && a.logL_x >= 0;
+#define FS(E, RTV)                                                                                                    \
+  do {                                                                                                                \
+    if (dual) hipLaunchKernelGGL((linear_bwd_factors_self_dual_kernel<E, RTV>), dim3((unsigned)nrb), dim3(kFT), 0, st, a); \
+    else hipLaunchKernelGGL((linear_bwd_factors_self_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a);                \
+  } while (0)
 #define FS_E(E) do { if (RT == 4) FS(E, 4); else if (RT == 8) FS(E, 8); else FS(E, 16); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: FS_E(f32_t); break;

@@ -100,9 +100,17 @@ class LoraAmdAttnProcessor:
             return None
         backend, D = pad
         lay = (h, d, D)
-        q = attn.to_q.forward_heads(x, None, lay).view(B, T, h, D).transpose(1, 2)
-        k = attn.to_k.forward_heads(ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
-        v = attn.to_v.forward_heads(ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+        grouped = lora_linear_group([attn.to_q, attn.to_k, attn.to_v], x, out_heads=lay) if ctx is x else None
+        kv = lora_linear_group([attn.to_k, attn.to_v], ctx, out_heads=lay) if ctx is not x else None
+        q, k, v = grouped if grouped is not None else (None, None, None)
+        if kv is not None:
+            k, v = kv
+        q = attn.to_q.forward_heads(x, None, lay) if q is None else q
+        k = attn.to_k.forward_heads(ctx, None, lay) if k is None else k
+        v = attn.to_v.forward_heads(ctx, None, lay) if v is None else v
+        q = q.view(B, T, h, D).transpose(1, 2)
+        k = k.view(B, ctx.shape[1], h, D).transpose(1, 2)
+        v = v.view(B, ctx.shape[1], h, D).transpose(1, 2)
         o = attention.sdpa_padded(q, k, v, d, backend).transpose(1, 2).reshape(B, T, h * D)
         o = attn.to_out[1](attn.to_out[0].forward_heads(o, lay, None))
         rescale = getattr(attn, "rescale_output_factor", 1.0)

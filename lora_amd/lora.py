@@ -178,7 +178,7 @@ class LoraInjectedLinear(_Adapter):
         self.selector.weight.data = torch.diag(diag).to(self.lora_up.weight.device).to(self.lora_up.weight.dtype)
 
 
-def lora_linear_group(adapters, x: torch.Tensor):
+def lora_linear_group(adapters, x: torch.Tensor, out_heads=None):
     """Apply several ``LoraInjectedLinear`` adapters to the SAME input in one launch where that is possible (device
     tensors, 16-bit compute, no dropout in effect, no selector, f32 factors, equal rank, shapes the weight-stationary
     kernel covers); returns the list of outputs, or None when the caller should simply call the adapters one by one.
@@ -189,7 +189,23 @@ def lora_linear_group(adapters, x: torch.Tensor):
     if not x.is_cuda or len(adapters) < 2 or not all(isinstance(a, LoraInjectedLinear) for a in adapters):
         return None
     if all(a.__dict__.get("_merged") is not None for a in adapters):
-        return None  # merged-weight path: every site is a plain dense GEMM on its own merged weight
+        # merged-weight path: every site is a dense GEMM on its own merged weight; grouped so that the sites' input
+        # gradients accumulate inside the GEMMs (``out_heads``: the outputs leave in the padded head layout)
+        dt = _autocast_dtype(x, adapters[0].linear.weight)
+        xc = x if x.dtype == dt else x.to(dt)
+        flat = []
+        for a in adapters:
+            wc, bc = a._shadow(a.linear.weight, dt, "w"), a._shadow(a.linear.bias, dt, "b")
+            if not ops.merged_ok(xc, wc, a.lora_down.weight, a.lora_up.weight, a._selector_matrix(), a._dropout_p(), None,
+                                 out_heads):
+                return None
+            w_eff, b_eff = a.__dict__["_merged"].lookup(a, wc, bc, dt, None, out_heads)
+            flat += [w_eff, b_eff, a.lora_down.weight, a.lora_up.weight, float(a.scale), a.__dict__.get("_grad_sink"),
+                     out_heads]
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            return list(ops.LoraLinearMergedGroupFunction.apply(xc, len(adapters), *flat))
+    if out_heads is not None:
+        return None  # the per-site fused kernels take head layouts one adapter at a time (forward_heads)
     a0 = adapters[0]
     w0 = a0.linear.weight
     dt = _autocast_dtype(x, w0)

@@ -556,6 +556,79 @@ class LoraLinearMergedFunction(torch.autograd.Function):
         return dx, None, db, d_down, d_up, None, None, None, None
 
 
+class LoraLinearMergedGroupFunction(torch.autograd.Function):
+    """Several merged-weight sites on ONE input (attn1's to_q / to_k / to_v, attn2's to_k / to_v) as one autograd node:
+    the input gradients of the sites are accumulated by the GEMMs themselves (``addmm_``: beta = 1 in the library's
+    epilogue) instead of n - 1 elementwise ``add`` launches over [M, K] that autograd would issue for n separate nodes.
+
+    Inputs: x, n, then per site (w_eff, b_eff, down, up, scale, sink, out_heads)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *args):
+        _C.require()
+        sites = [args[7 * i:7 * i + 7] for i in range(n)]
+        K = sites[0][0].shape[1]
+        x2 = _rows2d(x, K)
+        outs = []
+        with _gemm_range():
+            for (w_eff, b_eff, down, up, scale, sink, out_heads) in sites:
+                y = F.linear(x2, w_eff, b_eff)
+                outs.append(y.view(*x.shape[:-1], y.shape[1]))
+                N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
+                _log("fwd", "merged_group" + ("_heads" if out_heads else ""), x2.shape[0], K, N, down.shape[0])
+        ctx.save_for_backward(x2, *[t for st in sites for t in (st[0], st[2], st[3])])
+        ctx.meta = [(float(st[4]), st[5], st[6]) for st in sites]
+        ctx.n, ctx.x_shape = n, x.shape
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        M, K = x2.shape
+        need_x = ctx.needs_input_grad[0]
+        dx = None
+        grads = [None, None]
+        for i in range(ctx.n):
+            w_eff, down, up = saved[1 + 3 * i:4 + 3 * i]
+            scale, sink, out_heads = ctx.meta[i]
+            g = gs[i]
+            r = down.shape[0]
+            N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
+            d_down = d_up = None
+            if g is not None:
+                g2 = _rows2d(g, w_eff.shape[0])
+                if need_x:
+                    with _gemm_range():
+                        dx = (g2 @ w_eff) if dx is None else dx.addmm_(g2, w_eff)
+                plan = _C.factors_self_plan(M, K, N, r)
+                key = ("self", M, K, N, r)
+                if sink is not None:
+                    if sink.pending is not None:
+                        sink.flush()
+                    up_part, down_part = sink.self_workspace(key, plan, g2.device)
+                else:
+                    up_part, down_part = (torch.empty(max(int(q), 1), dtype=torch.float32, device=g2.device)
+                                          for q in (plan.up_part_floats, plan.down_part_floats))
+                _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale,
+                                           g_heads=out_heads, x_heads=None)
+                _log("bwd", "merged_group_dx+factors_self", M, K, N, r)
+                if sink is not None:
+                    sink.pending = key
+                else:
+                    d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+                    d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+                    rows = [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                            (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+                    table, cnt, total = _C.make_reduce_table(rows, g2.device)
+                    _C.reduce_batched(table, cnt, total)
+                    d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+            grads += [None, None, d_down, d_up, None, None, None]
+        grads[0] = dx.view(ctx.x_shape) if dx is not None else None
+        return tuple(grads)
+
+
 def merged_ok(x: torch.Tensor, weight: torch.Tensor, down: torch.Tensor, up: torch.Tensor, sel, dropout_p: float,
               in_heads, out_heads) -> bool:
     """Can this call take the merged-weight path?  (device, no dropout / selector, frozen weight, f32 factors, a shape

@@ -105,9 +105,24 @@ class CrossAttention(nn.Module):
             # (fused GEMM epilogue and operand remap, ops.lora_linear) instead of pad + slice copies around the core
             backend, D = pad
             lay = (h, d, D)
-            q = _project(self.to_q, x, None, lay).view(B, T, h, D).transpose(1, 2)
-            k = _project(self.to_k, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
-            v = _project(self.to_v, ctx, None, lay).view(B, ctx.shape[1], h, D).transpose(1, 2)
+            q = k = v = None
+            if x.is_cuda and os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0":
+                from ..lora import lora_linear_group
+
+                if context is None:
+                    out = lora_linear_group([self.to_q, self.to_k, self.to_v], x, out_heads=lay)
+                    if out is not None:
+                        q, k, v = out
+                else:
+                    out = lora_linear_group([self.to_k, self.to_v], ctx, out_heads=lay)
+                    if out is not None:
+                        k, v = out
+            q = _project(self.to_q, x, None, lay) if q is None else q
+            k = _project(self.to_k, ctx, None, lay) if k is None else k
+            v = _project(self.to_v, ctx, None, lay) if v is None else v
+            q = q.view(B, T, h, D).transpose(1, 2)
+            k = k.view(B, ctx.shape[1], h, D).transpose(1, 2)
+            v = v.view(B, ctx.shape[1], h, D).transpose(1, 2)
             o = attention.sdpa_padded(q, k, v, d, backend).transpose(1, 2).reshape(B, T, h * D)
             return self.to_out[1](_project(self.to_out[0], o, lay, None))
         q, k, v = project_qkv(self, x, context)

@@ -272,6 +272,51 @@ def test_merged_weight_adapter_forward_backward_vs_oracle(in_heads, out_heads, r
     assert mw.refreshes == 1 and len(mw.entries) == 1  # the first refresh() found no site yet
 
 
+@pytest.mark.parametrize("out_heads", [None, (8, 40, 64)])
+def test_merged_weight_group_of_sites_on_one_input_vs_oracle(out_heads):
+    """to_q / to_k / to_v on one tensor through lora.lora_linear_group with the adapters on ops.MergedWeights: each output
+    vs oracle.lora_linear_forward, the input gradient vs the SUM of the three oracle input gradients (accumulated inside
+    the GEMMs), every factor gradient vs oracle.lora_linear_backward."""
+    from lora_amd import ops
+
+    M, K, N, r, s = 1024, 320, 320, 4, 1.0
+    torch.manual_seed(1)
+    mw = ops.MergedWeights()
+    mods = []
+    for i in range(3):
+        m = L.LoraInjectedLinear(K, N, False, r=r, dropout_p=0.0, scale=s).to(DEV).to(torch.bfloat16)
+        m.linear.requires_grad_(False)
+        T.promote_lora_to_fp32(m)
+        m.lora_up.weight.data.normal_(0, 0.05)
+        m.__dict__["_merged"] = mw
+        mods.append(m)
+    x = rnd((M, K), "bf16", seed=7).requires_grad_(True)
+    gs = [rnd((M, N), "bf16", seed=8 + i) for i in range(3)]
+    outs = L.lora_linear_group(mods, x, out_heads=out_heads)
+    assert outs is not None and len(outs) == 3
+    gd = [torch.from_numpy(_heads_pack(n(g), out_heads)).to(DEV).bfloat16() if out_heads else g for g in gs]
+    torch.autograd.backward(outs, gd)
+    X = n(x)
+    dx_sum, absdx = 0.0, 0.0
+    for m, y, g in zip(mods, outs, gs):
+        W, A, U, G = n(m.linear.weight), n(m.lora_down.weight), n(m.lora_up.weight), n(g)
+        yo, _ = O.lora_linear_forward(X, W, None, A, U, s)
+        dxo, ddo, duo, _, _ = O.lora_linear_backward(G, X, W, A, U, s)
+        yv = n(y)
+        if out_heads:
+            h, d, D = out_heads
+            assert np.all(yv.reshape(M, h, D)[:, :, d:] == 0)
+            yv = yv.reshape(M, h, D)[:, :, :d].reshape(M, N)
+        absy = np.abs(X) @ (np.abs(W) + s * np.abs(U) @ np.abs(A)).T
+        assert np.all(np.abs(yv - yo) <= 2.0 ** -8 * absy + 2.0 ** -8 * np.abs(yo) + 1e-3)
+        dx_sum = dx_sum + dxo
+        absdx = absdx + np.abs(G) @ (np.abs(W) + s * np.abs(U) @ np.abs(A))
+        close(n(m.lora_up.weight.grad), duo, s * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
+        close(n(m.lora_down.weight.grad), ddo, (s * np.abs(G) @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
+    # three bf16 roundings of the running sum (addmm_ accumulates in the output dtype)
+    assert np.all(np.abs(n(x.grad) - dx_sum) <= 2.0 ** -8 * absdx + 3 * 2.0 ** -8 * np.abs(dx_sum) + 2e-3)
+
+
 # ----------------------------------------------------------------------------- f1: every shape group in one launch
 def test_ragged_svd_of_several_shape_groups_vs_exact_svd():
     """cli_svd.py:24-92 over a model = sites of several shapes.  ``topr_svd_ragged`` (one descriptor-table launch per
