@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 2
+#define LORA_AMD_ABI_VERSION 3
 
 /* status codes */
 #define LORA_AMD_OK 0

@@ -779,8 +779,10 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
 // and ONE to L2 (phase B: waves 0-1 sum G columns weighted by T, waves 2-3 X columns weighted by Gt) instead of four
 // trips in sequence.  Needs both factor slabs in LDS together: RT * (N + K) <= kSelfLdsFloats (every attention site and
 // the smallest GEGLU projection at rank 4; the sequential kernel above takes the rest).
-constexpr int kSelfLdsFloats = 12288;  // 48 KiB: [down slab | up slab] in phase A, the two slot-reduction areas in phase B
-constexpr int kHalf = kFT / 2;
+constexpr int kSelfLdsFloats = 16384;  // 64 KiB: [down slab | up slab] in phase A, the two slot-reduction areas in phase B
+constexpr int kDualThreads = 512;      // 8 waves: 4 per tensor
+constexpr int kHalf = kDualThreads / 2;
+constexpr int kSelfRowsMax = 64;
 
 template <class E, int RT>
 __device__ inline void half_rowdots(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
@@ -788,8 +790,8 @@ __device__ inline void half_rowdots(const float *s_f, float *s_out, const typena
   const int lane = threadIdx.x & 63;
   const int L = 1 << logL, G = 64 >> logL;
   const int l = lane & (L - 1), g = lane >> logL;
-  const int rows_iter = G * 2, c8 = C >> 3;
-  constexpr int U = 4;
+  const int rows_iter = G * (kHalf / 64), c8 = C >> 3;
+  constexpr int U = 8;  // loads in flight per lane: a 320-wide row block is one trip to memory
   for (int rl = hw * G + g; rl < nrows; rl += rows_iter) {
     float acc[RT];
 #pragma unroll
@@ -828,11 +830,24 @@ __device__ inline void half_rowdots(const float *s_f, float *s_out, const typena
   }
 }
 
+// staging with all kDualThreads threads (stage_factor strides by kFT: its callers are 256-thread kernels)
+template <int RT>
+__device__ inline void stage_factor_dual(float *s_f, const float *f, int layout, int r, int C) {
+  const int c8 = C >> 3;
+  for (int i = threadIdx.x; i < RT * C; i += kDualThreads) {
+    int j, c;
+    if (layout == LORA_AMD_FACTOR_RK) { j = i / C; c = i - j * C; }
+    else { c = i / RT; j = i - c * RT; }  // [C, r]: consecutive threads read consecutive ranks of a column
+    const float v = j < r ? f[layout == LORA_AMD_FACTOR_RK ? (int64_t)j * C + c : (int64_t)c * r + j] : 0.f;
+    s_f[((j * 2 + ((c >> 2) & 1)) * c8 + (c >> 3)) * 4 + (c & 3)] = v;
+  }
+}
+
 template <class E, int RT>
-__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_dual_kernel(const SelfArgs a) {
+__global__ __launch_bounds__(kDualThreads) void linear_bwd_factors_self_dual_kernel(const SelfArgs a) {
   __shared__ __attribute__((aligned(16))) float s_buf[kSelfLdsFloats];
-  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
-  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_t[kSelfRowsMax * RT];
+  __shared__ __attribute__((aligned(16))) float s_gt[kSelfRowsMax * RT];
   using S = typename E::storage;
   const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
   const int64_t rb = blockIdx.x;
@@ -840,22 +855,22 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_dual_kernel(const
   const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool first = wave < 2;  // wave-uniform
+  const bool first = wave < kHalf / 64;  // wave-uniform
   float *s_fx = s_buf, *s_fg = s_buf + RT * a.K;
-  stage_factor<RT>(s_fx, a.down, LORA_AMD_F32, LORA_AMD_FACTOR_RK, a.r, a.K, 0, a.K);
-  stage_factor<RT>(s_fg, a.up, LORA_AMD_F32, LORA_AMD_FACTOR_KR, a.r, a.N, 0, a.N);
+  stage_factor_dual<RT>(s_fx, a.down, LORA_AMD_FACTOR_RK, a.r, a.K);
+  stage_factor_dual<RT>(s_fg, a.up, LORA_AMD_FACTOR_KR, a.r, a.N);
   __syncthreads();
   // ---- phase A
   if (first) half_rowdots<E, RT>(s_fx, s_t, x, a.ldx, m0, nrows, a.K, a.logL_x, a.scale, a.xhc, a.xhp, wave);
-  else half_rowdots<E, RT>(s_fg, s_gt, g, a.ldg, m0, nrows, a.N, a.logL_g, a.scale, a.ghc, a.ghp, wave - 2);
+  else half_rowdots<E, RT>(s_fg, s_gt, g, a.ldg, m0, nrows, a.N, a.logL_g, a.scale, a.ghc, a.ghp, wave - kHalf / 64);
   __syncthreads();
-  // ---- phase B: this half's tensor, its row vectors, its partial slab and its 16 KiB of the slot-reduction area
+  // ---- phase B: this half's tensor, its row vectors, its partial slab and its half of the slot-reduction area
   const S *data = first ? g : x;
   const int64_t ld = first ? a.ldg : a.ldx;
   const int C = first ? a.N : a.K, hc = first ? a.ghc : a.xhc, hp = first ? a.ghp : a.xhp;
   const float *s_vec = first ? s_t : s_gt;
   float *part = first ? a.up_part + rb * RT * (int64_t)a.N : a.down_part + rb * RT * (int64_t)a.K;
-  float *s_red = s_buf + (first ? 0 : 4096);
+  float *s_red = s_buf + (first ? 0 : kSelfLdsFloats / 2);
   const int c8 = C >> 3;
   const int ntile = (c8 + kHalf - 1) / kHalf, tile = (c8 + ntile - 1) / ntile;
   const int ntile_max = max(((a.N >> 3) + kHalf - 1) / kHalf, ((a.K >> 3) + kHalf - 1) / kHalf);
@@ -872,7 +887,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_dual_kernel(const
     for (int j = 0; j < RT; ++j)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-    constexpr int U = 4;
+    constexpr int U = RT <= 8 ? 8 : 4;
     if (owner) {
       const int pcol = hchunk(c0 + cl, hc, hp) * 8;
       for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
@@ -1227,7 +1242,7 @@ static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64
   // least 16 rows (the partial slabs are RT*4 / (rows*2) of the stream) and at most what the LDS row vectors hold
   int64_t rows = (M + 511) / 512;
   rows = std::max<int64_t>(rows, 16);
-  rows = std::min<int64_t>(rows, std::min<int64_t>(64, kFLdsT / RT));
+  rows = std::min<int64_t>(rows, std::min<int64_t>(kSelfRowsMax, kFLdsT / RT));
   rows = std::min<int64_t>(rows, M);
   const int64_t nrb = (M + rows - 1) / rows;
   // phase B tiles: the whole row when it has <= 256 chunks, else equal tiles of <= 256 chunks
@@ -1288,7 +1303,7 @@ extern "C" int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, cons
   const bool dual = !no_dual && (int64_t)RT * (N + K) <= kSelfLdsFloats && a.logL_x >= 0;
 #define FS(E, RTV)                                                                                                    \
   do {                                                                                                                \
-    if (dual) hipLaunchKernelGGL((linear_bwd_factors_self_dual_kernel<E, RTV>), dim3((unsigned)nrb), dim3(kFT), 0, st, a); \
+    if (dual) hipLaunchKernelGGL((linear_bwd_factors_self_dual_kernel<E, RTV>), dim3((unsigned)nrb), dim3(kDualThreads), 0, st, a); \
     else hipLaunchKernelGGL((linear_bwd_factors_self_kernel<E, RTV>), dim3(grid), dim3(kFT), 0, st, a);                \
   } while (0)
 #define FS_E(E) do { if (RT == 4) FS(E, 4); else if (RT == 8) FS(E, 8); else FS(E, 16); } while (0)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"declared in include/lora_amd.h but not exported: {missing}"
     assert sorted(_C.SYMBOLS) == declared, "lora_amd/_C.py SYMBOLS out of sync with the header"
-    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 2 and lib.lora_amd_target_arch() == b"gfx950"
+    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 3 and lib.lora_amd_target_arch() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
@@ -130,3 +130,38 @@ def test_conv3_nhwc_plan_is_pure_host_arithmetic():
         assert _C.conv3_nhwc_plan(*bad).native == 0
     lib = _C.require()
     assert lib.lora_amd_conv3_nhwc_plan(1, 64, 8, 8, 65, C.byref(_C.Conv3NhwcPlan())) == -2
+
+
+def test_round3_planners_are_pure_host_arithmetic():
+    """lora_amd_ragged_plan, lora_amd_linear_factors_self_plan and the head layout of lora_amd_merge_plan: no device."""
+    lib = _C.require()
+    assert C.sizeof(_C.RaggedDesc) == 128 and _C.RaggedDesc.begin1.offset == 88 and C.sizeof(_C.SubDesc) == 40
+    descs = (_C.RaggedDesc * 2)()
+    for d, (B, M, K) in zip(descs, [(3, 320, 320), (2, 1280, 23040)]):
+        d.x, d.f, d.out, d.partial = 4096, 8192, 12288, 16384
+        d.ldx, d.stride_x, d.M, d.K, d.batch = K, M * K, M, K, B
+        d.stride_f, d.stride_out = M * 16, 16 * K
+    g1, g2 = C.c_int64(0), C.c_int64(0)
+    assert lib.lora_amd_ragged_plan(_C.RAGGED_COLREDUCE, descs, 2, 16, C.byref(g1), C.byref(g2)) == 0
+    # 256-row blocks x 512-column tiles; stage 2: 64 outputs per block of the [16, K] result
+    assert descs[0].blocks1 == 2 * 1 and descs[1].blocks1 == 5 * 45 and descs[1].begin1 == 3 * 2
+    assert g1.value == 3 * 2 + 2 * 225 and g2.value == 3 * (16 * 320 // 64) + 2 * (16 * 23040 // 64)
+    assert lib.lora_amd_ragged_plan(_C.RAGGED_ROWDOT, descs, 2, 16, C.byref(g1), C.byref(g2)) == 0
+    assert g2.value == 0 and descs[0].rows_per_block > 0 and descs[0].kt_cols == 320
+    descs[1].K = 23041  # rows no longer 32-byte friendly
+    assert lib.lora_amd_ragged_plan(_C.RAGGED_ROWDOT, descs, 2, 16, C.byref(g1), C.byref(g2)) != 0
+
+    pl = _C.factors_self_plan(16384, 320, 320, 4)
+    assert pl.supported == 1 and pl.rank_tile == 4 and pl.nparts == 512
+    assert pl.up_part_floats == 512 * 4 * 320 and pl.down_part_floats == 512 * 4 * 320
+    assert _C.factors_self_plan(1024, 1280, 10240, 16).supported == 1
+    assert _C.factors_self_plan(64, 24, 320, 4).supported == 0 and _C.factors_self_plan(64, 320, 324, 4).supported == 0
+
+    sites = (_C.MergeSite * 1)()
+    s = sites[0]
+    s.N, s.K, s.r, s.w_in, s.w_out, s.down = 320, 320, 4, 4096, 8192, 4096
+    s.out_heads = 40 | (64 << 16)
+    summ = _C.MergeSummary()
+    assert lib.lora_amd_merge_plan(sites, 1, 2, C.byref(summ)) == 0 and summ.n_fast_sites == 1
+    s.out_heads = 48 | (64 << 16)  # 320 % 48 != 0
+    assert lib.lora_amd_merge_plan(sites, 1, 2, C.byref(summ)) != 0
