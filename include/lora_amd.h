@@ -358,6 +358,25 @@ int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, const void *x, 
                                      const float *up, float *up_part, float *down_part, int64_t M, int32_t K,
                                      int32_t N, int32_t r, int32_t act_dtype, float scale, int32_t g_head_dim,
                                      int32_t g_head_pad, int32_t x_head_dim, int32_t x_head_pad, void *stream);
+/* ... and for every site of a model in ONE launch (issued once per step after the backward, when every G and X is at
+ * hand): one lora_amd_self_site per adapter; same activation dtype and rank tile (4 / 8 / 16) throughout a table.  The
+ * caller fills the first block, lora_amd_linear_factors_self_ragged_plan (host) the second and returns the grid; the
+ * partial slabs are sized by lora_amd_linear_factors_self_plan per site and folded by lora_amd_reduce_batched. */
+typedef struct lora_amd_self_site {
+  const void *g, *x;            /* [M, N] output gradient, [M, K] input (act_dtype; rows may be head-padded) */
+  const float *down, *up;       /* f32 [r, K], [N, r] */
+  float *up_part, *down_part;   /* [nparts][RT][N], [nparts][RT][K] */
+  int64_t ldg, ldx, M;
+  int32_t N, K, r;
+  float scale;
+  int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
+  /* filled by the plan */
+  int32_t rows_per_block, nsplit, kt_g, logL_g, kt_x, logL_x, tile_g, nct_g, tile_x, nct_x;
+  int64_t block_begin;
+} lora_amd_self_site;
+int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *sites, int32_t n, int32_t act_dtype, int64_t *grid);
+int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid, int32_t rank,
+                                            int32_t act_dtype, void *stream);
 int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
 
 /* ------------------------------------------------------------------------

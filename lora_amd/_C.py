@@ -35,6 +35,7 @@ SYMBOLS = (
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_bwd_factors_self",
+    "lora_amd_linear_factors_self_ragged_plan", "lora_amd_linear_bwd_factors_self_ragged",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
@@ -58,6 +59,21 @@ class HipExtensionMissing(RuntimeError):
 class FactorsSelfPlan(C.Structure):
     _fields_ = [("supported", C.c_int32), ("rank_tile", C.c_int32), ("nparts", C.c_int32), ("reserved", C.c_int32),
                 ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64)]
+
+
+class SelfSite(C.Structure):
+    """lora_amd_self_site (include/lora_amd.h): one adapter of the one-launch factor-gradient pass."""
+    _fields_ = [
+        ("g", C.c_void_p), ("x", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
+        ("up_part", C.c_void_p), ("down_part", C.c_void_p),
+        ("ldg", C.c_int64), ("ldx", C.c_int64), ("M", C.c_int64),
+        ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("scale", C.c_float),
+        ("g_head_dim", C.c_int32), ("g_head_pad", C.c_int32), ("x_head_dim", C.c_int32), ("x_head_pad", C.c_int32),
+        ("rows_per_block", C.c_int32), ("nsplit", C.c_int32), ("kt_g", C.c_int32), ("logL_g", C.c_int32),
+        ("kt_x", C.c_int32), ("logL_x", C.c_int32), ("tile_g", C.c_int32), ("nct_g", C.c_int32),
+        ("tile_x", C.c_int32), ("nct_x", C.c_int32),
+        ("block_begin", C.c_int64),
+    ]
 
 
 class RaggedDesc(C.Structure):
@@ -190,6 +206,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_factors_self.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32,
                                                      i32, i32, i32, i32, vp]
     lib.lora_amd_linear_factors_self_plan.restype = lib.lora_amd_linear_bwd_factors_self.restype = C.c_int
+    lib.lora_amd_linear_factors_self_ragged_plan.argtypes = [vp, i32, i32, C.POINTER(C.c_int64)]
+    lib.lora_amd_linear_bwd_factors_self_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
+    lib.lora_amd_linear_factors_self_ragged_plan.restype = lib.lora_amd_linear_bwd_factors_self_ragged.restype = C.c_int
     lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
                                                    f32, f32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
@@ -765,6 +784,31 @@ def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor
                                                       down_part.data_ptr(), g.shape[0], K, N, r, dtype_code(g.dtype),
                                                       float(scale), gd, gD, xd, xD, _stream()),
            "lora_amd_linear_bwd_factors_self")
+
+
+def factors_self_ragged_table(sites, act_dtype: torch.dtype):
+    """Host half of the one-launch factor-gradient pass: ``sites`` = [(g, x, down, up, up_part, down_part, scale,
+    g_heads, x_heads)] (one activation dtype, one rank tile) -> (planned ctypes table, grid)."""
+    lib = require()
+    arr = (SelfSite * len(sites))()
+    for q, (g, x, down, up, up_part, down_part, scale, g_heads, x_heads) in zip(arr, sites):
+        q.g, q.x, q.down, q.up = g.data_ptr(), x.data_ptr(), down.data_ptr(), up.data_ptr()
+        q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
+        q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
+        q.N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
+        q.K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+        q.r, q.scale = down.shape[0], float(scale)
+        q.g_head_dim, q.g_head_pad = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
+        q.x_head_dim, q.x_head_pad = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    grid = C.c_int64(0)
+    _check(lib.lora_amd_linear_factors_self_ragged_plan(arr, len(sites), dtype_code(act_dtype), C.byref(grid)),
+           "lora_amd_linear_factors_self_ragged_plan")
+    return arr, grid.value
+
+
+def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, rank: int, act_dtype: torch.dtype) -> None:
+    _check(require().lora_amd_linear_bwd_factors_self_ragged(table_dev.data_ptr(), n, grid, rank, dtype_code(act_dtype),
+                                                             _stream()), "lora_amd_linear_bwd_factors_self_ragged")
 
 
 def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, float, float]],

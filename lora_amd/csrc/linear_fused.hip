@@ -742,7 +742,7 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
 }
 
 template <class E, int RT>
-__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const SelfArgs a) {
+__device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
   // phase A stages the factor slab, phase B reduces row slots: never live together
   __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
@@ -750,8 +750,8 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
   static_assert(kFT * 8 * 4 >= kFLdsFactor, "shared buffer");
   using S = typename E::storage;
   const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
-  const int64_t rb = blockIdx.x / a.nsplit;
-  const int sp = (int)(blockIdx.x - rb * a.nsplit);
+  const int64_t rb = bid / a.nsplit;
+  const int sp = (int)(bid - rb * a.nsplit);
   const int64_t m0 = rb * a.rows_per_block;
   const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
   block_rowdots<E, RT>(s_buf, s_t, x, a.ldx, m0, nrows, a.K, a.down, LORA_AMD_FACTOR_RK, a.r, a.kt_x, a.logL_x, a.scale,
@@ -772,6 +772,34 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
                            a.down_part + rb * RT * (int64_t)a.K, a.xhc, a.xhp);
     }
   }
+}
+
+template <class E, int RT>
+__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const SelfArgs a) {
+  factors_self_body<E, RT>(a, blockIdx.x);
+}
+
+// Every site of a model in ONE launch: the table holds one lora_amd_self_site per adapter (same activation dtype and rank
+// tile), blocks are numbered through it.  The per-site launches of a training step are latency-bound (a site is 1-90 MB,
+// one or two rounds of workgroups, four dependent trips to memory each); deferred to the end of the backward and issued
+// together, the sites' phases overlap across ~50 000 workgroups and the pass runs at memory throughput.
+template <class E, int RT>
+__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(const lora_amd_self_site *__restrict__ sites,
+                                                                             int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_self_site q = sites[lo];
+  SelfArgs a;
+  a.g = q.g; a.x = q.x; a.ldg = q.ldg; a.ldx = q.ldx; a.M = q.M; a.down = q.down; a.up = q.up;
+  a.up_part = q.up_part; a.down_part = q.down_part; a.scale = q.scale; a.N = q.N; a.K = q.K; a.r = q.r;
+  a.rows_per_block = q.rows_per_block; a.nsplit = q.nsplit;
+  a.ghc = q.g_head_dim >> 3; a.ghp = q.g_head_pad >> 3; a.xhc = q.x_head_dim >> 3; a.xhp = q.x_head_pad >> 3;
+  a.kt_g = q.kt_g; a.logL_g = q.logL_g; a.kt_x = q.kt_x; a.logL_x = q.logL_x;
+  a.tile_g = q.tile_g; a.nct_g = q.nct_g; a.tile_x = q.tile_x; a.nct_x = q.nct_x;
+  factors_self_body<E, RT>(a, (int64_t)blockIdx.x - q.block_begin);
 }
 
 // ---- the same, wave-specialised: the two halves of the workgroup work on the two tensors at the same time, so a block's
@@ -1315,6 +1343,57 @@ extern "C" int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, cons
 #undef FS_E
 #undef FS
   return check_launch("lora_amd_linear_bwd_factors_self");
+}
+
+extern "C" int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *sites, int32_t n, int32_t act_dtype,
+                                                        int64_t *grid) {
+  LORA_AMD_CHECK(sites && n >= 1 && grid && dtype_ok(act_dtype), LORA_AMD_EINVAL, "factors_self_ragged_plan: bad argument");
+  auto heads_ok = [](int d, int D, int cols, int64_t ld) {
+    return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
+  };
+  int64_t begin = 0;
+  const int rt0 = frank_tile(sites[0].r);
+  for (int i = 0; i < n; ++i) {
+    lora_amd_self_site &q = sites[i];
+    SelfArgs a;
+    int64_t nrb = 0;
+    LORA_AMD_CHECK(q.r >= 1 && q.r <= 16 && frank_tile(q.r) == rt0, LORA_AMD_ERANK,
+                   "factors_self_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
+    LORA_AMD_CHECK(q.g && q.x && q.down && q.up && q.up_part && q.down_part, LORA_AMD_EINVAL,
+                   "factors_self_ragged_plan: site %d: null pointer", i);
+    LORA_AMD_CHECK(factors_self_geom(q.M, q.K, q.N, q.r, &a, &nrb) && aligned_ok(q.g, q.ldg, q.N, act_dtype) &&
+                       aligned_ok(q.x, q.ldx, q.K, act_dtype) && ((uintptr_t)q.down % 16) == 0 && ((uintptr_t)q.up % 16) == 0 &&
+                       heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
+                   LORA_AMD_EINVAL, "factors_self_ragged_plan: site %d: shape / alignment / head layout not supported", i);
+    // throughput-bound launch: no column splits (they redo phase A), the row blocks of all sites fill the chip
+    q.rows_per_block = a.rows_per_block; q.nsplit = 1;
+    q.kt_g = a.kt_g; q.logL_g = a.logL_g; q.kt_x = a.kt_x; q.logL_x = a.logL_x;
+    q.tile_g = a.tile_g; q.nct_g = a.nct_g; q.tile_x = a.tile_x; q.nct_x = a.nct_x;
+    q.block_begin = begin;
+    begin += nrb;
+  }
+  LORA_AMD_CHECK(begin < (1ll << 31), LORA_AMD_EINVAL, "factors_self_ragged_plan: too many blocks");
+  *grid = begin;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid,
+                                                       int32_t rank, int32_t act_dtype, void *stream) {
+  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && dtype_ok(act_dtype), LORA_AMD_EINVAL,
+                 "linear_bwd_factors_self_ragged: bad argument");
+  LORA_AMD_CHECK(rank >= 1 && rank <= 16, LORA_AMD_ERANK, "linear_bwd_factors_self_ragged: rank %d outside [1,16]", rank);
+  const int RT = frank_tile(rank);
+  hipStream_t st = (hipStream_t)stream;
+#define FR(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n)
+#define FR_E(E) do { if (RT == 4) FR(E, 4); else if (RT == 8) FR(E, 8); else FR(E, 16); } while (0)
+  switch (act_dtype) {
+    case LORA_AMD_F32: FR_E(f32_t); break;
+    case LORA_AMD_F16: FR_E(f16_t); break;
+    default: FR_E(bf16_t); break;
+  }
+#undef FR_E
+#undef FR
+  return check_launch("lora_amd_linear_bwd_factors_self_ragged");
 }
 
 extern "C" int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total,

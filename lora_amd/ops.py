@@ -156,6 +156,9 @@ class GradSink:
         """Reduce this site's pending partials now (a second backward is about to overwrite them)."""
         if self.pending is None:
             return
+        mw = getattr(self.owner, "merged", None)
+        if mw is not None:
+            mw.flush_factors()  # the partials may still be owed by the deferred one-launch pass
         table, n, total = _C.make_reduce_table(self.rows[self.pending], self.up_grad.device)
         _C.reduce_batched(table, n, total)
         self.pending = None
@@ -418,6 +421,12 @@ class MergedWeights:
         self.refreshes = 0
         self._state = state  # the optimiser state whose ``step_count`` says when the merged weights went stale
         self._fresh_at = None
+        # factor gradients of every site in ONE launch after the backward (trainer: FlatLoraState.reduce_pending):
+        # the backward of a site only records (G, X, factors, partial slabs); see flush_factors
+        self.defer_factors = state is not None and os.environ.get("LORA_AMD_DEFER_FACTORS", "1") != "0"
+        self._owed = []
+        self._tables = {}    # (dtype, rank tile, table bytes) -> [eager (pinned, device) pair, copy event, spare pairs]
+        self._graph_keep = []
 
     def lookup(self, module, w, b, dt, in_heads, out_heads):
         """(w_eff, bias_eff) for this adapter and layout; creates (and fills) the entry on first use."""
@@ -482,6 +491,52 @@ class MergedWeights:
             plan.launch(alpha, _C.ROUND_ONCE)
         self.refreshes += 1
 
+    def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads) -> None:
+        self._owed.append((g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads))
+
+    def flush_factors(self) -> None:
+        """ONE ``lora_amd_linear_bwd_factors_self_ragged`` launch per (activation dtype, rank tile) — one in practice —
+        for every site whose backward ran since the last flush.  The site table changes every eager step (fresh G / X
+        addresses) and never under hipGraph replay (the capture's private pool hands out the same addresses): it is
+        written into a persistent pinned buffer and copied to a persistent device buffer on the launch stream, which is
+        a memcpy node of the captured graph."""
+        if not self._owed:
+            return
+        owed, self._owed = self._owed, []
+        groups = {}
+        for st in owed:
+            r = st[2].shape[0]
+            groups.setdefault((st[0].dtype, 4 if r <= 4 else 8 if r <= 8 else 16), []).append(st)
+        capturing = torch.cuda.is_current_stream_capturing()
+        for (dt, rt), sites in groups.items():
+            arr, grid = _C.factors_self_ragged_table(sites, dt)
+            raw = bytes(arr)
+            key = (dt, rt, len(raw))
+            slot = self._tables.get(key)
+            if slot is None:
+                if capturing:
+                    raise RuntimeError("MergedWeights.flush_factors: the site table's buffers must exist before hipGraph "
+                                       "capture (run the step eagerly once first)")
+                mk = lambda: (torch.empty(len(raw), dtype=torch.uint8).pin_memory(),  # noqa: E731
+                              torch.empty(len(raw), dtype=torch.uint8, device=sites[0][0].device))
+                # [eager pair, copy-done event, pairs set aside for captures (pinned memory cannot be allocated inside one)]
+                slot = self._tables[key] = [mk(), None, [mk() for _ in range(4)]]
+            if capturing:
+                if not slot[2]:
+                    raise RuntimeError("MergedWeights.flush_factors: more than 4 hipGraph captures of this step shape")
+                host, dev = slot[2].pop()  # owned by this graph from now on: its memcpy node re-reads `host` every replay
+                self._graph_keep.append((host, dev))
+            else:
+                host, dev = slot[0]
+                if slot[1] is not None:
+                    slot[1].synchronize()  # the previous step's copy has read the pinned buffer
+            host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dev.copy_(host, non_blocking=True)
+            if not capturing:
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
+            _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt)
+
     def invalidate(self) -> None:
         """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
         self.entries.clear()
@@ -535,9 +590,14 @@ class LoraLinearMergedFunction(torch.autograd.Function):
             else:
                 up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
                                       for n in (plan.up_part_floats, plan.down_part_floats))
-            _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale,
-                                       g_heads=ctx.out_heads, x_heads=ctx.in_heads)
-            _log("bwd", "merged_dx+factors_self", M, K, N, r)
+            mw = getattr(getattr(sink, "owner", None), "merged", None)
+            if mw is not None and mw.defer_factors:
+                mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale, ctx.out_heads, ctx.in_heads)
+                _log("bwd", "merged_dx+factors_deferred", M, K, N, r)
+            else:
+                _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale,
+                                           g_heads=ctx.out_heads, x_heads=ctx.in_heads)
+                _log("bwd", "merged_dx+factors_self", M, K, N, r)
             if sink is not None:
                 sink.pending = key
             else:
@@ -611,9 +671,14 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 else:
                     up_part, down_part = (torch.empty(max(int(q), 1), dtype=torch.float32, device=g2.device)
                                           for q in (plan.up_part_floats, plan.down_part_floats))
-                _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale,
-                                           g_heads=out_heads, x_heads=None)
-                _log("bwd", "merged_group_dx+factors_self", M, K, N, r)
+                mw = getattr(getattr(sink, "owner", None), "merged", None)
+                if mw is not None and mw.defer_factors:
+                    mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale, out_heads, None)
+                    _log("bwd", "merged_group_dx+factors_deferred", M, K, N, r)
+                else:
+                    _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale,
+                                               g_heads=out_heads, x_heads=None)
+                    _log("bwd", "merged_group_dx+factors_self", M, K, N, r)
                 if sink is not None:
                     sink.pending = key
                 else:

@@ -142,7 +142,11 @@ class FlatLoraState:
         return mw
 
     def reduce_pending(self) -> None:
-        """Sum every site's backward partials into the flat gradient buffer: ONE launch for all sites."""
+        """Sum every site's backward partials into the flat gradient buffer: ONE launch for all sites (after the one
+        launch that produces the partials of the merged-weight sites, when those were deferred)."""
+        mw = getattr(self, "merged", None)
+        if mw is not None:
+            mw.flush_factors()
         live = [s for s in self._sinks if s.pending is not None]
         if not live:
             return
@@ -159,6 +163,8 @@ class FlatLoraState:
             s.pending = None
 
     def zero_grad(self) -> None:
+        if getattr(self, "merged", None) is not None:
+            self.merged._owed.clear()
         for s in self._sinks:
             s.pending = None
         self.flat_g.zero_()

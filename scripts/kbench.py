@@ -194,6 +194,46 @@ def bench_ws(args):
                               frac8_one=round(byts / one / HBM, 3))), flush=True)
 
 
+SELF_SHAPES = [(16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280), (256, 1280, 1280), (308, 768, 320),
+               (308, 768, 1280), (16384, 320, 2560), (4096, 640, 5120), (1024, 1280, 10240)]
+
+
+def bench_self(args):
+    """The merged-weight path's pieces per site shape (M, K, N): the library GEMMs on W_eff (forward, input gradient),
+    lora_amd_linear_bwd_factors_self (T and Gt recomputed inside) next to lora_amd_linear_bwd_factors (T and Gt given) and
+    the two rowdot launches that would produce them."""
+    r, dt = args.rank, torch.bfloat16
+    for (M, K, N) in SELF_SHAPES:
+        x = torch.randn(M, K, device=DEV).to(dt)
+        g = torch.randn(M, N, device=DEV).to(dt)
+        w = (torch.randn(N, K, device=DEV) * 0.03).to(dt)
+        down, up = torch.randn(r, K, device=DEV) * 0.25, torch.randn(N, r, device=DEV) * 0.05
+        rec = {"M": M, "K": K, "N": N, "r": r, "GX_MB": round((M * K + M * N) * 2 / 1e6, 2)}
+        floor = (M * K + M * N) * 2 / 8e12
+        sp = _C.factors_self_plan(M, K, N, r)
+        if sp.supported:
+            up_part = torch.empty(int(sp.up_part_floats), device=DEV)
+            down_part = torch.empty(int(sp.down_part_floats), device=DEV)
+            t, _ = timeit(lambda: _C.linear_bwd_factors_self(g, x, down, up, up_part, down_part, 1.0))
+            rec["self_us"] = round(t * 1e6, 2)
+            rec["self_frac8"] = round(floor / t, 3)
+            rec["self_nparts"] = sp.nparts
+        lp = _C.linear_plan(M, K, N, r)
+        if lp.fused:
+            tt, gt = torch.randn(M, r, device=DEV), torch.randn(M, r, device=DEV)
+            up_p = torch.empty(int(lp.up_part_floats), device=DEV)
+            down_p = torch.empty(int(lp.down_part_floats), device=DEV)
+            t, _ = timeit(lambda: _C.linear_bwd_factors(g, tt, up_p, x, gt, down_p, r, 1.0))
+            rec["factors_given_T_Gt_us"] = round(t * 1e6, 2)
+        t, _ = timeit(lambda: (_C.rowdot(x, down, _C.FACTOR_RK), _C.rowdot(g, up, _C.FACTOR_KR)))
+        rec["two_rowdots_us"] = round(t * 1e6, 2)
+        t, _ = timeit(lambda: torch.nn.functional.linear(x, w))
+        rec["lib_fwd_us"] = round(t * 1e6, 2)
+        t, _ = timeit(lambda: g @ w)
+        rec["lib_dx_us"] = round(t * 1e6, 2)
+        print(json.dumps(rec), flush=True)
+
+
 def bench_conv(args):
     """K4 conv-adapter kernels at SD1.5 ResNet sites (bf16 activations, f32 factors)."""
     from lora_amd import ops
@@ -321,6 +361,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="merge,linear,ws,conv,hostops")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rank", type=int, default=4)
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), flush=True)
     if "merge" in a.what:
@@ -335,3 +376,5 @@ if __name__ == "__main__":
         bench_nhwc(a)
     if "hostops" in a.what:
         bench_hostops(a)
+    if "self" in a.what:
+        bench_self(a)
