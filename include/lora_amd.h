@@ -354,6 +354,10 @@ typedef struct lora_amd_factors_self_plan_t {
   int64_t up_part_floats, down_part_floats;
 } lora_amd_factors_self_plan_t;
 int lora_amd_linear_factors_self_plan(int64_t M, int32_t K, int32_t N, int32_t r, lora_amd_factors_self_plan_t *out);
+/* the same with the rows of a block chosen by the caller (0: as above); the one-launch pass takes `rows_per_block` of
+ * lora_amd_self_site as that choice, so a site's slabs must be sized with the same value */
+int lora_amd_linear_factors_self_plan_rows(int64_t M, int32_t K, int32_t N, int32_t r, int32_t rows,
+                                           lora_amd_factors_self_plan_t *out);
 int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, const void *x, int64_t ldx, const float *down,
                                      const float *up, float *up_part, float *down_part, int64_t M, int32_t K,
                                      int32_t N, int32_t r, int32_t act_dtype, float scale, int32_t g_head_dim,
@@ -370,7 +374,7 @@ typedef struct lora_amd_self_site {
   int32_t N, K, r;
   float scale;
   int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
-  /* filled by the plan */
+  /* rows_per_block: caller's choice (0: the per-site default); everything else is filled by the plan */
   int32_t rows_per_block, nsplit, kt_g, logL_g, kt_x, logL_x, tile_g, nct_g, tile_x, nct_x;
   int64_t block_begin;
 } lora_amd_self_site;

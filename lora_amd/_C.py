@@ -34,7 +34,7 @@ SYMBOLS = (
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
-    "lora_amd_linear_factors_self_plan", "lora_amd_linear_bwd_factors_self",
+    "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
     "lora_amd_linear_factors_self_ragged_plan", "lora_amd_linear_bwd_factors_self_ragged",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
@@ -206,6 +206,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_bwd_factors_self.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32,
                                                      i32, i32, i32, i32, vp]
     lib.lora_amd_linear_factors_self_plan.restype = lib.lora_amd_linear_bwd_factors_self.restype = C.c_int
+    lib.lora_amd_linear_factors_self_plan_rows.argtypes = [i64, i32, i32, i32, i32, C.POINTER(FactorsSelfPlan)]
+    lib.lora_amd_linear_factors_self_plan_rows.restype = C.c_int
     lib.lora_amd_linear_factors_self_ragged_plan.argtypes = [vp, i32, i32, C.POINTER(C.c_int64)]
     lib.lora_amd_linear_bwd_factors_self_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_linear_factors_self_ragged_plan.restype = lib.lora_amd_linear_bwd_factors_self_ragged.restype = C.c_int
@@ -755,14 +757,21 @@ def linear_bwd_factors(g: torch.Tensor, t: torch.Tensor, up_part: torch.Tensor, 
 _self_plan_cache = {}
 
 
-def factors_self_plan(M: int, K: int, N: int, r: int) -> FactorsSelfPlan:
-    key = (M, K, N, r)
+def factors_self_plan(M: int, K: int, N: int, r: int, rows: int = 0) -> FactorsSelfPlan:
+    """``rows`` > 0: rows per block chosen by the caller (the deferred one-launch pass: SELF_ROWS_DEFERRED)."""
+    key = (M, K, N, r, rows)
     pl = _self_plan_cache.get(key)
     if pl is None:
         pl = FactorsSelfPlan()
-        _check(require().lora_amd_linear_factors_self_plan(M, K, N, r, C.byref(pl)), "lora_amd_linear_factors_self_plan")
+        _check(require().lora_amd_linear_factors_self_plan_rows(M, K, N, r, rows, C.byref(pl)),
+               "lora_amd_linear_factors_self_plan")
         _self_plan_cache[key] = pl
     return pl
+
+
+# rows per block of the deferred one-launch factor-gradient pass: throughput-bound, so tall blocks (half the partial
+# slabs of the per-site launch's 32 rows at M = 16384)
+SELF_ROWS_DEFERRED = int(os.environ.get("LORA_AMD_SELF_ROWS", "64"))
 
 
 def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor, up: torch.Tensor,
@@ -792,6 +801,7 @@ def factors_self_ragged_table(sites, act_dtype: torch.dtype):
     lib = require()
     arr = (SelfSite * len(sites))()
     for q, (g, x, down, up, up_part, down_part, scale, g_heads, x_heads) in zip(arr, sites):
+        q.rows_per_block = SELF_ROWS_DEFERRED
         q.g, q.x, q.down, q.up = g.data_ptr(), x.data_ptr(), down.data_ptr(), up.data_ptr()
         q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
         q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]

@@ -1263,13 +1263,14 @@ static int bwd_factors_impl(const void *g, int64_t ldg, const float *t, float *u
 }
 
 // Geometry of the self-sufficient factor-gradient launch (also the size of its partial workspaces).
-static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64_t *nrb_out) {
+static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64_t *nrb_out, int rows_hint = 0) {
   if (M <= 0 || r < 1 || r > 16 || K % 8 || N % 8 || K < 32 || N < 32) return false;
   const int RT = frank_tile(r);
   // rows per block: one workgroup streams its rows twice (phase A, phase B); enough blocks to give every CU two, at
   // least 16 rows (the partial slabs are RT*4 / (rows*2) of the stream) and at most what the LDS row vectors hold
   int64_t rows = (M + 511) / 512;
   rows = std::max<int64_t>(rows, 16);
+  if (rows_hint > 0) rows = rows_hint;  // the one-launch pass is throughput-bound: its caller asks for tall blocks
   rows = std::min<int64_t>(rows, std::min<int64_t>(kSelfRowsMax, kFLdsT / RT));
   rows = std::min<int64_t>(rows, M);
   const int64_t nrb = (M + rows - 1) / rows;
@@ -1290,11 +1291,16 @@ static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64
 
 extern "C" int lora_amd_linear_factors_self_plan(int64_t M, int32_t K, int32_t N, int32_t r,
                                                  lora_amd_factors_self_plan_t *out) {
-  LORA_AMD_CHECK(out != nullptr, LORA_AMD_EINVAL, "factors_self_plan: null output");
+  return lora_amd_linear_factors_self_plan_rows(M, K, N, r, 0, out);
+}
+
+extern "C" int lora_amd_linear_factors_self_plan_rows(int64_t M, int32_t K, int32_t N, int32_t r, int32_t rows,
+                                                      lora_amd_factors_self_plan_t *out) {
+  LORA_AMD_CHECK(out != nullptr && rows >= 0, LORA_AMD_EINVAL, "factors_self_plan: bad argument");
   memset(out, 0, sizeof(*out));
   SelfArgs a;
   int64_t nrb = 0;
-  if (!factors_self_geom(M, K, N, r, &a, &nrb)) return LORA_AMD_OK;
+  if (!factors_self_geom(M, K, N, r, &a, &nrb, rows)) return LORA_AMD_OK;
   out->supported = 1;
   out->rank_tile = frank_tile(r);
   out->nparts = (int32_t)nrb;
@@ -1361,7 +1367,7 @@ extern "C" int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *site
                    "factors_self_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
     LORA_AMD_CHECK(q.g && q.x && q.down && q.up && q.up_part && q.down_part, LORA_AMD_EINVAL,
                    "factors_self_ragged_plan: site %d: null pointer", i);
-    LORA_AMD_CHECK(factors_self_geom(q.M, q.K, q.N, q.r, &a, &nrb) && aligned_ok(q.g, q.ldg, q.N, act_dtype) &&
+    LORA_AMD_CHECK(factors_self_geom(q.M, q.K, q.N, q.r, &a, &nrb, q.rows_per_block) && aligned_ok(q.g, q.ldg, q.N, act_dtype) &&
                        aligned_ok(q.x, q.ldx, q.K, act_dtype) && ((uintptr_t)q.down % 16) == 0 && ((uintptr_t)q.up % 16) == 0 &&
                        heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
                    LORA_AMD_EINVAL, "factors_self_ragged_plan: site %d: shape / alignment / head layout not supported", i);

@@ -581,7 +581,9 @@ class LoraLinearMergedFunction(torch.autograd.Function):
                 dx = (g2 @ w_eff).view(ctx.x_shape)  # frozen dense GEMM; pad columns of a head-padded dX come out zero
         d_down = d_up = None
         if need_down or need_up:
-            plan = _C.factors_self_plan(M, K, N, r)
+            mw = getattr(getattr(sink, "owner", None), "merged", None)
+            defer = mw is not None and mw.defer_factors
+            plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
             key = ("self", M, K, N, r)
             if sink is not None:
                 if sink.pending is not None:
@@ -590,8 +592,7 @@ class LoraLinearMergedFunction(torch.autograd.Function):
             else:
                 up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
                                       for n in (plan.up_part_floats, plan.down_part_floats))
-            mw = getattr(getattr(sink, "owner", None), "merged", None)
-            if mw is not None and mw.defer_factors:
+            if defer:
                 mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale, ctx.out_heads, ctx.in_heads)
                 _log("bwd", "merged_dx+factors_deferred", M, K, N, r)
             else:
@@ -662,7 +663,9 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 if need_x:
                     with _gemm_range():
                         dx = (g2 @ w_eff) if dx is None else dx.addmm_(g2, w_eff)
-                plan = _C.factors_self_plan(M, K, N, r)
+                mw = getattr(getattr(sink, "owner", None), "merged", None)
+                defer = mw is not None and mw.defer_factors
+                plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
                 key = ("self", M, K, N, r)
                 if sink is not None:
                     if sink.pending is not None:
@@ -671,8 +674,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 else:
                     up_part, down_part = (torch.empty(max(int(q), 1), dtype=torch.float32, device=g2.device)
                                           for q in (plan.up_part_floats, plan.down_part_floats))
-                mw = getattr(getattr(sink, "owner", None), "merged", None)
-                if mw is not None and mw.defer_factors:
+                if defer:
                     mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale, out_heads, None)
                     _log("bwd", "merged_group_dx+factors_deferred", M, K, N, r)
                 else:
