@@ -121,12 +121,13 @@ class GradSink:
         return w
 
     def self_workspace(self, key, plan, device):
-        """Merged-weight Linear site, key = ("self", M, K, N, r): (up_part, down_part) of ``linear_bwd_factors_self``."""
+        """Merged-weight Linear site, key = ("self", M, K, N, r, row blocks): (up_part, down_part) of
+        ``linear_bwd_factors_self`` / the deferred one-launch pass."""
         w = self.ws.get(key)
         if w is None:
             w = tuple(torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
                       for n in (plan.up_part_floats, plan.down_part_floats))
-            _, _, K, N, r = key
+            _, _, K, N, r, _ = key
             self._new(key, w, [(w[0], self.up_grad, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 1.0),
                                (w[1], self.down_grad, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 1.0)])
         return w
@@ -584,7 +585,7 @@ class LoraLinearMergedFunction(torch.autograd.Function):
             mw = getattr(getattr(sink, "owner", None), "merged", None)
             defer = mw is not None and mw.defer_factors
             plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
-            key = ("self", M, K, N, r)
+            key = ("self", M, K, N, r, int(plan.nparts))
             if sink is not None:
                 if sink.pending is not None:
                     sink.flush()
@@ -666,7 +667,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 mw = getattr(getattr(sink, "owner", None), "merged", None)
                 defer = mw is not None and mw.defer_factors
                 plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
-                key = ("self", M, K, N, r)
+                key = ("self", M, K, N, r, int(plan.nparts))
                 if sink is not None:
                     if sink.pending is not None:
                         sink.flush()
