@@ -385,6 +385,10 @@ def train(instance_data_dir: str, pretrained_model_name_or_path: str, output_dir
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
     if dev.type == "cuda":
         state.attach_direct_grads(unet, *([text_encoder] if train_text_encoder else []))
+        if lora_dropout_p == 0.0:
+            # maskless adapters: the step's merged weight; the eager loop needs no explicit refresh — the first
+            # adapter forward after an optimiser step re-merges (MergedWeights.lookup)
+            state.enable_merged_weights(unet, *([text_encoder] if train_text_encoder else []))
     if wdt == torch.float16:
         state.enable_loss_scaling()
     perform_tuning(unet, vae, text_encoder, dataloader, max_train_steps_tuning, noise_scheduler, state, list(state.lrs),

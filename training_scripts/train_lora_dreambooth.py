@@ -14,7 +14,8 @@ Same command line (every flag of ref :168-483, same defaults), same outputs (``l
   trains the SD1.5-shaped stand-in UNet, a random-init ``transformers`` CLIP text encoder, a fixed stand-in VAE
   encoder and a hash tokenizer (``lora_amd/standin``), and ``--instance_data_dir synthetic:N`` generates N images.
 
-Extra flags (not in the reference): ``--standin {sd15,tiny}``, ``--device``, ``--hip_graph``, ``--channels_last``.
+Extra flags (not in the reference): ``--standin {sd15,tiny}``, ``--device``, ``--hip_graph``, ``--channels_last``,
+``--merged_weights``.
 """
 from __future__ import annotations
 
@@ -94,6 +95,9 @@ def parse_args(input_args=None):
     a("--standin", type=str, default="sd15", choices=["sd15", "tiny"], help="Stand-in UNet size when no checkpoint.")
     a("--device", type=str, default=None, help="cuda | cpu (default: cuda if available).")
     a("--hip_graph", type=int, default=0, help="Capture forward+backward into a hipGraph (fixed batch shape).")
+    a("--merged_weights", type=int, default=1, help="Run the maskless Linear adapters (--lora_dropout 0, the reference's "
+      "default) on the step's merged weight W + scale*up@down: one merge launch per step, frozen GEMMs forward / "
+      "input gradient, one launch for every site's factor gradients (DESIGN 9.1).  0: one fused kernel per site.")
     a("--channels_last", type=int, default=0, help="Run the UNet in NHWC (the layout MIOpen's convolutions use on "
       "MI355X; +5 %% steps/s on the SD1.5 stand-in).  Linear sites run as they are; Conv2d adapter sites take the "
       "channels-last MFMA kernels of csrc/conv_nhwc.hip (3x3) or the Linear kernels on the pixel rows (1x1).")
@@ -188,6 +192,9 @@ def main(args):
                             max_grad_norm=args.max_grad_norm, device=device)
     if device.type == "cuda":
         state.attach_direct_grads(unet, *([text_encoder] if args.train_text_encoder else []))
+    merged = None
+    if device.type == "cuda" and args.merged_weights:
+        merged = state.enable_merged_weights(unet, *([text_encoder] if args.train_text_encoder else []))
     if weight_dtype == torch.float16:  # fp16 activation gradients underflow without it (accelerate's GradScaler)
         state.enable_loss_scaling()
     base_lrs = list(state.lrs)
@@ -233,7 +240,7 @@ def main(args):
 
     te_arg = text_encoder  # the reference always runs the text encoder inside the step (ref :840)
     fwd_bwd = lambda lat, ids: T.forward_backward(unet, noise_scheduler, lat, ids, cfg, text_encoder=te_arg,  # noqa: E731
-                                                  loss_scale=state.loss_scale)
+                                                  loss_scale=state.loss_scale, merged=merged)
     graphed = None
     global_step, last_save, t0 = 0, 0, time.perf_counter()
     done = False
