@@ -14,6 +14,7 @@
 // live in LDS, K-reductions are xor-shuffles over the ct8 lanes, M-reductions are register accumulators
 // + an LDS slot reduction + per-block partials.  Everything is HBM-streaming: 16 B/lane, 4 loads in flight.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -158,7 +159,7 @@ __device__ inline void stage_rowvecs(float *s_t, const float *part, int nparts, 
 // reads consecutive columns with consecutive lanes (conflict-free) and stores 256-byte runs of one output row.
 template <int RT>
 __device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8], int slot, int nslots, int cl,
-                                         int ct8, float *out, int64_t ld, int col0) {
+                                         int ct8, float *out, int64_t ld, int col0) {  // ld = row length: the last tile may overhang
   const int ncols = ct8 * 8;
 #pragma unroll
   for (int jb = 0; jb < RT; jb += 4) {
@@ -177,7 +178,7 @@ __device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8]
       const float *src = &s_red[(jj * nslots) * ncols + col];
       float sum = 0.f;
       for (int s = 0; s < nslots; ++s) sum += src[s * ncols];
-      out[(int64_t)(jb + jj) * ld + col0 + col] = sum;
+      if (col0 + col < ld) out[(int64_t)(jb + jj) * ld + col0 + col] = sum;
     }
   }
 }
@@ -361,9 +362,10 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
   const int64_t m0 = rb * rows_per_block;
   const int nrows = (int)min((int64_t)rows_per_block, M - m0);
   const int col = (ct * ct8 + cl) * 8;
+  const bool colok = col < N;  // the last tile of a row whose chunk count is not a multiple of ct8 overhangs: idle lanes
 
   float fc[RT][8];
-  load_factor_cols<RT>(fc, up, fdt, LORA_AMD_FACTOR_KR, r, N, col);
+  load_factor_cols<RT>(fc, up, fdt, LORA_AMD_FACTOR_KR, r, N, colok ? col : 0);
   stage_rowvecs<RT>(s_t, t, 1, 0, m0, nrows, r, nullptr, 0, scale);  // dUp partials carry `scale`
   __syncthreads();
 
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots + slot;
-      load8_sel<E>(g + (m0 + (rl < nrows ? rl : nrows - 1)) * ldg + col, rl < nrows, gv[u]);
+      load8_sel<E>(g + (m0 + (rl < nrows ? rl : nrows - 1)) * ldg + (colok ? col : 0), rl < nrows && colok, gv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -449,7 +451,9 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
   const int ct = (int)(blockIdx.x - rb * nct);
   const int64_t m0 = rb * rows_per_block;
   const int nrows = (int)min((int64_t)rows_per_block, M - m0);
-  const int col = (ct * ct8 + cl) * 8;
+  const int colv = (ct * ct8 + cl) * 8;
+  const bool colok = colv < K;  // overhanging lanes of the last tile idle
+  const int col = colok ? colv : 0;
 
   float fc[RT][8];
   if (HAS_DX) load_factor_cols<RT>(fc, down, fdt, LORA_AMD_FACTOR_RK, r, K, col);
@@ -469,8 +473,8 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots;
       const int rc = rl < nrows ? rl : nrows - 1;
-      load8_sel<E>(x + (m0 + rc) * ldx + col, rl < nrows, xv[u]);
-      if (HAS_DX) load8_sel<E>(dx + (m0 + rc) * lddx + col, rl < nrows, dv[u]);
+      load8_sel<E>(x + (m0 + rc) * ldx + col, rl < nrows && colok, xv[u]);
+      if (HAS_DX) load8_sel<E>(dx + (m0 + rc) * lddx + col, rl < nrows && colok, dv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_x_kernel(
           if (HAS_DX) dv[u][i] = fmaf(tj, fc[j][i], dv[u][i]);
         }
       }
-      if (HAS_DX) store8<E>(dx + (m0 + rl) * lddx + col, dv[u]);
+      if (HAS_DX && colok) store8<E>(dx + (m0 + rl) * lddx + col, dv[u]);
     }
   }
   slot_reduce_store<RT>(s_red, acc, slot, nslots, cl, ct8, down_part + (int64_t)rb * RT * K, K, ct * ct8 * 8);
@@ -539,7 +543,9 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
   const int ct = (int)(bid - rb * nct);
   const int64_t m0 = rb * rows_per_block;
   const int nrows = (int)min((int64_t)rows_per_block, M - m0);
-  const int col = (ct * ct8 + cl) * 8;                                              // logical column (partials)
+  const int colv = (ct * ct8 + cl) * 8;                                             // logical column (partials)
+  const bool colok = colv < C;                                                      // last tile may overhang the row
+  const int col = colok ? colv : 0;
   const int pcol = hc ? (((col >> 3) / hc) * hp + ((col >> 3) % hc)) * 8 : col;     // where it lives in `data`
 
   stage_rowvecs<RT>(s_t, rowvec, 1, 0, m0, nrows, r, sel, 1, mult);
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rl = rb0 + u * nslots;
-      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows, v[u]);
+      load8_sel<E>(data + (m0 + (rl < nrows ? rl : nrows - 1)) * ld + pcol, rl < nrows && colok, v[u]);
     }
     if (dp > 0.f) {
 #pragma unroll
@@ -593,6 +599,8 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
 // so G and X leave HBM once (phase B re-reads the block's rows from L2 / the Infinity Cache: a row block is
 // rows * (N + K) * 2 bytes).  grid = row blocks x `nsplit`; the splits of a row block share out the column tiles of
 // phase B (and each redo phase A: only taken when M is too small to fill the chip with row blocks alone).
+constexpr int kSelfRowsCap = 64;  // rows of a block: their r-vectors live in LDS next to the 32 KiB work buffer
+
 struct SelfArgs {
   const void *g, *x;
   int64_t ldg, ldx, M;
@@ -618,7 +626,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
   const int l = lane & (L - 1), g = lane >> logL;
   const int rows_iter = G * (kFT / 64);
   const int niter = (nrows + rows_iter - 1) / rows_iter;
-  constexpr int U = 4;
+  constexpr int U = RT <= 8 ? 8 : 4;  // loads in flight per lane
   for (int k0 = 0; k0 < C; k0 += kt_cols) {
     const int ncols = min(kt_cols, C - k0), c8 = ncols >> 3;
     __syncthreads();
@@ -685,7 +693,7 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
   for (int j = 0; j < RT; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-  constexpr int U = 4;
+  constexpr int U = RT <= 8 ? 8 : 4;
   if (owner) {
     for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
       float v[U][8];
@@ -745,8 +753,8 @@ template <class E, int RT>
 __device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
   // phase A stages the factor slab, phase B reduces row slots: never live together
   __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
-  __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
-  __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];
+  __shared__ __attribute__((aligned(16))) float s_t[kSelfRowsCap * RT];   // rows_per_block <= kSelfRowsCap (factors_self_geom)
+  __shared__ __attribute__((aligned(16))) float s_gt[kSelfRowsCap * RT];
   static_assert(kFT * 8 * 4 >= kFLdsFactor, "shared buffer");
   using S = typename E::storage;
   const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(con
 constexpr int kSelfLdsFloats = 16384;  // 64 KiB: [down slab | up slab] in phase A, the two slot-reduction areas in phase B
 constexpr int kDualThreads = 512;      // 8 waves: 4 per tensor
 constexpr int kHalf = kDualThreads / 2;
-constexpr int kSelfRowsMax = 64;
+constexpr int kSelfRowsMax = kSelfRowsCap;
 
 template <class E, int RT>
 __device__ inline void half_rowdots(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
@@ -1032,9 +1040,18 @@ struct BwdGeom { int log_ct8, nct, rows_per_block; int64_t nrb; };
 static BwdGeom bwd_geom(int64_t M, int cols, int RT, int cap) {
   BwdGeom q;
   const int c8 = cols / 8;
-  const int ct8 = pow2_divisor(c8, cap);
+  // column tile = a power of two of 16-byte chunks (lane groups reduce by xor-shuffle).  Rows whose chunk count has only a
+  // small power-of-two factor (320 columns = 40 chunks = 8 x 5) used to get tiles of that factor: five 64-column tiles
+  // with a 32-slot reduction each.  Now: the next power of two (<= cap) with the last tile overhanging — 40 chunks are
+  // ONE 64-lane tile with 24 idle lanes; measured on configs[3] (rank 16, dropout): see DESIGN 9.4.
+  int ct8 = pow2_divisor(c8, cap);
+  static const bool legacy = getenv("LORA_AMD_POW2_TILES") && atoi(getenv("LORA_AMD_POW2_TILES")) == 1;
+  if (!legacy && ct8 < 32 && ct8 < cap) {
+    ct8 = 4;
+    while (ct8 < c8 && ct8 < std::min(cap, 64)) ct8 *= 2;
+  }
   q.log_ct8 = ilog2(ct8);
-  q.nct = c8 / ct8;
+  q.nct = (c8 + ct8 - 1) / ct8;
   // rows per block: as many workgroups as stay co-resident (3 per CU by LDS -> 768) and no more, so that no CU is
   // left with an extra workgroup while the rest idle; >= 32 rows (partials are RT*4/(rows*e) of the stream) and
   // <= kFLdsT/RT rows (their r-vectors live in LDS)
