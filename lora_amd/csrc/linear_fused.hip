@@ -1040,13 +1040,14 @@ struct BwdGeom { int log_ct8, nct, rows_per_block; int64_t nrb; };
 static BwdGeom bwd_geom(int64_t M, int cols, int RT, int cap) {
   BwdGeom q;
   const int c8 = cols / 8;
-  // column tile = a power of two of 16-byte chunks (lane groups reduce by xor-shuffle).  Rows whose chunk count has only a
-  // small power-of-two factor (320 columns = 40 chunks = 8 x 5) used to get tiles of that factor: five 64-column tiles
-  // with a 32-slot reduction each.  Now: the next power of two (<= cap) with the last tile overhanging — 40 chunks are
-  // ONE 64-lane tile with 24 idle lanes; measured on configs[3] (rank 16, dropout): see DESIGN 9.4.
+  // column tile = a power of two of 16-byte chunks (lane groups reduce by xor-shuffle): the largest one dividing the row
+  // (320 columns = 40 chunks -> five 8-chunk tiles).  LORA_AMD_POW2_TILES=0 selects the alternative that round 3 tried —
+  // the next power of two with the last tile overhanging (40 chunks = ONE 64-lane tile, 24 lanes idle; the kernels guard
+  // the overhang) — which measured 1 % SLOWER on configs[3] (21.75 vs 21.97 steps/s, same box): fewer slot reductions
+  // do not pay for the idle lanes.
   int ct8 = pow2_divisor(c8, cap);
-  static const bool legacy = getenv("LORA_AMD_POW2_TILES") && atoi(getenv("LORA_AMD_POW2_TILES")) == 1;
-  if (!legacy && ct8 < 32 && ct8 < cap) {
+  static const bool padded = getenv("LORA_AMD_POW2_TILES") && atoi(getenv("LORA_AMD_POW2_TILES")) == 0;
+  if (padded && ct8 < 32 && ct8 < cap) {
     ct8 = 4;
     while (ct8 < c8 && ct8 < std::min(cap, 64)) ct8 *= 2;
   }
