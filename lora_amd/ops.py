@@ -406,7 +406,9 @@ class MergedWeights:
     used): once per step ONE K3 launch (``lora_amd_merge_batched``, HBM-bound, every site) writes
     ``W_eff = W + scale * up @ down`` of every eligible Linear adapter into a scratch buffer; the adapter's forward is then
     the frozen dense GEMM on ``W_eff`` (``Y = X W_eff^T + b`` = ``X W^T + b + scale (X down^T) up^T``, no dropout), its
-    input gradient the dense GEMM ``G W_eff``, and the parameter gradients one ``linear_bwd_factors_self`` launch.
+    input gradient the dense GEMM ``G W_eff``, and the parameter gradients of ALL sites one
+    ``linear_bwd_factors_self_ragged`` launch after the backward (``flush_factors``; without a trainer state: one
+    ``linear_bwd_factors_self`` launch per site, in its backward).
     Eligible: device tensors, dropout not in effect, no selector, frozen weight, f32 factors, rank <= 16.
 
     Head-padded activations (``forward_heads``): the scratch weight is laid out for them — rows of a head-padded OUTPUT
