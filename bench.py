@@ -660,7 +660,9 @@ def main():
     # which kernel runs which site, device time of the adapter kernels, adapter-path bytes: one eager profiled step,
     # BEFORE the capture (rank 0 of a 1-GPU run; its attention / MIOpen choices are the ones the graph then bakes in)
     adapter_path, kernel_choices = None, {}
-    if on_gpu and rank == 0 and args.adapters == "hip" and not args.no_roofline:
+    # world == 1 only: the eager steps below run the step's collectives (the flat-gradient all-reduce, the broadcast of rank
+    # 0's attention choices) and must never be entered by one rank of several
+    if on_gpu and world == 1 and args.adapters == "hip" and not args.no_roofline:
         def eager_step():
             fwd_bwd(latents, ehs)
             state.step(state.all_reduce())
