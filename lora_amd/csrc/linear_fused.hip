@@ -617,7 +617,7 @@ __device__ inline int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp 
 
 // s_out[rl * RT + j] = mult * sum_c data[m0 + rl, c] * factor(j, c) for the block's rows; L lanes per row.  The factor
 // passes through LDS in slabs of kt_cols columns (outer loop: a slab is staged once per block, not once per row group).
-template <class E, int RT>
+template <class E, int RT, int U>
 __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
                                      int nrows, int C, const float *factor, int layout, int r, int kt_cols, int logL,
                                      float mult, int hc, int hp) {
@@ -626,8 +626,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
   const int l = lane & (L - 1), g = lane >> logL;
   const int rows_iter = G * (kFT / 64);
   const int niter = (nrows + rows_iter - 1) / rows_iter;
-  constexpr int U = RT <= 8 ? 8 : 4;  // loads in flight per lane
-  for (int k0 = 0; k0 < C; k0 += kt_cols) {
+  for (int k0 = 0; k0 < C; k0 += kt_cols) {  // U = loads in flight per lane
     const int ncols = min(kt_cols, C - k0), c8 = ncols >> 3;
     __syncthreads();
     stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, k0, ncols);
@@ -679,7 +678,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
 // part[j][c] (this block's [RT][C] slab) = sum over the block's rows of s_vec[row][j] * data[row, c] for the column tile
 // [c0, c0 + tc8) (16-byte chunks; tc8 <= 256, any value: slot = tid / tc8, so a 320-wide row is ONE tile of 40 chunks x 6
 // row slots instead of five power-of-two tiles with a slot reduction each).
-template <class E, int RT>
+template <class E, int RT, int U>
 __device__ inline void block_colsums(float *s_red, const float *s_vec, const typename E::storage *data, int64_t ld,
                                      int64_t m0, int nrows, int C, int c0, int tc8, float *part, int hc, int hp) {
   const int tid = threadIdx.x;
@@ -693,7 +692,6 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
   for (int j = 0; j < RT; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-  constexpr int U = RT <= 8 ? 8 : 4;
   if (owner) {
     for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
       float v[U][8];
@@ -749,7 +747,7 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
   }
 }
 
-template <class E, int RT>
+template <class E, int RT, int U = 4>
 __device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
   // phase A stages the factor slab, phase B reduces row slots: never live together
   __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
@@ -762,9 +760,9 @@ __device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
   const int sp = (int)(bid - rb * a.nsplit);
   const int64_t m0 = rb * a.rows_per_block;
   const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
-  block_rowdots<E, RT>(s_buf, s_t, x, a.ldx, m0, nrows, a.K, a.down, LORA_AMD_FACTOR_RK, a.r, a.kt_x, a.logL_x, a.scale,
+  block_rowdots<E, RT, U>(s_buf, s_t, x, a.ldx, m0, nrows, a.K, a.down, LORA_AMD_FACTOR_RK, a.r, a.kt_x, a.logL_x, a.scale,
                        a.xhc, a.xhp);
-  block_rowdots<E, RT>(s_buf, s_gt, g, a.ldg, m0, nrows, a.N, a.up, LORA_AMD_FACTOR_KR, a.r, a.kt_g, a.logL_g, a.scale,
+  block_rowdots<E, RT, U>(s_buf, s_gt, g, a.ldg, m0, nrows, a.N, a.up, LORA_AMD_FACTOR_KR, a.r, a.kt_g, a.logL_g, a.scale,
                        a.ghc, a.ghp);
   __syncthreads();
   // phase B: column tiles of <= 256 chunks, G's first, shared out among the splits of the row block
@@ -772,11 +770,11 @@ __device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
   for (int t = sp; t < a.nct_g + a.nct_x; t += a.nsplit) {
     if (t < a.nct_g) {
       const int c0 = t * a.tile_g;
-      block_colsums<E, RT>(s_buf, s_t, g, a.ldg, m0, nrows, a.N, c0, min(a.tile_g, c8g - c0),
+      block_colsums<E, RT, U>(s_buf, s_t, g, a.ldg, m0, nrows, a.N, c0, min(a.tile_g, c8g - c0),
                            a.up_part + rb * RT * (int64_t)a.N, a.ghc, a.ghp);
     } else {
       const int c0 = (t - a.nct_g) * a.tile_x;
-      block_colsums<E, RT>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, c0, min(a.tile_x, c8x - c0),
+      block_colsums<E, RT, U>(s_buf, s_gt, x, a.ldx, m0, nrows, a.K, c0, min(a.tile_x, c8x - c0),
                            a.down_part + rb * RT * (int64_t)a.K, a.xhc, a.xhp);
     }
   }
@@ -791,7 +789,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
 // tile), blocks are numbered through it.  The per-site launches of a training step are latency-bound (a site is 1-90 MB,
 // one or two rounds of workgroups, four dependent trips to memory each); deferred to the end of the backward and issued
 // together, the sites' phases overlap across ~50 000 workgroups and the pass runs at memory throughput.
-template <class E, int RT>
+template <class E, int RT, int U>
 __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(const lora_amd_self_site *__restrict__ sites,
                                                                              int n) {
   int lo = 0, hi = n - 1;
@@ -807,7 +805,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(con
   a.ghc = q.g_head_dim >> 3; a.ghp = q.g_head_pad >> 3; a.xhc = q.x_head_dim >> 3; a.xhp = q.x_head_pad >> 3;
   a.kt_g = q.kt_g; a.logL_g = q.logL_g; a.kt_x = q.kt_x; a.logL_x = q.logL_x;
   a.tile_g = q.tile_g; a.nct_g = q.nct_g; a.tile_x = q.tile_x; a.nct_x = q.nct_x;
-  factors_self_body<E, RT>(a, (int64_t)blockIdx.x - q.block_begin);
+  factors_self_body<E, RT, U>(a, (int64_t)blockIdx.x - q.block_begin);
 }
 
 // ---- the same, wave-specialised: the two halves of the workgroup work on the two tensors at the same time, so a block's
@@ -1408,7 +1406,13 @@ extern "C" int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site 
   LORA_AMD_CHECK(rank >= 1 && rank <= 16, LORA_AMD_ERANK, "linear_bwd_factors_self_ragged: rank %d outside [1,16]", rank);
   const int RT = frank_tile(rank);
   hipStream_t st = (hipStream_t)stream;
-#define FR(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n)
+  // loads in flight per lane: 4 measured best in the one-launch pass (8 costs occupancy: 1.9 vs ~1.1 ms on configs[1])
+  static const bool u8 = getenv("LORA_AMD_SELF_U") && atoi(getenv("LORA_AMD_SELF_U")) == 8;
+#define FR(E, RTV)                                                                                                   \
+  do {                                                                                                               \
+    if (u8 && RTV <= 8) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV, 8>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n); \
+    else hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV, 4>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n); \
+  } while (0)
 #define FR_E(E) do { if (RT == 4) FR(E, 4); else if (RT == 8) FR(E, 8); else FR(E, 16); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: FR_E(f32_t); break;
