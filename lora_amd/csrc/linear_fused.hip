@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
 // so G and X leave HBM once (phase B re-reads the block's rows from L2 / the Infinity Cache: a row block is
 // rows * (N + K) * 2 bytes).  grid = row blocks x `nsplit`; the splits of a row block share out the column tiles of
 // phase B (and each redo phase A: only taken when M is too small to fill the chip with row blocks alone).
-constexpr int kSelfRowsCap = 64;  // rows of a block: their r-vectors live in LDS next to the 32 KiB work buffer
+constexpr int kSelfRowsCap = 128;  // rows of a block: their r-vectors live in LDS next to the 32 KiB work buffer
 
 struct SelfArgs {
   const void *g, *x;
