@@ -234,6 +234,27 @@ def bench_self(args):
         print(json.dumps(rec), flush=True)
 
 
+def bench_gemm_layouts(args):
+    """The merged-weight path's library GEMMs per site shape, in both storage layouts of the scratch weight: forward
+    X W^T as F.linear on W [N, K] (TN) or X @ Wt on Wt [K, N] (NN); input gradient G W as G @ W (NN) or F.linear(G, Wt) (TN).
+    Head-padded variants of the 320-wide sites included (N or K = 512)."""
+    dt = torch.bfloat16
+    shapes = SELF_SHAPES + [(16384, 320, 512), (16384, 512, 320)]
+    for (M, K, N) in shapes:
+        x = torch.randn(M, K, device=DEV).to(dt)
+        g = torch.randn(M, N, device=DEV).to(dt)
+        w = (torch.randn(N, K, device=DEV) * 0.03).to(dt)
+        wt = w.t().contiguous()
+        rec = {"M": M, "K": K, "N": N}
+        for name, fn in (("fwd_TN_linear(x,W)", lambda: torch.nn.functional.linear(x, w)),
+                         ("fwd_NN_x@Wt", lambda: x @ wt),
+                         ("dx_NN_g@W", lambda: g @ w),
+                         ("dx_TN_linear(g,Wt)", lambda: torch.nn.functional.linear(g, wt))):
+            t, _ = timeit(fn)
+            rec[name] = round(t * 1e6, 2)
+        print(json.dumps(rec), flush=True)
+
+
 def bench_conv(args):
     """K4 conv-adapter kernels at SD1.5 ResNet sites (bf16 activations, f32 factors)."""
     from lora_amd import ops
@@ -378,3 +399,5 @@ if __name__ == "__main__":
         bench_hostops(a)
     if "self" in a.what:
         bench_self(a)
+    if "gemmlayout" in a.what:
+        bench_gemm_layouts(a)
