@@ -81,6 +81,13 @@ typedef struct lora_amd_merge_site {
                             weight whose INPUT is head-padded — row stride (K/d)*D, logical column k at
                             (k/d)*D + k%d (d, D multiples of 8, K % d == 0; pad columns are never written: zero them
                             once).  Column-owner sites only (lora_amd_merge_plan refuses it elsewhere)             */
+  int32_t transposed;    /* caller: 0 = as described above.  1 = the site describes the TRANSPOSED product
+                            W'^T = W^T + alpha (up down)^T: w_in / w_out are [N, K] with N = the ORIGINAL K and K = the
+                            ORIGINAL N, `up` points at the original lora_down.weight [r, N] (row n of this site, rank j:
+                            up[j*N + n]) and `down` at the original lora_up.weight [K, r] (column k, rank j: down[k*r + j]).
+                            Same values as the untransposed site, element for element (same rank order of the fma chain);
+                            what the input-gradient GEMM G W' wants as its [out, in] operand.  Column-owner sites only */
+  int32_t reserved;
 } lora_amd_merge_site;
 
 typedef struct lora_amd_merge_summary {

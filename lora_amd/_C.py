@@ -98,6 +98,7 @@ class MergeSite(C.Structure):
         ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32),
         ("rows_per_tile", C.c_int32), ("cols_per_tile", C.c_int32), ("tiles_k", C.c_int32),
         ("tile_begin", C.c_int64), ("flags", C.c_int32), ("out_heads", C.c_int32),
+        ("transposed", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -358,6 +359,7 @@ class MergePlan:
         for i, site in enumerate(sites):
             w_in, w_out, up, down = site[:4]
             heads = site[4] if len(site) > 4 else None  # (d, D): w_out is [N, (K/d)*D], input columns head-padded
+            transposed = bool(site[5]) if len(site) > 5 else False  # see lora_amd_merge_site.transposed
             _dev_check(w_in, w_out, up, down)
             if w_in.dtype != self.w_dtype or w_out.dtype != self.w_dtype:
                 raise TypeError("MergePlan: mixed weight dtypes in one plan")
@@ -367,15 +369,17 @@ class MergePlan:
                 raise ValueError("MergePlan: tensors must be contiguous")
             N = w_in.shape[0]
             K = w_in.numel() // N
-            r = down.shape[0]
+            r = up.shape[0] if transposed else down.shape[0]  # transposed: `up` is the original down [r, N]
             ko = K if heads is None else (K // heads[0]) * heads[1]
-            if up.shape[0] != N or up.numel() != N * r or down.numel() != r * K or w_out.numel() != N * ko:
+            if (up.shape[0] != (r if transposed else N) or up.numel() != N * r or down.numel() != r * K
+                    or w_out.numel() != N * ko):
                 raise ValueError(f"MergePlan: site {i} shape mismatch W{tuple(w_in.shape)} up{tuple(up.shape)} "
                                  f"down{tuple(down.shape)}")
             s = arr[i]
             s.w_in, s.w_out, s.up, s.down = w_in.data_ptr(), w_out.data_ptr(), up.data_ptr(), down.data_ptr()
             s.N, s.K, s.r = N, K, r
             s.out_heads = 0 if heads is None else int(heads[0]) | (int(heads[1]) << 16)
+            s.transposed = int(transposed)
             self.keep.append((w_in, w_out, up, down))
             self.bytes_algorithmic += 2 * N * K * w_in.element_size() + (N + K) * r * up.element_size()
         self.summary = MergeSummary()

@@ -192,10 +192,16 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
   // this thread's r x 8 block of `down`
   float fc[RT][8];
   const SAB *dn = reinterpret_cast<const SAB *>(s.down);
+  const bool tpo = s.transposed != 0;  // the transposed product: `down` holds the original up [K, r], `up` the original down [r, N]
 #pragma unroll
   for (int j = 0; j < RT; ++j) {
     if (j < r) {
-      load8<EAB>(dn + (int64_t)j * s.K + col, fc[j]);
+      if (tpo) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fc[j][i] = EAB::to_f(dn[(int64_t)(col + i) * r + j]);
+      } else {
+        load8<EAB>(dn + (int64_t)j * s.K + col, fc[j]);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) fc[j][i] = 0.f;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
   const SAB *upp = reinterpret_cast<const SAB *>(s.up);
   for (int i = tid; i < nrows * RT; i += kMergeThreads) {
     const int rl = i / RT, j = i - rl * RT;
-    s_up[i] = j < r ? EAB::to_f(upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
+    s_up[i] = j < r ? EAB::to_f(tpo ? upp[(int64_t)j * s.N + row0 + rl] : upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
   }
   __syncthreads();
 
@@ -299,7 +305,9 @@ extern "C" int lora_amd_merge_plan(lora_amd_merge_site *sites, int32_t n_sites, 
                    LORA_AMD_EINVAL, "merge_plan: site %d: bad head layout d=%d D=%d for K=%d", i, hd, hD, s.K);
     LORA_AMD_CHECK(s.out_heads == 0 || (aligned && ab_aligned && ct8 >= 4 && s.r <= 16), LORA_AMD_EINVAL,
                    "merge_plan: site %d: a head-padded output needs the column-owner kernel (16-byte rows, rank <= 16)", i);
-    if (aligned && ab_aligned && s.K % 8 == 0 && ct8 >= 4 && s.r <= 16) {
+    LORA_AMD_CHECK(s.transposed == 0 || (aligned && s.K % 8 == 0 && ct8 >= 4 && s.r <= 16), LORA_AMD_EINVAL,
+                   "merge_plan: site %d: the transposed product needs the column-owner kernel (16-byte rows, rank <= 16)", i);
+    if (aligned && (ab_aligned || s.transposed) && s.K % 8 == 0 && ct8 >= 4 && s.r <= 16) {
       // column-owner tiles: (ct8*8) columns x rows_per_tile rows
       const int cols = ct8 * 8;
       const int rt = s.r <= 4 ? 4 : s.r <= 8 ? 8 : 16;

@@ -154,10 +154,11 @@ class LoraInjectedLinear(_Adapter):
                                                 self._selector_matrix(), self._dropout_p(), in_heads, out_heads):
                 # the step's merged weight W + scale up down (trainer.enable_merged_weights): frozen GEMM forward and
                 # input gradient, one launch for both factor gradients
-                w_eff, b_eff = mw.lookup(self, wc, bc, dt, in_heads, out_heads)
+                need_dx = xc.requires_grad and torch.is_grad_enabled()
+                w_eff, b_eff, w_eff_t = mw.lookup(self, wc, bc, dt, in_heads, out_heads, need_dx)
                 return ops.LoraLinearMergedFunction.apply(xc, w_eff, b_eff, self.lora_down.weight, self.lora_up.weight,
                                                           float(self.scale), self.__dict__.get("_grad_sink"), in_heads,
-                                                          out_heads)
+                                                          out_heads, w_eff_t)
             return ops.lora_linear(xc, wc, bc, self.lora_down.weight, self.lora_up.weight,
                                    self._selector_matrix(), self.scale, self._dropout_p(),
                                    self.__dict__.get("_grad_sink"), in_heads, out_heads)
@@ -199,9 +200,10 @@ def lora_linear_group(adapters, x: torch.Tensor, out_heads=None):
             if not ops.merged_ok(xc, wc, a.lora_down.weight, a.lora_up.weight, a._selector_matrix(), a._dropout_p(), None,
                                  out_heads):
                 return None
-            w_eff, b_eff = a.__dict__["_merged"].lookup(a, wc, bc, dt, None, out_heads)
+            need_dx = xc.requires_grad and torch.is_grad_enabled()
+            w_eff, b_eff, w_eff_t = a.__dict__["_merged"].lookup(a, wc, bc, dt, None, out_heads, need_dx)
             flat += [w_eff, b_eff, a.lora_down.weight, a.lora_up.weight, float(a.scale), a.__dict__.get("_grad_sink"),
-                     out_heads]
+                     out_heads, w_eff_t]
         with torch.autocast(device_type=x.device.type, enabled=False):
             return list(ops.LoraLinearMergedGroupFunction.apply(xc, len(adapters), *flat))
     if out_heads is not None:

@@ -391,6 +391,10 @@ class LoraLinearFunction(torch.autograd.Function):
         return dx, dw, db, d_down, d_up, None, None, None, None
 
 
+# Input gradients of the merged-weight sites as F.linear(G, W_eff^T-stored) instead of G @ W_eff (see MergedWeights.lookup)
+TRANSPOSED_DX = os.environ.get("LORA_AMD_TRANSPOSED_DX", "1") != "0"
+
+
 def _gemm_range():
     """Profiler range around the library GEMMs of the merged-weight path (only while bench.py's adapter-path profile is
     recording: PATH_LOG is a list), so that their device time can be attributed to the adapter path."""
@@ -431,8 +435,11 @@ class MergedWeights:
         self._tables = {}    # (dtype, rank tile, table bytes) -> [eager (pinned, device) pair, copy event, spare pairs]
         self._graph_keep = []
 
-    def lookup(self, module, w, b, dt, in_heads, out_heads):
-        """(w_eff, bias_eff) for this adapter and layout; creates (and fills) the entry on first use."""
+    def lookup(self, module, w, b, dt, in_heads, out_heads, need_dx: bool = True):
+        """(w_eff, bias_eff, w_eff_t) for this adapter and layout; creates (and fills) the entry on first use.
+        ``w_eff_t`` = the same merged weight stored transposed ([K, N]: what the library's faster [out, in]-operand GEMM
+        wants for the input gradient G W_eff — 12.4 vs 14.4 us at 16384 x 320 x 320, 45.6 vs 80.7 us at 1024 x 10240 -> 1280,
+        profiles/r03_kbench_gemmlayout.log); None when no input gradient is needed or the input is head-padded."""
         if (self._state is not None and self._fresh_at != self._state.step_count
                 and not torch.cuda.is_current_stream_capturing()):
             self.refresh()  # an optimiser step since the last merge (an eager forward outside trainer.forward_backward)
@@ -446,7 +453,9 @@ class MergedWeights:
         if e is None:
             e = self._create(module, w, b, in_heads, out_heads)
             self.entries[key] = e
-        return e["w_eff"], e["b_eff"]
+        if need_dx and TRANSPOSED_DX and in_heads is None and e["w_eff_t"] is None:
+            self._add_transposed(e, module, w, out_heads)
+        return e["w_eff"], e["b_eff"], e["w_eff_t"]
 
     def _create(self, module, w, b, in_heads, out_heads):
         if torch.cuda.is_current_stream_capturing():
@@ -469,11 +478,26 @@ class MergedWeights:
                               down.detach()) + ((heads_in,) if heads_in else ()))
         else:
             sites.append((w.detach(), w_eff, up.detach(), down.detach()) + ((heads_in,) if heads_in else ()))
-        e = dict(module=module, w_eff=w_eff, b_eff=b_eff, sites=sites, scale=float(module.scale),
+        e = dict(module=module, w_eff=w_eff, b_eff=b_eff, w_eff_t=None, w_t=None, sites=sites, scale=float(module.scale),
                  ptrs=(up.data_ptr(), down.data_ptr(), w.data_ptr()))
         _C.MergePlan(sites).launch(float(module.scale), _C.ROUND_ONCE)  # this forward's values; the step plan is rebuilt
         self._plans = None
         return e
+
+    def _add_transposed(self, e, module, w, out_heads) -> None:
+        """Second scratch weight of the entry: W_eff^T, merged from a frozen transposed copy of W by a ``transposed`` site
+        of the same launch (bit-identical values).  A head-padded output becomes padded COLUMNS here (``out_heads``)."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("MergedWeights: a site's transposed scratch weight must exist before hipGraph capture")
+        N, K = w.shape
+        n_out = out_heads[0] * out_heads[2] if out_heads else N
+        e["w_t"] = w.detach().t().contiguous()  # frozen: built once
+        e["w_eff_t"] = torch.zeros((K, n_out), dtype=w.dtype, device=w.device)  # pad columns stay zero
+        heads = (out_heads[1], out_heads[2]) if out_heads else None
+        site = (e["w_t"], e["w_eff_t"], module.lora_down.weight.detach(), module.lora_up.weight.detach(), heads, True)
+        e["sites"].append(site)
+        _C.MergePlan([site]).launch(e["scale"], _C.ROUND_ONCE)
+        self._plans = None
 
     def refresh(self) -> None:
         """ONE merge launch per (weight dtype, scale) group — one in practice — over every registered site."""
@@ -556,7 +580,7 @@ class LoraLinearMergedFunction(torch.autograd.Function):
     reduced here."""
 
     @staticmethod
-    def forward(ctx, x, w_eff, b_eff, down, up, scale, sink, in_heads, out_heads):
+    def forward(ctx, x, w_eff, b_eff, down, up, scale, sink, in_heads, out_heads, w_eff_t=None):
         _C.require()
         x2 = _rows2d(x, w_eff.shape[1])
         with _gemm_range():
@@ -565,6 +589,7 @@ class LoraLinearMergedFunction(torch.autograd.Function):
         N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
         _log("fwd", "merged" + ("_heads" if (in_heads or out_heads) else ""), x2.shape[0], K, N, down.shape[0])
         ctx.save_for_backward(x2, w_eff, down, up)
+        ctx.w_eff_t = w_eff_t  # frozen for the step (never an autograd input)
         ctx.scale, ctx.sink, ctx.x_shape = float(scale), sink, x.shape
         ctx.in_heads, ctx.out_heads, ctx.dims = in_heads, out_heads, (K, N)
         return y.view(*x.shape[:-1], y.shape[1])
@@ -580,8 +605,8 @@ class LoraLinearMergedFunction(torch.autograd.Function):
         sink = ctx.sink
         dx = None
         if need_x:
-            with _gemm_range():
-                dx = (g2 @ w_eff).view(ctx.x_shape)  # frozen dense GEMM; pad columns of a head-padded dX come out zero
+            with _gemm_range():  # frozen dense GEMM; pad columns of a head-padded dX come out zero
+                dx = (F.linear(g2, ctx.w_eff_t) if ctx.w_eff_t is not None else g2 @ w_eff).view(ctx.x_shape)
         d_down = d_up = None
         if need_down or need_up:
             mw = getattr(getattr(sink, "owner", None), "merged", None)
@@ -617,7 +642,7 @@ class LoraLinearMergedFunction(torch.autograd.Function):
             db = (unpack_heads(g2, ctx.out_heads) if ctx.out_heads else g2).sum(0)
             if ctx.out_heads:
                 db = pack_heads(db, ctx.out_heads)
-        return dx, None, db, d_down, d_up, None, None, None, None
+        return dx, None, db, d_down, d_up, None, None, None, None, None
 
 
 class LoraLinearMergedGroupFunction(torch.autograd.Function):
@@ -625,23 +650,23 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
     the input gradients of the sites are accumulated by the GEMMs themselves (``addmm_``: beta = 1 in the library's
     epilogue) instead of n - 1 elementwise ``add`` launches over [M, K] that autograd would issue for n separate nodes.
 
-    Inputs: x, n, then per site (w_eff, b_eff, down, up, scale, sink, out_heads)."""
+    Inputs: x, n, then per site (w_eff, b_eff, down, up, scale, sink, out_heads, w_eff_t)."""
 
     @staticmethod
     def forward(ctx, x, n, *args):
         _C.require()
-        sites = [args[7 * i:7 * i + 7] for i in range(n)]
+        sites = [args[8 * i:8 * i + 8] for i in range(n)]
         K = sites[0][0].shape[1]
         x2 = _rows2d(x, K)
         outs = []
         with _gemm_range():
-            for (w_eff, b_eff, down, up, scale, sink, out_heads) in sites:
+            for (w_eff, b_eff, down, up, scale, sink, out_heads, _) in sites:
                 y = F.linear(x2, w_eff, b_eff)
                 outs.append(y.view(*x.shape[:-1], y.shape[1]))
                 N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
                 _log("fwd", "merged_group" + ("_heads" if out_heads else ""), x2.shape[0], K, N, down.shape[0])
         ctx.save_for_backward(x2, *[t for st in sites for t in (st[0], st[2], st[3])])
-        ctx.meta = [(float(st[4]), st[5], st[6]) for st in sites]
+        ctx.meta = [(float(st[4]), st[5], st[6], st[7]) for st in sites]
         ctx.n, ctx.x_shape = n, x.shape
         return tuple(outs)
 
@@ -656,7 +681,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
         grads = [None, None]
         for i in range(ctx.n):
             w_eff, down, up = saved[1 + 3 * i:4 + 3 * i]
-            scale, sink, out_heads = ctx.meta[i]
+            scale, sink, out_heads, w_eff_t = ctx.meta[i]
             g = gs[i]
             r = down.shape[0]
             N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
@@ -665,7 +690,8 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 g2 = _rows2d(g, w_eff.shape[0])
                 if need_x:
                     with _gemm_range():
-                        dx = (g2 @ w_eff) if dx is None else dx.addmm_(g2, w_eff)
+                        wb = w_eff_t.t() if w_eff_t is not None else w_eff  # [N', K] operand; transposed storage: TN GEMM
+                        dx = (g2 @ wb) if dx is None else dx.addmm_(g2, wb)
                 mw = getattr(getattr(sink, "owner", None), "merged", None)
                 defer = mw is not None and mw.defer_factors
                 plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
@@ -694,7 +720,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                     table, cnt, total = _C.make_reduce_table(rows, g2.device)
                     _C.reduce_batched(table, cnt, total)
                     d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
-            grads += [None, None, d_down, d_up, None, None, None]
+            grads += [None, None, d_down, d_up, None, None, None, None]
         grads[0] = dx.view(ctx.x_shape) if dx is not None else None
         return tuple(grads)
 

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_header_symbols():
 
 
 def test_struct_layout_matches_header():
-    assert C.sizeof(_C.MergeSite) == 72 and _C.MergeSite.tile_begin.offset == 56 and _C.MergeSite.N.offset == 32
+    assert C.sizeof(_C.MergeSite) == 80 and _C.MergeSite.tile_begin.offset == 56 and _C.MergeSite.N.offset == 32
     assert C.sizeof(_C.AdamWGroup) == 24
     assert C.sizeof(_C.WsSite) == 112 and _C.WsSite.dropout_p.offset == 80 and _C.WsSite.offset_dev.offset == 104
 
