@@ -224,6 +224,31 @@ def test_factors_self_kernel_vs_oracle(M, K, N, r, dt, gh, xh):
     close(n(d_down), ddo, Gt_abs.T @ np.abs(X), "f32", k=1e-4, msg="dDown")
 
 
+@pytest.mark.parametrize("N,K,r,heads", [(320, 320, 4, None), (1280, 320, 8, None), (320, 768, 16, None),
+                                          (320, 320, 4, (40, 64)), (10240, 1280, 4, None)])
+def test_merge_transposed_site_is_the_bitwise_transpose(N, K, r, heads):
+    """lora.py:635-669 through ``lora_amd_merge_site.transposed``: W^T + alpha (up down)^T merged from the transposed
+    frozen weight equals the transpose of the ordinary merge BIT FOR BIT (same fma chain per element), also when the
+    transposed result's columns are head-padded (``out_heads`` on the transposed site = a head-padded OUTPUT of the
+    adapter); and both equal oracle.collapse within one rounding."""
+    w = rnd((N, K), "bf16", 0.05, seed=1)
+    up, down = rnd((N, r), "f32", 0.3, seed=2), rnd((r, K), "f32", 0.3, seed=3)
+    w_eff = torch.empty_like(w)
+    _C.MergePlan([(w, w_eff, up, down)]).launch(0.7, _C.ROUND_ONCE)
+    wt = w.t().contiguous()
+    n_out = N if heads is None else (N // heads[0]) * heads[1]
+    w_eff_t = torch.zeros(K, n_out, dtype=w.dtype, device=DEV)
+    _C.MergePlan([(wt, w_eff_t, down, up, heads, True)]).launch(0.7, _C.ROUND_ONCE)
+    got = w_eff_t
+    if heads is not None:
+        d, D = heads
+        assert torch.all(w_eff_t.view(K, N // d, D)[:, :, d:] == 0)
+        got = w_eff_t.view(K, N // d, D)[:, :, :d].reshape(K, N)
+    assert torch.equal(got, w_eff.t())
+    want = O.collapse(n(w), n(up), n(down), 0.7)
+    assert np.abs(n(w_eff) - want).max() <= 2.0 ** -8 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("rows", [0, 32, 128])
 def test_factors_self_ragged_one_launch_for_several_sites_vs_oracle(rows, monkeypatch):
     """lora_amd_linear_bwd_factors_self_ragged: the factor gradients of several sites of different shapes (one of them
