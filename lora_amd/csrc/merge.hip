@@ -192,13 +192,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
   // this thread's r x 8 block of `down`
   float fc[RT][8];
   const SAB *dn = reinterpret_cast<const SAB *>(s.down);
+  const bool tvec = s.transposed != 0 && sizeof(SAB) == 4 && (r & 3) == 0 && (reinterpret_cast<uintptr_t>(s.down) & 15u) == 0;
   const bool tpo = s.transposed != 0;  // the transposed product: `down` holds the original up [K, r], `up` the original down [r, N]
 #pragma unroll
   for (int j = 0; j < RT; ++j) {
     if (j < r) {
       if (tpo) {
+        // the 8 columns' ranks are 8 r consecutive factor elements ([K, r] row-major): the r % 4 == 0 f32 case below
+        // fetches them as 16-byte loads; anything else element by element
+        if (!tvec) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fc[j][i] = EAB::to_f(dn[(int64_t)(col + i) * r + j]);
+          for (int i = 0; i < 8; ++i) fc[j][i] = EAB::to_f(dn[(int64_t)(col + i) * r + j]);
+        }
       } else {
         load8<EAB>(dn + (int64_t)j * s.K + col, fc[j]);
       }
@@ -207,11 +212,29 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
       for (int i = 0; i < 8; ++i) fc[j][i] = 0.f;
     }
   }
+  if (tvec) {
+    const float *dnf = reinterpret_cast<const float *>(s.down) + (int64_t)col * r;  // 16-byte aligned: col % 8 == 0, r % 4 == 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int q = 0; q < RT / 4; ++q)
+        if (q * 4 < r) {
+          const float4 v = *reinterpret_cast<const float4 *>(dnf + i * r + q * 4);
+          fc[q * 4 + 0][i] = v.x; fc[q * 4 + 1][i] = v.y; fc[q * 4 + 2][i] = v.z; fc[q * 4 + 3][i] = v.w;
+        }
+  }
   // the tile's rows of `up` -> LDS [nrows][RT]
   const SAB *upp = reinterpret_cast<const SAB *>(s.up);
-  for (int i = tid; i < nrows * RT; i += kMergeThreads) {
-    const int rl = i / RT, j = i - rl * RT;
-    s_up[i] = j < r ? EAB::to_f(tpo ? upp[(int64_t)j * s.N + row0 + rl] : upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
+  if (tpo) {  // rank-major source [r, N]: consecutive threads read consecutive rows of one rank
+    for (int i = tid; i < nrows * RT; i += kMergeThreads) {
+      const int j = i / nrows, rl = i - j * nrows;
+      s_up[rl * RT + j] = j < r ? EAB::to_f(upp[(int64_t)j * s.N + row0 + rl]) : 0.f;
+    }
+  } else {
+    for (int i = tid; i < nrows * RT; i += kMergeThreads) {
+      const int rl = i / RT, j = i - rl * RT;
+      s_up[i] = j < r ? EAB::to_f(upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
+    }
   }
   __syncthreads();
 
