@@ -38,7 +38,7 @@ __device__ inline float ld_factor(const void *p, int dt, int64_t i) {
 // [RT][2][ncols/8][4] (vec) so that a lane's 8 columns are two 16-byte slots whose
 // addresses advance 16 B per lane (conflict-free ds_read_b128).  Ranks >= r are zero.
 template <int RT>
-__device__ inline void stage_factor_vec(float *s_f, const void *f, int fdt, int layout, int r,
+__device__ __forceinline__ void stage_factor_vec(float *s_f, const void *f, int fdt, int layout, int r,
                                         int64_t C, int c0, int ncols) {
   const int c8 = ncols >> 3;
   for (int i = threadIdx.x; i < RT * ncols; i += kThreads) {
@@ -53,7 +53,7 @@ __device__ inline void stage_factor_vec(float *s_f, const void *f, int fdt, int 
 }
 
 template <int RT>
-__device__ inline void fma_chunk(const float *s_f, int c8, int cc, const float (&x)[8], float (&acc)[RT]) {
+__device__ __forceinline__ void fma_chunk(const float *s_f, int c8, int cc, const float (&x)[8], float (&acc)[RT]) {
 #pragma unroll
   for (int j = 0; j < RT; ++j) {
     const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
@@ -73,7 +73,7 @@ __device__ inline void fma_chunk(const float *s_f, int c8, int cc, const float (
 // ---------------------------------------------------------------------------
 // `bx` = row block of the matrix; the pointers already address the matrix (batched and ragged launches offset them).
 template <class EX, int RT, bool MASKED>
-__device__ inline void rowdot_body(
+__device__ __forceinline__ void rowdot_body(
     const typename EX::storage *__restrict__ x, int64_t ldx, const void *__restrict__ f, int fdt,
     int layout, float *__restrict__ t_out, int64_t M, int K, int r, int kt_cols, int logL,
     int rows_per_block, float scale, const float *__restrict__ sel, int sel_transposed, float p,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void rowdot_kernel(
 // A table of jobs, one per stack of same-shape matrices; blocks are numbered through the table (begin1 / begin2 are the
 // running block counts of the two launch kinds, filled by lora_amd_ragged_plan).  Uniform per workgroup: the lookup is
 // a binary search on scalar loads.
-__device__ inline int ragged_find(const lora_amd_ragged_desc *__restrict__ d, int n, int64_t b, bool second) {
+__device__ __forceinline__ int ragged_find(const lora_amd_ragged_desc *__restrict__ d, int n, int64_t b, bool second) {
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -355,7 +355,7 @@ constexpr int kColMaxChunks = 64;
 constexpr int kColRowsRagged = 256;
 
 template <class EX, int RT, bool MASKED, int RB = kColRowsPerBlock>
-__device__ inline void colreduce_stage1_body(
+__device__ __forceinline__ void colreduce_stage1_body(
     const typename EX::storage *__restrict__ x, int64_t ldx, const float *__restrict__ t,
     float *__restrict__ partial, int64_t M, int K, int r, int rank0, int col_tiles, float p,
     uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int64_t bx) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void colreduce_stage1_ragged_kernel(const
 // stage 2: D[j,k] = beta*D + scale * sum_b partial[b][j][k]  (j in [rank0, rank0+RT)).
 // Block = 64 consecutive (j,k) elements x 4 waves; wave w sums row blocks w, w+4, ... (8 loads in
 // flight per lane), the four wave sums meet in LDS.
-__device__ inline void colreduce_stage2_body(
+__device__ __forceinline__ void colreduce_stage2_body(
     const float *__restrict__ partial, float *__restrict__ d, int64_t nblocks, int K, int r,
     int RT, int rank0, int out_layout, float scale, float beta, int64_t bx) {
   __shared__ float s_sum[kThreads];

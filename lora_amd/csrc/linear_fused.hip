@@ -34,7 +34,7 @@ __device__ inline float ldf(const void *p, int dt, int64_t i) {
 // Factor slab -> LDS layout [RT][2][ncols/8][4] (two conflict-free 16-byte planes per lane).
 // f32 [r,C] slabs move as float4 with 4 loads in flight per thread; anything else element-wise.
 template <int RT>
-__device__ inline void stage_factor(float *s_f, const void *f, int fdt, int layout, int r, int64_t C, int c0,
+__device__ __forceinline__ void stage_factor(float *s_f, const void *f, int fdt, int layout, int r, int64_t C, int c0,
                                     int ncols) {
   const int c8 = ncols >> 3;
   const bool fast = fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_RK && (C & 3) == 0 && (c0 & 3) == 0 &&
@@ -98,7 +98,7 @@ __device__ inline void stage_factor(float *s_f, const void *f, int fdt, int layo
 
 // The r x 8 factor block a column-owner thread needs, straight into registers.
 template <int RT>
-__device__ inline void load_factor_cols(float (&fc)[RT][8], const void *f, int fdt, int layout, int r, int64_t C,
+__device__ __forceinline__ void load_factor_cols(float (&fc)[RT][8], const void *f, int fdt, int layout, int r, int64_t C,
                                         int col) {
   if (fdt == LORA_AMD_F32 && layout == LORA_AMD_FACTOR_RK && (C & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(f) & 15u) == 0)) {
@@ -134,7 +134,7 @@ __device__ inline void load_factor_cols(float (&fc)[RT][8], const void *f, int f
 
 // s_t[row][RT] = (sum over nparts of part[p][m0+row][0..r)) (@ S | @ S^T), zero padded to RT.
 template <int RT>
-__device__ inline void stage_rowvecs(float *s_t, const float *part, int nparts, int64_t part_stride, int64_t m0,
+__device__ __forceinline__ void stage_rowvecs(float *s_t, const float *part, int nparts, int64_t part_stride, int64_t m0,
                                      int nrows, int r, const float *sel, int sel_transposed, float mult) {
   for (int i = threadIdx.x; i < nrows * RT; i += kFT) {
     const int rl = i / RT, j = i - rl * RT;
@@ -158,7 +158,7 @@ __device__ inline void stage_rowvecs(float *s_t, const float *part, int nparts, 
 // LDS image [4 ranks][slot][col]: every thread drops its 8 columns as two 16-byte writes per rank, the summing pass
 // reads consecutive columns with consecutive lanes (conflict-free) and stores 256-byte runs of one output row.
 template <int RT>
-__device__ inline void slot_reduce_store(float *s_red, const float (&acc)[RT][8], int slot, int nslots, int cl,
+__device__ __forceinline__ void slot_reduce_store(float *s_red, const float (&acc)[RT][8], int slot, int nslots, int cl,
                                          int ct8, float *out, int64_t ld, int col0) {  // ld = row length: the last tile may overhang
   const int ncols = ct8 * 8;
 #pragma unroll
@@ -613,12 +613,12 @@ struct SelfArgs {
   int tile_g, nct_g, tile_x, nct_x;  // phase B: 16-byte chunks per column tile (<= 256), number of tiles
 };
 
-__device__ inline int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
+__device__ __forceinline__ int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
 
 // s_out[rl * RT + j] = mult * sum_c data[m0 + rl, c] * factor(j, c) for the block's rows; L lanes per row.  The factor
 // passes through LDS in slabs of kt_cols columns (outer loop: a slab is staged once per block, not once per row group).
 template <class E, int RT, int U>
-__device__ inline void block_rowdots(float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
+__device__ __forceinline__ void block_rowdots(float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
                                      int nrows, int C, const float *factor, int layout, int r, int kt_cols, int logL,
                                      float mult, int hc, int hp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -631,6 +631,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
     __syncthreads();
     stage_factor<RT>(s_f, factor, LORA_AMD_F32, layout, r, C, k0, ncols);
     __syncthreads();
+#pragma unroll 1
     for (int it = 0; it < niter; ++it) {
       const int rl = it * rows_iter + wave * G + g;
       const bool live = rl < nrows;
@@ -640,6 +641,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
       if (live) {
         const typename E::storage *xr = data + (m0 + rl) * ld;
         const int cbase = k0 >> 3;
+#pragma unroll 1
         for (int cb = l; cb < c8; cb += L * U) {
           float xv[U][8];
 #pragma unroll
@@ -679,7 +681,7 @@ __device__ inline void block_rowdots(float *s_f, float *s_out, const typename E:
 // [c0, c0 + tc8) (16-byte chunks; tc8 <= 256, any value: slot = tid / tc8, so a 320-wide row is ONE tile of 40 chunks x 6
 // row slots instead of five power-of-two tiles with a slot reduction each).
 template <class E, int RT, int U>
-__device__ inline void block_colsums(float *s_red, const float *s_vec, const typename E::storage *data, int64_t ld,
+__device__ __forceinline__ void block_colsums(float *s_red, const float *s_vec, const typename E::storage *data, int64_t ld,
                                      int64_t m0, int nrows, int C, int c0, int tc8, float *part, int hc, int hp) {
   const int tid = threadIdx.x;
   const int nslots = kFT / tc8;
@@ -693,6 +695,7 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
   if (owner) {
+#pragma unroll 1
     for (int rb0 = slot; rb0 < nrows; rb0 += nslots * U) {
       float v[U][8];
 #pragma unroll
@@ -748,7 +751,7 @@ __device__ inline void block_colsums(float *s_red, const float *s_vec, const typ
 }
 
 template <class E, int RT, int U = 4>
-__device__ inline void factors_self_body(const SelfArgs &a, int64_t bid) {
+__device__ __forceinline__ void factors_self_body(const SelfArgs &a, int64_t bid) {
   // phase A stages the factor slab, phase B reduces row slots: never live together
   __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
   __shared__ __attribute__((aligned(16))) float s_t[kSelfRowsCap * RT];   // rows_per_block <= kSelfRowsCap (factors_self_geom)
@@ -789,6 +792,9 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_kernel(const Self
 // tile), blocks are numbered through it.  The per-site launches of a training step are latency-bound (a site is 1-90 MB,
 // one or two rounds of workgroups, four dependent trips to memory each); deferred to the end of the backward and issued
 // together, the sites' phases overlap across ~50 000 workgroups and the pass runs at memory throughput.
+// Occupancy: the pass is bound by how many loads the chip keeps in flight.  The helpers are __forceinline__: left as
+// plain `inline`, hipcc emitted real calls to them (s_swappc) and the call ABI cost the kernel 232 registers (2 waves per
+// SIMD); inlined, rank tile 4 takes 117 (4 waves per SIMD, 36 KiB of LDS per workgroup).
 template <class E, int RT, int U>
 __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(const lora_amd_self_site *__restrict__ sites,
                                                                              int n) {
@@ -819,7 +825,7 @@ constexpr int kHalf = kDualThreads / 2;
 constexpr int kSelfRowsMax = kSelfRowsCap;
 
 template <class E, int RT>
-__device__ inline void half_rowdots(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
+__device__ __forceinline__ void half_rowdots(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld, int64_t m0,
                                     int nrows, int C, int logL, float mult, int hc, int hp, int hw) {
   const int lane = threadIdx.x & 63;
   const int L = 1 << logL, G = 64 >> logL;
@@ -866,7 +872,7 @@ __device__ inline void half_rowdots(const float *s_f, float *s_out, const typena
 
 // staging with all kDualThreads threads (stage_factor strides by kFT: its callers are 256-thread kernels)
 template <int RT>
-__device__ inline void stage_factor_dual(float *s_f, const float *f, int layout, int r, int C) {
+__device__ __forceinline__ void stage_factor_dual(float *s_f, const float *f, int layout, int r, int C) {
   const int c8 = C >> 3;
   for (int i = threadIdx.x; i < RT * C; i += kDualThreads) {
     int j, c;
