@@ -346,12 +346,18 @@ __global__ __launch_bounds__(kFT) void linear_fwd_kernel(
 // grid = row blocks x column tiles (column tile fastest).  Outputs:
 //   gt_part[ct][M][r]  = scale * sum over this tile's columns of (mask*G)[m, n] * up[n, j]
 //   up_part[rb][RT][N] = scale * sum over this block's rows of (mask*G)[m, n] * T[m, j]
-template <class E, int RT, bool DROP>
+// FCL: the thread's RT x 8 block of `up` lives in LDS instead of registers (rank tile 16: 128 registers less — two waves
+// per SIMD instead of one; the block is the same for every row slot, so the slot-0 threads stage it once, in the area
+// the slot reduction uses at the end; rows of RT*8 + 4 floats keep the 16-byte reads of different columns off each other's banks)
+constexpr int kFclStride16 = 16 * 8 + 4;
+
+template <class E, int RT, bool DROP, bool FCL = false>
 __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
     const typename E::storage *__restrict__ g, int64_t ldg, const float *__restrict__ t,
     const void *__restrict__ up, int fdt, float *__restrict__ gt_part, float *__restrict__ up_part, int64_t M,
     int N, int r, int log_ct8, int nct, int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
-  __shared__ __attribute__((aligned(16))) float s_red[kFT * 8 * 4];
+  __shared__ __attribute__((aligned(16))) float s_red[FCL ? 64 * kFclStride16 : kFT * 8 * 4];
+  static_assert(64 * kFclStride16 >= kFT * 8 * 4, "slot-reduction area");
   __shared__ __attribute__((aligned(16))) float s_t[kFLdsT];
   __shared__ __attribute__((aligned(16))) float s_gt[kFLdsT];  // this block's Gt rows, stored once at the end
   const int tid = threadIdx.x;
@@ -364,8 +370,22 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
   const int col = (ct * ct8 + cl) * 8;
   const bool colok = col < N;  // the last tile of a row whose chunk count is not a multiple of ct8 overhangs: idle lanes
 
-  float fc[RT][8];
-  load_factor_cols<RT>(fc, up, fdt, LORA_AMD_FACTOR_KR, r, N, colok ? col : 0);
+  float fc[FCL ? 1 : RT][8];
+  constexpr int FS = RT * 8 + 4;
+  const float *s_fc = s_red + cl * FS;
+  if constexpr (FCL) {
+    if (slot == 0) {
+      float tmp[RT][8];
+      load_factor_cols<RT>(tmp, up, fdt, LORA_AMD_FACTOR_KR, r, N, colok ? col : 0);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        *reinterpret_cast<float4 *>(s_red + cl * FS + j * 8) = make_float4(tmp[j][0], tmp[j][1], tmp[j][2], tmp[j][3]);
+        *reinterpret_cast<float4 *>(s_red + cl * FS + j * 8 + 4) = make_float4(tmp[j][4], tmp[j][5], tmp[j][6], tmp[j][7]);
+      }
+    }
+  } else {
+    load_factor_cols<RT>(fc, up, fdt, LORA_AMD_FACTOR_KR, r, N, colok ? col : 0);
+  }
   stage_rowvecs<RT>(s_t, t, 1, 0, m0, nrows, r, nullptr, 0, scale);  // dUp partials carry `scale`
   __syncthreads();
 
@@ -406,9 +426,17 @@ __global__ __launch_bounds__(kFT) void linear_bwd_g_kernel(
         for (int j = 0; j < RT; ++j) {
           const float tj = tr[j];
           float d = 0.f;
+          float fj[8];
+          if constexpr (FCL) {
+            const float4 f0 = *reinterpret_cast<const float4 *>(s_fc + j * 8), f1 = *reinterpret_cast<const float4 *>(s_fc + j * 8 + 4);
+            fj[0] = f0.x; fj[1] = f0.y; fj[2] = f0.z; fj[3] = f0.w; fj[4] = f1.x; fj[5] = f1.y; fj[6] = f1.z; fj[7] = f1.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fj[i] = fc[j][i];
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            d = fmaf(gv[u][i], fc[j][i], d);
+            d = fmaf(gv[u][i], fj[i], d);
             acc[j][i] = fmaf(tj, gv[u][i], acc[j][i]);
           }
           dot[j] = d;
@@ -1169,7 +1197,12 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
   hipLaunchKernelGGL((linear_bwd_g_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                        \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \
                      N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset, offset_dev)
-#define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else BG(E, 16, D); } while (0)
+#define BG16(E, D)                                                                                          \
+  hipLaunchKernelGGL((linear_bwd_g_kernel<E, 16, D, true>), dim3(grid), dim3(kFT), 0, st,                   \
+                     reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \
+                     N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset, offset_dev)
+  static const bool fcl = !(getenv("LORA_AMD_BWDG_FCL") && atoi(getenv("LORA_AMD_BWDG_FCL")) == 0);
+#define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else if (fcl) BG16(E, D); else BG(E, 16, D); } while (0)
 #define BG_E(E) do { if (drop) BG_RT(E, true); else BG_RT(E, false); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: BG_E(f32_t); break;
@@ -1178,6 +1211,7 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
   }
 #undef BG_E
 #undef BG_RT
+#undef BG16
 #undef BG
   return check_launch("lora_amd_linear_bwd_g");
 }
