@@ -624,8 +624,8 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_kernel(FactorJob a, Fa
 // T = X down^T nor Gt = s G up at hand.  This kernel recomputes both per row block and consumes them in place:
 //   phase A   s_t[m][j]  = s * sum_k X[m, k] down[j, k]          s_gt[m][j] = s * sum_n G[m, n] up[n, j]      (LDS)
 //   phase B   up_part[rb][j][n] = sum_m s_t[m][j] G[m, n]        down_part[rb][j][k] = sum_m s_gt[m][j] X[m, k]
-// so G and X leave HBM once (phase B re-reads the block's rows from L2 / the Infinity Cache: a row block is
-// rows * (N + K) * 2 bytes).  grid = row blocks x `nsplit`; the splits of a row block share out the column tiles of
+// (phase B reads the block's rows a second time: rows * (N + K) * 2 bytes per block; in the one-launch pass that second
+// read is served past the L2 — FETCH_SIZE 2.0x algorithmic).  grid = row blocks x `nsplit`; the splits of a row block share out the column tiles of
 // phase B (and each redo phase A: only taken when M is too small to fill the chip with row blocks alone).
 constexpr int kSelfRowsCap = 128;  // rows of a block: their r-vectors live in LDS next to the 32 KiB work buffer
 
