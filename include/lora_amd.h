@@ -353,7 +353,7 @@ typedef struct lora_amd_reduce_desc {
 
 /* The parameter gradients of a site on the merged-weight path (no T, no Gt saved or produced by another launch):
  * up_part[rb][RT][N] = sum_m (s X down^T)[m, j] G[m, n],  down_part[rb][RT][K] = sum_m (s G up)[m, j] X[m, k] per row
- * block rb, in ONE launch that reads G and X from HBM once (replaces the autograd of lora.py:53-58 for dA, dB when the
+ * block rb, in ONE launch (each row block of G and X is read twice: row-dot phase, column-sum phase; replaces the autograd of lora.py:53-58 for dA, dB when the
  * forward ran on W + s up down).  f32 factors; G / X rows may be head-padded (d, D as in linear_bwd_factors_heads).
  * The plan sizes the partial slabs: `nparts` row blocks, folded by lora_amd_reduce_batched. */
 typedef struct lora_amd_factors_self_plan_t {
