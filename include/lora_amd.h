@@ -383,11 +383,17 @@ typedef struct lora_amd_self_site {
   int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
   /* rows_per_block: caller's choice (0: the per-site default); everything else is filled by the plan */
   int32_t rows_per_block, nsplit, kt_g, logL_g, kt_x, logL_x, tile_g, nct_g, tile_x, nct_x;
+  int32_t sub_rows, reserved;   /* caller: 0, or the rows of a sub-block (lora_amd_linear_bwd_factors_self_ragged_sub) */
   int64_t block_begin;
 } lora_amd_self_site;
 int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *sites, int32_t n, int32_t act_dtype, int64_t *grid);
 int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid, int32_t rank,
                                             int32_t act_dtype, void *stream);
+/* the sub-block form (experimental, rank <= 8): a table whose every site was planned with sub_rows > 0 (the caller's
+ * request; N, K <= 2048 and RT (N + K) <= 8192) — row dots and column sums of 16-32 rows at a time with the column
+ * accumulators kept in registers across them, so that the second read of a row is an L2 hit */
+int lora_amd_linear_bwd_factors_self_ragged_sub(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid, int32_t rank,
+                                                int32_t act_dtype, void *stream);
 int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
 
 /* ------------------------------------------------------------------------

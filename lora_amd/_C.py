@@ -36,6 +36,7 @@ SYMBOLS = (
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
     "lora_amd_linear_factors_self_ragged_plan", "lora_amd_linear_bwd_factors_self_ragged",
+    "lora_amd_linear_bwd_factors_self_ragged_sub",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
@@ -72,6 +73,7 @@ class SelfSite(C.Structure):
         ("rows_per_block", C.c_int32), ("nsplit", C.c_int32), ("kt_g", C.c_int32), ("logL_g", C.c_int32),
         ("kt_x", C.c_int32), ("logL_x", C.c_int32), ("tile_g", C.c_int32), ("nct_g", C.c_int32),
         ("tile_x", C.c_int32), ("nct_x", C.c_int32),
+        ("sub_rows", C.c_int32), ("reserved", C.c_int32),
         ("block_begin", C.c_int64),
     ]
 
@@ -212,6 +214,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_factors_self_ragged_plan.argtypes = [vp, i32, i32, C.POINTER(C.c_int64)]
     lib.lora_amd_linear_bwd_factors_self_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_linear_factors_self_ragged_plan.restype = lib.lora_amd_linear_bwd_factors_self_ragged.restype = C.c_int
+    lib.lora_amd_linear_bwd_factors_self_ragged_sub.argtypes = [vp, i32, i64, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors_self_ragged_sub.restype = C.c_int
     lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
                                                    f32, f32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
@@ -800,13 +804,23 @@ def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor
            "lora_amd_linear_bwd_factors_self")
 
 
-def factors_self_ragged_table(sites, act_dtype: torch.dtype):
+# rows of a sub-block for the experimental sub-block form of the one-launch pass (0 = off, the default)
+SELF_SUB_ROWS = int(os.environ.get("LORA_AMD_SELF_SUBROWS", "0"))
+
+
+def self_sub_ok(N: int, K: int, r: int) -> bool:
+    rt = 4 if r <= 4 else 8 if r <= 8 else 16
+    return SELF_SUB_ROWS >= 8 and rt <= 8 and N <= 2048 and K <= 2048 and rt * (N + K) <= 8192
+
+
+def factors_self_ragged_table(sites, act_dtype: torch.dtype, sub_rows: int = 0):
     """Host half of the one-launch factor-gradient pass: ``sites`` = [(g, x, down, up, up_part, down_part, scale,
     g_heads, x_heads)] (one activation dtype, one rank tile) -> (planned ctypes table, grid)."""
     lib = require()
     arr = (SelfSite * len(sites))()
     for q, (g, x, down, up, up_part, down_part, scale, g_heads, x_heads) in zip(arr, sites):
         q.rows_per_block = SELF_ROWS_DEFERRED
+        q.sub_rows = int(sub_rows)
         q.g, q.x, q.down, q.up = g.data_ptr(), x.data_ptr(), down.data_ptr(), up.data_ptr()
         q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
         q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
@@ -821,7 +835,13 @@ def factors_self_ragged_table(sites, act_dtype: torch.dtype):
     return arr, grid.value
 
 
-def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, rank: int, act_dtype: torch.dtype) -> None:
+def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, rank: int, act_dtype: torch.dtype,
+                                   sub: bool = False) -> None:
+    if sub:
+        _check(require().lora_amd_linear_bwd_factors_self_ragged_sub(table_dev.data_ptr(), n, grid, rank,
+                                                                     dtype_code(act_dtype), _stream()),
+               "lora_amd_linear_bwd_factors_self_ragged_sub")
+        return
     _check(require().lora_amd_linear_bwd_factors_self_ragged(table_dev.data_ptr(), n, grid, rank, dtype_code(act_dtype),
                                                              _stream()), "lora_amd_linear_bwd_factors_self_ragged")
 

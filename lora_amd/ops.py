@@ -533,12 +533,14 @@ class MergedWeights:
         groups = {}
         for st in owed:
             r = st[2].shape[0]
-            groups.setdefault((st[0].dtype, 4 if r <= 4 else 8 if r <= 8 else 16), []).append(st)
+            N = st[7][0] * st[7][1] if st[7] else st[0].shape[1]
+            K = st[8][0] * st[8][1] if st[8] else st[1].shape[1]
+            groups.setdefault((st[0].dtype, 4 if r <= 4 else 8 if r <= 8 else 16, _C.self_sub_ok(N, K, r)), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
-        for (dt, rt), sites in groups.items():
-            arr, grid = _C.factors_self_ragged_table(sites, dt)
+        for (dt, rt, sub), sites in groups.items():
+            arr, grid = _C.factors_self_ragged_table(sites, dt, _C.SELF_SUB_ROWS if sub else 0)
             raw = bytes(arr)
-            key = (dt, rt, len(raw))
+            key = (dt, rt, sub, len(raw))
             slot = self._tables.get(key)
             if slot is None:
                 if capturing:
@@ -562,7 +564,7 @@ class MergedWeights:
             if not capturing:
                 slot[1] = torch.cuda.Event()
                 slot[1].record()
-            _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt)
+            _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt, sub)
 
     def invalidate(self) -> None:
         """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
