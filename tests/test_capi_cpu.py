@@ -165,3 +165,46 @@ def test_round3_planners_are_pure_host_arithmetic():
     assert lib.lora_amd_merge_plan(sites, 1, 2, C.byref(summ)) == 0 and summ.n_fast_sites == 1
     s.out_heads = 48 | (64 << 16)  # 320 % 48 != 0
     assert lib.lora_amd_merge_plan(sites, 1, 2, C.byref(summ)) != 0
+
+
+def test_factor_pass_planner_invariants_over_random_shapes():
+    """lora_amd_linear_factors_self_plan_rows / lora_amd_linear_factors_self_ragged_plan (host arithmetic): for random
+    (M, K, N, r) the row blocks cover the rows, the column tiles cover the row, LDS limits hold, and the ragged table's block
+    ranges are the running sum of the per-site block counts."""
+    import random
+
+    lib = _C.require()
+    rng = random.Random(0)
+    sites_spec = []
+    for _ in range(200):
+        M = rng.choice([1, 7, 64, 130, 308, 1024, 4096, 16384])
+        K = 8 * rng.randint(4, 400)
+        N = 8 * rng.randint(4, 1300)
+        r = rng.choice([1, 3, 4, 8, 12, 16])
+        rows = rng.choice([0, 16, 64, 128, 300])
+        pl = _C.factors_self_plan(M, K, N, r, rows)
+        assert pl.supported == 1, (M, K, N, r)
+        rt = 4 if r <= 4 else 8 if r <= 8 else 16
+        assert pl.rank_tile == rt
+        rows_eff = -(-M // pl.nparts)
+        assert 1 <= pl.nparts <= M and rows_eff <= min(128, 2048 // rt)      # r-vectors of a block fit the LDS arrays
+        assert pl.up_part_floats == pl.nparts * rt * N and pl.down_part_floats == pl.nparts * rt * K
+        sites_spec.append((M, K, N, r, rows, pl.nparts))
+    # one ragged table per rank tile
+    for rt in (4, 8, 16):
+        spec = [s_ for s_ in sites_spec if (4 if s_[3] <= 4 else 8 if s_[3] <= 8 else 16) == rt][:40]
+        arr = (_C.SelfSite * len(spec))()
+        for q, (M, K, N, r, rows, _) in zip(arr, spec):
+            q.g = q.x = q.down = q.up = q.up_part = q.down_part = 4096
+            q.ldg, q.ldx, q.M, q.N, q.K, q.r, q.scale, q.rows_per_block = N, K, M, N, K, r, 1.0, rows
+        grid = C.c_int64(0)
+        assert lib.lora_amd_linear_factors_self_ragged_plan(arr, len(spec), 2, C.byref(grid)) == 0
+        begin = 0
+        for q, (M, K, N, r, rows, nparts) in zip(arr, spec):
+            assert q.block_begin == begin and q.nsplit == 1
+            nrb = -(-M // q.rows_per_block)
+            assert nrb == nparts                                             # slabs sized by the plan == blocks launched
+            assert q.tile_g * q.nct_g >= N // 8 and q.tile_g <= 256 and q.tile_x * q.nct_x >= K // 8 and q.tile_x <= 256
+            assert 0 <= q.logL_g <= 6 and 0 <= q.logL_x <= 6 and q.kt_g % 8 == 0 and q.kt_g * rt <= 8192
+            begin += nrb
+        assert grid.value == begin
