@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 3
+#define LORA_AMD_ABI_VERSION 4
 
 /* status codes */
 #define LORA_AMD_OK 0
@@ -383,18 +383,58 @@ typedef struct lora_amd_self_site {
   int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
   /* rows_per_block: caller's choice (0: the per-site default); everything else is filled by the plan */
   int32_t rows_per_block, nsplit, kt_g, logL_g, kt_x, logL_x, tile_g, nct_g, tile_x, nct_x;
-  int32_t sub_rows, reserved;   /* caller: 0, or the rows of a sub-block (lora_amd_linear_bwd_factors_self_ragged_sub) */
+  int32_t reserved0, reserved;  /* 0 */
   int64_t block_begin;
 } lora_amd_self_site;
 int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *sites, int32_t n, int32_t act_dtype, int64_t *grid);
 int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid, int32_t rank,
                                             int32_t act_dtype, void *stream);
-/* the sub-block form (experimental, rank <= 8): a table whose every site was planned with sub_rows > 0 (the caller's
- * request; N, K <= 2048 and RT (N + K) <= 8192) — row dots and column sums of 16-32 rows at a time with the column
- * accumulators kept in registers across them, so that the second read of a row is an L2 hit */
-int lora_amd_linear_bwd_factors_self_ragged_sub(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid, int32_t rank,
-                                                int32_t act_dtype, void *stream);
 int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, int64_t total, void *stream);
+/* The same pass on the matrix cores, every row of G and X read from HBM ONCE (16-bit activations; csrc/factor_mfma.hip):
+ * a workgroup keeps the R rows of the narrower of (X, G) resident in LDS, streams the wider one through LDS in column
+ * chunks, and runs both contractions of lora.py:53-58's factor autograd as v_mfma_f32_16x16x32 tiles
+ *     T = s X down^T,  Gt = s G up    (rank padded to 16, factors and T / Gt split hi + lo: f32-grade results)
+ *     up_part[rb] = T^T G,  down_part[rb] = Gt^T X    (the row-contraction operand = ds_read_b64_tr_b16 transpose reads)
+ * Same partial-slab layout as lora_amd_linear_bwd_factors_self_ragged ([nparts][RT][C], folded by lora_amd_reduce_batched).
+ * The factors arrive packed in MFMA fragment order (lora_amd_factor_pack, one launch per step for all sites).
+ * lds_class: 1 = <= 80 KiB per workgroup (two per CU), 2 = <= 160 KiB (one per CU: the 1280-wide sites); one launch per
+ * class.  Shapes: N, K multiples of 32, rank <= 16; anything else: supported = 0, use the _self_ragged pass. */
+typedef struct lora_amd_factors_mfma_plan_t {
+  int32_t supported, lds_class, rank_tile, rows_per_block, nparts, lds_bytes;
+  int64_t up_part_floats, down_part_floats;
+  int64_t pack_up_elems, pack_down_elems;   /* elements (activation dtype) of the two fragment packs of a site */
+} lora_amd_factors_mfma_plan_t;
+/* rows: 0 = the planner's choice (64, else 32; LORA_AMD_FM_ROWS overrides), else 32 / 64 / 128 tried first */
+int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows,
+                               lora_amd_factors_mfma_plan_t *out);
+/* f32 masters -> fragment packs: pk[split][c/8][16][8] in the activation dtype, split 0 = rounded value, split 1 = the
+ * remainder, ranks >= r zero; pk_down from down [r, K], pk_up from up [N, r].  `begin` is filled by the plan (host). */
+typedef struct lora_amd_pack_site {
+  const float *down, *up;
+  void *pk_down, *pk_up;
+  int32_t N, K, r, reserved;
+  int64_t begin;
+} lora_amd_pack_site;
+int lora_amd_factor_pack_plan(lora_amd_pack_site *sites, int32_t n, int64_t *total);
+int lora_amd_factor_pack(const lora_amd_pack_site *sites_dev, int32_t n, int64_t total, int32_t act_dtype, void *stream);
+typedef struct lora_amd_fm_site {
+  const void *g, *x;              /* [M, N] output gradient, [M, K] input (act_dtype; rows may be head-padded) */
+  const void *pk_up, *pk_down;    /* fragment packs of this step's factors (lora_amd_factor_pack) */
+  float *up_part, *down_part;     /* [nparts][RT][N], [nparts][RT][K] */
+  int64_t ldg, ldx, M;
+  int32_t N, K, r;
+  float scale;
+  int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
+  int32_t rows_per_block;         /* caller: lora_amd_factors_mfma_plan's rows_per_block for this site */
+  /* filled by lora_amd_factors_mfma_ragged_plan */
+  int32_t resident_is_x, cw, nchunk, pitch_a, pitch_b, lds_bytes, reserved;
+  int64_t block_begin;
+} lora_amd_fm_site;
+int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_t act_dtype, int32_t lds_class,
+                                      int64_t *grid);
+int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid, int32_t lds_class,
+                                            int32_t act_dtype, void *stream);
+
 
 /* ------------------------------------------------------------------------
  * K4  LoraInjectedConv2d low-rank branch (lora.py:94-135) and its autograd, NCHW.

@@ -20,7 +20,7 @@ F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
 ROUND_REFERENCE, ROUND_ONCE = 0, 1
 MAX_RANK = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -36,7 +36,8 @@ SYMBOLS = (
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
     "lora_amd_linear_factors_self_ragged_plan", "lora_amd_linear_bwd_factors_self_ragged",
-    "lora_amd_linear_bwd_factors_self_ragged_sub",
+    "lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
+    "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
@@ -73,7 +74,35 @@ class SelfSite(C.Structure):
         ("rows_per_block", C.c_int32), ("nsplit", C.c_int32), ("kt_g", C.c_int32), ("logL_g", C.c_int32),
         ("kt_x", C.c_int32), ("logL_x", C.c_int32), ("tile_g", C.c_int32), ("nct_g", C.c_int32),
         ("tile_x", C.c_int32), ("nct_x", C.c_int32),
-        ("sub_rows", C.c_int32), ("reserved", C.c_int32),
+        ("reserved0", C.c_int32), ("reserved", C.c_int32),
+        ("block_begin", C.c_int64),
+    ]
+
+
+class FactorsMfmaPlan(C.Structure):
+    _fields_ = [("supported", C.c_int32), ("lds_class", C.c_int32), ("rank_tile", C.c_int32),
+                ("rows_per_block", C.c_int32), ("nparts", C.c_int32), ("lds_bytes", C.c_int32),
+                ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64),
+                ("pack_up_elems", C.c_int64), ("pack_down_elems", C.c_int64)]
+
+
+class PackSite(C.Structure):
+    """lora_amd_pack_site: the f32 factors of one adapter -> MFMA fragment packs."""
+    _fields_ = [("down", C.c_void_p), ("up", C.c_void_p), ("pk_down", C.c_void_p), ("pk_up", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("reserved", C.c_int32), ("begin", C.c_int64)]
+
+
+class FmSite(C.Structure):
+    """lora_amd_fm_site: one adapter of the matrix-core factor-gradient pass."""
+    _fields_ = [
+        ("g", C.c_void_p), ("x", C.c_void_p), ("pk_up", C.c_void_p), ("pk_down", C.c_void_p),
+        ("up_part", C.c_void_p), ("down_part", C.c_void_p),
+        ("ldg", C.c_int64), ("ldx", C.c_int64), ("M", C.c_int64),
+        ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("scale", C.c_float),
+        ("g_head_dim", C.c_int32), ("g_head_pad", C.c_int32), ("x_head_dim", C.c_int32), ("x_head_pad", C.c_int32),
+        ("rows_per_block", C.c_int32),
+        ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("pitch_a", C.c_int32),
+        ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32), ("reserved", C.c_int32),
         ("block_begin", C.c_int64),
     ]
 
@@ -214,8 +243,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_factors_self_ragged_plan.argtypes = [vp, i32, i32, C.POINTER(C.c_int64)]
     lib.lora_amd_linear_bwd_factors_self_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_linear_factors_self_ragged_plan.restype = lib.lora_amd_linear_bwd_factors_self_ragged.restype = C.c_int
-    lib.lora_amd_linear_bwd_factors_self_ragged_sub.argtypes = [vp, i32, i64, i32, i32, vp]
-    lib.lora_amd_linear_bwd_factors_self_ragged_sub.restype = C.c_int
+    lib.lora_amd_factors_mfma_plan.argtypes = [i64, i32, i32, i32, i32, i32, C.POINTER(FactorsMfmaPlan)]
+    lib.lora_amd_factor_pack_plan.argtypes = [C.POINTER(PackSite), i32, C.POINTER(i64)]
+    lib.lora_amd_factor_pack.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_factors_mfma_ragged_plan.argtypes = [C.POINTER(FmSite), i32, i32, i32, C.POINTER(i64)]
+    lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
+    for name in ("lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
+                 "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged"):
+        getattr(lib, name).restype = C.c_int
     lib.lora_amd_linear_gemm_fwd_heads.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32,
                                                    f32, f32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_linear_gemm_fwd_heads.restype = C.c_int
@@ -804,23 +839,13 @@ def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor
            "lora_amd_linear_bwd_factors_self")
 
 
-# rows of a sub-block for the experimental sub-block form of the one-launch pass (0 = off, the default)
-SELF_SUB_ROWS = int(os.environ.get("LORA_AMD_SELF_SUBROWS", "0"))
-
-
-def self_sub_ok(N: int, K: int, r: int) -> bool:
-    rt = 4 if r <= 4 else 8 if r <= 8 else 16
-    return SELF_SUB_ROWS >= 8 and rt <= 8 and N <= 2048 and K <= 2048 and rt * (N + K) <= 8192
-
-
-def factors_self_ragged_table(sites, act_dtype: torch.dtype, sub_rows: int = 0):
+def factors_self_ragged_table(sites, act_dtype: torch.dtype):
     """Host half of the one-launch factor-gradient pass: ``sites`` = [(g, x, down, up, up_part, down_part, scale,
     g_heads, x_heads)] (one activation dtype, one rank tile) -> (planned ctypes table, grid)."""
     lib = require()
     arr = (SelfSite * len(sites))()
     for q, (g, x, down, up, up_part, down_part, scale, g_heads, x_heads) in zip(arr, sites):
         q.rows_per_block = SELF_ROWS_DEFERRED
-        q.sub_rows = int(sub_rows)
         q.g, q.x, q.down, q.up = g.data_ptr(), x.data_ptr(), down.data_ptr(), up.data_ptr()
         q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
         q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
@@ -835,15 +860,77 @@ def factors_self_ragged_table(sites, act_dtype: torch.dtype, sub_rows: int = 0):
     return arr, grid.value
 
 
-def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, rank: int, act_dtype: torch.dtype,
-                                   sub: bool = False) -> None:
-    if sub:
-        _check(require().lora_amd_linear_bwd_factors_self_ragged_sub(table_dev.data_ptr(), n, grid, rank,
-                                                                     dtype_code(act_dtype), _stream()),
-               "lora_amd_linear_bwd_factors_self_ragged_sub")
-        return
+def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, rank: int, act_dtype: torch.dtype) -> None:
     _check(require().lora_amd_linear_bwd_factors_self_ragged(table_dev.data_ptr(), n, grid, rank, dtype_code(act_dtype),
                                                              _stream()), "lora_amd_linear_bwd_factors_self_ragged")
+
+
+# ----------------------------------------------------------------------------- the matrix-core factor pass
+# LORA_AMD_FACTORS_MFMA=0: 16-bit sites keep the VALU pass (lora_amd_linear_bwd_factors_self_ragged) — same-box A/B runs
+FACTORS_MFMA = os.environ.get("LORA_AMD_FACTORS_MFMA", "1") != "0"
+_mfma_plan_cache = {}
+
+
+def factors_mfma_plan(M: int, K: int, N: int, r: int, act_dtype: torch.dtype, rows: int = 0) -> FactorsMfmaPlan:
+    """Geometry of a site in the matrix-core factor pass (csrc/factor_mfma.hip): ``supported`` = 0 for f32 activations,
+    N / K not multiples of 32, rank > 16 or a row block that does not fit the LDS."""
+    key = (M, K, N, r, act_dtype, rows)
+    pl = _mfma_plan_cache.get(key)
+    if pl is None:
+        pl = FactorsMfmaPlan()
+        if act_dtype in (torch.float16, torch.bfloat16):
+            _check(require().lora_amd_factors_mfma_plan(M, K, N, r, dtype_code(act_dtype), rows, C.byref(pl)),
+                   "lora_amd_factors_mfma_plan")
+        _mfma_plan_cache[key] = pl
+    return pl
+
+
+def factor_pack_table(sites):
+    """``sites`` = [(down f32 [r, K], up f32 [N, r], pk_down, pk_up)] -> (planned ctypes table, total work items)."""
+    arr = (PackSite * len(sites))()
+    for q, (down, up, pk_down, pk_up) in zip(arr, sites):
+        if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
+            raise ValueError("factor_pack: contiguous f32 factors expected")
+        q.down, q.up, q.pk_down, q.pk_up = down.data_ptr(), up.data_ptr(), pk_down.data_ptr(), pk_up.data_ptr()
+        q.N, q.K, q.r = up.shape[0], down.shape[1], down.shape[0]
+    total = C.c_int64(0)
+    _check(require().lora_amd_factor_pack_plan(arr, len(sites), C.byref(total)), "lora_amd_factor_pack_plan")
+    return arr, total.value
+
+
+def factor_pack(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dtype) -> None:
+    _check(require().lora_amd_factor_pack(table_dev.data_ptr(), n, total, dtype_code(act_dtype), _stream()),
+           "lora_amd_factor_pack")
+
+
+def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
+    """Host half of the matrix-core pass: ``sites`` = [(g, x, pk_down, pk_up, up_part, down_part, scale, g_heads,
+    x_heads, r, rows_per_block)] of one LDS class and rank tile -> (planned ctypes table, grid)."""
+    arr = (FmSite * len(sites))()
+    for q, (g, x, pk_down, pk_up, up_part, down_part, scale, g_heads, x_heads, r, rows) in zip(arr, sites):
+        q.g, q.x, q.pk_down, q.pk_up = g.data_ptr(), x.data_ptr(), pk_down.data_ptr(), pk_up.data_ptr()
+        q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
+        q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
+        q.N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
+        q.K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+        q.r, q.scale, q.rows_per_block = int(r), float(scale), int(rows)
+        q.g_head_dim, q.g_head_pad = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
+        q.x_head_dim, q.x_head_pad = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    grid = C.c_int64(0)
+    _check(require().lora_amd_factors_mfma_ragged_plan(arr, len(sites), dtype_code(act_dtype), lds_class, C.byref(grid)),
+           "lora_amd_factors_mfma_ragged_plan")
+    return arr, grid.value
+
+
+def linear_bwd_factors_mfma_ragged(table_dev: torch.Tensor, n: int, grid: int, lds_class: int,
+                                   act_dtype: torch.dtype) -> None:
+    _check(require().lora_amd_linear_bwd_factors_mfma_ragged(table_dev.data_ptr(), n, grid, lds_class,
+                                                             dtype_code(act_dtype), _stream()),
+           "lora_amd_linear_bwd_factors_mfma_ragged")
+
+
+def table_to_device(arr, device) -> torch.Tensor:
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
 def make_reduce_table(rows: Sequence[Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, float, float]],

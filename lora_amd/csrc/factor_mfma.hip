@@ -1,0 +1,519 @@
+// K2 on the merged-weight path, matrix-core form: both factor gradients of every Linear adapter in one launch, each
+// row of G and X read from HBM exactly ONCE.
+//
+// replaces: the autograd of lora_diffusion/lora.py:53-58 for lora_up.weight / lora_down.weight
+//           (dUp = s G^T (X down^T), dDown = (s G up)^T X) when the forward ran on W + s up down (ops.MergedWeights),
+//           and csrc/linear_fused.hip's linear_bwd_factors_self_ragged_kernel for 16-bit activations: that VALU pass
+//           reads every row block twice (row-dot phase, column-sum phase; the second read misses the L2: FETCH_SIZE
+//           2.0x algorithmic, 0.25 of the byte roof).
+//
+// One workgroup (4 waves) owns R rows of one site.  With A = the narrower of (X, G) and B = the wider one, fa / fb the
+// factor contracted against A's / B's columns (A = X: fa = down, fb = up):
+//
+//     TA = s A fa^T [R, r]        outB[j, c] = sum_m TA[m, j] B[m, c]       (A = X: T,  outB = dUp partial)
+//     TB = s B fb^T [R, r]        outA[j, c] = sum_m TB[m, j] A[m, c]       (        Gt, outA = dDown partial)
+//
+//   * A's row block [R, Ca] stays RESIDENT in LDS (160 KiB per CU on gfx950: 64 rows x 320 columns = 42 KB, two
+//     workgroups per CU; the 1280-wide sites take one workgroup per CU), B streams through a second LDS buffer in column
+//     chunks [R, CW]: chunk c + 1 is in flight (registers) while chunk c is consumed.  Per chunk: TB accumulates
+//     (phase 1) and outB's columns of the chunk are finished and stored (phase 2, TA is complete by then); after the
+//     last chunk TB is complete and outA is computed from the resident block.  Nothing is read twice.
+//   * both phases are v_mfma_f32_16x16x32 (the rank padded to the 16 of the tile):
+//       phase 1  D[row, j]  += Data[row, 32 cols] . F[j, 32 cols]^T      A-operand = ds_read_b128 of a row, B-operand = a
+//                packed factor fragment (lora_amd_factor_pack: 1 KB coalesced per wave, L2-resident);
+//       phase 2  D[col, j]  += Data^T[col, 32 rows] . T[32 rows, j]      A-operand = two ds_read_b64_tr_b16 (the LDS
+//                transpose read of gfx950: the row-major tile delivered column-major), B-operand = T from LDS.
+//     f32 precision is kept by splitting every 16-bit operand that is not data: factor = hi + lo, T = hi + lo (two MFMAs
+//     into the same accumulator) — the matrix pipe is < 20 % busy at the HBM rate, so the split is free.
+//   * phase 1 is split over the waves by k-step (each packed fragment is fetched by ONE wave and reused for all R / 16
+//     row tiles); the four partial [R, 16] blocks meet once in LDS.
+//   * LDS rows are padded to pitch = 32 (mod 64) bytes: the ds_read_b128 of 16 rows and the transpose reads of 8 rows
+//     x 32 B are both bank-conflict-free (scripts/lds_banks.py checks the lane groups of the microarchitecture guide).
+// Algorithmic bytes per site: M (N + K) e (G and X once) + the partial slabs 2 RT 4 (N + K) M / R (written here, read by
+// lora_amd_reduce_batched).  HBM-bound: 4 MFMA per KB against ~90 cycles per KB per CU.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace lora_amd {
+
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mu32x2 __attribute__((ext_vector_type(2)));
+typedef short ms16x4 __attribute__((ext_vector_type(4)));
+
+template <class E> struct FmMfma;
+template <> struct FmMfma<bf16_t> {
+  typedef __bf16 frag __attribute__((ext_vector_type(8)));
+  __device__ static mf32x4 mma(frag a, frag b, mf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct FmMfma<f16_t> {
+  typedef _Float16 frag __attribute__((ext_vector_type(8)));
+  __device__ static mf32x4 mma(frag a, frag b, mf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <class E>
+__device__ __forceinline__ typename FmMfma<E>::frag fm_frag(mu32x4 v) {
+  union { typename FmMfma<E>::frag f; mu32x4 u; } c;
+  c.u = v;
+  return c.f;
+}
+
+constexpr int kFmThreads = 256;   // 4 waves
+constexpr int kFmNPA = 8;         // 16-byte pieces per thread and batch of the resident block's loads
+constexpr int kFmNPB = 8;         // ... of one streamed chunk (R * CW <= 16384 elements)
+constexpr int kFmMaxRT16 = 4;     // row tiles of 16 per block (R <= 64)
+constexpr int kFmLdsSmall = 81920, kFmLdsLarge = 163840;  // two workgroups per CU / one
+
+__host__ __device__ inline int fm_pitch(int cols) {  // bytes; smallest p >= 2 cols with p % 64 == 32
+  const int b = cols * 2;
+  return ((b + 31) / 64) * 64 + 32;
+}
+__host__ __device__ inline int fm_tpitch(int R) { return R * 2 + 16; }
+
+__device__ __forceinline__ int fm_hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
+
+// ---------------------------------------------------------------------------------------------------------- factor pack
+// f32 masters -> MFMA fragment order in the activation dtype, hi and lo parts:
+//   pk[split][c8][jj][e] = part_split(factor(jj, c8 * 8 + e))   jj < r, else 0;   16 x 8 elements = 256 B per c8
+// factor(jj, c) = down[jj, c] (FACTOR_RK) or up[c, jj] (FACTOR_KR).  A k-step's fragment (4 consecutive c8) is 1 KB
+// contiguous and lane l reads its 16 bytes at l * 16.
+template <class E>
+__global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_site *__restrict__ sites, int n, int64_t total) {
+  using S = typename E::storage;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sites[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const lora_amd_pack_site q = sites[lo];
+    int64_t p = i - q.begin;                 // piece = (side, c8, jj): down side first
+    const int64_t nd = (int64_t)(q.K >> 3) * 16;
+    const bool is_up = p >= nd;
+    if (is_up) p -= nd;
+    const int c8 = (int)(p >> 4), jj = (int)(p & 15);
+    const int C = is_up ? q.N : q.K;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (jj < q.r) {
+      if (is_up) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = q.up[(int64_t)(c8 * 8 + e) * q.r + jj];
+      } else {
+        const float *src = q.down + (int64_t)jj * C + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e];
+      }
+    }
+    Chunk8<E> h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h.v[e] = E::from_f(v[e]);
+      l.v[e] = E::from_f(v[e] - E::to_f(h.v[e]));
+    }
+    S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
+    const int64_t split_stride = (int64_t)(C >> 3) * 128;  // elements per split
+    *reinterpret_cast<Chunk8<E> *>(dst + ((int64_t)c8 * 16 + jj) * 8) = h;
+    *reinterpret_cast<Chunk8<E> *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8) = l;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- the pass
+template <class E, int NP>
+struct FmStage { mu32x4 v[NP]; };
+
+// Pieces (16 bytes) of a [R, c8w] tile, row-major, dealt to the threads with stride 256: piece p0 + tid + i * 256 is
+// (row, c).  One division per tile instead of one per piece.
+struct FmPieces {
+  int row, c, dr, dc, c8w;
+  __device__ __forceinline__ FmPieces(int p0, int c8w_) : c8w(c8w_) {
+    const int p = p0 + threadIdx.x;
+    row = p / c8w; c = p - row * c8w;
+    dr = kFmThreads / c8w; dc = kFmThreads - dr * c8w;
+  }
+  __device__ __forceinline__ void next() {
+    row += dr; c += dc;
+    if (c >= c8w) { c -= c8w; ++row; }
+  }
+};
+
+// Issue the loads of a thread's pieces of the tile whose first column chunk is c8_0 — all in flight.  Rows past the end
+// of the matrix (and pieces past the end of the tile) read a valid address and are zeroed.
+template <class E, int NP>
+__device__ __forceinline__ void fm_issue(FmStage<E, NP> &st, const typename E::storage *data, int64_t ld, int64_t m0,
+                                         int nrows, int p0, int c8w, int c8_0, int hc, int hp) {
+  FmPieces it(p0, c8w);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const bool ok = it.row < nrows;
+    const typename E::storage *src = data + (m0 + (ok ? it.row : 0)) * ld + (int64_t)fm_hchunk(c8_0 + it.c, hc, hp) * 8;
+    const mu32x4 v = *reinterpret_cast<const mu32x4 *>(src);
+    st.v[i] = ok ? v : mu32x4{0u, 0u, 0u, 0u};
+    it.next();
+  }
+}
+template <class E, int NP>
+__device__ __forceinline__ void fm_write(const FmStage<E, NP> &st, unsigned char *buf, int pitch, int R, int p0, int c8w) {
+  FmPieces it(p0, c8w);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (it.row < R) *reinterpret_cast<mu32x4 *>(buf + it.row * pitch + it.c * 16) = st.v[i];
+    it.next();
+  }
+}
+
+// phase 1 of one tile [R, ncols] in LDS: acc[t] += Data[tile t rows, k-step] . (hi + lo of the packed factor), for the
+// k-steps ks = wave, wave + 4, ... of the tile.  `pk` points at the fragment of the tile's first column (split 0),
+// `split_stride` = elements between the hi and the lo pack.
+template <class E>
+__device__ __forceinline__ void fm_phase1(mf32x4 (&acc)[kFmMaxRT16], const unsigned char *buf, int pitch, int nrt, int nks,
+                                          const typename E::storage *pk, int64_t split_stride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned char *rowp = buf + (lane & 15) * pitch + (lane >> 4) * 16;
+  if (wave >= nks) return;
+  mu32x4 fh = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)wave * 512 + lane * 8);
+  mu32x4 fl = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)wave * 512 + lane * 8);
+#pragma unroll 1
+  for (int ks = wave; ks < nks; ks += 4) {
+    const int kn = ks + 4 < nks ? ks + 4 : ks;  // next fragment in flight while this one is used
+    const mu32x4 nh = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)kn * 512 + lane * 8);
+    const mu32x4 nl = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kn * 512 + lane * 8);
+    const typename FmMfma<E>::frag bh = fm_frag<E>(fh), bl = fm_frag<E>(fl);
+#pragma unroll
+    for (int t = 0; t < kFmMaxRT16; ++t) {
+      if (t < nrt) {
+        const typename FmMfma<E>::frag a =
+            fm_frag<E>(*reinterpret_cast<const mu32x4 *>(rowp + t * 16 * pitch + ks * 64));
+        acc[t] = FmMfma<E>::mma(a, bh, acc[t]);
+        acc[t] = FmMfma<E>::mma(a, bl, acc[t]);
+      }
+    }
+    fh = nh; fl = nl;
+  }
+}
+
+// The four waves' partial [R, 16] blocks -> T = s * sum, split hi / lo, stored [split][jj][position] so that phase 2
+// reads a lane's 8 contraction rows with one 16-byte load.  Position of row ro (0..31) inside its 32-row k-step:
+//   ro < 16: 8 (ro / 4) + ro % 4        ro >= 16: 8 ((ro - 16) / 4) + 4 + ro % 4
+// (the rows a transpose read hands to lane group q: 4q..4q+3 with the first read, 16+4q..16+4q+3 with the second).
+template <class E>
+__device__ __forceinline__ void fm_combine(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, unsigned char *tt, int nrt,
+                                           int R, float scale) {
+  using S = typename E::storage;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < kFmMaxRT16; ++t) {
+    if (t < nrt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) scratch[((wave * nrt + t) * 4 + g) * 64 + lane] = acc[t][g];
+    }
+  }
+  __syncthreads();
+  const int tp = fm_tpitch(R);
+  for (int t = wave; t < nrt; t += 4) {
+    union { S s[4]; mu32x2 u; } h, l;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += scratch[((w * nrt + t) * 4 + g) * 64 + lane];
+      v *= scale;
+      h.s[g] = E::from_f(v);
+      l.s[g] = E::from_f(v - E::to_f(h.s[g]));
+    }
+    const int jj = lane & 15, q = lane >> 4;
+    const int pos = (t >> 1) * 32 + 8 * q + 4 * (t & 1);
+    *reinterpret_cast<mu32x2 *>(tt + jj * tp + pos * 2) = h.u;
+    *reinterpret_cast<mu32x2 *>(tt + (16 + jj) * tp + pos * 2) = l.u;
+  }
+}
+
+// 8 contraction rows x 1 column of a row-major LDS tile as an MFMA operand: lane (q = lane / 16, i = lane % 16) gets
+// rows {32 ks + 4q + e, e < 4} and {32 ks + 16 + 4q + e} of column c0 + i.  TR: two ds_read_b64_tr_b16 (each 16-lane
+// group reads a [4 rows][16 columns] block; lane s of the group supplies the address of row s / 4, columns 4 (s % 4) ..).
+template <class E, bool TR>
+__device__ __forceinline__ typename FmMfma<E>::frag fm_colfrag(const unsigned char *buf, int pitch, int ks, int c0) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
+  if constexpr (TR) {
+    const unsigned char *p = buf + (ks * 32 + 4 * q + (i >> 2)) * pitch + (c0 + 4 * (i & 3)) * 2;
+    union { ms16x4 h[2]; mu32x4 u; } r;
+    r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p));
+    r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p + 16 * pitch));
+    return fm_frag<E>(r.u);
+  } else {
+    union { unsigned short s[8]; mu32x4 u; } r;
+    const unsigned char *p = buf + (ks * 32 + 4 * q) * pitch + (c0 + i) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r.s[e] = *reinterpret_cast<const unsigned short *>(p + e * pitch);
+      r.s[4 + e] = *reinterpret_cast<const unsigned short *>(p + (16 + e) * pitch);
+    }
+    return fm_frag<E>(r.u);
+  }
+}
+
+// phase 2 of one tile [R, ncols] in LDS: out[jj][col0 + c] = sum_rows T[row, jj] Data[row, c] for the tile's columns;
+// column tiles of 16 are dealt to the waves.  `tf` = the T fragments (hi, lo per 32-row k-step) in registers.
+template <class E, bool TR>
+__device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, int nk2, int ncols,
+                                          const mu32x4 (&tf)[kFmMaxRT16], float *out, int64_t ldo, int RT) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jj = lane & 15, q = lane >> 4;
+  const int nct = ncols >> 4;
+#pragma unroll 1
+  for (int ct = wave; ct < nct; ct += 4) {
+    mf32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
+      if (k2 < nk2) {
+        const typename FmMfma<E>::frag a = fm_colfrag<E, TR>(buf, pitch, k2, ct * 16);
+        d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2]), d);
+        d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2 + 1]), d);
+      }
+    }
+    if (jj < RT) *reinterpret_cast<mf32x4 *>(out + jj * ldo + ct * 16 + 4 * q) = d;
+  }
+}
+
+template <class E>
+__device__ __forceinline__ void fm_load_tfrags(mu32x4 (&tf)[kFmMaxRT16], const unsigned char *tt, int R, int nk2) {
+  const int lane = threadIdx.x & 63, jj = lane & 15, q = lane >> 4;
+  const int tp = fm_tpitch(R);
+#pragma unroll
+  for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
+    if (k2 < nk2) {
+      tf[2 * k2] = *reinterpret_cast<const mu32x4 *>(tt + jj * tp + (k2 * 32 + 8 * q) * 2);
+      tf[2 * k2 + 1] = *reinterpret_cast<const mu32x4 *>(tt + (16 + jj) * tp + (k2 * 32 + 8 * q) * 2);
+    }
+  }
+}
+
+template <class E, int LDSB, bool TR>
+__global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfma_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+  using S = typename E::storage;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_fm_site q = sites[lo];
+  const int64_t rb = (int64_t)blockIdx.x - q.block_begin;
+  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
+  const int64_t m0 = rb * R;
+  const int nrows = (int)min((int64_t)R, q.M - m0);
+  const bool ax = q.resident_is_x != 0;
+  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
+  // A = resident operand, B = streamed operand
+  const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
+  const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
+  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
+  const int hca = (ax ? q.x_head_dim : q.g_head_dim) >> 3, hpa = (ax ? q.x_head_pad : q.g_head_pad) >> 3;
+  const int hcb = (ax ? q.g_head_dim : q.x_head_dim) >> 3, hpb = (ax ? q.g_head_pad : q.x_head_pad) >> 3;
+  const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
+  float *outa = (ax ? q.down_part : q.up_part) + rb * RT * (int64_t)Ca;   // = TB^T A
+  float *outb = (ax ? q.up_part : q.down_part) + rb * RT * (int64_t)Cb;   // = TA^T B
+  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
+  unsigned char *bufA = lds, *bufB = bufA + R * pa;
+  unsigned char *ttA = bufB + R * pb, *ttB = ttA + 32 * fm_tpitch(R);
+  float *scratch = reinterpret_cast<float *>(bufB);  // [4 waves][nrt][4][64] f32 <= R * pitch_b (planner)
+
+  // ---- resident block and the first chunk of B: everything in flight before the first wait
+  FmStage<E, kFmNPA> sa;
+  FmStage<E, kFmNPB> sb;
+  const int c8a = Ca >> 3, totalA = R * c8a;
+  const int cw0 = min(CW, Cb);
+  fm_issue<E, kFmNPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hca, hpa);
+  fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hcb, hpb);
+  fm_write<E, kFmNPA>(sa, bufA, pa, R, 0, c8a);
+  for (int p0 = kFmThreads * kFmNPA; p0 < totalA; p0 += kFmThreads * kFmNPA) {
+    fm_issue<E, kFmNPA>(sa, da, lda, m0, nrows, p0, c8a, 0, hca, hpa);
+    fm_write<E, kFmNPA>(sa, bufA, pa, R, p0, c8a);
+  }
+  __syncthreads();
+  // ---- TA
+  mf32x4 acc[kFmMaxRT16];
+#pragma unroll
+  for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, (int64_t)c8a * 128);
+  fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale);
+  __syncthreads();  // TA visible; the scratch (= chunk buffer) is free
+  mu32x4 tf[kFmMaxRT16];
+  fm_load_tfrags<E>(tf, ttA, R, nk2);
+  // ---- B in column chunks
+#pragma unroll
+  for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t splitb = (int64_t)(Cb >> 3) * 128;
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const int col0 = c * CW, cw = min(CW, Cb - col0);
+    fm_write<E, kFmNPB>(sb, bufB, pb, R, 0, cw >> 3);
+    __syncthreads();
+    if (c + 1 < nch) {
+      const int col1 = col0 + CW, cw1 = min(CW, Cb - col1);
+      fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hcb, hpb);
+    }
+    fm_phase1<E>(acc, bufB, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb);
+    fm_phase2<E, TR>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT);
+    __syncthreads();  // the chunk buffer is free
+  }
+  // ---- TB, then the resident block's column sums
+  fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale);
+  __syncthreads();
+  fm_load_tfrags<E>(tf, ttB, R, nk2);
+  fm_phase2<E, TR>(bufA, pa, nk2, Ca, tf, outa, Ca, RT);
+}
+
+// ---------------------------------------------------------------------------------------------------------- host side
+struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
+
+// Geometry of a site at R rows per block inside `lds_cap` bytes of LDS: the widest chunk of B that fits.
+static bool fm_fit(int64_t M, int K, int N, int r, int act_dtype, int R, int lds_cap, FmGeom *g) {
+  if (act_dtype == LORA_AMD_F32 || M <= 0 || r < 1 || r > 16 || K % 32 || N % 32 || K < 32 || N < 32) return false;
+  if (R != 32 && R != 64) return false;
+  g->resident_is_x = K <= N;
+  const int Ca = std::min(K, N), Cb = std::max(K, N);
+  g->pitch_a = fm_pitch(Ca);
+  const int fixed = R * g->pitch_a + 2 * 32 * fm_tpitch(R);
+  // pieces per thread <= kFmNPB; the chunk buffer also holds the [4][R/16][4][64] f32 scratch of the phase-1 combine
+  for (int cwmax = std::min(kFmNPB * kFmThreads * 8 / R, 512); cwmax >= 32; cwmax -= 32) {
+    const int nch = (Cb + cwmax - 1) / cwmax;
+    const int cw = std::min(((Cb + nch - 1) / nch + 31) / 32 * 32, cwmax);
+    const int pb = std::max(fm_pitch(cw), 288);  // >= 256: the chunk buffer doubles as the combine scratch
+    if (fixed + R * pb > lds_cap) continue;
+    g->R = R; g->cw = cw; g->nchunk = (Cb + cw - 1) / cw; g->pitch_b = pb; g->lds = fixed + R * pb;
+    return true;
+  }
+  return false;
+}
+
+// rows per block and LDS class (1: two workgroups per CU, 2: one) of a site.  A caller's / LORA_AMD_FM_ROWS' row count is
+// tried first in both classes; default: 64 rows, then 32, two workgroups per CU before one.
+static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, FmGeom *g, int *cls) {
+  const int caps[2] = {kFmLdsSmall, kFmLdsLarge};
+  if (hint > 0)
+    for (int c = 0; c < 2; ++c)
+      if (fm_fit(M, K, N, r, act_dtype, hint, caps[c], g)) { *cls = c + 1; return true; }
+  for (int c = 0; c < 2; ++c)
+    for (int R = 64; R >= 32; R >>= 1)
+      if (fm_fit(M, K, N, r, act_dtype, R, caps[c], g)) { *cls = c + 1; return true; }
+  return false;
+}
+
+static int fm_rows_env() {
+  static const int v = getenv("LORA_AMD_FM_ROWS") ? atoi(getenv("LORA_AMD_FM_ROWS")) : 0;
+  return v;
+}
+
+}  // namespace lora_amd
+
+using namespace lora_amd;
+
+extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows,
+                                          lora_amd_factors_mfma_plan_t *out) {
+  LORA_AMD_CHECK(out != nullptr && rows >= 0 && dtype_ok(act_dtype), LORA_AMD_EINVAL, "factors_mfma_plan: bad argument");
+  memset(out, 0, sizeof(*out));
+  FmGeom g;
+  int cls = 0;
+  if (!fm_choose(M, K, N, r, act_dtype, rows > 0 ? rows : fm_rows_env(), &g, &cls)) return LORA_AMD_OK;
+  out->supported = 1;
+  out->lds_class = cls;
+  out->rank_tile = r <= 4 ? 4 : r <= 8 ? 8 : 16;
+  out->rows_per_block = g.R;
+  out->nparts = (int32_t)((M + g.R - 1) / g.R);
+  out->lds_bytes = g.lds;
+  out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
+  out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
+  out->pack_up_elems = (int64_t)N * 32;    // [2][N/8][16][8]
+  out->pack_down_elems = (int64_t)K * 32;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_factor_pack_plan(lora_amd_pack_site *sites, int32_t n, int64_t *total) {
+  LORA_AMD_CHECK(sites && n >= 1 && total, LORA_AMD_EINVAL, "factor_pack_plan: bad argument");
+  int64_t begin = 0;
+  for (int i = 0; i < n; ++i) {
+    lora_amd_pack_site &q = sites[i];
+    LORA_AMD_CHECK(q.down && q.up && q.pk_down && q.pk_up, LORA_AMD_EINVAL, "factor_pack_plan: site %d: null pointer", i);
+    LORA_AMD_CHECK(q.r >= 1 && q.r <= 16, LORA_AMD_ERANK, "factor_pack_plan: site %d: rank %d outside [1,16]", i, q.r);
+    LORA_AMD_CHECK(q.N >= 32 && q.K >= 32 && q.N % 32 == 0 && q.K % 32 == 0 && ((uintptr_t)q.pk_down % 16) == 0 &&
+                       ((uintptr_t)q.pk_up % 16) == 0,
+                   LORA_AMD_EINVAL, "factor_pack_plan: site %d: N, K must be multiples of 32, packs 16-byte aligned", i);
+    q.begin = begin;
+    begin += (int64_t)((q.N + q.K) >> 3) * 16;
+  }
+  *total = begin;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_factor_pack(const lora_amd_pack_site *sites_dev, int32_t n, int64_t total, int32_t act_dtype,
+                                    void *stream) {
+  LORA_AMD_CHECK(sites_dev && n >= 1 && total >= 1, LORA_AMD_EINVAL, "factor_pack: bad argument");
+  LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
+                 "factor_pack: the matrix-core factor pass takes f16 / bf16 activations");
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (act_dtype == LORA_AMD_F16) hipLaunchKernelGGL(factor_pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
+  else hipLaunchKernelGGL(factor_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
+  return check_launch("lora_amd_factor_pack");
+}
+
+extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_t act_dtype, int32_t lds_class,
+                                                 int64_t *grid) {
+  LORA_AMD_CHECK(sites && n >= 1 && grid && (lds_class == 1 || lds_class == 2), LORA_AMD_EINVAL,
+                 "factors_mfma_ragged_plan: bad argument");
+  LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
+                 "factors_mfma_ragged_plan: f16 / bf16 activations only");
+  auto heads_ok = [](int d, int D, int cols, int64_t ld) {
+    return d == 0 || (d > 0 && D >= d && d % 8 == 0 && D % 8 == 0 && cols % d == 0 && ld >= (int64_t)(cols / d) * D);
+  };
+  int64_t begin = 0;
+  const int rt0 = sites[0].r <= 4 ? 4 : sites[0].r <= 8 ? 8 : 16;
+  for (int i = 0; i < n; ++i) {
+    lora_amd_fm_site &q = sites[i];
+    FmGeom g;
+    LORA_AMD_CHECK(q.r >= 1 && q.r <= 16 && (q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16) == rt0, LORA_AMD_ERANK,
+                   "factors_mfma_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
+    LORA_AMD_CHECK(q.g && q.x && q.pk_up && q.pk_down && q.up_part && q.down_part, LORA_AMD_EINVAL,
+                   "factors_mfma_ragged_plan: site %d: null pointer", i);
+    const bool ok = fm_fit(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, lds_class == 1 ? kFmLdsSmall : kFmLdsLarge, &g);
+    LORA_AMD_CHECK(ok && ((uintptr_t)q.g % 16) == 0 && ((uintptr_t)q.x % 16) == 0 && q.ldg % 8 == 0 && q.ldx % 8 == 0 &&
+                       ((uintptr_t)q.pk_up % 16) == 0 && ((uintptr_t)q.pk_down % 16) == 0 &&
+                       heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
+                   LORA_AMD_EINVAL, "factors_mfma_ragged_plan: site %d: shape / alignment / head layout / LDS class not supported", i);
+    q.rows_per_block = g.R; q.resident_is_x = g.resident_is_x; q.cw = g.cw; q.nchunk = g.nchunk;
+    q.pitch_a = g.pitch_a; q.pitch_b = g.pitch_b; q.lds_bytes = g.lds; q.reserved = 0;
+    q.block_begin = begin;
+    begin += (q.M + g.R - 1) / g.R;
+  }
+  LORA_AMD_CHECK(begin < (1ll << 31), LORA_AMD_EINVAL, "factors_mfma_ragged_plan: too many blocks");
+  *grid = begin;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
+                                                       int32_t lds_class, int32_t act_dtype, void *stream) {
+  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
+                 LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
+  LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
+                 "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
+  hipStream_t st = (hipStream_t)stream;
+  // LORA_AMD_FM_GATHER=1: the column operand of phase 2 gathered with 2-byte LDS reads instead of the transpose read
+  const bool gather = getenv("LORA_AMD_FM_GATHER") && atoi(getenv("LORA_AMD_FM_GATHER")) == 1;  // read per launch (tests flip it)
+#define FM(E, L)                                                                                                      \
+  do {                                                                                                                \
+    if (gather) hipLaunchKernelGGL((factors_mfma_kernel<E, L, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    else hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+  } while (0)
+  if (act_dtype == LORA_AMD_F16) {
+    if (lds_class == 1) FM(f16_t, kFmLdsSmall); else FM(f16_t, kFmLdsLarge);
+  } else {
+    if (lds_class == 1) FM(bf16_t, kFmLdsSmall); else FM(bf16_t, kFmLdsLarge);
+  }
+#undef FM
+  return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
+}
+

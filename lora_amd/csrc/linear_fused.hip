@@ -639,7 +639,6 @@ struct SelfArgs {
   int ghc, ghp, xhc, xhp;          // head-padded rows (16-byte chunks per head: logical, physical); 0 = dense
   int kt_g, logL_g, kt_x, logL_x;  // phase A: factor columns per LDS stage, lanes per row (log2)
   int tile_g, nct_g, tile_x, nct_x;  // phase B: 16-byte chunks per column tile (<= 256), number of tiles
-  int sub_rows;                    // > 0: sub-block mode (see factors_self_subblocks)
 };
 
 __device__ __forceinline__ int hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
@@ -792,89 +791,6 @@ __device__ __forceinline__ void block_colsums(float *s_red, const float *s_vec, 
   colsum_finish<RT>(s_red, acc, C, c0, tc8, part);
 }
 
-// Row dots of a few rows against a factor slab that is ALREADY in LDS (whole row: c8 = C / 8 chunks); no barrier inside.
-template <class E, int RT, int U>
-__device__ __forceinline__ void rowdots_staged(const float *s_f, float *s_out, const typename E::storage *data, int64_t ld,
-                                               int64_t m0, int nrows, int C, int logL, float mult, int hc, int hp) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = 1 << logL, G = 64 >> logL;
-  const int l = lane & (L - 1), g = lane >> logL;
-  const int rows_iter = G * (kFT / 64), c8 = C >> 3;
-#pragma unroll 1
-  for (int rl = wave * G + g; rl < nrows; rl += rows_iter) {
-    float acc[RT];
-#pragma unroll
-    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
-    const typename E::storage *xr = data + (m0 + rl) * ld;
-#pragma unroll 1
-    for (int cb = l; cb < c8; cb += L * U) {
-      float xv[U][8];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int cc = cb + u * L;
-        load8_sel<E>(xr + hchunk(cc < c8 ? cc : cb, hc, hp) * 8, cc < c8, xv[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int cc = cb + u * L;
-        if (cc >= c8) continue;
-#pragma unroll
-        for (int j = 0; j < RT; ++j) {
-          const float4 d0 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 0) * c8 + cc) * 4]);
-          const float4 d1 = *reinterpret_cast<const float4 *>(&s_f[((j * 2 + 1) * c8 + cc) * 4]);
-          float a = acc[j];
-          a = fmaf(xv[u][0], d0.x, a); a = fmaf(xv[u][1], d0.y, a); a = fmaf(xv[u][2], d0.z, a);
-          a = fmaf(xv[u][3], d0.w, a); a = fmaf(xv[u][4], d1.x, a); a = fmaf(xv[u][5], d1.y, a);
-          a = fmaf(xv[u][6], d1.z, a); a = fmaf(xv[u][7], d1.w, a);
-          acc[j] = a;
-        }
-      }
-    }
-    for (int off = L >> 1; off > 0; off >>= 1)
-#pragma unroll
-      for (int j = 0; j < RT; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-    if (l == 0) {
-#pragma unroll
-      for (int j = 0; j < RT; ++j) s_out[rl * RT + j] = acc[j] * mult;
-    }
-  }
-}
-
-// Sub-block mode of the factor pass (sites whose two factor slabs fit the 32 KiB work buffer together and whose rows are one
-// column tile each: N, K <= 2048 and RT (N + K) <= 8192): the block's rows are walked in sub-blocks of `sub_rows` rows —
-// row dots, then column sums of the SAME rows while they are still in the L2 (a sub-block is 16 x (N + K) x 2 B = 20 KB at
-// a 320-wide site; a whole 128-row block is 164 KB and its second read misses the L2: 2.0x algorithmic fetches) — with the
-// column accumulators kept in registers across the sub-blocks: one slot reduction and one partial slab per block, as before.
-template <class E, int RT, int U>
-__device__ __forceinline__ void factors_self_subblocks(const SelfArgs &a, int64_t rb, float *s_buf, float *s_t, float *s_gt) {
-  using S = typename E::storage;
-  const S *g = reinterpret_cast<const S *>(a.g), *x = reinterpret_cast<const S *>(a.x);
-  const int64_t m0 = rb * a.rows_per_block;
-  const int nrows = (int)min((int64_t)a.rows_per_block, a.M - m0);
-  float *s_fx = s_buf, *s_fg = s_buf + RT * a.K;
-  stage_factor<RT>(s_fx, a.down, LORA_AMD_F32, LORA_AMD_FACTOR_RK, a.r, a.K, 0, a.K);
-  stage_factor<RT>(s_fg, a.up, LORA_AMD_F32, LORA_AMD_FACTOR_KR, a.r, a.N, 0, a.N);
-  __syncthreads();
-  const int c8g = a.N >> 3, c8x = a.K >> 3;
-  float acc_g[RT][8], acc_x[RT][8];
-#pragma unroll
-  for (int j = 0; j < RT; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc_g[j][i] = acc_x[j][i] = 0.f;
-#pragma unroll 1
-  for (int sb0 = 0; sb0 < nrows; sb0 += a.sub_rows) {
-    const int nsb = min(a.sub_rows, nrows - sb0);
-    rowdots_staged<E, RT, U>(s_fx, s_t, x, a.ldx, m0 + sb0, nsb, a.K, a.logL_x, a.scale, a.xhc, a.xhp);
-    rowdots_staged<E, RT, U>(s_fg, s_gt, g, a.ldg, m0 + sb0, nsb, a.N, a.logL_g, a.scale, a.ghc, a.ghp);
-    __syncthreads();
-    colsum_acc<E, RT, U>(acc_g, s_t, g, a.ldg, m0 + sb0, nsb, 0, c8g, a.ghc, a.ghp);
-    colsum_acc<E, RT, U>(acc_x, s_gt, x, a.ldx, m0 + sb0, nsb, 0, c8x, a.xhc, a.xhp);
-    __syncthreads();  // the next sub-block rewrites the row vectors; after the last one: the factor slabs may be overwritten
-  }
-  colsum_finish<RT>(s_buf, acc_g, a.N, 0, c8g, a.up_part + rb * RT * (int64_t)a.N);
-  colsum_finish<RT>(s_buf, acc_x, a.K, 0, c8x, a.down_part + rb * RT * (int64_t)a.K);
-}
-
 template <class E, int RT, int U = 4>
 __device__ __forceinline__ void factors_self_body(const SelfArgs &a, int64_t bid) {
   // phase A stages the factor slab, phase B reduces row slots: never live together
@@ -936,33 +852,7 @@ __global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_kernel(con
   a.ghc = q.g_head_dim >> 3; a.ghp = q.g_head_pad >> 3; a.xhc = q.x_head_dim >> 3; a.xhp = q.x_head_pad >> 3;
   a.kt_g = q.kt_g; a.logL_g = q.logL_g; a.kt_x = q.kt_x; a.logL_x = q.logL_x;
   a.tile_g = q.tile_g; a.nct_g = q.nct_g; a.tile_x = q.tile_x; a.nct_x = q.nct_x;
-  a.sub_rows = q.sub_rows;
   factors_self_body<E, RT, U>(a, (int64_t)blockIdx.x - q.block_begin);
-}
-
-// The sub-block form as its own launch (a table of sub-block-eligible sites only): inside the general kernel it would raise
-// every site's register count (117 -> 225).
-template <class E, int RT, int U>
-__global__ __launch_bounds__(kFT) void linear_bwd_factors_self_ragged_sub_kernel(const lora_amd_self_site *__restrict__ sites,
-                                                                                 int n) {
-  __shared__ __attribute__((aligned(16))) float s_buf[kFT * 8 * 4];
-  __shared__ __attribute__((aligned(16))) float s_t[kSelfRowsCap * RT];
-  __shared__ __attribute__((aligned(16))) float s_gt[kSelfRowsCap * RT];
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const lora_amd_self_site q = sites[lo];
-  SelfArgs a;
-  a.g = q.g; a.x = q.x; a.ldg = q.ldg; a.ldx = q.ldx; a.M = q.M; a.down = q.down; a.up = q.up;
-  a.up_part = q.up_part; a.down_part = q.down_part; a.scale = q.scale; a.N = q.N; a.K = q.K; a.r = q.r;
-  a.rows_per_block = q.rows_per_block; a.nsplit = 1;
-  a.ghc = q.g_head_dim >> 3; a.ghp = q.g_head_pad >> 3; a.xhc = q.x_head_dim >> 3; a.xhp = q.x_head_pad >> 3;
-  a.kt_g = q.kt_g; a.logL_g = q.logL_g; a.kt_x = q.kt_x; a.logL_x = q.logL_x;
-  a.tile_g = q.tile_g; a.nct_g = q.nct_g; a.tile_x = q.tile_x; a.nct_x = q.nct_x;
-  a.sub_rows = q.sub_rows;
-  factors_self_subblocks<E, RT, U>(a, (int64_t)blockIdx.x - q.block_begin, s_buf, s_t, s_gt);
 }
 
 // ---- the same, wave-specialised: the two halves of the workgroup work on the two tensors at the same time, so a block's
@@ -1460,7 +1350,6 @@ static bool factors_self_geom(int64_t M, int K, int N, int r, SelfArgs *a, int64
   int nsplit = (int)std::min<int64_t>((512 + nrb - 1) / nrb, 4);
   nsplit = std::max(1, std::min(nsplit, a->nct_g + a->nct_x));
   a->nsplit = nsplit;
-  a->sub_rows = 0;
   a->rows_per_block = (int)rows;
   const int kt = (kFLdsFactor / RT) & ~7;
   a->kt_g = std::min(kt, N); a->logL_g = pick_logL(a->kt_g >> 3);
@@ -1513,8 +1402,7 @@ extern "C" int lora_amd_linear_bwd_factors_self(const void *g, int64_t ldg, cons
   const int RT = frank_tile(r);
   hipStream_t st = (hipStream_t)stream;
   // both factor slabs in LDS at once -> the wave-specialised kernel (one row block per workgroup, no column splits)
-  static const bool no_dual = getenv("LORA_AMD_SELF_DUAL") && atoi(getenv("LORA_AMD_SELF_DUAL")) == 0;
-  const bool dual = !no_dual && (int64_t)RT * (N + K) <= kSelfLdsFloats && a.logL_x >= 0;
+  const bool dual = (int64_t)RT * (N + K) <= kSelfLdsFloats && a.logL_x >= 0;
 #define FS(E, RTV)                                                                                                    \
   do {                                                                                                                \
     if (dual) hipLaunchKernelGGL((linear_bwd_factors_self_dual_kernel<E, RTV>), dim3((unsigned)nrb), dim3(kDualThreads), 0, st, a); \
@@ -1555,38 +1443,12 @@ extern "C" int lora_amd_linear_factors_self_ragged_plan(lora_amd_self_site *site
     q.rows_per_block = a.rows_per_block; q.nsplit = 1;
     q.kt_g = a.kt_g; q.logL_g = a.logL_g; q.kt_x = a.kt_x; q.logL_x = a.logL_x;
     q.tile_g = a.tile_g; q.nct_g = a.nct_g; q.tile_x = a.tile_x; q.nct_x = a.nct_x;
-    // sub-block mode (factors_self_subblocks): both factor slabs in the work buffer at once, one column tile per tensor
-    // (the caller asks for it with sub_rows > 0; every site of such a table must qualify)
-    const bool sub_ok = a.nct_g == 1 && a.nct_x == 1 && (int64_t)rt0 * (q.N + q.K) <= kFLdsFactor && q.N <= a.kt_g && q.K <= a.kt_x;
-    LORA_AMD_CHECK(q.sub_rows == 0 || (sub_ok && q.sub_rows >= 8 && q.sub_rows == sites[0].sub_rows), LORA_AMD_EINVAL,
-                   "factors_self_ragged_plan: site %d does not qualify for the sub-block form (N, K <= 2048, RT (N + K) <= %d)", i, kFLdsFactor);
-    LORA_AMD_CHECK((q.sub_rows == 0) == (sites[0].sub_rows == 0), LORA_AMD_EINVAL,
-                   "factors_self_ragged_plan: sub-block and plain sites in one table");
     q.block_begin = begin;
     begin += nrb;
   }
   LORA_AMD_CHECK(begin < (1ll << 31), LORA_AMD_EINVAL, "factors_self_ragged_plan: too many blocks");
   *grid = begin;
   return LORA_AMD_OK;
-}
-
-extern "C" int lora_amd_linear_bwd_factors_self_ragged_sub(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid,
-                                                           int32_t rank, int32_t act_dtype, void *stream) {
-  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && dtype_ok(act_dtype), LORA_AMD_EINVAL,
-                 "linear_bwd_factors_self_ragged_sub: bad argument");
-  LORA_AMD_CHECK(rank >= 1 && rank <= 8, LORA_AMD_ERANK, "linear_bwd_factors_self_ragged_sub: rank %d outside [1,8]", rank);
-  const int RT = frank_tile(rank);
-  hipStream_t st = (hipStream_t)stream;
-#define FRS(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_sub_kernel<E, RTV, 4>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n)
-#define FRS_E(E) do { if (RT == 4) FRS(E, 4); else FRS(E, 8); } while (0)
-  switch (act_dtype) {
-    case LORA_AMD_F32: FRS_E(f32_t); break;
-    case LORA_AMD_F16: FRS_E(f16_t); break;
-    default: FRS_E(bf16_t); break;
-  }
-#undef FRS_E
-#undef FRS
-  return check_launch("lora_amd_linear_bwd_factors_self_ragged_sub");
 }
 
 extern "C" int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site *sites_dev, int32_t n, int64_t grid,
@@ -1597,12 +1459,7 @@ extern "C" int lora_amd_linear_bwd_factors_self_ragged(const lora_amd_self_site 
   const int RT = frank_tile(rank);
   hipStream_t st = (hipStream_t)stream;
   // loads in flight per lane: 4 measured best in the one-launch pass (8 costs occupancy: 1.9 vs ~1.1 ms on configs[1])
-  static const bool u8 = getenv("LORA_AMD_SELF_U") && atoi(getenv("LORA_AMD_SELF_U")) == 8;
-#define FR(E, RTV)                                                                                                   \
-  do {                                                                                                               \
-    if (u8 && RTV <= 8) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV, 8>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n); \
-    else hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV, 4>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n); \
-  } while (0)
+#define FR(E, RTV) hipLaunchKernelGGL((linear_bwd_factors_self_ragged_kernel<E, RTV, 4>), dim3((unsigned)grid), dim3(kFT), 0, st, sites_dev, n)
 #define FR_E(E) do { if (RT == 4) FR(E, 4); else if (RT == 8) FR(E, 8); else FR(E, 16); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: FR_E(f32_t); break;

@@ -432,7 +432,9 @@ class MergedWeights:
         # the backward of a site only records (G, X, factors, partial slabs); see flush_factors
         self.defer_factors = state is not None and os.environ.get("LORA_AMD_DEFER_FACTORS", "1") != "0"
         self._owed = []
-        self._tables = {}    # (dtype, rank tile, table bytes) -> [eager (pinned, device) pair, copy event, spare pairs]
+        self._tables = {}    # (pass, dtype, rank tile, LDS class, table bytes) -> [eager (pinned, device) pair, copy event, spare pairs]
+        self._packs = {}     # (down ptr, up ptr, dtype) -> (pk_down, pk_up, down, up): fragment packs of the matrix-core pass
+        self._pack_tables = {}
         self._graph_keep = []
 
     def lookup(self, module, w, b, dt, in_heads, out_heads, need_dx: bool = True):
@@ -518,53 +520,100 @@ class MergedWeights:
             plan.launch(alpha, _C.ROUND_ONCE)
         self.refreshes += 1
 
-    def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads) -> None:
-        self._owed.append((g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads))
+    def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind="self", plan=None) -> None:
+        self._owed.append((g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind, plan))
+
+    def _upload(self, key, raw: bytes, device, capturing: bool) -> torch.Tensor:
+        """A site table -> device memory on the launch stream.  The table changes every eager step (fresh G / X
+        addresses) and never under hipGraph replay (the capture's private pool hands out the same addresses): it is
+        written into a persistent pinned buffer and copied to a persistent device buffer, which is a memcpy node of the
+        captured graph."""
+        key = key + (len(raw),)
+        slot = self._tables.get(key)
+        if slot is None:
+            if capturing:
+                raise RuntimeError("MergedWeights.flush_factors: the site table's buffers must exist before hipGraph "
+                                   "capture (run the step eagerly once first)")
+            mk = lambda: (torch.empty(len(raw), dtype=torch.uint8).pin_memory(),  # noqa: E731
+                          torch.empty(len(raw), dtype=torch.uint8, device=device))
+            # [eager pair, copy-done event, pairs set aside for captures (pinned memory cannot be allocated inside one)]
+            slot = self._tables[key] = [mk(), None, [mk() for _ in range(4)]]
+        if capturing:
+            if not slot[2]:
+                raise RuntimeError("MergedWeights.flush_factors: more than 4 hipGraph captures of this step shape")
+            host, dev = slot[2].pop()  # owned by this graph from now on: its memcpy node re-reads `host` every replay
+            self._graph_keep.append((host, dev))
+        else:
+            host, dev = slot[0]
+            if slot[1] is not None:
+                slot[1].synchronize()  # the previous step's copy has read the pinned buffer
+        host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dev.copy_(host, non_blocking=True)
+        if not capturing:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return dev
+
+    def _packs_of(self, down, up, dt, plan):
+        """Persistent MFMA fragment packs (csrc/factor_mfma.hip) of one adapter's factors in the activation dtype."""
+        key = (down.data_ptr(), up.data_ptr(), dt)
+        pk = self._packs.get(key)
+        if pk is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MergedWeights: a site's fragment packs must exist before hipGraph capture")
+            pk = self._packs[key] = (torch.empty(int(plan.pack_down_elems), dtype=dt, device=down.device),
+                                     torch.empty(int(plan.pack_up_elems), dtype=dt, device=down.device), down, up)
+            self._pack_tables.clear()
+        return pk
+
+    def _pack_factors(self, dt, packs) -> None:
+        """ONE launch: this step's f32 factors -> hi / lo fragment packs of every site of the matrix-core pass."""
+        sig = (dt,) + tuple(id(p[0]) for p in packs)
+        tab = self._pack_tables.get(sig)
+        if tab is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MergedWeights: the pack table must exist before hipGraph capture")
+            arr, total = _C.factor_pack_table([(p[2], p[3], p[0], p[1]) for p in packs])
+            tab = self._pack_tables[sig] = (_C.table_to_device(arr, packs[0][0].device), len(packs), total)
+        _C.factor_pack(tab[0], tab[1], tab[2], dt)
 
     def flush_factors(self) -> None:
-        """ONE ``lora_amd_linear_bwd_factors_self_ragged`` launch per (activation dtype, rank tile) — one in practice —
-        for every site whose backward ran since the last flush.  The site table changes every eager step (fresh G / X
-        addresses) and never under hipGraph replay (the capture's private pool hands out the same addresses): it is
-        written into a persistent pinned buffer and copied to a persistent device buffer on the launch stream, which is
-        a memcpy node of the captured graph."""
+        """ONE factor-gradient launch per (pass, activation dtype, rank tile[, LDS class]) — one or two in practice — for
+        every site whose backward ran since the last flush: ``lora_amd_linear_bwd_factors_mfma_ragged`` (16-bit
+        activations: G and X read once, matrix cores; preceded by one ``lora_amd_factor_pack`` launch) or
+        ``lora_amd_linear_bwd_factors_self_ragged`` (f32 activations, shapes the former does not take)."""
         if not self._owed:
             return
         owed, self._owed = self._owed, []
         groups = {}
         for st in owed:
-            r = st[2].shape[0]
-            N = st[7][0] * st[7][1] if st[7] else st[0].shape[1]
-            K = st[8][0] * st[8][1] if st[8] else st[1].shape[1]
-            groups.setdefault((st[0].dtype, 4 if r <= 4 else 8 if r <= 8 else 16, _C.self_sub_ok(N, K, r)), []).append(st)
+            r, kind, plan = st[2].shape[0], st[9], st[10]
+            rt = 4 if r <= 4 else 8 if r <= 8 else 16
+            groups.setdefault((kind, st[0].dtype, rt, int(plan.lds_class) if kind == "mfma" else 0), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
-        for (dt, rt, sub), sites in groups.items():
-            arr, grid = _C.factors_self_ragged_table(sites, dt, _C.SELF_SUB_ROWS if sub else 0)
-            raw = bytes(arr)
-            key = (dt, rt, sub, len(raw))
-            slot = self._tables.get(key)
-            if slot is None:
-                if capturing:
-                    raise RuntimeError("MergedWeights.flush_factors: the site table's buffers must exist before hipGraph "
-                                       "capture (run the step eagerly once first)")
-                mk = lambda: (torch.empty(len(raw), dtype=torch.uint8).pin_memory(),  # noqa: E731
-                              torch.empty(len(raw), dtype=torch.uint8, device=sites[0][0].device))
-                # [eager pair, copy-done event, pairs set aside for captures (pinned memory cannot be allocated inside one)]
-                slot = self._tables[key] = [mk(), None, [mk() for _ in range(4)]]
-            if capturing:
-                if not slot[2]:
-                    raise RuntimeError("MergedWeights.flush_factors: more than 4 hipGraph captures of this step shape")
-                host, dev = slot[2].pop()  # owned by this graph from now on: its memcpy node re-reads `host` every replay
-                self._graph_keep.append((host, dev))
+        packed = {}  # activation dtype -> packs of this flush's sites, each adapter once
+        for (kind, dt, rt, cls), sites in groups.items():
+            if kind == "mfma":
+                for st in sites:
+                    pk = self._packs_of(st[2], st[3], dt, st[10])
+                    packed.setdefault(dt, {})[id(pk[0])] = pk
+        for dt, pks in packed.items():
+            self._pack_factors(dt, list(pks.values()))
+        for (kind, dt, rt, cls), sites in groups.items():
+            dev0 = sites[0][0].device
+            if kind == "mfma":
+                rows = []
+                for (g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, _, plan) in sites:
+                    pk = self._packs_of(down, up, dt, plan)
+                    rows.append((g2, x2, pk[0], pk[1], up_part, down_part, scale, g_heads, x_heads, down.shape[0],
+                                 int(plan.rows_per_block)))
+                arr, grid = _C.factors_mfma_table(rows, dt, cls)
+                dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
+                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls, dt)
             else:
-                host, dev = slot[0]
-                if slot[1] is not None:
-                    slot[1].synchronize()  # the previous step's copy has read the pinned buffer
-            host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            dev.copy_(host, non_blocking=True)
-            if not capturing:
-                slot[1] = torch.cuda.Event()
-                slot[1].record()
-            _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt, sub)
+                arr, grid = _C.factors_self_ragged_table([st[:9] for st in sites], dt)
+                dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
+                _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt)
 
     def invalidate(self) -> None:
         """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
@@ -574,6 +623,46 @@ class MergedWeights:
     @property
     def bytes_algorithmic(self) -> int:
         return sum(p.bytes_algorithmic for p, _ in (self._plans or []))
+
+
+def _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, in_heads, K, N, tag):
+    """Both factor gradients of one merged-weight site: deferred to the step's one-launch pass (trainer state with
+    ``MergedWeights.defer_factors``: the matrix-core pass for 16-bit activations, the VALU pass otherwise), or one
+    ``linear_bwd_factors_self`` launch here.  Returns (d_down, d_up) — None when they leave through ``sink``."""
+    M, r = x2.shape[0], down.shape[0]
+    mw = getattr(getattr(sink, "owner", None), "merged", None)
+    defer = mw is not None and mw.defer_factors
+    plan, kind = None, "self"
+    if defer and _C.FACTORS_MFMA:
+        plan = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
+        kind = "mfma" if plan.supported else "self"
+    if kind == "self":
+        plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
+    key = (kind, M, K, N, r, int(plan.nparts))
+    if sink is not None:
+        if sink.pending is not None:
+            sink.flush()
+        up_part, down_part = sink.self_workspace(key, plan, g2.device)
+    else:
+        up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
+                              for n in (plan.up_part_floats, plan.down_part_floats))
+    if defer:
+        mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale, out_heads, in_heads, kind, plan)
+        _log("bwd", f"{tag}_dx+factors_deferred_{kind}", M, K, N, r)
+    else:
+        _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale,
+                                   g_heads=out_heads, x_heads=in_heads)
+        _log("bwd", f"{tag}_dx+factors_self", M, K, N, r)
+    if sink is not None:
+        sink.pending = key
+        return None, None
+    d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
+    d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
+    rows = [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+            (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    table, n, total = _C.make_reduce_table(rows, g2.device)
+    _C.reduce_batched(table, n, total)
+    return d_down.to(down.dtype), d_up.to(up.dtype)
 
 
 class LoraLinearMergedFunction(torch.autograd.Function):
@@ -611,34 +700,8 @@ class LoraLinearMergedFunction(torch.autograd.Function):
                 dx = (F.linear(g2, ctx.w_eff_t) if ctx.w_eff_t is not None else g2 @ w_eff).view(ctx.x_shape)
         d_down = d_up = None
         if need_down or need_up:
-            mw = getattr(getattr(sink, "owner", None), "merged", None)
-            defer = mw is not None and mw.defer_factors
-            plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
-            key = ("self", M, K, N, r, int(plan.nparts))
-            if sink is not None:
-                if sink.pending is not None:
-                    sink.flush()
-                up_part, down_part = sink.self_workspace(key, plan, g2.device)
-            else:
-                up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
-                                      for n in (plan.up_part_floats, plan.down_part_floats))
-            if defer:
-                mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale, ctx.out_heads, ctx.in_heads)
-                _log("bwd", "merged_dx+factors_deferred", M, K, N, r)
-            else:
-                _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, ctx.scale,
-                                           g_heads=ctx.out_heads, x_heads=ctx.in_heads)
-                _log("bwd", "merged_dx+factors_self", M, K, N, r)
-            if sink is not None:
-                sink.pending = key
-            else:
-                d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
-                d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
-                rows = [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
-                        (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
-                table, n, total = _C.make_reduce_table(rows, g2.device)
-                _C.reduce_batched(table, n, total)
-                d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+            d_down, d_up = _merged_factor_grads(g2, x2, down, up, ctx.scale, sink, ctx.out_heads, ctx.in_heads, K, N,
+                                                "merged")
         db = None
         if need_b:
             db = (unpack_heads(g2, ctx.out_heads) if ctx.out_heads else g2).sum(0)
@@ -694,34 +757,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                     with _gemm_range():
                         wb = w_eff_t.t() if w_eff_t is not None else w_eff  # [N', K] operand; transposed storage: TN GEMM
                         dx = (g2 @ wb) if dx is None else dx.addmm_(g2, wb)
-                mw = getattr(getattr(sink, "owner", None), "merged", None)
-                defer = mw is not None and mw.defer_factors
-                plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED if defer else 0)
-                key = ("self", M, K, N, r, int(plan.nparts))
-                if sink is not None:
-                    if sink.pending is not None:
-                        sink.flush()
-                    up_part, down_part = sink.self_workspace(key, plan, g2.device)
-                else:
-                    up_part, down_part = (torch.empty(max(int(q), 1), dtype=torch.float32, device=g2.device)
-                                          for q in (plan.up_part_floats, plan.down_part_floats))
-                if defer:
-                    mw.owe(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale, out_heads, None)
-                    _log("bwd", "merged_group_dx+factors_deferred", M, K, N, r)
-                else:
-                    _C.linear_bwd_factors_self(g2, x2, down.contiguous(), up.contiguous(), up_part, down_part, scale,
-                                               g_heads=out_heads, x_heads=None)
-                    _log("bwd", "merged_group_dx+factors_self", M, K, N, r)
-                if sink is not None:
-                    sink.pending = key
-                else:
-                    d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
-                    d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
-                    rows = [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
-                            (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
-                    table, cnt, total = _C.make_reduce_table(rows, g2.device)
-                    _C.reduce_batched(table, cnt, total)
-                    d_up, d_down = d_up.to(up.dtype), d_down.to(down.dtype)
+                d_down, d_up = _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, None, K, N, "merged_group")
             grads += [None, None, d_down, d_up, None, None, None, None]
         grads[0] = dx.view(ctx.x_shape) if dx is not None else None
         return tuple(grads)

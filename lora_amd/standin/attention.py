@@ -96,21 +96,25 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     choice = _CHOICE.get(key)
     if choice is not None:
         choice = tuple(choice)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # multi-rank agreement only inside a training forward: every rank reaches the same attention calls in the same order
+    # there (same model, same step), which a rank-0-only evaluation / sampling call or an uneven last batch does not
+    # guarantee — a collective entered by one rank alone would hang the job
+    multi = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.is_grad_enabled()
+             and (q.requires_grad or k.requires_grad or v.requires_grad))
     if (choice is None or (multi and key not in _AGREED)) and not torch.cuda.is_current_stream_capturing():
         if choice is None and _TUNE and q.dtype in (torch.bfloat16, torch.float16):
             with torch.enable_grad():
                 choice = _tune(q, k, v)
         if multi:
             # data-parallel replicas run the same kernels: every rank adopts rank 0's pick the first time it meets a
-            # shape (all ranks meet the shapes in the same order — same model, same step), instead of each timing the
-            # candidates on its own GPU and possibly settling on different ones (noisy per-rank step times)
+            # shape, instead of each timing the candidates on its own GPU and possibly settling on different ones
             box = [list(choice) if choice is not None else None]
             dist.broadcast_object_list(box, src=0)
             choice = tuple(box[0]) if box[0] is not None else None
             _AGREED.add(key)
-        if choice is not None:
-            _CHOICE[key] = list(choice)
+        if choice is None:
+            choice = (None, q.shape[-1])  # the agreed default is cached too: one collective per shape, not one per call
+        _CHOICE[key] = list(choice)
     if choice is None:
         choice = (None, q.shape[-1])
     return _run(q, k, v, *choice)

@@ -395,6 +395,12 @@ class UNet2DConditionModel(nn.Module):
     def enable_gradient_checkpointing(self):  # ref: train_lora_dreambooth.py:627-628
         self._grad_ckpt = True
 
+    @property
+    def gradient_checkpointing(self) -> bool:
+        """The diffusers / transformers attribute name (what trainer._dropout_pool looks for: a step that recomputes
+        activations must regenerate the SAME dropout masks, so it keeps the per-site RNG draws)."""
+        return self._grad_ckpt
+
     def _run(self, blk, *a):
         if self._grad_ckpt and self.training and torch.is_grad_enabled():
             return checkpoint(blk, *a, use_reentrant=False)

@@ -282,7 +282,8 @@ def _ckpt_candidates(model):
     """The modules of ``model`` that carry a ``gradient_checkpointing`` switch (walked once per model)."""
     c = _CKPT_CAND.get(id(model))
     if c is None:
-        c = _CKPT_CAND[id(model)] = [m for m in model.modules() if hasattr(m, "gradient_checkpointing")]
+        c = _CKPT_CAND[id(model)] = [m for m in model.modules()
+                                     if hasattr(m, "gradient_checkpointing") or hasattr(m, "_grad_ckpt")]
     return c
 
 
@@ -293,8 +294,8 @@ def _dropout_pool(unet, text_encoder, device):
 
     if device.type != "cuda":
         return contextlib.nullcontext()
-    ckpt = any(getattr(m, "gradient_checkpointing", False) and m.training for mod in (unet, text_encoder)
-               if mod is not None for m in _ckpt_candidates(mod))
+    ckpt = any((getattr(m, "gradient_checkpointing", False) or getattr(m, "_grad_ckpt", False)) and m.training
+               for mod in (unet, text_encoder) if mod is not None for m in _ckpt_candidates(mod))
     if ckpt:
         return contextlib.nullcontext()
     return ops.dropout_pool(device)

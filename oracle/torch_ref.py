@@ -15,22 +15,27 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def linear_adapter_forward(x, W, b, down, up, scale, selector=None, p=0.0, training=False):
-    """ref: lora_diffusion/lora.py:53-58 — addmm, mm, (selector mm), mm, dropout, mul, add."""
+def linear_adapter_forward(x, W, b, down, up, scale, selector=None, p=0.0, training=False, mask=None):
+    """ref: lora_diffusion/lora.py:53-58 — addmm, mm, (selector mm), mm, dropout, mul, add.
+    ``mask``: nn.Dropout's random draw GIVEN (the multiplier tensor 0 | 1/(1-p), broadcastable to the branch) instead of
+    drawn — the way pti_loss_step below takes its noise and timesteps; then ``p`` / ``training`` are not consulted."""
     t = F.linear(x, down)
     if selector is not None:
         t = F.linear(t, selector)
-    branch = F.dropout(F.linear(t, up), p, training)
+    branch = F.linear(t, up)
+    branch = branch * mask.reshape(branch.shape) if mask is not None else F.dropout(branch, p, training)
     return F.linear(x, W, b) + branch * scale
 
 
 def conv_adapter_forward(x, W, b, down, up, scale, stride, padding, dilation, groups, selector=None, p=0.0,
-                         training=False):
-    """ref: lora_diffusion/lora.py:130-135 — conv2d, conv2d (k x k -> r), conv2d 1x1, dropout, mul, add."""
+                         training=False, mask=None):
+    """ref: lora_diffusion/lora.py:130-135 — conv2d, conv2d (k x k -> r), conv2d 1x1, dropout, mul, add.
+    ``mask``: as in linear_adapter_forward ([B, C_out, H, W])."""
     t = F.conv2d(x, down, None, stride, padding, dilation, groups)
     if selector is not None:
         t = F.conv2d(t, selector)
-    branch = F.dropout(F.conv2d(t, up), p, training)
+    branch = F.conv2d(t, up)
+    branch = branch * mask if mask is not None else F.dropout(branch, p, training)
     return F.conv2d(x, W, b, stride, padding, dilation, groups) + branch * scale
 
 
@@ -44,10 +49,11 @@ class RefLinearSite(nn.Module):
         self.frozen, self.r, self.p, self.scale = frozen, r, dropout_p, scale
         self.down = nn.Parameter(torch.randn(r, frozen.in_features) / r)
         self.up = nn.Parameter(torch.zeros(frozen.out_features, r))
+        self.mask = None  # a given dropout draw for the next forward (tests: the device's mask)
 
     def forward(self, x):
         return linear_adapter_forward(x, self.frozen.weight, self.frozen.bias, self.down, self.up, self.scale,
-                                      None, self.p, self.training)
+                                      None, self.p, self.training, self.mask)
 
 
 class RefConvSite(nn.Module):
@@ -59,11 +65,12 @@ class RefConvSite(nn.Module):
         kh, kw = frozen.kernel_size
         self.down = nn.Parameter(torch.randn(r, frozen.in_channels // frozen.groups, kh, kw) / r)
         self.up = nn.Parameter(torch.zeros(frozen.out_channels, r, 1, 1))
+        self.mask = None
 
     def forward(self, x):
         f = self.frozen
         return conv_adapter_forward(x, f.weight, f.bias, self.down, self.up, self.scale, f.stride, f.padding,
-                                    f.dilation, f.groups, None, self.p, self.training)
+                                    f.dilation, f.groups, None, self.p, self.training, self.mask)
 
 
 def _sites(model: nn.Module, targets: Iterable[str], kinds: Tuple[type, ...]):

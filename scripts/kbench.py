@@ -234,6 +234,91 @@ def bench_self(args):
         print(json.dumps(rec), flush=True)
 
 
+def sd15_site_list(batch=4, hw=64, seq=77):
+    """(M, K, N) of the 144 Linear adapter sites of the default injection at one step's shapes: attention
+    projections per level, cross-attention k / v on the text states, GEGLU projections."""
+    out = []
+    for lvl, (c, nblk) in enumerate(((320, 5), (640, 5), (1280, 5))):
+        tokens = batch * (hw >> lvl) ** 2
+        for _ in range(nblk):
+            out += [(tokens, c, c)] * 4                     # attn1 q k v out
+            out += [(tokens, c, c), (batch * seq, 768, c), (batch * seq, 768, c), (tokens, c, c)]  # attn2 q k v out
+            out += [(tokens, c, 8 * c)]                     # GEGLU proj
+    tokens = batch * (hw >> 3) ** 2                          # mid block
+    out += [(tokens, 1280, 1280)] * 4 + [(tokens, 1280, 1280), (batch * seq, 768, 1280), (batch * seq, 768, 1280),
+                                          (tokens, 1280, 1280)] + [(tokens, 1280, 10240)]
+    return out
+
+
+def bench_fm(args):
+    """The factor-gradient pass of a whole step (144 sites, batch 4, 512^2) both ways: the VALU pass
+    (lora_amd_linear_bwd_factors_self_ragged: 128-row blocks, each row block read twice) and the matrix-core pass
+    (lora_amd_factor_pack + lora_amd_linear_bwd_factors_mfma_ragged per LDS class: read once), each followed by the fold
+    (lora_amd_reduce_batched); algorithmic bytes = G + X once.  LORA_AMD_FM_ROWS / LORA_AMD_FM_GATHER select variants."""
+    r, dt = args.rank, torch.bfloat16
+    sites = sd15_site_list()
+    byts = sum((M * K + M * N) * 2 for M, K, N in sites)
+    gs, xs, downs, ups = {}, {}, [], []
+    for i, (M, K, N) in enumerate(sites):  # activations shared per shape (memory), factors per site
+        if (M, K, N) not in gs:
+            gs[(M, K, N)] = torch.randn(M, N, device=DEV).to(dt)
+            xs[(M, K, N)] = torch.randn(M, K, device=DEV).to(dt)
+        downs.append(torch.randn(r, K, device=DEV) * 0.25)
+        ups.append(torch.randn(N, r, device=DEV) * 0.05)
+    rec = {"sites": len(sites), "GX_GB": round(byts / 1e9, 4), "floor_us_8TBs": round(byts / 8e12 * 1e6, 1)}
+    # ---- VALU pass
+    vs, rows_v = [], []
+    for (M, K, N), down, up in zip(sites, downs, ups):
+        pl = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED)
+        up_part, down_part = torch.empty(int(pl.up_part_floats), device=DEV), torch.empty(int(pl.down_part_floats), device=DEV)
+        vs.append((gs[(M, K, N)], xs[(M, K, N)], down, up, up_part, down_part, 1.0, None, None))
+        rows_v += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                   (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    arr, grid = _C.factors_self_ragged_table(vs, dt)
+    tab_v = _C.table_to_device(arr, DEV)
+    red_v = _C.make_reduce_table(rows_v, DEV)
+    t, _ = timeit(lambda: _C.linear_bwd_factors_self_ragged(tab_v, len(vs), grid, r, dt), inner=5)
+    rec["valu_pass_us"], rec["valu_frac8"] = round(t * 1e6, 1), round(byts / 8e12 / t, 3)
+    t, _ = timeit(lambda: _C.reduce_batched(*red_v), inner=5)
+    rec["valu_fold_us"] = round(t * 1e6, 1)
+    # ---- matrix-core pass
+    by_cls, packs, rows_m, part_bytes = {}, [], [], 0
+    for (M, K, N), down, up in zip(sites, downs, ups):
+        pl = _C.factors_mfma_plan(M, K, N, r, dt)
+        assert pl.supported, (M, K, N)
+        up_part, down_part = torch.empty(int(pl.up_part_floats), device=DEV), torch.empty(int(pl.down_part_floats), device=DEV)
+        part_bytes += (int(pl.up_part_floats) + int(pl.down_part_floats)) * 4
+        pk_down, pk_up = torch.empty(int(pl.pack_down_elems), dtype=dt, device=DEV), torch.empty(int(pl.pack_up_elems), dtype=dt, device=DEV)
+        packs.append((down, up, pk_down, pk_up))
+        by_cls.setdefault(int(pl.lds_class), []).append((gs[(M, K, N)], xs[(M, K, N)], pk_down, pk_up, up_part, down_part, 1.0,
+                                                        None, None, r, int(pl.rows_per_block)))
+        rows_m += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+                   (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
+    arr, total = _C.factor_pack_table(packs)
+    tab_p = _C.table_to_device(arr, DEV)
+    t, _ = timeit(lambda: _C.factor_pack(tab_p, len(packs), total, dt), inner=5)
+    rec["pack_us"] = round(t * 1e6, 1)
+    tot = 0.0
+    for cls, ss in sorted(by_cls.items()):
+        arr, grid = _C.factors_mfma_table(ss, dt, cls)
+        tab = _C.table_to_device(arr, DEV)
+        b = sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt), inner=5)
+        rec[f"mfma_class{cls}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
+                                   "frac8": round(b / 8e12 / t, 3), "rows": sorted({s_[10] for s_ in ss})}
+        tot += t
+    red_m = _C.make_reduce_table(rows_m, DEV)
+    t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
+    rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)
+    rec["mfma_pass_us"], rec["mfma_frac8"] = round(tot * 1e6, 1), round(byts / 8e12 / tot, 3)
+    # numeric cross-check of the two passes on the folded gradients
+    worst = 0.0
+    for (a, b) in zip(rows_v, rows_m):
+        worst = max(worst, float((a[1] - b[1]).abs().max() / (a[1].abs().max() + 1e-30)))
+    rec["max_rel_diff_valu_vs_mfma"] = worst
+    print(json.dumps(rec), flush=True)
+
+
 def bench_gemm_layouts(args):
     """The merged-weight path's library GEMMs per site shape, in both storage layouts of the scratch weight: forward
     X W^T as F.linear on W [N, K] (TN) or X @ Wt on Wt [K, N] (NN); input gradient G W as G @ W (NN) or F.linear(G, Wt) (TN).
@@ -399,5 +484,7 @@ if __name__ == "__main__":
         bench_hostops(a)
     if "self" in a.what:
         bench_self(a)
+    if "fm" in a.what.split(","):
+        bench_fm(a)
     if "gemmlayout" in a.what:
         bench_gemm_layouts(a)

@@ -190,3 +190,38 @@ class PtiToyText(nn.Module):
 
     def forward(self, ids):
         return (self.emb(ids),)
+
+
+# ----------------------------------------------------------------------------- the kernels' dropout stream, restated
+def philox_dropout_mask(numel: int, p: float, seed: int, offset: int, device="cpu") -> torch.Tensor:
+    """The multiplier (0 or 1/(1-p)) csrc/common.hpp's ``dropout_mult8`` gives element ``e`` of a dense tensor in memory
+    order: Philox4x32-10 keyed by ``seed``, counter (e >> 3, offset), eight 16-bit uniforms per call, keep <=>
+    u16 >= round(p * 65536).  A restatement for tests (int64 tensor arithmetic), independent of the HIP code."""
+    assert numel % 8 == 0
+    M32 = 0xFFFFFFFF
+    idx = torch.arange(numel // 8, dtype=torch.int64, device=device)
+    c0, c1 = idx & M32, (idx >> 32) & M32
+    c2 = torch.full_like(idx, offset & M32)
+    c3 = torch.full_like(idx, (offset >> 32) & M32)
+    k0, k1 = seed & M32, (seed >> 32) & M32
+
+    def mulhilo(a: int, b: torch.Tensor):
+        # 32x32 -> 64 without overflowing int64: split b into 16-bit halves
+        lo16, hi16 = b & 0xFFFF, b >> 16
+        p_lo = a * lo16                      # < 2^48
+        p_hi = a * hi16                      # < 2^48
+        full_lo = (p_lo + ((p_hi & 0xFFFF) << 16))
+        lo = full_lo & M32
+        hi = ((p_hi >> 16) + (full_lo >> 32)) & M32
+        return hi, lo
+
+    for _ in range(10):
+        h0, l0 = mulhilo(0xD2511F53, c0)
+        h1, l1 = mulhilo(0xCD9E8D57, c2)
+        c0, c1, c2, c3 = (h1 ^ c1 ^ k0) & M32, l1, (h0 ^ c3 ^ k1) & M32, l0
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    thr = int(p * 65536.0 + 0.5)
+    keep = 1.0 / (1.0 - p)
+    words = torch.stack([c0, c1, c2, c3], dim=1)                          # [n/8, 4]
+    u16 = torch.stack([words & 0xFFFF, words >> 16], dim=2).reshape(-1)   # element 2i = low half, 2i+1 = high half
+    return (u16 >= thr).to(torch.float32) * keep

@@ -1,0 +1,64 @@
+"""CPU checks of the matrix-core factor pass (csrc/factor_mfma.hip): the lane-level index model (scripts/fm_model.py)
+against the dense formula, the host planner (pure CPU arithmetic in the C-ABI library) against the model's geometry, its
+LDS budget, and the bank-conflict freedom of the padded row pitch (scripts/lds_banks.py)."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+
+from lora_amd import _C
+from tests import helpers as H
+
+sys.path.insert(0, os.path.join(H.REPO, "scripts"))
+import fm_model  # noqa: E402
+import lds_banks  # noqa: E402
+
+
+@pytest.mark.parametrize("args", [dict(M=70, K=64, N=64, r=4, R=64), dict(M=40, K=320, N=96, r=8, R=32),
+                                  dict(M=50, K=320, N=320, r=4, R=32, gh=(8, 40, 64)),
+                                  dict(M=33, K=320, N=640, r=4, R=64, xh=(8, 40, 64))])
+def test_lane_level_model_of_the_pass_equals_the_dense_formula(args):
+    fm_model.check(**args)
+
+
+@pytest.mark.skipif(not _C.available(), reason="C-ABI library not built")
+@pytest.mark.parametrize("M,K,N,r", [(16384, 320, 320, 4), (4096, 640, 640, 8), (1024, 1280, 1280, 16), (308, 768, 320, 4),
+                                     (16384, 320, 2560, 4), (4096, 640, 5120, 4), (1024, 1280, 10240, 4), (100, 64, 96, 4)])
+def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
+    pl = _C.factors_mfma_plan(M, K, N, r, torch.bfloat16)
+    assert pl.supported and pl.rows_per_block in (32, 64) and pl.lds_class in (1, 2)
+    cap = 81920 if pl.lds_class == 1 else 163840
+    assert 0 < pl.lds_bytes <= cap
+    assert pl.nparts == -(-M // pl.rows_per_block)
+    assert pl.up_part_floats == pl.nparts * pl.rank_tile * N and pl.down_part_floats == pl.nparts * pl.rank_tile * K
+    assert pl.pack_up_elems == 32 * N and pl.pack_down_elems == 32 * K
+    g = fm_model.geometry(M, K, N, pl.rows_per_block, cap)
+    assert g is not None and g["lds"] == pl.lds_bytes
+    # the ragged planner fills the same geometry into the site table
+    site = (_C.FmSite * 1)()
+    q = site[0]
+    q.g = q.x = q.pk_up = q.pk_down = q.up_part = q.down_part = 4096  # any non-null, 16-byte aligned address
+    q.ldg, q.ldx, q.M, q.N, q.K, q.r, q.scale, q.rows_per_block = N, K, M, N, K, r, 1.0, pl.rows_per_block
+    grid = C.c_int64(0)
+    rc = _C.require().lora_amd_factors_mfma_ragged_plan(site, 1, _C.BF16, pl.lds_class, C.byref(grid))
+    assert rc == 0 and grid.value == pl.nparts
+    assert (q.cw, q.nchunk, q.pitch_a, q.pitch_b, q.lds_bytes) == (g["cw"], g["nchunk"], g["pitch_a"], g["pitch_b"], g["lds"])
+    assert bool(q.resident_is_x) == (K <= N)
+    assert q.cw % 32 == 0 and q.rows_per_block * q.cw <= 16384 and q.rows_per_block * q.pitch_b >= q.rows_per_block * 256
+
+
+@pytest.mark.skipif(not _C.available(), reason="C-ABI library not built")
+def test_planner_refuses_what_the_pass_does_not_take():
+    assert not _C.factors_mfma_plan(1024, 320, 320, 4, torch.float32).supported      # f32 activations: VALU pass
+    assert not _C.factors_mfma_plan(1024, 328, 320, 4, torch.bfloat16).supported     # K not a multiple of 32
+    assert not _C.factors_mfma_plan(1024, 320, 320, 17, torch.bfloat16).supported    # rank > 16
+    assert not _C.factors_mfma_plan(1024, 4096, 4096, 4, torch.bfloat16).supported   # no 32-row block of 4096 columns fits
+
+
+@pytest.mark.parametrize("cols", [64, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1280])
+def test_padded_row_pitch_is_bank_conflict_free_for_both_operand_reads(cols):
+    pitch, res = lds_banks.check(cols)
+    assert pitch % 64 == 32 and pitch >= cols * 2
+    assert res["phase1_b128"] == 1 and res["phase2_tr_b64"] == 1

@@ -286,42 +286,6 @@ def test_factors_self_ragged_one_launch_for_several_sites_vs_oracle(rows, monkey
         close(n(d_down), ddo, absd, "f32", k=1e-4, msg=f"dDown {N}x{K}")
 
 
-@pytest.mark.parametrize("sub_rows", [16, 32])
-def test_factors_self_ragged_sub_block_form_vs_oracle(sub_rows, monkeypatch):
-    """lora_amd_linear_bwd_factors_self_ragged_sub (experimental): the same factor gradients with the rows walked in
-    sub-blocks and the column accumulators kept in registers across them, vs oracle.lora_linear_backward."""
-    monkeypatch.setattr(_C, "SELF_SUB_ROWS", sub_rows)
-    r, s_ = 4, 1.1
-    specs = [(4096, 320, 320, None, None), (1000, 640, 640, None, None), (2048, 320, 320, (8, 40, 64), None),
-             (2048, 320, 320, None, (8, 40, 64)), (308, 768, 1280, None, None), (130, 768, 320, None, None)]
-    sites, refs = [], []
-    for i, (M, K, N, gh, xh) in enumerate(specs):
-        assert _C.self_sub_ok(N, K, r)
-        x, g = rnd((M, K), "bf16", seed=110 + i), rnd((M, N), "bf16", seed=130 + i)
-        down, up = rnd((r, K), "f32", 0.2, seed=150 + i), rnd((N, r), "f32", 0.3, seed=170 + i)
-        X, G, A, U = n(x), n(g), n(down), n(up)
-        _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s_)
-        gd = torch.from_numpy(_heads_pack(G, gh)).to(DEV).bfloat16() if gh else g
-        xd = torch.from_numpy(_heads_pack(X, xh)).to(DEV).bfloat16() if xh else x
-        plan = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED)
-        up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
-        down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
-        sites.append((gd, xd, down, up, up_part, down_part, s_, gh, xh))
-        refs.append((plan, N, K, duo, ddo, s_ * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)),
-                     (s_ * np.abs(G) @ np.abs(U)).T @ np.abs(X)))
-    arr, grid = _C.factors_self_ragged_table(sites, torch.bfloat16, sub_rows)
-    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
-    _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, r, torch.bfloat16, sub=True)
-    for (gd, xd, down, up, up_part, down_part, _, _, _), (plan, N, K, duo, ddo, absu, absd) in zip(sites, refs):
-        d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
-        table, cnt, total = _C.make_reduce_table(
-            [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
-             (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)], DEV)
-        _C.reduce_batched(table, cnt, total)
-        close(n(d_up), duo, absu, "f32", k=1e-4, msg=f"dUp {N}x{K}")
-        close(n(d_down), ddo, absd, "f32", k=1e-4, msg=f"dDown {N}x{K}")
-
-
 @pytest.mark.parametrize("in_heads,out_heads,r,bias", [(None, None, 4, True), (None, (8, 40, 64), 4, False),
                                                        ((8, 40, 64), None, 8, True), (None, None, 16, False)])
 def test_merged_weight_adapter_forward_backward_vs_oracle(in_heads, out_heads, r, bias):
