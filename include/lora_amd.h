@@ -49,6 +49,7 @@ extern "C" {
 /* rounding of the merge kernel */
 #define LORA_AMD_ROUND_REFERENCE 0 /* round exactly where collapse_lora does */
 #define LORA_AMD_ROUND_ONCE 1      /* fp32 throughout, one final rounding   */
+#define LORA_AMD_ROUND_DITHER 2    /* lora_amd_merge_step only: one final rounding with a fixed per-element dither */
 
 int lora_amd_abi_version(void);
 const char *lora_amd_last_error(void);
@@ -107,6 +108,33 @@ int lora_amd_merge_batched(const lora_amd_merge_site *sites_dev, int32_t n_sites
                            const lora_amd_merge_summary *summary_host,
                            int32_t w_dtype, int32_t ab_dtype, float alpha,
                            int32_t rounding, void *stream);
+
+/* The merge INSIDE the training step (ops.MergedWeights; csrc/merge_step.hip): per site, from ONE read of the frozen
+ * 16-bit W [N, K], the scratch weight W_eff = W + alpha up down (the operand of the forward GEMM, lora.py:53-58 without
+ * dropout) and, when out_t is given, its transpose W_eff^T (the [out, in] operand of the input-gradient GEMM) — the same
+ * values, written in the layouts the GEMMs consume:
+ *   out   : logical (n, k) at out   + rowmap(n) * ld_out   + colmap(k)      rowmap(n) = (n / row_d) * row_D + n % row_d
+ *   out_t : logical (k, n) at out_t + colmap(k) * ld_out_t + rowmap(n)      colmap(k) = (k / col_d) * col_D + k % col_d
+ * (row_d / col_d = 0: dense; pad rows / columns are never written: zero them once).  ld_out / ld_out_t in elements: several
+ * sites may share one wider buffer (q, k, v of an attention block: one GEMM forward).  f32 factors up [N, r], down [r, K].
+ * rounding: LORA_AMD_ROUND_ONCE (nearest even) or LORA_AMD_ROUND_DITHER: nearest after adding a fixed per-element dither
+ * hash(dither_key, n, k) in [0, 1) ulp — P(round away from zero) = frac((W + delta) / ulp), exactly W where delta = 0,
+ * identical from step to step: a delta below half an ulp of the frozen weight survives in the sum over a row instead of
+ * vanishing element by element.  tiles_k / tile_begin are filled by the plan (host, no GPU needed). */
+typedef struct lora_amd_mstep_site {
+  const void *w;
+  const float *up, *down;
+  void *out, *out_t;
+  int64_t ld_out, ld_out_t;
+  int32_t N, K, r;
+  int32_t row_d, row_D, col_d, col_D;
+  int32_t dither_key;
+  int32_t tiles_k, reserved;
+  int64_t tile_begin;
+} lora_amd_mstep_site;
+int lora_amd_merge_step_plan(lora_amd_mstep_site *sites_host, int32_t n, int32_t w_dtype, int64_t *total_tiles);
+int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t total_tiles, int32_t rank_max,
+                        int32_t w_dtype, float alpha, int32_t rounding, void *stream);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
  * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100
@@ -397,10 +425,13 @@ int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, in
  *     up_part[rb] = T^T G,  down_part[rb] = Gt^T X    (the row-contraction operand = ds_read_b64_tr_b16 transpose reads)
  * Same partial-slab layout as lora_amd_linear_bwd_factors_self_ragged ([nparts][RT][C], folded by lora_amd_reduce_batched).
  * The factors arrive packed in MFMA fragment order (lora_amd_factor_pack, one launch per step for all sites).
+ * A workgroup walks blocks_per_wg consecutive row blocks (the next block's loads in flight while the current one is
+ * consumed) and leaves ONE partial slab for them.
  * lds_class: 1 = <= 80 KiB per workgroup (two per CU), 2 = <= 160 KiB (one per CU: the 1280-wide sites); one launch per
  * class.  Shapes: N, K multiples of 32, rank <= 16; anything else: supported = 0, use the _self_ragged pass. */
 typedef struct lora_amd_factors_mfma_plan_t {
   int32_t supported, lds_class, rank_tile, rows_per_block, nparts, lds_bytes;
+  int32_t blocks_per_wg, reserved;          /* row blocks one workgroup walks: nparts = ceil(ceil(M / rows) / blocks_per_wg) */
   int64_t up_part_floats, down_part_floats;
   int64_t pack_up_elems, pack_down_elems;   /* elements (activation dtype) of the two fragment packs of a site */
 } lora_amd_factors_mfma_plan_t;
@@ -425,9 +456,10 @@ typedef struct lora_amd_fm_site {
   int32_t N, K, r;
   float scale;
   int32_t g_head_dim, g_head_pad, x_head_dim, x_head_pad;
-  int32_t rows_per_block;         /* caller: lora_amd_factors_mfma_plan's rows_per_block for this site */
+  int32_t rows_per_block;         /* caller: lora_amd_factors_mfma_plan's rows_per_block and ... */
+  int32_t blocks_per_wg;          /* ... blocks_per_wg for this site */
   /* filled by lora_amd_factors_mfma_ragged_plan */
-  int32_t resident_is_x, cw, nchunk, pitch_a, pitch_b, lds_bytes, reserved;
+  int32_t resident_is_x, cw, nchunk, pitch_a, pitch_b, lds_bytes;
   int64_t block_begin;
 } lora_amd_fm_site;
 int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_t act_dtype, int32_t lds_class,

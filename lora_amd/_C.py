@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblora_amd.so")
 OK = 0
 F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
-ROUND_REFERENCE, ROUND_ONCE = 0, 1
+ROUND_REFERENCE, ROUND_ONCE, ROUND_DITHER = 0, 1, 2
 MAX_RANK = 64
 ABI_VERSION = 4
 
@@ -28,6 +28,7 @@ _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 SYMBOLS = (
     "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
     "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
+    "lora_amd_merge_step_plan", "lora_amd_merge_step",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
@@ -82,6 +83,7 @@ class SelfSite(C.Structure):
 class FactorsMfmaPlan(C.Structure):
     _fields_ = [("supported", C.c_int32), ("lds_class", C.c_int32), ("rank_tile", C.c_int32),
                 ("rows_per_block", C.c_int32), ("nparts", C.c_int32), ("lds_bytes", C.c_int32),
+                ("blocks_per_wg", C.c_int32), ("reserved", C.c_int32),
                 ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64),
                 ("pack_up_elems", C.c_int64), ("pack_down_elems", C.c_int64)]
 
@@ -100,9 +102,9 @@ class FmSite(C.Structure):
         ("ldg", C.c_int64), ("ldx", C.c_int64), ("M", C.c_int64),
         ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("scale", C.c_float),
         ("g_head_dim", C.c_int32), ("g_head_pad", C.c_int32), ("x_head_dim", C.c_int32), ("x_head_pad", C.c_int32),
-        ("rows_per_block", C.c_int32),
+        ("rows_per_block", C.c_int32), ("blocks_per_wg", C.c_int32),
         ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("pitch_a", C.c_int32),
-        ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32), ("reserved", C.c_int32),
+        ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32),
         ("block_begin", C.c_int64),
     ]
 
@@ -130,6 +132,18 @@ class MergeSite(C.Structure):
         ("rows_per_tile", C.c_int32), ("cols_per_tile", C.c_int32), ("tiles_k", C.c_int32),
         ("tile_begin", C.c_int64), ("flags", C.c_int32), ("out_heads", C.c_int32),
         ("transposed", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MstepSite(C.Structure):
+    """lora_amd_mstep_site (include/lora_amd.h): one adapter of the in-step merge (W_eff and W_eff^T from one read of W)."""
+    _fields_ = [
+        ("w", C.c_void_p), ("up", C.c_void_p), ("down", C.c_void_p), ("out", C.c_void_p), ("out_t", C.c_void_p),
+        ("ld_out", C.c_int64), ("ld_out_t", C.c_int64),
+        ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32),
+        ("row_d", C.c_int32), ("row_D", C.c_int32), ("col_d", C.c_int32), ("col_D", C.c_int32),
+        ("dither_key", C.c_int32), ("tiles_k", C.c_int32), ("reserved", C.c_int32),
+        ("tile_begin", C.c_int64),
     ]
 
 
@@ -189,6 +203,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_target_arch.restype = C.c_char_p
     lib.lora_amd_merge_plan.argtypes = [C.POINTER(MergeSite), i32, i32, C.POINTER(MergeSummary)]
     lib.lora_amd_merge_batched.argtypes = [vp, i32, C.POINTER(MergeSummary), i32, i32, f32, i32, vp]
+    lib.lora_amd_merge_step_plan.argtypes = [C.POINTER(MstepSite), i32, i32, C.POINTER(i64)]
+    lib.lora_amd_merge_step.argtypes = [vp, i32, i64, i32, i32, f32, i32, vp]
+    lib.lora_amd_merge_step_plan.restype = lib.lora_amd_merge_step.restype = C.c_int
     lib.lora_amd_merge_set_tuning.argtypes = [i64, i64]
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
@@ -433,6 +450,58 @@ class MergePlan:
         _check(lib.lora_amd_merge_batched(self.table.data_ptr(), self.n_sites, C.byref(self.summary),
                                           dtype_code(self.w_dtype), dtype_code(self.ab_dtype), float(alpha),
                                           int(rounding), _stream()), "lora_amd_merge_batched")
+
+
+class MergeStepPlan:
+    """Planned table of the in-step merge (``lora_amd_merge_step``): per site the frozen 16-bit weight, the f32 factors and
+    where W_eff / W_eff^T go.  ``sites``: dicts with ``w`` [N, K], ``up`` [N, r], ``down`` [r, K], ``out`` (2-D view whose
+    row stride is ld_out), ``out_t`` (2-D view or None), ``row_heads`` / ``col_heads`` = (d, D) or None, ``key`` (dither)."""
+
+    def __init__(self, sites):
+        if not sites:
+            raise ValueError("MergeStepPlan: no sites")
+        lib = require()
+        self.w_dtype, self.device = sites[0]["w"].dtype, sites[0]["w"].device
+        arr = (MstepSite * len(sites))()
+        self.keep, self.bytes_algorithmic, self.rank_max = [], 0, 1
+        for q, st in zip(arr, sites):
+            w, up, down, out, out_t = st["w"], st["up"], st["down"], st["out"], st.get("out_t")
+            _dev_check(w, up, down, out)
+            if w.dtype != self.w_dtype or out.dtype != self.w_dtype or (out_t is not None and out_t.dtype != self.w_dtype):
+                raise TypeError("MergeStepPlan: mixed weight dtypes in one plan")
+            if up.dtype != torch.float32 or down.dtype != torch.float32:
+                raise TypeError("MergeStepPlan: f32 factors expected")
+            if not (w.is_contiguous() and up.is_contiguous() and down.is_contiguous()) or out.stride(1) != 1 or \
+                    (out_t is not None and out_t.stride(1) != 1):
+                raise ValueError("MergeStepPlan: contiguous W / factors and unit inner stride of the outputs expected")
+            N, K = w.shape
+            r = down.shape[0]
+            rh, ch = st.get("row_heads"), st.get("col_heads")
+            np_, kp = ((N // rh[0]) * rh[1] if rh else N), ((K // ch[0]) * ch[1] if ch else K)
+            if tuple(up.shape) != (N, r) or tuple(down.shape) != (r, K) or tuple(out.shape) != (np_, kp) or \
+                    (out_t is not None and tuple(out_t.shape) != (kp, np_)):
+                raise ValueError(f"MergeStepPlan: shape mismatch W{tuple(w.shape)} up{tuple(up.shape)} down{tuple(down.shape)} "
+                                 f"out{tuple(out.shape)}")
+            q.w, q.up, q.down, q.out = w.data_ptr(), up.data_ptr(), down.data_ptr(), out.data_ptr()
+            q.out_t = out_t.data_ptr() if out_t is not None else None
+            q.ld_out, q.ld_out_t = out.stride(0), (out_t.stride(0) if out_t is not None else 0)
+            q.N, q.K, q.r = N, K, r
+            q.row_d, q.row_D = rh if rh else (0, 0)
+            q.col_d, q.col_D = ch if ch else (0, 0)
+            q.dither_key = int(st.get("key", 0)) & 0x7FFFFFFF
+            self.rank_max = max(self.rank_max, r)
+            self.keep.append((w, up, down, out, out_t))
+            self.bytes_algorithmic += (2 + (out_t is not None)) * N * K * w.element_size() + (N + K) * r * 4
+        total = C.c_int64(0)
+        _check(lib.lora_amd_merge_step_plan(arr, len(sites), dtype_code(self.w_dtype), C.byref(total)),
+               "lora_amd_merge_step_plan")
+        self.n_sites, self.total_tiles, self.host = len(sites), total.value, arr
+        self.table = table_to_device(arr, self.device)
+
+    def launch(self, alpha: float = 1.0, rounding: int = ROUND_ONCE) -> None:
+        _check(require().lora_amd_merge_step(self.table.data_ptr(), self.n_sites, self.total_tiles, self.rank_max,
+                                             dtype_code(self.w_dtype), float(alpha), int(rounding), _stream()),
+               "lora_amd_merge_step")
 
 
 def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
@@ -905,15 +974,17 @@ def factor_pack(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dt
 
 def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
     """Host half of the matrix-core pass: ``sites`` = [(g, x, pk_down, pk_up, up_part, down_part, scale, g_heads,
-    x_heads, r, rows_per_block)] of one LDS class and rank tile -> (planned ctypes table, grid)."""
+    x_heads, r, plan)] of one LDS class and rank tile (``plan`` = the site's ``factors_mfma_plan``) -> (planned ctypes
+    table, grid)."""
     arr = (FmSite * len(sites))()
-    for q, (g, x, pk_down, pk_up, up_part, down_part, scale, g_heads, x_heads, r, rows) in zip(arr, sites):
+    for q, (g, x, pk_down, pk_up, up_part, down_part, scale, g_heads, x_heads, r, plan) in zip(arr, sites):
         q.g, q.x, q.pk_down, q.pk_up = g.data_ptr(), x.data_ptr(), pk_down.data_ptr(), pk_up.data_ptr()
         q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
         q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
         q.N = g_heads[0] * g_heads[1] if g_heads else g.shape[1]
         q.K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
-        q.r, q.scale, q.rows_per_block = int(r), float(scale), int(rows)
+        q.r, q.scale = int(r), float(scale)
+        q.rows_per_block, q.blocks_per_wg = int(plan.rows_per_block), int(plan.blocks_per_wg)
         q.g_head_dim, q.g_head_pad = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
         q.x_head_dim, q.x_head_pad = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
     grid = C.c_int64(0)

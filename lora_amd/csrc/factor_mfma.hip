@@ -61,8 +61,9 @@ __device__ __forceinline__ typename FmMfma<E>::frag fm_frag(mu32x4 v) {
 }
 
 constexpr int kFmThreads = 256;   // 4 waves
-constexpr int kFmNPA = 8;         // 16-byte pieces per thread and batch of the resident block's loads
+constexpr int kFmNPA1 = 10, kFmNPA2 = 20;  // 16-byte pieces per thread of ONE resident block (R * Ca <= 20480 / 40960 elements)
 constexpr int kFmNPB = 8;         // ... of one streamed chunk (R * CW <= 16384 elements)
+constexpr int kFmMaxNB = 8;       // row blocks one workgroup walks (their partial sums meet in its slab)
 constexpr int kFmMaxRT16 = 4;     // row tiles of 16 per block (R <= 64)
 constexpr int kFmLdsSmall = 81920, kFmLdsLarge = 163840;  // two workgroups per CU / one
 
@@ -130,7 +131,11 @@ struct FmStage { mu32x4 v[NP]; };
 struct FmPieces {
   int row, c, dr, dc, c8w;
   __device__ __forceinline__ FmPieces(int p0, int c8w_) : c8w(c8w_) {
-    const int p = p0 + threadIdx.x;
+    // an opaque zero: the pieces' (row, c) depend only on the thread and the tile shape, and hipcc otherwise hoists all of
+    // them out of the row-block loop and keeps them live (+54 registers: spills at two workgroups per CU)
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    const int p = p0 + threadIdx.x + z;
     row = p / c8w; c = p - row * c8w;
     dr = kFmThreads / c8w; dc = kFmThreads - dr * c8w;
   }
@@ -165,17 +170,29 @@ __device__ __forceinline__ void fm_write(const FmStage<E, NP> &st, unsigned char
   }
 }
 
+// The first fragment pair (hi, lo) of a wave's share of a tile's k-steps: issued BEFORE the barrier that publishes the tile,
+// so that the L2 trip of the factors is not on the path from "tile in LDS" to "first MFMA".
+struct FmFrag2 { mu32x4 h, l; };
+template <class E>
+__device__ __forceinline__ FmFrag2 fm_first_frags(const typename E::storage *pk, int64_t split_stride, int nks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ks = wave < nks ? wave : 0;
+  FmFrag2 f;
+  f.h = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)ks * 512 + lane * 8);
+  f.l = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)ks * 512 + lane * 8);
+  return f;
+}
+
 // phase 1 of one tile [R, ncols] in LDS: acc[t] += Data[tile t rows, k-step] . (hi + lo of the packed factor), for the
 // k-steps ks = wave, wave + 4, ... of the tile.  `pk` points at the fragment of the tile's first column (split 0),
-// `split_stride` = elements between the hi and the lo pack.
+// `split_stride` = elements between the hi and the lo pack, `f0` = fm_first_frags of the same arguments.
 template <class E>
 __device__ __forceinline__ void fm_phase1(mf32x4 (&acc)[kFmMaxRT16], const unsigned char *buf, int pitch, int nrt, int nks,
-                                          const typename E::storage *pk, int64_t split_stride) {
+                                          const typename E::storage *pk, int64_t split_stride, FmFrag2 f0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned char *rowp = buf + (lane & 15) * pitch + (lane >> 4) * 16;
   if (wave >= nks) return;
-  mu32x4 fh = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)wave * 512 + lane * 8);
-  mu32x4 fl = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)wave * 512 + lane * 8);
+  mu32x4 fh = f0.h, fl = f0.l;
 #pragma unroll 1
   for (int ks = wave; ks < nks; ks += 4) {
     const int kn = ks + 4 < nks ? ks + 4 : ks;  // next fragment in flight while this one is used
@@ -255,16 +272,24 @@ __device__ __forceinline__ typename FmMfma<E>::frag fm_colfrag(const unsigned ch
   }
 }
 
-// phase 2 of one tile [R, ncols] in LDS: out[jj][col0 + c] = sum_rows T[row, jj] Data[row, c] for the tile's columns;
+// phase 2 of one tile [R, ncols] in LDS: out[jj][col0 + c] (+)= sum_rows T[row, jj] Data[row, c] for the tile's columns;
 // column tiles of 16 are dealt to the waves.  `tf` = the T fragments (hi, lo per 32-row k-step) in registers.
+// `accumulate`: the workgroup's earlier row blocks already left their sums in `out` (its own slab: the same lane wrote
+// the same 16 bytes; read back past the L1 with a non-temporal load, one column tile ahead of its use).
 template <class E, bool TR>
 __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, int nk2, int ncols,
-                                          const mu32x4 (&tf)[kFmMaxRT16], float *out, int64_t ldo, int RT) {
+                                          const mu32x4 (&tf)[kFmMaxRT16], float *out, int64_t ldo, int RT, bool accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jj = lane & 15, q = lane >> 4;
   const int nct = ncols >> 4;
+  const bool owner = jj < RT;
+  float *base = out + (owner ? jj : 0) * ldo + 4 * q;
+  mf32x4 old = {0.f, 0.f, 0.f, 0.f};
+  if (accumulate && owner && wave < nct) old = __builtin_nontemporal_load(reinterpret_cast<const mf32x4 *>(base + wave * 16));
 #pragma unroll 1
   for (int ct = wave; ct < nct; ct += 4) {
+    mf32x4 nxt = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate && owner && ct + 4 < nct) nxt = __builtin_nontemporal_load(reinterpret_cast<const mf32x4 *>(base + (ct + 4) * 16));
     mf32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
@@ -274,7 +299,8 @@ __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, i
         d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2 + 1]), d);
       }
     }
-    if (jj < RT) *reinterpret_cast<mf32x4 *>(out + jj * ldo + ct * 16 + 4 * q) = d;
+    if (owner) *reinterpret_cast<mf32x4 *>(base + ct * 16) = d + old;
+    old = nxt;
   }
 }
 
@@ -295,16 +321,18 @@ template <class E, int LDSB, bool TR>
 __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfma_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
   using S = typename E::storage;
+  constexpr int NPA = LDSB <= 81920 ? kFmNPA1 : kFmNPA2;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const lora_amd_fm_site q = sites[lo];
-  const int64_t rb = (int64_t)blockIdx.x - q.block_begin;
+  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;   // this workgroup's slab = its run of row blocks
   const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
-  const int64_t m0 = rb * R;
-  const int nrows = (int)min((int64_t)R, q.M - m0);
+  const int64_t nrb = (q.M + R - 1) / R;
+  const int64_t rb0 = sb_idx * q.blocks_per_wg;
+  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
   const bool ax = q.resident_is_x != 0;
   const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
   // A = resident operand, B = streamed operand
@@ -314,57 +342,75 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   const int hca = (ax ? q.x_head_dim : q.g_head_dim) >> 3, hpa = (ax ? q.x_head_pad : q.g_head_pad) >> 3;
   const int hcb = (ax ? q.g_head_dim : q.x_head_dim) >> 3, hpb = (ax ? q.g_head_pad : q.x_head_pad) >> 3;
   const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
-  float *outa = (ax ? q.down_part : q.up_part) + rb * RT * (int64_t)Ca;   // = TB^T A
-  float *outb = (ax ? q.up_part : q.down_part) + rb * RT * (int64_t)Cb;   // = TA^T B
+  float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;   // = sum over the blocks of TB^T A
+  float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;   // = ... TA^T B
   const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
   unsigned char *bufA = lds, *bufB = bufA + R * pa;
   unsigned char *ttA = bufB + R * pb, *ttB = ttA + 32 * fm_tpitch(R);
   float *scratch = reinterpret_cast<float *>(bufB);  // [4 waves][nrt][4][64] f32 <= R * pitch_b (planner)
+  const int c8a = Ca >> 3, cw0 = min(CW, Cb);
+  const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
 
-  // ---- resident block and the first chunk of B: everything in flight before the first wait
-  FmStage<E, kFmNPA> sa;
+  // ---- the first block's resident rows and first chunk: in flight before the first wait.  From here on the NEXT block's
+  // resident rows (sa) and the next chunk (sb) are always in flight while the current ones are consumed.
+  FmStage<E, NPA> sa;
   FmStage<E, kFmNPB> sb;
-  const int c8a = Ca >> 3, totalA = R * c8a;
-  const int cw0 = min(CW, Cb);
-  fm_issue<E, kFmNPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hca, hpa);
-  fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hcb, hpb);
-  fm_write<E, kFmNPA>(sa, bufA, pa, R, 0, c8a);
-  for (int p0 = kFmThreads * kFmNPA; p0 < totalA; p0 += kFmThreads * kFmNPA) {
-    fm_issue<E, kFmNPA>(sa, da, lda, m0, nrows, p0, c8a, 0, hca, hpa);
-    fm_write<E, kFmNPA>(sa, bufA, pa, R, p0, c8a);
+  {
+    const int64_t m0 = rb0 * R;
+    const int nrows = (int)min((int64_t)R, q.M - m0);
+    fm_issue<E, NPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hca, hpa);
+    fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hcb, hpb);
   }
-  __syncthreads();
-  // ---- TA
   mf32x4 acc[kFmMaxRT16];
-#pragma unroll
-  for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-  fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, (int64_t)c8a * 128);
-  fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale);
-  __syncthreads();  // TA visible; the scratch (= chunk buffer) is free
   mu32x4 tf[kFmMaxRT16];
-  fm_load_tfrags<E>(tf, ttA, R, nk2);
-  // ---- B in column chunks
-#pragma unroll
-  for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-  const int64_t splitb = (int64_t)(Cb >> 3) * 128;
 #pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
-    const int col0 = c * CW, cw = min(CW, Cb - col0);
-    fm_write<E, kFmNPB>(sb, bufB, pb, R, 0, cw >> 3);
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t m0 = (rb0 + blk) * R, m1 = m0 + R;
+    const int nrows = (int)min((int64_t)R, q.M - m0);
+    const int nrows1 = (int)min((int64_t)R, q.M - m1);   // of the next block (if any)
+    const bool more = blk + 1 < nblk;
+    const bool accum = blk > 0;
+    FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
+    fm_write<E, NPA>(sa, bufA, pa, R, 0, c8a);
     __syncthreads();
-    if (c + 1 < nch) {
-      const int col1 = col0 + CW, cw1 = min(CW, Cb - col1);
-      fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hcb, hpb);
+    if (more) fm_issue<E, NPA>(sa, da, lda, m1, nrows1, 0, c8a, 0, hca, hpa);
+    // ---- TA
+#pragma unroll
+    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+    fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, splita, f0);
+    fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale);
+    f0 = fm_first_frags<E>(pkb, splitb, cw0 >> 5);
+    __syncthreads();  // TA visible; the scratch (= chunk buffer) is free
+    fm_load_tfrags<E>(tf, ttA, R, nk2);
+    // ---- B in column chunks
+#pragma unroll
+    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      const int col0 = c * CW, cw = min(CW, Cb - col0);
+      fm_write<E, kFmNPB>(sb, bufB, pb, R, 0, cw >> 3);
+      __syncthreads();
+      if (c + 1 < nch) {
+        const int col1 = col0 + CW, cw1 = min(CW, Cb - col1);
+        fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hcb, hpb);
+      } else if (more) {
+        fm_issue<E, kFmNPB>(sb, db, ldb, m1, nrows1, 0, cw0 >> 3, 0, hcb, hpb);
+      }
+      fm_phase1<E>(acc, bufB, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb, f0);
+      if (c + 1 < nch) {
+        const int col1 = col0 + CW;
+        f0 = fm_first_frags<E>(pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
+      }
+      fm_phase2<E, TR>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
+      __syncthreads();  // the chunk buffer is free
     }
-    fm_phase1<E>(acc, bufB, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb);
-    fm_phase2<E, TR>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT);
-    __syncthreads();  // the chunk buffer is free
+    // ---- TB, then the resident block's column sums
+    fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale);
+    __syncthreads();
+    fm_load_tfrags<E>(tf, ttB, R, nk2);
+    fm_phase2<E, TR>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
+    __syncthreads();  // the resident buffer is free for the next block
   }
-  // ---- TB, then the resident block's column sums
-  fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale);
-  __syncthreads();
-  fm_load_tfrags<E>(tf, ttB, R, nk2);
-  fm_phase2<E, TR>(bufA, pa, nk2, Ca, tf, outa, Ca, RT);
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
@@ -377,6 +423,8 @@ static bool fm_fit(int64_t M, int K, int N, int r, int act_dtype, int R, int lds
   g->resident_is_x = K <= N;
   const int Ca = std::min(K, N), Cb = std::max(K, N);
   g->pitch_a = fm_pitch(Ca);
+  // the NEXT block's resident rows wait in registers while the current block is consumed: NPA pieces per thread
+  if ((int64_t)R * Ca > (int64_t)(lds_cap <= kFmLdsSmall ? kFmNPA1 : kFmNPA2) * kFmThreads * 8) return false;
   const int fixed = R * g->pitch_a + 2 * 32 * fm_tpitch(R);
   // pieces per thread <= kFmNPB; the chunk buffer also holds the [4][R/16][4][64] f32 scratch of the phase-1 combine
   for (int cwmax = std::min(kFmNPB * kFmThreads * 8 / R, 512); cwmax >= 32; cwmax -= 32) {
@@ -407,6 +455,12 @@ static int fm_rows_env() {
   static const int v = getenv("LORA_AMD_FM_ROWS") ? atoi(getenv("LORA_AMD_FM_ROWS")) : 0;
   return v;
 }
+// row blocks one workgroup walks (LORA_AMD_FM_NB, default 4): their partial sums meet in the workgroup's slab, and the next
+// block's loads are in flight while the current one is consumed
+static int fm_blocks_per_wg(int64_t nrb) {
+  static const int v = getenv("LORA_AMD_FM_NB") ? atoi(getenv("LORA_AMD_FM_NB")) : 4;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
+}
 
 }  // namespace lora_amd
 
@@ -423,7 +477,9 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   out->lds_class = cls;
   out->rank_tile = r <= 4 ? 4 : r <= 8 ? 8 : 16;
   out->rows_per_block = g.R;
-  out->nparts = (int32_t)((M + g.R - 1) / g.R);
+  const int64_t nrb = (M + g.R - 1) / g.R;
+  out->blocks_per_wg = fm_blocks_per_wg(nrb);
+  out->nparts = (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
@@ -485,9 +541,12 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
                        heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
                    LORA_AMD_EINVAL, "factors_mfma_ragged_plan: site %d: shape / alignment / head layout / LDS class not supported", i);
     q.rows_per_block = g.R; q.resident_is_x = g.resident_is_x; q.cw = g.cw; q.nchunk = g.nchunk;
-    q.pitch_a = g.pitch_a; q.pitch_b = g.pitch_b; q.lds_bytes = g.lds; q.reserved = 0;
+    q.pitch_a = g.pitch_a; q.pitch_b = g.pitch_b; q.lds_bytes = g.lds;
+    const int64_t nrb = (q.M + g.R - 1) / g.R;
+    LORA_AMD_CHECK(q.blocks_per_wg >= 1 && q.blocks_per_wg <= kFmMaxNB, LORA_AMD_EINVAL,
+                   "factors_mfma_ragged_plan: site %d: blocks_per_wg %d outside [1, %d]", i, q.blocks_per_wg, kFmMaxNB);
     q.block_begin = begin;
-    begin += (q.M + g.R - 1) / g.R;
+    begin += (nrb + q.blocks_per_wg - 1) / q.blocks_per_wg;
   }
   LORA_AMD_CHECK(begin < (1ll << 31), LORA_AMD_EINVAL, "factors_mfma_ragged_plan: too many blocks");
   *grid = begin;

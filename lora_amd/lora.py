@@ -151,7 +151,7 @@ class LoraInjectedLinear(_Adapter):
         with torch.autocast(device_type=x.device.type, enabled=False):
             mw = self.__dict__.get("_merged")
             if mw is not None and ops.merged_ok(xc, wc, self.lora_down.weight, self.lora_up.weight,
-                                                self._selector_matrix(), self._dropout_p(), in_heads, out_heads):
+                                                self._selector_matrix(), self._dropout_p(), in_heads, out_heads, b):
                 # the step's merged weight W + scale up down (trainer.enable_merged_weights): frozen GEMM forward and
                 # input gradient, one launch for both factor gradients
                 need_dx = xc.requires_grad and torch.is_grad_enabled()
@@ -194,18 +194,29 @@ def lora_linear_group(adapters, x: torch.Tensor, out_heads=None):
         # gradients accumulate inside the GEMMs (``out_heads``: the outputs leave in the padded head layout)
         dt = _autocast_dtype(x, adapters[0].linear.weight)
         xc = x if x.dtype == dt else x.to(dt)
-        flat = []
-        for a in adapters:
-            wc, bc = a._shadow(a.linear.weight, dt, "w"), a._shadow(a.linear.bias, dt, "b")
-            if not ops.merged_ok(xc, wc, a.lora_down.weight, a.lora_up.weight, a._selector_matrix(), a._dropout_p(), None,
-                                 out_heads):
+        mw = adapters[0].__dict__["_merged"]
+        wcs = [a._shadow(a.linear.weight, dt, "w") for a in adapters]
+        bcs = [a._shadow(a.linear.bias, dt, "b") for a in adapters]
+        for a, wc in zip(adapters, wcs):
+            if a.__dict__["_merged"] is not mw or not ops.merged_ok(xc, wc, a.lora_down.weight, a.lora_up.weight,
+                                                                    a._selector_matrix(), a._dropout_p(), None, out_heads,
+                                                                    a.linear.bias):
                 return None
-            need_dx = xc.requires_grad and torch.is_grad_enabled()
-            w_eff, b_eff, w_eff_t = a.__dict__["_merged"].lookup(a, wc, bc, dt, None, out_heads, need_dx)
+        need_dx = xc.requires_grad and torch.is_grad_enabled()
+        # one scratch buffer for the group (one GEMM forward) where the sites' entries do not exist apart already
+        g = mw.lookup_group(adapters, wcs, bcs, dt, out_heads, need_dx) if ops.CONCAT_GROUPS else None
+        flat = []
+        for i, a in enumerate(adapters):
+            if g is not None:
+                e = g["entries"][i]
+                w_eff, b_eff, w_eff_t = e["w_eff"], e["b_eff"], e["w_eff_t"]
+            else:
+                w_eff, b_eff, w_eff_t = mw.lookup(a, wcs[i], bcs[i], dt, None, out_heads, need_dx)
             flat += [w_eff, b_eff, a.lora_down.weight, a.lora_up.weight, float(a.scale), a.__dict__.get("_grad_sink"),
                      out_heads, w_eff_t]
         with torch.autocast(device_type=x.device.type, enabled=False):
-            return list(ops.LoraLinearMergedGroupFunction.apply(xc, len(adapters), *flat))
+            return list(ops.LoraLinearMergedGroupFunction.apply(xc, len(adapters), g["cat"] if g is not None else None,
+                                                                g["bias"] if g is not None else None, *flat))
     if out_heads is not None:
         return None  # the per-site fused kernels take head layouts one adapter at a time (forward_heads)
     a0 = adapters[0]

@@ -393,6 +393,11 @@ class LoraLinearFunction(torch.autograd.Function):
 
 # Input gradients of the merged-weight sites as F.linear(G, W_eff^T-stored) instead of G @ W_eff (see MergedWeights.lookup)
 TRANSPOSED_DX = os.environ.get("LORA_AMD_TRANSPOSED_DX", "1") != "0"
+# q / k / v (k / v) of an attention block on ONE concatenated scratch weight: one forward GEMM per group (A/B: 0)
+CONCAT_GROUPS = os.environ.get("LORA_AMD_CONCAT_GROUPS", "1") != "0"
+# Rounding of the in-step merge of 16-bit weights (csrc/merge_step.hip): "dither" (default) = nearest with a fixed
+# per-element dither, so that a delta below half an ulp of the frozen weight survives in the row sums; "once" = nearest even
+MERGE_ROUNDING = _C.ROUND_ONCE if os.environ.get("LORA_AMD_MERGE_ROUNDING", "dither") == "once" else _C.ROUND_DITHER
 
 
 def _gemm_range():
@@ -436,12 +441,20 @@ class MergedWeights:
         self._packs = {}     # (down ptr, up ptr, dtype) -> (pk_down, pk_up, down, up): fragment packs of the matrix-core pass
         self._pack_tables = {}
         self._graph_keep = []
+        self.groups = {}     # (ids of the adapters of one input, out_heads, dtype) -> concatenated scratch weights
 
     def lookup(self, module, w, b, dt, in_heads, out_heads, need_dx: bool = True):
         """(w_eff, bias_eff, w_eff_t) for this adapter and layout; creates (and fills) the entry on first use.
         ``w_eff_t`` = the same merged weight stored transposed ([K, N]: what the library's faster [out, in]-operand GEMM
         wants for the input gradient G W_eff — 12.4 vs 14.4 us at 16384 x 320 x 320, 45.6 vs 80.7 us at 1024 x 10240 -> 1280,
-        profiles/r03_kbench_gemmlayout.log); None when no input gradient is needed or the input is head-padded."""
+        profiles/r03_kbench_gemmlayout.log); None when no input gradient is needed."""
+        e = self._entry(module, w, b, dt, in_heads, out_heads)
+        # f32 weights go through the collapse kernel, whose transposed sites need 32 | N (its column tiles)
+        if need_dx and TRANSPOSED_DX and e["w_eff_t"] is None and (e["step"] or (in_heads is None and w.shape[0] % 32 == 0)):
+            self._add_transposed(e)
+        return e["w_eff"], e["b_eff"], e["w_eff_t"]
+
+    def _entry(self, module, w, b, dt, in_heads, out_heads, out=None):
         if (self._state is not None and self._fresh_at != self._state.step_count
                 and not torch.cuda.is_current_stream_capturing()):
             self.refresh()  # an optimiser step since the last merge (an eager forward outside trainer.forward_backward)
@@ -451,54 +464,123 @@ class MergedWeights:
         # was replaced, or tune_lora_scale changed the scale: the entry is rebuilt
         if e is not None and (e["ptrs"] != (module.lora_up.weight.data_ptr(), module.lora_down.weight.data_ptr(),
                                             w.data_ptr()) or e["scale"] != float(module.scale)):
+            if e.get("group") is not None:
+                self.groups.pop(e["group"], None)
             e = None
         if e is None:
-            e = self._create(module, w, b, in_heads, out_heads)
+            e = self._create(module, w, b, in_heads, out_heads, out)
             self.entries[key] = e
-        if need_dx and TRANSPOSED_DX and in_heads is None and e["w_eff_t"] is None:
-            self._add_transposed(e, module, w, out_heads)
-        return e["w_eff"], e["b_eff"], e["w_eff_t"]
+        return e
 
-    def _create(self, module, w, b, in_heads, out_heads):
+    def lookup_group(self, modules, ws, bs, dt, out_heads, need_dx: bool):
+        """Several adapters that read ONE tensor (attn1's to_q / to_k / to_v, attn2's to_k / to_v): their scratch weights
+        are row ranges of ONE buffer (and column ranges of one transposed buffer), so that the forward of the group is
+        one GEMM ``X [W_q; W_k; W_v]^T`` whose output columns are the sites' outputs.  Returns the group record
+        (``cat`` [sum n_out, K], ``bias`` or None, ``splits``) or None when the sites' entries already exist apart."""
+        gkey = tuple(id(m) for m in modules) + (out_heads, dt)
+        g = self.groups.get(gkey)
+        if g is not None:
+            ok = all(self.entries.get((id(m), None, out_heads, dt)) is not None and
+                     self.entries[(id(m), None, out_heads, dt)].get("group") == gkey and
+                     self.entries[(id(m), None, out_heads, dt)]["ptrs"] == (m.lora_up.weight.data_ptr(),
+                                                                         m.lora_down.weight.data_ptr(), w.data_ptr()) and
+                     self.entries[(id(m), None, out_heads, dt)]["scale"] == float(m.scale)
+                     for m, w in zip(modules, ws))
+            if not ok:
+                for m in modules:
+                    self.entries.pop((id(m), None, out_heads, dt), None)
+                self.groups.pop(gkey, None)
+                g = None
+        if g is None:
+            if any((id(m), None, out_heads, dt) in self.entries for m in modules) or ws[0].dtype == torch.float32:
+                return None
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MergedWeights: a new adapter group appeared during hipGraph capture")
+            K = ws[0].shape[1]
+            n_outs = [(out_heads[0] * out_heads[2] if out_heads else w.shape[0]) for w in ws]
+            cat = torch.zeros((sum(n_outs), K), dtype=ws[0].dtype, device=ws[0].device)
+            g = dict(cat=cat, cat_t=None, splits=n_outs, bias=None)
+            pos = 0
+            for m, w, b, n_o in zip(modules, ws, bs, n_outs):
+                e = self._entry(m, w, b, dt, None, out_heads, out=cat[pos:pos + n_o])
+                e["group"] = gkey
+                pos += n_o
+            es = [self.entries[(id(m), None, out_heads, dt)] for m in modules]
+            if any(e["b_eff"] is not None for e in es):
+                g["bias"] = torch.cat([e["b_eff"] if e["b_eff"] is not None else
+                                       torch.zeros(n_o, dtype=cat.dtype, device=cat.device) for e, n_o in zip(es, n_outs)])
+            self.groups[gkey] = g
+        es = [self.entries[(id(m), None, out_heads, dt)] for m in modules]
+        if need_dx and TRANSPOSED_DX and g["cat_t"] is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MergedWeights: a group's transposed scratch weight must exist before hipGraph capture")
+            g["cat_t"] = torch.zeros((g["cat"].shape[1], g["cat"].shape[0]), dtype=g["cat"].dtype, device=g["cat"].device)
+            pos = 0
+            for e, n_o in zip(es, g["splits"]):
+                self._add_transposed(e, out_t=g["cat_t"][:, pos:pos + n_o])
+                pos += n_o
+        g["entries"] = es
+        return g
+
+    def _create(self, module, w, b, in_heads, out_heads, out=None):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("MergedWeights: a new adapter / layout appeared during hipGraph capture; run the step "
                                "eagerly once first (GraphedForwardBackward's warm-up does)")
         N, K = w.shape
         n_out = out_heads[0] * out_heads[2] if out_heads else N
         k_out = in_heads[0] * in_heads[2] if in_heads else K
-        w_eff = torch.zeros((n_out, k_out), dtype=w.dtype, device=w.device)   # pad rows / columns stay zero
+        w_eff = out if out is not None else torch.zeros((n_out, k_out), dtype=w.dtype, device=w.device)  # pads stay zero
         b_eff = None
         if b is not None:
             b_eff = pack_heads(b.detach(), out_heads).contiguous() if out_heads else b.detach()
         up, down = module.lora_up.weight, module.lora_down.weight
-        heads_in = (in_heads[1], in_heads[2]) if in_heads else None
-        sites = []
-        if out_heads:
-            h, d, D = out_heads
-            for i in range(h):
-                sites.append((w.detach()[i * d:(i + 1) * d], w_eff[i * D:i * D + d], up.detach()[i * d:(i + 1) * d],
-                              down.detach()) + ((heads_in,) if heads_in else ()))
-        else:
-            sites.append((w.detach(), w_eff, up.detach(), down.detach()) + ((heads_in,) if heads_in else ()))
-        e = dict(module=module, w_eff=w_eff, b_eff=b_eff, w_eff_t=None, w_t=None, sites=sites, scale=float(module.scale),
-                 ptrs=(up.data_ptr(), down.data_ptr(), w.data_ptr()))
-        _C.MergePlan(sites).launch(float(module.scale), _C.ROUND_ONCE)  # this forward's values; the step plan is rebuilt
+        step = w.dtype in (torch.bfloat16, torch.float16)  # the in-step merge kernel (csrc/merge_step.hip)
+        e = dict(module=module, w=w.detach(), w_eff=w_eff, b_eff=b_eff, w_eff_t=None, w_t=None, scale=float(module.scale),
+                 ptrs=(up.data_ptr(), down.data_ptr(), w.data_ptr()), in_heads=in_heads, out_heads=out_heads, step=step,
+                 key=len(self.entries) + 1, group=None)
+        if not step:  # f32 weights: the collapse kernel's sites (round 3's form; head sub-ranges, separate transposed site)
+            heads_in = (in_heads[1], in_heads[2]) if in_heads else None
+            sites = []
+            if out_heads:
+                h, d, D = out_heads
+                for i in range(h):
+                    sites.append((w.detach()[i * d:(i + 1) * d], w_eff[i * D:i * D + d], up.detach()[i * d:(i + 1) * d],
+                                  down.detach()) + ((heads_in,) if heads_in else ()))
+            else:
+                sites.append((w.detach(), w_eff, up.detach(), down.detach()) + ((heads_in,) if heads_in else ()))
+            e["sites"] = sites
+        self._launch_one(e)  # this forward's values; the step plan is rebuilt
         self._plans = None
         return e
 
-    def _add_transposed(self, e, module, w, out_heads) -> None:
-        """Second scratch weight of the entry: W_eff^T, merged from a frozen transposed copy of W by a ``transposed`` site
-        of the same launch (bit-identical values).  A head-padded output becomes padded COLUMNS here (``out_heads``)."""
+    def _msite(self, e) -> dict:
+        m = e["module"]
+        ih, oh = e["in_heads"], e["out_heads"]
+        return dict(w=e["w"], up=m.lora_up.weight.detach(), down=m.lora_down.weight.detach(), out=e["w_eff"],
+                    out_t=e["w_eff_t"], row_heads=(oh[1], oh[2]) if oh else None, col_heads=(ih[1], ih[2]) if ih else None,
+                    key=e["key"])
+
+    def _launch_one(self, e) -> None:
+        if e["step"]:
+            _C.MergeStepPlan([self._msite(e)]).launch(e["scale"], MERGE_ROUNDING)
+        else:
+            _C.MergePlan(e["sites"]).launch(e["scale"], _C.ROUND_ONCE)
+
+    def _add_transposed(self, e, out_t=None) -> None:
+        """Second scratch weight of the entry: W_eff^T.  16-bit weights: written by the SAME tile of the in-step merge that
+        writes W_eff (one read of W, identical values).  f32 weights: a ``transposed`` site of the collapse kernel on a
+        frozen transposed copy of W."""
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("MergedWeights: a site's transposed scratch weight must exist before hipGraph capture")
-        N, K = w.shape
-        n_out = out_heads[0] * out_heads[2] if out_heads else N
-        e["w_t"] = w.detach().t().contiguous()  # frozen: built once
-        e["w_eff_t"] = torch.zeros((K, n_out), dtype=w.dtype, device=w.device)  # pad columns stay zero
-        heads = (out_heads[1], out_heads[2]) if out_heads else None
-        site = (e["w_t"], e["w_eff_t"], module.lora_down.weight.detach(), module.lora_up.weight.detach(), heads, True)
-        e["sites"].append(site)
-        _C.MergePlan([site]).launch(e["scale"], _C.ROUND_ONCE)
+        w, module, out_heads = e["w"], e["module"], e["out_heads"]
+        e["w_eff_t"] = out_t if out_t is not None else torch.zeros((e["w_eff"].shape[1], e["w_eff"].shape[0]),
+                                                                   dtype=w.dtype, device=w.device)  # pads stay zero
+        if not e["step"]:
+            e["w_t"] = w.t().contiguous()  # frozen: built once
+            heads = (out_heads[1], out_heads[2]) if out_heads else None
+            e["sites"].append((e["w_t"], e["w_eff_t"], module.lora_down.weight.detach(), module.lora_up.weight.detach(),
+                               heads, True))
+        self._launch_one(e)
         self._plans = None
 
     def refresh(self) -> None:
@@ -511,13 +593,17 @@ class MergedWeights:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("MergedWeights.refresh: the site table must exist before hipGraph capture (run two "
                                    "eager steps first: the first registers the sites, the second builds the table)")
-            groups = {}
+            step_groups, old_groups = {}, {}
             for e in self.entries.values():
-                for st in e["sites"]:
-                    groups.setdefault((st[0].dtype, e["scale"]), []).append(st)
-            self._plans = [(_C.MergePlan(sites), alpha) for (_, alpha), sites in groups.items()]
-        for plan, alpha in self._plans:
-            plan.launch(alpha, _C.ROUND_ONCE)
+                if e["step"]:
+                    step_groups.setdefault((e["w"].dtype, e["scale"]), []).append(self._msite(e))
+                else:
+                    for st in e["sites"]:
+                        old_groups.setdefault((st[0].dtype, e["scale"]), []).append(st)
+            self._plans = [(_C.MergeStepPlan(sites), alpha, MERGE_ROUNDING) for (_, alpha), sites in step_groups.items()]
+            self._plans += [(_C.MergePlan(sites), alpha, _C.ROUND_ONCE) for (_, alpha), sites in old_groups.items()]
+        for plan, alpha, rounding in self._plans:
+            plan.launch(alpha, rounding)
         self.refreshes += 1
 
     def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind="self", plan=None) -> None:
@@ -606,7 +692,7 @@ class MergedWeights:
                 for (g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, _, plan) in sites:
                     pk = self._packs_of(down, up, dt, plan)
                     rows.append((g2, x2, pk[0], pk[1], up_part, down_part, scale, g_heads, x_heads, down.shape[0],
-                                 int(plan.rows_per_block)))
+                                 plan))
                 arr, grid = _C.factors_mfma_table(rows, dt, cls)
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
                 _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls, dt)
@@ -618,11 +704,12 @@ class MergedWeights:
     def invalidate(self) -> None:
         """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
         self.entries.clear()
+        self.groups.clear()
         self._plans = None
 
     @property
     def bytes_algorithmic(self) -> int:
-        return sum(p.bytes_algorithmic for p, _ in (self._plans or []))
+        return sum(p[0].bytes_algorithmic for p in (self._plans or []))
 
 
 def _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, in_heads, K, N, tag):
@@ -715,21 +802,29 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
     the input gradients of the sites are accumulated by the GEMMs themselves (``addmm_``: beta = 1 in the library's
     epilogue) instead of n - 1 elementwise ``add`` launches over [M, K] that autograd would issue for n separate nodes.
 
-    Inputs: x, n, then per site (w_eff, b_eff, down, up, scale, sink, out_heads, w_eff_t)."""
+    Inputs: x, n, cat, bias_cat, then per site (w_eff, b_eff, down, up, scale, sink, out_heads, w_eff_t).  ``cat`` (or
+    None): the sites' scratch weights as row ranges of ONE buffer (``MergedWeights.lookup_group``) — the forward is then
+    one GEMM whose output columns are the sites' outputs (views, no copies)."""
 
     @staticmethod
-    def forward(ctx, x, n, *args):
+    def forward(ctx, x, n, cat, bias_cat, *args):
         _C.require()
         sites = [args[8 * i:8 * i + 8] for i in range(n)]
         K = sites[0][0].shape[1]
         x2 = _rows2d(x, K)
         outs = []
         with _gemm_range():
+            ycat, pos = (F.linear(x2, cat, bias_cat) if cat is not None else None), 0
             for (w_eff, b_eff, down, up, scale, sink, out_heads, _) in sites:
-                y = F.linear(x2, w_eff, b_eff)
+                if ycat is not None:
+                    y = ycat[:, pos:pos + w_eff.shape[0]]
+                    pos += w_eff.shape[0]
+                else:
+                    y = F.linear(x2, w_eff, b_eff)
                 outs.append(y.view(*x.shape[:-1], y.shape[1]))
                 N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
-                _log("fwd", "merged_group" + ("_heads" if out_heads else ""), x2.shape[0], K, N, down.shape[0])
+                _log("fwd", "merged_group" + ("_cat" if cat is not None else "") + ("_heads" if out_heads else ""),
+                     x2.shape[0], K, N, down.shape[0])
         ctx.save_for_backward(x2, *[t for st in sites for t in (st[0], st[2], st[3])])
         ctx.meta = [(float(st[4]), st[5], st[6], st[7]) for st in sites]
         ctx.n, ctx.x_shape = n, x.shape
@@ -743,7 +838,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
         M, K = x2.shape
         need_x = ctx.needs_input_grad[0]
         dx = None
-        grads = [None, None]
+        grads = [None, None, None, None]
         for i in range(ctx.n):
             w_eff, down, up = saved[1 + 3 * i:4 + 3 * i]
             scale, sink, out_heads, w_eff_t = ctx.meta[i]
@@ -764,11 +859,20 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
 
 
 def merged_ok(x: torch.Tensor, weight: torch.Tensor, down: torch.Tensor, up: torch.Tensor, sel, dropout_p: float,
-              in_heads, out_heads) -> bool:
-    """Can this call take the merged-weight path?  (device, no dropout / selector, frozen weight, f32 factors, a shape
-    the one-launch factor-gradient kernel covers, 16-bit or f32 activations matching the weight)."""
+              in_heads, out_heads, bias=None) -> bool:
+    """Can this call take the merged-weight path?  (device, no dropout / selector, frozen weight AND bias, f32 factors, a
+    shape and alignment the merge and the one-launch factor-gradient kernels cover, 16-bit or f32 activations matching
+    the weight).  Mirrors the planners' preconditions so that a site they would refuse takes the per-site kernels
+    instead of raising inside the forward."""
     if not x.is_cuda or dropout_p > 0.0 or sel is not None or weight.requires_grad:
         return False
+    if bias is not None and bias.requires_grad:  # the merged path caches the bias and returns no gradient for it
+        return False
+    if (weight.data_ptr() | down.data_ptr() | up.data_ptr()) % 16 or not weight.is_contiguous():
+        return False
+    if weight.dtype == torch.float32 and (in_heads is not None or out_heads is not None) and \
+            (weight.shape[0] % 32 or weight.shape[1] % 32):
+        return False  # head layouts of f32 weights run on the collapse kernel's column-owner tiles
     if down.dtype != torch.float32 or up.dtype != torch.float32 or x.dtype != weight.dtype:
         return False
     N, K = weight.shape

@@ -291,7 +291,7 @@ def bench_fm(args):
         pk_down, pk_up = torch.empty(int(pl.pack_down_elems), dtype=dt, device=DEV), torch.empty(int(pl.pack_up_elems), dtype=dt, device=DEV)
         packs.append((down, up, pk_down, pk_up))
         by_cls.setdefault(int(pl.lds_class), []).append((gs[(M, K, N)], xs[(M, K, N)], pk_down, pk_up, up_part, down_part, 1.0,
-                                                        None, None, r, int(pl.rows_per_block)))
+                                                        None, None, r, pl))
         rows_m += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
                    (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
     arr, total = _C.factor_pack_table(packs)
@@ -305,7 +305,8 @@ def bench_fm(args):
         b = sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)
         t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt), inner=5)
         rec[f"mfma_class{cls}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
-                                   "frac8": round(b / 8e12 / t, 3), "rows": sorted({s_[10] for s_ in ss})}
+                                   "frac8": round(b / 8e12 / t, 3), "rows": sorted({int(s_[10].rows_per_block) for s_ in ss}),
+                                   "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
         tot += t
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)

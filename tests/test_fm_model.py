@@ -31,9 +31,11 @@ def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
     assert pl.supported and pl.rows_per_block in (32, 64) and pl.lds_class in (1, 2)
     cap = 81920 if pl.lds_class == 1 else 163840
     assert 0 < pl.lds_bytes <= cap
-    assert pl.nparts == -(-M // pl.rows_per_block)
+    nrb = -(-M // pl.rows_per_block)
+    assert 1 <= pl.blocks_per_wg <= min(8, nrb) and pl.nparts == -(-nrb // pl.blocks_per_wg)
     assert pl.up_part_floats == pl.nparts * pl.rank_tile * N and pl.down_part_floats == pl.nparts * pl.rank_tile * K
     assert pl.pack_up_elems == 32 * N and pl.pack_down_elems == 32 * K
+    assert pl.rows_per_block * min(K, N) <= (10 if pl.lds_class == 1 else 20) * 2048  # the next block waits in registers
     g = fm_model.geometry(M, K, N, pl.rows_per_block, cap)
     assert g is not None and g["lds"] == pl.lds_bytes
     # the ragged planner fills the same geometry into the site table
@@ -41,6 +43,7 @@ def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
     q = site[0]
     q.g = q.x = q.pk_up = q.pk_down = q.up_part = q.down_part = 4096  # any non-null, 16-byte aligned address
     q.ldg, q.ldx, q.M, q.N, q.K, q.r, q.scale, q.rows_per_block = N, K, M, N, K, r, 1.0, pl.rows_per_block
+    q.blocks_per_wg = pl.blocks_per_wg
     grid = C.c_int64(0)
     rc = _C.require().lora_amd_factors_mfma_ragged_plan(site, 1, _C.BF16, pl.lds_class, C.byref(grid))
     assert rc == 0 and grid.value == pl.nparts

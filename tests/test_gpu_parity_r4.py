@@ -72,7 +72,7 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
         pk_up = torch.full((int(plan.pack_up_elems),), float("nan"), dtype=dt, device=DEV)
         packs.append((down, up, pk_down, pk_up))
         by_cls.setdefault(int(plan.lds_class), []).append(
-            (gd, xd, pk_down, pk_up, up_part, down_part, s_, gh, xh, r, int(plan.rows_per_block)))
+            (gd, xd, pk_down, pk_up, up_part, down_part, s_, gh, xh, r, plan))
         out.append(dict(plan=plan, N=N, K=K, up_part=up_part, down_part=down_part, duo=duo, ddo=ddo,
                         absu=s_ * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)), absd=(s_ * np.abs(G) @ np.abs(U)).T @ np.abs(X)))
     arr, total = _C.factor_pack_table(packs)
@@ -133,6 +133,97 @@ def test_philox_restatement_equals_the_kernels_dropout_mask():
     _C.rank_update_(mk, torch.ones(M, 1, device=DEV), torch.ones(1, N, device=DEV), _C.FACTOR_RK, 1.0, p, seed, off)
     want = H.philox_dropout_mask(M * N, p, seed, int(off.item())).view(M, N)
     assert torch.equal(mk.cpu(), want)
+
+
+# ----------------------------------------------------------------------------- a4 in the step: W_eff and W_eff^T from one read
+@pytest.mark.parametrize("N,K,r,rh,ch,dt", [
+    (320, 320, 4, None, None, "bf16"), (1280, 320, 8, None, None, "bf16"), (320, 768, 16, None, None, "bf16"),
+    (320, 320, 4, (40, 64), None, "bf16"), (320, 320, 4, None, (40, 64), "bf16"), (2560, 320, 4, None, None, "f16"),
+    (10240, 1280, 4, None, None, "bf16"), (328, 72, 3, None, None, "bf16")])
+def test_merge_step_writes_w_eff_and_its_transpose_vs_oracle(N, K, r, rh, ch, dt):
+    """lora.py:635-669 through lora_amd_merge_step (ROUND_ONCE): W + alpha up down in the layouts the step's GEMMs read —
+    dense, head-padded rows (the adapter's OUTPUT), head-padded columns (its INPUT) — and the transpose from the same
+    tile: W_eff^T is the transpose of W_eff bit for bit; both equal oracle.collapse within one rounding; pad rows / columns
+    are never written."""
+    w = rnd((N, K), dt, 0.05, seed=1)
+    up, down = rnd((N, r), "f32", 0.3, seed=2), rnd((r, K), "f32", 0.3, seed=3)
+    np_, kp = ((N // rh[0]) * rh[1] if rh else N), ((K // ch[0]) * ch[1] if ch else K)
+    out = torch.full((np_, kp), 9.0, dtype=w.dtype, device=DEV)
+    out_t = torch.full((kp, np_), 9.0, dtype=w.dtype, device=DEV)
+    _C.MergeStepPlan([dict(w=w, up=up, down=down, out=out, out_t=out_t, row_heads=rh, col_heads=ch, key=7)]).launch(0.7, _C.ROUND_ONCE)
+    assert torch.equal(out_t, out.t())
+    got = out
+    if rh:
+        assert torch.all(got.view(N // rh[0], rh[1], kp)[:, rh[0]:, :] == 9.0)
+        got = got.view(N // rh[0], rh[1], kp)[:, :rh[0], :].reshape(N, kp)
+    if ch:
+        assert torch.all(got.view(N, K // ch[0], ch[1])[:, :, ch[0]:] == 9.0)
+        got = got.view(N, K // ch[0], ch[1])[:, :, :ch[0]].reshape(N, K)
+    want = O.collapse(n(w), n(up), n(down), 0.7)
+    assert np.abs(n(got) - want).max() <= 2.0 ** (-8 if dt == "bf16" else -10) * np.abs(want).max()
+    # the column-owner kernel of collapse_lora computes the same fma chain: ROUND_ONCE results are identical
+    ref = torch.empty_like(w)
+    _C.MergePlan([(w, ref, up, down)]).launch(0.7, _C.ROUND_ONCE)
+    assert torch.equal(got, ref)
+
+
+def test_merge_step_sites_share_one_buffer():
+    """q / k / v of an attention block as row ranges of ONE scratch weight and column ranges of one transposed buffer
+    (ld_out / ld_out_t wider than the site): each range equals the site merged on its own."""
+    K, r = 320, 4
+    ws = [rnd((320, K), "bf16", 0.05, seed=10 + i) for i in range(3)]
+    ups = [rnd((320, r), "f32", 0.3, seed=20 + i) for i in range(3)]
+    downs = [rnd((r, K), "f32", 0.3, seed=30 + i) for i in range(3)]
+    lay = (40, 64)
+    cat = torch.zeros(3 * 512, K, dtype=torch.bfloat16, device=DEV)
+    cat_t = torch.zeros(K, 3 * 512, dtype=torch.bfloat16, device=DEV)
+    sites = [dict(w=w, up=u, down=d, out=cat[i * 512:(i + 1) * 512], out_t=cat_t[:, i * 512:(i + 1) * 512], row_heads=lay,
+                  col_heads=None, key=i) for i, (w, u, d) in enumerate(zip(ws, ups, downs))]
+    _C.MergeStepPlan(sites).launch(1.0, _C.ROUND_ONCE)
+    assert torch.equal(cat_t, cat.t())
+    for i, (w, u, d) in enumerate(zip(ws, ups, downs)):
+        one = torch.zeros(512, K, dtype=torch.bfloat16, device=DEV)
+        _C.MergeStepPlan([dict(w=w, up=u, down=d, out=one, out_t=None, row_heads=lay, col_heads=None, key=i)]).launch(1.0, _C.ROUND_ONCE)
+        assert torch.equal(cat[i * 512:(i + 1) * 512], one)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_merge_step_dithered_rounding_keeps_sub_ulp_deltas_in_the_row_sums(dt):
+    """LORA_AMD_ROUND_DITHER: (a) delta = 0 leaves W bit for bit; (b) a delta of a fraction of an ulp — which nearest-even
+    rounding deletes entirely — survives in expectation: the mean of (W_eff - W) over many elements is the mean delta within
+    4 %; (c) every element is one of the two neighbours of W + delta; (d) the same inputs give the same bits (fixed dither),
+    and W_eff^T is still the exact transpose."""
+    N, K, r = 1024, 640, 4
+    w = rnd((N, K), dt, 0.05, seed=1)
+    wf = w.float()
+    up0, down = torch.zeros(N, r, device=DEV), rnd((r, K), "f32", 0.3, seed=3)
+    out, out_t = torch.empty_like(w), torch.empty(K, N, dtype=w.dtype, device=DEV)
+    site = lambda u: [dict(w=w, up=u, down=down, out=out, out_t=out_t, row_heads=None, col_heads=None, key=3)]  # noqa: E731
+    _C.MergeStepPlan(site(up0)).launch(1.0, _C.ROUND_DITHER)
+    assert torch.equal(out, w) and torch.equal(out_t, w.t())
+    # delta = 0.2 ulp of each element (rank-1 structure is irrelevant here: build it exactly with rank 1 of 4)
+    ulp = torch.where(wf != 0, 2.0 ** (torch.floor(torch.log2(wf.abs())) - (7 if dt == "bf16" else 10)), torch.zeros_like(wf))
+    # a constant small delta instead: 1e-5 is 0.04-0.3 ulp of |w| ~ 0.01..0.1 in bf16
+    dval = 1e-5 if dt == "bf16" else 2e-6
+    up = torch.zeros(N, r, device=DEV)
+    up[:, 0] = 1.0
+    down1 = torch.zeros(r, K, device=DEV)
+    down1[0] = dval
+    site1 = [dict(w=w, up=up, down=down1, out=out, out_t=out_t, row_heads=None, col_heads=None, key=3)]
+    once = torch.empty_like(w)
+    _C.MergeStepPlan([dict(w=w, up=up, down=down1, out=once, out_t=None, row_heads=None, col_heads=None, key=3)]).launch(1.0, _C.ROUND_ONCE)
+    big = ulp > 4 * dval                          # elements where the delta is below a quarter ulp
+    assert big.float().mean() > 0.5
+    assert torch.equal(once[big], w[big])         # nearest-even: the delta is gone there
+    _C.MergeStepPlan(site1).launch(1.0, _C.ROUND_DITHER)
+    got = out.float()
+    mean_delta = float((got - wf)[big].mean())
+    assert abs(mean_delta - dval) <= 0.04 * dval, (mean_delta, dval)
+    err = (got - (wf + dval)).abs()
+    assert bool((err[big] <= ulp[big] * 2.0).all())
+    again, again_t = torch.empty_like(w), torch.empty_like(out_t)
+    _C.MergeStepPlan([dict(w=w, up=up, down=down1, out=again, out_t=again_t, row_heads=None, col_heads=None, key=3)]).launch(1.0, _C.ROUND_DITHER)
+    assert torch.equal(again, out) and torch.equal(again_t, out.t())
 
 
 # ----------------------------------------------------------------------------- consecutive optimiser steps, timed path
@@ -257,7 +348,6 @@ def test_consecutive_optimizer_steps_on_the_timed_merged_path_vs_oracle(sd15_thr
                 assert np.abs(upd_dev[solid] - upd_ref[solid]).max() <= 0.02 * LR_STEPS
             st.flat_p.copy_(so["after"].to(DEV))
             st.exp_avg.copy_(so["m"].to(DEV)), st.exp_avg_sq.copy_(so["v"].to(DEV))
-        assert merged.refreshes >= 5
     finally:
         for m in unet.modules():
             m.__dict__.pop("_grad_sink", None)
@@ -294,7 +384,9 @@ def test_bf16_merged_trajectory_from_the_reference_initial_state(monkeypatch):
         return [torch.randn(m.lora_down.weight.shape if hasattr(m, "lora_down") else m.down.shape, generator=g) / 4
                 for m in mods]
 
-    def run_device(merged_on: bool):
+    def run_device(merged_on: bool, rounding=None):
+        if rounding is not None:
+            monkeypatch.setattr(ops, "MERGE_ROUNDING", rounding)
         unet = build_unet(torch.device(DEV), torch.bfloat16, seed=0)
         unet.to(memory_format=torch.channels_last)
         L.inject_trainable_lora(unet, r=4)
@@ -350,7 +442,8 @@ def test_bf16_merged_trajectory_from_the_reference_initial_state(monkeypatch):
     monkeypatch.setenv("LORA_AMD_HEAD_PAD", "1")
     monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1")
     monkeypatch.setattr(fused, "_ENABLED", True)
-    l_m, u_m = run_device(True)
+    l_m, u_m = run_device(True, _C.ROUND_DITHER)
+    l_o, u_o = run_device(True, _C.ROUND_ONCE)
     l_b, u_b = run_device(False)
     l_r, u_r = run_f32_reference()
 
@@ -361,8 +454,13 @@ def test_bf16_merged_trajectory_from_the_reference_initial_state(monkeypatch):
                up_norm=(float(np.linalg.norm(u_m)), float(np.linalg.norm(u_b)), float(np.linalg.norm(u_r))),
                cos_merged_ref=cosv(u_m, u_r), cos_branch_ref=cosv(u_b, u_r), cos_merged_branch=cosv(u_m, u_b),
                max_rel_loss_gap_merged=float(np.abs(l_m - l_r).max() / np.abs(l_r).max()),
-               max_rel_loss_gap_branch=float(np.abs(l_b - l_r).max() / np.abs(l_r).max()))
-    print("\n[from-zero trajectory] (merged bf16, per-site branch bf16, f32 reference):", rep)
+               max_rel_loss_gap_branch=float(np.abs(l_b - l_r).max() / np.abs(l_r).max()),
+               round_once=dict(up_norm=float(np.linalg.norm(u_o)), cos_ref=cosv(u_o, u_r),
+                               max_rel_loss_gap=float(np.abs(l_o - l_r).max() / np.abs(l_r).max()),
+                               mean_rel_loss_gap=float(np.abs(l_o - l_r).mean() / np.abs(l_r).mean())),
+               mean_rel_loss_gap_merged=float(np.abs(l_m - l_r).mean() / np.abs(l_r).mean()),
+               mean_rel_loss_gap_branch=float(np.abs(l_b - l_r).mean() / np.abs(l_r).mean()))
+    print("\n[from-zero trajectory] (merged bf16 dithered, per-site branch bf16, f32 reference; round_once = merged, nearest even):", rep)
     # step 0: up = 0 -> the merged weight IS the frozen weight and all three forwards compute the frozen model
     assert abs(l_m[0] - l_r[0]) <= 0.01 * l_r[0] and abs(l_b[0] - l_r[0]) <= 0.01 * l_r[0]
     # the merged path may not be worse than the per-site bf16 branch path by more than these margins
