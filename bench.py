@@ -97,6 +97,77 @@ def merge_roofline(unet, iters=30):
 HBM_PEAK, MFMA_BF16_PEAK = 8.0e12, 2.5e15  # MI355X_MICROARCH.md: HBM3E spec, dense bf16 MFMA
 
 
+def _time_launch(fn, iters=20, inner=4) -> float:
+    """Average seconds of one call of ``fn`` (HIP events on the launch stream, ``inner`` back-to-back calls per pair)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / (iters * inner) * 1e-3
+
+
+def in_step_rooflines(state, fwd_bwd, latents, ehs) -> dict:
+    """The two hand-written launches INSIDE the timed step, timed live on this run's own tables (HIP events on the launch
+    stream): the in-step merge (``MergedWeights.refresh``: W_eff and W_eff^T of every site from one read of W) and the
+    factor-gradient pass (``MergedWeights.flush_factors``: pack + matrix-core pass per LDS class, re-issued on the G / X of
+    one eager step), each against its algorithmic bytes."""
+    mw = getattr(state, "merged", None)
+    if mw is None or not mw.entries:
+        return {}
+    out = {}
+    sec = _time_launch(mw.refresh)
+    byts = mw.bytes_algorithmic
+    n_t = sum(1 for e in mw.entries.values() if e["w_eff_t"] is not None)
+    out["merge"] = {"kernel": "lora_amd::merge_step_kernel<bf16,4> (W_eff + W_eff^T of %d sites (%d with a transpose), 1 launch, "
+                              "rounding %s)" % (len(mw.entries), n_t, "dither" if ops_mod().MERGE_ROUNDING == _C.ROUND_DITHER else "once"),
+                    "bound": "hbm", "algorithmic_bytes_per_launch": int(byts), "avg_launch_us": round(sec * 1e6, 2),
+                    "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(byts / sec / HBM_PEAK, 4)}
+    # factor pass: one eager forward+backward leaves the sites owed; replay the flush on the same tensors
+    state.zero_grad()
+    fwd_bwd(latents, ehs)
+    owed = list(mw._owed)
+    if owed:
+        gx = sum((st[0].numel() + st[1].numel()) * st[0].element_size() for st in owed)
+
+        # record the launches of ONE flush (tables built and uploaded once), then time re-issuing exactly those launches:
+        # the host's table building must not sit between the timed launches
+        names = ("factor_pack", "linear_bwd_factors_mfma_ragged", "linear_bwd_factors_self_ragged")
+        orig, calls = {nm: getattr(_C, nm) for nm in names}, []
+        try:
+            for nm in names:
+                setattr(_C, nm, (lambda *a, _n=nm: (calls.append((_n, a)), orig[_n](*a))[1]))
+            mw._owed = list(owed)
+            mw.flush_factors()
+        finally:
+            for nm in names:
+                setattr(_C, nm, orig[nm])
+        torch.cuda.synchronize()
+        sec = _time_launch(lambda: [orig[nm](*a) for nm, a in calls], iters=10, inner=2)
+        kinds = sorted({st[9] for st in owed})
+        out["factor_pass"] = {"kernel": "lora_amd::factors_mfma_kernel<bf16> + factor_pack (G and X of %d sites read once; passes: %s)"
+                                        % (len(owed), "+".join(kinds)),
+                              "bound": "hbm", "algorithmic_bytes_per_launch": int(gx), "avg_launch_us": round(sec * 1e6, 2),
+                              "achieved": round(gx / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(gx / sec / HBM_PEAK, 4),
+                              "launches": [nm for nm, _ in calls],
+                              "includes": "the pack launch and one pass launch per LDS class; the fold (reduce_batched) is not in it"}
+    state.reduce_pending()
+    state.zero_grad()
+    return out
+
+
+def ops_mod():
+    from lora_amd import ops
+    return ops
+
+
 def roofline_entry(flops: float, byts: float, sec: float) -> dict:
     """Which roof binds a launch of `flops` / algorithmic `byts`, and the fraction of it reached in `sec` seconds."""
     t_hbm, t_mfma = byts / HBM_PEAK, flops / MFMA_BF16_PEAK
@@ -312,14 +383,16 @@ def adapter_path_profile(step_fn, state) -> dict:
     mw = getattr(state, "merged", None)
     if mw is not None:
         byts += mw.bytes_algorithmic  # the step's one merge launch: read W, write W_eff, read the factors
-    fused_sites = sum(1 for ph, path, *_ in log_ if ph == "fwd" and not path.startswith("lib"))
+    own_sites = sum(1 for ph, path, *_ in log_ if ph == "fwd" and not (path.startswith("lib") or path.startswith("merged")))
+    merged_sites = sum(1 for ph, path, *_ in log_ if ph == "fwd" and path.startswith("merged"))
     out = {"how": "one eager step under torch.profiler (device-side kernel durations); bytes per SURVEY 8d: fused "
                   "formula where the frozen product is inside our launch, branch-only bound where it is a library GEMM",
            "gpu_ms_per_step": round(ours_us / 1e3, 3), "algorithmic_bytes_per_step": int(byts),
            "frac": round(byts / (ours_us * 1e-6) / HBM_PEAK, 4) if ours_us else None, "bound": "hbm",
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": round(byts / (ours_us * 1e-6) / 1e9, 1) if ours_us else None,
            "hostops_gpu_ms_per_step": round(host_us / 1e3, 3), "all_kernels_gpu_ms_per_step": round(total_us / 1e3, 3),
-           "sites_fwd_fused": fused_sites, "sites_fwd_total": sum(1 for ph, *_ in log_ if ph == "fwd"),
+           "sites_fwd_frozen_product_in_our_launch": own_sites, "sites_fwd_library_gemm_on_merged_weight": merged_sites,
+           "sites_fwd_total": sum(1 for ph, *_ in log_ if ph == "fwd"),
            "kernels": {k: {"calls": v[0], "us": round(v[1], 1)} for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
     return out, {f"{ph}:{path}": c for (ph, path), c in sorted(choices.items())}
 
@@ -363,6 +436,12 @@ SECONDARY = [  # (tag, extra argv, env, timeout s): driver-observed lines for th
 ]
 
 
+def _attention_choices() -> dict:
+    from lora_amd.standin import attention as _att
+
+    return {k: v for k, v in _att.choices().items()}
+
+
 def run_secondaries(budget_s: float, steps: int) -> list:
     """Each secondary line is its own `python bench.py ...` child (fresh process, GPU shared sequentially), bounded by a
     timeout and by the remaining budget; what does not fit is reported as skipped, never silently dropped."""
@@ -384,7 +463,11 @@ def run_secondaries(budget_s: float, steps: int) -> list:
             r = subprocess.run(argv, capture_output=True, text=True, timeout=min(tmo, left), env={**os.environ, **env})
             d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             rec.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
-                        "workload": d["config"].get("workload"), "wall_s": round(time.perf_counter() - t0, 1)})
+                        "workload": d["config"].get("workload"), "wall_s": round(time.perf_counter() - t0, 1),
+                        "execution": d["config"].get("execution"), "attention_kernels": d["config"].get("attention_kernels"),
+                        "merged_sites": (d["config"].get("adapter_options", {}).get("merged_weights") or {}).get("sites")})
+            if r.stderr and "capture failed" in r.stderr:
+                rec["note"] = [ln for ln in r.stderr.splitlines() if "capture failed" in ln][-1][:300]
             if "roofline" in d:
                 rec["roofline_frac"] = d["roofline"].get("frac")
         except subprocess.TimeoutExpired:
@@ -764,16 +847,20 @@ def main():
                                            "merged_weights": None if merged is None else {
                                                "sites": len(merged.entries), "merge_launches_per_step": len(merged._plans or []),
                                                "merge_bytes_per_step": merged.bytes_algorithmic,
-                                               "what": "W_eff = W + scale up down for every maskless Linear adapter, one K3 "
-                                                       "launch per step inside the timed region; forward / input gradient = "
-                                                       "frozen GEMM on W_eff, factor gradients = linear_bwd_factors_self"}},
+                                               "concatenated_groups": len(merged.groups),
+                                               "what": "W_eff = W + scale up down (and its transpose, from one read of W) for "
+                                                       "every maskless Linear adapter, one merge_step launch per step inside "
+                                                       "the timed region; forward / input gradient = frozen GEMM on it (q/k/v "
+                                                       "of a block: one GEMM on a concatenated scratch weight), factor "
+                                                       "gradients = one matrix-core pass after the backward"}},
                        "host_model_options": {"channels_last": bool(args.channels_last),
                                               "head_padded_projections": os.environ.get("LORA_AMD_HEAD_PAD") == "1",
                                               "fused_hostops": os.environ.get("LORA_AMD_HOSTOPS", "1") != "0",
                                               "miopen_find": bool(args.conv_find and on_gpu),
                                               "scope": "stand-in UNet only (lora_amd/standin); a diffusers host gets the "
                                                        "grouped q/k/v processor of diffusers_glue.py and nothing else"},
-                       "execution": mode, "channels_last": bool(args.channels_last), "host_model": host_model,
+                       "execution": mode, "attention_kernels": _attention_choices() if on_gpu else None,
+                       "channels_last": bool(args.channels_last), "host_model": host_model,
                        "device": args.device, "trainable_params": state.n,
                        "allreduce_payload_bytes": state.payload_bytes, "final_loss": round(loss_v, 5)},
         }
@@ -787,7 +874,8 @@ def main():
                                "floor_ms_at_peak": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK * 1e3, 4),
                                "frac_of_step": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK
                                                      / (out["ms_per_step"] * 1e-3), 5)}
-            pmc = os.path.join(REPO, "profiles", "r03_step_pmc.json")
+            pmc = next((p_ for p_ in (os.path.join(REPO, "profiles", f) for f in ("r04_step_pmc.json", "r03_step_pmc.json"))
+                        if os.path.exists(p_)), "")
             if os.path.exists(pmc):
                 try:
                     m = json.load(open(pmc))
@@ -796,14 +884,23 @@ def main():
                                                                                     (out["ms_per_step"] * 1e-3) / 1e9, 1),
                                             "measured_frac_of_peak": round(m["hbm_bytes_per_step"] /
                                                                            (out["ms_per_step"] * 1e-3) / HBM_PEAK, 4),
-                                            "source": "profiles/r03_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                      "summed over every dispatch of a step, separate passes)"})
+                                            "static": True,
+                                            "source": "profiles/%s: a SEPARATE rocprofv3 --pmc run of this command (FETCH_SIZE / "
+                                                      "WRITE_SIZE summed over every dispatch of a step, separate passes), "
+                                                      "divided by THIS run's step time; not measured in this run"
+                                                      % os.path.basename(pmc)})
                     if "mfma" in m:
-                        out["mfma_util"] = m["mfma"]
+                        out["mfma_util"] = dict(m["mfma"], static=True, source="profiles/%s (separate counter run)"
+                                                % os.path.basename(pmc))
                 except (KeyError, ValueError):
                     pass
         if on_gpu and not args.no_roofline:
             out["roofline"] = merge_roofline(unet)
+            if merged is not None and world == 1:
+                try:
+                    out["roofline_in_step"] = in_step_rooflines(state, fwd_bwd, latents, ehs)
+                except Exception as e:  # noqa: BLE001 - evidence, not the product
+                    log(f"[bench] in-step roofline failed: {type(e).__name__}: {e}")
             out["roofline_fused_gemm"] = gemm_roofline()
         if world == 1 and on_gpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.lora_rank)

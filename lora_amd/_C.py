@@ -83,7 +83,7 @@ class SelfSite(C.Structure):
 class FactorsMfmaPlan(C.Structure):
     _fields_ = [("supported", C.c_int32), ("lds_class", C.c_int32), ("rank_tile", C.c_int32),
                 ("rows_per_block", C.c_int32), ("nparts", C.c_int32), ("lds_bytes", C.c_int32),
-                ("blocks_per_wg", C.c_int32), ("reserved", C.c_int32),
+                ("blocks_per_wg", C.c_int32), ("a_bufs", C.c_int32),
                 ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64),
                 ("pack_up_elems", C.c_int64), ("pack_down_elems", C.c_int64)]
 
@@ -106,6 +106,8 @@ class FmSite(C.Structure):
         ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("pitch_a", C.c_int32),
         ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32),
         ("block_begin", C.c_int64),
+        ("dropout_p", C.c_float), ("a_bufs", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("offset_dev", C.c_void_p),
     ]
 
 
@@ -182,7 +184,7 @@ class WsSite(C.Structure):
     _fields_ = [("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
                 ("t_out", C.c_void_p), ("ldy", C.c_int64), ("N", C.c_int32), ("r", C.c_int32),
                 ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float),
-                ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("dropout_p", C.c_float), ("a_bufs", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("offset_dev", C.c_void_p)]
 
 
@@ -260,11 +262,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_linear_factors_self_ragged_plan.argtypes = [vp, i32, i32, C.POINTER(C.c_int64)]
     lib.lora_amd_linear_bwd_factors_self_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_linear_factors_self_ragged_plan.restype = lib.lora_amd_linear_bwd_factors_self_ragged.restype = C.c_int
-    lib.lora_amd_factors_mfma_plan.argtypes = [i64, i32, i32, i32, i32, i32, C.POINTER(FactorsMfmaPlan)]
+    lib.lora_amd_factors_mfma_plan.argtypes = [i64, i32, i32, i32, i32, i32, i32, C.POINTER(FactorsMfmaPlan)]
     lib.lora_amd_factor_pack_plan.argtypes = [C.POINTER(PackSite), i32, C.POINTER(i64)]
     lib.lora_amd_factor_pack.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_factors_mfma_ragged_plan.argtypes = [C.POINTER(FmSite), i32, i32, i32, C.POINTER(i64)]
-    lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, i32, vp]
     for name in ("lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
                  "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged"):
         getattr(lib, name).restype = C.c_int
@@ -940,15 +942,18 @@ FACTORS_MFMA = os.environ.get("LORA_AMD_FACTORS_MFMA", "1") != "0"
 _mfma_plan_cache = {}
 
 
-def factors_mfma_plan(M: int, K: int, N: int, r: int, act_dtype: torch.dtype, rows: int = 0) -> FactorsMfmaPlan:
+def factors_mfma_plan(M: int, K: int, N: int, r: int, act_dtype: torch.dtype, rows: int = 0,
+                      masked: bool = False, engine: bool = True) -> FactorsMfmaPlan:
     """Geometry of a site in the matrix-core factor pass (csrc/factor_mfma.hip): ``supported`` = 0 for f32 activations,
-    N / K not multiples of 32, rank > 16 or a row block that does not fit the LDS."""
-    key = (M, K, N, r, act_dtype, rows)
+    N / K not multiples of 32, rank > 16 or a row block that does not fit the LDS.  ``masked``: the site has dropout
+    (register-staged kernel, LDS class 1 / 2); else the engine kernel (class 3) where it fits."""
+    key = (M, K, N, r, act_dtype, rows, bool(masked), bool(engine))
     pl = _mfma_plan_cache.get(key)
     if pl is None:
         pl = FactorsMfmaPlan()
         if act_dtype in (torch.float16, torch.bfloat16):
-            _check(require().lora_amd_factors_mfma_plan(M, K, N, r, dtype_code(act_dtype), rows, C.byref(pl)),
+            _check(require().lora_amd_factors_mfma_plan(M, K, N, r, dtype_code(act_dtype), rows,
+                                                        int(bool(masked)) | (0 if engine else 2), C.byref(pl)),
                    "lora_amd_factors_mfma_plan")
         _mfma_plan_cache[key] = pl
     return pl
@@ -974,10 +979,21 @@ def factor_pack(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dt
 
 def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
     """Host half of the matrix-core pass: ``sites`` = [(g, x, pk_down, pk_up, up_part, down_part, scale, g_heads,
-    x_heads, r, plan)] of one LDS class and rank tile (``plan`` = the site's ``factors_mfma_plan``) -> (planned ctypes
+    x_heads, r, plan[, (p, seed, offset)])] of one LDS class and rank tile (``plan`` = the site's ``factors_mfma_plan``;
+    the optional last item = nn.Dropout on the branch: ``scale`` is then multiplied by 1 / (1 - p) here) -> (planned ctypes
     table, grid)."""
     arr = (FmSite * len(sites))()
-    for q, (g, x, pk_down, pk_up, up_part, down_part, scale, g_heads, x_heads, r, plan) in zip(arr, sites):
+    for q, site in zip(arr, sites):
+        g, x, pk_down, pk_up, up_part, down_part, scale, g_heads, x_heads, r, plan = site[:11]
+        drop = site[11] if len(site) > 11 else None
+        if drop is not None and drop[0] > 0.0:
+            p, seed, off = drop
+            q.dropout_p, q.seed = float(p), int(seed)
+            scale = float(scale) / (1.0 - float(p))
+            if torch.is_tensor(off):
+                q.offset, q.offset_dev = 0, off.data_ptr()
+            else:
+                q.offset, q.offset_dev = int(off), None
         q.g, q.x, q.pk_down, q.pk_up = g.data_ptr(), x.data_ptr(), pk_down.data_ptr(), pk_up.data_ptr()
         q.up_part, q.down_part = up_part.data_ptr(), down_part.data_ptr()
         q.ldg, q.ldx, q.M = g.stride(0), x.stride(0), g.shape[0]
@@ -994,9 +1010,9 @@ def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
 
 
 def linear_bwd_factors_mfma_ragged(table_dev: torch.Tensor, n: int, grid: int, lds_class: int,
-                                   act_dtype: torch.dtype) -> None:
+                                   act_dtype: torch.dtype, masked: bool = False) -> None:
     _check(require().lora_amd_linear_bwd_factors_mfma_ragged(table_dev.data_ptr(), n, grid, lds_class,
-                                                             dtype_code(act_dtype), _stream()),
+                                                             dtype_code(act_dtype), int(bool(masked)), _stream()),
            "lora_amd_linear_bwd_factors_mfma_ragged")
 
 

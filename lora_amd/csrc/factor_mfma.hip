@@ -73,7 +73,19 @@ __host__ __device__ inline int fm_pitch(int cols) {  // bytes; smallest p >= 2 c
 }
 __host__ __device__ inline int fm_tpitch(int R) { return R * 2 + 16; }
 
-__device__ __forceinline__ int fm_hchunk(int c, int hc, int hp) { return hc ? (c / hc) * hp + (c % hc) : c; }
+// chunk index of a head-padded row, branch-free (a branch around the address of a load costs its own s_waitcnt): q = c / hc by
+// a 32-bit magic multiply (exact for c < 2^16), hc = 0 (dense) has magic 0 and gives c back
+struct FmHeads { uint32_t magic; int hc, hp; };
+__device__ __forceinline__ FmHeads fm_heads(int hc, int hp) {
+  FmHeads h;
+  h.magic = hc ? (uint32_t)((0x100000000ull + hc - 1) / (uint32_t)hc) : 0u;
+  h.hc = hc; h.hp = hp;
+  return h;
+}
+__device__ __forceinline__ int fm_hchunk(int c, const FmHeads &h) {
+  const int q = (int)__umulhi((uint32_t)c, h.magic);
+  return q * h.hp + (c - q * h.hc);
+}
 
 // ---------------------------------------------------------------------------------------------------------- factor pack
 // f32 masters -> MFMA fragment order in the activation dtype, hi and lo parts:
@@ -126,6 +138,15 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
 template <class E, int NP>
 struct FmStage { mu32x4 v[NP]; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + s_barrier: hipcc drains EVERY outstanding
+// global load (s_waitcnt vmcnt(0)) before it, which would end the flight of the next chunk's / next row block's loads at
+// the first barrier after they were issued — the whole point of this kernel's pipeline is that they stay in flight across
+// the barriers until their registers are written to LDS.  All cross-wave communication here goes through LDS
+// (lgkmcnt(0) = this wave's ds_write / ds_read have completed); global stores are never read by another wave.
+__device__ __forceinline__ void fm_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Pieces (16 bytes) of a [R, c8w] tile, row-major, dealt to the threads with stride 256: piece p0 + tid + i * 256 is
 // (row, c).  One division per tile instead of one per piece.
 struct FmPieces {
@@ -149,23 +170,42 @@ struct FmPieces {
 // of the matrix (and pieces past the end of the tile) read a valid address and are zeroed.
 template <class E, int NP>
 __device__ __forceinline__ void fm_issue(FmStage<E, NP> &st, const typename E::storage *data, int64_t ld, int64_t m0,
-                                         int nrows, int p0, int c8w, int c8_0, int hc, int hp) {
+                                         int nrows, int p0, int c8w, int c8_0, const FmHeads &hd) {
   FmPieces it(p0, c8w);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const bool ok = it.row < nrows;
-    const typename E::storage *src = data + (m0 + (ok ? it.row : 0)) * ld + (int64_t)fm_hchunk(c8_0 + it.c, hc, hp) * 8;
+    const typename E::storage *src = data + (m0 + (ok ? it.row : 0)) * ld + (int64_t)fm_hchunk(c8_0 + it.c, hd) * 8;
     const mu32x4 v = *reinterpret_cast<const mu32x4 *>(src);
     st.v[i] = ok ? v : mu32x4{0u, 0u, 0u, 0u};
     it.next();
   }
 }
-template <class E, int NP>
-__device__ __forceinline__ void fm_write(const FmStage<E, NP> &st, unsigned char *buf, int pitch, int R, int p0, int c8w) {
+// nn.Dropout on the branch (lora.py:45, 57): G enters both contractions as mask (.) G.  The keep pattern of the forward is
+// regenerated here from (seed, offset) — Philox chunk = 8 consecutive elements of the dense [M, N] output, as every other
+// kernel of the library indexes it — and applied as a bit mask when the piece goes to LDS; the 1 / (1 - p) factor is folded
+// into the site's scale (both outputs are linear in G).
+struct FmDrop { bool on; uint64_t seed, off; uint32_t thr; int64_t row0; int n8, c8_0; };
+
+template <class E, int NP, bool DROP>
+__device__ __forceinline__ void fm_write(const FmStage<E, NP> &st, unsigned char *buf, int pitch, int R, int p0, int c8w,
+                                         const FmDrop &dr) {
   FmPieces it(p0, c8w);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    if (it.row < R) *reinterpret_cast<mu32x4 *>(buf + it.row * pitch + it.c * 16) = st.v[i];
+    if (it.row < R) {
+      mu32x4 v = st.v[i];
+      if constexpr (DROP) {  // straight-line: `on` only selects between the mask and all-ones
+        uint32_t rr[4];
+        Philox ph(dr.seed);
+        ph((uint64_t)((dr.row0 + it.row) * dr.n8 + dr.c8_0 + it.c), dr.off, rr);
+        const uint32_t all = dr.on ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          v[w] &= all | ((rr[w] & 0xFFFFu) >= dr.thr ? 0x0000FFFFu : 0u) | ((rr[w] >> 16) >= dr.thr ? 0xFFFF0000u : 0u);
+      }
+      *reinterpret_cast<mu32x4 *>(buf + it.row * pitch + it.c * 16) = v;
+    }
     it.next();
   }
 }
@@ -217,9 +257,7 @@ __device__ __forceinline__ void fm_phase1(mf32x4 (&acc)[kFmMaxRT16], const unsig
 //   ro < 16: 8 (ro / 4) + ro % 4        ro >= 16: 8 ((ro - 16) / 4) + 4 + ro % 4
 // (the rows a transpose read hands to lane group q: 4q..4q+3 with the first read, 16+4q..16+4q+3 with the second).
 template <class E>
-__device__ __forceinline__ void fm_combine(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, unsigned char *tt, int nrt,
-                                           int R, float scale) {
-  using S = typename E::storage;
+__device__ __forceinline__ void fm_combine_put(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, int nrt) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < kFmMaxRT16; ++t) {
@@ -228,55 +266,57 @@ __device__ __forceinline__ void fm_combine(const mf32x4 (&acc)[kFmMaxRT16], floa
       for (int g = 0; g < 4; ++g) scratch[((wave * nrt + t) * 4 + g) * 64 + lane] = acc[t][g];
     }
   }
-  __syncthreads();
+}
+// ... after a barrier: rows >= nrows (past the end of the matrix: the engine kernel's tiles repeat the last row there)
+// give T = 0
+template <class E>
+__device__ __forceinline__ void fm_combine_get(const float *scratch, unsigned char *tt, int nrt, int R, float scale, int nrows) {
+  using S = typename E::storage;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tp = fm_tpitch(R);
   for (int t = wave; t < nrt; t += 4) {
     union { S s[4]; mu32x2 u; } h, l;
+    const int jj = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += scratch[((w * nrt + t) * 4 + g) * 64 + lane];
-      v *= scale;
+      v = (t * 16 + 4 * q + g) < nrows ? v * scale : 0.f;
       h.s[g] = E::from_f(v);
       l.s[g] = E::from_f(v - E::to_f(h.s[g]));
     }
-    const int jj = lane & 15, q = lane >> 4;
     const int pos = (t >> 1) * 32 + 8 * q + 4 * (t & 1);
     *reinterpret_cast<mu32x2 *>(tt + jj * tp + pos * 2) = h.u;
     *reinterpret_cast<mu32x2 *>(tt + (16 + jj) * tp + pos * 2) = l.u;
   }
 }
+template <class E>
+__device__ __forceinline__ void fm_combine(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, unsigned char *tt, int nrt,
+                                           int R, float scale, int nrows) {
+  fm_combine_put<E>(acc, scratch, nrt);
+  fm_barrier();
+  fm_combine_get<E>(scratch, tt, nrt, R, scale, nrows);
+}
 
 // 8 contraction rows x 1 column of a row-major LDS tile as an MFMA operand: lane (q = lane / 16, i = lane % 16) gets
-// rows {32 ks + 4q + e, e < 4} and {32 ks + 16 + 4q + e} of column c0 + i.  TR: two ds_read_b64_tr_b16 (each 16-lane
+// rows {32 ks + 4q + e, e < 4} and {32 ks + 16 + 4q + e} of column c0 + i: two ds_read_b64_tr_b16 (each 16-lane
 // group reads a [4 rows][16 columns] block; lane s of the group supplies the address of row s / 4, columns 4 (s % 4) ..).
-template <class E, bool TR>
+template <class E>
 __device__ __forceinline__ typename FmMfma<E>::frag fm_colfrag(const unsigned char *buf, int pitch, int ks, int c0) {
   const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
-  if constexpr (TR) {
-    const unsigned char *p = buf + (ks * 32 + 4 * q + (i >> 2)) * pitch + (c0 + 4 * (i & 3)) * 2;
-    union { ms16x4 h[2]; mu32x4 u; } r;
-    r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p));
-    r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p + 16 * pitch));
-    return fm_frag<E>(r.u);
-  } else {
-    union { unsigned short s[8]; mu32x4 u; } r;
-    const unsigned char *p = buf + (ks * 32 + 4 * q) * pitch + (c0 + i) * 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      r.s[e] = *reinterpret_cast<const unsigned short *>(p + e * pitch);
-      r.s[4 + e] = *reinterpret_cast<const unsigned short *>(p + (16 + e) * pitch);
-    }
-    return fm_frag<E>(r.u);
-  }
+  const unsigned char *p = buf + (ks * 32 + 4 * q + (i >> 2)) * pitch + (c0 + 4 * (i & 3)) * 2;
+  union { ms16x4 h[2]; mu32x4 u; } r;
+  r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p));
+  r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p + 16 * pitch));
+  return fm_frag<E>(r.u);
 }
 
 // phase 2 of one tile [R, ncols] in LDS: out[jj][col0 + c] (+)= sum_rows T[row, jj] Data[row, c] for the tile's columns;
 // column tiles of 16 are dealt to the waves.  `tf` = the T fragments (hi, lo per 32-row k-step) in registers.
 // `accumulate`: the workgroup's earlier row blocks already left their sums in `out` (its own slab: the same lane wrote
 // the same 16 bytes; read back past the L1 with a non-temporal load, one column tile ahead of its use).
-template <class E, bool TR>
+template <class E>
 __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, int nk2, int ncols,
                                           const mu32x4 (&tf)[kFmMaxRT16], float *out, int64_t ldo, int RT, bool accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -294,7 +334,7 @@ __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, i
 #pragma unroll
     for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
       if (k2 < nk2) {
-        const typename FmMfma<E>::frag a = fm_colfrag<E, TR>(buf, pitch, k2, ct * 16);
+        const typename FmMfma<E>::frag a = fm_colfrag<E>(buf, pitch, k2, ct * 16);
         d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2]), d);
         d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2 + 1]), d);
       }
@@ -317,7 +357,7 @@ __device__ __forceinline__ void fm_load_tfrags(mu32x4 (&tf)[kFmMaxRT16], const u
   }
 }
 
-template <class E, int LDSB, bool TR>
+template <class E, int LDSB, bool DROP>
 __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfma_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
   using S = typename E::storage;
@@ -339,8 +379,8 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
   const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
   const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
-  const int hca = (ax ? q.x_head_dim : q.g_head_dim) >> 3, hpa = (ax ? q.x_head_pad : q.g_head_pad) >> 3;
-  const int hcb = (ax ? q.g_head_dim : q.x_head_dim) >> 3, hpb = (ax ? q.g_head_pad : q.x_head_pad) >> 3;
+  const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
+  const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
   const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
   float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;   // = sum over the blocks of TB^T A
   float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;   // = ... TA^T B
@@ -350,6 +390,15 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   float *scratch = reinterpret_cast<float *>(bufB);  // [4 waves][nrt][4][64] f32 <= R * pitch_b (planner)
   const int c8a = Ca >> 3, cw0 = min(CW, Cb);
   const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
+  // dropout: G is the streamed operand when X is resident, else the resident one
+  const bool drop = DROP && q.dropout_p > 0.f;
+  FmDrop dra, drb;
+  dra.on = drop && !ax; drb.on = drop && ax;
+  dra.seed = drb.seed = q.seed;
+  dra.off = drb.off = drop ? dropout_offset(q.offset, q.offset_dev) : 0;
+  dra.thr = drb.thr = (uint32_t)(q.dropout_p * 65536.0f + 0.5f);
+  dra.n8 = drb.n8 = q.N >> 3;
+  dra.c8_0 = 0;
 
   // ---- the first block's resident rows and first chunk: in flight before the first wait.  From here on the NEXT block's
   // resident rows (sa) and the next chunk (sb) are always in flight while the current ones are consumed.
@@ -358,8 +407,8 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   {
     const int64_t m0 = rb0 * R;
     const int nrows = (int)min((int64_t)R, q.M - m0);
-    fm_issue<E, NPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hca, hpa);
-    fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hcb, hpb);
+    fm_issue<E, NPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hda);
+    fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hdb);
   }
   mf32x4 acc[kFmMaxRT16];
   mu32x4 tf[kFmMaxRT16];
@@ -371,16 +420,17 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
     const bool more = blk + 1 < nblk;
     const bool accum = blk > 0;
     FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
-    fm_write<E, NPA>(sa, bufA, pa, R, 0, c8a);
-    __syncthreads();
-    if (more) fm_issue<E, NPA>(sa, da, lda, m1, nrows1, 0, c8a, 0, hca, hpa);
+    dra.row0 = drb.row0 = m0;
+    fm_write<E, NPA, DROP>(sa, bufA, pa, R, 0, c8a, dra);
+    fm_barrier();
+    if (more) fm_issue<E, NPA>(sa, da, lda, m1, nrows1, 0, c8a, 0, hda);
     // ---- TA
 #pragma unroll
     for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
     fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, splita, f0);
-    fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale);
+    fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale, nrows);
     f0 = fm_first_frags<E>(pkb, splitb, cw0 >> 5);
-    __syncthreads();  // TA visible; the scratch (= chunk buffer) is free
+    fm_barrier();  // TA visible; the scratch (= chunk buffer) is free
     fm_load_tfrags<E>(tf, ttA, R, nk2);
     // ---- B in column chunks
 #pragma unroll
@@ -388,28 +438,226 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
       const int col0 = c * CW, cw = min(CW, Cb - col0);
-      fm_write<E, kFmNPB>(sb, bufB, pb, R, 0, cw >> 3);
-      __syncthreads();
+      drb.c8_0 = col0 >> 3;
+      fm_write<E, kFmNPB, DROP>(sb, bufB, pb, R, 0, cw >> 3, drb);
+      fm_barrier();
       if (c + 1 < nch) {
         const int col1 = col0 + CW, cw1 = min(CW, Cb - col1);
-        fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hcb, hpb);
+        fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hdb);
       } else if (more) {
-        fm_issue<E, kFmNPB>(sb, db, ldb, m1, nrows1, 0, cw0 >> 3, 0, hcb, hpb);
+        fm_issue<E, kFmNPB>(sb, db, ldb, m1, nrows1, 0, cw0 >> 3, 0, hdb);
       }
       fm_phase1<E>(acc, bufB, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb, f0);
       if (c + 1 < nch) {
         const int col1 = col0 + CW;
         f0 = fm_first_frags<E>(pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
       }
-      fm_phase2<E, TR>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
-      __syncthreads();  // the chunk buffer is free
+      fm_phase2<E>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
+      fm_barrier();  // the chunk buffer is free
     }
     // ---- TB, then the resident block's column sums
-    fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale);
-    __syncthreads();
+    fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale, nrows);
+    fm_barrier();
     fm_load_tfrags<E>(tf, ttB, R, nk2);
-    fm_phase2<E, TR>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
-    __syncthreads();  // the resident buffer is free for the next block
+    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
+    fm_barrier();  // the resident buffer is free for the next block
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- the engine
+// The same pass with the HBM stream decoupled from the arithmetic: one workgroup per CU = four consumer waves (phase 1 /
+// combine / phase 2 exactly as above) + ONE loader wave that does nothing but `global_load_lds_dwordx4` (16 bytes per lane
+// straight into LDS, 1 KB per instruction, no registers) and runs ahead of the consumers.  Why a separate wave: every wave
+// has ONE in-order vmcnt counter, so in the register-staged kernel a wait for a packed factor fragment (issued late) also
+// waits for every prefetched tile issued before it — the prefetch can never stay in flight across the fragment loads.  The
+// loader wave's counter sees only tile loads; the consumers' only fragments and slab accesses.
+//   LDS (<= 160 KiB): resident block x 2 (block i + 1 lands while block i is consumed; x 1 for the 1280-wide sites),
+//   a 2-slot ring of column chunks of the streamed operand, the combine scratch, the two T images.
+//   Barrier protocol per row block (all five waves execute the same s_barrier sequence):
+//     C1 resident block landed | C2 phase-1 partials in scratch | C3 T image visible |
+//     per chunk: C4 chunk landed, C5 chunk consumed (its slot may be overwritten) | C6, C7 as C2, C3 | C8 resident consumed
+//   Loader between C4(c) and C5(c): issues the NEXT chunk (of this block, or chunk 0 of the next) into the slot freed by
+//   C5(c - 1), then 1 / nchunk of the next resident block.  Before C4(c) it waits vmcnt(n) with n = the instructions issued
+//   after chunk c (that part of the next resident block): the chunk has landed, the part stays in flight.
+//   Tiles are written lane-linearly (LDS address = base + 1024 k + 16 lane): the padded row pitch is produced by
+//   computing each lane's SOURCE address from its LDS offset (pad bytes and rows past the end of the matrix re-read a valid
+//   row; the combine step zeroes T for those rows, so they contribute nothing).
+constexpr int kFeThreads = 320;
+
+__device__ __forceinline__ void fe_glds16(const void *gsrc, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
+                                   (void __attribute__((address_space(3))) *)lds_wave_base, 16, 0, 0);
+}
+// s_waitcnt vmcnt(n) for a run-time n (0..63): the operand is an immediate
+__device__ __forceinline__ void fe_wait_vmcnt(int n) {
+#define FE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    FE_W(0) FE_W(1) FE_W(2) FE_W(3) FE_W(4) FE_W(5) FE_W(6) FE_W(7) FE_W(8) FE_W(9) FE_W(10) FE_W(11) FE_W(12) FE_W(13)
+    FE_W(14) FE_W(15) FE_W(16) FE_W(17) FE_W(18) FE_W(19) FE_W(20) FE_W(21) FE_W(22) FE_W(23) FE_W(24) FE_W(25) FE_W(26)
+    FE_W(27) FE_W(28) FE_W(29) FE_W(30) FE_W(31) FE_W(32) FE_W(33) FE_W(34) FE_W(35) FE_W(36) FE_W(37) FE_W(38) FE_W(39)
+    FE_W(40) FE_W(41) FE_W(42) FE_W(43) FE_W(44) FE_W(45) FE_W(46) FE_W(47) FE_W(48) FE_W(49) FE_W(50) FE_W(51) FE_W(52)
+    FE_W(53) FE_W(54) FE_W(55) FE_W(56) FE_W(57) FE_W(58) FE_W(59) FE_W(60) FE_W(61) FE_W(62)
+    default: break;  // 63 or more: nothing to wait for (the counter saturates at 63)
+  }
+#undef FE_W
+}
+
+// One tile [R rows][pitch bytes] of LDS, instructions [k0, k1): lane's LDS offset o = 1024 k + 16 lane -> (row, byte in row)
+// -> its source piece.  Columns: `ncol8` 16-byte pieces starting at piece c8_0 of the (possibly head-padded) row.
+template <class E>
+__device__ __forceinline__ void fe_issue(unsigned char *tile, int pitch, uint32_t pitch_magic, int R, int k0, int k1,
+                                         const typename E::storage *data, int64_t ld, int64_t m0, int nrows, int ncol8, int c8_0,
+                                         const FmHeads &hd) {
+  const int lane = threadIdx.x & 63;
+  const int total = R * pitch;
+#pragma unroll 1
+  for (int k = k0; k < k1; ++k) {
+    const int o = k * 1024 + lane * 16;
+    if (o < total) {
+      const int row = (int)__umulhi((uint32_t)o, pitch_magic);
+      const int cb = o - row * pitch;
+      const int c8 = (cb >> 4) < ncol8 ? (cb >> 4) : 0;
+      const int rowc = row < nrows ? row : nrows - 1;
+      fe_glds16(data + (m0 + rowc) * ld + (int64_t)fm_hchunk(c8_0 + c8, hd) * 8, tile + k * 1024);
+    }
+  }
+}
+
+template <class E>
+__global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kFmLdsLarge];
+  using S = typename E::storage;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_fm_site q = sites[lo];
+  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;
+  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
+  const int64_t nrb = (q.M + R - 1) / R;
+  const int64_t rb0 = sb_idx * q.blocks_per_wg;
+  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
+  const bool ax = q.resident_is_x != 0;
+  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
+  const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
+  const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
+  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
+  const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
+  const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
+  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
+  // LDS carve (every region starts on a 1 KB boundary: DMA instructions never straddle two regions)
+  const int szA = (R * pa + 1023) & ~1023, szB = (R * pb + 1023) & ~1023, nbufA = q.a_bufs;
+  unsigned char *bufA0 = lds, *ring = lds + nbufA * szA;
+  float *scratch = reinterpret_cast<float *>(ring + 2 * szB);
+  unsigned char *ttA = reinterpret_cast<unsigned char *>(scratch) + R * 256, *ttB = ttA + 32 * fm_tpitch(R);
+  const int nA = (R * pa + 1023) >> 10;                 // DMA instructions of a resident block
+  const int nApart = (nA + nch - 1) / nch;               // ... of the share issued per chunk step
+  const int c8a = Ca >> 3;
+  const uint32_t mga = (uint32_t)((0x100000000ull + pa - 1) / (uint32_t)pa), mgb = (uint32_t)((0x100000000ull + pb - 1) / (uint32_t)pb);
+  const int wave = threadIdx.x >> 6;
+
+  if (wave == 4) {
+    // ================================================================== loader wave
+    {
+      const int64_t m0 = rb0 * R;
+      const int nrows = (int)min((int64_t)R, q.M - m0);
+      fe_issue<E>(bufA0, pa, mga, R, 0, nA, da, lda, m0, nrows, c8a, 0, hda);
+      const int cw0 = min(CW, Cb);
+      fe_issue<E>(ring, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m0, nrows, cw0 >> 3, 0, hdb);
+      fe_wait_vmcnt(min((R * pb + 1023) >> 10, 63));  // the resident block has landed; chunk 0 may still fly
+    }
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int64_t m0 = (rb0 + blk) * R, m1 = m0 + R;
+      const int nrows = (int)min((int64_t)R, q.M - m0);
+      const int nrows1 = (int)min((int64_t)R, q.M - m1);
+      const bool more = blk + 1 < nblk;
+      unsigned char *bufAn = bufA0 + (nbufA == 2 ? ((blk + 1) & 1) * szA : 0);
+      fm_barrier();  // C1
+      fm_barrier();  // C2
+      fm_barrier();  // C3
+      int newer = 0;   // instructions issued after the chunk the consumers wait for next
+#pragma unroll 1
+      for (int c = 0; c < nch; ++c) {
+        fe_wait_vmcnt(min(newer, 63));
+        fm_barrier();  // C4(c): chunk c has landed
+        // ring slot = running chunk index & 1; the slot of the previous chunk (= of the next one) is free since its C5:
+        // the next tile of the stream goes there
+        unsigned char *nslot = ring + ((blk * nch + c + 1) & 1) * szB;
+        if (c + 1 < nch) {
+          const int col1 = (c + 1) * CW, cw1 = min(CW, Cb - col1);
+          fe_issue<E>(nslot, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m0, nrows, cw1 >> 3, col1 >> 3, hdb);
+        } else if (more) {
+          const int cw0 = min(CW, Cb);
+          fe_issue<E>(nslot, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m1, nrows1, cw0 >> 3, 0, hdb);
+        }
+        newer = 0;
+        if (more && nbufA == 2) {  // this step's share of the next resident block
+          const int k0 = c * nApart, k1 = min(nA, k0 + nApart);
+          fe_issue<E>(bufAn, pa, mga, R, k0, k1, da, lda, m1, nrows1, c8a, 0, hda);
+          newer = max(k1 - k0, 0);
+        }
+        fm_barrier();  // C5(c)
+      }
+      fm_barrier();  // C6
+      fm_barrier();  // C7
+      fm_barrier();  // C8: the resident buffer of block blk is free
+      if (more && nbufA == 1) fe_issue<E>(bufA0, pa, mga, R, 0, nA, da, lda, m1, nrows1, c8a, 0, hda);
+      // the next resident block must have landed before C1; the next block's chunk 0 was issued BEFORE its last share
+      // (nbufA == 2) or before the whole block (nbufA == 1), so it has landed too — its first C4 waits for nothing
+      if (more) fe_wait_vmcnt(0);
+    }
+    return;
+  }
+
+  // ==================================================================== consumer waves (threads 0..255)
+  const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
+  float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;
+  float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;
+  const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
+  const int cw0 = min(CW, Cb);
+  mf32x4 acc[kFmMaxRT16];
+  mu32x4 tf[kFmMaxRT16];
+#pragma unroll 1
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t m0 = (rb0 + blk) * R;
+    const int nrows = (int)min((int64_t)R, q.M - m0);
+    const bool accum = blk > 0;
+    const unsigned char *bufA = bufA0 + (nbufA == 2 ? (blk & 1) * szA : 0);
+    FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
+    fm_barrier();  // C1
+#pragma unroll
+    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+    fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, splita, f0);
+    fm_combine_put<E>(acc, scratch, nrt);
+    f0 = fm_first_frags<E>(pkb, splitb, cw0 >> 5);
+    fm_barrier();  // C2
+    fm_combine_get<E>(scratch, ttA, nrt, R, q.scale, nrows);
+    fm_barrier();  // C3
+    fm_load_tfrags<E>(tf, ttA, R, nk2);
+#pragma unroll
+    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      const int col0 = c * CW, cw = min(CW, Cb - col0);
+      const unsigned char *slot = ring + ((blk * nch + c) & 1) * szB;
+      fm_barrier();  // C4(c)
+      fm_phase1<E>(acc, slot, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb, f0);
+      if (c + 1 < nch) {
+        const int col1 = col0 + CW;
+        f0 = fm_first_frags<E>(pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
+      }
+      fm_phase2<E>(slot, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
+      fm_barrier();  // C5(c)
+    }
+    fm_combine_put<E>(acc, scratch, nrt);
+    fm_barrier();  // C6
+    fm_combine_get<E>(scratch, ttB, nrt, R, q.scale, nrows);
+    fm_barrier();  // C7
+    fm_load_tfrags<E>(tf, ttB, R, nk2);
+    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
+    fm_barrier();  // C8
   }
 }
 
@@ -438,6 +686,33 @@ static bool fm_fit(int64_t M, int K, int N, int r, int act_dtype, int R, int lds
   return false;
 }
 
+// The engine kernel's geometry: resident block x 2 (x 1 if two do not fit), a 2-slot ring of chunks, scratch, T images in
+// 160 KiB.  The chunk as wide as fits (fewer barriers), at most 63 DMA instructions per chunk and per share of the next
+// resident block (the loader's counted waits).
+static bool fm_fit_engine(int64_t M, int K, int N, int r, int act_dtype, int R, FmGeom *g, int *a_bufs, int nb_min = 1) {
+  if (act_dtype == LORA_AMD_F32 || M <= 0 || r < 1 || r > 16 || K % 32 || N % 32 || K < 32 || N < 32) return false;
+  if (R != 32 && R != 64) return false;
+  g->resident_is_x = K <= N;
+  const int Ca = std::min(K, N), Cb = std::max(K, N);
+  g->pitch_a = fm_pitch(Ca);
+  auto up1k = [](int b) { return (b + 1023) & ~1023; };
+  const int szA = up1k(R * g->pitch_a), fixed = R * 256 + 2 * 32 * fm_tpitch(R);
+  for (int nb = 2; nb >= nb_min; --nb) {
+    for (int cwmax = 512; cwmax >= 32; cwmax -= 32) {
+      const int nch = (Cb + cwmax - 1) / cwmax;
+      const int cw = std::min(((Cb + nch - 1) / nch + 31) / 32 * 32, cwmax);
+      const int pb = fm_pitch(cw), szB = up1k(R * pb);
+      const int nchunk = (Cb + cw - 1) / cw;
+      if (nb * szA + 2 * szB + fixed > kFmLdsLarge) continue;
+      if ((szB >> 10) > 63 || ((szA >> 10) + nchunk - 1) / nchunk > 63) continue;
+      g->R = R; g->cw = cw; g->nchunk = nchunk; g->pitch_b = pb; g->lds = nb * szA + 2 * szB + fixed;
+      *a_bufs = nb;
+      return true;
+    }
+  }
+  return false;
+}
+
 // rows per block and LDS class (1: two workgroups per CU, 2: one) of a site.  A caller's / LORA_AMD_FM_ROWS' row count is
 // tried first in both classes; default: 64 rows, then 32, two workgroups per CU before one.
 static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, FmGeom *g, int *cls) {
@@ -455,10 +730,14 @@ static int fm_rows_env() {
   static const int v = getenv("LORA_AMD_FM_ROWS") ? atoi(getenv("LORA_AMD_FM_ROWS")) : 0;
   return v;
 }
-// row blocks one workgroup walks (LORA_AMD_FM_NB, default 4): their partial sums meet in the workgroup's slab, and the next
-// block's loads are in flight while the current one is consumed
-static int fm_blocks_per_wg(int64_t nrb) {
-  static const int v = getenv("LORA_AMD_FM_NB") ? atoi(getenv("LORA_AMD_FM_NB")) : 4;
+// row blocks one workgroup walks (LORA_AMD_FM_NB): their partial sums meet in the workgroup's slab.  Register-staged
+// kernel: 1 (measured: with its loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run
+// only serialises: 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks); the engine kernel (loader wave): 8
+static int fm_blocks_per_wg(int64_t nrb, int engine, int64_t block_bytes) {
+  static const int env = getenv("LORA_AMD_FM_NB") ? atoi(getenv("LORA_AMD_FM_NB")) : 0;
+  // engine: about 640 KB of G + X per workgroup (8 blocks of a 320-wide attention site, 2 of a GEGLU site): long enough to
+  // amortise the exposed first resident block, short enough that the last workgroups do not leave the chip idle
+  const int v = env > 0 ? env : (engine ? (int)std::max<int64_t>(1, (655360 + block_bytes / 2) / block_bytes) : 1);
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
 }
 
@@ -467,18 +746,31 @@ static int fm_blocks_per_wg(int64_t nrb) {
 using namespace lora_amd;
 
 extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows,
-                                          lora_amd_factors_mfma_plan_t *out) {
+                                          int32_t flags, lora_amd_factors_mfma_plan_t *out) {
   LORA_AMD_CHECK(out != nullptr && rows >= 0 && dtype_ok(act_dtype), LORA_AMD_EINVAL, "factors_mfma_plan: bad argument");
   memset(out, 0, sizeof(*out));
   FmGeom g;
-  int cls = 0;
-  if (!fm_choose(M, K, N, r, act_dtype, rows > 0 ? rows : fm_rows_env(), &g, &cls)) return LORA_AMD_OK;
+  int cls = 0, a_bufs = 0;
+  const int hint = rows > 0 ? rows : fm_rows_env();
+  static const bool no_engine = getenv("LORA_AMD_FM_ENGINE") && atoi(getenv("LORA_AMD_FM_ENGINE")) == 0;
+  // the engine (class 3) unless the site has dropout (the mask is applied in registers: register-staged kernel) or the
+  // caller / LORA_AMD_FM_ENGINE=0 turns it off; 64 rows first (half the partial slabs), then 32
+  bool eng = false;
+  if (!(flags & 3) && !no_engine) {
+    if (hint > 0) eng = fm_fit_engine(M, K, N, r, act_dtype, hint, &g, &a_bufs);
+    // a double-buffered resident block first (the next block lands while this one is consumed), 64 rows before 32
+    for (int nb = 2; !eng && nb >= 1; --nb)
+      for (int R = 64; !eng && R >= 32; R >>= 1) eng = fm_fit_engine(M, K, N, r, act_dtype, R, &g, &a_bufs, nb) && a_bufs >= nb;
+  }
+  if (eng) cls = 3;
+  else if (!fm_choose(M, K, N, r, act_dtype, hint, &g, &cls)) return LORA_AMD_OK;
+  out->a_bufs = a_bufs;
   out->supported = 1;
   out->lds_class = cls;
   out->rank_tile = r <= 4 ? 4 : r <= 8 ? 8 : 16;
   out->rows_per_block = g.R;
   const int64_t nrb = (M + g.R - 1) / g.R;
-  out->blocks_per_wg = fm_blocks_per_wg(nrb);
+  out->blocks_per_wg = fm_blocks_per_wg(nrb, cls == 3, (int64_t)g.R * (N + K) * 2);
   out->nparts = (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
@@ -519,7 +811,7 @@ extern "C" int lora_amd_factor_pack(const lora_amd_pack_site *sites_dev, int32_t
 
 extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_t act_dtype, int32_t lds_class,
                                                  int64_t *grid) {
-  LORA_AMD_CHECK(sites && n >= 1 && grid && (lds_class == 1 || lds_class == 2), LORA_AMD_EINVAL,
+  LORA_AMD_CHECK(sites && n >= 1 && grid && lds_class >= 1 && lds_class <= 3, LORA_AMD_EINVAL,
                  "factors_mfma_ragged_plan: bad argument");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "factors_mfma_ragged_plan: f16 / bf16 activations only");
@@ -535,7 +827,12 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
                    "factors_mfma_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
     LORA_AMD_CHECK(q.g && q.x && q.pk_up && q.pk_down && q.up_part && q.down_part, LORA_AMD_EINVAL,
                    "factors_mfma_ragged_plan: site %d: null pointer", i);
-    const bool ok = fm_fit(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, lds_class == 1 ? kFmLdsSmall : kFmLdsLarge, &g);
+    int a_bufs = 0;
+    const bool ok = lds_class == 3 ? fm_fit_engine(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, &g, &a_bufs)
+                                   : fm_fit(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, lds_class == 1 ? kFmLdsSmall : kFmLdsLarge, &g);
+    LORA_AMD_CHECK(lds_class != 3 || q.dropout_p == 0.f, LORA_AMD_EINVAL,
+                   "factors_mfma_ragged_plan: site %d: a dropout site in an engine table (plan it with flags = 1)", i);
+    q.a_bufs = a_bufs;
     LORA_AMD_CHECK(ok && ((uintptr_t)q.g % 16) == 0 && ((uintptr_t)q.x % 16) == 0 && q.ldg % 8 == 0 && q.ldx % 8 == 0 &&
                        ((uintptr_t)q.pk_up % 16) == 0 && ((uintptr_t)q.pk_down % 16) == 0 &&
                        heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
@@ -554,18 +851,25 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
 }
 
 extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
-                                                       int32_t lds_class, int32_t act_dtype, void *stream) {
-  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
+                                                       int32_t lds_class, int32_t act_dtype, int32_t masked, void *stream) {
+  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && lds_class >= 1 && lds_class <= 3,
                  LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
-  // LORA_AMD_FM_GATHER=1: the column operand of phase 2 gathered with 2-byte LDS reads instead of the transpose read
-  const bool gather = getenv("LORA_AMD_FM_GATHER") && atoi(getenv("LORA_AMD_FM_GATHER")) == 1;  // read per launch (tests flip it)
+  if (lds_class == 3) {
+    LORA_AMD_CHECK(!masked, LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: the engine kernel takes no dropout sites");
+    if (act_dtype == LORA_AMD_F16)
+      hipLaunchKernelGGL(factors_mfma_engine_kernel<f16_t>, dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
+    else
+      hipLaunchKernelGGL(factors_mfma_engine_kernel<bf16_t>, dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
+    return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
+  }
+  const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
 #define FM(E, L)                                                                                                      \
   do {                                                                                                                \
-    if (gather) hipLaunchKernelGGL((factors_mfma_kernel<E, L, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    else hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    if (drop) hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    else hipLaunchKernelGGL((factors_mfma_kernel<E, L, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
   } while (0)
   if (act_dtype == LORA_AMD_F16) {
     if (lds_class == 1) FM(f16_t, kFmLdsSmall); else FM(f16_t, kFmLdsLarge);

@@ -346,8 +346,21 @@ class LoraLinearFunction(torch.autograd.Function):
                     dx2, gt = _C.linear_ws_dx(g2, weight, down_c, up_c, s, 0, p, seed, off)
                 else:
                     dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
-                _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
-                _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors", M, K, N, r)
+                # both factor gradients: deferred to the step's one-launch matrix-core pass when a trainer state runs one
+                # (T recomputed from X, the forward's dropout mask regenerated on G inside the pass), else one launch here
+                mw = getattr(getattr(sink, "owner", None), "merged", None)
+                plan_m = None
+                if (mw is not None and mw.defer_factors and _C.FACTORS_MFMA and DEFER_MASKED_FACTORS
+                        and g2.dtype in (torch.bfloat16, torch.float16)):
+                    plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype, 0, p > 0.0)
+                if plan_m is not None and plan_m.supported:
+                    key = ("mfma", M, K, N, r, int(plan_m.nparts))
+                    up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
+                    mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, None, None, "mfma", plan_m, (p, seed, off))
+                    _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors_deferred_mfma", M, K, N, r)
+                else:
+                    _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
+                    _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors", M, K, N, r)
             else:
                 _log("bwd", "g+lib+x", M, K, N, r)
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
@@ -393,6 +406,9 @@ class LoraLinearFunction(torch.autograd.Function):
 
 # Input gradients of the merged-weight sites as F.linear(G, W_eff^T-stored) instead of G @ W_eff (see MergedWeights.lookup)
 TRANSPOSED_DX = os.environ.get("LORA_AMD_TRANSPOSED_DX", "1") != "0"
+# Factor gradients of the dropout sites that run the fused MFMA input-gradient kernels: deferred to the step's matrix-core
+# pass (mask regenerated inside) instead of one linear_bwd_factors launch per site (A/B: 0)
+DEFER_MASKED_FACTORS = os.environ.get("LORA_AMD_DEFER_MASKED_FACTORS", "1") != "0"
 # q / k / v (k / v) of an attention block on ONE concatenated scratch weight: one forward GEMM per group (A/B: 0)
 CONCAT_GROUPS = os.environ.get("LORA_AMD_CONCAT_GROUPS", "1") != "0"
 # Rounding of the in-step merge of 16-bit weights (csrc/merge_step.hip): "dither" (default) = nearest with a fixed
@@ -606,8 +622,9 @@ class MergedWeights:
             plan.launch(alpha, rounding)
         self.refreshes += 1
 
-    def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind="self", plan=None) -> None:
-        self._owed.append((g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind, plan))
+    def owe(self, g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind="self", plan=None, drop=None) -> None:
+        """``drop`` = (p, seed, offset) of nn.Dropout on the site's branch (matrix-core pass only): G enters masked."""
+        self._owed.append((g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, kind, plan, drop))
 
     def _upload(self, key, raw: bytes, device, capturing: bool) -> torch.Tensor:
         """A site table -> device memory on the launch stream.  The table changes every eager step (fresh G / X
@@ -675,7 +692,8 @@ class MergedWeights:
         for st in owed:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16
-            groups.setdefault((kind, st[0].dtype, rt, int(plan.lds_class) if kind == "mfma" else 0), []).append(st)
+            masked = kind == "mfma" and st[11] is not None and st[11][0] > 0.0
+            groups.setdefault((kind, st[0].dtype, rt, (int(plan.lds_class), masked) if kind == "mfma" else 0), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
         packed = {}  # activation dtype -> packs of this flush's sites, each adapter once
         for (kind, dt, rt, cls), sites in groups.items():
@@ -689,13 +707,13 @@ class MergedWeights:
             dev0 = sites[0][0].device
             if kind == "mfma":
                 rows = []
-                for (g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, _, plan) in sites:
+                for (g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, _, plan, drop) in sites:
                     pk = self._packs_of(down, up, dt, plan)
                     rows.append((g2, x2, pk[0], pk[1], up_part, down_part, scale, g_heads, x_heads, down.shape[0],
-                                 plan))
-                arr, grid = _C.factors_mfma_table(rows, dt, cls)
+                                 plan, drop))
+                arr, grid = _C.factors_mfma_table(rows, dt, cls[0])
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
-                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls, dt)
+                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls[0], dt, cls[1])
             else:
                 arr, grid = _C.factors_self_ragged_table([st[:9] for st in sites], dt)
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)

@@ -47,7 +47,7 @@ def test_ds_read_tr16_b64_semantics(tmp_path):
 
 
 # ----------------------------------------------------------------------------- a2: the matrix-core factor pass
-def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
+def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
     """Build packs + tables for ``specs`` = [(M, K, N, gh, xh)], launch (one launch per LDS class), fold, return per-site
     (d_up, d_down, oracle d_up, oracle d_down, abs bounds, plan)."""
     name = {torch.bfloat16: "bf16", torch.float16: "f16"}[dt]
@@ -64,8 +64,9 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
             gd.view(M, gh[0], gh[2])[:, :, gh[1]:] = 7.0
         if xh:
             xd.view(M, xh[0], xh[2])[:, :, xh[1]:] = -3.0
-        plan = _C.factors_mfma_plan(M, K, N, r, dt, rows)
+        plan = _C.factors_mfma_plan(M, K, N, r, dt, rows, False, engine)
         assert plan.supported, (M, K, N)
+        assert (int(plan.lds_class) == 3) == engine
         up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
         down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
         pk_down = torch.full((int(plan.pack_down_elems),), float("nan"), dtype=dt, device=DEV)
@@ -91,7 +92,7 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
     return out
 
 
-@pytest.mark.parametrize("gather", [0, 1])
+@pytest.mark.parametrize("engine", [True, False])
 @pytest.mark.parametrize("M,K,N,r,dt,gh,xh,rows", [
     (16384, 320, 320, 4, torch.bfloat16, None, None, 0), (4096, 640, 640, 8, torch.bfloat16, None, None, 0),
     (1024, 1280, 1280, 16, torch.bfloat16, None, None, 0), (256, 1280, 1280, 4, torch.float16, None, None, 0),
@@ -100,28 +101,61 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
     (2048, 320, 320, 16, torch.bfloat16, None, (8, 40, 64), 0), (777, 64, 96, 4, torch.bfloat16, None, None, 0),
     (4096, 640, 640, 4, torch.bfloat16, None, None, 64), (5000, 320, 320, 4, torch.bfloat16, None, None, 32),
     (333, 768, 768, 8, torch.bfloat16, None, None, 0)])
-def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows, gather, monkeypatch):
+def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows, engine):
     """autograd of lora.py:53-58 for the factors (dB = s G^T (X A^T), dA = (s G B)^T X) through
     lora_amd_factor_pack + lora_amd_linear_bwd_factors_mfma_ragged vs oracle.lora_linear_backward; resident X and
-    resident G sites, chunked wide operands, both LDS classes, head-padded rows, a ragged last row block, f16; ``gather``
-    = the column operand gathered with 2-byte LDS reads instead of the transpose read.  f32-grade tolerance (the 16-bit
-    factor / T operands are split hi + lo)."""
-    monkeypatch.setenv("LORA_AMD_FM_GATHER", str(gather))
-    (o,) = _fm_run([(M, K, N, gh, xh)], r, 0.7, dt, rows)
+    resident G sites, chunked wide operands, head-padded rows, a ragged last row block, f16 — on the engine kernel (loader
+    wave + LDS DMA, several row blocks per workgroup accumulating in its slab) and on the register-staged kernel (both
+    LDS classes).  f32-grade tolerance (the 16-bit factor / T operands are split hi + lo)."""
+    (o,) = _fm_run([(M, K, N, gh, xh)], r, 0.7, dt, rows, engine)
     if rows:
         assert o["plan"].rows_per_block == rows
     close(o["d_up"], o["duo"], o["absu"], "f32", k=1e-4, msg="dUp")
     close(o["d_down"], o["ddo"], o["absd"], "f32", k=1e-4, msg="dDown")
 
 
-def test_factors_mfma_one_launch_for_several_sites_vs_oracle():
+@pytest.mark.parametrize("engine", [True, False])
+def test_factors_mfma_one_launch_for_several_sites_vs_oracle(engine):
     """Several sites of different shapes, LDS classes and layouts through ONE pack launch and one pass launch per class."""
     specs = [(4096, 320, 320, None, None), (1000, 640, 640, None, None), (2048, 320, 320, (8, 40, 64), None),
              (2048, 320, 320, None, (8, 40, 64)), (308, 768, 1280, None, None), (512, 320, 2560, None, None),
              (100, 1280, 1280, None, None), (1, 320, 320, None, None)]
-    for o in _fm_run(specs, 4, 0.9):
+    for o in _fm_run(specs, 4, 0.9, engine=engine):
         close(o["d_up"], o["duo"], o["absu"], "f32", k=1e-4, msg=f"dUp {o['N']}x{o['K']}")
         close(o["d_down"], o["ddo"], o["absd"], "f32", k=1e-4, msg=f"dDown {o['N']}x{o['K']}")
+
+
+@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2000, 640, 320, 4, 0.25), (308, 768, 1280, 8, 0.1)])
+def test_factors_mfma_pass_with_dropout_vs_oracle(M, K, N, r, p):
+    """nn.Dropout on the branch (lora.py:45, 57) in the matrix-core pass: G enters as mask (.) G with the mask regenerated
+    from (seed, offset_dev) inside the kernel (G resident, G streamed), 1 / (1 - p) folded into the scale — vs
+    oracle.lora_linear_backward(mask=) with the mask tests/helpers.philox_dropout_mask restates."""
+    dt, s_, seed = torch.bfloat16, 0.8, 0x5EED1234
+    off = torch.tensor([(1 << 33) + 12345], dtype=torch.int64, device=DEV)
+    x, g = rnd((M, K), "bf16", seed=1), rnd((M, N), "bf16", seed=2)
+    down, up = rnd((r, K), "f32", 0.2, seed=3), rnd((N, r), "f32", 0.3, seed=4)
+    mask = H.philox_dropout_mask(M * N, p, seed, int(off.item())).view(M, N).numpy()
+    X, G, A, U = n(x), n(g), n(down), n(up)
+    _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s_, None, mask)
+    plan = _C.factors_mfma_plan(M, K, N, r, dt, 0, True)
+    assert plan.supported and plan.lds_class in (1, 2)
+    up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
+    down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
+    pk_down = torch.empty(int(plan.pack_down_elems), dtype=dt, device=DEV)
+    pk_up = torch.empty(int(plan.pack_up_elems), dtype=dt, device=DEV)
+    arr, total = _C.factor_pack_table([(down, up, pk_down, pk_up)])
+    _C.factor_pack(_C.table_to_device(arr, DEV), 1, total, dt)
+    arr, grid = _C.factors_mfma_table([(g, x, pk_down, pk_up, up_part, down_part, s_, None, None, r, plan, (p, seed, off))],
+                                      dt, int(plan.lds_class))
+    _C.linear_bwd_factors_mfma_ragged(_C.table_to_device(arr, DEV), 1, grid, int(plan.lds_class), dt, True)
+    d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+    table, cnt, total = _C.make_reduce_table(
+        [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+         (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)], DEV)
+    _C.reduce_batched(table, cnt, total)
+    Gm = np.abs(G) * mask
+    close(n(d_up), duo, s_ * (Gm.T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
+    close(n(d_down), ddo, (s_ * Gm @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
 
 
 def test_philox_restatement_equals_the_kernels_dropout_mask():
@@ -333,7 +367,8 @@ def test_consecutive_optimizer_steps_on_the_timed_merged_path_vs_oracle(sd15_thr
                 if tuple(e["w_eff"].shape) != tuple(m.linear.weight.shape) or checked >= 12:
                     continue  # head-padded layouts: covered per site by test_merged_weight_adapter_forward_backward_vs_oracle
                 want = (m.linear.weight.float() + float(m.scale) * (m.lora_up.weight.float() @ m.lora_down.weight.float()))
-                assert (e["w_eff"].float() - want).abs().max() <= 2.0 ** -8 * want.abs().max(), (k, tuple(want.shape))
+                # one rounding to bf16, dithered: within one ulp
+                assert (e["w_eff"].float() - want).abs().max() <= 2.0 ** -7 * want.abs().max(), (k, tuple(want.shape))
                 if e["w_eff_t"] is not None and tuple(e["w_eff_t"].shape) == tuple(want.t().shape):
                     assert torch.equal(e["w_eff_t"], e["w_eff"].t())
                 checked += 1
