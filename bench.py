@@ -766,15 +766,20 @@ def main():
             mode, runner = "eager", fwd_bwd
             state.zero_grad()
 
+    tail_host = []  # host seconds spent ENQUEUEING the eager tail of a step (all-reduce + clip + AdamW: three launches)
+
     def step():
         loss = runner(latents, ehs)
+        t_h = time.perf_counter()
         scale = state.all_reduce()
         state.step(scale)
+        tail_host.append(time.perf_counter() - t_h)
         return loss
 
     for _ in range(args.warmup):
         step()
     barrier()
+    tail_host.clear()
     if rank == 0 and on_gpu:  # which kernels the per-shape tuning settled on (stderr; the JSON line stays alone on stdout)
         from lora_amd.standin import attention as _att
 
@@ -841,6 +846,11 @@ def main():
                        "VAE encode and CLIP forward (ref :818-840) are outside it: latents and text states are the "
                        "synthetic inputs SURVEY 8d prescribes (cached_latents-style)",
                        "allreduce_us": allreduce_us,
+                       "eager_tail": {"what": "the part of a step outside the captured hipGraph: ONE all-reduce of the flat "
+                                              "gradient + sumsq + clip/AdamW (three launches), enqueued by the host while the "
+                                              "graph's kernels still run",
+                                      "host_enqueue_us_per_step": round(sum(tail_host) / max(len(tail_host), 1) * 1e6, 1),
+                                      "frac_of_step": round(sum(tail_host) / max(len(tail_host), 1) / (dt / args.steps), 5)},
                        "kernel_choices": kernel_choices,
                        "adapter_options": {"grouped_qkv_one_launch": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
                                            "adapters": args.adapters,

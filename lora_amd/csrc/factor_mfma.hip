@@ -523,49 +523,93 @@ __device__ __forceinline__ void fe_issue(unsigned char *tile, int pitch, uint32_
   }
 }
 
-template <class E>
-__global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[kFmLdsLarge];
-  using S = typename E::storage;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+// The loader's inner loop must be SHORT: measured with the per-instruction address arithmetic above (two magic divisions,
+// a 64-bit row multiply, the exec mask: ~50 instructions, several quarter-rate) the loader wave needed ~27 us per 82 KB row
+// block and the whole engine ran at 0.18 of the byte roof — the loader, not HBM, was the bottleneck.  A lane's piece of
+// instruction k is the same in every full row block: its element offset from the block's first row is computed ONCE per
+// workgroup into registers; issuing is then one 64-bit add + the DMA per instruction.  (Rows past the end of the matrix —
+// the last block of a site only — and chunks that do not start on a head boundary take the slow path above.)
+template <int NK>
+struct FeOffs { uint32_t o[NK]; };
+
+template <int NK>
+__device__ __forceinline__ void fe_offsets(FeOffs<NK> &f, int pitch, uint32_t pitch_magic, int R, int64_t ld, int ncol8,
+                                           const FmHeads &hd) {
+  const int lane = threadIdx.x & 63;
+  const int total = R * pitch;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int o = k * 1024 + lane * 16;
+    const int row = (int)__umulhi((uint32_t)o, pitch_magic);
+    const int cb = o - row * pitch;
+    const int c8 = (cb >> 4) < ncol8 ? (cb >> 4) : 0;
+    // lanes past the end of the tile (last instruction only) re-read piece 0: their 16 bytes land in the region's 1 KB
+    // rounding, which nothing reads — no per-lane predicate in the issue loop
+    f.o[k] = o < total ? (uint32_t)(row * (int)ld + fm_hchunk(c8, hd) * 8) * (uint32_t)sizeof(uint16_t) : 0u;  // bytes
   }
-  const lora_amd_fm_site q = sites[lo];
-  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;
-  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
+}
+template <class E, int NK>
+__device__ __forceinline__ void fe_issue_fast(unsigned char *tile, const FeOffs<NK> &f, int k0, int k1,
+                                              const typename E::storage *base) {
+  k0 = __builtin_amdgcn_readfirstlane(k0);  // wave-uniform by construction: keep the loop control on the scalar unit
+  k1 = __builtin_amdgcn_readfirstlane(k1);
+  // the block's base address as a SCALAR pair + the lane's 32-bit byte offset: the saddr form of global_load_lds (no 64-bit
+  // per-lane address arithmetic, the offset table stays 32-bit)
+  const uint64_t b64 = reinterpret_cast<uint64_t>(base);
+  const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+  const char *sbase = reinterpret_cast<const char *>(sb);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    if (k >= k0 && k < k1) fe_glds16(sbase + f.o[k], tile + k * 1024);
+  }
+}
+
+constexpr int kFeNKA = 44, kFeNKB = 32;  // most DMA instructions of a resident block / of a chunk (planner): their offsets
+                                         // live in the loader's registers (5 waves per workgroup: 256 registers per wave)
+
+// The loader wave's program, kept out of line: its register file (the two offset tables) is allocated apart from the
+// consumers' accumulators (inlined into the kernel the two lived side by side: 256 registers + spills).
+template <class E>
+__device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, unsigned char *lds, int64_t sb_idx) {
+  using S = typename E::storage;
+  const int R = q.rows_per_block;
   const int64_t nrb = (q.M + R - 1) / R;
   const int64_t rb0 = sb_idx * q.blocks_per_wg;
   const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
   const bool ax = q.resident_is_x != 0;
-  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
   const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
   const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
   const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
   const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
   const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
   const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
-  // LDS carve (every region starts on a 1 KB boundary: DMA instructions never straddle two regions)
   const int szA = (R * pa + 1023) & ~1023, szB = (R * pb + 1023) & ~1023, nbufA = q.a_bufs;
   unsigned char *bufA0 = lds, *ring = lds + nbufA * szA;
-  float *scratch = reinterpret_cast<float *>(ring + 2 * szB);
-  unsigned char *ttA = reinterpret_cast<unsigned char *>(scratch) + R * 256, *ttB = ttA + 32 * fm_tpitch(R);
-  const int nA = (R * pa + 1023) >> 10;                 // DMA instructions of a resident block
-  const int nApart = (nA + nch - 1) / nch;               // ... of the share issued per chunk step
-  const int c8a = Ca >> 3;
+  const int nA = (R * pa + 1023) >> 10, nApart = (nA + nch - 1) / nch, c8a = Ca >> 3;
   const uint32_t mga = (uint32_t)((0x100000000ull + pa - 1) / (uint32_t)pa), mgb = (uint32_t)((0x100000000ull + pb - 1) / (uint32_t)pb);
-  const int wave = threadIdx.x >> 6;
-
-  if (wave == 4) {
-    // ================================================================== loader wave
+    const int nB = (R * pb + 1023) >> 10;
+    FeOffs<kFeNKA> offa;
+    FeOffs<kFeNKB> offb;
+    fe_offsets<kFeNKA>(offa, pa, mga, R, lda, c8a, hda);
+    fe_offsets<kFeNKB>(offb, pb, mgb, R, ldb, CW >> 3, hdb);
+    // a chunk's pieces are the first chunk's shifted by the chunk's first column — if the chunk starts on a head boundary
+    // (or the rows are dense); the last chunk may be narrower than CW: its surplus columns would read past the row
+    const bool bfast = (hdb.hc == 0 || (CW >> 3) % hdb.hc == 0) && Cb % CW == 0;
+    auto issue_a = [&](unsigned char *tile, int k0, int k1, int64_t m0, int nrows) {
+      if (nrows == R) fe_issue_fast<E, kFeNKA>(tile, offa, k0, k1, da + m0 * lda);
+      else fe_issue<E>(tile, pa, mga, R, k0, k1, da, lda, m0, nrows, c8a, 0, hda);
+    };
+    auto issue_b = [&](unsigned char *tile, int64_t m0, int nrows, int col0, int cw) {
+      if (nrows == R && bfast) fe_issue_fast<E, kFeNKB>(tile, offb, 0, nB, db + m0 * ldb + (int64_t)fm_hchunk(col0 >> 3, hdb) * 8);
+      else fe_issue<E>(tile, pb, mgb, R, 0, nB, db, ldb, m0, nrows, cw >> 3, col0 >> 3, hdb);
+    };
     {
       const int64_t m0 = rb0 * R;
       const int nrows = (int)min((int64_t)R, q.M - m0);
-      fe_issue<E>(bufA0, pa, mga, R, 0, nA, da, lda, m0, nrows, c8a, 0, hda);
-      const int cw0 = min(CW, Cb);
-      fe_issue<E>(ring, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m0, nrows, cw0 >> 3, 0, hdb);
-      fe_wait_vmcnt(min((R * pb + 1023) >> 10, 63));  // the resident block has landed; chunk 0 may still fly
+      issue_a(bufA0, 0, nA, m0, nrows);
+      issue_b(ring, m0, nrows, 0, min(CW, Cb));
+      fe_wait_vmcnt(min(nB, 63));  // the resident block has landed; chunk 0 may still fly
     }
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
@@ -586,16 +630,15 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
         // the next tile of the stream goes there
         unsigned char *nslot = ring + ((blk * nch + c + 1) & 1) * szB;
         if (c + 1 < nch) {
-          const int col1 = (c + 1) * CW, cw1 = min(CW, Cb - col1);
-          fe_issue<E>(nslot, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m0, nrows, cw1 >> 3, col1 >> 3, hdb);
+          const int col1 = (c + 1) * CW;
+          issue_b(nslot, m0, nrows, col1, min(CW, Cb - col1));
         } else if (more) {
-          const int cw0 = min(CW, Cb);
-          fe_issue<E>(nslot, pb, mgb, R, 0, (R * pb + 1023) >> 10, db, ldb, m1, nrows1, cw0 >> 3, 0, hdb);
+          issue_b(nslot, m1, nrows1, 0, min(CW, Cb));
         }
         newer = 0;
         if (more && nbufA == 2) {  // this step's share of the next resident block
           const int k0 = c * nApart, k1 = min(nA, k0 + nApart);
-          fe_issue<E>(bufAn, pa, mga, R, k0, k1, da, lda, m1, nrows1, c8a, 0, hda);
+          issue_a(bufAn, k0, k1, m1, nrows1);
           newer = max(k1 - k0, 0);
         }
         fm_barrier();  // C5(c)
@@ -603,11 +646,42 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
       fm_barrier();  // C6
       fm_barrier();  // C7
       fm_barrier();  // C8: the resident buffer of block blk is free
-      if (more && nbufA == 1) fe_issue<E>(bufA0, pa, mga, R, 0, nA, da, lda, m1, nrows1, c8a, 0, hda);
+      if (more && nbufA == 1) issue_a(bufA0, 0, nA, m1, nrows1);
       // the next resident block must have landed before C1; the next block's chunk 0 was issued BEFORE its last share
       // (nbufA == 2) or before the whole block (nbufA == 1), so it has landed too — its first C4 waits for nothing
       if (more) fe_wait_vmcnt(0);
     }
+}
+
+template <class E>
+__global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kFmLdsLarge];
+  using S = typename E::storage;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_fm_site q = sites[lo];
+  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;
+  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
+  const int64_t nrb = (q.M + R - 1) / R;
+  const int64_t rb0 = sb_idx * q.blocks_per_wg;
+  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
+  const bool ax = q.resident_is_x != 0;
+  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
+  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
+  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
+  // LDS carve (every region starts on a 1 KB boundary: DMA instructions never straddle two regions)
+  const int szA = (R * pa + 1023) & ~1023, szB = (R * pb + 1023) & ~1023, nbufA = q.a_bufs;
+  unsigned char *bufA0 = lds, *ring = lds + nbufA * szA;
+  float *scratch = reinterpret_cast<float *>(ring + 2 * szB);
+  unsigned char *ttA = reinterpret_cast<unsigned char *>(scratch) + R * 256, *ttB = ttA + 32 * fm_tpitch(R);
+  const int c8a = Ca >> 3;
+  const int wave = threadIdx.x >> 6;
+
+  if (wave == 4) {  // the loader wave
+    fe_loader<E>(q, lds, sb_idx);
     return;
   }
 
@@ -704,7 +778,7 @@ static bool fm_fit_engine(int64_t M, int K, int N, int r, int act_dtype, int R, 
       const int pb = fm_pitch(cw), szB = up1k(R * pb);
       const int nchunk = (Cb + cw - 1) / cw;
       if (nb * szA + 2 * szB + fixed > kFmLdsLarge) continue;
-      if ((szB >> 10) > 63 || ((szA >> 10) + nchunk - 1) / nchunk > 63) continue;
+      if ((szB >> 10) > kFeNKB || (szA >> 10) > kFeNKA) continue;
       g->R = R; g->cw = cw; g->nchunk = nchunk; g->pitch_b = pb; g->lds = nb * szA + 2 * szB + fixed;
       *a_bufs = nb;
       return true;

@@ -739,3 +739,26 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
     assert cos >= 0.99, cos
     na, nb = float(np.linalg.norm(flat)), float(np.sqrt(sum(float(g_ @ g_) for g_ in g_ref)))
     assert abs(na - nb) <= 0.1 * nb, (na, nb)
+
+
+# ----------------------------------------------------------------------------- multi-GPU: the bench line over RCCL
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on this node (the driver's 8-GPU box runs it)")
+def test_bench_two_rccl_ranks_print_one_line():
+    """`python bench.py --gpus 2` on a node with >= 2 GPUs: self-launched ranks (torch.distributed.run, 127.0.0.1), backend
+    nccl = RCCL, the headline workload sharded by rank, ONE all-reduce of the flat gradient per step, rank 0's JSON line with
+    n_gpus 2, weak scaling, the all-reduce timed on its real payload and the eager tail's host cost below 1 % of the step."""
+    import json
+
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-secondary", "--no-roofline"], capture_output=True, text=True, timeout=1500,
+                       env=env, cwd=H.REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 8 and d["config"]["allreduce_us"] > 0 and "backend nccl" in r.stderr
+    assert d["config"]["eager_tail"]["frac_of_step"] < 0.01

@@ -92,3 +92,5 @@ def test_bench_self_launch_runs_two_gloo_ranks_end_to_end():
     assert d["config"]["allreduce_payload_bytes"] == 4 * d["config"]["trainable_params"]
     assert d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
     assert "backend gloo" in r.stderr
+    # the part of a step outside the graph (one all-reduce + clip + AdamW) is reported with its host cost
+    assert d["config"]["eager_tail"]["host_enqueue_us_per_step"] > 0 and 0 < d["config"]["eager_tail"]["frac_of_step"] < 1
