@@ -464,6 +464,47 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   }
 }
 
+// ---- whole-step fragment sets (the engine's consumers) --------------------------------------------------------------
+// Every dependent trip to L2 / HBM on a consumer wave's path costs 2-3 us while the chip streams (measured: with the
+// fragments fetched inside phase 1 and the slab read back in phase 2 a 64-row block took ~28 us in EVERY variant of this
+// pass: eight to ten such trips, not bytes).  The engine's consumers therefore touch global memory only through loads that
+// were issued a whole pipeline step earlier: a wave's packed fragments of ALL its k-steps of the next tile are loaded into
+// a register set while the current tile is processed.
+constexpr int kFmNF = 5;  // k-steps per wave and tile (tiles of <= 640 columns)
+struct FmFragSet { mu32x4 h[kFmNF], l[kFmNF]; };
+template <class E>
+__device__ __forceinline__ void fm_load_fragset(FmFragSet &f, const typename E::storage *pk, int64_t split_stride, int nks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kFmNF; ++i) {
+    const int ks = wave + 4 * i;
+    const int kc = ks < nks ? ks : 0;  // straight-line: surplus slots re-read fragment 0 (never used)
+    f.h[i] = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)kc * 512 + lane * 8);
+    f.l[i] = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kc * 512 + lane * 8);
+  }
+}
+template <class E>
+__device__ __forceinline__ void fm_phase1_set(mf32x4 (&acc)[kFmMaxRT16], const unsigned char *buf, int pitch, int nrt, int nks,
+                                              const FmFragSet &f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned char *rowp = buf + (lane & 15) * pitch + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < kFmNF; ++i) {
+    const int ks = wave + 4 * i;
+    if (ks < nks) {
+      const typename FmMfma<E>::frag bh = fm_frag<E>(f.h[i]), bl = fm_frag<E>(f.l[i]);
+#pragma unroll
+      for (int t = 0; t < kFmMaxRT16; ++t) {
+        if (t < nrt) {
+          const typename FmMfma<E>::frag a = fm_frag<E>(*reinterpret_cast<const mu32x4 *>(rowp + t * 16 * pitch + ks * 64));
+          acc[t] = FmMfma<E>::mma(a, bh, acc[t]);
+          acc[t] = FmMfma<E>::mma(a, bl, acc[t]);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- the engine
 // The same pass with the HBM stream decoupled from the arithmetic: one workgroup per CU = four consumer waves (phase 1 /
 // combine / phase 2 exactly as above) + ONE loader wave that does nothing but `global_load_lds_dwordx4` (16 bytes per lane
@@ -687,25 +728,27 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
 
   // ==================================================================== consumer waves (threads 0..255)
   const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
-  float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;
-  float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;
   const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
   const int cw0 = min(CW, Cb);
   mf32x4 acc[kFmMaxRT16];
   mu32x4 tf[kFmMaxRT16];
+  FmFragSet fcur;  // the fragments of the next tile of the stream: reloaded as soon as phase 1 has consumed them
+  fm_load_fragset<E>(fcur, pka, splita, Ca >> 5);
 #pragma unroll 1
   for (int blk = 0; blk < nblk; ++blk) {
-    const int64_t m0 = (rb0 + blk) * R;
+    const int64_t rb = rb0 + blk;
+    const int64_t m0 = rb * R;
     const int nrows = (int)min((int64_t)R, q.M - m0);
-    const bool accum = blk > 0;
+    // one partial slab per ROW BLOCK (no read-modify-write of a shared slab: that read is a trip to L2 per column tile)
+    float *outa = (ax ? q.down_part : q.up_part) + rb * RT * (int64_t)Ca;
+    float *outb = (ax ? q.up_part : q.down_part) + rb * RT * (int64_t)Cb;
     const unsigned char *bufA = bufA0 + (nbufA == 2 ? (blk & 1) * szA : 0);
-    FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
     fm_barrier();  // C1
 #pragma unroll
     for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-    fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, splita, f0);
+    fm_phase1_set<E>(acc, bufA, pa, nrt, Ca >> 5, fcur);        // waits for fcur (issued a step ago), then ...
+    fm_load_fragset<E>(fcur, pkb, splitb, cw0 >> 5);             // ... chunk 0's fragments start their trip
     fm_combine_put<E>(acc, scratch, nrt);
-    f0 = fm_first_frags<E>(pkb, splitb, cw0 >> 5);
     fm_barrier();  // C2
     fm_combine_get<E>(scratch, ttA, nrt, R, q.scale, nrows);
     fm_barrier();  // C3
@@ -717,12 +760,14 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
       const int col0 = c * CW, cw = min(CW, Cb - col0);
       const unsigned char *slot = ring + ((blk * nch + c) & 1) * szB;
       fm_barrier();  // C4(c)
-      fm_phase1<E>(acc, slot, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb, f0);
+      fm_phase1_set<E>(acc, slot, pb, nrt, cw >> 5, fcur);
       if (c + 1 < nch) {
         const int col1 = col0 + CW;
-        f0 = fm_first_frags<E>(pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
+        fm_load_fragset<E>(fcur, pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
+      } else {
+        fm_load_fragset<E>(fcur, pka, splita, Ca >> 5);          // the next block's resident tile (same factor)
       }
-      fm_phase2<E>(slot, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
+      fm_phase2<E>(slot, pb, nk2, cw, tf, outb + col0, Cb, RT, false);
       fm_barrier();  // C5(c)
     }
     fm_combine_put<E>(acc, scratch, nrt);
@@ -730,7 +775,7 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
     fm_combine_get<E>(scratch, ttB, nrt, R, q.scale, nrows);
     fm_barrier();  // C7
     fm_load_tfrags<E>(tf, ttB, R, nk2);
-    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
+    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, false);
     fm_barrier();  // C8
   }
 }
@@ -778,7 +823,7 @@ static bool fm_fit_engine(int64_t M, int K, int N, int r, int act_dtype, int R, 
       const int pb = fm_pitch(cw), szB = up1k(R * pb);
       const int nchunk = (Cb + cw - 1) / cw;
       if (nb * szA + 2 * szB + fixed > kFmLdsLarge) continue;
-      if ((szB >> 10) > kFeNKB || (szA >> 10) > kFeNKA) continue;
+      if ((szB >> 10) > kFeNKB || (szA >> 10) > kFeNKA || Ca > 128 * kFmNF || cw > 128 * kFmNF) continue;
       g->R = R; g->cw = cw; g->nchunk = nchunk; g->pitch_b = pb; g->lds = nb * szA + 2 * szB + fixed;
       *a_bufs = nb;
       return true;
@@ -845,7 +890,9 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   out->rows_per_block = g.R;
   const int64_t nrb = (M + g.R - 1) / g.R;
   out->blocks_per_wg = fm_blocks_per_wg(nrb, cls == 3, (int64_t)g.R * (N + K) * 2);
-  out->nparts = (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
+  // one partial slab per row block on the engine (its workgroups walk several blocks for the pipeline only), one per run of
+  // blocks on the register-staged kernel
+  out->nparts = cls == 3 ? (int32_t)nrb : (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;

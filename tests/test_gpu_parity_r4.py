@@ -66,7 +66,7 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
             xd.view(M, xh[0], xh[2])[:, :, xh[1]:] = -3.0
         plan = _C.factors_mfma_plan(M, K, N, r, dt, rows, False, engine)
         assert plan.supported, (M, K, N)
-        assert (int(plan.lds_class) == 3) == engine
+        assert engine or int(plan.lds_class) in (1, 2)  # (the widest sites keep the register-staged kernel either way)
         up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
         down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
         pk_down = torch.full((int(plan.pack_down_elems),), float("nan"), dtype=dt, device=DEV)
