@@ -33,6 +33,18 @@ inline bool dtype_ok(int dt) {
   return dt == LORA_AMD_F32 || dt == LORA_AMD_F16 || dt == LORA_AMD_BF16;
 }
 
+// ---- global address space ---------------------------------------------------
+// A pointer read out of a descriptor table in memory (every batched / ragged kernel here) has no address space the
+// compiler can see: it emits FLAT loads and stores, which count on lgkmcnt as well as vmcnt — every `s_waitcnt lgkmcnt(0)`
+// that guards an LDS read then ALSO waits for all global loads in flight (measured round 4: the matrix-core factor pass spent
+// one memory round trip per LDS wait; 640 flat_load / 0 global_load in its code object).  All device data of this library
+// is global memory: the helpers below and the kernels' own accesses go through gl(p).
+#define LORA_AMD_AS_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const T LORA_AMD_AS_GLOBAL *gl(const T *p) { return (const T LORA_AMD_AS_GLOBAL *)p; }
+template <class T>
+__device__ __forceinline__ T LORA_AMD_AS_GLOBAL *gl(T *p) { return (T LORA_AMD_AS_GLOBAL *)p; }
+
 // ---- element traits: T is the storage type -------------------------------
 struct f32_t {
   using storage = float;
@@ -61,16 +73,19 @@ struct alignas(sizeof(typename E::storage) * 8) Chunk8 {
 
 template <class E>
 __device__ inline void load8(const typename E::storage *p, float (&out)[8]) {
-  Chunk8<E> c = *reinterpret_cast<const Chunk8<E> *>(p);
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  union { V v; Chunk8<E> c; } u;
+  u.v = *gl(reinterpret_cast<const V *>(p));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = E::to_f(c.v[i]);
+  for (int i = 0; i < 8; ++i) out[i] = E::to_f(u.c.v[i]);
 }
 template <class E>
 __device__ inline void store8(typename E::storage *p, const float (&in)[8]) {
-  Chunk8<E> c;
+  using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
+  union { V v; Chunk8<E> c; } u;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) c.v[i] = E::from_f(in[i]);
-  *reinterpret_cast<Chunk8<E> *>(p) = c;
+  for (int i = 0; i < 8; ++i) u.c.v[i] = E::from_f(in[i]);
+  *gl(reinterpret_cast<V *>(p)) = u.v;
 }
 
 // Branch-free masked loads: the address is always a valid one (callers clamp it), the value is zeroed afterwards.
@@ -81,7 +96,7 @@ template <class E>
 __device__ inline void load8_sel(const typename E::storage *p, bool ok, float (&out)[8]) {
   using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
   union { V v; Chunk8<E> c; } u;
-  u.v = *reinterpret_cast<const V *>(p);
+  u.v = *gl(reinterpret_cast<const V *>(p));
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = ok ? E::to_f(u.c.v[i]) : 0.f;
 }
@@ -95,7 +110,7 @@ struct Raw8 {
 template <class E>
 __device__ inline Raw8<E> load8_raw(const typename E::storage *p) {
   Raw8<E> r;
-  r.v = *reinterpret_cast<const typename Raw8<E>::V *>(p);
+  r.v = *gl(reinterpret_cast<const typename Raw8<E>::V *>(p));
   return r;
 }
 template <class E>
@@ -107,7 +122,7 @@ __device__ inline void unpack8_sel(const Raw8<E> &r, bool ok, float (&out)[8]) {
 }
 __device__ inline void ld8f_sel(const float *p, bool ok, float (&v)[8]) {
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+  const f4 a = *gl(reinterpret_cast<const f4 *>(p)), b = *gl(reinterpret_cast<const f4 *>(p + 4));
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = ok ? a[i] : 0.f; v[i + 4] = ok ? b[i] : 0.f; }
 }
@@ -118,7 +133,7 @@ template <class E>
 __device__ inline void load8_nt(const typename E::storage *p, float (&out)[8]) {
   using V = unsigned int __attribute__((ext_vector_type(sizeof(typename E::storage) * 2)));
   union { V v; Chunk8<E> c; } u;
-  u.v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+  u.v = __builtin_nontemporal_load(gl(reinterpret_cast<const V *>(p)));
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = E::to_f(u.c.v[i]);
 }
@@ -128,7 +143,7 @@ __device__ inline void store8_nt(typename E::storage *p, const float (&in)[8]) {
   union { V v; Chunk8<E> c; } u;
 #pragma unroll
   for (int i = 0; i < 8; ++i) u.c.v[i] = E::from_f(in[i]);
-  __builtin_nontemporal_store(u.v, reinterpret_cast<V *>(p));
+  __builtin_nontemporal_store(u.v, gl(reinterpret_cast<V *>(p)));
 }
 
 // Round an f32 value to E's precision and back (used to reproduce torch's
@@ -190,7 +205,7 @@ __device__ inline void dropout_mult8(uint64_t seed, uint64_t offset, uint64_t ch
 // torch's generator INSIDE the captured / recomputed region, so every replay sees a fresh value and a recompute sees
 // the forward's value again, while the scalar arguments stay baked into the graph.
 __device__ inline uint64_t dropout_offset(uint64_t offset, const uint64_t *offset_dev) {
-  return offset_dev != nullptr ? offset + __builtin_nontemporal_load(offset_dev) : offset;
+  return offset_dev != nullptr ? offset + __builtin_nontemporal_load(gl(offset_dev)) : offset;
 }
 
 // ---- cross-lane moves on the DPP path (no LDS crossbar traffic) ------------

@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
     if (jj < q.r) {
       if (is_up) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = q.up[(int64_t)(c8 * 8 + e) * q.r + jj];
+        for (int e = 0; e < 8; ++e) v[e] = gl(q.up)[(int64_t)(c8 * 8 + e) * q.r + jj];
       } else {
         const float *src = q.down + (int64_t)jj * C + c8 * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = src[e];
+        for (int e = 0; e < 8; ++e) v[e] = gl(src)[e];
       }
     }
     Chunk8<E> h, l;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
     }
     S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
     const int64_t split_stride = (int64_t)(C >> 3) * 128;  // elements per split
-    *reinterpret_cast<Chunk8<E> *>(dst + ((int64_t)c8 * 16 + jj) * 8) = h;
-    *reinterpret_cast<Chunk8<E> *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8) = l;
+    *gl(reinterpret_cast<Chunk8<E> *>(dst + ((int64_t)c8 * 16 + jj) * 8)) = h;
+    *gl(reinterpret_cast<Chunk8<E> *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8)) = l;
   }
 }
 
@@ -176,7 +176,7 @@ __device__ __forceinline__ void fm_issue(FmStage<E, NP> &st, const typename E::s
   for (int i = 0; i < NP; ++i) {
     const bool ok = it.row < nrows;
     const typename E::storage *src = data + (m0 + (ok ? it.row : 0)) * ld + (int64_t)fm_hchunk(c8_0 + it.c, hd) * 8;
-    const mu32x4 v = *reinterpret_cast<const mu32x4 *>(src);
+    const mu32x4 v = *gl(reinterpret_cast<const mu32x4 *>(src));
     st.v[i] = ok ? v : mu32x4{0u, 0u, 0u, 0u};
     it.next();
   }
@@ -218,8 +218,8 @@ __device__ __forceinline__ FmFrag2 fm_first_frags(const typename E::storage *pk,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ks = wave < nks ? wave : 0;
   FmFrag2 f;
-  f.h = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)ks * 512 + lane * 8);
-  f.l = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)ks * 512 + lane * 8);
+  f.h = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)ks * 512 + lane * 8));
+  f.l = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)ks * 512 + lane * 8));
   return f;
 }
 
@@ -236,8 +236,8 @@ __device__ __forceinline__ void fm_phase1(mf32x4 (&acc)[kFmMaxRT16], const unsig
 #pragma unroll 1
   for (int ks = wave; ks < nks; ks += 4) {
     const int kn = ks + 4 < nks ? ks + 4 : ks;  // next fragment in flight while this one is used
-    const mu32x4 nh = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)kn * 512 + lane * 8);
-    const mu32x4 nl = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kn * 512 + lane * 8);
+    const mu32x4 nh = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)kn * 512 + lane * 8));
+    const mu32x4 nl = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kn * 512 + lane * 8));
     const typename FmMfma<E>::frag bh = fm_frag<E>(fh), bl = fm_frag<E>(fl);
 #pragma unroll
     for (int t = 0; t < kFmMaxRT16; ++t) {
@@ -325,11 +325,11 @@ __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, i
   const bool owner = jj < RT;
   float *base = out + (owner ? jj : 0) * ldo + 4 * q;
   mf32x4 old = {0.f, 0.f, 0.f, 0.f};
-  if (accumulate && owner && wave < nct) old = __builtin_nontemporal_load(reinterpret_cast<const mf32x4 *>(base + wave * 16));
+  if (accumulate && owner && wave < nct) old = __builtin_nontemporal_load(gl(reinterpret_cast<const mf32x4 *>(base + wave * 16)));
 #pragma unroll 1
   for (int ct = wave; ct < nct; ct += 4) {
     mf32x4 nxt = {0.f, 0.f, 0.f, 0.f};
-    if (accumulate && owner && ct + 4 < nct) nxt = __builtin_nontemporal_load(reinterpret_cast<const mf32x4 *>(base + (ct + 4) * 16));
+    if (accumulate && owner && ct + 4 < nct) nxt = __builtin_nontemporal_load(gl(reinterpret_cast<const mf32x4 *>(base + (ct + 4) * 16)));
     mf32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
@@ -339,7 +339,7 @@ __device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, i
         d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2 + 1]), d);
       }
     }
-    if (owner) *reinterpret_cast<mf32x4 *>(base + ct * 16) = d + old;
+    if (owner) *gl(reinterpret_cast<mf32x4 *>(base + ct * 16)) = d + old;
     old = nxt;
   }
 }
@@ -479,8 +479,8 @@ __device__ __forceinline__ void fm_load_fragset(FmFragSet &f, const typename E::
   for (int i = 0; i < kFmNF; ++i) {
     const int ks = wave + 4 * i;
     const int kc = ks < nks ? ks : 0;  // straight-line: surplus slots re-read fragment 0 (never used)
-    f.h[i] = *reinterpret_cast<const mu32x4 *>(pk + (int64_t)kc * 512 + lane * 8);
-    f.l[i] = *reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kc * 512 + lane * 8);
+    f.h[i] = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)kc * 512 + lane * 8));
+    f.l[i] = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kc * 512 + lane * 8));
   }
 }
 template <class E>

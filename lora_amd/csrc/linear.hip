@@ -29,9 +29,9 @@ struct BatchStride {
 };
 
 __device__ inline float ld_factor(const void *p, int dt, int64_t i) {
-  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
-  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
-  return (float)reinterpret_cast<const __bf16 *>(p)[i];
+  if (dt == LORA_AMD_F32) return gl(reinterpret_cast<const float *>(p))[i];
+  if (dt == LORA_AMD_F16) return (float)gl(reinterpret_cast<const _Float16 *>(p))[i];
+  return (float)gl(reinterpret_cast<const __bf16 *>(p))[i];
 }
 
 // Stage factor[:, c0:c0+ncols] (logical [r, C]; stored [r,C] or [C,r]) into LDS as
@@ -161,7 +161,7 @@ __device__ __forceinline__ void rowdot_body(
 #pragma unroll
         for (int j = 0; j < RT; ++j) o[j] = acc[j] * scale;
       }
-      float *tr = t_out + row * r;
+      float LORA_AMD_AS_GLOBAL *tr = gl(t_out) + row * r;
 #pragma unroll
       for (int j = 0; j < RT; ++j)
         if (j < r) tr[j] = o[j];
@@ -438,7 +438,7 @@ __device__ __forceinline__ void colreduce_stage1_body(
       if (jb + jj < RT) {
         float sum = 0.f;
         for (int s = 0; s < nslots; ++s) sum += s_red[(s * ncols + col) * 4 + jj];
-        pout[(int64_t)(jb + jj) * K + col0 + col] = sum;
+        gl(pout)[(int64_t)(jb + jj) * K + col0 + col] = sum;
       }
     }
   }
@@ -485,7 +485,7 @@ __device__ __forceinline__ void colreduce_stage2_body(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t bb = b + 4 * u;
-      const float x = partial[(bb < nblocks ? bb : b) * stride + ic];
+      const float x = gl(partial)[(bb < nblocks ? bb : b) * stride + ic];
       v[u] = bb < nblocks ? x : 0.f;
     }
 #pragma unroll
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(kThreads) void sub_ragged_kernel(const lora_amd_sub
       for (int i = 0; i < 8; ++i) av[i] -= bv[i];
       store8<f32_t>(d.out + e, av);
     } else {
-      for (int i = 0; i < 8 && e + i < d.n; ++i) d.out[e + i] = E::to_f(a[e + i]) - E::to_f(b[e + i]);
+      for (int i = 0; i < 8 && e + i < d.n; ++i) gl(d.out)[e + i] = E::to_f(gl(a)[e + i]) - E::to_f(gl(b)[e + i]);
     }
   }
 }

@@ -26,9 +26,9 @@ constexpr int kFLdsFactor = 8192;    // floats, staged factor slab (forward)
 constexpr int kFLdsT = 2048;         // floats, per-row r-vectors
 
 __device__ inline float ldf(const void *p, int dt, int64_t i) {
-  if (dt == LORA_AMD_F32) return reinterpret_cast<const float *>(p)[i];
-  if (dt == LORA_AMD_F16) return (float)reinterpret_cast<const _Float16 *>(p)[i];
-  return (float)reinterpret_cast<const __bf16 *>(p)[i];
+  if (dt == LORA_AMD_F32) return gl(reinterpret_cast<const float *>(p))[i];
+  if (dt == LORA_AMD_F16) return (float)gl(reinterpret_cast<const _Float16 *>(p))[i];
+  return (float)gl(reinterpret_cast<const __bf16 *>(p))[i];
 }
 
 // Factor slab -> LDS layout [RT][2][ncols/8][4] (two conflict-free 16-byte planes per lane).
@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_factor(float *s_f, const void *f, int fdt,
         if (i < total) {
           const int j = i / n4, c4 = i - j * n4;
           dst[u] = ((j * 2 + (c4 & 1)) * c8 + (c4 >> 1)) * 4;
-          v[u] = j < r ? *reinterpret_cast<const float4 *>(fp + (int64_t)j * C + c0 + c4 * 4)
+          v[u] = j < r ? float4(*gl(reinterpret_cast<const float4 *>(fp + (int64_t)j * C + c0 + c4 * 4)))
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_factor(float *s_f, const void *f, int fdt,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0b + u * kFT;
-        if (c < ncols) v[u] = *reinterpret_cast<const float4 *>(fp + (int64_t)(c0 + c) * 4);
+        if (c < ncols) v[u] = *gl(reinterpret_cast<const float4 *>(fp + (int64_t)(c0 + c) * 4));
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -749,8 +749,8 @@ __device__ __forceinline__ void colsum_finish(float *s_red, const float (&acc)[R
   if (nslots == 1) {  // a tile of more than 128 chunks: one row slot, every owner holds final column sums
 #pragma unroll
     for (int j = 0; owner && j < RT; ++j) {
-      *reinterpret_cast<float4 *>(part + (int64_t)j * C + col) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-      *reinterpret_cast<float4 *>(part + (int64_t)j * C + col + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+      *gl(reinterpret_cast<float4 *>(part + (int64_t)j * C + col)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      *gl(reinterpret_cast<float4 *>(part + (int64_t)j * C + col + 4)) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
     }
     return;
   }
@@ -774,7 +774,7 @@ __device__ __forceinline__ void colsum_finish(float *s_red, const float (&acc)[R
       const float *src = &s_red[(jj * nslots) * ncols + cc];
       float sum = 0.f;
       for (int q = 0; q < nslots; ++q) sum += src[q * ncols];
-      part[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
+      gl(part)[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
     }
   }
 }
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(kDualThreads) void linear_bwd_factors_self_dual_ker
           const float *src = &s_red[(jj * nslots) * ncols + cc];
           float sum = 0.f;
           for (int q = 0; q < nslots; ++q) sum += src[q * ncols];
-          part[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
+          gl(part)[(int64_t)(jb + jj) * C + c0 * 8 + cc] = sum;
         }
       }
     }
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(kFT) void reduce_batched_kernel(const lora_amd_redu
     const lora_amd_reduce_desc d = descs[lo];
     const int64_t e = i - d.begin;
     const int j = (int)(e / d.C), c = (int)(e - (int64_t)j * d.C);
-    const float *pp = d.part + (int64_t)j * d.C + c;
+    const float LORA_AMD_AS_GLOBAL *pp = gl(d.part) + (int64_t)j * d.C + c;
     const int64_t stride = (int64_t)d.RT * d.C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int p = 0;
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kFT) void reduce_batched_kernel(const lora_amd_redu
     for (; p < d.nparts; ++p) s0 += pp[p * stride];
     const float sum = (s0 + s1) + (s2 + s3);
     const int64_t o = d.layout == LORA_AMD_FACTOR_RK ? (int64_t)j * d.C + c : (int64_t)c * d.r + j;
-    d.out[o] = (d.beta == 0.f ? 0.f : d.beta * d.out[o]) + d.scale * sum;
+    gl(d.out)[o] = (d.beta == 0.f ? 0.f : d.beta * gl(d.out)[o]) + d.scale * sum;
   }
 }
 

@@ -26,7 +26,7 @@ static int g_merge_nt = 1;  // non-temporal W loads/stores: W is streamed exactl
 
 template <class E>
 __device__ inline float ld_as_f32(const void *p, int64_t i) {
-  return E::to_f(reinterpret_cast<const typename E::storage *>(p)[i]);
+  return E::to_f(gl(reinterpret_cast<const typename E::storage *>(p))[i]);
 }
 
 // uniform binary search: last site whose tile_begin <= tile
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_kernel(
         float p = 0.f;
         for (int j = 0; j < r; ++j) p = fmaf(s_up[rl * r + j], s_down[j * ncols + c], p);
         int64_t off = (int64_t)(row0 + rl) * s.K + col0 + c;
-        wout[off] = EW::from_f(merge_one<EW, EAB, ROUND>(EW::to_f(win[off]), p, alpha));
+        gl(wout)[off] = EW::from_f(merge_one<EW, EAB, ROUND>(EW::to_f(gl(win)[off]), p, alpha));
       }
     }
   }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
         // fetches them as 16-byte loads; anything else element by element
         if (!tvec) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) fc[j][i] = EAB::to_f(dn[(int64_t)(col + i) * r + j]);
+          for (int i = 0; i < 8; ++i) fc[j][i] = EAB::to_f(gl(dn)[(int64_t)(col + i) * r + j]);
         }
       } else {
         load8<EAB>(dn + (int64_t)j * s.K + col, fc[j]);
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
 #pragma unroll
       for (int q = 0; q < RT / 4; ++q)
         if (q * 4 < r) {
-          const float4 v = *reinterpret_cast<const float4 *>(dnf + i * r + q * 4);
+          const float4 v = *gl(reinterpret_cast<const float4 *>(dnf + i * r + q * 4));
           fc[q * 4 + 0][i] = v.x; fc[q * 4 + 1][i] = v.y; fc[q * 4 + 2][i] = v.z; fc[q * 4 + 3][i] = v.w;
         }
   }
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
   if (tpo) {  // rank-major source [r, N]: consecutive threads read consecutive rows of one rank
     for (int i = tid; i < nrows * RT; i += kMergeThreads) {
       const int j = i / nrows, rl = i - j * nrows;
-      s_up[rl * RT + j] = j < r ? EAB::to_f(upp[(int64_t)j * s.N + row0 + rl]) : 0.f;
+      s_up[rl * RT + j] = j < r ? EAB::to_f(gl(upp)[(int64_t)j * s.N + row0 + rl]) : 0.f;
     }
   } else {
     for (int i = tid; i < nrows * RT; i += kMergeThreads) {
       const int rl = i / RT, j = i - rl * RT;
-      s_up[i] = j < r ? EAB::to_f(upp[(int64_t)(row0 + rl) * r + j]) : 0.f;
+      s_up[i] = j < r ? EAB::to_f(gl(upp)[(int64_t)(row0 + rl) * r + j]) : 0.f;
     }
   }
   __syncthreads();

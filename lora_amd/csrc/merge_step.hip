@@ -118,8 +118,8 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
 #pragma unroll
   for (int j = 0; j < RT; ++j) {
     if (j < r && live) {
-      const float4 a = *reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col);
-      const float4 b = *reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col + 4);
+      const float4 a = *gl(reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col));
+      const float4 b = *gl(reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col + 4));
       fc[j][0] = a.x; fc[j][1] = a.y; fc[j][2] = a.z; fc[j][3] = a.w;
       fc[j][4] = b.x; fc[j][5] = b.y; fc[j][6] = b.z; fc[j][7] = b.w;
     } else {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
   // the tile's rows of `up` (f32 [N, r]) -> LDS [nrows][RT]
   for (int i = tid; i < nrows * RT; i += kMsThreads) {
     const int rl = i / RT, j = i - rl * RT;
-    s_up[i] = j < r ? s.up[(int64_t)(row0 + rl) * r + j] : 0.f;
+    s_up[i] = j < r ? gl(s.up)[(int64_t)(row0 + rl) * r + j] : 0.f;
   }
   __syncthreads();
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
   for (int u = 0; u < U; ++u) {
     const int rl = slot + u * 32;
     const bool ok = live && rl < nrows;
-    w[u] = __builtin_nontemporal_load(reinterpret_cast<const su32x4 *>(win + (int64_t)(ok ? rl : 0) * s.K));
+    w[u] = __builtin_nontemporal_load(gl(reinterpret_cast<const su32x4 *>(win + (int64_t)(ok ? rl : 0) * s.K)));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
     su32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = b[2 * i] | (b[2 * i + 1] << 16);
-    __builtin_nontemporal_store(o, reinterpret_cast<su32x4 *>(wout + (int64_t)ms_map(n, s.row_d, s.row_D) * s.ld_out));
+    __builtin_nontemporal_store(o, gl(reinterpret_cast<su32x4 *>(wout + (int64_t)ms_map(n, s.row_d, s.row_D) * s.ld_out)));
     if (s.out_t != nullptr) {
       uint32_t *img = reinterpret_cast<uint32_t *>(s_img + rl * kMsPitch + cl * 16);
 #pragma unroll
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
     for (int i = 0; i < 4; ++i) o[i] = (uint32_t)e[2 * i] | ((uint32_t)e[2 * i + 1] << 16);
     SW *dst = wt + (int64_t)ms_map(col0 + k, s.col_d, s.col_D) * s.ld_out_t + ms_map(n0, s.row_d, s.row_D);
     if (n0 + 8 <= s.N) {
-      __builtin_nontemporal_store(o, reinterpret_cast<su32x4 *>(dst));
+      __builtin_nontemporal_store(o, gl(reinterpret_cast<su32x4 *>(dst)));
     } else {
-      for (int i = 0; i < s.N - n0; ++i) reinterpret_cast<unsigned short *>(dst)[i] = e[i];
+      for (int i = 0; i < s.N - n0; ++i) gl(reinterpret_cast<unsigned short *>(dst))[i] = e[i];
     }
   }
 }
