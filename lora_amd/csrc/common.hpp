@@ -44,6 +44,16 @@ template <class T>
 __device__ __forceinline__ const T LORA_AMD_AS_GLOBAL *gl(const T *p) { return (const T LORA_AMD_AS_GLOBAL *)p; }
 template <class T>
 __device__ __forceinline__ T LORA_AMD_AS_GLOBAL *gl(T *p) { return (T LORA_AMD_AS_GLOBAL *)p; }
+// 16 bytes of floats through a plain vector type (class types such as float4 cannot be copied through an
+// address-space-qualified pointer)
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gl_ld4(const float *p) {
+  const gf32x4 v = *gl(reinterpret_cast<const gf32x4 *>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void gl_st4(float *p, float a, float b, float c, float d) {
+  *gl(reinterpret_cast<gf32x4 *>(p)) = gf32x4{a, b, c, d};
+}
 
 // ---- element traits: T is the storage type -------------------------------
 struct f32_t {

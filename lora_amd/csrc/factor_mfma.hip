@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
     }
     S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
     const int64_t split_stride = (int64_t)(C >> 3) * 128;  // elements per split
-    *gl(reinterpret_cast<Chunk8<E> *>(dst + ((int64_t)c8 * 16 + jj) * 8)) = h;
-    *gl(reinterpret_cast<Chunk8<E> *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8)) = l;
+    union { Chunk8<E> c; mu32x4 u; } hb, lb;
+    hb.c = h; lb.c = l;
+    *gl(reinterpret_cast<mu32x4 *>(dst + ((int64_t)c8 * 16 + jj) * 8)) = hb.u;
+    *gl(reinterpret_cast<mu32x4 *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8)) = lb.u;
   }
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_factor(float *s_f, const void *f, int fdt,
         if (i < total) {
           const int j = i / n4, c4 = i - j * n4;
           dst[u] = ((j * 2 + (c4 & 1)) * c8 + (c4 >> 1)) * 4;
-          v[u] = j < r ? float4(*gl(reinterpret_cast<const float4 *>(fp + (int64_t)j * C + c0 + c4 * 4)))
+          v[u] = j < r ? gl_ld4(fp + (int64_t)j * C + c0 + c4 * 4)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_factor(float *s_f, const void *f, int fdt,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0b + u * kFT;
-        if (c < ncols) v[u] = *gl(reinterpret_cast<const float4 *>(fp + (int64_t)(c0 + c) * 4));
+        if (c < ncols) v[u] = gl_ld4(fp + (int64_t)(c0 + c) * 4);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -749,8 +749,8 @@ __device__ __forceinline__ void colsum_finish(float *s_red, const float (&acc)[R
   if (nslots == 1) {  // a tile of more than 128 chunks: one row slot, every owner holds final column sums
 #pragma unroll
     for (int j = 0; owner && j < RT; ++j) {
-      *gl(reinterpret_cast<float4 *>(part + (int64_t)j * C + col)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-      *gl(reinterpret_cast<float4 *>(part + (int64_t)j * C + col + 4)) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+      gl_st4(part + (int64_t)j * C + col, acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      gl_st4(part + (int64_t)j * C + col + 4, acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
     }
     return;
   }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_co_kernel(
 #pragma unroll
       for (int q = 0; q < RT / 4; ++q)
         if (q * 4 < r) {
-          const float4 v = *gl(reinterpret_cast<const float4 *>(dnf + i * r + q * 4));
+          const float4 v = gl_ld4(dnf + i * r + q * 4);
           fc[q * 4 + 0][i] = v.x; fc[q * 4 + 1][i] = v.y; fc[q * 4 + 2][i] = v.z; fc[q * 4 + 3][i] = v.w;
         }
   }

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
 #pragma unroll
   for (int j = 0; j < RT; ++j) {
     if (j < r && live) {
-      const float4 a = *gl(reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col));
-      const float4 b = *gl(reinterpret_cast<const float4 *>(s.down + (int64_t)j * s.K + col + 4));
+      const float4 a = gl_ld4(s.down + (int64_t)j * s.K + col);
+      const float4 b = gl_ld4(s.down + (int64_t)j * s.K + col + 4);
       fc[j][0] = a.x; fc[j][1] = a.y; fc[j][2] = a.z; fc[j][3] = a.w;
       fc[j][4] = b.x; fc[j][5] = b.y; fc[j][6] = b.z; fc[j][7] = b.w;
     } else {
