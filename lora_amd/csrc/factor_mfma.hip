@@ -527,6 +527,19 @@ __device__ __forceinline__ void fm_phase1_set(mf32x4 (&acc)[kFmMaxRT16], const u
 //   row; the combine step zeroes T for those rows, so they contribute nothing).
 constexpr int kFeThreads = 320;
 
+// LORA_AMD_FM_TRACE (scripts/fm_trace.py): cycle stamps of one workgroup's barriers — consumer wave 0 and the loader wave —
+// into a caller buffer passed through `offset_dev` of site 0.  A diagnostic: TRACE = false compiles it out.
+template <bool TRACE>
+__device__ __forceinline__ void fe_stamp(unsigned long long *tr, int &idx, int tag) {
+  if constexpr (TRACE) {
+    if (tr != nullptr && (threadIdx.x & 63) == 0 && idx < 250) {
+      tr[idx * 2] = (unsigned long long)tag;
+      tr[idx * 2 + 1] = clock64();
+      ++idx;
+    }
+  }
+}
+
 __device__ __forceinline__ void fe_glds16(const void *gsrc, void *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
                                    (void __attribute__((address_space(3))) *)lds_wave_base, 16, 0, 0);
@@ -613,8 +626,10 @@ constexpr int kFeNKA = 44, kFeNKB = 32;  // most DMA instructions of a resident 
 
 // The loader wave's program, kept out of line: its register file (the two offset tables) is allocated apart from the
 // consumers' accumulators (inlined into the kernel the two lived side by side: 256 registers + spills).
-template <class E>
-__device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, unsigned char *lds, int64_t sb_idx) {
+template <class E, bool TRACE>
+__device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, unsigned char *lds, int64_t sb_idx,
+                                                    unsigned long long *tr) {
+  int ti = 0;
   using S = typename E::storage;
   const int R = q.rows_per_block;
   const int64_t nrb = (q.M + R - 1) / R;
@@ -661,14 +676,19 @@ __device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, u
       const int nrows1 = (int)min((int64_t)R, q.M - m1);
       const bool more = blk + 1 < nblk;
       unsigned char *bufAn = bufA0 + (nbufA == 2 ? ((blk + 1) & 1) * szA : 0);
+      fe_stamp<TRACE>(tr, ti, 100);
       fm_barrier();  // C1
       fm_barrier();  // C2
       fm_barrier();  // C3
+      fe_stamp<TRACE>(tr, ti, 103);
       int newer = 0;   // instructions issued after the chunk the consumers wait for next
 #pragma unroll 1
       for (int c = 0; c < nch; ++c) {
+        fe_stamp<TRACE>(tr, ti, 110);
         fe_wait_vmcnt(min(newer, 63));
+        fe_stamp<TRACE>(tr, ti, 111);
         fm_barrier();  // C4(c): chunk c has landed
+        fe_stamp<TRACE>(tr, ti, 104);
         // ring slot = running chunk index & 1; the slot of the previous chunk (= of the next one) is free since its C5:
         // the next tile of the stream goes there
         unsigned char *nslot = ring + ((blk * nch + c + 1) & 1) * szB;
@@ -684,19 +704,23 @@ __device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, u
           issue_a(bufAn, k0, k1, m1, nrows1);
           newer = max(k1 - k0, 0);
         }
+        fe_stamp<TRACE>(tr, ti, 112);
         fm_barrier();  // C5(c)
+        fe_stamp<TRACE>(tr, ti, 105);
       }
       fm_barrier();  // C6
       fm_barrier();  // C7
       fm_barrier();  // C8: the resident buffer of block blk is free
+      fe_stamp<TRACE>(tr, ti, 108);
       if (more && nbufA == 1) issue_a(bufA0, 0, nA, m1, nrows1);
       // the next resident block must have landed before C1; the next block's chunk 0 was issued BEFORE its last share
       // (nbufA == 2) or before the whole block (nbufA == 1), so it has landed too — its first C4 waits for nothing
       if (more) fe_wait_vmcnt(0);
+      fe_stamp<TRACE>(tr, ti, 109);
     }
 }
 
-template <class E>
+template <class E, bool TRACE>
 __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kFmLdsLarge];
   using S = typename E::storage;
@@ -723,10 +747,16 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
   const int c8a = Ca >> 3;
   const int wave = threadIdx.x >> 6;
 
+  unsigned long long *tr = nullptr;
+  if constexpr (TRACE) {  // site 0's offset_dev carries the trace buffer; the traced workgroup = a middle one of the grid
+    if (blockIdx.x == gridDim.x / 2) tr = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(sites[0].offset_dev));
+  }
   if (wave == 4) {  // the loader wave
-    fe_loader<E>(q, lds, sb_idx);
+    fe_loader<E, TRACE>(q, lds, sb_idx, tr != nullptr ? tr + 512 : nullptr);
     return;
   }
+  if (wave != 0) tr = nullptr;
+  int ti = 0;
 
   // ==================================================================== consumer waves (threads 0..255)
   const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
@@ -745,15 +775,21 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
     float *outa = (ax ? q.down_part : q.up_part) + rb * RT * (int64_t)Ca;
     float *outb = (ax ? q.up_part : q.down_part) + rb * RT * (int64_t)Cb;
     const unsigned char *bufA = bufA0 + (nbufA == 2 ? (blk & 1) * szA : 0);
+    fe_stamp<TRACE>(tr, ti, 0);
     fm_barrier();  // C1
+    fe_stamp<TRACE>(tr, ti, 1);
 #pragma unroll
     for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
     fm_phase1_set<E>(acc, bufA, pa, nrt, Ca >> 5, fcur);        // waits for fcur (issued a step ago), then ...
     fm_load_fragset<E>(fcur, pkb, splitb, cw0 >> 5);             // ... chunk 0's fragments start their trip
     fm_combine_put<E>(acc, scratch, nrt);
+    fe_stamp<TRACE>(tr, ti, 20);
     fm_barrier();  // C2
+    fe_stamp<TRACE>(tr, ti, 2);
     fm_combine_get<E>(scratch, ttA, nrt, R, q.scale, nrows);
+    fe_stamp<TRACE>(tr, ti, 30);
     fm_barrier();  // C3
+    fe_stamp<TRACE>(tr, ti, 3);
     fm_load_tfrags<E>(tf, ttA, R, nk2);
 #pragma unroll
     for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
@@ -761,7 +797,9 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
     for (int c = 0; c < nch; ++c) {
       const int col0 = c * CW, cw = min(CW, Cb - col0);
       const unsigned char *slot = ring + ((blk * nch + c) & 1) * szB;
+      fe_stamp<TRACE>(tr, ti, 40);
       fm_barrier();  // C4(c)
+      fe_stamp<TRACE>(tr, ti, 4);
       fm_phase1_set<E>(acc, slot, pb, nrt, cw >> 5, fcur);
       if (c + 1 < nch) {
         const int col1 = col0 + CW;
@@ -769,16 +807,25 @@ __global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(cons
       } else {
         fm_load_fragset<E>(fcur, pka, splita, Ca >> 5);          // the next block's resident tile (same factor)
       }
+      fe_stamp<TRACE>(tr, ti, 45);
       fm_phase2<E>(slot, pb, nk2, cw, tf, outb + col0, Cb, RT, false);
+      fe_stamp<TRACE>(tr, ti, 50);
       fm_barrier();  // C5(c)
+      fe_stamp<TRACE>(tr, ti, 5);
     }
     fm_combine_put<E>(acc, scratch, nrt);
+    fe_stamp<TRACE>(tr, ti, 60);
     fm_barrier();  // C6
+    fe_stamp<TRACE>(tr, ti, 6);
     fm_combine_get<E>(scratch, ttB, nrt, R, q.scale, nrows);
+    fe_stamp<TRACE>(tr, ti, 70);
     fm_barrier();  // C7
+    fe_stamp<TRACE>(tr, ti, 7);
     fm_load_tfrags<E>(tf, ttB, R, nk2);
     fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, false);
+    fe_stamp<TRACE>(tr, ti, 80);
     fm_barrier();  // C8
+    fe_stamp<TRACE>(tr, ti, 8);
   }
 }
 
@@ -982,10 +1029,13 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   hipStream_t st = (hipStream_t)stream;
   if (lds_class == 3) {
     LORA_AMD_CHECK(!masked, LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: the engine kernel takes no dropout sites");
+    const bool trace = getenv("LORA_AMD_FM_TRACE") && atoi(getenv("LORA_AMD_FM_TRACE")) == 1;
     if (act_dtype == LORA_AMD_F16)
-      hipLaunchKernelGGL(factors_mfma_engine_kernel<f16_t>, dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
+      hipLaunchKernelGGL((factors_mfma_engine_kernel<f16_t, false>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
+    else if (trace)
+      hipLaunchKernelGGL((factors_mfma_engine_kernel<bf16_t, true>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
     else
-      hipLaunchKernelGGL(factors_mfma_engine_kernel<bf16_t>, dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
+      hipLaunchKernelGGL((factors_mfma_engine_kernel<bf16_t, false>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
     return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
   }
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
