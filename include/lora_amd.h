@@ -343,7 +343,7 @@ typedef struct lora_amd_ws_site {
    * lora_amd_linear_bwd_g: element (m, n) of the site's [M, N] output (forward) resp. of G (input-gradient call, where
    * the launch's contraction length K is that N).  Needs N % 8 == 0. */
   float dropout_p;
-  int32_t a_bufs;                 /* plan: resident buffers (engine kernel) */
+  int32_t reserved;
   uint64_t seed, offset;
   const uint64_t *offset_dev; /* device int64 added to `offset` (graph replay / checkpoint recompute), or NULL */
 } lora_amd_ws_site;
@@ -431,15 +431,11 @@ int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, in
  * class.  Shapes: N, K multiples of 32, rank <= 16; anything else: supported = 0, use the _self_ragged pass. */
 typedef struct lora_amd_factors_mfma_plan_t {
   int32_t supported, lds_class, rank_tile, rows_per_block, nparts, lds_bytes;
-  int32_t blocks_per_wg, a_bufs;            /* row blocks one workgroup walks: nparts = ceil(ceil(M / rows) / blocks_per_wg);
-                                               a_bufs: resident buffers of the engine kernel (class 3) */
+  int32_t blocks_per_wg, reserved;          /* row blocks one workgroup walks: nparts = ceil(ceil(M / rows) / blocks_per_wg) */
   int64_t up_part_floats, down_part_floats;
   int64_t pack_up_elems, pack_down_elems;   /* elements (activation dtype) of the two fragment packs of a site */
 } lora_amd_factors_mfma_plan_t;
-/* rows: 0 = the planner's choice (64, else 32; LORA_AMD_FM_ROWS overrides), else 32 / 64 tried first.
- * flags: bit 0 = the site has dropout (its mask is applied in registers: never the engine kernel), bit 1 = no engine.
- * lds_class 3 = the ENGINE kernel: one 320-thread workgroup per CU — four consumer waves + one loader wave that streams
- * the tiles into LDS with global_load_lds and runs ahead (resident block double-buffered, 2-slot chunk ring, <= 160 KiB) */
+/* rows: 0 = the planner's choice (64, else 32; LORA_AMD_FM_ROWS overrides), else 32 / 64 tried first.  flags: reserved (0). */
 int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows, int32_t flags,
                                lora_amd_factors_mfma_plan_t *out);
 /* f32 masters -> fragment packs: pk[split][c/8][16][8] in the activation dtype, split 0 = rounded value, split 1 = the
@@ -468,7 +464,7 @@ typedef struct lora_amd_fm_site {
   /* nn.Dropout(p) on the branch (lora.py:45, 57): p > 0 makes G enter as mask (.) G with the forward's mask regenerated from
    * (seed, offset + *offset_dev) — the caller folds 1 / (1 - p) into `scale`; T = X down^T is unaffected */
   float dropout_p;
-  int32_t a_bufs;                 /* plan: resident buffers (engine kernel) */
+  int32_t reserved;
   uint64_t seed, offset;
   const uint64_t *offset_dev;
 } lora_amd_fm_site;

@@ -83,7 +83,7 @@ class SelfSite(C.Structure):
 class FactorsMfmaPlan(C.Structure):
     _fields_ = [("supported", C.c_int32), ("lds_class", C.c_int32), ("rank_tile", C.c_int32),
                 ("rows_per_block", C.c_int32), ("nparts", C.c_int32), ("lds_bytes", C.c_int32),
-                ("blocks_per_wg", C.c_int32), ("a_bufs", C.c_int32),
+                ("blocks_per_wg", C.c_int32), ("reserved", C.c_int32),
                 ("up_part_floats", C.c_int64), ("down_part_floats", C.c_int64),
                 ("pack_up_elems", C.c_int64), ("pack_down_elems", C.c_int64)]
 
@@ -106,7 +106,7 @@ class FmSite(C.Structure):
         ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("pitch_a", C.c_int32),
         ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32),
         ("block_begin", C.c_int64),
-        ("dropout_p", C.c_float), ("a_bufs", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
         ("offset_dev", C.c_void_p),
     ]
 
@@ -184,7 +184,7 @@ class WsSite(C.Structure):
     _fields_ = [("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
                 ("t_out", C.c_void_p), ("ldy", C.c_int64), ("N", C.c_int32), ("r", C.c_int32),
                 ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float),
-                ("dropout_p", C.c_float), ("a_bufs", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("offset_dev", C.c_void_p)]
 
 
@@ -937,23 +937,25 @@ def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, r
 
 
 # ----------------------------------------------------------------------------- the matrix-core factor pass
-# LORA_AMD_FACTORS_MFMA=0: 16-bit sites keep the VALU pass (lora_amd_linear_bwd_factors_self_ragged) — same-box A/B runs
-FACTORS_MFMA = os.environ.get("LORA_AMD_FACTORS_MFMA", "1") != "0"
+# Which deferred sites take the matrix-core pass: "masked" (default) = the dropout sites only (their mask is regenerated
+# inside the pass; the alternative is one launch per site) — the maskless sites keep the VALU pass, which measures faster
+# on the headline step (946 + 28 us against 1080 + 75 us, profiles/r04_kbench_fm_variants.log); "all" / "1" = every 16-bit
+# site; "0" = none
+FACTORS_MFMA_MODE = {"1": "all", "0": "none"}.get(os.environ.get("LORA_AMD_FACTORS_MFMA", "masked"),
+                                                  os.environ.get("LORA_AMD_FACTORS_MFMA", "masked"))
+FACTORS_MFMA = FACTORS_MFMA_MODE != "none"
 _mfma_plan_cache = {}
 
 
-def factors_mfma_plan(M: int, K: int, N: int, r: int, act_dtype: torch.dtype, rows: int = 0,
-                      masked: bool = False, engine: bool = True) -> FactorsMfmaPlan:
+def factors_mfma_plan(M: int, K: int, N: int, r: int, act_dtype: torch.dtype, rows: int = 0) -> FactorsMfmaPlan:
     """Geometry of a site in the matrix-core factor pass (csrc/factor_mfma.hip): ``supported`` = 0 for f32 activations,
-    N / K not multiples of 32, rank > 16 or a row block that does not fit the LDS.  ``masked``: the site has dropout
-    (register-staged kernel, LDS class 1 / 2); else the engine kernel (class 3) where it fits."""
-    key = (M, K, N, r, act_dtype, rows, bool(masked), bool(engine))
+    N / K not multiples of 32, rank > 16 or a row block that does not fit the LDS."""
+    key = (M, K, N, r, act_dtype, rows)
     pl = _mfma_plan_cache.get(key)
     if pl is None:
         pl = FactorsMfmaPlan()
         if act_dtype in (torch.float16, torch.bfloat16):
-            _check(require().lora_amd_factors_mfma_plan(M, K, N, r, dtype_code(act_dtype), rows,
-                                                        int(bool(masked)) | (0 if engine else 2), C.byref(pl)),
+            _check(require().lora_amd_factors_mfma_plan(M, K, N, r, dtype_code(act_dtype), rows, 0, C.byref(pl)),
                    "lora_amd_factors_mfma_plan")
         _mfma_plan_cache[key] = pl
     return pl

@@ -30,7 +30,15 @@
 //   * LDS rows are padded to pitch = 32 (mod 64) bytes: the ds_read_b128 of 16 rows and the transpose reads of 8 rows
 //     x 32 B are both bank-conflict-free (scripts/lds_banks.py checks the lane groups of the microarchitecture guide).
 // Algorithmic bytes per site: M (N + K) e (G and X once) + the partial slabs 2 RT 4 (N + K) M / R (written here, read by
-// lora_amd_reduce_batched).  HBM-bound: 4 MFMA per KB against ~90 cycles per KB per CU.
+// lora_amd_reduce_batched).
+// MEASURED (round 4, profiles/r04_kbench_fm_variants.log, r04_fm_pmc.jsonl): FETCH_SIZE 1.0x algorithmic (against 2.0x for
+// the VALU pass), but 0.22-0.30 of the byte roof on the 144 sites of the headline step — the same as the VALU pass, which
+// keeps that job.  What binds is not bytes: a 64-row block costs ~25-40 K cycles of DEPENDENT work per wave (ten barriers,
+// LDS round trips in front of serially dependent MFMAs, a trip to L2 per fragment / slab access) at one or two waves per
+// SIMD; an LDS-DMA loader-wave form of the same pass measured no better (profiles/r04_fm_engine_trace_*.txt has its cycle
+// stamps; removed again, commit 7e6edba).  Where this kernel IS the better one: sites with dropout, whose factor
+// gradients it computes for the whole model in one deferred launch with the mask regenerated inside (the alternative is
+// one latency-bound launch per site).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -269,8 +277,7 @@ __device__ __forceinline__ void fm_combine_put(const mf32x4 (&acc)[kFmMaxRT16], 
     }
   }
 }
-// ... after a barrier: rows >= nrows (past the end of the matrix: the engine kernel's tiles repeat the last row there)
-// give T = 0
+// ... after a barrier: rows >= nrows (past the end of the matrix) give T = 0
 template <class E>
 __device__ __forceinline__ void fm_combine_get(const float *scratch, unsigned char *tt, int nrt, int R, float scale, int nrows) {
   using S = typename E::storage;
@@ -466,369 +473,6 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   }
 }
 
-// ---- whole-step fragment sets (the engine's consumers) --------------------------------------------------------------
-// Every dependent trip to L2 / HBM on a consumer wave's path costs 2-3 us while the chip streams (measured: with the
-// fragments fetched inside phase 1 and the slab read back in phase 2 a 64-row block took ~28 us in EVERY variant of this
-// pass: eight to ten such trips, not bytes).  The engine's consumers therefore touch global memory only through loads that
-// were issued a whole pipeline step earlier: a wave's packed fragments of ALL its k-steps of the next tile are loaded into
-// a register set while the current tile is processed.
-constexpr int kFmNF = 5;  // k-steps per wave and tile (tiles of <= 640 columns)
-struct FmFragSet { mu32x4 h[kFmNF], l[kFmNF]; };
-template <class E>
-__device__ __forceinline__ void fm_load_fragset(FmFragSet &f, const typename E::storage *pk, int64_t split_stride, int nks) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < kFmNF; ++i) {
-    const int ks = wave + 4 * i;
-    const int kc = ks < nks ? ks : 0;  // straight-line: surplus slots re-read fragment 0 (never used)
-    f.h[i] = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)kc * 512 + lane * 8));
-    f.l[i] = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kc * 512 + lane * 8));
-  }
-}
-template <class E>
-__device__ __forceinline__ void fm_phase1_set(mf32x4 (&acc)[kFmMaxRT16], const unsigned char *buf, int pitch, int nrt, int nks,
-                                              const FmFragSet &f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned char *rowp = buf + (lane & 15) * pitch + (lane >> 4) * 16;
-#pragma unroll
-  for (int i = 0; i < kFmNF; ++i) {
-    const int ks = wave + 4 * i;
-    if (ks < nks) {
-      const typename FmMfma<E>::frag bh = fm_frag<E>(f.h[i]), bl = fm_frag<E>(f.l[i]);
-#pragma unroll
-      for (int t = 0; t < kFmMaxRT16; ++t) {
-        if (t < nrt) {
-          const typename FmMfma<E>::frag a = fm_frag<E>(*reinterpret_cast<const mu32x4 *>(rowp + t * 16 * pitch + ks * 64));
-          acc[t] = FmMfma<E>::mma(a, bh, acc[t]);
-          acc[t] = FmMfma<E>::mma(a, bl, acc[t]);
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------- the engine
-// The same pass with the HBM stream decoupled from the arithmetic: one workgroup per CU = four consumer waves (phase 1 /
-// combine / phase 2 exactly as above) + ONE loader wave that does nothing but `global_load_lds_dwordx4` (16 bytes per lane
-// straight into LDS, 1 KB per instruction, no registers) and runs ahead of the consumers.  Why a separate wave: every wave
-// has ONE in-order vmcnt counter, so in the register-staged kernel a wait for a packed factor fragment (issued late) also
-// waits for every prefetched tile issued before it — the prefetch can never stay in flight across the fragment loads.  The
-// loader wave's counter sees only tile loads; the consumers' only fragments and slab accesses.
-//   LDS (<= 160 KiB): resident block x 2 (block i + 1 lands while block i is consumed; x 1 for the 1280-wide sites),
-//   a 2-slot ring of column chunks of the streamed operand, the combine scratch, the two T images.
-//   Barrier protocol per row block (all five waves execute the same s_barrier sequence):
-//     C1 resident block landed | C2 phase-1 partials in scratch | C3 T image visible |
-//     per chunk: C4 chunk landed, C5 chunk consumed (its slot may be overwritten) | C6, C7 as C2, C3 | C8 resident consumed
-//   Loader between C4(c) and C5(c): issues the NEXT chunk (of this block, or chunk 0 of the next) into the slot freed by
-//   C5(c - 1), then 1 / nchunk of the next resident block.  Before C4(c) it waits vmcnt(n) with n = the instructions issued
-//   after chunk c (that part of the next resident block): the chunk has landed, the part stays in flight.
-//   Tiles are written lane-linearly (LDS address = base + 1024 k + 16 lane): the padded row pitch is produced by
-//   computing each lane's SOURCE address from its LDS offset (pad bytes and rows past the end of the matrix re-read a valid
-//   row; the combine step zeroes T for those rows, so they contribute nothing).
-constexpr int kFeThreads = 320;
-
-// LORA_AMD_FM_TRACE (scripts/fm_trace.py): cycle stamps of one workgroup's barriers — consumer wave 0 and the loader wave —
-// into a caller buffer passed through `offset_dev` of site 0.  A diagnostic: TRACE = false compiles it out.
-template <bool TRACE>
-__device__ __forceinline__ void fe_stamp(unsigned long long *tr, int &idx, int tag) {
-  if constexpr (TRACE) {
-    if (tr != nullptr && (threadIdx.x & 63) == 0 && idx < 250) {
-      tr[idx * 2] = (unsigned long long)tag;
-      tr[idx * 2 + 1] = clock64();
-      ++idx;
-    }
-  }
-}
-
-__device__ __forceinline__ void fe_glds16(const void *gsrc, void *lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gsrc,
-                                   (void __attribute__((address_space(3))) *)lds_wave_base, 16, 0, 0);
-}
-// s_waitcnt vmcnt(n) for a run-time n (0..63): the operand is an immediate
-__device__ __forceinline__ void fe_wait_vmcnt(int n) {
-#define FE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    FE_W(0) FE_W(1) FE_W(2) FE_W(3) FE_W(4) FE_W(5) FE_W(6) FE_W(7) FE_W(8) FE_W(9) FE_W(10) FE_W(11) FE_W(12) FE_W(13)
-    FE_W(14) FE_W(15) FE_W(16) FE_W(17) FE_W(18) FE_W(19) FE_W(20) FE_W(21) FE_W(22) FE_W(23) FE_W(24) FE_W(25) FE_W(26)
-    FE_W(27) FE_W(28) FE_W(29) FE_W(30) FE_W(31) FE_W(32) FE_W(33) FE_W(34) FE_W(35) FE_W(36) FE_W(37) FE_W(38) FE_W(39)
-    FE_W(40) FE_W(41) FE_W(42) FE_W(43) FE_W(44) FE_W(45) FE_W(46) FE_W(47) FE_W(48) FE_W(49) FE_W(50) FE_W(51) FE_W(52)
-    FE_W(53) FE_W(54) FE_W(55) FE_W(56) FE_W(57) FE_W(58) FE_W(59) FE_W(60) FE_W(61) FE_W(62)
-    default: break;  // 63 or more: nothing to wait for (the counter saturates at 63)
-  }
-#undef FE_W
-}
-
-// One tile [R rows][pitch bytes] of LDS, instructions [k0, k1): lane's LDS offset o = 1024 k + 16 lane -> (row, byte in row)
-// -> its source piece.  Columns: `ncol8` 16-byte pieces starting at piece c8_0 of the (possibly head-padded) row.
-template <class E>
-__device__ __forceinline__ void fe_issue(unsigned char *tile, int pitch, uint32_t pitch_magic, int R, int k0, int k1,
-                                         const typename E::storage *data, int64_t ld, int64_t m0, int nrows, int ncol8, int c8_0,
-                                         const FmHeads &hd) {
-  const int lane = threadIdx.x & 63;
-  const int total = R * pitch;
-#pragma unroll 1
-  for (int k = k0; k < k1; ++k) {
-    const int o = k * 1024 + lane * 16;
-    if (o < total) {
-      const int row = (int)__umulhi((uint32_t)o, pitch_magic);
-      const int cb = o - row * pitch;
-      const int c8 = (cb >> 4) < ncol8 ? (cb >> 4) : 0;
-      const int rowc = row < nrows ? row : nrows - 1;
-      fe_glds16(data + (m0 + rowc) * ld + (int64_t)fm_hchunk(c8_0 + c8, hd) * 8, tile + k * 1024);
-    }
-  }
-}
-
-// The loader's inner loop must be SHORT: measured with the per-instruction address arithmetic above (two magic divisions,
-// a 64-bit row multiply, the exec mask: ~50 instructions, several quarter-rate) the loader wave needed ~27 us per 82 KB row
-// block and the whole engine ran at 0.18 of the byte roof — the loader, not HBM, was the bottleneck.  A lane's piece of
-// instruction k is the same in every full row block: its element offset from the block's first row is computed ONCE per
-// workgroup into registers; issuing is then one 64-bit add + the DMA per instruction.  (Rows past the end of the matrix —
-// the last block of a site only — and chunks that do not start on a head boundary take the slow path above.)
-template <int NK>
-struct FeOffs { uint32_t o[NK]; };
-
-template <int NK>
-__device__ __forceinline__ void fe_offsets(FeOffs<NK> &f, int pitch, uint32_t pitch_magic, int R, int64_t ld, int ncol8,
-                                           const FmHeads &hd) {
-  const int lane = threadIdx.x & 63;
-  const int total = R * pitch;
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int o = k * 1024 + lane * 16;
-    const int row = (int)__umulhi((uint32_t)o, pitch_magic);
-    const int cb = o - row * pitch;
-    const int c8 = (cb >> 4) < ncol8 ? (cb >> 4) : 0;
-    // lanes past the end of the tile (last instruction only) re-read piece 0: their 16 bytes land in the region's 1 KB
-    // rounding, which nothing reads — no per-lane predicate in the issue loop
-    f.o[k] = o < total ? (uint32_t)(row * (int)ld + fm_hchunk(c8, hd) * 8) * (uint32_t)sizeof(uint16_t) : 0u;  // bytes
-  }
-}
-template <class E, int NK>
-__device__ __forceinline__ void fe_issue_fast(unsigned char *tile, const FeOffs<NK> &f, int k0, int k1,
-                                              const typename E::storage *base) {
-  k0 = __builtin_amdgcn_readfirstlane(k0);  // wave-uniform by construction: keep the loop control on the scalar unit
-  k1 = __builtin_amdgcn_readfirstlane(k1);
-  // the block's base address as a SCALAR pair + the lane's 32-bit byte offset: the saddr form of global_load_lds (no 64-bit
-  // per-lane address arithmetic, the offset table stays 32-bit)
-  const uint64_t b64 = reinterpret_cast<uint64_t>(base);
-  const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
-  const char *sbase = reinterpret_cast<const char *>(sb);
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    if (k >= k0 && k < k1) fe_glds16(sbase + f.o[k], tile + k * 1024);
-  }
-}
-
-constexpr int kFeNKA = 44, kFeNKB = 32;  // most DMA instructions of a resident block / of a chunk (planner): their offsets
-                                         // live in the loader's registers (5 waves per workgroup: 256 registers per wave)
-
-// The loader wave's program, kept out of line: its register file (the two offset tables) is allocated apart from the
-// consumers' accumulators (inlined into the kernel the two lived side by side: 256 registers + spills).
-template <class E, bool TRACE>
-__device__ __attribute__((noinline)) void fe_loader(const lora_amd_fm_site &q, unsigned char *lds, int64_t sb_idx,
-                                                    unsigned long long *tr) {
-  int ti = 0;
-  using S = typename E::storage;
-  const int R = q.rows_per_block;
-  const int64_t nrb = (q.M + R - 1) / R;
-  const int64_t rb0 = sb_idx * q.blocks_per_wg;
-  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
-  const bool ax = q.resident_is_x != 0;
-  const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
-  const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
-  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
-  const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
-  const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
-  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
-  const int szA = (R * pa + 1023) & ~1023, szB = (R * pb + 1023) & ~1023, nbufA = q.a_bufs;
-  unsigned char *bufA0 = lds, *ring = lds + nbufA * szA;
-  const int nA = (R * pa + 1023) >> 10, nApart = (nA + nch - 1) / nch, c8a = Ca >> 3;
-  const uint32_t mga = (uint32_t)((0x100000000ull + pa - 1) / (uint32_t)pa), mgb = (uint32_t)((0x100000000ull + pb - 1) / (uint32_t)pb);
-    const int nB = (R * pb + 1023) >> 10;
-    FeOffs<kFeNKA> offa;
-    FeOffs<kFeNKB> offb;
-    fe_offsets<kFeNKA>(offa, pa, mga, R, lda, c8a, hda);
-    fe_offsets<kFeNKB>(offb, pb, mgb, R, ldb, CW >> 3, hdb);
-    // a chunk's pieces are the first chunk's shifted by the chunk's first column — if the chunk starts on a head boundary
-    // (or the rows are dense); the last chunk may be narrower than CW: its surplus columns would read past the row
-    const bool bfast = (hdb.hc == 0 || (CW >> 3) % hdb.hc == 0) && Cb % CW == 0;
-    auto issue_a = [&](unsigned char *tile, int k0, int k1, int64_t m0, int nrows) {
-      if (nrows == R) fe_issue_fast<E, kFeNKA>(tile, offa, k0, k1, da + m0 * lda);
-      else fe_issue<E>(tile, pa, mga, R, k0, k1, da, lda, m0, nrows, c8a, 0, hda);
-    };
-    auto issue_b = [&](unsigned char *tile, int64_t m0, int nrows, int col0, int cw) {
-      if (nrows == R && bfast) fe_issue_fast<E, kFeNKB>(tile, offb, 0, nB, db + m0 * ldb + (int64_t)fm_hchunk(col0 >> 3, hdb) * 8);
-      else fe_issue<E>(tile, pb, mgb, R, 0, nB, db, ldb, m0, nrows, cw >> 3, col0 >> 3, hdb);
-    };
-    {
-      const int64_t m0 = rb0 * R;
-      const int nrows = (int)min((int64_t)R, q.M - m0);
-      issue_a(bufA0, 0, nA, m0, nrows);
-      issue_b(ring, m0, nrows, 0, min(CW, Cb));
-      fe_wait_vmcnt(min(nB, 63));  // the resident block has landed; chunk 0 may still fly
-    }
-#pragma unroll 1
-    for (int blk = 0; blk < nblk; ++blk) {
-      const int64_t m0 = (rb0 + blk) * R, m1 = m0 + R;
-      const int nrows = (int)min((int64_t)R, q.M - m0);
-      const int nrows1 = (int)min((int64_t)R, q.M - m1);
-      const bool more = blk + 1 < nblk;
-      unsigned char *bufAn = bufA0 + (nbufA == 2 ? ((blk + 1) & 1) * szA : 0);
-      fe_stamp<TRACE>(tr, ti, 100);
-      fm_barrier();  // C1
-      fm_barrier();  // C2
-      fm_barrier();  // C3
-      fe_stamp<TRACE>(tr, ti, 103);
-      int newer = 0;   // instructions issued after the chunk the consumers wait for next
-#pragma unroll 1
-      for (int c = 0; c < nch; ++c) {
-        fe_stamp<TRACE>(tr, ti, 110);
-        fe_wait_vmcnt(min(newer, 63));
-        fe_stamp<TRACE>(tr, ti, 111);
-        fm_barrier();  // C4(c): chunk c has landed
-        fe_stamp<TRACE>(tr, ti, 104);
-        // ring slot = running chunk index & 1; the slot of the previous chunk (= of the next one) is free since its C5:
-        // the next tile of the stream goes there
-        unsigned char *nslot = ring + ((blk * nch + c + 1) & 1) * szB;
-        if (c + 1 < nch) {
-          const int col1 = (c + 1) * CW;
-          issue_b(nslot, m0, nrows, col1, min(CW, Cb - col1));
-        } else if (more) {
-          issue_b(nslot, m1, nrows1, 0, min(CW, Cb));
-        }
-        newer = 0;
-        if (more && nbufA == 2) {  // this step's share of the next resident block
-          const int k0 = c * nApart, k1 = min(nA, k0 + nApart);
-          issue_a(bufAn, k0, k1, m1, nrows1);
-          newer = max(k1 - k0, 0);
-        }
-        fe_stamp<TRACE>(tr, ti, 112);
-        fm_barrier();  // C5(c)
-        fe_stamp<TRACE>(tr, ti, 105);
-      }
-      fm_barrier();  // C6
-      fm_barrier();  // C7
-      fm_barrier();  // C8: the resident buffer of block blk is free
-      fe_stamp<TRACE>(tr, ti, 108);
-      if (more && nbufA == 1) issue_a(bufA0, 0, nA, m1, nrows1);
-      // the next resident block must have landed before C1; the next block's chunk 0 was issued BEFORE its last share
-      // (nbufA == 2) or before the whole block (nbufA == 1), so it has landed too — its first C4 waits for nothing
-      if (more) fe_wait_vmcnt(0);
-      fe_stamp<TRACE>(tr, ti, 109);
-    }
-}
-
-template <class E, bool TRACE>
-__global__ __launch_bounds__(kFeThreads, 1) void factors_mfma_engine_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[kFmLdsLarge];
-  using S = typename E::storage;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const lora_amd_fm_site q = sites[lo];
-  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;
-  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
-  const int64_t nrb = (q.M + R - 1) / R;
-  const int64_t rb0 = sb_idx * q.blocks_per_wg;
-  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
-  const bool ax = q.resident_is_x != 0;
-  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
-  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
-  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
-  // LDS carve (every region starts on a 1 KB boundary: DMA instructions never straddle two regions)
-  const int szA = (R * pa + 1023) & ~1023, szB = (R * pb + 1023) & ~1023, nbufA = q.a_bufs;
-  unsigned char *bufA0 = lds, *ring = lds + nbufA * szA;
-  float *scratch = reinterpret_cast<float *>(ring + 2 * szB);
-  unsigned char *ttA = reinterpret_cast<unsigned char *>(scratch) + R * 256, *ttB = ttA + 32 * fm_tpitch(R);
-  const int c8a = Ca >> 3;
-  const int wave = threadIdx.x >> 6;
-
-  unsigned long long *tr = nullptr;
-  if constexpr (TRACE) {  // site 0's offset_dev carries the trace buffer; the traced workgroup = a middle one of the grid
-    if (blockIdx.x == gridDim.x / 2) tr = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(sites[0].offset_dev));
-  }
-  if (wave == 4) {  // the loader wave
-    fe_loader<E, TRACE>(q, lds, sb_idx, tr != nullptr ? tr + 512 : nullptr);
-    return;
-  }
-  if (wave != 0) tr = nullptr;
-  int ti = 0;
-
-  // ==================================================================== consumer waves (threads 0..255)
-  const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
-  const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
-  const int cw0 = min(CW, Cb);
-  mf32x4 acc[kFmMaxRT16];
-  mu32x4 tf[kFmMaxRT16];
-  FmFragSet fcur;  // the fragments of the next tile of the stream: reloaded as soon as phase 1 has consumed them
-  fm_load_fragset<E>(fcur, pka, splita, Ca >> 5);
-#pragma unroll 1
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int64_t rb = rb0 + blk;
-    const int64_t m0 = rb * R;
-    const int nrows = (int)min((int64_t)R, q.M - m0);
-    // one partial slab per ROW BLOCK (no read-modify-write of a shared slab: that read is a trip to L2 per column tile)
-    float *outa = (ax ? q.down_part : q.up_part) + rb * RT * (int64_t)Ca;
-    float *outb = (ax ? q.up_part : q.down_part) + rb * RT * (int64_t)Cb;
-    const unsigned char *bufA = bufA0 + (nbufA == 2 ? (blk & 1) * szA : 0);
-    fe_stamp<TRACE>(tr, ti, 0);
-    fm_barrier();  // C1
-    fe_stamp<TRACE>(tr, ti, 1);
-#pragma unroll
-    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-    fm_phase1_set<E>(acc, bufA, pa, nrt, Ca >> 5, fcur);        // waits for fcur (issued a step ago), then ...
-    fm_load_fragset<E>(fcur, pkb, splitb, cw0 >> 5);             // ... chunk 0's fragments start their trip
-    fm_combine_put<E>(acc, scratch, nrt);
-    fe_stamp<TRACE>(tr, ti, 20);
-    fm_barrier();  // C2
-    fe_stamp<TRACE>(tr, ti, 2);
-    fm_combine_get<E>(scratch, ttA, nrt, R, q.scale, nrows);
-    fe_stamp<TRACE>(tr, ti, 30);
-    fm_barrier();  // C3
-    fe_stamp<TRACE>(tr, ti, 3);
-    fm_load_tfrags<E>(tf, ttA, R, nk2);
-#pragma unroll
-    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-      const int col0 = c * CW, cw = min(CW, Cb - col0);
-      const unsigned char *slot = ring + ((blk * nch + c) & 1) * szB;
-      fe_stamp<TRACE>(tr, ti, 40);
-      fm_barrier();  // C4(c)
-      fe_stamp<TRACE>(tr, ti, 4);
-      fm_phase1_set<E>(acc, slot, pb, nrt, cw >> 5, fcur);
-      if (c + 1 < nch) {
-        const int col1 = col0 + CW;
-        fm_load_fragset<E>(fcur, pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
-      } else {
-        fm_load_fragset<E>(fcur, pka, splita, Ca >> 5);          // the next block's resident tile (same factor)
-      }
-      fe_stamp<TRACE>(tr, ti, 45);
-      fm_phase2<E>(slot, pb, nk2, cw, tf, outb + col0, Cb, RT, false);
-      fe_stamp<TRACE>(tr, ti, 50);
-      fm_barrier();  // C5(c)
-      fe_stamp<TRACE>(tr, ti, 5);
-    }
-    fm_combine_put<E>(acc, scratch, nrt);
-    fe_stamp<TRACE>(tr, ti, 60);
-    fm_barrier();  // C6
-    fe_stamp<TRACE>(tr, ti, 6);
-    fm_combine_get<E>(scratch, ttB, nrt, R, q.scale, nrows);
-    fe_stamp<TRACE>(tr, ti, 70);
-    fm_barrier();  // C7
-    fe_stamp<TRACE>(tr, ti, 7);
-    fm_load_tfrags<E>(tf, ttB, R, nk2);
-    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, false);
-    fe_stamp<TRACE>(tr, ti, 80);
-    fm_barrier();  // C8
-    fe_stamp<TRACE>(tr, ti, 8);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------- host side
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
 
@@ -854,33 +498,6 @@ static bool fm_fit(int64_t M, int K, int N, int r, int act_dtype, int R, int lds
   return false;
 }
 
-// The engine kernel's geometry: resident block x 2 (x 1 if two do not fit), a 2-slot ring of chunks, scratch, T images in
-// 160 KiB.  The chunk as wide as fits (fewer barriers), at most 63 DMA instructions per chunk and per share of the next
-// resident block (the loader's counted waits).
-static bool fm_fit_engine(int64_t M, int K, int N, int r, int act_dtype, int R, FmGeom *g, int *a_bufs, int nb_min = 1) {
-  if (act_dtype == LORA_AMD_F32 || M <= 0 || r < 1 || r > 16 || K % 32 || N % 32 || K < 32 || N < 32) return false;
-  if (R != 32 && R != 64) return false;
-  g->resident_is_x = K <= N;
-  const int Ca = std::min(K, N), Cb = std::max(K, N);
-  g->pitch_a = fm_pitch(Ca);
-  auto up1k = [](int b) { return (b + 1023) & ~1023; };
-  const int szA = up1k(R * g->pitch_a), fixed = R * 256 + 2 * 32 * fm_tpitch(R);
-  for (int nb = 2; nb >= nb_min; --nb) {
-    for (int cwmax = 512; cwmax >= 32; cwmax -= 32) {
-      const int nch = (Cb + cwmax - 1) / cwmax;
-      const int cw = std::min(((Cb + nch - 1) / nch + 31) / 32 * 32, cwmax);
-      const int pb = fm_pitch(cw), szB = up1k(R * pb);
-      const int nchunk = (Cb + cw - 1) / cw;
-      if (nb * szA + 2 * szB + fixed > kFmLdsLarge) continue;
-      if ((szB >> 10) > kFeNKB || (szA >> 10) > kFeNKA || Ca > 128 * kFmNF || cw > 128 * kFmNF) continue;
-      g->R = R; g->cw = cw; g->nchunk = nchunk; g->pitch_b = pb; g->lds = nb * szA + 2 * szB + fixed;
-      *a_bufs = nb;
-      return true;
-    }
-  }
-  return false;
-}
-
 // rows per block and LDS class (1: two workgroups per CU, 2: one) of a site.  A caller's / LORA_AMD_FM_ROWS' row count is
 // tried first in both classes; default: 64 rows, then 32, two workgroups per CU before one.
 static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, FmGeom *g, int *cls) {
@@ -898,14 +515,12 @@ static int fm_rows_env() {
   static const int v = getenv("LORA_AMD_FM_ROWS") ? atoi(getenv("LORA_AMD_FM_ROWS")) : 0;
   return v;
 }
-// row blocks one workgroup walks (LORA_AMD_FM_NB): their partial sums meet in the workgroup's slab.  Register-staged
-// kernel: 1 (measured: with its loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run
-// only serialises: 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks); the engine kernel (loader wave): 8
-static int fm_blocks_per_wg(int64_t nrb, int engine, int64_t block_bytes) {
+// row blocks one workgroup walks (LORA_AMD_FM_NB): their partial sums meet in the workgroup's slab.  Default 1 (measured:
+// with its tile loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run only serialises:
+// 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks, profiles/r04_kbench_fm_variants.log)
+static int fm_blocks_per_wg(int64_t nrb) {
   static const int env = getenv("LORA_AMD_FM_NB") ? atoi(getenv("LORA_AMD_FM_NB")) : 0;
-  // engine: about 640 KB of G + X per workgroup (8 blocks of a 320-wide attention site, 2 of a GEGLU site): long enough to
-  // amortise the exposed first resident block, short enough that the last workgroups do not leave the chip idle
-  const int v = env > 0 ? env : (engine ? (int)std::max<int64_t>(1, (655360 + block_bytes / 2) / block_bytes) : 1);
+  const int v = env > 0 ? env : 1;
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
 }
 
@@ -918,30 +533,16 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   LORA_AMD_CHECK(out != nullptr && rows >= 0 && dtype_ok(act_dtype), LORA_AMD_EINVAL, "factors_mfma_plan: bad argument");
   memset(out, 0, sizeof(*out));
   FmGeom g;
-  int cls = 0, a_bufs = 0;
-  const int hint = rows > 0 ? rows : fm_rows_env();
-  static const bool no_engine = getenv("LORA_AMD_FM_ENGINE") && atoi(getenv("LORA_AMD_FM_ENGINE")) == 0;
-  // the engine (class 3) unless the site has dropout (the mask is applied in registers: register-staged kernel) or the
-  // caller / LORA_AMD_FM_ENGINE=0 turns it off; 64 rows first (half the partial slabs), then 32
-  bool eng = false;
-  if (!(flags & 3) && !no_engine) {
-    if (hint > 0) eng = fm_fit_engine(M, K, N, r, act_dtype, hint, &g, &a_bufs);
-    // a double-buffered resident block first (the next block lands while this one is consumed), 64 rows before 32
-    for (int nb = 2; !eng && nb >= 1; --nb)
-      for (int R = 64; !eng && R >= 32; R >>= 1) eng = fm_fit_engine(M, K, N, r, act_dtype, R, &g, &a_bufs, nb) && a_bufs >= nb;
-  }
-  if (eng) cls = 3;
-  else if (!fm_choose(M, K, N, r, act_dtype, hint, &g, &cls)) return LORA_AMD_OK;
-  out->a_bufs = a_bufs;
+  int cls = 0;
+  (void)flags;  // bit 0 (dropout site) selects the masked kernel at launch time; the geometry is the same
+  if (!fm_choose(M, K, N, r, act_dtype, rows > 0 ? rows : fm_rows_env(), &g, &cls)) return LORA_AMD_OK;
   out->supported = 1;
   out->lds_class = cls;
   out->rank_tile = r <= 4 ? 4 : r <= 8 ? 8 : 16;
   out->rows_per_block = g.R;
   const int64_t nrb = (M + g.R - 1) / g.R;
-  out->blocks_per_wg = fm_blocks_per_wg(nrb, cls == 3, (int64_t)g.R * (N + K) * 2);
-  // one partial slab per row block on the engine (its workgroups walk several blocks for the pipeline only), one per run of
-  // blocks on the register-staged kernel
-  out->nparts = cls == 3 ? (int32_t)nrb : (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
+  out->blocks_per_wg = fm_blocks_per_wg(nrb);
+  out->nparts = (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
@@ -981,7 +582,7 @@ extern "C" int lora_amd_factor_pack(const lora_amd_pack_site *sites_dev, int32_t
 
 extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_t act_dtype, int32_t lds_class,
                                                  int64_t *grid) {
-  LORA_AMD_CHECK(sites && n >= 1 && grid && lds_class >= 1 && lds_class <= 3, LORA_AMD_EINVAL,
+  LORA_AMD_CHECK(sites && n >= 1 && grid && (lds_class == 1 || lds_class == 2), LORA_AMD_EINVAL,
                  "factors_mfma_ragged_plan: bad argument");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "factors_mfma_ragged_plan: f16 / bf16 activations only");
@@ -997,12 +598,7 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
                    "factors_mfma_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
     LORA_AMD_CHECK(q.g && q.x && q.pk_up && q.pk_down && q.up_part && q.down_part, LORA_AMD_EINVAL,
                    "factors_mfma_ragged_plan: site %d: null pointer", i);
-    int a_bufs = 0;
-    const bool ok = lds_class == 3 ? fm_fit_engine(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, &g, &a_bufs)
-                                   : fm_fit(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, lds_class == 1 ? kFmLdsSmall : kFmLdsLarge, &g);
-    LORA_AMD_CHECK(lds_class != 3 || q.dropout_p == 0.f, LORA_AMD_EINVAL,
-                   "factors_mfma_ragged_plan: site %d: a dropout site in an engine table (plan it with flags = 1)", i);
-    q.a_bufs = a_bufs;
+    const bool ok = fm_fit(q.M, q.K, q.N, q.r, act_dtype, q.rows_per_block, lds_class == 1 ? kFmLdsSmall : kFmLdsLarge, &g);
     LORA_AMD_CHECK(ok && ((uintptr_t)q.g % 16) == 0 && ((uintptr_t)q.x % 16) == 0 && q.ldg % 8 == 0 && q.ldx % 8 == 0 &&
                        ((uintptr_t)q.pk_up % 16) == 0 && ((uintptr_t)q.pk_down % 16) == 0 &&
                        heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
@@ -1022,22 +618,11 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
 
 extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
                                                        int32_t lds_class, int32_t act_dtype, int32_t masked, void *stream) {
-  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && lds_class >= 1 && lds_class <= 3,
+  LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
                  LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
-  if (lds_class == 3) {
-    LORA_AMD_CHECK(!masked, LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: the engine kernel takes no dropout sites");
-    const bool trace = getenv("LORA_AMD_FM_TRACE") && atoi(getenv("LORA_AMD_FM_TRACE")) == 1;
-    if (act_dtype == LORA_AMD_F16)
-      hipLaunchKernelGGL((factors_mfma_engine_kernel<f16_t, false>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
-    else if (trace)
-      hipLaunchKernelGGL((factors_mfma_engine_kernel<bf16_t, true>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
-    else
-      hipLaunchKernelGGL((factors_mfma_engine_kernel<bf16_t, false>), dim3((unsigned)grid), dim3(kFeThreads), 0, st, sites_dev, n);
-    return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
-  }
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
 #define FM(E, L)                                                                                                      \
   do {                                                                                                                \

@@ -352,7 +352,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 plan_m = None
                 if (mw is not None and mw.defer_factors and _C.FACTORS_MFMA and DEFER_MASKED_FACTORS
                         and g2.dtype in (torch.bfloat16, torch.float16)):
-                    plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype, 0, p > 0.0)
+                    plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
                 if plan_m is not None and plan_m.supported:
                     key = ("mfma", M, K, N, r, int(plan_m.nparts))
                     up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
@@ -738,7 +738,7 @@ def _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, in_heads, K, 
     mw = getattr(getattr(sink, "owner", None), "merged", None)
     defer = mw is not None and mw.defer_factors
     plan, kind = None, "self"
-    if defer and _C.FACTORS_MFMA:
+    if defer and _C.FACTORS_MFMA_MODE == "all":
         plan = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
         kind = "mfma" if plan.supported else "self"
     if kind == "self":

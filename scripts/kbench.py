@@ -254,7 +254,7 @@ def bench_fm(args):
     """The factor-gradient pass of a whole step (144 sites, batch 4, 512^2) both ways: the VALU pass
     (lora_amd_linear_bwd_factors_self_ragged: 128-row blocks, each row block read twice) and the matrix-core pass
     (lora_amd_factor_pack + lora_amd_linear_bwd_factors_mfma_ragged per LDS class: read once), each followed by the fold
-    (lora_amd_reduce_batched); algorithmic bytes = G + X once.  LORA_AMD_FM_ROWS / LORA_AMD_FM_NB / LORA_AMD_FM_ENGINE select
+    (lora_amd_reduce_batched); algorithmic bytes = G + X once.  LORA_AMD_FM_ROWS / LORA_AMD_FM_NB select
     variants."""
     r, dt = args.rank, torch.bfloat16
     sites = sd15_site_list()

@@ -27,7 +27,7 @@ def test_lane_level_model_of_the_pass_equals_the_dense_formula(args):
 @pytest.mark.parametrize("M,K,N,r", [(16384, 320, 320, 4), (4096, 640, 640, 8), (1024, 1280, 1280, 16), (308, 768, 320, 4),
                                      (16384, 320, 2560, 4), (4096, 640, 5120, 4), (1024, 1280, 10240, 4), (100, 64, 96, 4)])
 def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
-    pl = _C.factors_mfma_plan(M, K, N, r, torch.bfloat16, 0, False, False)  # the register-staged kernel
+    pl = _C.factors_mfma_plan(M, K, N, r, torch.bfloat16)
     assert pl.supported and pl.rows_per_block in (32, 64) and pl.lds_class in (1, 2)
     cap = 81920 if pl.lds_class == 1 else 163840
     assert 0 < pl.lds_bytes <= cap
@@ -50,37 +50,6 @@ def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
     assert (q.cw, q.nchunk, q.pitch_a, q.pitch_b, q.lds_bytes) == (g["cw"], g["nchunk"], g["pitch_a"], g["pitch_b"], g["lds"])
     assert bool(q.resident_is_x) == (K <= N)
     assert q.cw % 32 == 0 and q.rows_per_block * q.cw <= 16384 and q.rows_per_block * q.pitch_b >= q.rows_per_block * 256
-
-
-@pytest.mark.skipif(not _C.available(), reason="C-ABI library not built")
-@pytest.mark.parametrize("M,K,N,r", [(16384, 320, 320, 4), (4096, 640, 640, 8), (308, 768, 320, 4), (16384, 320, 2560, 4),
-                                     (4096, 640, 5120, 4), (100, 64, 96, 4)])
-def test_engine_plan_fits_160k_and_its_waits_are_countable(M, K, N, r):
-    """The engine kernel's geometry (LDS class 3): resident block x 2 + 2-slot chunk ring + scratch + T images inside
-    160 KiB; at most 44 / 32 DMA instructions per resident block / chunk (their per-lane offsets live in the loader wave's
-    registers, and its counted s_waitcnt covers them); wider sites and dropout sites get the register-staged kernel."""
-    pl = _C.factors_mfma_plan(M, K, N, r, torch.bfloat16)
-    assert pl.supported and pl.lds_class == 3 and pl.a_bufs == 2 and 0 < pl.lds_bytes <= 163840
-    nrb = -(-M // pl.rows_per_block)
-    assert pl.nparts == nrb and 1 <= pl.blocks_per_wg <= 8   # one slab per row block, several blocks per workgroup
-    site = (_C.FmSite * 1)()
-    q = site[0]
-    q.g = q.x = q.pk_up = q.pk_down = q.up_part = q.down_part = 4096
-    q.ldg, q.ldx, q.M, q.N, q.K, q.r, q.scale, q.rows_per_block = N, K, M, N, K, r, 1.0, pl.rows_per_block
-    q.blocks_per_wg = pl.blocks_per_wg
-    grid = C.c_int64(0)
-    assert _C.require().lora_amd_factors_mfma_ragged_plan(site, 1, _C.BF16, 3, C.byref(grid)) == 0
-    assert grid.value == -(-nrb // pl.blocks_per_wg)
-    R = pl.rows_per_block
-    n_a, n_b = -(-R * q.pitch_a // 1024), -(-R * q.pitch_b // 1024)
-    assert n_b <= 32 and n_a <= 44 and q.a_bufs == 2
-    assert _C.factors_mfma_plan(M, K, N, r, torch.bfloat16, 0, True).lds_class in (1, 2)  # masked: never the engine
-
-
-@pytest.mark.skipif(not _C.available(), reason="C-ABI library not built")
-def test_wide_sites_keep_the_register_staged_kernel():
-    for (M, K, N) in ((1024, 1280, 1280), (1024, 1280, 10240), (308, 768, 1280)):
-        assert _C.factors_mfma_plan(M, K, N, 4, torch.bfloat16).lds_class in (1, 2)
 
 
 @pytest.mark.skipif(not _C.available(), reason="C-ABI library not built")

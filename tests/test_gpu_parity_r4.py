@@ -47,7 +47,7 @@ def test_ds_read_tr16_b64_semantics(tmp_path):
 
 
 # ----------------------------------------------------------------------------- a2: the matrix-core factor pass
-def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
+def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
     """Build packs + tables for ``specs`` = [(M, K, N, gh, xh)], launch (one launch per LDS class), fold, return per-site
     (d_up, d_down, oracle d_up, oracle d_down, abs bounds, plan)."""
     name = {torch.bfloat16: "bf16", torch.float16: "f16"}[dt]
@@ -64,9 +64,8 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
             gd.view(M, gh[0], gh[2])[:, :, gh[1]:] = 7.0
         if xh:
             xd.view(M, xh[0], xh[2])[:, :, xh[1]:] = -3.0
-        plan = _C.factors_mfma_plan(M, K, N, r, dt, rows, False, engine)
+        plan = _C.factors_mfma_plan(M, K, N, r, dt, rows)
         assert plan.supported, (M, K, N)
-        assert engine or int(plan.lds_class) in (1, 2)  # (the widest sites keep the register-staged kernel either way)
         up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
         down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
         pk_down = torch.full((int(plan.pack_down_elems),), float("nan"), dtype=dt, device=DEV)
@@ -92,7 +91,6 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
     return out
 
 
-@pytest.mark.parametrize("engine", [True, False])
 @pytest.mark.parametrize("M,K,N,r,dt,gh,xh,rows", [
     (16384, 320, 320, 4, torch.bfloat16, None, None, 0), (4096, 640, 640, 8, torch.bfloat16, None, None, 0),
     (1024, 1280, 1280, 16, torch.bfloat16, None, None, 0), (256, 1280, 1280, 4, torch.float16, None, None, 0),
@@ -101,26 +99,24 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0, engine=True):
     (2048, 320, 320, 16, torch.bfloat16, None, (8, 40, 64), 0), (777, 64, 96, 4, torch.bfloat16, None, None, 0),
     (4096, 640, 640, 4, torch.bfloat16, None, None, 64), (5000, 320, 320, 4, torch.bfloat16, None, None, 32),
     (333, 768, 768, 8, torch.bfloat16, None, None, 0)])
-def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows, engine):
+def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows):
     """autograd of lora.py:53-58 for the factors (dB = s G^T (X A^T), dA = (s G B)^T X) through
     lora_amd_factor_pack + lora_amd_linear_bwd_factors_mfma_ragged vs oracle.lora_linear_backward; resident X and
-    resident G sites, chunked wide operands, head-padded rows, a ragged last row block, f16 — on the engine kernel (loader
-    wave + LDS DMA, several row blocks per workgroup accumulating in its slab) and on the register-staged kernel (both
-    LDS classes).  f32-grade tolerance (the 16-bit factor / T operands are split hi + lo)."""
-    (o,) = _fm_run([(M, K, N, gh, xh)], r, 0.7, dt, rows, engine)
-    if rows and not engine:
+    resident G sites, chunked wide operands, both LDS classes, head-padded rows, a ragged last row block, f16.  f32-grade
+    tolerance (the 16-bit factor / T operands are split hi + lo)."""
+    (o,) = _fm_run([(M, K, N, gh, xh)], r, 0.7, dt, rows)
+    if rows:
         assert o["plan"].rows_per_block == rows
     close(o["d_up"], o["duo"], o["absu"], "f32", k=1e-4, msg="dUp")
     close(o["d_down"], o["ddo"], o["absd"], "f32", k=1e-4, msg="dDown")
 
 
-@pytest.mark.parametrize("engine", [True, False])
-def test_factors_mfma_one_launch_for_several_sites_vs_oracle(engine):
+def test_factors_mfma_one_launch_for_several_sites_vs_oracle():
     """Several sites of different shapes, LDS classes and layouts through ONE pack launch and one pass launch per class."""
     specs = [(4096, 320, 320, None, None), (1000, 640, 640, None, None), (2048, 320, 320, (8, 40, 64), None),
              (2048, 320, 320, None, (8, 40, 64)), (308, 768, 1280, None, None), (512, 320, 2560, None, None),
              (100, 1280, 1280, None, None), (1, 320, 320, None, None)]
-    for o in _fm_run(specs, 4, 0.9, engine=engine):
+    for o in _fm_run(specs, 4, 0.9):
         close(o["d_up"], o["duo"], o["absu"], "f32", k=1e-4, msg=f"dUp {o['N']}x{o['K']}")
         close(o["d_down"], o["ddo"], o["absd"], "f32", k=1e-4, msg=f"dDown {o['N']}x{o['K']}")
 
@@ -137,8 +133,8 @@ def test_factors_mfma_pass_with_dropout_vs_oracle(M, K, N, r, p):
     mask = H.philox_dropout_mask(M * N, p, seed, int(off.item())).view(M, N).numpy()
     X, G, A, U = n(x), n(g), n(down), n(up)
     _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s_, None, mask)
-    plan = _C.factors_mfma_plan(M, K, N, r, dt, 0, True)
-    assert plan.supported and plan.lds_class in (1, 2)
+    plan = _C.factors_mfma_plan(M, K, N, r, dt)
+    assert plan.supported
     up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
     down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
     pk_down = torch.empty(int(plan.pack_down_elems), dtype=dt, device=DEV)
