@@ -548,11 +548,6 @@ def svd_bench(args) -> dict:
 
     def step():
         gen = torch.Generator(device=dev).manual_seed(1)
-        if os.environ.get("LORA_AMD_SVD_PER_GROUP", "0") == "1":  # A/B: one batched iteration per shape group (round 2)
-            last = None
-            for tuned, base in groups:
-                last = S.distill_group(tuned, base, rank, 0.99, gen, n_iter=n_iter)
-            return last
         return S.distill_model(groups, rank, 0.99, gen, n_iter=n_iter)[-1]
 
     for _ in range(args.warmup):

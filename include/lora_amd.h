@@ -435,7 +435,7 @@ typedef struct lora_amd_factors_mfma_plan_t {
   int64_t up_part_floats, down_part_floats;
   int64_t pack_up_elems, pack_down_elems;   /* elements (activation dtype) of the two fragment packs of a site */
 } lora_amd_factors_mfma_plan_t;
-/* rows: 0 = the planner's choice (64, else 32; LORA_AMD_FM_ROWS overrides), else 32 / 64 tried first.  flags: reserved (0). */
+/* rows: 0 = the planner's choice (64, else 32), else 32 / 64 tried first.  flags: reserved (0). */
 int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows, int32_t flags,
                                lora_amd_factors_mfma_plan_t *out);
 /* f32 masters -> fragment packs: pk[split][c/8][16][8] in the activation dtype, split 0 = rounded value, split 1 = the

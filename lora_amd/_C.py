@@ -886,7 +886,7 @@ def factors_self_plan(M: int, K: int, N: int, r: int, rows: int = 0) -> FactorsS
 # rows per block of the deferred one-launch factor-gradient pass: throughput-bound, so tall blocks (half the partial
 # slabs of the per-site launch at M = 16384; 64 / 96 / 128 rows measured 1179 / 1141 / 1155 us for the pass and
 # 86 / 63 / 49 us for the fold that follows it)
-SELF_ROWS_DEFERRED = int(os.environ.get("LORA_AMD_SELF_ROWS", "128"))
+SELF_ROWS_DEFERRED = 128
 
 
 def linear_bwd_factors_self(g: torch.Tensor, x: torch.Tensor, down: torch.Tensor, up: torch.Tensor,

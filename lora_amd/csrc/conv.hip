@@ -572,8 +572,6 @@ struct ConvGeo {
 };
 
 static int pick_split(int ngroups, int C, int r) {
-  if (const char *e = getenv("LORA_AMD_CONV_SPLIT"))  // tuning knob (scripts/kbench.py sweeps it)
-    return std::max(1, std::min(atoi(e), std::max(1, C / 8)));
   int s = (512 + ngroups - 1) / ngroups;            // aim at >= 512 workgroups
   s = std::min(s, std::max(1, C / (4 * r)));        // partial-sum traffic <= ~50 % of the activation bytes
   s = std::min(s, std::max(1, C / 8));              // >= 2 channels per wave
@@ -581,7 +579,6 @@ static int pick_split(int ngroups, int C, int r) {
   return std::max(1, s);
 }
 static int stream_split(int ngroups, int C) {       // passes that own their output: split for parallelism only
-  if (const char *e = getenv("LORA_AMD_CONV_SPLIT")) return std::max(1, std::min(atoi(e), std::max(1, C / 8)));
   return std::max(1, std::min((1024 + ngroups - 1) / ngroups, C / 8));  // measured: the dX / dDown passes keep gaining to ~1000 workgroups
 }
 

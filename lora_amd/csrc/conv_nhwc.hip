@@ -544,14 +544,8 @@ __global__ __launch_bounds__(256) void nh_sum_parts_kernel(const float *__restri
 
 // ---------------------------------------------------------------------------- host
 static inline int nh_rank_pad(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
-static inline int nh_env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 static inline int64_t nh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static int nh_pick_pt(int B, int H, int W) {
-  const int forced = nh_env_int("LORA_AMD_NHWC_PT", 0);
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
   const int64_t ntc = (W + 15) / 16;
   const int64_t t4 = (int64_t)B * ((H + 3) / 4) * ntc, t2 = (int64_t)B * ((H + 1) / 2) * ntc;
   if (t4 >= 200) return 4;
@@ -579,21 +573,19 @@ static NhCuts nh_cuts(int B, int C, int H, int W, int r) {
   q.pt = nh_pick_pt(B, H, W);
   // forward: few pixel tiles (small maps) -> also split the channel k-steps (C/32; >= 4 per share, one per wave)
   const int64_t tiles = (int64_t)B * nh_cdiv(H, q.pt) * ntc;
-  int ks = nh_env_int("LORA_AMD_NHWC_KSPLIT", 0);
-  if (ks <= 0) ks = tiles >= 192 ? 1 : (int)nh_cdiv(256, tiles);
+  const int ks = tiles >= 192 ? 1 : (int)nh_cdiv(256, tiles);
   q.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(ks, (C / 32) / 4));
   // input gradient: PT * KS Gt fragments stay in registers -> at most 2 tile rows; channel blocks (C/64) over grid.y
   q.pt_dx = std::min(q.pt, 2);
   const int64_t tiles_dx = (int64_t)B * nh_cdiv(H, q.pt_dx) * ntc;
-  int cs = nh_env_int("LORA_AMD_NHWC_CSPLIT", 0);
-  if (cs <= 0) cs = tiles_dx >= 192 ? 1 : (int)nh_cdiv(256, tiles_dx);
+  const int cs = tiles_dx >= 192 ? 1 : (int)nh_cdiv(256, tiles_dx);
   q.csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cs, C / 64));
   // factor gradient: strips of PR rows, dealt to nsplit workgroups per 64-channel chunk; the nsplit partials are
   // nsplit * 18 r / M of the X stream: at most ~30 % of it (or 4 MB, whichever is more), <= 256 workgroups in all
   q.pr = nh_pick_pr(H, W);
   const int64_t nstrips = (int64_t)B * nh_cdiv(H, std::max(q.pr, 1));
-  int ns = nh_env_int("LORA_AMD_NHWC_SPLIT", 0);
-  if (ns <= 0) {
+  int ns = 0;
+  {
     // at most one workgroup per CU (a 257th would share a CU with another one and double the critical path), the cap
     // on the partial bytes, and then EQUAL shares: strips per workgroup = ceil(nstrips / that bound)
     const int64_t cap = std::max<int64_t>((int64_t)(0.30 * (double)M / (18.0 * r)),
@@ -757,7 +749,7 @@ extern "C" int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, floa
 #define NH_LAUNCH_DD2(E, RQ_)                                                                                   \
   hipLaunchKernelGGL((conv3_ddown_nhwc_kernel<E, RQ_>), grid, dim3(kDdThreads), 0, (hipStream_t)stream,        \
                      (const typename E::storage *)x, gt, down_part, g, q.pr, q.nsplit, rank_pad,          \
-                     nh_env_int("LORA_AMD_NHWC_DD_XCD", 1));
+                     1);
 #define NH_LAUNCH_DD(E)                    \
   switch (r / 4) {                         \
     case 1: NH_LAUNCH_DD2(E, 1) break;     \

@@ -498,7 +498,7 @@ static bool fm_fit(int64_t M, int K, int N, int r, int act_dtype, int R, int lds
   return false;
 }
 
-// rows per block and LDS class (1: two workgroups per CU, 2: one) of a site.  A caller's / LORA_AMD_FM_ROWS' row count is
+// rows per block and LDS class (1: two workgroups per CU, 2: one) of a site.  A caller's row count is
 // tried first in both classes; default: 64 rows, then 32, two workgroups per CU before one.
 static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, FmGeom *g, int *cls) {
   const int caps[2] = {kFmLdsSmall, kFmLdsLarge};
@@ -511,16 +511,11 @@ static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, F
   return false;
 }
 
-static int fm_rows_env() {
-  static const int v = getenv("LORA_AMD_FM_ROWS") ? atoi(getenv("LORA_AMD_FM_ROWS")) : 0;
-  return v;
-}
-// row blocks one workgroup walks (LORA_AMD_FM_NB): their partial sums meet in the workgroup's slab.  Default 1 (measured:
-// with its tile loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run only serialises:
-// 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks, profiles/r04_kbench_fm_variants.log)
+// row blocks one workgroup walks: their partial sums meet in the workgroup's slab (the kernel supports up to kFmMaxNB).
+// 1: with its tile loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run only
+// serialises (measured 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks, profiles/r04_kbench_fm_variants.log)
 static int fm_blocks_per_wg(int64_t nrb) {
-  static const int env = getenv("LORA_AMD_FM_NB") ? atoi(getenv("LORA_AMD_FM_NB")) : 0;
-  const int v = env > 0 ? env : 1;
+  const int v = 1;
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
 }
 
@@ -535,7 +530,7 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   FmGeom g;
   int cls = 0;
   (void)flags;  // bit 0 (dropout site) selects the masked kernel at launch time; the geometry is the same
-  if (!fm_choose(M, K, N, r, act_dtype, rows > 0 ? rows : fm_rows_env(), &g, &cls)) return LORA_AMD_OK;
+  if (!fm_choose(M, K, N, r, act_dtype, rows, &g, &cls)) return LORA_AMD_OK;
   out->supported = 1;
   out->lds_class = cls;
   out->rank_tile = r <= 4 ? 4 : r <= 8 ? 8 : 16;

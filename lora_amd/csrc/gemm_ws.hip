@@ -70,7 +70,6 @@ struct WsArgs {
   const void *x;
   int64_t ldx, M;
   int32_t nsites, row_groups, ntiles, total_panels;
-  int32_t debug;  // timing experiments only (LORA_AMD_WS_DEBUG): 1 = no output stores, 2 = no k-loop, 4 = no input DMA
   lora_amd_ws_site site[LORA_AMD_WS_MAX_SITES];
 };
 
@@ -138,7 +137,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
   const int ldx32 = (int)ldx;
   const int lane_row = lane >> 3, lane_sw = lane & 7;
   auto issue_tile = [&](int tile, int slot) {
-    if (a.debug & 4) return;
     const int64_t m0t = (int64_t)tile * BM;
     const S *tbase = x + m0t * ldx;
     const int rows_valid = (int)min((int64_t)BM, M - m0t);
@@ -279,7 +277,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
     for (int i = 0; i < RS; ++i)
 #pragma unroll
       for (int j = 0; j < CS; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(a.debug & 2))
 #pragma unroll
     for (int kf = 0; kf < KF; ++kf) {
       F xf[RS];
@@ -381,8 +378,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
       return o;
     };
     // ---- epilogue: lane holds OUT[m = i*16 + l15][n_wave + j*16 + lg*4 + 0..3]
-    if (a.debug & 1) {
-    } else if (cols8 && !accum) {  // the common case, branch-free: 8-byte stores, always issued (rows past M -> trash line)
+    if (cols8 && !accum) {  // the common case, branch-free: 8-byte stores, always issued (rows past M -> trash line)
 #pragma unroll
       for (int i = 0; i < RS; ++i) {
         const int64_t m = m0 + i * 16 + l15;
@@ -533,8 +529,6 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
   const int BN = c.CS * 64, BM = c.RS * 16;
   WsArgs a;
   a.x = x; a.ldx = ldx; a.M = M; a.nsites = nsites;
-  static const int dbg = getenv("LORA_AMD_WS_DEBUG") ? atoi(getenv("LORA_AMD_WS_DEBUG")) : 0;
-  a.debug = dbg;
   a.ntiles = (int)((M + BM - 1) / BM);
   int panels = 0;
   for (int s = 0; s < nsites; ++s) {

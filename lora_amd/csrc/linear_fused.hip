@@ -1086,16 +1086,9 @@ static BwdGeom bwd_geom(int64_t M, int cols, int RT, int cap) {
   BwdGeom q;
   const int c8 = cols / 8;
   // column tile = a power of two of 16-byte chunks (lane groups reduce by xor-shuffle): the largest one dividing the row
-  // (320 columns = 40 chunks -> five 8-chunk tiles).  LORA_AMD_POW2_TILES=0 selects the alternative that round 3 tried —
-  // the next power of two with the last tile overhanging (40 chunks = ONE 64-lane tile, 24 lanes idle; the kernels guard
-  // the overhang) — which measured 1 % SLOWER on configs[3] (21.75 vs 21.97 steps/s, same box): fewer slot reductions
-  // do not pay for the idle lanes.
-  int ct8 = pow2_divisor(c8, cap);
-  static const bool padded = getenv("LORA_AMD_POW2_TILES") && atoi(getenv("LORA_AMD_POW2_TILES")) == 0;
-  if (padded && ct8 < 32 && ct8 < cap) {
-    ct8 = 4;
-    while (ct8 < c8 && ct8 < std::min(cap, 64)) ct8 *= 2;
-  }
+  // (320 columns = 40 chunks -> five 8-chunk tiles; the next power of two with the last tile overhanging measured 1 %
+  // slower on configs[3], round 3)
+  const int ct8 = pow2_divisor(c8, cap);
   q.log_ct8 = ilog2(ct8);
   q.nct = (c8 + ct8 - 1) / ct8;
   // rows per block: as many workgroups as stay co-resident (3 per CU by LDS -> 768) and no more, so that no CU is
@@ -1214,8 +1207,7 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
   hipLaunchKernelGGL((linear_bwd_g_kernel<E, 16, D, true>), dim3(grid), dim3(kFT), 0, st,                   \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \
                      N, r, q.log_ct8, q.nct, q.rows_per_block, scale, dropout_p, seed, offset, offset_dev)
-  static const bool fcl = !(getenv("LORA_AMD_BWDG_FCL") && atoi(getenv("LORA_AMD_BWDG_FCL")) == 0);
-#define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else if (fcl) BG16(E, D); else BG(E, 16, D); } while (0)
+#define BG_RT(E, D) do { if (RT == 4) BG(E, 4, D); else if (RT == 8) BG(E, 8, D); else BG16(E, D); } while (0)
 #define BG_E(E) do { if (drop) BG_RT(E, true); else BG_RT(E, false); } while (0)
   switch (act_dtype) {
     case LORA_AMD_F32: BG_E(f32_t); break;

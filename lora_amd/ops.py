@@ -70,13 +70,10 @@ class dropout_pool:
         return False
 
 
-# nn.Dropout on the branch inside the weight-stationary kernels (0: frozen GEMM + streaming kernels, for A/B runs)
-WS_DROPOUT = os.environ.get("LORA_AMD_WS_DROPOUT", "3") != "0"
-# 1: only the shapes of the p = 0 table (_C.static_fwd_choice / static_bwd_choice); 2: under dropout the forward also
-# takes the shapes whose p = 0 choice is another kernel (there the alternative is the rank-16 VALU kernel on top of the
-# library GEMM; configs[3], same box: 21.26 -> 22.20 steps/s); 3 (default): the backward as well (22.20 -> 22.44)
-WS_DROPOUT_WIDE = os.environ.get("LORA_AMD_WS_DROPOUT", "3") in ("2", "3")
-WS_DROPOUT_WIDE_BWD = os.environ.get("LORA_AMD_WS_DROPOUT", "3") == "3"
+# nn.Dropout on the branch runs inside the weight-stationary kernels; under dropout they also take the shapes whose p = 0
+# choice is another kernel, forward and backward (the alternative there is the rank-16 VALU kernel on top of the library
+# GEMM; configs[3], same box: 21.26 -> 22.20 -> 22.44 steps/s, round 2).  Module constants (tests flip them), no switches.
+WS_DROPOUT = WS_DROPOUT_WIDE = WS_DROPOUT_WIDE_BWD = True
 
 
 # When a list: every adapter forward / backward appends (phase, kernel path, M, K, N, r) — what bench.py turns into
@@ -404,13 +401,32 @@ class LoraLinearFunction(torch.autograd.Function):
         return dx, dw, db, d_down, d_up, None, None, None, None
 
 
-# Input gradients of the merged-weight sites as F.linear(G, W_eff^T-stored) instead of G @ W_eff (see MergedWeights.lookup)
-TRANSPOSED_DX = os.environ.get("LORA_AMD_TRANSPOSED_DX", "1") != "0"
-# Factor gradients of the dropout sites that run the fused MFMA input-gradient kernels: deferred to the step's matrix-core
-# pass (mask regenerated inside) instead of one linear_bwd_factors launch per site (A/B: 0)
-DEFER_MASKED_FACTORS = os.environ.get("LORA_AMD_DEFER_MASKED_FACTORS", "1") != "0"
-# q / k / v (k / v) of an attention block on ONE concatenated scratch weight: one forward GEMM per group (A/B: 0)
-CONCAT_GROUPS = os.environ.get("LORA_AMD_CONCAT_GROUPS", "1") != "0"
+# Module constants (tests and A/B scripts flip them; not environment switches):
+# input gradients of the merged-weight sites as F.linear(G, W_eff^T-stored) instead of G @ W_eff (MergedWeights.lookup);
+TRANSPOSED_DX = True
+# factor gradients of the dropout sites that run the fused MFMA input-gradient kernels: deferred to the step's matrix-core
+# pass (mask regenerated inside) instead of one linear_bwd_factors launch per site (configs[3]: 22.54 -> 24.09 steps/s,
+# same box, profiles/r04_cfg3_ab.txt);
+DEFER_MASKED_FACTORS = True
+# q / k / v (k / v) of an attention block on ONE concatenated scratch weight: one forward GEMM per group (+0.8 %, same box)
+CONCAT_GROUPS = True
+
+
+def apply_ab_overrides(spec: str, namespace: dict) -> dict:
+    """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
+    above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "WS_DROPOUT", "WS_DROPOUT_WIDE", "WS_DROPOUT_WIDE_BWD")
+    done = {}
+    for item in filter(None, (s.strip() for s in spec.split(","))):
+        name, _, val = item.partition("=")
+        if name not in allowed:
+            raise ValueError(f"LORA_AMD_AB: unknown constant {name!r} (one of {', '.join(allowed)})")
+        namespace[name] = done[name] = val.strip() not in ("0", "", "false", "False")
+    return done
+
+
+apply_ab_overrides(os.environ.get("LORA_AMD_AB", ""), globals())
+
 # Rounding of the in-step merge of 16-bit weights (csrc/merge_step.hip): "dither" (default) = nearest with a fixed
 # per-element dither, so that a delta below half an ulp of the frozen weight survives in the row sums; "once" = nearest even
 MERGE_ROUNDING = _C.ROUND_ONCE if os.environ.get("LORA_AMD_MERGE_ROUNDING", "dither") == "once" else _C.ROUND_DITHER
@@ -451,7 +467,7 @@ class MergedWeights:
         self._fresh_at = None
         # factor gradients of every site in ONE launch after the backward (trainer: FlatLoraState.reduce_pending):
         # the backward of a site only records (G, X, factors, partial slabs); see flush_factors
-        self.defer_factors = state is not None and os.environ.get("LORA_AMD_DEFER_FACTORS", "1") != "0"
+        self.defer_factors = state is not None
         self._owed = []
         self._tables = {}    # (pass, dtype, rank tile, LDS class, table bytes) -> [eager (pinned, device) pair, copy event, spare pairs]
         self._packs = {}     # (down ptr, up ptr, dtype) -> (pk_down, pk_up, down, up): fragment packs of the matrix-core pass

@@ -52,9 +52,7 @@ def _run(q, k, v, backend: Optional[str], pad_to: int, pad_v: bool = True):
 
 def _pad_candidates(d: int):
     """Head sizes worth timing: as is, and the next multiples of 16 / 32 / 64-128-256 (what the library kernels are
-    specialised for: 40 -> 48, 64; 80 -> 96, 128).  LORA_AMD_SDPA_PADS=0 keeps only the 64/128/256 step."""
-    if os.environ.get("LORA_AMD_SDPA_PADS", "1") == "0":
-        return sorted({d, _padded(d)})
+    specialised for: 40 -> 48, 64; 80 -> 96, 128)."""
     return sorted({d, -(-d // 16) * 16, -(-d // 32) * 32, _padded(d)})
 
 

@@ -357,6 +357,17 @@ class GraphedForwardBackward:
             for _ in range(warmup):  # also builds every lazily-allocated workspace / descriptor table
                 body()
                 state.zero_grad()
+            # the merged-weight site table is built by the first refresh() AFTER the last new site / layout appeared, and
+            # layouts keep appearing while the host model settles (the head-padded projections exist from the second
+            # forward on): warm up until a step adds nothing, or the capture would find no table and the caller would fall
+            # back to eager execution (round 3's configs[2] line ran 23 % slow for exactly this reason)
+            mw = getattr(state, "merged", None)
+            for _ in range(4):
+                if mw is None or (mw._plans is not None and len(mw.entries) == getattr(self, "_n_entries", -1)):
+                    break
+                self._n_entries = len(mw.entries)
+                body()
+                state.zero_grad()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

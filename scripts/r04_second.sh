@@ -16,7 +16,7 @@ done
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
 timeout 400 python bench.py $ARGS > $OUT/r04b_bench_default.json 2> $OUT/r04b_bench_default.err
 LORA_AMD_FACTORS_MFMA=0 timeout 400 python bench.py $ARGS > $OUT/r04b_bench_valu.json 2> $OUT/r04b_bench_valu.err
-LORA_AMD_CONCAT_GROUPS=0 timeout 400 python bench.py $ARGS > $OUT/r04b_bench_noconcat.json 2> $OUT/r04b_bench_noconcat.err
+LORA_AMD_AB=CONCAT_GROUPS=0 timeout 400 python bench.py $ARGS > $OUT/r04b_bench_noconcat.json 2> $OUT/r04b_bench_noconcat.err
 LORA_AMD_MERGE_ROUNDING=once timeout 400 python bench.py $ARGS > $OUT/r04b_bench_once.json 2> $OUT/r04b_bench_once.err
 python - <<'PY'
 import json

@@ -154,6 +154,50 @@ def test_factors_mfma_pass_with_dropout_vs_oracle(M, K, N, r, p):
     close(n(d_down), ddo, (s_ * Gm @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
 
 
+def test_factor_pass_selection_modes_agree(monkeypatch):
+    """LORA_AMD_FACTORS_MFMA = masked (default) | all | 0: which deferred sites take the matrix-core pass.  One step of a
+    small bf16 UNet on the merged-weight path (maskless sites) gives the same flat gradient in all three positions: VALU pass,
+    matrix-core pass, VALU pass again."""
+    from lora_amd.standin import tiny_unet
+
+    torch.manual_seed(0)
+    unet = tiny_unet(cross_attention_dim=64).to(DEV).to(torch.bfloat16)
+    unet.requires_grad_(False)
+    L.inject_trainable_lora(unet, r=4)
+    T.promote_lora_to_fp32(unet)
+    for m in unet.modules():
+        if isinstance(m, L.LoraInjectedLinear):
+            m.lora_up.weight.data.normal_(0, 0.05)
+    unet.train()
+    st = T.FlatLoraState([{"params": T.lora_params(unet), "lr": 1e-3, "weight_decay": 1e-2}], max_grad_norm=1.0,
+                         device=torch.device(DEV))
+    st.attach_direct_grads(unet)
+    merged = st.enable_merged_weights(unet)
+    g = torch.Generator().manual_seed(3)
+    lat, ehs = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16(), torch.randn(2, 77, 64, generator=g).to(DEV).bfloat16()
+    noise, ts = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16(), torch.randint(0, 1000, (2,), generator=g).to(DEV)
+    sched = DDPMScheduler()
+    grads, kinds = {}, {}
+    for mode in ("masked", "all", "none"):
+        monkeypatch.setattr(_C, "FACTORS_MFMA_MODE", mode)
+        monkeypatch.setattr(_C, "FACTORS_MFMA", mode != "none")
+        st.zero_grad()
+        ops.PATH_LOG = []
+        try:
+            T.forward_backward(unet, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
+            st.reduce_pending()
+        finally:
+            log_, ops.PATH_LOG = ops.PATH_LOG, None
+        grads[mode] = st.flat_g.clone()
+        kinds[mode] = {path for ph, path, *_ in log_ if ph == "bwd"}
+    assert any("deferred_mfma" in k for k in kinds["all"]) and not any("deferred_mfma" in k for k in kinds["masked"])
+    assert any("deferred_self" in k for k in kinds["masked"]) and any("deferred_self" in k for k in kinds["none"])
+    ref = grads["masked"]
+    assert float(ref.abs().max()) > 0
+    for mode in ("all", "none"):
+        assert float((grads[mode] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), mode
+
+
 def test_philox_restatement_equals_the_kernels_dropout_mask():
     """tests/helpers.philox_dropout_mask (torch integer arithmetic) == the multipliers csrc/common.hpp's dropout_mult8
     applies for the same (seed, offset): what the whole-step dropout parity test below hands to the oracle."""

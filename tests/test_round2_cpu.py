@@ -208,7 +208,13 @@ def test_conv_layout_routing_is_decided_from_strides_only():
     assert not ops.conv_nhwc_ok(xl.float(), w3.float(), 4, *geom3)     # f32 activations
     one = torch.zeros(2, 64, 1, 1, dtype=torch.bfloat16)  # H = W = 1: both formats at once -> NCHW path
     assert not ops.conv_nhwc_ok(one, w1, 4, *geom1)
-    assert ops.WS_DROPOUT and ops.WS_DROPOUT_WIDE and ops.WS_DROPOUT_WIDE_BWD  # defaults (LORA_AMD_WS_DROPOUT unset)
+    assert ops.WS_DROPOUT and ops.WS_DROPOUT_WIDE and ops.WS_DROPOUT_WIDE_BWD  # defaults
+    # the one A/B switch: LORA_AMD_AB flips module constants by name, and nothing else
+    ns = {"CONCAT_GROUPS": True, "WS_DROPOUT": True}
+    assert ops.apply_ab_overrides("CONCAT_GROUPS=0, WS_DROPOUT=1", ns) == {"CONCAT_GROUPS": False, "WS_DROPOUT": True}
+    assert ns == {"CONCAT_GROUPS": False, "WS_DROPOUT": True}
+    with pytest.raises(ValueError):
+        ops.apply_ab_overrides("NOT_A_CONSTANT=1", {})
 
 
 def test_weight_cache_keys_accept_inference_tensors():
