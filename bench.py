@@ -328,6 +328,9 @@ def _site_bytes(phase: str, path: str, M: int, K: int, N: int, r: int, e: int = 
     return ((2 * M * K + M * N + N * K) * e + 2 * ab) if fused else (M * N * e + 3 * M * K * e + 2 * ab)
 
 
+PATH_LOG_FILE = None  # --path-log
+
+
 def adapter_path_profile(step_fn, state) -> dict:
     """One EAGER step under torch.profiler (kineto's device-side kernel records, i.e. kernel durations without launch
     gaps): which kernel ran which adapter site (ops.PATH_LOG), device time of every lora_amd:: kernel, and the adapter
@@ -379,6 +382,9 @@ def adapter_path_profile(step_fn, state) -> dict:
         kern["(library GEMM) X W_eff^T / G W_eff of the merged-weight sites"] = [merged_gemm_calls, merged_gemm_us]
         ours_us += merged_gemm_us
     choices = Counter((ph, path) for ph, path, *_ in log_)
+    if PATH_LOG_FILE:
+        with open(PATH_LOG_FILE, "w") as f:
+            json.dump([list(map(lambda v: v if isinstance(v, (int, float, str)) else str(v), rec)) for rec in log_], f)
     byts = sum(_site_bytes(*rec) for rec in log_)
     mw = getattr(state, "merged", None)
     if mw is not None:
@@ -627,6 +633,8 @@ def main():
     ap.add_argument("--standin", choices=["sd15", "tiny"], default="sd15", help="tiny: 4-level miniature UNet (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--path-log", default=None, help="write the adapter-path profile's per-site records (phase, kernel path, "
+                    "M, K, N, r) of one eager step to this JSON file")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary lines (other BASELINE "
                     "geometries, host options off, ATen adapters) the default 1-GPU run appends under `secondary`")
     ap.add_argument("--secondary-budget", type=float, default=420.0, help="seconds all secondary lines may take together")
@@ -635,6 +643,8 @@ def main():
                     "instead of the training step; prints its own JSON line")
     ap.add_argument("--svd-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global PATH_LOG_FILE
+    PATH_LOG_FILE = args.path_log
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
     if args.svd_worker:

@@ -132,9 +132,13 @@ typedef struct lora_amd_mstep_site {
   int32_t tiles_k, reserved;
   int64_t tile_begin;
 } lora_amd_mstep_site;
-int lora_amd_merge_step_plan(lora_amd_mstep_site *sites_host, int32_t n, int32_t w_dtype, int64_t *total_tiles);
-int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t total_tiles, int32_t rank_max,
+int lora_amd_merge_step_plan(lora_amd_mstep_site *sites_host, int32_t n, int32_t w_dtype, int64_t *plan_value);
+/* plan_value: what the plan returned (tile count and tile geometry, opaque) */
+int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t plan_value, int32_t rank_max,
                         int32_t w_dtype, float alpha, int32_t rounding, void *stream);
+/* Tuning hook (scripts/kbench.py): tile geometry 0..3 = 128x64 | 64x128 | 128x128 | 256x64 (rows x columns; applies to
+ * tables planned after the call), dither form 1 = one hash per element, 2 = one hash chain per 16-byte chunk.  < 0 keeps. */
+int lora_amd_merge_step_set_tuning(int32_t tile, int32_t dither);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
  * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100

@@ -27,7 +27,7 @@ _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 # every symbol include/lora_amd.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
-    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning",
+    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning",
     "lora_amd_merge_step_plan", "lora_amd_merge_step",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
@@ -209,6 +209,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_merge_step.argtypes = [vp, i32, i64, i32, i32, f32, i32, vp]
     lib.lora_amd_merge_step_plan.restype = lib.lora_amd_merge_step.restype = C.c_int
     lib.lora_amd_merge_set_tuning.argtypes = [i64, i64]
+    lib.lora_amd_merge_step_set_tuning.argtypes = [i32, i32]
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
                                            f32, u64, u64, vp, vp]
@@ -497,17 +498,22 @@ class MergeStepPlan:
         total = C.c_int64(0)
         _check(lib.lora_amd_merge_step_plan(arr, len(sites), dtype_code(self.w_dtype), C.byref(total)),
                "lora_amd_merge_step_plan")
-        self.n_sites, self.total_tiles, self.host = len(sites), total.value, arr
+        self.n_sites, self.plan_value, self.host = len(sites), total.value, arr
+        self.total_tiles = total.value & ((1 << 40) - 1)
         self.table = table_to_device(arr, self.device)
 
     def launch(self, alpha: float = 1.0, rounding: int = ROUND_ONCE) -> None:
-        _check(require().lora_amd_merge_step(self.table.data_ptr(), self.n_sites, self.total_tiles, self.rank_max,
+        _check(require().lora_amd_merge_step(self.table.data_ptr(), self.n_sites, self.plan_value, self.rank_max,
                                              dtype_code(self.w_dtype), float(alpha), int(rounding), _stream()),
                "lora_amd_merge_step")
 
 
 def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
     require().lora_amd_merge_set_tuning(int(tile_elems), int(blocks_per_cu))
+
+
+def merge_step_set_tuning(tile: int = -1, dither: int = -1) -> None:
+    _check(require().lora_amd_merge_step_set_tuning(int(tile), int(dither)), "lora_amd_merge_step_set_tuning")
 
 
 # ----------------------------------------------------------------------------- K1/K2 primitives

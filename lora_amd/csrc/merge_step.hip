@@ -35,9 +35,12 @@ namespace lora_amd {
 typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMsThreads = 256;
-constexpr int kMsTR = 128, kMsTC = 64;          // tile: rows (n) x columns (k)
-constexpr int kMsPitch = kMsTC * 2 + 4;         // bytes per LDS image row: 132 (the column gather is then 2-way at worst)
 constexpr int kMsMaxSitesLds = 1024;
+// tile geometries (rows n x columns k); the LDS image row is TC * 2 + 4 bytes (the column gather is then 2-way at worst)
+struct MsTile { int tr, tc; };
+constexpr MsTile kMsTiles[4] = {{128, 64}, {64, 128}, {128, 128}, {256, 64}};
+static int g_ms_tile = 0;     // lora_amd_merge_step_set_tuning
+static int g_ms_dither = 2;   // 1: one hash per element; 2: two hashes per 16-byte chunk, 16-bit windows of the 64 bits
 
 __device__ __forceinline__ int ms_map(int i, int d, int D) { return d ? (i / d) * D + (i % d) : i; }
 
@@ -46,6 +49,24 @@ __device__ __forceinline__ uint32_t ms_dither16(uint32_t lo, uint32_t hi) {
   uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u + 0x165667B1u;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
   return h >> 16;
+}
+
+// the dithers of the 8 elements of a 16-byte chunk from ONE hash chain (four 32-bit multiplies per chunk instead of
+// twenty-four: v_mul_lo_u32 is a quarter-rate instruction and the per-element hash was half of the kernel's VALU time):
+// element i takes bytes (i, i + 1 mod 8) of the 64 hashed bits — uniform 16-bit marginals, independent high bytes
+struct MsDither8 { uint32_t h1, h2; };
+__device__ __forceinline__ MsDither8 ms_dither_chunk(uint32_t lo, uint32_t hi) {
+  uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u + 0x165667B1u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+  MsDither8 d;
+  d.h1 = h * 0x297A2D39u; d.h1 ^= d.h1 >> 15;
+  d.h2 = h * 0xC2B2AE3Du; d.h2 ^= d.h2 >> 13;
+  return d;
+}
+template <int I>
+__device__ __forceinline__ uint32_t ms_dither_pick(const MsDither8 &d) {
+  // v_perm_b32: selector bytes 0-3 = h1's bytes, 4-7 = h2's bytes, 0x0c = zero
+  return __builtin_amdgcn_perm(d.h2, d.h1, 0x0c0c0000u | (uint32_t)(((I + 1) & 7) << 8) | (uint32_t)I);
 }
 
 // f32 -> 16-bit storage bits, nearest-even or dithered (see the header).  Finite inputs.
@@ -75,13 +96,15 @@ __device__ __forceinline__ uint32_t ms_round(float v, uint32_t u16) {
   }
 }
 
-template <class EW, int RT, bool DITHER>
+template <class EW, int RT, int DITHER, int TR, int TC>
 __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_mstep_site *__restrict__ sites, int n_sites,
                                                                 float alpha) {
   using SW = typename EW::storage;
+  constexpr int C8 = TC / 8, SLOTS = kMsThreads / C8, U = TR / SLOTS, PITCH = TC * 2 + 4, CH = TR / 8;
+  static_assert(U >= 1 && U * SLOTS == TR && (CH & (CH - 1)) == 0, "tile geometry");
   __shared__ int64_t s_begin[kMsMaxSitesLds];
-  __shared__ __attribute__((aligned(16))) float s_up[kMsTR * RT];
-  __shared__ __attribute__((aligned(16))) unsigned char s_img[kMsTR * kMsPitch];
+  __shared__ __attribute__((aligned(16))) float s_up[TR * RT];
+  __shared__ __attribute__((aligned(16))) unsigned char s_img[TR * PITCH];
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
   int si;
@@ -106,10 +129,10 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
   const int r = s.r;
   const int64_t tl = tile - s.tile_begin;
   const int tn = (int)(tl / s.tiles_k), tk = (int)(tl - (int64_t)tn * s.tiles_k);
-  const int row0 = tn * kMsTR, col0 = tk * kMsTC;
-  const int nrows = min(kMsTR, s.N - row0);
-  const int ncol8 = min(kMsTC, s.K - col0) >> 3;   // 16-byte chunks of this tile (K % 8 == 0)
-  const int cl = tid & 7, slot = tid >> 3;          // 8 chunk columns x 32 row slots
+  const int row0 = tn * TR, col0 = tk * TC;
+  const int nrows = min(TR, s.N - row0);
+  const int ncol8 = min(TC, s.K - col0) >> 3;      // 16-byte chunks of this tile (K % 8 == 0)
+  const int cl = tid % C8, slot = tid / C8;         // C8 chunk columns x SLOTS row slots
   const bool live = cl < ncol8;
   const int col = col0 + (live ? cl : 0) * 8;      // idle lanes of a ragged last column tile stay inside the row
 
@@ -136,17 +159,16 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
 
   const SW *win = reinterpret_cast<const SW *>(s.w) + (int64_t)row0 * s.K + col;
   SW *wout = reinterpret_cast<SW *>(s.out) + ms_map(col, s.col_d, s.col_D);
-  constexpr int U = kMsTR / 32;  // rows per thread
   su32x4 w[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int rl = slot + u * 32;
+    const int rl = slot + u * SLOTS;
     const bool ok = live && rl < nrows;
     w[u] = __builtin_nontemporal_load(gl(reinterpret_cast<const su32x4 *>(win + (int64_t)(ok ? rl : 0) * s.K)));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int rl = slot + u * 32;
+    const int rl = slot + u * SLOTS;
     if (!(live && rl < nrows)) continue;
     union { su32x4 v; SW e[8]; } in;
     in.v = w[u];
@@ -159,38 +181,43 @@ __global__ __launch_bounds__(kMsThreads) void merge_step_kernel(const lora_amd_m
       for (int i = 0; i < 8; ++i) p[i] = fmaf(uj, fc[j][i], p[i]);
     }
     const int n = row0 + rl;
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (DITHER == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = ms_dither16((uint32_t)n * (uint32_t)s.K + (uint32_t)(col + i), (uint32_t)s.dither_key);
+    } else if constexpr (DITHER == 2) {
+      const MsDither8 h = ms_dither_chunk((uint32_t)n * (uint32_t)s.K + (uint32_t)col, (uint32_t)s.dither_key);
+      d[0] = ms_dither_pick<0>(h); d[1] = ms_dither_pick<1>(h); d[2] = ms_dither_pick<2>(h); d[3] = ms_dither_pick<3>(h);
+      d[4] = ms_dither_pick<4>(h); d[5] = ms_dither_pick<5>(h); d[6] = ms_dither_pick<6>(h); d[7] = ms_dither_pick<7>(h);
+    }
     uint32_t b[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float v = fmaf(alpha, p[i], EW::to_f(in.e[i]));
-      uint32_t d = 0;
-      if constexpr (DITHER) d = ms_dither16((uint32_t)n * (uint32_t)s.K + (uint32_t)(col + i), (uint32_t)s.dither_key);
-      b[i] = ms_round<EW, DITHER>(v, d);
-    }
+    for (int i = 0; i < 8; ++i) b[i] = ms_round<EW, DITHER != 0>(fmaf(alpha, p[i], EW::to_f(in.e[i])), d[i]);
     su32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = b[2 * i] | (b[2 * i + 1] << 16);
     __builtin_nontemporal_store(o, gl(reinterpret_cast<su32x4 *>(wout + (int64_t)ms_map(n, s.row_d, s.row_D) * s.ld_out)));
     if (s.out_t != nullptr) {
-      uint32_t *img = reinterpret_cast<uint32_t *>(s_img + rl * kMsPitch + cl * 16);
+      uint32_t *img = reinterpret_cast<uint32_t *>(s_img + rl * PITCH + cl * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i) img[i] = o[i];
     }
   }
   if (s.out_t == nullptr) return;   // site-uniform
   __syncthreads();
-  // the image column-wise: a task = (column k of the tile, chunk of 8 rows); lanes take k fastest (4 consecutive k per
-  // 16 lanes x ... ) so that one instruction stores 16 row chunks = 256 contiguous bytes of 4 rows of W_eff^T
+  // the image column-wise: a task = (column k of the tile, chunk of 8 rows); lanes take k fastest (4 consecutive k, then
+  // the row chunks) so that one instruction stores whole runs of 16-byte row chunks: 256 contiguous bytes per k row of
+  // W_eff^T for a 128-row tile
   const int nk = ncol8 * 8, nchunks = (nrows + 7) >> 3;
   SW *wt = reinterpret_cast<SW *>(s.out_t);
-  for (int t = tid; t < nk * 16; t += kMsThreads) {
-    const int kq = t >> 6, rem = t & 63;          // 4 columns per group of 64 tasks
+  for (int t = tid; t < nk * CH; t += kMsThreads) {
+    const int kq = t / (4 * CH), rem = t % (4 * CH);  // 4 columns per group of 4 CH tasks
     const int k = kq * 4 + (rem & 3), ch = rem >> 2;
     if (ch >= nchunks) continue;
-    const unsigned char *src = s_img + (ch * 8) * kMsPitch + k * 2;
+    const unsigned char *src = s_img + (ch * 8) * PITCH + k * 2;
     unsigned short e[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = *reinterpret_cast<const unsigned short *>(src + i * kMsPitch);
+    for (int i = 0; i < 8; ++i) e[i] = *reinterpret_cast<const unsigned short *>(src + i * PITCH);
     const int n0 = row0 + ch * 8;
     su32x4 o;
 #pragma unroll
@@ -227,17 +254,21 @@ extern "C" int lora_amd_merge_step_plan(lora_amd_mstep_site *sites, int32_t n, i
                        ((uintptr_t)s.up & 3u) == 0 && s.ld_out >= kp && s.ld_out % 8 == 0 &&
                        (s.out_t == nullptr || (s.ld_out_t >= np && s.ld_out_t % 8 == 0)),
                    LORA_AMD_EINVAL, "merge_step_plan: site %d: 16-byte aligned tensors and row strides expected", i);
-    s.tiles_k = (s.K + kMsTC - 1) / kMsTC;
+    const MsTile tg = kMsTiles[g_ms_tile];
+    s.tiles_k = (s.K + tg.tc - 1) / tg.tc;
     s.tile_begin = acc;
-    acc += (int64_t)s.tiles_k * ((s.N + kMsTR - 1) / kMsTR);
+    acc += (int64_t)s.tiles_k * ((s.N + tg.tr - 1) / tg.tr);
   }
   LORA_AMD_CHECK(acc < (1ll << 31), LORA_AMD_EINVAL, "merge_step_plan: too many tiles");
-  *total_tiles = acc;
+  *total_tiles = acc | ((int64_t)g_ms_tile << 40);  // opaque to the caller: the tile count and the geometry it was planned for
   return LORA_AMD_OK;
 }
 
-extern "C" int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t total_tiles, int32_t rank_max,
+extern "C" int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t plan_value, int32_t rank_max,
                                    int32_t w_dtype, float alpha, int32_t rounding, void *stream) {
+  const int ms_tile = (int)(plan_value >> 40);
+  const int64_t total_tiles = plan_value & ((1ll << 40) - 1);
+  LORA_AMD_CHECK(ms_tile >= 0 && ms_tile < 4, LORA_AMD_EINVAL, "merge_step: not a value of lora_amd_merge_step_plan");
   LORA_AMD_CHECK(sites_dev && n >= 1 && total_tiles >= 1 && total_tiles < (1ll << 31), LORA_AMD_EINVAL, "merge_step: bad argument");
   LORA_AMD_CHECK(w_dtype == LORA_AMD_F16 || w_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL, "merge_step: 16-bit weights only");
   LORA_AMD_CHECK(rank_max >= 1 && rank_max <= 16, LORA_AMD_ERANK, "merge_step: rank %d outside [1,16]", rank_max);
@@ -246,14 +277,32 @@ extern "C" int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t
   hipStream_t st = (hipStream_t)stream;
   const int RT = rank_max <= 4 ? 4 : rank_max <= 8 ? 8 : 16;
   const bool dith = rounding == LORA_AMD_ROUND_DITHER;
+  const int dmode = dith ? g_ms_dither : 0;
+#define MS_K(E, RTV, DV, TRV, TCV)                                                                                     \
+  hipLaunchKernelGGL((merge_step_kernel<E, RTV, DV, TRV, TCV>), dim3((unsigned)total_tiles), dim3(kMsThreads), 0, st, sites_dev, n, alpha)
+#define MS_D(E, RTV, TRV, TCV)                                                                                         \
+  do { if (dmode == 0) MS_K(E, RTV, 0, TRV, TCV); else if (dmode == 1) MS_K(E, RTV, 1, TRV, TCV); else MS_K(E, RTV, 2, TRV, TCV); } while (0)
 #define MS(E, RTV)                                                                                                     \
   do {                                                                                                                 \
-    if (dith) hipLaunchKernelGGL((merge_step_kernel<E, RTV, true>), dim3((unsigned)total_tiles), dim3(kMsThreads), 0, st, sites_dev, n, alpha); \
-    else hipLaunchKernelGGL((merge_step_kernel<E, RTV, false>), dim3((unsigned)total_tiles), dim3(kMsThreads), 0, st, sites_dev, n, alpha); \
+    if (ms_tile == 0) MS_D(E, RTV, 128, 64);                                                                           \
+    else if (ms_tile == 1) MS_D(E, RTV, 64, 128);                                                                      \
+    else if (ms_tile == 2) MS_D(E, RTV, 128, 128);                                                                     \
+    else MS_D(E, RTV, 256, 64);                                                                                        \
   } while (0)
 #define MS_E(E) do { if (RT == 4) MS(E, 4); else if (RT == 8) MS(E, 8); else MS(E, 16); } while (0)
   if (w_dtype == LORA_AMD_F16) MS_E(f16_t); else MS_E(bf16_t);
 #undef MS_E
 #undef MS
+#undef MS_D
+#undef MS_K
   return check_launch("lora_amd_merge_step");
+}
+
+// Tuning hook (kbench / tests): tile geometry 0..3 = 128x64, 64x128, 128x128, 256x64 (rows x columns; tables must be planned
+// AFTER the call), dither form 1 = hash per element, 2 = hash per 16-byte chunk.  Negative keeps the current value.
+extern "C" int lora_amd_merge_step_set_tuning(int32_t tile, int32_t dither) {
+  LORA_AMD_CHECK(tile < 4 && dither < 3 && dither != 0, LORA_AMD_EINVAL, "merge_step_set_tuning: tile %d, dither %d", tile, dither);
+  if (tile >= 0) g_ms_tile = tile;
+  if (dither > 0) g_ms_dither = dither;
+  return LORA_AMD_OK;
 }

@@ -241,6 +241,34 @@ def test_merge_step_writes_w_eff_and_its_transpose_vs_oracle(N, K, r, rh, ch, dt
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_merge_step_tile_geometries_agree(tile):
+    """The tuning hook's other tile geometries (64x128, 128x128, 256x64) write the same bits as the default 128x64 tile —
+    nearest-even AND dithered (the dither is a function of (site, n, k) only) — on dense, ragged and head-padded sites."""
+    cases = [(320, 320, 4, None, None), (328, 72, 3, None, None), (1280, 320, 8, (40, 64), None), (640, 640, 4, None, (80, 128)),
+             (2560, 320, 16, None, None)]
+    for N, K, r, rh, ch in cases:
+        w = rnd((N, K), "bf16", 0.05, seed=1)
+        up, down = rnd((N, r), "f32", 0.02, seed=2), rnd((r, K), "f32", 0.02, seed=3)
+        np_, kp = ((N // rh[0]) * rh[1] if rh else N), ((K // ch[0]) * ch[1] if ch else K)
+        res = {}
+        for tl in (0, tile):
+            for rounding in (_C.ROUND_ONCE, _C.ROUND_DITHER):
+                out = torch.full((np_, kp), 9.0, dtype=w.dtype, device=DEV)
+                out_t = torch.full((kp, np_), 9.0, dtype=w.dtype, device=DEV)
+                _C.merge_step_set_tuning(tl, -1)
+                try:
+                    plan = _C.MergeStepPlan([dict(w=w, up=up, down=down, out=out, out_t=out_t, row_heads=rh, col_heads=ch, key=5)])
+                finally:
+                    _C.merge_step_set_tuning(0, -1)
+                plan.launch(0.7, rounding)   # the plan carries its geometry: launching after the reset is fine
+                assert torch.equal(out_t, out.t())
+                res[(tl, rounding)] = out
+        for rounding in (_C.ROUND_ONCE, _C.ROUND_DITHER):
+            assert torch.equal(res[(0, rounding)], res[(tile, rounding)]), (N, K, r, rh, ch, rounding)
+        assert not torch.equal(res[(0, _C.ROUND_ONCE)], res[(0, _C.ROUND_DITHER)])
+
+
 def test_merge_step_sites_share_one_buffer():
     """q / k / v of an attention block as row ranges of ONE scratch weight and column ranges of one transposed buffer
     (ld_out / ld_out_t wider than the site): each range equals the site merged on its own."""
