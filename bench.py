@@ -857,7 +857,8 @@ def main():
                                       "host_enqueue_us_per_step": round(sum(tail_host) / max(len(tail_host), 1) * 1e6, 1),
                                       "frac_of_step": round(sum(tail_host) / max(len(tail_host), 1) / (dt / args.steps), 5)},
                        "kernel_choices": kernel_choices,
-                       "adapter_options": {"grouped_qkv_one_launch": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
+                       "adapter_options": {"ab_overrides": os.environ.get("LORA_AMD_AB", "") or None,
+                                           "grouped_qkv_one_launch": os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0",
                                            "adapters": args.adapters,
                                            "merged_weights": None if merged is None else {
                                                "sites": len(merged.entries), "merge_launches_per_step": len(merged._plans or []),

@@ -139,6 +139,10 @@ int lora_amd_merge_step(const lora_amd_mstep_site *sites_dev, int32_t n, int64_t
 /* Tuning hook (scripts/kbench.py): tile geometry 0..3 = 128x64 | 64x128 | 128x128 | 256x64 (rows x columns; applies to
  * tables planned after the call), dither form 1 = one hash per element, 2 = one hash chain per 16-byte chunk.  < 0 keeps. */
 int lora_amd_merge_step_set_tuning(int32_t tile, int32_t dither);
+/* Ranks 9..16 on 16-bit activations with f32 factors: rowdot / rowdot_masked / rank_update / linear_fwd / linear_bwd_g run
+ * their matrix-core forms (csrc/rank16_mfma.hip; same arguments, outputs and partial-buffer geometry).  enable = 0 routes
+ * them back to the VALU kernels (parity tests compare the two), 1 = default, < 0 only reads.  Returns the previous value. */
+int lora_amd_rank16_mfma(int32_t enable);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
  * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100

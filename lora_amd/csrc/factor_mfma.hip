@@ -44,29 +44,9 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "mfma16.hpp"
 
 namespace lora_amd {
-
-typedef float mf32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int mu32x2 __attribute__((ext_vector_type(2)));
-typedef short ms16x4 __attribute__((ext_vector_type(4)));
-
-template <class E> struct FmMfma;
-template <> struct FmMfma<bf16_t> {
-  typedef __bf16 frag __attribute__((ext_vector_type(8)));
-  __device__ static mf32x4 mma(frag a, frag b, mf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct FmMfma<f16_t> {
-  typedef _Float16 frag __attribute__((ext_vector_type(8)));
-  __device__ static mf32x4 mma(frag a, frag b, mf32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <class E>
-__device__ __forceinline__ typename FmMfma<E>::frag fm_frag(mu32x4 v) {
-  union { typename FmMfma<E>::frag f; mu32x4 u; } c;
-  c.u = v;
-  return c.f;
-}
 
 constexpr int kFmThreads = 256;   // 4 waves
 constexpr int kFmNPA1 = 10, kFmNPA2 = 20;  // 16-byte pieces per thread of ONE resident block (R * Ca <= 20480 / 40960 elements)

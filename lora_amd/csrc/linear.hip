@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "rank16_mfma.hpp"
 
 namespace lora_amd {
 
@@ -711,6 +712,10 @@ extern "C" int lora_amd_rowdot_masked(const void *x, int64_t ldx, const void *fa
   LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "rowdot: dropout p=%f", dropout_p);
   hipStream_t st = (hipStream_t)stream;
   const bool masked = dropout_p > 0.f;
+  // ranks 9..16 on 16-bit rows: the matrix-core form (csrc/rank16_mfma.hip)
+  if (sel == nullptr && r16_rowdot(x, ldx, factor, factor_dtype, factor_layout, reinterpret_cast<float *>(t_out), M, K, r,
+                                   x_dtype, scale, dropout_p, seed, offset, offset_dev, st))
+    return check_launch("lora_amd_rowdot(mfma)");
 #define GO(E)                                                                                          \
   return masked ? launch_rowdot<E, true>(x, ldx, factor, t_out, M, K, r, factor_dtype, factor_layout, scale, sel, \
                                          sel_transposed, dropout_p, seed, offset, offset_dev, st)                  \
@@ -741,6 +746,9 @@ extern "C" int lora_amd_rank_update(void *y, int64_t ldy, const float *t, const 
   LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "rank_update: dropout p=%f", dropout_p);
   hipStream_t st = (hipStream_t)stream;
   const bool drop = dropout_p > 0.f;
+  if (r16_rank_update(y, ldy, t, 1, 0, factor, factor_dtype, factor_layout, M, N, r, y_dtype, scale, dropout_p, seed, offset,
+                      offset_dev, st))
+    return check_launch("lora_amd_rank_update(mfma)");
 #define GO(E)                                                                                              \
   return drop ? launch_rank_update<E, true>(y, ldy, t, factor, M, N, r, factor_dtype, factor_layout, scale, \
                                             dropout_p, seed, offset, offset_dev, st)                                   \

@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "rank16_mfma.hpp"
 
 namespace lora_amd {
 
@@ -1145,6 +1146,16 @@ extern "C" int lora_amd_linear_fwd(const void *x, int64_t ldx, void *y, int64_t 
                  "linear_fwd: needs K%%8==0, N%%8==0, ld%%8==0 and 16-byte aligned rows (use the primitives otherwise)");
   LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "linear_fwd: dropout p=%f", dropout_p);
   const int RT = frank_tile(r);
+  // rank tile 16 on 16-bit rows: T = X down^T, then Y += s mask . (T up^T), both on the matrix cores (csrc/rank16_mfma.hip)
+  if (RT == 16 && sel == nullptr && K % 32 == 0 && g_r16_mfma &&
+      r16_rowdot(x, ldx, down, factor_dtype, LORA_AMD_FACTOR_RK, t_out, M, K, r, act_dtype, 1.0f, 0.f, 0, 0, nullptr,
+                 (hipStream_t)stream)) {
+    if (r16_rank_update(y, ldy, t_out, 1, 0, up, factor_dtype, LORA_AMD_FACTOR_KR, M, N, r, act_dtype, scale, dropout_p, seed,
+                        offset, offset_dev, (hipStream_t)stream))
+      return check_launch("lora_amd_linear_fwd(mfma)");
+    return lora_amd_rank_update(y, ldy, t_out, up, M, N, r, act_dtype, factor_dtype, LORA_AMD_FACTOR_KR, scale, dropout_p, seed,
+                                offset, offset_dev, stream);
+  }
   int kt = (kFLdsFactor / RT) & ~7, nt = kt;
   if (kt > K) kt = K;
   if (nt > N) nt = N;
@@ -1199,6 +1210,10 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
   const unsigned grid = (unsigned)(q.nrb * q.nct);
   hipStream_t st = (hipStream_t)stream;
   const bool drop = dropout_p > 0.f;
+  // rank tile 16 on 16-bit rows: the matrix-core form with the same outputs and geometry (csrc/rank16_mfma.hip)
+  if (RT == 16 && r16_bwd_g(g, ldg, t, up, factor_dtype, gt_part, up_part, M, N, r, q.log_ct8, q.nct, q.rows_per_block, q.nrb,
+                            act_dtype, scale, dropout_p, seed, offset, offset_dev, st))
+    return check_launch("lora_amd_linear_bwd_g(mfma)");
 #define BG(E, RTV, D)                                                                                       \
   hipLaunchKernelGGL((linear_bwd_g_kernel<E, RTV, D>), dim3(grid), dim3(kFT), 0, st,                        \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, up, factor_dtype, gt_part, up_part, M, \

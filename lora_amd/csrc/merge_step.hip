@@ -35,11 +35,11 @@ namespace lora_amd {
 typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMsThreads = 256;
-constexpr int kMsMaxSitesLds = 1024;
+constexpr int kMsMaxSitesLds = 256;   // site-table prefix kept in LDS for the tile search (larger tables: searched in L2)
 // tile geometries (rows n x columns k); the LDS image row is TC * 2 + 4 bytes (the column gather is then 2-way at worst)
 struct MsTile { int tr, tc; };
 constexpr MsTile kMsTiles[4] = {{128, 64}, {64, 128}, {128, 128}, {256, 64}};
-static int g_ms_tile = 0;     // lora_amd_merge_step_set_tuning
+static int g_ms_tile = 2;     // lora_amd_merge_step_set_tuning; 128 x 128 measured best (profiles/r04_kbench_mstep.log)
 static int g_ms_dither = 2;   // 1: one hash per element; 2: two hashes per 16-byte chunk, 16-bit windows of the 64 bits
 
 __device__ __forceinline__ int ms_map(int i, int d, int D) { return d ? (i / d) * D + (i % d) : i; }

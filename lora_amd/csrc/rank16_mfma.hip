@@ -1,0 +1,420 @@
+// Rank-tile-16 forms of the adapter's streaming kernels on the matrix cores (ranks 9..16, 16-bit activations, f32 factors).
+//
+// replaces: csrc/linear.hip's rowdot / rank_update kernels and csrc/linear_fused.hip's linear_bwd_g_kernel<E, 16> for
+//           lora_diffusion/lora.py:53-58 (Linear) and lora.py:130-135 (Conv2d, channels-last rows) at rank 16 — BASELINE
+//           configs[3].  At rank 16 the VALU forms spend 16-32 FMAs per element and sit at 0.1-0.2 of the byte roof
+//           (profiles/r04_cfg3_by_grid_before_rank16.txt: 25-110 us per launch whatever the size); the contractions are dense enough for
+//           v_mfma_f32_16x16x32 (rank padded to the 16 of the tile), which leaves the dropout mask (one Philox call per
+//           16-byte chunk) as the only per-element VALU work.
+//
+// All three kernels are WAVE-AUTONOMOUS: a wave owns a 16-row (rowdot, rank_update) or 32-row x 32-column (bwd_g) unit,
+// takes the 16-byte piece a lane loads from a row-major row straight as the MFMA A operand (lane = row (l & 15), columns
+// 8 (l >> 4) ..), and never meets another wave inside its loop — no workgroup barrier between the prologue and the epilogue.
+// Operands that are not data (factors, T, Gt) are split hi + lo into two fragments of the same accumulator (f32-grade).
+//
+//   rowdot16:       T[M, r]  = s (mask . X)[M, C] F^T         wave = 16 rows x all C; fragments of F built per k-step
+//   rank_update16:  Y[M, N] += s mask . (T[M, r] F)           workgroup = 64 rows; wave = its 32-column groups; the product
+//                   is taken transposed, D[n, m] = sum_j U[n, j] T[m, j], with the rows of the two 16 x 16 tiles interleaved
+//                   (tile t row i <-> n0 + 8 (i / 4) + 4 t + i % 4) so that a lane ends up with 8 consecutive columns of one
+//                   row: one 16-byte read-modify-write per lane.  k = 32 holds (hi | lo) of the 16 ranks of U against T's hi
+//                   twice, then T's lo twice: two MFMAs per tile.
+//   bwd_g16:        gt_part[ct][M, r] = s (mask . G)[., column tile] up ;  up_part[rb][16][N] = s (mask . G)^T T (block rows)
+//                   same outputs and launch geometry as linear_bwd_g_kernel.  Per unit: phase 1 straight from the registers,
+//                   then the two pieces go through the wave's own 32 x 32 LDS tile and come back column-major through
+//                   ds_read_b64_tr_b16 for phase 2 (A = G^T, B = T); the LDS queue of a wave is in order, so write -> transpose
+//                   read -> next write needs no wait beyond the data dependence.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+#include "mfma16.hpp"
+#include "rank16_mfma.hpp"
+
+namespace lora_amd {
+
+int g_r16_mfma = 1;
+
+constexpr int kR16Threads = 256;
+constexpr int kR16Pitch = 96;  // bytes per row of a wave's 32 x 32 16-bit tile: ds_write_b128 and the transpose reads conflict-free
+
+__device__ __forceinline__ mu32x4 r16_zero() { return mu32x4{0u, 0u, 0u, 0u}; }
+
+// B-operand fragment pair (hi, lo) of the factor for the 32 columns c0 .. c0 + 31: lane (j = l & 15, kq = l >> 4) holds
+// mult * F[j, c0 + 8 kq + e].  layout RK: F = [r, C] (8 consecutive floats); KR: F = [C, r] (stride r).
+template <class E>
+__device__ __forceinline__ void r16_factor_frag(const float *__restrict__ f, int layout, int r, int C, int c0, float mult,
+                                                mu32x4 &hi, mu32x4 &lo) {
+  const int lane = threadIdx.x & 63, jj = lane & 15, kq = lane >> 4;
+  const int c = c0 + 8 * kq;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (jj < r && c < C) {  // C % 8 == 0: the chunk is inside or outside as a whole
+    if (layout == LORA_AMD_FACTOR_RK) {
+      const float4 a = gl_ld4(f + (int64_t)jj * C + c), b = gl_ld4(f + (int64_t)jj * C + c + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gl(f)[(int64_t)(c + e) * r + jj];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= mult;
+  }
+  split_hi_lo<E>(v, hi, lo);
+}
+
+// ============================================================================ rowdot16
+template <class E, bool DROP>
+__global__ __launch_bounds__(kR16Threads) void rowdot16_mfma_kernel(
+    const typename E::storage *__restrict__ x, int64_t ldx, const float *__restrict__ f, int layout, float *__restrict__ t_out,
+    int64_t M, int C, int r, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+  using S = typename E::storage;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, q = lane >> 4;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (m0 >= M) return;
+  float sc = scale;
+  uint32_t thr = 0;
+  uint64_t off = 0;
+  if constexpr (DROP) {
+    sc = scale * (1.0f / (1.0f - p));
+    thr = (uint32_t)(p * 65536.0f + 0.5f);
+    off = dropout_offset(offset, offset_dev);
+  }
+  const int64_t row = m0 + jj;
+  const bool rok = row < M;
+  const S *xr = x + (rok ? row : m0) * ldx + 8 * q;
+  const int nks = C >> 5;  // C % 32 == 0 (host check)
+  mf32x4 d = {0.f, 0.f, 0.f, 0.f};
+  mu32x4 cur = *gl(reinterpret_cast<const mu32x4 *>(xr));
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ++ks) {
+    mu32x4 nxt = r16_zero();
+    if (ks + 1 < nks) nxt = *gl(reinterpret_cast<const mu32x4 *>(xr + (ks + 1) * 32));
+    mu32x4 fh, fl;
+    r16_factor_frag<E>(f, layout, r, C, ks * 32, sc, fh, fl);
+    if constexpr (DROP) cur &= dropout_and8(seed, off, (uint64_t)(row * (int64_t)(C >> 3) + ks * 4 + q), thr);
+    if (!rok) cur = r16_zero();
+    d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fh), d);
+    d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fl), d);
+    cur = nxt;
+  }
+  // D: lane (column j = jj, rows 4 q + reg)
+  if (jj < r) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t rw = m0 + 4 * q + reg;
+      if (rw < M) t_out[rw * r + jj] = d[reg];
+    }
+  }
+}
+
+// ============================================================================ rank_update16
+// grid (row blocks of 64, column splits); `cols_per_y` columns per split (a multiple of 32).
+template <class E, bool DROP>
+__global__ __launch_bounds__(kR16Threads) void rank_update16_mfma_kernel(
+    typename E::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t, int nparts, int64_t part_stride,
+    const float *__restrict__ f, int layout, int64_t M, int N, int r, int cols_per_y, float scale, float p, uint64_t seed,
+    uint64_t offset, const uint64_t *offset_dev) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mm = lane & 15, q = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int c_begin = blockIdx.y * cols_per_y, c_end = min(N, c_begin + cols_per_y);
+  uint64_t off = 0;
+  if constexpr (DROP) off = dropout_offset(offset, offset_dev);
+  // B operands: T of the block's four 16-row slabs, (hi | hi) and (lo | lo) along k
+  mu32x4 th[4], tl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int64_t row = m0 + s * 16 + mm;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (row < M) {
+      const int j0 = 8 * (q & 1);
+      for (int pi = 0; pi < nparts; ++pi) {
+        const float *tp = t + pi * part_stride + row * r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (j0 + e < r) v[e] += gl(tp)[j0 + e];
+      }
+    }
+    split_hi_lo<E>(v, th[s], tl[s]);
+  }
+  const int ngroups = (c_end - c_begin + 31) >> 5;
+#pragma unroll 1
+  for (int gi = wave; gi < ngroups; gi += 4) {
+    const int n0 = c_begin + gi * 32;
+    // A operands of the two interleaved tiles: lane (i = mm, kq = q) holds (hi for kq < 2, lo for kq >= 2) of
+    // U[n(i, tile), 8 (kq & 1) + e], n(i, tile) = n0 + 8 (i / 4) + 4 tile + i % 4
+    mu32x4 ua[2];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      const int n = n0 + 8 * (mm >> 2) + 4 * tile + (mm & 3);
+      const int j0 = 8 * (q & 1);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (n < N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (j0 + e < r) v[e] = layout == LORA_AMD_FACTOR_KR ? gl(f)[(int64_t)n * r + j0 + e] : gl(f)[(int64_t)(j0 + e) * N + n];
+      }
+      mu32x4 hi, lo;
+      split_hi_lo<E>(v, hi, lo);
+      ua[tile] = q < 2 ? hi : lo;
+    }
+    const int col = n0 + 8 * q;  // this lane's 16-byte chunk of each row
+    const bool cok = col < N;
+    mu32x4 yv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int64_t row = m0 + s * 16 + mm;
+      const bool ok = cok && row < M;
+      yv[s] = *gl(reinterpret_cast<const mu32x4 *>(y + (ok ? row : m0) * ldy + (ok ? col : 0)));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int64_t row = m0 + s * 16 + mm;
+      if (m0 + s * 16 >= M) break;  // wave-uniform
+      mf32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(th[s]), d0);
+      d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(tl[s]), d0);
+      d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(th[s]), d1);
+      d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(tl[s]), d1);
+      // lane (row m = mm, q): d0[reg] -> column col + reg, d1[reg] -> column col + 4 + reg
+      float pr[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      if constexpr (DROP) {
+        float mk[8];
+        dropout_mult8(seed, off, (uint64_t)((row * (int64_t)N + col) >> 3), p, mk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pr[e] *= mk[e];
+      }
+      if (cok && row < M) {
+        union { mu32x4 u; Chunk8<E> c; } in, out;
+        in.u = yv[s];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out.c.v[e] = E::from_f(fmaf(scale, pr[e], E::to_f(in.c.v[e])));
+        *gl(reinterpret_cast<mu32x4 *>(y + row * ldy + col)) = out.u;
+      }
+    }
+  }
+}
+
+// ============================================================================ bwd_g16
+template <class E, bool DROP>
+__global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
+    const typename E::storage *__restrict__ g, int64_t ldg, const float *__restrict__ t, const float *__restrict__ up,
+    float *__restrict__ gt_part, float *__restrict__ up_part, int64_t M, int N, int r, int log_ct8, int nct,
+    int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kR16Pitch];  // a 32 x 32 tile per wave (12 KB)
+  __shared__ __attribute__((aligned(16))) mu32x4 s_tf[4 * 2 * 64];                     // T fragments [row step][hi, lo][lane]
+  __shared__ __attribute__((aligned(16))) float s_gtw[4 * 128 * 16];                   // Gt partial of each column wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
+  const int CW = 8 << log_ct8, ngroups = CW >> 5;     // 32-column groups of the tile: 1, 2, 4, 8, 16
+  const int GW = ngroups < 4 ? ngroups : 4, RW = 4 / GW;  // waves across the groups x waves across the 32-row steps
+  const int cgw = wave % GW, rw = wave / GW;
+  const int ncg = ngroups / GW;                       // groups per wave: 1, 2, 4
+  const int64_t rb = blockIdx.x / nct;
+  const int ct = (int)(blockIdx.x - rb * nct);
+  const int64_t m0 = rb * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int nsteps = (nrows + 31) >> 5;
+  const int col0 = ct * CW;
+  float sc = scale;
+  uint32_t thr = 0;
+  uint64_t off = 0;
+  if constexpr (DROP) {
+    sc = scale * (1.0f / (1.0f - p));
+    thr = (uint32_t)(p * 65536.0f + 0.5f);
+    off = dropout_offset(offset, offset_dev);
+  }
+  // T fragments of the block's row steps (B operand of phase 2): k slot 8 q + e <-> row 4 q + e (e < 4) / 16 + 4 q + e - 4
+  // of the step — the order the two transpose reads deliver G's rows in
+  if (wave < nsteps) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = wave * 32 + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+      v[e] = (row < nrows && jj < r) ? sc * gl(t)[(m0 + row) * r + jj] : 0.f;
+    }
+    mu32x4 hi, lo;
+    split_hi_lo<E>(v, hi, lo);
+    s_tf[(wave * 2 + 0) * 64 + lane] = hi;
+    s_tf[(wave * 2 + 1) * 64 + lane] = lo;
+  }
+  // `up` fragments of this wave's column groups (B operand of phase 1), scaled
+  mu32x4 uh[4], ul[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uh[c] = ul[c] = r16_zero();
+    if (c < ncg) r16_factor_frag<E>(up, LORA_AMD_FACTOR_KR, r, N, col0 + (cgw + GW * c) * 32, sc, uh[c], ul[c]);
+  }
+  __syncthreads();
+
+  auto piece = [&](int rs, int c, int rg) -> mu32x4 {
+    const int row = rs * 32 + rg * 16 + jj, col = col0 + (cgw + GW * c) * 32 + 8 * q;
+    const bool ok = row < nrows && col < N;
+    return *gl(reinterpret_cast<const mu32x4 *>(g + (m0 + (ok ? row : 0)) * ldg + (ok ? col : 0)));
+  };
+  auto finish = [&](mu32x4 v, int rs, int c, int rg) -> mu32x4 {  // out-of-range pieces -> 0, the forward's mask
+    const int row = rs * 32 + rg * 16 + jj, col = col0 + (cgw + GW * c) * 32 + 8 * q;
+    if (!(row < nrows && col < N)) return r16_zero();
+    if constexpr (DROP) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)(N >> 3) + (col >> 3)), thr);
+    return v;
+  };
+  mf32x4 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned char *stage = s_stage + wave * 32 * kR16Pitch;
+  mu32x4 cur0 = r16_zero(), cur1 = r16_zero();
+  if (rw < nsteps) { cur0 = piece(rw, 0, 0); cur1 = piece(rw, 0, 1); }
+#pragma unroll 1
+  for (int rs = rw; rs < nsteps; rs += RW) {
+    const mu32x4 tfh = s_tf[(rs * 2 + 0) * 64 + lane], tfl = s_tf[(rs * 2 + 1) * 64 + lane];
+    mf32x4 d1[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < ncg) {
+        const bool last = c + 1 >= ncg;
+        const int prs = last ? rs + RW : rs, pc = last ? 0 : c + 1;
+        mu32x4 nx0 = r16_zero(), nx1 = r16_zero();
+        if (prs < nsteps) { nx0 = piece(prs, pc, 0); nx1 = piece(prs, pc, 1); }
+        cur0 = finish(cur0, rs, c, 0);
+        cur1 = finish(cur1, rs, c, 1);
+        d1[0] = FmMfma<E>::mma(fm_frag<E>(cur0), fm_frag<E>(uh[c]), d1[0]);
+        d1[0] = FmMfma<E>::mma(fm_frag<E>(cur0), fm_frag<E>(ul[c]), d1[0]);
+        d1[1] = FmMfma<E>::mma(fm_frag<E>(cur1), fm_frag<E>(uh[c]), d1[1]);
+        d1[1] = FmMfma<E>::mma(fm_frag<E>(cur1), fm_frag<E>(ul[c]), d1[1]);
+        *reinterpret_cast<mu32x4 *>(stage + jj * kR16Pitch + q * 16) = cur0;
+        *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kR16Pitch + q * 16) = cur1;
+        asm volatile("" ::: "memory");  // the LDS queue of a wave is in order: only the compiler must keep the order
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const unsigned char *pp = stage + (4 * q + (jj >> 2)) * kR16Pitch + (16 * nt + 4 * (jj & 3)) * 2;
+          union { ms16x4 h[2]; mu32x4 u; } a;
+          a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(pp));
+          a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(pp + 16 * kR16Pitch));
+          acc[c][nt] = FmMfma<E>::mma(fm_frag<E>(a.u), fm_frag<E>(tfh), acc[c][nt]);
+          acc[c][nt] = FmMfma<E>::mma(fm_frag<E>(a.u), fm_frag<E>(tfl), acc[c][nt]);
+        }
+        asm volatile("" ::: "memory");
+        cur0 = nx0;
+        cur1 = nx1;
+      }
+    }
+    // this wave's share of Gt for the step's 32 rows: D1 lane (j = jj, rows 4 q + reg)
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = rs * 32 + rg * 16 + 4 * q + reg;
+        if (row < nrows) s_gtw[(cgw * 128 + row) * 16 + jj] = d1[rg][reg];
+      }
+  }
+  __syncthreads();
+  if (gt_part != nullptr) {
+    float *gtp = gt_part + (int64_t)ct * M * r + m0 * r;
+    for (int i = tid; i < nrows * r; i += kR16Threads) {
+      const int row = i / r, j = i - row * r;
+      float sum = 0.f;
+      for (int w = 0; w < GW; ++w) sum += s_gtw[(w * 128 + row) * 16 + j];
+      gtp[i] = sum;
+    }
+  }
+  if (RW > 1) {  // ncg == 1: the row waves of a column group meet in LDS (the staging tiles are free now)
+    float *red = reinterpret_cast<float *>(s_stage);
+    if (rw > 0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[((wave - GW) * 8 + nt * 4 + reg) * 64 + lane] = acc[0][nt][reg];
+    }
+    __syncthreads();
+    if (rw > 0) return;
+    for (int k = 1; k < RW; ++k)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[0][nt][reg] += red[((cgw + GW * k - GW) * 8 + nt * 4 + reg) * 64 + lane];
+  }
+  // D2: lane (j = jj, n = group base + 16 nt + 4 q + reg): 16 bytes of row j of the block's slab
+  float *slab = up_part + (int64_t)rb * 16 * N + (int64_t)jj * N;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < ncg) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = col0 + (cgw + GW * c) * 32 + 16 * nt + 4 * q;
+        if (n < N) *gl(reinterpret_cast<mf32x4 *>(slab + n)) = acc[c][nt];
+      }
+    }
+  }
+}
+
+static bool r16_common_ok(int act_dtype, int fdt, int r) {
+  return g_r16_mfma && (act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16) && fdt == LORA_AMD_F32 && r > 8 && r <= 16;
+}
+
+bool r16_rowdot(const void *x, int64_t ldx, const void *f, int fdt, int layout, float *t_out, int64_t M, int C, int r,
+                int act_dtype, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+  if (!r16_common_ok(act_dtype, fdt, r) || C % 32 || ldx % 8 || ((uintptr_t)x & 15u) || M <= 0) return false;
+  const unsigned grid = (unsigned)((M + 63) / 64);
+  const float *ff = reinterpret_cast<const float *>(f);
+#define RD(E, D)                                                                                                      \
+  hipLaunchKernelGGL((rowdot16_mfma_kernel<E, D>), dim3(grid), dim3(kR16Threads), 0, st,                              \
+                     reinterpret_cast<const typename E::storage *>(x), ldx, ff, layout, t_out, M, C, r, scale, p, seed, offset, offset_dev)
+  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RD(f16_t, true); else RD(f16_t, false); }
+  else { if (p > 0.f) RD(bf16_t, true); else RD(bf16_t, false); }
+#undef RD
+  return true;
+}
+
+bool r16_rank_update(void *y, int64_t ldy, const float *t, int nparts, int64_t part_stride, const void *f, int fdt, int layout,
+                     int64_t M, int N, int r, int act_dtype, float scale, float p, uint64_t seed, uint64_t offset,
+                     const uint64_t *offset_dev, hipStream_t st) {
+  if (!r16_common_ok(act_dtype, fdt, r) || N % 8 || ldy % 8 || ((uintptr_t)y & 15u) || M <= 0 || nparts < 1) return false;
+  const int64_t gx = (M + 63) / 64;
+  // column splits: ~1024 workgroups in total, at least 128 columns each (a wave = one 32-column group per pass)
+  int64_t ny = std::max<int64_t>(1, std::min<int64_t>((N + 127) / 128, (1024 + gx - 1) / gx));
+  int cols_per_y = (int)((((N + ny - 1) / ny) + 31) & ~31);
+  ny = (N + cols_per_y - 1) / cols_per_y;
+  if (gx > 0x7fffffff || ny > 65535) return false;
+  const float *ff = reinterpret_cast<const float *>(f);
+#define RU(E, D)                                                                                                      \
+  hipLaunchKernelGGL((rank_update16_mfma_kernel<E, D>), dim3((unsigned)gx, (unsigned)ny), dim3(kR16Threads), 0, st,   \
+                     reinterpret_cast<typename E::storage *>(y), ldy, t, nparts, part_stride, ff, layout, M, N, r,    \
+                     cols_per_y, scale, p, seed, offset, offset_dev)
+  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RU(f16_t, true); else RU(f16_t, false); }
+  else { if (p > 0.f) RU(bf16_t, true); else RU(bf16_t, false); }
+#undef RU
+  return true;
+}
+
+bool r16_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, int fdt, float *gt_part, float *up_part, int64_t M,
+               int N, int r, int log_ct8, int nct, int rows_per_block, int64_t nrb, int act_dtype, float scale, float p,
+               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+  const int cw = 8 << log_ct8;
+  if (!r16_common_ok(act_dtype, fdt, r) || cw < 32 || cw > 512 || rows_per_block > 128 || N % 8 || ldg % 8 ||
+      ((uintptr_t)g & 15u) || M <= 0 || !up_part || ((uintptr_t)up_part & 15u) || nrb * nct > 0x7fffffff)
+    return false;
+  const unsigned grid = (unsigned)(nrb * nct);
+  const float *uf = reinterpret_cast<const float *>(up);
+#define BG(E, D)                                                                                                      \
+  hipLaunchKernelGGL((bwd_g16_mfma_kernel<E, D>), dim3(grid), dim3(kR16Threads), 0, st,                               \
+                     reinterpret_cast<const typename E::storage *>(g), ldg, t, uf, gt_part, up_part, M, N, r, log_ct8, nct, \
+                     rows_per_block, scale, p, seed, offset, offset_dev)
+  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) BG(f16_t, true); else BG(f16_t, false); }
+  else { if (p > 0.f) BG(bf16_t, true); else BG(bf16_t, false); }
+#undef BG
+  return true;
+}
+
+}  // namespace lora_amd
+
+// Tuning / test hook: 0 routes ranks 9..16 back to the VALU kernels (parity tests compare both), 1 (default) the
+// matrix-core forms.  Returns the previous value.
+extern "C" int lora_amd_rank16_mfma(int32_t enable) {
+  const int prev = lora_amd::g_r16_mfma;
+  if (enable >= 0) lora_amd::g_r16_mfma = enable ? 1 : 0;
+  return prev;
+}

@@ -317,9 +317,28 @@ class LoraLinearFunction(torch.autograd.Function):
         if ctx.fused and _C._rows_ok(g2) and (need_down or need_up or need_x):
             key = (M, K, N, r)
             plan = _C.linear_plan(*key)
+            if sink is not None and sink.pending is not None:
+                sink.flush()
+            mw = getattr(getattr(sink, "owner", None), "merged", None)
+            plan_m = None
+            if (mw is not None and mw.defer_factors and _C.FACTORS_MFMA and DEFER_MASKED_FACTORS and sel is None
+                    and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
+                    and g2.dtype in (torch.bfloat16, torch.float16) and x2.dtype == g2.dtype):
+                plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
+                if not plan_m.supported:
+                    plan_m = None
+            if not need_x and not need_w and plan_m is not None:
+                # no input gradient wanted (cross-attention k / v on the text states, the time-embedding projections):
+                # the backward of the site is its two factor gradients, and both are the deferred pass's — no launch here
+                # (configs[3]: 54 sites x two latency-bound launches of 10-23 us each)
+                key = ("mfma", M, K, N, r, int(plan_m.nparts))
+                up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
+                mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, None, None, "mfma", plan_m, (p, seed, off))
+                _log("bwd", "factors_deferred_mfma", M, K, N, r)
+                sink.pending = key
+                db = g2.sum(0) if (ctx.has_bias and need_b) else None
+                return None, None, db, None, None, None, None, None, None
             if sink is not None:
-                if sink.pending is not None:
-                    sink.flush()
                 gt_part, up_part, down_part = sink.workspace(key, plan, g2.device)
             else:
                 gt_part, up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
@@ -345,12 +364,7 @@ class LoraLinearFunction(torch.autograd.Function):
                     dx2, gt = _C.linear_gemm_dx(g2, _C.weight_t(weight), down_c, up_c, s, tile)
                 # both factor gradients: deferred to the step's one-launch matrix-core pass when a trainer state runs one
                 # (T recomputed from X, the forward's dropout mask regenerated on G inside the pass), else one launch here
-                mw = getattr(getattr(sink, "owner", None), "merged", None)
-                plan_m = None
-                if (mw is not None and mw.defer_factors and _C.FACTORS_MFMA and DEFER_MASKED_FACTORS
-                        and g2.dtype in (torch.bfloat16, torch.float16)):
-                    plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
-                if plan_m is not None and plan_m.supported:
+                if plan_m is not None:
                     key = ("mfma", M, K, N, r, int(plan_m.nparts))
                     up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
                     mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, None, None, "mfma", plan_m, (p, seed, off))
@@ -358,6 +372,18 @@ class LoraLinearFunction(torch.autograd.Function):
                 else:
                     _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
                     _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors", M, K, N, r)
+            elif plan_m is not None and need_x and r > 8 and not need_w:
+                # ranks 9..16 off the fused-GEMM tables (the GEGLU projections, M = 144 sites): Gt and the low-rank term of
+                # dX on the matrix-core primitives around the frozen GEMM, both factor gradients deferred
+                gt = rowdot_any(g2, up_c, _C.FACTOR_KR, s, None, True, p, seed, off)
+                dx2 = g2 @ weight  # frozen dense GEMM
+                if not _C._rows_ok(dx2):
+                    dx2 = dx2.contiguous()
+                rank_update_any_(dx2, gt, down_c, _C.FACTOR_RK, 1.0)
+                key = ("mfma", M, K, N, r, int(plan_m.nparts))
+                up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
+                mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, None, None, "mfma", plan_m, (p, seed, off))
+                _log("bwd", "rowdot+lib+rank_update+factors_deferred_mfma", M, K, N, r)
             else:
                 _log("bwd", "g+lib+x", M, K, N, r)
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
@@ -410,12 +436,16 @@ TRANSPOSED_DX = True
 DEFER_MASKED_FACTORS = True
 # q / k / v (k / v) of an attention block on ONE concatenated scratch weight: one forward GEMM per group (+0.8 %, same box)
 CONCAT_GROUPS = True
+# ranks 9..16 on 16-bit activations: matrix-core forms of rowdot / rank_update / linear_fwd / linear_bwd_g
+# (csrc/rank16_mfma.hip; 0 = the VALU kernels, through the library's lora_amd_rank16_mfma hook)
+RANK16_MFMA = True
 
 
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "WS_DROPOUT", "WS_DROPOUT_WIDE", "WS_DROPOUT_WIDE_BWD")
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "WS_DROPOUT", "WS_DROPOUT_WIDE",
+               "WS_DROPOUT_WIDE_BWD")
     done = {}
     for item in filter(None, (s.strip() for s in spec.split(","))):
         name, _, val = item.partition("=")
@@ -426,6 +456,8 @@ def apply_ab_overrides(spec: str, namespace: dict) -> dict:
 
 
 apply_ab_overrides(os.environ.get("LORA_AMD_AB", ""), globals())
+if not RANK16_MFMA and _C.available():
+    _C.rank16_mfma(0)
 
 # Rounding of the in-step merge of 16-bit weights (csrc/merge_step.hip): "dither" (default) = nearest with a fixed
 # per-element dither, so that a delta below half an ulp of the frozen weight survives in the row sums; "once" = nearest even

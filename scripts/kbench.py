@@ -98,7 +98,32 @@ def bench_mstep(args):
                                   dither={1: "per element", 2: "per chunk"}[dith] if rounding == _C.ROUND_DITHER else "none",
                                   sites=plan.n_sites, tiles=plan.total_tiles, MB=plan.bytes_algorithmic / 1e6,
                                   us=med * 1e6, best_us=best * 1e6, GBs=gbs, frac8=gbs / 8000)), flush=True)
-    _C.merge_step_set_tuning(0, 2)
+    _C.merge_step_set_tuning(2, 2)
+
+
+def bench_r16(args):
+    """Rank-16 kernels of BASELINE configs[3] (768^2, batch 1, dropout 0.1): matrix-core form (csrc/rank16_mfma.hip) against
+    the VALU kernel it replaces, same call, hook on / off.  Bytes: the activation once (rowdot, bwd_g) or twice (rank_update)."""
+    r, p, dt = 16, 0.1, torch.bfloat16
+    for (M, C) in ((9216, 320), (9216, 2560), (2304, 640), (2304, 5120), (576, 1280), (576, 10240), (144, 1280), (77, 1280)):
+        a = torch.randn(M, C, device=DEV).to(dt)
+        t = torch.randn(M, r, device=DEV)
+        fkr, frk = torch.randn(C, r, device=DEV) * 0.2, torch.randn(r, C, device=DEV) * 0.2
+        plan = _C.linear_plan(M, 320, C, r)
+        gt_part = torch.empty(plan.gt_part_floats, device=DEV)
+        up_part = torch.empty(plan.up_part_floats, device=DEV)
+        calls = {"rowdot_masked": (lambda: _C.rowdot(a, fkr, _C.FACTOR_KR, 0.7, None, False, p, 5, 9), M * C * 2),
+                 "rowdot": (lambda: _C.rowdot(a, frk, _C.FACTOR_RK, 1.0), M * C * 2),
+                 "rank_update": (lambda: _C.rank_update_(a, t, fkr, _C.FACTOR_KR, 1e-3, p, 5, 9), 2 * M * C * 2),
+                 "bwd_g": (lambda: _C.linear_bwd_g(a, t, fkr, gt_part, up_part, 0.7, p, 5, 9), M * C * 2)}
+        for name, (fn, byts) in calls.items():
+            res = dict(kernel=name, M=M, C=C, r=r)
+            for tag, on in (("mfma", 1), ("valu", 0)):
+                prev = _C.rank16_mfma(on)
+                med, _ = timeit(fn, args.iters)
+                _C.rank16_mfma(prev)
+                res[tag + "_us"], res[tag + "_GBs"] = round(med * 1e6, 2), round(byts / med / 1e9, 1)
+            print(json.dumps(res), flush=True)
 
 
 def bench_linear(args):
@@ -498,6 +523,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "merge" in a.what:
         bench_merge(a)
+    if "r16" in a.what.split(","):
+        bench_r16(a)
     if "mstep" in a.what.split(","):
         bench_mstep(a)
     if "linear" in a.what:

@@ -243,7 +243,7 @@ def test_merge_step_writes_w_eff_and_its_transpose_vs_oracle(N, K, r, rh, ch, dt
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
 def test_merge_step_tile_geometries_agree(tile):
-    """The tuning hook's other tile geometries (64x128, 128x128, 256x64) write the same bits as the default 128x64 tile —
+    """The tuning hook's tile geometries (64x128, 128x128 = the default, 256x64) write the same bits as the 128x64 tile —
     nearest-even AND dithered (the dither is a function of (site, n, k) only) — on dense, ragged and head-padded sites."""
     cases = [(320, 320, 4, None, None), (328, 72, 3, None, None), (1280, 320, 8, (40, 64), None), (640, 640, 4, None, (80, 128)),
              (2560, 320, 16, None, None)]
@@ -260,7 +260,7 @@ def test_merge_step_tile_geometries_agree(tile):
                 try:
                     plan = _C.MergeStepPlan([dict(w=w, up=up, down=down, out=out, out_t=out_t, row_heads=rh, col_heads=ch, key=5)])
                 finally:
-                    _C.merge_step_set_tuning(0, -1)
+                    _C.merge_step_set_tuning(2, -1)
                 plan.launch(0.7, rounding)   # the plan carries its geometry: launching after the reset is fine
                 assert torch.equal(out_t, out.t())
                 res[(tl, rounding)] = out
