@@ -65,3 +65,19 @@ def test_padded_row_pitch_is_bank_conflict_free_for_both_operand_reads(cols):
     pitch, res = lds_banks.check(cols)
     assert pitch % 64 == 32 and pitch >= cols * 2
     assert res["phase1_b128"] == 1 and res["phase2_tr_b64"] == 1
+
+
+def test_rank16_fragment_index_arithmetic_reproduces_matrix_products():
+    """scripts/r16_model.py: rank_update16's interleaved transposed product, bwd_g16's register phase and transpose-read
+    phase, rowdot16's k-step — lane by lane against numpy, ranks 16, 12 and 9."""
+    import r16_model
+
+    assert r16_model.check()
+
+
+def test_rank16_wave_tile_pitch_is_conflict_free_for_the_transpose_reads():
+    pitch = 96  # kR16Pitch
+    tr = max(lds_banks.worst(lds_banks.HALVES, [(4 * (l >> 4) + ((l & 15) >> 2)) * pitch + (c0 + 4 * (l & 3)) * 2
+                                                 for l in range(64)], 8, 64) for c0 in (0, 16))
+    wr = lds_banks.worst(lds_banks.OCTETS, [(l & 15) * pitch + (l >> 4) * 16 for l in range(64)], 16, 64)
+    assert tr == 1 and wr == 1
