@@ -41,38 +41,52 @@ constexpr int kR16Pitch = 96;  // bytes per row of a wave's 32 x 32 16-bit tile:
 __device__ __forceinline__ mu32x4 r16_zero() { return mu32x4{0u, 0u, 0u, 0u}; }
 
 // B-operand fragment pair (hi, lo) of the factor for the 32 columns c0 .. c0 + 31: lane (j = l & 15, kq = l >> 4) holds
-// mult * F[j, c0 + 8 kq + e].  layout RK: F = [r, C] (8 consecutive floats); KR: F = [C, r] (stride r).
-template <class E>
-__device__ __forceinline__ void r16_factor_frag(const float *__restrict__ f, int layout, int r, int C, int c0, float mult,
-                                                mu32x4 &hi, mu32x4 &lo) {
+// mult * F[j, c0 + 8 kq + e].  layout RK: F = [r, C] (8 consecutive floats); KR: F = [C, r] (stride r).  Two steps, so that
+// a loop can have the next k-step's values in flight: r16_factor_load (global -> 8 floats), r16_factor_split.
+struct R16Raw { float v[8]; };
+__device__ __forceinline__ R16Raw r16_factor_load(const float *__restrict__ f, int layout, int r, int C, int c0) {
   const int lane = threadIdx.x & 63, jj = lane & 15, kq = lane >> 4;
   const int c = c0 + 8 * kq;
-  float v[8];
+  R16Raw w;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int e = 0; e < 8; ++e) w.v[e] = 0.f;
   if (jj < r && c < C) {  // C % 8 == 0: the chunk is inside or outside as a whole
     if (layout == LORA_AMD_FACTOR_RK) {
       const float4 a = gl_ld4(f + (int64_t)jj * C + c), b = gl_ld4(f + (int64_t)jj * C + c + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      w.v[0] = a.x; w.v[1] = a.y; w.v[2] = a.z; w.v[3] = a.w; w.v[4] = b.x; w.v[5] = b.y; w.v[6] = b.z; w.v[7] = b.w;
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gl(f)[(int64_t)(c + e) * r + jj];
+      for (int e = 0; e < 8; ++e) w.v[e] = gl(f)[(int64_t)(c + e) * r + jj];
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= mult;
   }
+  return w;
+}
+template <class E>
+__device__ __forceinline__ void r16_factor_split(const R16Raw &w, float mult, mu32x4 &hi, mu32x4 &lo) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = w.v[e] * mult;
   split_hi_lo<E>(v, hi, lo);
+}
+template <class E>
+__device__ __forceinline__ void r16_factor_frag(const float *__restrict__ f, int layout, int r, int C, int c0, float mult,
+                                                mu32x4 &hi, mu32x4 &lo) {
+  r16_factor_split<E>(r16_factor_load(f, layout, r, C, c0), mult, hi, lo);
 }
 
 // ============================================================================ rowdot16
+// A workgroup = `slabs` 16-row slabs x `wps` waves per slab (slabs * wps = blockDim / 64); the waves of a slab take the
+// k-steps ks = cw, cw + wps, ... and meet once in LDS.  Two data pieces and one factor fragment ahead of the MFMAs.
 template <class E, bool DROP>
-__global__ __launch_bounds__(kR16Threads) void rowdot16_mfma_kernel(
+__global__ __launch_bounds__(1024) void rowdot16_mfma_kernel(
     const typename E::storage *__restrict__ x, int64_t ldx, const float *__restrict__ f, int layout, float *__restrict__ t_out,
-    int64_t M, int C, int r, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+    int64_t M, int C, int r, int wps, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
   using S = typename E::storage;
+  __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, q = lane >> 4;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
-  if (m0 >= M) return;
+  const int nwaves = blockDim.x >> 6, slabs = nwaves / wps;
+  const int sl = wave / wps, cw = wave - sl * wps;
+  const int64_t m0 = ((int64_t)blockIdx.x * slabs + sl) * 16;
   float sc = scale;
   uint32_t thr = 0;
   uint64_t off = 0;
@@ -83,24 +97,43 @@ __global__ __launch_bounds__(kR16Threads) void rowdot16_mfma_kernel(
   }
   const int64_t row = m0 + jj;
   const bool rok = row < M;
-  const S *xr = x + (rok ? row : m0) * ldx + 8 * q;
+  const S *xr = x + (rok ? row : 0) * ldx + 8 * q;
   const int nks = C >> 5;  // C % 32 == 0 (host check)
   mf32x4 d = {0.f, 0.f, 0.f, 0.f};
-  mu32x4 cur = *gl(reinterpret_cast<const mu32x4 *>(xr));
+  if (m0 < M) {
+    auto piece = [&](int ks) -> mu32x4 {
+      return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(xr + (int64_t)ks * 32)) : r16_zero();
+    };
+    mu32x4 c0 = piece(cw), c1 = piece(cw + wps);
+    R16Raw fr = r16_factor_load(f, layout, r, C, (cw < nks ? cw : 0) * 32);
 #pragma unroll 1
-  for (int ks = 0; ks < nks; ++ks) {
-    mu32x4 nxt = r16_zero();
-    if (ks + 1 < nks) nxt = *gl(reinterpret_cast<const mu32x4 *>(xr + (ks + 1) * 32));
-    mu32x4 fh, fl;
-    r16_factor_frag<E>(f, layout, r, C, ks * 32, sc, fh, fl);
-    if constexpr (DROP) cur &= dropout_and8(seed, off, (uint64_t)(row * (int64_t)(C >> 3) + ks * 4 + q), thr);
-    if (!rok) cur = r16_zero();
-    d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fh), d);
-    d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fl), d);
-    cur = nxt;
+    for (int ks = cw; ks < nks; ks += wps) {
+      const mu32x4 c2 = piece(ks + 2 * wps);
+      mu32x4 fh, fl;
+      r16_factor_split<E>(fr, sc, fh, fl);
+      if (ks + wps < nks) fr = r16_factor_load(f, layout, r, C, (ks + wps) * 32);
+      mu32x4 cur = c0;
+      if constexpr (DROP) cur &= dropout_and8(seed, off, (uint64_t)(row * (int64_t)(C >> 3) + ks * 4 + q), thr);
+      if (!rok) cur = r16_zero();
+      d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fh), d);
+      d = FmMfma<E>::mma(fm_frag<E>(cur), fm_frag<E>(fl), d);
+      c0 = c1;
+      c1 = c2;
+    }
+  }
+  if (wps > 1) {  // block-uniform
+    if (cw > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) s_red[(wave * 4 + reg) * 64 + lane] = d[reg];
+    }
+    __syncthreads();
+    if (cw > 0) return;
+    for (int k = 1; k < wps; ++k)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) d[reg] += s_red[((wave + k) * 4 + reg) * 64 + lane];
   }
   // D: lane (column j = jj, rows 4 q + reg)
-  if (jj < r) {
+  if (jj < r && m0 < M) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t rw = m0 + 4 * q + reg;
@@ -110,21 +143,23 @@ __global__ __launch_bounds__(kR16Threads) void rowdot16_mfma_kernel(
 }
 
 // ============================================================================ rank_update16
-// grid (row blocks of 64, column splits); `cols_per_y` columns per split (a multiple of 32).
+// grid (row blocks of `rows_per_block` = 64 | 128 | 256, column splits of 128 columns); a wave owns ONE 32-column group:
+// its two A fragments are built once and meet every 16-row slab of the block, whose T fragments all four waves share
+// through LDS.
 template <class E, bool DROP>
 __global__ __launch_bounds__(kR16Threads) void rank_update16_mfma_kernel(
     typename E::storage *__restrict__ y, int64_t ldy, const float *__restrict__ t, int nparts, int64_t part_stride,
-    const float *__restrict__ f, int layout, int64_t M, int N, int r, int cols_per_y, float scale, float p, uint64_t seed,
+    const float *__restrict__ f, int layout, int64_t M, int N, int r, int rows_per_block, float scale, float p, uint64_t seed,
     uint64_t offset, const uint64_t *offset_dev) {
+  __shared__ __attribute__((aligned(16))) mu32x4 s_t[16 * 2 * 64];  // [slab][hi, lo][lane]: B operands (32 KB)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mm = lane & 15, q = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * 64;
-  const int c_begin = blockIdx.y * cols_per_y, c_end = min(N, c_begin + cols_per_y);
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nrows = (int)min((int64_t)rows_per_block, M - m0);
+  const int nslabs = (nrows + 15) >> 4;
   uint64_t off = 0;
   if constexpr (DROP) off = dropout_offset(offset, offset_dev);
-  // B operands: T of the block's four 16-row slabs, (hi | hi) and (lo | lo) along k
-  mu32x4 th[4], tl[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  // B operands: T of the block's 16-row slabs, (hi | hi) and (lo | lo) along k
+  for (int s = wave; s < nslabs; s += 4) {
     const int64_t row = m0 + s * 16 + mm;
     float v[8];
 #pragma unroll
@@ -138,65 +173,68 @@ __global__ __launch_bounds__(kR16Threads) void rank_update16_mfma_kernel(
           if (j0 + e < r) v[e] += gl(tp)[j0 + e];
       }
     }
-    split_hi_lo<E>(v, th[s], tl[s]);
+    mu32x4 hi, lo;
+    split_hi_lo<E>(v, hi, lo);
+    s_t[(s * 2 + 0) * 64 + lane] = hi;
+    s_t[(s * 2 + 1) * 64 + lane] = lo;
   }
-  const int ngroups = (c_end - c_begin + 31) >> 5;
+  const int n0 = (blockIdx.y * 4 + wave) * 32;
+  // A operands of the two interleaved tiles: lane (i = mm, kq = q) holds (hi for kq < 2, lo for kq >= 2) of
+  // U[n(i, tile), 8 (kq & 1) + e], n(i, tile) = n0 + 8 (i / 4) + 4 tile + i % 4
+  mu32x4 ua[2];
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    const int n = n0 + 8 * (mm >> 2) + 4 * tile + (mm & 3);
+    const int j0 = 8 * (q & 1);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (n < N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (j0 + e < r) v[e] = layout == LORA_AMD_FACTOR_KR ? gl(f)[(int64_t)n * r + j0 + e] : gl(f)[(int64_t)(j0 + e) * N + n];
+    }
+    mu32x4 hi, lo;
+    split_hi_lo<E>(v, hi, lo);
+    ua[tile] = q < 2 ? hi : lo;
+  }
+  __syncthreads();
+  const int col = n0 + 8 * q;  // this lane's 16-byte chunk of each row
+  const bool cok = col < N;
+  if (n0 >= N) return;         // wave-uniform (no barrier below)
+  auto yload = [&](int s) -> mu32x4 {
+    const int64_t row = m0 + s * 16 + mm;
+    const bool ok = cok && row < M && s < nslabs;
+    return *gl(reinterpret_cast<const mu32x4 *>(y + (ok ? row : m0) * ldy + (ok ? col : 0)));
+  };
+  mu32x4 y0 = yload(0), y1 = yload(1);
 #pragma unroll 1
-  for (int gi = wave; gi < ngroups; gi += 4) {
-    const int n0 = c_begin + gi * 32;
-    // A operands of the two interleaved tiles: lane (i = mm, kq = q) holds (hi for kq < 2, lo for kq >= 2) of
-    // U[n(i, tile), 8 (kq & 1) + e], n(i, tile) = n0 + 8 (i / 4) + 4 tile + i % 4
-    mu32x4 ua[2];
+  for (int s = 0; s < nslabs; ++s) {
+    const mu32x4 y2 = yload(s + 2);
+    const mu32x4 th = s_t[(s * 2 + 0) * 64 + lane], tl = s_t[(s * 2 + 1) * 64 + lane];
+    const int64_t row = m0 + s * 16 + mm;
+    mf32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(th), d0);
+    d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(tl), d0);
+    d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(th), d1);
+    d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(tl), d1);
+    // lane (row m = mm, q): d0[reg] -> column col + reg, d1[reg] -> column col + 4 + reg
+    float pr[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+    if constexpr (DROP) {
+      float mk[8];
+      dropout_mult8(seed, off, (uint64_t)((row * (int64_t)N + col) >> 3), p, mk);
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-      const int n = n0 + 8 * (mm >> 2) + 4 * tile + (mm & 3);
-      const int j0 = 8 * (q & 1);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (n < N) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (j0 + e < r) v[e] = layout == LORA_AMD_FACTOR_KR ? gl(f)[(int64_t)n * r + j0 + e] : gl(f)[(int64_t)(j0 + e) * N + n];
-      }
-      mu32x4 hi, lo;
-      split_hi_lo<E>(v, hi, lo);
-      ua[tile] = q < 2 ? hi : lo;
+      for (int e = 0; e < 8; ++e) pr[e] *= mk[e];
     }
-    const int col = n0 + 8 * q;  // this lane's 16-byte chunk of each row
-    const bool cok = col < N;
-    mu32x4 yv[4];
+    if (cok && row < M) {
+      union { mu32x4 u; Chunk8<E> c; } in, out;
+      in.u = y0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int64_t row = m0 + s * 16 + mm;
-      const bool ok = cok && row < M;
-      yv[s] = *gl(reinterpret_cast<const mu32x4 *>(y + (ok ? row : m0) * ldy + (ok ? col : 0)));
+      for (int e = 0; e < 8; ++e) out.c.v[e] = E::from_f(fmaf(scale, pr[e], E::to_f(in.c.v[e])));
+      *gl(reinterpret_cast<mu32x4 *>(y + row * ldy + col)) = out.u;
     }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int64_t row = m0 + s * 16 + mm;
-      if (m0 + s * 16 >= M) break;  // wave-uniform
-      mf32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-      d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(th[s]), d0);
-      d0 = FmMfma<E>::mma(fm_frag<E>(ua[0]), fm_frag<E>(tl[s]), d0);
-      d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(th[s]), d1);
-      d1 = FmMfma<E>::mma(fm_frag<E>(ua[1]), fm_frag<E>(tl[s]), d1);
-      // lane (row m = mm, q): d0[reg] -> column col + reg, d1[reg] -> column col + 4 + reg
-      float pr[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-      if constexpr (DROP) {
-        float mk[8];
-        dropout_mult8(seed, off, (uint64_t)((row * (int64_t)N + col) >> 3), p, mk);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pr[e] *= mk[e];
-      }
-      if (cok && row < M) {
-        union { mu32x4 u; Chunk8<E> c; } in, out;
-        in.u = yv[s];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) out.c.v[e] = E::from_f(fmaf(scale, pr[e], E::to_f(in.c.v[e])));
-        *gl(reinterpret_cast<mu32x4 *>(y + row * ldy + col)) = out.u;
-      }
-    }
+    y0 = y1;
+    y1 = y2;
   }
 }
 
@@ -358,11 +396,19 @@ static bool r16_common_ok(int act_dtype, int fdt, int r) {
 bool r16_rowdot(const void *x, int64_t ldx, const void *f, int fdt, int layout, float *t_out, int64_t M, int C, int r,
                 int act_dtype, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
   if (!r16_common_ok(act_dtype, fdt, r) || C % 32 || ldx % 8 || ((uintptr_t)x & 15u) || M <= 0) return false;
-  const unsigned grid = (unsigned)((M + 63) / 64);
+  // waves per 16-row slab: >= 4 k-steps per wave, ~4096 waves in flight at most (a wave's chain of dependent loads is what
+  // bounds a long row: 576 rows x 10240 columns on one wave per slab took 110-154 us, profiles/r04_kbench_r16_first.log)
+  const int nks = C >> 5;
+  const int64_t nslabs = (M + 15) / 16;
+  int wps = 1;
+  while (wps < 16 && nks / (2 * wps) >= 4 && nslabs * wps < 4096) wps *= 2;
+  const int slabs = wps <= 4 ? 4 / wps : 1;
+  const unsigned block = (unsigned)(64 * wps * slabs);
+  const unsigned grid = (unsigned)((nslabs + slabs - 1) / slabs);
   const float *ff = reinterpret_cast<const float *>(f);
 #define RD(E, D)                                                                                                      \
-  hipLaunchKernelGGL((rowdot16_mfma_kernel<E, D>), dim3(grid), dim3(kR16Threads), 0, st,                              \
-                     reinterpret_cast<const typename E::storage *>(x), ldx, ff, layout, t_out, M, C, r, scale, p, seed, offset, offset_dev)
+  hipLaunchKernelGGL((rowdot16_mfma_kernel<E, D>), dim3(grid), dim3(block), 0, st,                                    \
+                     reinterpret_cast<const typename E::storage *>(x), ldx, ff, layout, t_out, M, C, r, wps, scale, p, seed, offset, offset_dev)
   if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RD(f16_t, true); else RD(f16_t, false); }
   else { if (p > 0.f) RD(bf16_t, true); else RD(bf16_t, false); }
 #undef RD
@@ -373,17 +419,17 @@ bool r16_rank_update(void *y, int64_t ldy, const float *t, int nparts, int64_t p
                      int64_t M, int N, int r, int act_dtype, float scale, float p, uint64_t seed, uint64_t offset,
                      const uint64_t *offset_dev, hipStream_t st) {
   if (!r16_common_ok(act_dtype, fdt, r) || N % 8 || ldy % 8 || ((uintptr_t)y & 15u) || M <= 0 || nparts < 1) return false;
-  const int64_t gx = (M + 63) / 64;
-  // column splits: ~1024 workgroups in total, at least 128 columns each (a wave = one 32-column group per pass)
-  int64_t ny = std::max<int64_t>(1, std::min<int64_t>((N + 127) / 128, (1024 + gx - 1) / gx));
-  int cols_per_y = (int)((((N + ny - 1) / ny) + 31) & ~31);
-  ny = (N + cols_per_y - 1) / cols_per_y;
+  const int64_t ny = (N + 127) / 128;  // a wave = one 32-column group
+  // rows per workgroup: as many as keep >= 768 workgroups (the A fragments are rebuilt per workgroup)
+  int rows = 256;
+  while (rows > 64 && ((M + rows - 1) / rows) * ny < 768) rows >>= 1;
+  const int64_t gx = (M + rows - 1) / rows;
   if (gx > 0x7fffffff || ny > 65535) return false;
   const float *ff = reinterpret_cast<const float *>(f);
 #define RU(E, D)                                                                                                      \
   hipLaunchKernelGGL((rank_update16_mfma_kernel<E, D>), dim3((unsigned)gx, (unsigned)ny), dim3(kR16Threads), 0, st,   \
                      reinterpret_cast<typename E::storage *>(y), ldy, t, nparts, part_stride, ff, layout, M, N, r,    \
-                     cols_per_y, scale, p, seed, offset, offset_dev)
+                     rows, scale, p, seed, offset, offset_dev)
   if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RU(f16_t, true); else RU(f16_t, false); }
   else { if (p > 0.f) RU(bf16_t, true); else RU(bf16_t, false); }
 #undef RU
