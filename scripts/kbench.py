@@ -77,21 +77,29 @@ def bench_merge(args):
     return out
 
 
-def bench_mstep(args):
-    """The in-step merge (lora_amd_merge_step) on the 144 Linear sites of the SD1.5 UNet, W_eff^T for the sites whose input
-    takes a gradient (all but the cross-attention k / v): tile geometry x dither form x rounding."""
+def mstep_tensors(r=4):
     shapes = sd15_lora_site_shapes()
-    r = args.rank
     tens = []
     for N, K in shapes:
         w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
         tens.append((w, torch.randn(N, r, device=DEV) * 0.05, torch.randn(r, K, device=DEV) * 0.25, torch.empty_like(w),
                      torch.empty(K, N, dtype=w.dtype, device=DEV) if K != 768 else None))
+    return tens
+
+
+def mstep_plan(tens):
+    return _C.MergeStepPlan([dict(w=w, up=u, down=d, out=o, out_t=ot, row_heads=None, col_heads=None, key=i)
+                             for i, (w, u, d, o, ot) in enumerate(tens)])
+
+
+def bench_mstep(args):
+    """The in-step merge (lora_amd_merge_step) on the 144 Linear sites of the SD1.5 UNet, W_eff^T for the sites whose input
+    takes a gradient (all but the cross-attention k / v): tile geometry x dither form x rounding."""
+    tens = mstep_tensors(args.rank)
     for tile in (0, 1, 2, 3):
         for dith, rounding in ((2, _C.ROUND_DITHER), (1, _C.ROUND_DITHER), (2, _C.ROUND_ONCE)):
             _C.merge_step_set_tuning(tile, dith)
-            plan = _C.MergeStepPlan([dict(w=w, up=u, down=d, out=o, out_t=ot, row_heads=None, col_heads=None, key=i)
-                                     for i, (w, u, d, o, ot) in enumerate(tens)])
+            plan = mstep_plan(tens)
             med, best = timeit(lambda: plan.launch(0.7, rounding), iters=args.iters)
             gbs = plan.bytes_algorithmic / med / 1e9
             print(json.dumps(dict(kernel="merge_step", tile=("128x64", "64x128", "128x128", "256x64")[tile],

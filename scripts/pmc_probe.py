@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lora_amd import _C  # noqa: E402
-from scripts.kbench import merge_plan  # noqa: E402
+from scripts.kbench import merge_plan, mstep_plan, mstep_tensors  # noqa: E402
 
 DEV = "cuda:0"
 n = 192_634_880  # = total elements of the 144 SD1.5 sites: same footprint as the merge (beyond the 256 MiB L3)
@@ -25,4 +25,9 @@ plan = merge_plan(False)
 for _ in range(3):
     plan.launch(0.7)
 torch.cuda.synchronize()
-print("copy_bytes_each_way", n * 2, "merge_algorithmic_bytes", plan.bytes_algorithmic)
+splan = mstep_plan(mstep_tensors())   # the in-step merge: W_eff and W_eff^T from one read of W (csrc/merge_step.hip)
+for _ in range(3):
+    splan.launch(0.7, _C.ROUND_DITHER)
+torch.cuda.synchronize()
+print("copy_bytes_each_way", n * 2, "merge_algorithmic_bytes", plan.bytes_algorithmic, "merge_step_algorithmic_bytes",
+      splan.bytes_algorithmic)

@@ -41,4 +41,10 @@ if cf and cw and mf and mw:
     rd, wr = mf * copy_bytes / cf, mw * copy_bytes / cw
     res["merge_per_launch"] = {"hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_total_bytes": round(rd + wr),
                                "algorithmic_bytes": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 4)}
+alg_step = int(sys.argv[5]) if len(sys.argv) > 5 else None
+sf, sw = pick(fetch, "merge_step_kernel"), pick(write, "merge_step_kernel")
+if cf and cw and sf and sw and alg_step:
+    rd, wr = sf * copy_bytes / cf, sw * copy_bytes / cw
+    res["merge_step_per_launch"] = {"hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_total_bytes": round(rd + wr),
+                                    "algorithmic_bytes": alg_step, "traffic_over_algorithmic": round((rd + wr) / alg_step, 4)}
 print(json.dumps(res, indent=1))
