@@ -453,7 +453,241 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------- register form
+// The same pass with the resident operand in REGISTERS and every wave autonomous between four barriers (the structure of
+// csrc/rank16_mfma.hip's bwd_g16): a wave owns the 32-column groups cg = wave, wave + 4, ... of both operands.
+//   1. all of the block's A pieces are issued at once (<= 20 x 16 bytes per lane: 64 rows x 640 columns or 32 x 1280 over
+//      four waves) and stay in registers until step 5;
+//   2. phase 1 on them straight from the registers (A operand = the piece, B operand = the packed factor fragment):
+//      TA partials -> LDS, barrier, the four waves' partials are summed into T fragments (hi, lo), barrier;
+//   3. B streams through a 4-deep ring of units (32 rows x 32 columns = two pieces), each unit: phase 1 for TB from the
+//      registers, then through the wave's own 32 x 32 LDS tile and back column-major (ds_read_b64_tr_b16) for
+//      outB += B^T TA; a group's [16, 32] slab columns are complete after its row steps and stored at once;
+//   4. TB partials -> LDS, barrier, T fragments, barrier;
+//   5. outA += A^T TB from the resident pieces the same way.
+// No wave waits for another inside a step, the LDS queue of a wave is in order (write -> transpose read needs no wait),
+// and the only loads on the critical path of a block are its first ones.
+constexpr int kFrPairs = 10;   // resident (row step, group) units per wave
+constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
+
+template <class E, bool DROP>
+__global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+  using S = typename E::storage;
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
+  __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
+  __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_fm_site sd = sites[lo];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
+  const int R = sd.rows_per_block;
+  const bool rs2 = R == 64;            // two 32-row steps per block, else one
+  const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;
+  const int64_t m0 = rb * R;
+  const int nrows = (int)min((int64_t)R, sd.M - m0);
+  const bool ax = sd.resident_is_x != 0;
+  const int RT = sd.r <= 4 ? 4 : sd.r <= 8 ? 8 : 16;
+  const S *da = reinterpret_cast<const S *>(ax ? sd.x : sd.g), *db = reinterpret_cast<const S *>(ax ? sd.g : sd.x);
+  const int64_t lda = ax ? sd.ldx : sd.ldg, ldb = ax ? sd.ldg : sd.ldx;
+  const int Ca = ax ? sd.K : sd.N, Cb = ax ? sd.N : sd.K;
+  const FmHeads hda = fm_heads((ax ? sd.x_head_dim : sd.g_head_dim) >> 3, (ax ? sd.x_head_pad : sd.g_head_pad) >> 3);
+  const FmHeads hdb = fm_heads((ax ? sd.g_head_dim : sd.x_head_dim) >> 3, (ax ? sd.g_head_pad : sd.x_head_pad) >> 3);
+  const S *pka = reinterpret_cast<const S *>(ax ? sd.pk_down : sd.pk_up), *pkb = reinterpret_cast<const S *>(ax ? sd.pk_up : sd.pk_down);
+  const int64_t splita = (int64_t)(Ca >> 3) * 128, splitb = (int64_t)(Cb >> 3) * 128;
+  float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
+  float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
+  const int nga = Ca >> 5, ngb = Cb >> 5;
+  const bool drop = DROP && sd.dropout_p > 0.f;
+  const bool mask_a = drop && !ax, mask_b = drop && ax;   // G is the masked operand
+  const uint64_t seed = sd.seed, off = drop ? dropout_offset(sd.offset, sd.offset_dev) : 0;
+  const uint32_t thr = (uint32_t)(sd.dropout_p * 65536.0f + 0.5f);
+  const int n8 = sd.N >> 3;
+
+  auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int cg, int row, bool ok) -> mu32x4 {
+    const int ph = fm_hchunk(ok ? cg * 4 + q : 0, h);
+    return *gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8));
+  };
+  auto finish = [&](mu32x4 v, int cg, int row, bool masked) -> mu32x4 {
+    if (row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
+    if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + q), thr);
+    return v;
+  };
+  auto frag = [&](const S *pk, int64_t split, int cg, bool lo_part) -> mu32x4 {
+    return *gl(reinterpret_cast<const mu32x4 *>(pk + (lo_part ? split : 0) + (int64_t)cg * 512 + lane * 8));
+  };
+  unsigned char *stage = s_stage + wave * 32 * kFrPitch;
+  // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
+  auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, mf32x4 (&acc)[2]) {
+    *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
+    *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const unsigned char *pp = stage + (4 * q + (jj >> 2)) * kFrPitch + (16 * nt + 4 * (jj & 3)) * 2;
+      union { ms16x4 h[2]; mu32x4 u; } a;
+      a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(pp));
+      a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(pp + 16 * kFrPitch));
+      acc[nt] = FmMfma<E>::mma(fm_frag<E>(a.u), fm_frag<E>(th), acc[nt]);
+      acc[nt] = FmMfma<E>::mma(fm_frag<E>(a.u), fm_frag<E>(tl), acc[nt]);
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto store_group = [&](float *out, int C, int cg, mf32x4 (&acc)[2]) {
+    float *o = out + (int64_t)(jj < RT ? jj : 0) * C + cg * 32 + 4 * q;
+    if (jj < RT) {
+      *gl(reinterpret_cast<mf32x4 *>(o)) = acc[0];
+      *gl(reinterpret_cast<mf32x4 *>(o + 16)) = acc[1];
+    }
+    acc[0] = acc[1] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_parts = [&](const mf32x4 (&d)[4]) {   // D1 lane (j = jj, rows 4 q + reg) of (row step, 16-row group)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) s_part[(wave * 64 + (x >> 1) * 32 + (x & 1) * 16 + 4 * q + reg) * 16 + jj] = d[x][reg];
+  };
+  auto build_tf = [&]() {   // k slot 8 q + e <-> row 4 q + e (e < 4) / 16 + 4 q + e - 4: the order of the transposed reads
+    if (wave < (rs2 ? 2 : 1)) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = wave * 32 + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+        v[e] = sd.scale * (s_part[(0 * 64 + row) * 16 + jj] + s_part[(1 * 64 + row) * 16 + jj] +
+                           s_part[(2 * 64 + row) * 16 + jj] + s_part[(3 * 64 + row) * 16 + jj]);
+      }
+      mu32x4 h, l;
+      split_hi_lo<E>(v, h, l);
+      s_tf[(wave * 2 + 0) * 64 + lane] = h;
+      s_tf[(wave * 2 + 1) * 64 + lane] = l;
+    }
+  };
+
+  // ---- 1. the resident pieces: pair pp = (row step rs, group index gi), pieces 2 pp (rows rs 32 + jj) and 2 pp + 1 (+ 16)
+  mu32x4 pa[2 * kFrPairs];
+#pragma unroll
+  for (int pp = 0; pp < kFrPairs; ++pp) {
+    const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
+    pa[2 * pp] = pa[2 * pp + 1] = mu32x4{0u, 0u, 0u, 0u};
+    if (cg < nga) {   // wave-uniform
+      pa[2 * pp] = load_piece(da, lda, hda, cg, rs * 32 + jj, rs * 32 + jj < nrows);
+      pa[2 * pp + 1] = load_piece(da, lda, hda, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
+    }
+  }
+  // ---- 2. TA = A fa^T
+  mf32x4 d1[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
+    if (wave < nga) { nfh = frag(pka, splita, wave, false); nfl = frag(pka, splita, wave, true); }
+#pragma unroll
+    for (int pp = 0; pp < kFrPairs; ++pp) {
+      const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
+      if (!rs2 || !(pp & 1)) {  // first pair of a group
+        fh = nfh; fl = nfl;
+        if (cg + 4 < nga) { nfh = frag(pka, splita, cg + 4, false); nfl = frag(pka, splita, cg + 4, true); }
+      }
+      if (cg < nga) {
+        pa[2 * pp] = finish(pa[2 * pp], cg, rs * 32 + jj, mask_a);
+        pa[2 * pp + 1] = finish(pa[2 * pp + 1], cg, rs * 32 + 16 + jj, mask_a);
+        if (rs2 && (pp & 1)) {
+          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[2]);
+          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[2]);
+          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[3]);
+          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[3]);
+        } else {
+          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[0]);
+          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[0]);
+          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[1]);
+          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[1]);
+        }
+      }
+    }
+  }
+  // ---- 3. B: the first ring slots go out before the barrier
+  const int ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;
+  const int nunits = ngb_w * (rs2 ? 2 : 1);
+  mu32x4 b0[4], b1[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
+  auto load_unit = [&](int u, mu32x4 &x0, mu32x4 &x1) {
+    const int rs = rs2 ? (u & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
+    if (u < nunits) {   // wave-uniform
+      x0 = load_piece(db, ldb, hdb, cg, rs * 32 + jj, rs * 32 + jj < nrows);
+      x1 = load_piece(db, ldb, hdb, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
+    }
+  };
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) load_unit(sl, b0[sl], b1[sl]);
+  store_parts(d1);
+  __syncthreads();
+  build_tf();
+  __syncthreads();
+  mu32x4 tfh[2], tfl[2];
+  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
+  {
+    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
+    if (wave < ngb) { nfh = frag(pkb, splitb, wave, false); nfl = frag(pkb, splitb, wave, true); }
+#pragma unroll 1
+    for (int u0 = 0; u0 < nunits; u0 += 4) {
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const int u = u0 + sl;
+        if (u < nunits) {   // wave-uniform
+          const int rs = rs2 ? (sl & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
+          if (!rs2 || !(sl & 1)) {
+            fh = nfh; fl = nfl;
+            if (cg + 4 < ngb) { nfh = frag(pkb, splitb, cg + 4, false); nfl = frag(pkb, splitb, cg + 4, true); }
+          }
+          const mu32x4 p0 = finish(b0[sl], cg, rs * 32 + jj, mask_b), p1 = finish(b1[sl], cg, rs * 32 + 16 + jj, mask_b);
+          load_unit(u + 4, b0[sl], b1[sl]);
+          if (rs2 && (sl & 1)) {
+            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[2]);
+            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[2]);
+            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[3]);
+            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[3]);
+            phase2(p0, p1, tfh[1], tfl[1], acc);
+          } else {
+            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[0]);
+            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[0]);
+            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[1]);
+            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[1]);
+            phase2(p0, p1, tfh[0], tfl[0], acc);
+          }
+          if (!rs2 || (sl & 1)) store_group(outb, Cb, cg, acc);
+        }
+      }
+    }
+  }
+  // ---- 4. TB -> fragments
+  store_parts(d1);
+  __syncthreads();
+  build_tf();
+  __syncthreads();
+  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  // ---- 5. outA = A^T TB from the resident pieces
+#pragma unroll
+  for (int pp = 0; pp < kFrPairs; ++pp) {
+    const int cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
+    if (cg < nga) {
+      if (rs2 && (pp & 1)) phase2(pa[2 * pp], pa[2 * pp + 1], tfh[1], tfl[1], acc);
+      else phase2(pa[2 * pp], pa[2 * pp + 1], tfh[0], tfl[0], acc);
+      if (!rs2 || (pp & 1)) store_group(outa, Ca, cg, acc);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- host side
+static int g_fm_form = 0;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
+
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
 
 // Geometry of a site at R rows per block inside `lds_cap` bytes of LDS: the widest chunk of B that fits.
@@ -601,7 +835,10 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
 #define FM(E, L)                                                                                                      \
   do {                                                                                                                \
-    if (drop) hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    if (g_fm_form == 1) {                                                                                             \
+      if (drop) hipLaunchKernelGGL((factors_reg_kernel<E, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+      else hipLaunchKernelGGL((factors_reg_kernel<E, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    } else if (drop) hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
     else hipLaunchKernelGGL((factors_mfma_kernel<E, L, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
   } while (0)
   if (act_dtype == LORA_AMD_F16) {
@@ -613,3 +850,12 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
 }
 
+
+// Which kernel lora_amd_linear_bwd_factors_mfma_ragged launches on a planned table: 0 = LDS-resident row block
+// (factors_mfma_kernel), 1 = register-resident (factors_reg_kernel); same tables, same slabs.  < 0 only reads; returns the
+// previous value.
+extern "C" int lora_amd_factors_mfma_set_form(int32_t form) {
+  const int prev = g_fm_form;
+  if (form == 0 || form == 1) g_fm_form = form;
+  return prev;
+}

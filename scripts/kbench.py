@@ -357,15 +357,28 @@ def bench_fm(args):
     t, _ = timeit(lambda: _C.factor_pack(tab_p, len(packs), total, dt), inner=5)
     rec["pack_us"] = round(t * 1e6, 1)
     tot = 0.0
+    tabs = []
     for cls, ss in sorted(by_cls.items()):
         arr, grid = _C.factors_mfma_table(ss, dt, cls)
         tab = _C.table_to_device(arr, DEV)
+        tabs.append((tab, len(ss), grid, cls))
         b = sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)
         t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt), inner=5)
         rec[f"mfma_class{cls}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
                                    "frac8": round(b / 8e12 / t, 3), "rows": sorted({int(s_[10].rows_per_block) for s_ in ss}),
                                    "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
         tot += t
+    # the register-resident kernel on the same tables
+    prev = _C.factors_mfma_set_form(1)
+    try:
+        tot_r = 0.0
+        for tab, ns, grid, cls in tabs:
+            t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
+            rec[f"reg_class{cls}_us"] = round(t * 1e6, 1)
+            tot_r += t
+        rec["reg_pass_us"], rec["reg_frac8"] = round(tot_r * 1e6, 1), round(byts / 8e12 / tot_r, 3)
+    finally:
+        _C.factors_mfma_set_form(prev)
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
     rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)
@@ -374,7 +387,7 @@ def bench_fm(args):
     worst = 0.0
     for (a, b) in zip(rows_v, rows_m):
         worst = max(worst, float((a[1] - b[1]).abs().max() / (a[1].abs().max() + 1e-30)))
-    rec["max_rel_diff_valu_vs_mfma"] = worst
+    rec["max_rel_diff_valu_vs_matrix_core_last_run"] = worst   # the slabs hold the register form's result (it ran last)
     print(json.dumps(rec), flush=True)
 
 

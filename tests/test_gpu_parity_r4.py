@@ -47,6 +47,14 @@ def test_ds_read_tr16_b64_semantics(tmp_path):
 
 
 # ----------------------------------------------------------------------------- a2: the matrix-core factor pass
+@pytest.fixture(params=[0, 1], ids=["lds_resident", "register_resident"])
+def fm_form(request):
+    """Both kernels of the matrix-core factor pass (lora_amd_factors_mfma_set_form) on the same tables."""
+    prev = _C.factors_mfma_set_form(request.param)
+    yield request.param
+    _C.factors_mfma_set_form(prev)
+
+
 def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
     """Build packs + tables for ``specs`` = [(M, K, N, gh, xh)], launch (one launch per LDS class), fold, return per-site
     (d_up, d_down, oracle d_up, oracle d_down, abs bounds, plan)."""
@@ -99,7 +107,7 @@ def _fm_run(specs, r, s_, dt=torch.bfloat16, rows=0):
     (2048, 320, 320, 16, torch.bfloat16, None, (8, 40, 64), 0), (777, 64, 96, 4, torch.bfloat16, None, None, 0),
     (4096, 640, 640, 4, torch.bfloat16, None, None, 64), (5000, 320, 320, 4, torch.bfloat16, None, None, 32),
     (333, 768, 768, 8, torch.bfloat16, None, None, 0)])
-def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows):
+def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows, fm_form):
     """autograd of lora.py:53-58 for the factors (dB = s G^T (X A^T), dA = (s G B)^T X) through
     lora_amd_factor_pack + lora_amd_linear_bwd_factors_mfma_ragged vs oracle.lora_linear_backward; resident X and
     resident G sites, chunked wide operands, both LDS classes, head-padded rows, a ragged last row block, f16.  f32-grade
@@ -111,7 +119,7 @@ def test_factors_mfma_pass_vs_oracle(M, K, N, r, dt, gh, xh, rows):
     close(o["d_down"], o["ddo"], o["absd"], "f32", k=1e-4, msg="dDown")
 
 
-def test_factors_mfma_one_launch_for_several_sites_vs_oracle():
+def test_factors_mfma_one_launch_for_several_sites_vs_oracle(fm_form):
     """Several sites of different shapes, LDS classes and layouts through ONE pack launch and one pass launch per class."""
     specs = [(4096, 320, 320, None, None), (1000, 640, 640, None, None), (2048, 320, 320, (8, 40, 64), None),
              (2048, 320, 320, None, (8, 40, 64)), (308, 768, 1280, None, None), (512, 320, 2560, None, None),
@@ -122,7 +130,7 @@ def test_factors_mfma_one_launch_for_several_sites_vs_oracle():
 
 
 @pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2000, 640, 320, 4, 0.25), (308, 768, 1280, 8, 0.1)])
-def test_factors_mfma_pass_with_dropout_vs_oracle(M, K, N, r, p):
+def test_factors_mfma_pass_with_dropout_vs_oracle(M, K, N, r, p, fm_form):
     """nn.Dropout on the branch (lora.py:45, 57) in the matrix-core pass: G enters as mask (.) G with the mask regenerated
     from (seed, offset_dev) inside the kernel (G resident, G streamed), 1 / (1 - p) folded into the scale — vs
     oracle.lora_linear_backward(mask=) with the mask tests/helpers.philox_dropout_mask restates."""
