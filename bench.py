@@ -151,8 +151,11 @@ def in_step_rooflines(state, fwd_bwd, latents, ehs) -> dict:
         torch.cuda.synchronize()
         sec = _time_launch(lambda: [orig[nm](*a) for nm, a in calls], iters=10, inner=2)
         kinds = sorted({st[9] for st in owed})
-        out["factor_pass"] = {"kernel": "lora_amd::factors_mfma_kernel<bf16> + factor_pack (G and X of %d sites read once; passes: %s)"
-                                        % (len(owed), "+".join(kinds)),
+        launched = sorted({nm for nm, _ in calls})
+        kern = ("lora_amd::factors_reg_kernel<bf16> (register-resident matrix-core pass) + factor_pack"
+                if _C.factors_mfma_set_form(-1) == 1 else "lora_amd::factors_mfma_kernel<bf16> (LDS-resident) + factor_pack") \
+            if "linear_bwd_factors_mfma_ragged" in launched else "lora_amd::linear_bwd_factors_self_ragged_kernel<bf16> (VALU pass)"
+        out["factor_pass"] = {"kernel": "%s: G and X of %d sites; passes: %s" % (kern, len(owed), "+".join(kinds)),
                               "bound": "hbm", "algorithmic_bytes_per_launch": int(gx), "avg_launch_us": round(sec * 1e6, 2),
                               "achieved": round(gx / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(gx / sec / HBM_PEAK, 4),

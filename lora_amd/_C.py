@@ -957,12 +957,13 @@ def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, r
 
 
 # ----------------------------------------------------------------------------- the matrix-core factor pass
-# Which deferred sites take the matrix-core pass: "masked" (default) = the dropout sites only (their mask is regenerated
-# inside the pass; the alternative is one launch per site) — the maskless sites keep the VALU pass, which measures faster
-# on the headline step (946 + 28 us against 1080 + 75 us, profiles/r04_kbench_fm_variants.log); "all" / "1" = every 16-bit
-# site; "0" = none
-FACTORS_MFMA_MODE = {"1": "all", "0": "none"}.get(os.environ.get("LORA_AMD_FACTORS_MFMA", "masked"),
-                                                  os.environ.get("LORA_AMD_FACTORS_MFMA", "masked"))
+# Which deferred sites take the matrix-core pass (csrc/factor_mfma.hip): "all" (default, also "1") = every 16-bit site —
+# with the register-resident kernel the pass reads G and X once at 0.41-0.47 of the byte roof (595 + 79 us fold + 11 us pack
+# on the headline step's 144 sites against 938 + 28 us for the VALU pass, same call: profiles/r04_kbench_fm_register_form*.log);
+# "masked" = the dropout sites only (their mask is regenerated inside the pass), the maskless ones keep the VALU pass;
+# "0" = none
+FACTORS_MFMA_MODE = {"1": "all", "0": "none"}.get(os.environ.get("LORA_AMD_FACTORS_MFMA", "all"),
+                                                  os.environ.get("LORA_AMD_FACTORS_MFMA", "all"))
 FACTORS_MFMA = FACTORS_MFMA_MODE != "none"
 _mfma_plan_cache = {}
 

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
-static int g_fm_form = 0;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
+static int g_fm_form = 1;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
 
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
 
@@ -744,6 +744,8 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   FmGeom g;
   int cls = 0;
   (void)flags;  // bit 0 (dropout site) selects the masked kernel at launch time; the geometry is the same
+  // the register-resident kernel holds 20 pieces per lane: 64 rows up to 640 columns of the narrower operand, 32 beyond
+  if (rows == 0 && g_fm_form == 1) rows = 64;
   if (!fm_choose(M, K, N, r, act_dtype, rows, &g, &cls)) return LORA_AMD_OK;
   out->supported = 1;
   out->lds_class = cls;
