@@ -729,7 +729,7 @@ class MergedWeights:
         _C.factor_pack(tab[0], tab[1], tab[2], dt)
 
     def flush_factors(self) -> None:
-        """ONE factor-gradient launch per (pass, activation dtype, rank tile[, LDS class]) — one or two in practice — for
+        """ONE factor-gradient launch per (pass, activation dtype, rank tile, masked or not) — one in practice — for
         every site whose backward ran since the last flush: ``lora_amd_linear_bwd_factors_mfma_ragged`` (16-bit
         activations: G and X read once, matrix cores; preceded by one ``lora_amd_factor_pack`` launch) or
         ``lora_amd_linear_bwd_factors_self_ragged`` (f32 activations, shapes the former does not take)."""
@@ -737,11 +737,15 @@ class MergedWeights:
             return
         owed, self._owed = self._owed, []
         groups = {}
+        # the register-resident kernel needs no LDS class: every site of a (dtype, rank tile, masked) group in ONE launch
+        # (the table is planned against the large class, which every supported site fits)
+        one_class = _C.factors_mfma_set_form(-1) == 1 if any(st[9] == "mfma" for st in owed) else False
         for st in owed:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16
             masked = kind == "mfma" and st[11] is not None and st[11][0] > 0.0
-            groups.setdefault((kind, st[0].dtype, rt, (int(plan.lds_class), masked) if kind == "mfma" else 0), []).append(st)
+            cls = (2 if one_class else int(plan.lds_class), masked) if kind == "mfma" else 0
+            groups.setdefault((kind, st[0].dtype, rt, cls), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
         packed = {}  # activation dtype -> packs of this flush's sites, each adapter once
         for (kind, dt, rt, cls), sites in groups.items():

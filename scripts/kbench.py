@@ -377,6 +377,12 @@ def bench_fm(args):
             rec[f"reg_class{cls}_us"] = round(t * 1e6, 1)
             tot_r += t
         rec["reg_pass_us"], rec["reg_frac8"] = round(tot_r * 1e6, 1), round(byts / 8e12 / tot_r, 3)
+        # ... and as ONE launch over every site (what ops.MergedWeights.flush_factors issues for this kernel)
+        every = [s_ for _, ss in sorted(by_cls.items()) for s_ in ss]
+        arr, grid = _C.factors_mfma_table(every, dt, 2)
+        tab1 = _C.table_to_device(arr, DEV)
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab1, len(every), grid, 2, dt), inner=5)
+        rec["reg_one_launch_us"], rec["reg_one_launch_frac8"] = round(t * 1e6, 1), round(byts / 8e12 / t, 3)
     finally:
         _C.factors_mfma_set_form(prev)
     red_m = _C.make_reduce_table(rows_m, DEV)
