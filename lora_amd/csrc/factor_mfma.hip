@@ -508,7 +508,8 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
 
   auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int cg, int row, bool ok) -> mu32x4 {
     const int ph = fm_hchunk(ok ? cg * 4 + q : 0, h);
-    return __builtin_nontemporal_load(gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8)));  // read once
+    // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
+    return *gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8));
   };
   auto finish = [&](mu32x4 v, int cg, int row, bool masked) -> mu32x4 {
     if (row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
