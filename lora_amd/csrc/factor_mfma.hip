@@ -31,14 +31,11 @@
 //     x 32 B are both bank-conflict-free (scripts/lds_banks.py checks the lane groups of the microarchitecture guide).
 // Algorithmic bytes per site: M (N + K) e (G and X once) + the partial slabs 2 RT 4 (N + K) M / R (written here, read by
 // lora_amd_reduce_batched).
-// MEASURED (round 4, profiles/r04_kbench_fm_variants.log, r04_fm_pmc.jsonl): FETCH_SIZE 1.0x algorithmic (against 2.0x for
-// the VALU pass), but 0.22-0.30 of the byte roof on the 144 sites of the headline step — the same as the VALU pass, which
-// keeps that job.  What binds is not bytes: a 64-row block costs ~25-40 K cycles of DEPENDENT work per wave (ten barriers,
-// LDS round trips in front of serially dependent MFMAs, a trip to L2 per fragment / slab access) at one or two waves per
-// SIMD; an LDS-DMA loader-wave form of the same pass measured no better (profiles/r04_fm_engine_trace_*.txt has its cycle
-// stamps; removed again, commit 7e6edba).  Where this kernel IS the better one: sites with dropout, whose factor
-// gradients it computes for the whole model in one deferred launch with the mask regenerated inside (the alternative is
-// one latency-bound launch per site).
+// TWO kernels run the same tables (lora_amd_factors_mfma_set_form): the LDS-resident one described above (the round's first
+// form: FETCH_SIZE 1.0x algorithmic but 0.22-0.30 of the byte roof — ten barriers and LDS round trips in front of serially
+// dependent MFMAs cost a 64-row block ~25-40 K cycles of dependent work per wave; profiles/r04_kbench_fm_variants.log,
+// r04_fm_pmc.jsonl, r04_fm_engine_trace_*.txt) and the REGISTER-resident, wave-autonomous one further down
+// (factors_reg_kernel: the default; 0.39-0.42 of the roof on the headline step's 144 sites against 0.29 for the VALU pass).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
