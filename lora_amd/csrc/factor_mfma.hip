@@ -466,6 +466,7 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
 // and the only loads on the critical path of a block are its first ones.
 constexpr int kFrPairs = 10;   // resident (row step, group) units per wave
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
+constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
 
 template <class E, bool DROP>
 __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
@@ -473,13 +474,25 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
   __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
+  __shared__ int64_t s_begin[kFrSitesLds];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
+  // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
+  // memory is eight DEPENDENT trips to L2 in front of the block's first load)
   int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  if (n <= kFrSitesLds) {
+    for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
+    __syncthreads();
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_begin[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
   }
   const lora_amd_fm_site sd = sites[lo];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
   const int R = sd.rows_per_block;
   const bool rs2 = R == 64;            // two 32-row steps per block, else one
   const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;

@@ -2,7 +2,7 @@
 # Round 4, eleventh GPU call: one-launch register-resident factor pass with streaming loads
 set -u
 OUT=gpurun_out
-TAG=r04q
+TAG=${1:-r04q}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
