@@ -32,7 +32,7 @@ def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
     cap = 81920 if pl.lds_class == 1 else 163840
     assert 0 < pl.lds_bytes <= cap
     nrb = -(-M // pl.rows_per_block)
-    assert 1 <= pl.blocks_per_wg <= min(8, nrb) and pl.nparts == nrb   # one slab per row block, whatever a workgroup walks
+    assert 1 <= pl.blocks_per_wg <= min(8, nrb) and pl.nparts == -(-nrb // pl.blocks_per_wg)
     assert pl.up_part_floats == pl.nparts * pl.rank_tile * N and pl.down_part_floats == pl.nparts * pl.rank_tile * K
     assert pl.pack_up_elems == 32 * N and pl.pack_down_elems == 32 * K
     assert pl.rows_per_block * min(K, N) <= (10 if pl.lds_class == 1 else 20) * 2048  # the next block waits in registers
