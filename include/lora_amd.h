@@ -147,9 +147,6 @@ int lora_amd_rank16_mfma(int32_t enable);
  * resident in LDS, 1 = resident in registers, every wave autonomous between four barriers (same tables, same slabs).
  * < 0 only reads.  Returns the previous value. */
 int lora_amd_factors_mfma_set_form(int32_t form);
-/* Row blocks one workgroup of the register-resident kernel walks (1..8, default 4; applies to plans made afterwards: the
- * next block's first loads are in flight while the current block finishes).  < 1 only reads.  Returns the previous value. */
-int lora_amd_factors_mfma_set_blocks(int32_t blocks);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
  * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100

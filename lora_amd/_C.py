@@ -27,7 +27,7 @@ _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 # every symbol include/lora_amd.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
-    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma", "lora_amd_factors_mfma_set_form", "lora_amd_factors_mfma_set_blocks",
+    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma", "lora_amd_factors_mfma_set_form",
     "lora_amd_merge_step_plan", "lora_amd_merge_step",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
@@ -214,8 +214,6 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_rank16_mfma.restype = C.c_int
     lib.lora_amd_factors_mfma_set_form.argtypes = [i32]
     lib.lora_amd_factors_mfma_set_form.restype = C.c_int
-    lib.lora_amd_factors_mfma_set_blocks.argtypes = [i32]
-    lib.lora_amd_factors_mfma_set_blocks.restype = C.c_int
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
                                            f32, u64, u64, vp, vp]
@@ -521,12 +519,6 @@ def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
 def factors_mfma_set_form(form: int = -1) -> int:
     """Kernel of the matrix-core factor pass: 0 = LDS-resident row block, 1 = register-resident; returns the previous one."""
     return int(require().lora_amd_factors_mfma_set_form(int(form)))
-
-
-def factors_mfma_set_blocks(blocks: int = 0) -> int:
-    """Row blocks per workgroup of the register-resident factor pass (plans made afterwards); returns the previous value."""
-    _mfma_plan_cache.clear()
-    return int(require().lora_amd_factors_mfma_set_blocks(int(blocks)))
 
 
 def rank16_mfma(enable: int = -1) -> int:

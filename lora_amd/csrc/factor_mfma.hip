@@ -368,7 +368,8 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
   const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
   const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
   const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
-  float *outa0 = (ax ? q.down_part : q.up_part), *outb0 = (ax ? q.up_part : q.down_part);   // one [RT, C] slab per ROW BLOCK
+  float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;   // = sum over the blocks of TB^T A
+  float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;   // = ... TA^T B
   const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
   unsigned char *bufA = lds, *bufB = bufA + R * pa;
   unsigned char *ttA = bufB + R * pb, *ttB = ttA + 32 * fm_tpitch(R);
@@ -403,9 +404,7 @@ __global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfm
     const int nrows = (int)min((int64_t)R, q.M - m0);
     const int nrows1 = (int)min((int64_t)R, q.M - m1);   // of the next block (if any)
     const bool more = blk + 1 < nblk;
-    const bool accum = false;   // every row block has its own slab (both kernels of this file write the same layout)
-    float *outa = outa0 + (rb0 + blk) * RT * (int64_t)Ca;   // = TB^T A of this block
-    float *outb = outb0 + (rb0 + blk) * RT * (int64_t)Cb;   // = TA^T B
+    const bool accum = blk > 0;
     FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
     dra.row0 = drb.row0 = m0;
     fm_write<E, NPA, DROP>(sa, bufA, pa, R, 0, c8a, dra);
@@ -476,8 +475,7 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
   __shared__ int64_t s_begin[kFrSitesLds];
-  const int tid = threadIdx.x, wave = tid >> 6;
-  int lane = tid & 63, jj = lane & 15, q = lane >> 4;   // re-derived per row block (see the block loop)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
   // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
   // memory is eight DEPENDENT trips to L2 in front of the block's first load)
   int lo = 0, hi = n - 1;
@@ -497,9 +495,9 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   const lora_amd_fm_site sd = sites[lo];
   const int R = sd.rows_per_block;
   const bool rs2 = R == 64;            // two 32-row steps per block, else one
-  const int64_t nrb = (sd.M + R - 1) / R;
-  const int64_t rb0 = ((int64_t)blockIdx.x - sd.block_begin) * sd.blocks_per_wg;
-  const int nblk = (int)min((int64_t)sd.blocks_per_wg, nrb - rb0);
+  const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;
+  const int64_t m0 = rb * R;
+  const int nrows = (int)min((int64_t)R, sd.M - m0);
   const bool ax = sd.resident_is_x != 0;
   const int RT = sd.r <= 4 ? 4 : sd.r <= 8 ? 8 : 16;
   const S *da = reinterpret_cast<const S *>(ax ? sd.x : sd.g), *db = reinterpret_cast<const S *>(ax ? sd.g : sd.x);
@@ -509,7 +507,8 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   const FmHeads hdb = fm_heads((ax ? sd.g_head_dim : sd.x_head_dim) >> 3, (ax ? sd.g_head_pad : sd.x_head_pad) >> 3);
   const S *pka = reinterpret_cast<const S *>(ax ? sd.pk_down : sd.pk_up), *pkb = reinterpret_cast<const S *>(ax ? sd.pk_up : sd.pk_down);
   const int64_t splita = (int64_t)(Ca >> 3) * 128, splitb = (int64_t)(Cb >> 3) * 128;
-  float *outa0 = (ax ? sd.down_part : sd.up_part), *outb0 = (ax ? sd.up_part : sd.down_part);   // a slab per row block
+  float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
+  float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
   const int nga = Ca >> 5, ngb = Cb >> 5;
   const bool drop = DROP && sd.dropout_p > 0.f;
   const bool mask_a = drop && !ax, mask_b = drop && ax;   // G is the masked operand
@@ -517,16 +516,14 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   const uint32_t thr = (uint32_t)(sd.dropout_p * 65536.0f + 0.5f);
   const int n8 = sd.N >> 3;
 
-  // `qx` = q, handed in so that the loop below can make it opaque per iteration: hoisted out of the block loop, the twenty
-  // piece addresses would live in registers across it (the kernel sits at the 256-register limit)
-  auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int64_t mb, int cg, int row, bool ok, int qx) -> mu32x4 {
-    const int ph = fm_hchunk(ok ? cg * 4 + qx : 0, h);
+  auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int cg, int row, bool ok) -> mu32x4 {
+    const int ph = fm_hchunk(ok ? cg * 4 + q : 0, h);
     // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
-    return *gl(reinterpret_cast<const mu32x4 *>(d + (mb + (ok ? row : 0)) * ld + (int64_t)ph * 8));
+    return *gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8));
   };
-  auto finish = [&](mu32x4 v, int64_t mb, int nr, int cg, int row, bool masked) -> mu32x4 {
-    if (row >= nr) return mu32x4{0u, 0u, 0u, 0u};
-    if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((mb + row) * (int64_t)n8 + cg * 4 + q), thr);
+  auto finish = [&](mu32x4 v, int cg, int row, bool masked) -> mu32x4 {
+    if (row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
+    if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + q), thr);
     return v;
   };
   auto frag = [&](const S *pk, int64_t split, int cg, bool lo_part) -> mu32x4 {
@@ -534,8 +531,7 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   };
   unsigned char *stage = s_stage + wave * 32 * kFrPitch;
   // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
-  auto phase2 = [&](mu32x4 p0, mu32x4 p1, int rsx, mf32x4 (&acc)[2]) {   // T fragments of row step rsx: re-read from LDS (16 registers less)
-    const mu32x4 th = s_tf[(rsx * 2 + 0) * 64 + lane], tl = s_tf[(rsx * 2 + 1) * 64 + lane];
+  auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, mf32x4 (&acc)[2]) {
     *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
     *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
     asm volatile("" ::: "memory");
@@ -579,153 +575,130 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
       s_tf[(wave * 2 + 1) * 64 + lane] = l;
     }
   };
-  const int ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;
-  const int nunits = ngb_w * (rs2 ? 2 : 1);
-  auto load_unit = [&](int u, int64_t mb, int nr, mu32x4 &x0, mu32x4 &x1) {
-    const int rs = rs2 ? (u & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
-    if (u < nunits) {   // wave-uniform
-      x0 = load_piece(db, ldb, hdb, mb, cg, rs * 32 + jj, rs * 32 + jj < nr, q);
-      x1 = load_piece(db, ldb, hdb, mb, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nr, q);
-    }
-  };
 
-  // the resident pieces: pair pp = (row step rs, group index gi), pieces 2 pp (rows rs 32 + jj) and 2 pp + 1 (+ 16).
-  // The first block's go out here; every further block's are issued while the previous block's step 5 retires its own.
+  // ---- 1. the resident pieces: pair pp = (row step rs, group index gi), pieces 2 pp (rows rs 32 + jj) and 2 pp + 1 (+ 16)
   mu32x4 pa[2 * kFrPairs];
-  mu32x4 b0[4], b1[4];
+#pragma unroll
+  for (int pp = 0; pp < kFrPairs; ++pp) {
+    const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
+    pa[2 * pp] = pa[2 * pp + 1] = mu32x4{0u, 0u, 0u, 0u};
+    if (cg < nga) {   // wave-uniform
+      pa[2 * pp] = load_piece(da, lda, hda, cg, rs * 32 + jj, rs * 32 + jj < nrows);
+      pa[2 * pp + 1] = load_piece(da, lda, hda, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
+    }
+  }
+  // ---- 2. TA = A fa^T
+  mf32x4 d1[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const int64_t m0 = rb0 * R;
-    const int nrows = (int)min((int64_t)R, sd.M - m0);
+    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
+    if (wave < nga) { nfh = frag(pka, splita, wave, false); nfl = frag(pka, splita, wave, true); }
 #pragma unroll
     for (int pp = 0; pp < kFrPairs; ++pp) {
       const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-      pa[2 * pp] = pa[2 * pp + 1] = mu32x4{0u, 0u, 0u, 0u};
-      if (cg < nga) {   // wave-uniform
-        pa[2 * pp] = load_piece(da, lda, hda, m0, cg, rs * 32 + jj, rs * 32 + jj < nrows, q);
-        pa[2 * pp + 1] = load_piece(da, lda, hda, m0, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows, q);
+      if (!rs2 || !(pp & 1)) {  // first pair of a group
+        fh = nfh; fl = nfl;
+        if (cg + 4 < nga) { nfh = frag(pka, splita, cg + 4, false); nfl = frag(pka, splita, cg + 4, true); }
+      }
+      if (cg < nga) {
+        pa[2 * pp] = finish(pa[2 * pp], cg, rs * 32 + jj, mask_a);
+        pa[2 * pp + 1] = finish(pa[2 * pp + 1], cg, rs * 32 + 16 + jj, mask_a);
+        if (rs2 && (pp & 1)) {
+          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[2]);
+          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[2]);
+          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[3]);
+          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[3]);
+        } else {
+          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[0]);
+          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[0]);
+          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[1]);
+          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[1]);
+        }
       }
     }
   }
+  // ---- 3. B: the first ring slots go out before the barrier
+  const int ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;
+  const int nunits = ngb_w * (rs2 ? 2 : 1);
+  mu32x4 b0[4], b1[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
+  auto load_unit = [&](int u, mu32x4 &x0, mu32x4 &x1) {
+    const int rs = rs2 ? (u & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
+    if (u < nunits) {   // wave-uniform
+      x0 = load_piece(db, ldb, hdb, cg, rs * 32 + jj, rs * 32 + jj < nrows);
+      x1 = load_piece(db, ldb, hdb, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
+    }
+  };
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) load_unit(sl, b0[sl], b1[sl]);
+  store_parts(d1);
+  __syncthreads();
+  build_tf();
+  __syncthreads();
+  mu32x4 tfh[2], tfl[2];
+  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
+  {
+    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
+    if (wave < ngb) { nfh = frag(pkb, splitb, wave, false); nfl = frag(pkb, splitb, wave, true); }
 #pragma unroll 1
-  for (int blk = 0; blk < nblk; ++blk) {
-    // the lane coordinates are made opaque per block: everything derived from them (twenty piece addresses, the LDS
-    // addresses of the partials and the transposed reads) would otherwise be hoisted out of this loop and live in registers
-    // across it — the kernel sits at the 256-register limit
-    asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
-    jj = lane & 15;
-    q = lane >> 4;
-    const int64_t m0 = (rb0 + blk) * R, m1 = m0 + R;
-    const int nrows = (int)min((int64_t)R, sd.M - m0);
-    const bool more = blk + 1 < nblk;
-    const int nrows1 = more ? (int)min((int64_t)R, sd.M - m1) : 0;
-    float *outa = outa0 + (rb0 + blk) * RT * (int64_t)Ca;
-    float *outb = outb0 + (rb0 + blk) * RT * (int64_t)Cb;
-    // ---- 2. TA = A fa^T
-    mf32x4 d1[4];
+    for (int u0 = 0; u0 < nunits; u0 += 4) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
-      if (wave < nga) { nfh = frag(pka, splita, wave, false); nfl = frag(pka, splita, wave, true); }
-#pragma unroll
-      for (int pp = 0; pp < kFrPairs; ++pp) {
-        const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-        if (!rs2 || !(pp & 1)) {  // first pair of a group
-          fh = nfh; fl = nfl;
-          if (cg + 4 < nga) { nfh = frag(pka, splita, cg + 4, false); nfl = frag(pka, splita, cg + 4, true); }
-        }
-        if (cg < nga) {
-          pa[2 * pp] = finish(pa[2 * pp], m0, nrows, cg, rs * 32 + jj, mask_a);
-          pa[2 * pp + 1] = finish(pa[2 * pp + 1], m0, nrows, cg, rs * 32 + 16 + jj, mask_a);
-          if (rs2 && (pp & 1)) {
-            d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[2]);
-            d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[2]);
-            d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[3]);
-            d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[3]);
+      for (int sl = 0; sl < 4; ++sl) {
+        const int u = u0 + sl;
+        if (u < nunits) {   // wave-uniform
+          const int rs = rs2 ? (sl & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
+          if (!rs2 || !(sl & 1)) {
+            fh = nfh; fl = nfl;
+            if (cg + 4 < ngb) { nfh = frag(pkb, splitb, cg + 4, false); nfl = frag(pkb, splitb, cg + 4, true); }
+          }
+          const mu32x4 p0 = finish(b0[sl], cg, rs * 32 + jj, mask_b), p1 = finish(b1[sl], cg, rs * 32 + 16 + jj, mask_b);
+          load_unit(u + 4, b0[sl], b1[sl]);
+          if (rs2 && (sl & 1)) {
+            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[2]);
+            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[2]);
+            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[3]);
+            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[3]);
+            phase2(p0, p1, tfh[1], tfl[1], acc);
           } else {
-            d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[0]);
-            d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[0]);
-            d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[1]);
-            d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[1]);
+            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[0]);
+            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[0]);
+            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[1]);
+            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[1]);
+            phase2(p0, p1, tfh[0], tfl[0], acc);
           }
+          if (!rs2 || (sl & 1)) store_group(outb, Cb, cg, acc);
         }
       }
     }
-    // ---- 3. B: the first ring units go out before the barriers
+  }
+  // ---- 4. TB -> fragments
+  store_parts(d1);
+  __syncthreads();
+  build_tf();
+  __syncthreads();
+  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  // ---- 5. outA = A^T TB from the resident pieces
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
-      load_unit(sl, m0, nrows, b0[sl], b1[sl]);
+  for (int pp = 0; pp < kFrPairs; ++pp) {
+    const int cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
+    if (cg < nga) {
+      if (rs2 && (pp & 1)) phase2(pa[2 * pp], pa[2 * pp + 1], tfh[1], tfl[1], acc);
+      else phase2(pa[2 * pp], pa[2 * pp + 1], tfh[0], tfl[0], acc);
+      if (!rs2 || (pp & 1)) store_group(outa, Ca, cg, acc);
     }
-    store_parts(d1);
-    __syncthreads();
-    build_tf();
-    __syncthreads();
-#pragma unroll
-    for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
-    mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
-    {
-      mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
-      if (wave < ngb) { nfh = frag(pkb, splitb, wave, false); nfl = frag(pkb, splitb, wave, true); }
-#pragma unroll 1
-      for (int u0 = 0; u0 < nunits; u0 += 4) {
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-          const int u = u0 + sl;
-          if (u < nunits) {   // wave-uniform
-            const int rs = rs2 ? (sl & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
-            if (!rs2 || !(sl & 1)) {
-              fh = nfh; fl = nfl;
-              if (cg + 4 < ngb) { nfh = frag(pkb, splitb, cg + 4, false); nfl = frag(pkb, splitb, cg + 4, true); }
-            }
-            const mu32x4 p0 = finish(b0[sl], m0, nrows, cg, rs * 32 + jj, mask_b);
-            const mu32x4 p1 = finish(b1[sl], m0, nrows, cg, rs * 32 + 16 + jj, mask_b);
-            load_unit(u + 4, m0, nrows, b0[sl], b1[sl]);
-            if (rs2 && (sl & 1)) {
-              d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[2]);
-              d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[2]);
-              d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[3]);
-              d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[3]);
-              phase2(p0, p1, 1, acc);
-            } else {
-              d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[0]);
-              d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[0]);
-              d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[1]);
-              d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[1]);
-              phase2(p0, p1, 0, acc);
-            }
-            if (!rs2 || (sl & 1)) store_group(outb, Cb, cg, acc);
-          }
-          __builtin_amdgcn_sched_barrier(0);   // one unit at a time: interleaving the four slot bodies costs registers
-        }
-      }
-    }
-    // ---- 4. TB -> fragments
-    store_parts(d1);
-    __syncthreads();
-    build_tf();
-    __syncthreads();
-    // ---- 5. outA = A^T TB from the resident pieces; a retired pair's registers take the next block's pieces at once
-    int qv = q;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(qv));   // opaque: see load_piece
-#pragma unroll
-    for (int pp = 0; pp < kFrPairs; ++pp) {
-      const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-      if (cg < nga) {
-        phase2(pa[2 * pp], pa[2 * pp + 1], rs, acc);
-        if (!rs2 || (pp & 1)) store_group(outa, Ca, cg, acc);
-        if (more) {
-          pa[2 * pp] = load_piece(da, lda, hda, m1, cg, rs * 32 + jj, rs * 32 + jj < nrows1, qv);
-          pa[2 * pp + 1] = load_piece(da, lda, hda, m1, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows1, qv);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) __syncthreads();   // s_part / s_tf are rewritten by the next block's steps 2-3
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
+static int g_fm_form = 1;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
+
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
 
 // Geometry of a site at R rows per block inside `lds_cap` bytes of LDS: the widest chunk of B that fits.
@@ -763,16 +736,11 @@ static bool fm_choose(int64_t M, int K, int N, int r, int act_dtype, int hint, F
   return false;
 }
 
-// row blocks one workgroup walks (each with its own slab).  LDS-resident kernel: 1 — with its tile loads, its factor
-// fragments and its slab reads on ONE in-order vmcnt counter a longer run only serialised (1006 / 1174 / 1657 us at 1 / 2 /
-// 4 blocks, profiles/r04_kbench_fm_variants.log).  Register-resident kernel: several — the next block's resident pieces
-// are issued while the current block's last step retires its own, so only a workgroup's FIRST block waits
-// for its first loads, and the site lookup is paid once.
-static int g_fm_form = 1;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
-static int g_fm_blocks = 4;   // row blocks per workgroup of the register-resident kernel (lora_amd_factors_mfma_set_form)
-
+// row blocks one workgroup walks: their partial sums meet in the workgroup's slab (the kernel supports up to kFmMaxNB).
+// 1: with its tile loads, its factor fragments and its slab reads on ONE in-order vmcnt counter a longer run only
+// serialises (measured 1006 / 1174 / 1657 us at 1 / 2 / 4 blocks, profiles/r04_kbench_fm_variants.log)
 static int fm_blocks_per_wg(int64_t nrb) {
-  const int v = g_fm_form == 1 ? g_fm_blocks : 1;
+  const int v = 1;
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
 }
 
@@ -796,7 +764,7 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   out->rows_per_block = g.R;
   const int64_t nrb = (M + g.R - 1) / g.R;
   out->blocks_per_wg = fm_blocks_per_wg(nrb);
-  out->nparts = (int32_t)nrb;   // one [rank tile, C] slab per row block, whatever the blocks per workgroup
+  out->nparts = (int32_t)((nrb + out->blocks_per_wg - 1) / out->blocks_per_wg);
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
@@ -902,12 +870,5 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
 extern "C" int lora_amd_factors_mfma_set_form(int32_t form) {
   const int prev = g_fm_form;
   if (form == 0 || form == 1) g_fm_form = form;
-  return prev;
-}
-
-// Row blocks per workgroup the planner gives the register-resident kernel (1..8; plans made afterwards).  < 1 only reads.
-extern "C" int lora_amd_factors_mfma_set_blocks(int32_t blocks) {
-  const int prev = g_fm_blocks;
-  if (blocks >= 1 && blocks <= kFmMaxNB) g_fm_blocks = blocks;
   return prev;
 }

@@ -567,10 +567,6 @@ if __name__ == "__main__":
     if "self" in a.what:
         bench_self(a)
     if "fm" in a.what.split(","):
-        for nb in (1, 2, 4):   # row blocks per workgroup of the register-resident kernel (4 = default)
-            _C.factors_mfma_set_blocks(nb)
-            print(json.dumps({"factors_mfma_blocks_per_wg": nb}), flush=True)
-            bench_fm(a)
-        _C.factors_mfma_set_blocks(4)
+        bench_fm(a)
     if "gemmlayout" in a.what:
         bench_gemm_layouts(a)
