@@ -838,3 +838,64 @@ def test_bench_two_rccl_ranks_print_one_line():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 8 and d["config"]["allreduce_us"] > 0 and "backend nccl" in r.stderr
     assert d["config"]["eager_tail"]["frac_of_step"] < 0.01
+
+
+# ----------------------------------------------------------------------------- checkpointing + adapter dropout
+def test_standin_unet_checkpointing_with_adapter_dropout_regenerates_the_forward_masks():
+    """The stand-in UNet's own checkpointing flag (`_grad_ckpt`, set by enable_gradient_checkpointing) must switch the step
+    to per-site dropout draws: a checkpointed block re-runs its forward during the backward, after trainer._dropout_pool's
+    offset pool is gone, and has to regenerate the SAME masks.  With the same torch seed the checkpointed step and the
+    plain step draw the same per-site offsets only if both use per-site draws, so the comparison is: the checkpointed step
+    twice (same seed -> same loss and gradient: the recompute is consistent with the forward), and against the oracle-free
+    invariant that its gradient equals the gradient of a NON-checkpointed step run with the per-site draws forced."""
+    import lora_amd as L
+    from lora_amd import trainer as T
+    from lora_amd.standin import DDPMScheduler, tiny_unet
+
+    def make():
+        torch.manual_seed(0)
+        u = tiny_unet()
+        u.requires_grad_(False)
+        L.inject_trainable_lora_extended(u, r=4)
+        for m in u.modules():
+            if isinstance(m, (L.LoraInjectedLinear, L.LoraInjectedConv2d)):
+                m.dropout.p = 0.25
+                m.lora_up.weight.data.normal_(0, 0.05)
+        return u.to(DEV).train()
+
+    g = torch.Generator().manual_seed(11)
+    lat, ehs = torch.randn(2, 4, 32, 32, generator=g).to(DEV), torch.randn(2, 7, 32, generator=g).to(DEV)
+    noise, ts = torch.randn(2, 4, 32, 32, generator=g).to(DEV), torch.randint(0, 1000, (2,), generator=g).to(DEV)
+    sched = DDPMScheduler()
+
+    def step(u, seed):
+        st = T.FlatLoraState([{"params": T.lora_params(u), "lr": 1e-3}], max_grad_norm=1.0, device=torch.device(DEV))
+        st.attach_direct_grads(u)
+        st.zero_grad()
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed(seed)
+        loss = T.forward_backward(u, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=ts)
+        st.reduce_pending()
+        return float(loss), st.flat_g.clone()
+
+    ck = make()
+    ck.enable_gradient_checkpointing()
+    assert any(getattr(m, "_grad_ckpt", False) for m in ck.modules())
+    l1, g1 = step(ck, 123)
+    l2, g2 = step(ck, 123)
+    assert l1 == l2 and torch.equal(g1, g2)              # deterministic in the seed, recompute included
+    assert float(g1.abs().max()) > 0
+    plain = make()
+    import contextlib
+    pool = T.ops.dropout_pool
+    T.ops.dropout_pool = lambda device: contextlib.nullcontext()   # the plain step with per-site draws: the same offsets
+    try:
+        l3, g3 = step(plain, 123)
+    finally:
+        T.ops.dropout_pool = pool
+    # same masks in forward, recompute and backward <=> the checkpointed gradient is the plain one (f32 data: summation order only)
+    assert abs(l1 - l3) <= 1e-5 * abs(l3)
+    assert float((g1 - g3).abs().max()) <= 2e-4 * float(g3.abs().max())
+    # and with the offset pool a different stream is drawn: the masks, hence the gradients, differ visibly
+    l4, g4 = step(plain, 123)
+    assert float((g4 - g3).abs().max()) > 1e-2 * float(g3.abs().max())
