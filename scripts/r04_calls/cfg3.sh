@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ARGS="--extended 1 --rank 16 --res 768 --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline"
 timeout 400 python bench.py $ARGS > $OUT/r04h_cfg3_default.json 2> $OUT/r04h_cfg3_default.err
 LORA_AMD_AB=DEFER_MASKED_FACTORS=0 timeout 400 python bench.py $ARGS > $OUT/r04h_cfg3_nodefer.json 2> $OUT/r04h_cfg3_nodefer.err

@@ -5,7 +5,7 @@ OUT=gpurun_out
 TAG=r04l
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 600 python -m pytest tests/test_gpu_rank16.py -q -x > $OUT/${TAG}_pytest.log 2>&1
 tail -4 $OUT/${TAG}_pytest.log
 timeout 300 python scripts/kbench.py --what r16 > $OUT/${TAG}_kbench_r16.log 2>&1

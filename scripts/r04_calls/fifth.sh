@@ -3,7 +3,7 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_gpu_parity_r4.py -q -k "factors_mfma or merge_step" > $OUT/r04f_pytest_fm.log 2>&1
 tail -3 $OUT/r04f_pytest_fm.log
 for V in "" "LORA_AMD_FM_NB=1" "LORA_AMD_FM_NB=4" "LORA_AMD_FM_ENGINE=0"; do

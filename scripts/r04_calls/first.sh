@@ -5,7 +5,7 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 600 python -m pytest tests/test_gpu_parity_r4.py -q -s -k "tr16 or factors_mfma or philox" > $OUT/r04a_pytest_fm.log 2>&1
 tail -5 $OUT/r04a_pytest_fm.log
 timeout 300 python scripts/kbench.py --what fm > $OUT/r04a_kbench_fm.log 2>&1

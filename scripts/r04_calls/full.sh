@@ -5,7 +5,7 @@ OUT=gpurun_out
 TAG=${1:-r04i}
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_full.log 2>&1
 tail -6 $OUT/${TAG}_pytest_full.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; tail -2 $OUT/${TAG}_smoke.log

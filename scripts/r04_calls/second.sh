@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_gpu_parity_r4.py -q -s -k "tr16 or factors_mfma or philox or merge_step" > $OUT/r04b_pytest_kernels.log 2>&1
 tail -4 $OUT/r04b_pytest_kernels.log
 timeout 900 python -m pytest tests/test_gpu_parity_r3.py -q -k "merged or merge or factors" > $OUT/r04b_pytest_r3_merged.log 2>&1

@@ -5,7 +5,7 @@ OUT=gpurun_out
 TAG=r04k
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_gpu_rank16.py tests/test_gpu_parity_r4.py -q -x -k "rank16 or rowdot16 or rank_update16 or bwd_g16 or linear_fwd16 or merge_step or extended_rank16" > $OUT/${TAG}_pytest.log 2>&1
 tail -15 $OUT/${TAG}_pytest.log
 timeout 300 python scripts/kbench.py --what r16 > $OUT/${TAG}_kbench_r16.log 2>&1

@@ -5,7 +5,7 @@ OUT=gpurun_out
 TAG=r04j
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 600 python -m pytest tests/test_gpu_parity_r4.py -q -k "selection_modes or merge_step or consecutive" > $OUT/${TAG}_pytest.log 2>&1
 tail -5 $OUT/${TAG}_pytest.log
 timeout 300 python scripts/kbench.py --what mstep > $OUT/${TAG}_kbench_mstep.log 2>&1

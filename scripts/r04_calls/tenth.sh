@@ -5,7 +5,7 @@ OUT=gpurun_out
 TAG=r04p
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_gpu_parity_r4.py tests/test_gpu_parity_r3.py -q -x -k "factors_mfma or selection_modes or consecutive or sd15_size_step or merged_weight or extended_rank16 or sd15_unet_plus_clip" > $OUT/${TAG}_pytest.log 2>&1
 tail -5 $OUT/${TAG}_pytest.log
 timeout 300 python scripts/kbench.py --what fm > $OUT/${TAG}_kbench_fm.log 2>&1

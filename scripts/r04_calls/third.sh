@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_gpu_parity_r4.py -q -x -k "factors_mfma" > $OUT/r04c_pytest_fm.log 2>&1
 tail -6 $OUT/r04c_pytest_fm.log
 for V in "" "LORA_AMD_FM_NB=1" "LORA_AMD_FM_NB=4" "LORA_AMD_FM_NB=8" "LORA_AMD_FM_ROWS=32" "LORA_AMD_FM_ENGINE=0"; do
