@@ -958,7 +958,7 @@ def linear_bwd_factors_self_ragged(table_dev: torch.Tensor, n: int, grid: int, r
 
 # ----------------------------------------------------------------------------- the matrix-core factor pass
 # Which deferred sites take the matrix-core pass (csrc/factor_mfma.hip): "all" (default, also "1") = every 16-bit site —
-# with the register-resident kernel the pass reads G and X once at 0.41-0.47 of the byte roof (595 + 79 us fold + 11 us pack
+# with the register-resident kernel the pass reads G and X once at 0.43-0.45 of the byte roof in the step (600-650 + 59 us fold + 11 us pack
 # on the headline step's 144 sites against 938 + 28 us for the VALU pass, same call: profiles/r04_kbench_fm_register_form*.log);
 # "masked" = the dropout sites only (their mask is regenerated inside the pass), the maskless ones keep the VALU pass;
 # "0" = none

@@ -35,7 +35,7 @@
 // form: FETCH_SIZE 1.0x algorithmic but 0.22-0.30 of the byte roof — ten barriers and LDS round trips in front of serially
 // dependent MFMAs cost a 64-row block ~25-40 K cycles of dependent work per wave; profiles/r04_kbench_fm_variants.log,
 // r04_fm_pmc.jsonl, r04_fm_engine_trace_*.txt) and the REGISTER-resident, wave-autonomous one further down
-// (factors_reg_kernel: the default; 0.39-0.42 of the roof on the headline step's 144 sites against 0.29 for the VALU pass).
+// (factors_reg_kernel: the default; 0.43-0.45 of the roof on the headline step's 144 sites against 0.29 for the VALU pass).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
