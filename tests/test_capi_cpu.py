@@ -208,3 +208,44 @@ def test_factor_pass_planner_invariants_over_random_shapes():
             assert 0 <= q.logL_g <= 6 and 0 <= q.logL_x <= 6 and q.kt_g % 8 == 0 and q.kt_g * rt <= 8192
             begin += nrb
         assert grid.value == begin
+
+
+def test_round4_hooks_and_plan_values_are_host_state():
+    """The tuning hooks of ABI 4 read / write host globals (no GPU): each returns the previous value, refuses values outside
+    its range, and the in-step merge's plan value carries the tile geometry it was planned for."""
+    lib = _C.require()
+    assert _C.rank16_mfma(-1) == 1 and _C.rank16_mfma(0) == 1 and _C.rank16_mfma(-1) == 0 and _C.rank16_mfma(1) == 0
+    assert _C.factors_mfma_set_form(-1) == 1 and _C.factors_mfma_set_form(0) == 1 and _C.factors_mfma_set_form(7) == 0
+    assert _C.factors_mfma_set_form(1) == 0 and _C.factors_mfma_set_form(-1) == 1
+    assert lib.lora_amd_merge_step_set_tuning(9, -1) != 0 and b"tile 9" in lib.lora_amd_last_error()
+    sites = (_C.MstepSite * 2)()
+    for s, (N, K, r) in zip(sites, [(320, 320, 4), (2560, 328, 16)]):
+        s.N, s.K, s.r = N, K, r
+        s.w = s.up = s.down = s.out = 4096
+        s.ld_out = K
+    tiles = {}
+    for tile, (tr, tc) in enumerate([(128, 64), (64, 128), (128, 128), (256, 64)]):
+        _C.merge_step_set_tuning(tile, -1)
+        try:
+            val = C.c_int64(0)
+            assert lib.lora_amd_merge_step_plan(sites, 2, _C.BF16, C.byref(val)) == 0
+        finally:
+            _C.merge_step_set_tuning(2, -1)
+        want = sum(-(-s.N // tr) * -(-s.K // tc) for s in sites)
+        assert val.value >> 40 == tile and val.value & ((1 << 40) - 1) == want
+        assert sites[1].tile_begin == -(-320 // tr) * -(-320 // tc) and sites[1].tiles_k == -(-328 // tc)
+        tiles[tile] = want
+    assert tiles[2] < tiles[0]
+    sites[0].K = 321   # K % 8 != 0: the plan refuses (f32 weights and odd shapes stay on lora_amd_merge_batched)
+    assert lib.lora_amd_merge_step_plan(sites, 2, _C.BF16, C.byref(val)) != 0
+
+
+def test_matrix_core_factor_plan_prefers_64_row_blocks_for_the_register_kernel():
+    import torch
+
+    for (M, K, N), rows in (((16384, 320, 320), 64), ((4096, 640, 640), 64), ((1024, 1280, 1280), 32), ((308, 768, 1280), 32),
+                            ((4096, 640, 5120), 64), ((16384, 320, 2560), 64)):
+        pl = _C.factors_mfma_plan(M, K, N, 4, torch.bfloat16)
+        assert pl.supported and pl.rows_per_block == rows and pl.blocks_per_wg == 1 and pl.nparts == -(-M // rows)
+        # 20 resident 16-byte pieces per lane over four waves: rows x narrower width / (256 lanes x 8 elements)
+        assert rows * min(K, N) <= 20 * 256 * 8
