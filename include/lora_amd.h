@@ -245,6 +245,29 @@ int lora_amd_rowdot_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int
                            int32_t factor_layout, float scale, void *stream);
 int lora_amd_colreduce_ragged(const lora_amd_ragged_desc *descs_dev, int32_t n, int64_t grid1, int64_t grid2, int32_t r,
                               int32_t out_layout, float scale, void *stream);
+/* The same skinny products on the matrix cores for stacks held as two 16-bit planes (X = hi + lo, the bytes of f32):
+ * out[b] [M, r] = X[b] [M, C] @ F[b] [C, r]  (r <= 16, C % 32 == 0).  lora_amd_split16_ragged makes the planes of flat f32
+ * arrays (n % 8 == 0 each; `begin` = running count of 4096-element blocks, filled by the caller).
+ * replaces: the colreduce passes over dW / dW^T of the subspace iteration (cli_svd.py:24-92 as restated in cli_svd.py). */
+typedef struct lora_amd_planes_desc {
+  const void *hi, *lo;    /* planes of a dense stack [batch][M][C] */
+  const float *f;         /* [batch][C][r] */
+  float *out;             /* [batch][M][r] */
+  int64_t M;
+  int32_t C, batch;
+  /* filled by lora_amd_rowdot16_planes_plan */
+  int32_t wps, slabs_per_wg;
+  int64_t wg_begin;
+} lora_amd_planes_desc;
+int lora_amd_rowdot16_planes_plan(lora_amd_planes_desc *descs_host, int32_t n, int64_t *grid);
+int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t r, int32_t plane_dtype,
+                             void *stream);
+typedef struct lora_amd_split_desc {
+  const float *src;
+  void *hi, *lo;
+  int64_t n, begin;
+} lora_amd_split_desc;
+int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int32_t n, int64_t blocks, int32_t plane_dtype, void *stream);
 typedef struct lora_amd_sub_desc {
   const void *a, *b;
   float *out;

@@ -33,6 +33,7 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
+    "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_split16_ragged",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
@@ -125,6 +126,16 @@ class RaggedDesc(C.Structure):
 
 class SubDesc(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("begin", C.c_int64)]
+
+
+class PlanesDesc(C.Structure):
+    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("f", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64),
+                ("C", C.c_int32), ("batch", C.c_int32), ("wps", C.c_int32), ("slabs_per_wg", C.c_int32),
+                ("wg_begin", C.c_int64)]
+
+
+class SplitDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("n", C.c_int64), ("begin", C.c_int64)]
 
 
 class MergeSite(C.Structure):
@@ -231,6 +242,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_rowdot_ragged.argtypes = [vp, i32, i64, i32, i32, f32, vp]
     lib.lora_amd_colreduce_ragged.argtypes = [vp, i32, i64, i64, i32, i32, f32, vp]
     lib.lora_amd_sub_ragged.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_rowdot16_planes_plan.argtypes = [vp, i32, vp]
+    lib.lora_amd_rowdot16_planes.argtypes = [vp, i32, i64, i32, i32, vp]
+    lib.lora_amd_split16_ragged.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_rowdot16_planes_plan.restype = lib.lora_amd_rowdot16_planes.restype = C.c_int
+    lib.lora_amd_split16_ragged.restype = C.c_int
     lib.lora_amd_ragged_plan.restype = lib.lora_amd_rowdot_ragged.restype = C.c_int
     lib.lora_amd_colreduce_ragged.restype = lib.lora_amd_sub_ragged.restype = C.c_int
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
@@ -707,6 +723,61 @@ class RaggedProgram:
         else:
             _check(lib.lora_amd_colreduce_ragged(ptr, n, g1, g2, r, layout, float(scale), _stream()),
                    "lora_amd_colreduce_ragged")
+
+
+class PlanesProgram:
+    """Descriptor tables of the matrix-core skinny products over (hi, lo) 16-bit planes (``lora_amd_rowdot16_planes``):
+    declared once (``table``), uploaded in one copy, each run one C call.  rows: per shape group (hi [B, M, C], lo, f [B, C, r]
+    f32, out [B, M, r] f32)."""
+
+    def __init__(self, device, r: int, plane_dtype: torch.dtype = torch.bfloat16):
+        self.device, self.r, self.dt = device, int(r), plane_dtype
+        self._blobs, self._meta, self._size, self._dev = [], [], 0, None
+
+    def table(self, rows) -> int:
+        lib = require()
+        arr = (PlanesDesc * len(rows))()
+        for d, (hi, lo, f, out) in zip(arr, rows):
+            B, M, Cc = hi.shape
+            if hi.dtype != self.dt or lo.dtype != self.dt or f.dtype != torch.float32 or out.dtype != torch.float32:
+                raise TypeError("PlanesProgram: 16-bit planes, f32 factor and output expected")
+            if tuple(lo.shape) != (B, M, Cc) or tuple(f.shape) != (B, Cc, self.r) or tuple(out.shape) != (B, M, self.r):
+                raise ValueError(f"PlanesProgram: shape mismatch {tuple(hi.shape)} {tuple(f.shape)} {tuple(out.shape)}")
+            if not (hi.is_contiguous() and lo.is_contiguous() and f.is_contiguous() and out.is_contiguous()):
+                raise ValueError("PlanesProgram: contiguous stacks expected")
+            d.hi, d.lo, d.f, d.out, d.M, d.C, d.batch = hi.data_ptr(), lo.data_ptr(), f.data_ptr(), out.data_ptr(), M, Cc, B
+        grid = C.c_int64(0)
+        _check(lib.lora_amd_rowdot16_planes_plan(arr, len(rows), C.byref(grid)), "lora_amd_rowdot16_planes_plan")
+        blob = bytes(arr)
+        pad = (-len(blob)) % 64
+        self._blobs.append(blob + b"\0" * pad)
+        self._meta.append((len(rows), self._size, grid.value))
+        self._size += len(blob) + pad
+        return len(self._meta) - 1
+
+    def upload(self):
+        self._dev = torch.frombuffer(bytearray(b"".join(self._blobs)), dtype=torch.uint8).to(self.device)
+
+    def run(self, handle: int) -> None:
+        n, off, grid = self._meta[handle]
+        _check(require().lora_amd_rowdot16_planes(self._dev.data_ptr() + off, n, grid, self.r, dtype_code(self.dt), _stream()),
+               "lora_amd_rowdot16_planes")
+
+
+def split16_ragged(srcs, his, los) -> None:
+    """(his[i], los[i]) = the 16-bit hi / lo planes of the flat f32 arrays srcs[i] (numel % 8 == 0), ONE launch."""
+    lib = require()
+    arr = (SplitDesc * len(srcs))()
+    blocks, dt = 0, his[0].dtype
+    for d, s_, h, l in zip(arr, srcs, his, los):
+        _dev_check(s_, h, l)
+        if s_.dtype != torch.float32 or h.dtype != dt or l.dtype != dt or s_.numel() != h.numel() or s_.numel() != l.numel() \
+                or s_.numel() % 8 or not (s_.is_contiguous() and h.is_contiguous() and l.is_contiguous()):
+            raise ValueError("split16_ragged: contiguous f32 sources and same-size 16-bit planes (numel % 8 == 0) expected")
+        d.src, d.hi, d.lo, d.n, d.begin = s_.data_ptr(), h.data_ptr(), l.data_ptr(), s_.numel(), blocks
+        blocks += (s_.numel() + 4095) // 4096
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(his[0].device)
+    _check(lib.lora_amd_split16_ragged(dev.data_ptr(), len(srcs), blocks, dtype_code(dt), _stream()), "lora_amd_split16_ragged")
 
 
 def colreduce_workspace_floats(M: int, K: int, r: int) -> int:

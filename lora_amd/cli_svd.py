@@ -39,6 +39,12 @@ from .lora import (LoraInjectedConv2d, LoraInjectedLinear, inject_trainable_lora
                    save_all)
 
 
+# The four products with dW / dW^T of the ragged iteration on the matrix cores over (hi, lo) bf16 planes of the residuals
+# (csrc/rank16_mfma.hip: lora_amd_split16_ragged + lora_amd_rowdot16_planes) when the sketch is 16 wide and every shape is a
+# multiple of 32 both ways; False = the f32 column-reduction passes of rounds 2-3 (tests run both).
+PLANES = True
+
+
 def _iter_lora(model):  # ref :16-21
     for module in model.modules():
         if isinstance(module, (LoraInjectedConv2d, LoraInjectedLinear)):
@@ -201,10 +207,35 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
     prog = _C.RaggedProgram(dev)
     cr = lambda xs, fs, outs: prog.table(_C.RAGGED_COLREDUCE, l, list(zip(xs, fs, outs, ws)))  # noqa: E731
     rd = lambda xs, fs, outs, r=l: prog.table(_C.RAGGED_ROWDOT, r, [(x, f, o_, None) for x, f, o_ in zip(xs, fs, outs)])  # noqa: E731
-    t_sketch = cr(delta_t, Zc, Ya)          # Y = dW Omega
-    t_fwd = cr(deltas, Yb, Za)              # Z = dW^T Q
-    t_back = cr(delta_t, Zb, Ya)            # Y = dW Qz
-    t_b = cr(deltas, Yb, Zc)                # b^T = dW^T Q
+    planes = PLANES and l == 16 and all(N % 32 == 0 and K % 32 == 0 for _, N, K in dims)
+    if planes:
+        # dW and dW^T as (hi, lo) bf16 planes (the bytes of the f32 stacks, split by ONE launch); every product with them
+        # is then a row product on the matrix cores: Y = dW F streams the planes of dW, Z = dW^T F those of dW^T
+        def planes_of(stacks):
+            hs, ls = [], []
+            for st in stacks:
+                hs.append(torch.empty(st.shape, dtype=torch.bfloat16, device=dev))
+                ls.append(torch.empty(st.shape, dtype=torch.bfloat16, device=dev))
+            return hs, ls
+        dh, dl = planes_of(deltas)
+        th, tl = planes_of(delta_t)
+        _C.split16_ragged([x.view(-1) for x in list(deltas) + list(delta_t)], [x.view(-1) for x in dh + th],
+                          [x.view(-1) for x in dl + tl])
+        pprog = _C.PlanesProgram(dev, l)
+        p_sketch = pprog.table(list(zip(dh, dl, Zc, Ya)))     # Y = dW Omega
+        p_fwd = pprog.table(list(zip(th, tl, Yb, Za)))        # Z = dW^T Q
+        p_back = pprog.table(list(zip(dh, dl, Zb, Ya)))       # Y = dW Qz
+        p_b = pprog.table(list(zip(th, tl, Yb, Zc)))          # b^T = dW^T Q
+        pprog.upload()
+        big = {"sketch": lambda: pprog.run(p_sketch), "fwd": lambda: pprog.run(p_fwd), "back": lambda: pprog.run(p_back),
+               "b": lambda: pprog.run(p_b)}
+    else:
+        t_sketch = cr(delta_t, Zc, Ya)          # Y = dW Omega
+        t_fwd = cr(deltas, Yb, Za)              # Z = dW^T Q
+        t_back = cr(delta_t, Zb, Ya)            # Y = dW Qz
+        t_b = cr(deltas, Yb, Zc)                # b^T = dW^T Q
+        big = {"sketch": lambda: prog.run(t_sketch, _C.FACTOR_KR), "fwd": lambda: prog.run(t_fwd, _C.FACTOR_KR),
+               "back": lambda: prog.run(t_back, _C.FACTOR_KR), "b": lambda: prog.run(t_b, _C.FACTOR_KR)}
     t_core = cr(Za, Zc, Cr)                 # b Qb  [l, l]
     gram_of = {id(t[0]): cr(t, t, G) for t in (Ya, Yb, Za, Zb, Zc)}
     apply_l = {(id(a[0]), id(b[0])): rd(a, L, b) for a, b in ((Ya, Yb), (Yb, Ya), (Za, Zb), (Zb, Za), (Zc, Za))}
@@ -221,14 +252,14 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
             prog.run(apply_l[(id(a[0]), id(b[0]))], _C.FACTOR_RK)
 
     zc_flat.normal_(generator=generator)                          # Omega, every group at once
-    prog.run(t_sketch, _C.FACTOR_KR)
+    big["sketch"]()
     orth((Ya, Yb, Ya, Yb))                                        # q in Yb
     for _ in range(n_iter):
-        prog.run(t_fwd, _C.FACTOR_KR)
+        big["fwd"]()
         orth((Za, Zb, Za, Zb))                                    # qz in Zb
-        prog.run(t_back, _C.FACTOR_KR)
+        big["back"]()
         orth((Ya, Yb, Ya, Yb))
-    prog.run(t_b, _C.FACTOR_KR)                                   # b^T [K, l] in Zc
+    big["b"]()                                                    # b^T [K, l] in Zc
     orth((Zc, Za, Zb, Za))                                        # qb in Za
     prog.run(t_core, _C.FACTOR_RK)
     ub, s, vbh = torch.linalg.svd(core, full_matrices=False)      # [sum B, l, l]: one batched call for the model

@@ -389,6 +389,112 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
   }
 }
 
+// ============================================================================ rowdot16 over hi + lo planes (cli_svd)
+// out[b][M, r] = X[b][M, C] F[b][C, r] for stacks of f32 matrices held as TWO 16-bit planes (X = hi + lo to ~16 mantissa
+// bits; same bytes as f32): the skinny products of the randomized subspace iteration (cli_svd.py:24-92 restated in
+// lora_amd/cli_svd.py) on the matrix cores — hi F_hi + hi F_lo + lo F_hi per k-step.  One launch for every shape group of
+// a model (descriptor table); a workgroup = 16 waves = 16 / wps slabs of 16 rows, wps waves per slab dealing the k-steps.
+template <class E>
+__global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_planes_desc *__restrict__ descs, int n, int r) {
+  using S = typename E::storage;
+  __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
+  __shared__ int64_t s_begin[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
+  int lo = 0, hi = n - 1;
+  if (n <= 64) {
+    if (tid < n) s_begin[tid] = descs[tid].wg_begin;
+    __syncthreads();
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_begin[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].wg_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+  }
+  const lora_amd_planes_desc d = descs[lo];
+  const int wps = d.wps, spw = 16 / wps;
+  const int64_t nslabs = (d.M + 15) >> 4, wgs_per = (nslabs + spw - 1) / spw;
+  const int64_t wg = (int64_t)blockIdx.x - d.wg_begin;
+  const int64_t b = wg / wgs_per;
+  const int sl = wave / wps, cw = wave - sl * wps;
+  const int64_t slab = (wg - b * wgs_per) * spw + sl;
+  const int64_t m0 = slab * 16;
+  const bool active = slab < nslabs;
+  const int C = d.C, nks = C >> 5;
+  const int64_t row = m0 + jj;
+  const bool rok = active && row < d.M;
+  const int64_t base = (b * d.M + (rok ? row : 0)) * (int64_t)C + 8 * q;
+  const S *xh = reinterpret_cast<const S *>(d.hi) + base, *xl = reinterpret_cast<const S *>(d.lo) + base;
+  const float *f = d.f + b * (int64_t)C * r;
+  mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    auto piece = [&](const S *p, int ks) -> mu32x4 {
+      return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(p + (int64_t)ks * 32)) : r16_zero();
+    };
+    mu32x4 h0 = piece(xh, cw), l0 = piece(xl, cw), h1 = piece(xh, cw + wps), l1 = piece(xl, cw + wps);
+    R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
+#pragma unroll 1
+    for (int ks = cw; ks < nks; ks += wps) {
+      const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
+      mu32x4 fh, fl;
+      r16_factor_split<E>(fr, 1.0f, fh, fl);
+      if (ks + wps < nks) fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (ks + wps) * 32);
+      mu32x4 ch = h0, cl = l0;
+      if (!rok) { ch = r16_zero(); cl = r16_zero(); }
+      acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
+      acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
+      acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+      h0 = h1; l0 = l1; h1 = h2; l1 = l2;
+    }
+  }
+  if (wps > 1) {
+    if (cw > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) s_red[(wave * 4 + reg) * 64 + lane] = acc[reg];
+    }
+    __syncthreads();
+    if (cw > 0) return;
+    for (int k = 1; k < wps; ++k)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[reg] += s_red[((wave + k) * 4 + reg) * 64 + lane];
+  }
+  if (active && jj < r) {
+    float *o = d.out + b * d.M * r;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t rw = m0 + 4 * q + reg;
+      if (rw < d.M) o[rw * r + jj] = acc[reg];
+    }
+  }
+}
+
+// f32 -> (hi, lo) 16-bit planes of flat arrays, one launch over a table (8 elements per thread, 4096 per workgroup)
+template <class E>
+__global__ __launch_bounds__(256) void split16_ragged_kernel(const lora_amd_split_desc *__restrict__ descs, int n) {
+  using S = typename E::storage;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_split_desc d = descs[lo];
+  const int64_t i0 = ((int64_t)blockIdx.x - d.begin) * 4096;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int64_t i = i0 + ((int64_t)u * 256 + threadIdx.x) * 8;
+    if (i >= d.n) continue;   // n % 8 == 0 (host check)
+    const float4 a = gl_ld4(d.src + i), bq = gl_ld4(d.src + i + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+    mu32x4 ph, pl;
+    split_hi_lo<E>(v, ph, pl);
+    *gl(reinterpret_cast<mu32x4 *>(reinterpret_cast<S *>(d.hi) + i)) = ph;
+    *gl(reinterpret_cast<mu32x4 *>(reinterpret_cast<S *>(d.lo) + i)) = pl;
+  }
+}
+
 static bool r16_common_ok(int act_dtype, int fdt, int r) {
   return g_r16_mfma && (act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16) && fdt == LORA_AMD_F32 && r > 8 && r <= 16;
 }
@@ -463,4 +569,50 @@ extern "C" int lora_amd_rank16_mfma(int32_t enable) {
   const int prev = lora_amd::g_r16_mfma;
   if (enable >= 0) lora_amd::g_r16_mfma = enable ? 1 : 0;
   return prev;
+}
+
+using namespace lora_amd;
+
+extern "C" int lora_amd_rowdot16_planes_plan(lora_amd_planes_desc *descs, int32_t n, int64_t *grid) {
+  LORA_AMD_CHECK(descs && n >= 1 && grid, LORA_AMD_EINVAL, "rowdot16_planes_plan: bad argument");
+  int64_t begin = 0;
+  for (int i = 0; i < n; ++i) {
+    lora_amd_planes_desc &d = descs[i];
+    LORA_AMD_CHECK(d.hi && d.lo && d.f && d.out && d.M >= 1 && d.batch >= 1, LORA_AMD_EINVAL, "rowdot16_planes_plan: group %d: null pointer / empty", i);
+    LORA_AMD_CHECK(d.C >= 32 && d.C % 32 == 0 && (((uintptr_t)d.hi | (uintptr_t)d.lo) & 15u) == 0, LORA_AMD_EINVAL,
+                   "rowdot16_planes_plan: group %d: C = %d must be a multiple of 32, planes 16-byte aligned", i, d.C);
+    // waves per slab: >= 4 k-steps each (a wave's chain of dependent loads is what bounds a long row)
+    const int nks = d.C >> 5;
+    int wps = 1;
+    while (wps < 16 && nks / (2 * wps) >= 4) wps *= 2;
+    d.wps = wps;
+    d.slabs_per_wg = 16 / wps;
+    const int64_t nslabs = (d.M + 15) / 16;
+    d.wg_begin = begin;
+    begin += d.batch * ((nslabs + d.slabs_per_wg - 1) / d.slabs_per_wg);
+  }
+  LORA_AMD_CHECK(begin < (1ll << 31), LORA_AMD_EINVAL, "rowdot16_planes_plan: too many workgroups");
+  *grid = begin;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t r,
+                                        int32_t plane_dtype, void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && grid >= 1 && grid < (1ll << 31), LORA_AMD_EINVAL, "rowdot16_planes: bad argument");
+  LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, "rowdot16_planes: %d output columns outside [1,16]", r);
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "rowdot16_planes: 16-bit planes only");
+  hipStream_t st = (hipStream_t)stream;
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(rowdot16_planes_kernel<f16_t>, dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
+  else hipLaunchKernelGGL(rowdot16_planes_kernel<bf16_t>, dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
+  return check_launch("lora_amd_rowdot16_planes");
+}
+
+extern "C" int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int32_t n, int64_t blocks, int32_t plane_dtype,
+                                       void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && blocks >= 1 && blocks < (1ll << 31), LORA_AMD_EINVAL, "split16_ragged: bad argument");
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "split16_ragged: 16-bit planes only");
+  hipStream_t st = (hipStream_t)stream;
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(split16_ragged_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, descs_dev, n);
+  else hipLaunchKernelGGL(split16_ragged_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, descs_dev, n);
+  return check_launch("lora_amd_split16_ragged");
 }

@@ -130,3 +130,54 @@ def test_linear_fwd16_vs_float64_and_vs_valu(M, K, N, r, p, dt):
     bound = np.abs(n(y0)) + s / (1 - p) * ((np.abs(Xn) @ np.abs(An.T)) @ np.abs(Bn.T))
     close(n(y), want, bound, dt, msg="y")
     close(n(yv), want, bound, dt, msg="y valu")
+
+
+@pytest.mark.parametrize("B,M,C,r", [(3, 320, 320, 16), (1, 1280, 2880, 16), (2, 77, 10240, 16), (2, 2560, 320, 12), (1, 17, 64, 16)])
+def test_rowdot16_planes_vs_float64(B, M, C, r):
+    """cli_svd's skinny products on the matrix cores: out[b] = X[b] F[b] for f32 stacks held as (hi, lo) bf16 planes
+    (lora_amd_split16_ragged) — the planes reproduce X to 2^-17 relative, the product the float64 one within the f32-grade
+    tolerance of the other kernels of this file."""
+    g = torch.Generator().manual_seed(B * 1000 + M + C)
+    x = (torch.randn(B, M, C, generator=g) * 0.1).to(DEV)
+    f = torch.randn(B, C, r, generator=g).to(DEV)
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    _C.split16_ragged([x.view(-1)], [hi.view(-1)], [lo.view(-1)])
+    back = hi.float() + lo.float()
+    assert float((back - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    out = torch.full((B, M, r), 7.0, device=DEV)
+    prog = _C.PlanesProgram(torch.device(DEV), r)
+    h = prog.table([(hi, lo, f, out)])
+    prog.upload()
+    prog.run(h)
+    xn, fn = n(x).astype(np.float64), n(f).astype(np.float64)
+    want = np.einsum("bmc,bcr->bmr", xn, fn)
+    bound = np.einsum("bmc,bcr->bmr", np.abs(xn), np.abs(fn))
+    close(n(out), want, bound, k=3e-5, msg="rowdot16 over planes")
+
+
+def test_svd_iteration_on_planes_matches_the_f32_passes():
+    """topr_svd_ragged with the matrix-core products over (hi, lo) planes (cli_svd.PLANES) against the same iteration on the
+    f32 column-reduction passes, same random sketch: the rank-r products agree far inside the test tolerance of either
+    against the exact SVD (tests/test_gpu_parity_r3.py::test_ragged_svd_of_several_shape_groups_vs_exact_svd runs the
+    default, i.e. the planes)."""
+    from lora_amd import cli_svd as S
+    from tests.test_cli_svd import _planted
+
+    r = 8
+    shapes = [(2, 320, 320), (1, 640, 2880), (2, 1280, 320)]
+    deltas = []
+    for gi, (B, N, K) in enumerate(shapes):
+        tb = [_planted(N, K, r + 4, 2e-3 / (N ** 0.5 + K ** 0.5), 7 * gi + i, "cpu") for i in range(B)]
+        deltas.append(torch.stack([(t - b).to(DEV) for t, b in tb]))
+    res = {}
+    for planes in (True, False):
+        prev, S.PLANES = S.PLANES, planes
+        try:
+            res[planes] = S.topr_svd_ragged([d.clone() for d in deltas], r, generator=torch.Generator(device=DEV).manual_seed(0))
+        finally:
+            S.PLANES = prev
+    for (U1, S1, V1), (U0, S0, V0), d in zip(res[True], res[False], deltas):
+        p1, p0 = (U1 * S1[:, None, :]) @ V1, (U0 * S0[:, None, :]) @ V0
+        assert float((p1 - p0).norm()) <= 5e-5 * float(p0.norm())
+        assert float((S1 - S0).abs().max()) <= 2e-5 * float(S0.max())
