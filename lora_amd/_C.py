@@ -33,7 +33,7 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
-    "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_split16_ragged",
+    "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_split16_ragged", "lora_amd_split16_transpose",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
@@ -132,6 +132,11 @@ class PlanesDesc(C.Structure):
     _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("f", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64),
                 ("C", C.c_int32), ("batch", C.c_int32), ("wps", C.c_int32), ("slabs_per_wg", C.c_int32),
                 ("wg_begin", C.c_int64)]
+
+
+class SplitTDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("thi", C.c_void_p), ("tlo", C.c_void_p),
+                ("batch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32), ("tile_begin", C.c_int64)]
 
 
 class SplitDesc(C.Structure):
@@ -247,6 +252,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_split16_ragged.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_rowdot16_planes_plan.restype = lib.lora_amd_rowdot16_planes.restype = C.c_int
     lib.lora_amd_split16_ragged.restype = C.c_int
+    lib.lora_amd_split16_transpose.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_split16_transpose.restype = C.c_int
     lib.lora_amd_ragged_plan.restype = lib.lora_amd_rowdot_ragged.restype = C.c_int
     lib.lora_amd_colreduce_ragged.restype = lib.lora_amd_sub_ragged.restype = C.c_int
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
@@ -778,6 +785,26 @@ def split16_ragged(srcs, his, los) -> None:
         blocks += (s_.numel() + 4095) // 4096
     dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(his[0].device)
     _check(lib.lora_amd_split16_ragged(dev.data_ptr(), len(srcs), blocks, dtype_code(dt), _stream()), "lora_amd_split16_ragged")
+
+
+def split16_transpose(stacks, his, los, this, tlos) -> None:
+    """Per f32 stack [B, N, K]: the (hi, lo) 16-bit planes [B, N, K] and those of the transposed matrices [B, K, N], ONE launch
+    for all stacks, every stack read once."""
+    lib = require()
+    arr = (SplitTDesc * len(stacks))()
+    tiles, dt = 0, his[0].dtype
+    for d, x, h, l, th, tl in zip(arr, stacks, his, los, this, tlos):
+        B, N, K = x.shape
+        _dev_check(x, h, l, th, tl)
+        if x.dtype != torch.float32 or any(t.dtype != dt for t in (h, l, th, tl)) or N % 8 or K % 8 \
+                or tuple(h.shape) != (B, N, K) or tuple(l.shape) != (B, N, K) or tuple(th.shape) != (B, K, N) \
+                or tuple(tl.shape) != (B, K, N) or not all(t.is_contiguous() for t in (x, h, l, th, tl)):
+            raise ValueError("split16_transpose: contiguous f32 [B, N, K] (N, K multiples of 8) and matching 16-bit planes expected")
+        d.src, d.hi, d.lo, d.thi, d.tlo = x.data_ptr(), h.data_ptr(), l.data_ptr(), th.data_ptr(), tl.data_ptr()
+        d.batch, d.N, d.K, d.tile_begin = B, N, K, tiles
+        tiles += B * (-(-N // 64)) * (-(-K // 64))
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(his[0].device)
+    _check(lib.lora_amd_split16_transpose(dev.data_ptr(), len(stacks), tiles, dtype_code(dt), _stream()), "lora_amd_split16_transpose")
 
 
 def colreduce_workspace_floats(M: int, K: int, r: int) -> int:

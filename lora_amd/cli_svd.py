@@ -180,7 +180,9 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
         if not group_supported(N, K, rank, oversample) or _sketch_width(rank, oversample, N, K) != l:
             raise ValueError(f"topr_svd_ragged: shape {N}x{K} rank {rank} is outside the batched device path")
     nb = sum(B for B, _, _ in dims)
-    delta_t = [d.transpose(1, 2).contiguous() for d in deltas]      # second resident layout of the residuals
+    planes = PLANES and l == 16 and all(N % 32 == 0 and K % 32 == 0 for _, N, K in dims)
+    # second resident layout of the residuals (f32 passes only: the planes of dW^T come out of the split launch)
+    delta_t = None if planes else [d.transpose(1, 2).contiguous() for d in deltas]
     yshape = [(B, N, l) for B, N, K in dims]
     zshape = [(B, K, l) for B, N, K in dims]
     _ya, Ya = _flat_stacks(yshape, dev)
@@ -207,20 +209,16 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
     prog = _C.RaggedProgram(dev)
     cr = lambda xs, fs, outs: prog.table(_C.RAGGED_COLREDUCE, l, list(zip(xs, fs, outs, ws)))  # noqa: E731
     rd = lambda xs, fs, outs, r=l: prog.table(_C.RAGGED_ROWDOT, r, [(x, f, o_, None) for x, f, o_ in zip(xs, fs, outs)])  # noqa: E731
-    planes = PLANES and l == 16 and all(N % 32 == 0 and K % 32 == 0 for _, N, K in dims)
     if planes:
-        # dW and dW^T as (hi, lo) bf16 planes (the bytes of the f32 stacks, split by ONE launch); every product with them
-        # is then a row product on the matrix cores: Y = dW F streams the planes of dW, Z = dW^T F those of dW^T
-        def planes_of(stacks):
-            hs, ls = [], []
-            for st in stacks:
-                hs.append(torch.empty(st.shape, dtype=torch.bfloat16, device=dev))
-                ls.append(torch.empty(st.shape, dtype=torch.bfloat16, device=dev))
-            return hs, ls
-        dh, dl = planes_of(deltas)
-        th, tl = planes_of(delta_t)
-        _C.split16_ragged([x.view(-1) for x in list(deltas) + list(delta_t)], [x.view(-1) for x in dh + th],
-                          [x.view(-1) for x in dl + tl])
+        # dW and dW^T as (hi, lo) bf16 planes — the bytes of two f32 stacks, all four written by ONE launch that reads dW once
+        # (lora_amd_split16_transpose); every product with them is then a row product on the matrix cores: Y = dW F streams
+        # the planes of dW, Z = dW^T F those of dW^T
+        def planes_of(shapes_):
+            return ([torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes_],
+                    [torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes_])
+        dh, dl = planes_of([(B, N, K) for B, N, K in dims])
+        th, tl = planes_of([(B, K, N) for B, N, K in dims])
+        _C.split16_transpose([d.contiguous() for d in deltas], dh, dl, th, tl)
         pprog = _C.PlanesProgram(dev, l)
         p_sketch = pprog.table(list(zip(dh, dl, Zc, Ya)))     # Y = dW Omega
         p_fwd = pprog.table(list(zip(th, tl, Yb, Za)))        # Z = dW^T Q

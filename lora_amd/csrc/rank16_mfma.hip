@@ -495,6 +495,70 @@ __global__ __launch_bounds__(256) void split16_ragged_kernel(const lora_amd_spli
   }
 }
 
+// f32 stack [B][N][K] -> the (hi, lo) planes of every matrix AND of its transpose ([B][K][N]) from ONE read: 64 x 64 tiles,
+// the transposed planes through an LDS image of the tile (2-byte column gathers, 16-byte stores along n — the in-step merge's
+// way of writing W_eff^T).  Replaces a torch transpose copy per shape group plus a separate split.
+constexpr int kSpT = 64, kSpPitch = kSpT * 2 + 4;   // bytes per image row
+template <class E>
+__global__ __launch_bounds__(256) void split16_transpose_kernel(const lora_amd_splitt_desc *__restrict__ descs, int n) {
+  using S = typename E::storage;
+  __shared__ __attribute__((aligned(16))) unsigned char s_hi[kSpT * kSpPitch], s_lo[kSpT * kSpPitch];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const lora_amd_splitt_desc d = descs[lo];
+  const int tiles_k = (d.K + kSpT - 1) / kSpT, tiles_n = (d.N + kSpT - 1) / kSpT;
+  int64_t t = (int64_t)blockIdx.x - d.tile_begin;
+  const int64_t b = t / ((int64_t)tiles_k * tiles_n);
+  t -= b * (int64_t)tiles_k * tiles_n;
+  const int tn = (int)(t / tiles_k), tk = (int)(t - (int64_t)tn * tiles_k);
+  const int n0 = tn * kSpT, k0 = tk * kSpT;
+  const int tid = threadIdx.x;
+  const float *src = d.src + b * (int64_t)d.N * d.K;
+  S *ph = reinterpret_cast<S *>(d.hi) + b * (int64_t)d.N * d.K, *pl = reinterpret_cast<S *>(d.lo) + b * (int64_t)d.N * d.K;
+  S *th = reinterpret_cast<S *>(d.thi) + b * (int64_t)d.N * d.K, *tl = reinterpret_cast<S *>(d.tlo) + b * (int64_t)d.N * d.K;
+  // rows of the tile: 8 chunks of 8 columns per row, 32 rows per sweep
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rl = u * 32 + (tid >> 3), c8 = tid & 7;
+    const int row = n0 + rl, col = k0 + c8 * 8;
+    mu32x4 vh = r16_zero(), vl = r16_zero();
+    if (row < d.N && col < d.K) {   // K % 8 == 0
+      const float4 a = gl_ld4(src + (int64_t)row * d.K + col), bq = gl_ld4(src + (int64_t)row * d.K + col + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+      split_hi_lo<E>(v, vh, vl);
+      *gl(reinterpret_cast<mu32x4 *>(ph + (int64_t)row * d.K + col)) = vh;
+      *gl(reinterpret_cast<mu32x4 *>(pl + (int64_t)row * d.K + col)) = vl;
+    }
+    uint32_t *ih = reinterpret_cast<uint32_t *>(s_hi + rl * kSpPitch + c8 * 16), *il = reinterpret_cast<uint32_t *>(s_lo + rl * kSpPitch + c8 * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ih[i] = vh[i]; il[i] = vl[i]; }
+  }
+  __syncthreads();
+  // columns of the tile: task = (column k, chunk of 8 rows): 64 x 8 tasks, k fastest in groups of 4
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int task = u * 256 + tid;
+    const int kq = task >> 5, rem = task & 31;
+    const int k = kq * 4 + (rem & 3), ch = rem >> 2;
+    const int col = k0 + k, row0 = n0 + ch * 8;
+    if (col >= d.K || row0 >= d.N) continue;   // N % 8 == 0
+    const unsigned char *sh = s_hi + (ch * 8) * kSpPitch + k * 2, *sl = s_lo + (ch * 8) * kSpPitch + k * 2;
+    mu32x4 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      oh[i] = (uint32_t)*reinterpret_cast<const unsigned short *>(sh + (2 * i) * kSpPitch) |
+              ((uint32_t)*reinterpret_cast<const unsigned short *>(sh + (2 * i + 1) * kSpPitch) << 16);
+      ol[i] = (uint32_t)*reinterpret_cast<const unsigned short *>(sl + (2 * i) * kSpPitch) |
+              ((uint32_t)*reinterpret_cast<const unsigned short *>(sl + (2 * i + 1) * kSpPitch) << 16);
+    }
+    *gl(reinterpret_cast<mu32x4 *>(th + (int64_t)col * d.N + row0)) = oh;
+    *gl(reinterpret_cast<mu32x4 *>(tl + (int64_t)col * d.N + row0)) = ol;
+  }
+}
+
 static bool r16_common_ok(int act_dtype, int fdt, int r) {
   return g_r16_mfma && (act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16) && fdt == LORA_AMD_F32 && r > 8 && r <= 16;
 }
@@ -615,4 +679,14 @@ extern "C" int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int
   if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(split16_ragged_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, descs_dev, n);
   else hipLaunchKernelGGL(split16_ragged_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, descs_dev, n);
   return check_launch("lora_amd_split16_ragged");
+}
+
+extern "C" int lora_amd_split16_transpose(const lora_amd_splitt_desc *descs_dev, int32_t n, int64_t tiles, int32_t plane_dtype,
+                                          void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && tiles >= 1 && tiles < (1ll << 31), LORA_AMD_EINVAL, "split16_transpose: bad argument");
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "split16_transpose: 16-bit planes only");
+  hipStream_t st = (hipStream_t)stream;
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(split16_transpose_kernel<f16_t>, dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
+  else hipLaunchKernelGGL(split16_transpose_kernel<bf16_t>, dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
+  return check_launch("lora_amd_split16_transpose");
 }

@@ -145,6 +145,13 @@ def test_rowdot16_planes_vs_float64(B, M, C, r):
     back = hi.float() + lo.float()
     assert float((back - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
     assert torch.equal(hi, x.to(torch.bfloat16))
+    # the same planes, and those of the transposed matrices, from the one-read launch of the SVD path
+    if M % 8 == 0:
+        h2, l2 = torch.empty_like(hi), torch.empty_like(lo)
+        th, tl = (torch.empty(B, C, M, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        _C.split16_transpose([x], [h2], [l2], [th], [tl])
+        assert torch.equal(h2, hi) and torch.equal(l2, lo)
+        assert torch.equal(th, hi.transpose(1, 2)) and torch.equal(tl, lo.transpose(1, 2))
     out = torch.full((B, M, r), 7.0, device=DEV)
     prog = _C.PlanesProgram(torch.device(DEV), r)
     h = prog.table([(hi, lo, f, out)])
