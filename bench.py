@@ -575,14 +575,18 @@ def svd_bench(args) -> dict:
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 "
                                   "sites (31 shape groups, 730 M weight elements), randomized subspace iteration n_iter=4, "
-                                  "every step ONE ragged launch over all shape groups (lora_amd_colreduce_ragged / "
-                                  "rowdot_ragged descriptor tables), on-device CholeskyQR3",
+                                  "every step ONE ragged launch over all shape groups; the products with dW / dW^T on the "
+                                  "matrix cores over (hi, lo) bf16 planes of the residuals (lora_amd_split16_transpose + "
+                                  "lora_amd_rowdot16_planes), on-device CholeskyQR3",
                       "sites": n_sites, "groups": len(groups), "weight_elements": elems},
-           "roofline": {"kernel": "lora_amd::rowdot_kernel / colreduce_stage1_kernel <f32> (batched residual passes)",
+           "roofline": {"kernel": "lora_amd::rowdot16_planes_kernel<bf16> (the ten passes over the residuals: 812 us each = 3.6 TB/s "
+                                  "= 0.45 of the roof in the kernel trace, profiles/r04_svd_kernel_trace_summary_planes_first.txt) "
+                                  "+ everything else of the step",
                         "bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                         "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes,
-                        "note": "whole-step figure: includes the small dense steps (Gram, Cholesky, final SVD) and launch gaps"}}
+                        "note": "WHOLE-STEP figure: the ~2000 small launches of a step (Gram, Cholesky, the 16 x 16 SVDs, quantile "
+                                "sorts, sign fixes) cost twice what the ten passes over the residuals do"}}
     if not args.no_cpu_baseline:
         import subprocess
 
