@@ -133,10 +133,25 @@ def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 
     return U[0], S[0], Vh[0]
 
 
+def _quantile_rows(x: torch.Tensor, q: float) -> torch.Tensor:
+    """``torch.quantile(x, q, dim=1)`` (linear interpolation) bit for bit, from the top (1 - q) n order statistics only: for
+    the clamp's q = 0.99 a top-k of 1 % of a row instead of a full segmented sort of it (the sorts were ~3.5 ms of a 30 ms
+    distillation of 224 sites).  Same rank arithmetic as ATen's quantile: ranks and weights in the input dtype."""
+    n = x.shape[1]
+    if not x.is_cuda or not (0.5 <= q <= 1.0) or n < 64:
+        return torch.quantile(x, q, dim=1)
+    ranks = torch.tensor(q, dtype=x.dtype) * (n - 1)
+    below = ranks.floor()
+    lo = int(below.item())
+    hi = min(lo + 1, n - 1)
+    vals = torch.topk(x, n - lo, dim=1, largest=True, sorted=True).values   # descending: column j = order statistic n - 1 - j
+    return torch.lerp(vals[:, n - 1 - lo], vals[:, n - 1 - hi], float((ranks - below).item()))   # an exact f32 value
+
+
 def _clamp_pairs(U: torch.Tensor, Vh: torch.Tensor, clamp_quantile: float):
     """ref :39-47 for a stack: per site, clamp both factors at the quantile of their joint (signed) values."""
     dist = torch.cat([U.flatten(1), Vh.flatten(1)], dim=1)
-    hi = torch.quantile(dist, clamp_quantile, dim=1)
+    hi = _quantile_rows(dist, clamp_quantile)
     return torch.minimum(torch.maximum(U, -hi[:, None, None]), hi[:, None, None]), \
         torch.minimum(torch.maximum(Vh, -hi[:, None, None]), hi[:, None, None])
 

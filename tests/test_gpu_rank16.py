@@ -188,3 +188,14 @@ def test_svd_iteration_on_planes_matches_the_f32_passes():
         p1, p0 = (U1 * S1[:, None, :]) @ V1, (U0 * S0[:, None, :]) @ V0
         assert float((p1 - p0).norm()) <= 5e-5 * float(p0.norm())
         assert float((S1 - S0).abs().max()) <= 2e-5 * float(S0.max())
+
+
+def test_clamp_quantile_from_the_top_order_statistics_equals_torch_quantile():
+    """cli_svd._quantile_rows (ref cli_svd.py:39-47's torch.quantile of the joint factor values) on the device: bit for bit."""
+    from lora_amd import cli_svd as S
+
+    g = torch.Generator().manual_seed(4)
+    for B, nn_ in ((3, 5120), (2, 102400), (1, 99999), (4, 640), (2, 63)):
+        x = torch.randn(B, nn_, generator=g).to(DEV)
+        for q in (0.99, 0.9, 1.0, 0.5):
+            assert torch.equal(S._quantile_rows(x, q), torch.quantile(x, q, dim=1)), (B, nn_, q)
