@@ -17,7 +17,10 @@ each step of the iteration is ONE launch for the whole stack —
                              Q = Y L^{-T} (rowdot_batched); shift on the first pass, two clean passes after it
 
 — all HBM-streaming passes over dW with a skinny factor (``csrc/linear.hip``), plus one batched l x l SVD (torch) of
-the triangular-factor-sized core at the end.  With ``n_iter`` power iterations the captured subspace error decays like
+the triangular-factor-sized core at the end.  Model-level entry (``distill_model`` / ``topr_svd_ragged``): every step is ONE
+launch over all shape groups, and with a 16-wide sketch the products with dW / dW^T run on the matrix cores over (hi, lo)
+bf16 planes of the residuals (``PLANES``; ``csrc/rank16_mfma.hip``: ``lora_amd_split16_transpose`` +
+``lora_amd_rowdot16_planes``, 3.6 TB/s per pass).  With ``n_iter`` power iterations the captured subspace error decays like
 (s_{l+1}/s_r)^(2 n_iter + 1); the defaults reproduce ``up @ down`` of the reference to ~1e-4 relative on
 distillation-like spectra.  The signs of singular vectors are arbitrary (LAPACK's are too, and the reference's clamp
 threshold - a quantile of SIGNED entries - inherits that arbitrariness); the device path fixes them by making the

@@ -23,6 +23,11 @@
 //                   then the two pieces go through the wave's own 32 x 32 LDS tile and come back column-major through
 //                   ds_read_b64_tr_b16 for phase 2 (A = G^T, B = T); the LDS queue of a wave is in order, so write -> transpose
 //                   read -> next write needs no wait beyond the data dependence.
+//
+// The same row product also serves cli_svd (lora_diffusion/cli_svd.py:24-92 as restated in lora_amd/cli_svd.py): the residuals
+// dW = W_tuned - W_base are f32, which has no full-rate matrix-core path on gfx950, so they are held as TWO bf16 planes
+// (dW = hi + lo to ~16 mantissa bits: the bytes of f32) written by split16_transpose_kernel (one read of dW -> the planes of
+// dW and of dW^T), and rowdot16_planes_kernel computes out = X F as hi F_hi + hi F_lo + lo F_hi: 3.6 TB/s per pass.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
