@@ -268,17 +268,16 @@ typedef struct lora_amd_split_desc {
   int64_t n, begin;
 } lora_amd_split_desc;
 int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int32_t n, int64_t blocks, int32_t plane_dtype, void *stream);
-/* The bf16 planes of a stack [batch][N][K] AND of its transpose [batch][K][N] from one read (N % 8 == 0, K % 8 == 0; 64 x 64
- * tiles; `tile_begin` = running count of batch * ceil(N / 64) * ceil(K / 64), filled by the caller).  src_b != NULL: the
- * planes of the residual src - src_b (both of in_dtype, any of f32 / f16 / bf16; cli_svd.py:30-32), formed in f32 on the fly. */
+/* The planes of a stack [batch][N][K] AND of its transpose [batch][K][N] from one read (N % 8 == 0, K % 8 == 0; 64 x 64
+ * tiles; `tile_begin` = running count of batch * ceil(N / 64) * ceil(K / 64), filled by the caller). */
 typedef struct lora_amd_splitt_desc {
-  const void *src, *src_b;
+  const float *src;
   void *hi, *lo, *thi, *tlo;
   int32_t batch, N, K, reserved;
   int64_t tile_begin;
 } lora_amd_splitt_desc;
-int lora_amd_split16_transpose(const lora_amd_splitt_desc *descs_dev, int32_t n, int64_t tiles, int32_t in_dtype,
-                               int32_t plane_dtype, void *stream);
+int lora_amd_split16_transpose(const lora_amd_splitt_desc *descs_dev, int32_t n, int64_t tiles, int32_t plane_dtype,
+                               void *stream);
 typedef struct lora_amd_sub_desc {
   const void *a, *b;
   float *out;

@@ -135,9 +135,8 @@ class PlanesDesc(C.Structure):
 
 
 class SplitTDesc(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("src_b", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("thi", C.c_void_p),
-                ("tlo", C.c_void_p), ("batch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32),
-                ("tile_begin", C.c_int64)]
+    _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("thi", C.c_void_p), ("tlo", C.c_void_p),
+                ("batch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32), ("tile_begin", C.c_int64)]
 
 
 class SplitDesc(C.Structure):
@@ -253,7 +252,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_split16_ragged.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_rowdot16_planes_plan.restype = lib.lora_amd_rowdot16_planes.restype = C.c_int
     lib.lora_amd_split16_ragged.restype = C.c_int
-    lib.lora_amd_split16_transpose.argtypes = [vp, i32, i64, i32, i32, vp]
+    lib.lora_amd_split16_transpose.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_split16_transpose.restype = C.c_int
     lib.lora_amd_ragged_plan.restype = lib.lora_amd_rowdot_ragged.restype = C.c_int
     lib.lora_amd_colreduce_ragged.restype = lib.lora_amd_sub_ragged.restype = C.c_int
@@ -788,29 +787,24 @@ def split16_ragged(srcs, his, los) -> None:
     _check(lib.lora_amd_split16_ragged(dev.data_ptr(), len(srcs), blocks, dtype_code(dt), _stream()), "lora_amd_split16_ragged")
 
 
-def split16_transpose(stacks, his, los, this, tlos, bases=None) -> None:
-    """Per stack [B, N, K]: the (hi, lo) bf16 planes [B, N, K] and those of the transposed matrices [B, K, N], ONE launch for
-    all stacks, every stack read once.  ``bases`` (same shapes and dtype as ``stacks``, any of f32 / f16 / bf16): the planes
-    of the residuals ``stacks[i] - bases[i]``, formed in f32 on the fly; without it the stacks are f32."""
+def split16_transpose(stacks, his, los, this, tlos) -> None:
+    """Per f32 stack [B, N, K]: the (hi, lo) 16-bit planes [B, N, K] and those of the transposed matrices [B, K, N], ONE launch
+    for all stacks, every stack read once."""
     lib = require()
     arr = (SplitTDesc * len(stacks))()
-    tiles, dt, idt = 0, his[0].dtype, stacks[0].dtype
-    for i, (d, x, h, l, th, tl) in enumerate(zip(arr, stacks, his, los, this, tlos)):
+    tiles, dt = 0, his[0].dtype
+    for d, x, h, l, th, tl in zip(arr, stacks, his, los, this, tlos):
         B, N, K = x.shape
-        b = bases[i] if bases is not None else None
-        _dev_check(x, h, l, th, tl, b)
-        if x.dtype != idt or (b is None and idt != torch.float32) or any(t.dtype != dt for t in (h, l, th, tl)) or N % 8 or K % 8 \
+        _dev_check(x, h, l, th, tl)
+        if x.dtype != torch.float32 or any(t.dtype != dt for t in (h, l, th, tl)) or N % 8 or K % 8 \
                 or tuple(h.shape) != (B, N, K) or tuple(l.shape) != (B, N, K) or tuple(th.shape) != (B, K, N) \
-                or tuple(tl.shape) != (B, K, N) or not all(t.is_contiguous() for t in (x, h, l, th, tl)) \
-                or (b is not None and (b.dtype != idt or tuple(b.shape) != (B, N, K) or not b.is_contiguous())):
-            raise ValueError("split16_transpose: contiguous [B, N, K] inputs (N, K multiples of 8) and matching bf16 planes expected")
-        d.src, d.src_b = x.data_ptr(), (b.data_ptr() if b is not None else None)
-        d.hi, d.lo, d.thi, d.tlo = h.data_ptr(), l.data_ptr(), th.data_ptr(), tl.data_ptr()
+                or tuple(tl.shape) != (B, K, N) or not all(t.is_contiguous() for t in (x, h, l, th, tl)):
+            raise ValueError("split16_transpose: contiguous f32 [B, N, K] (N, K multiples of 8) and matching 16-bit planes expected")
+        d.src, d.hi, d.lo, d.thi, d.tlo = x.data_ptr(), h.data_ptr(), l.data_ptr(), th.data_ptr(), tl.data_ptr()
         d.batch, d.N, d.K, d.tile_begin = B, N, K, tiles
         tiles += B * (-(-N // 64)) * (-(-K // 64))
     dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(his[0].device)
-    _check(lib.lora_amd_split16_transpose(dev.data_ptr(), len(stacks), tiles, dtype_code(idt), dtype_code(dt), _stream()),
-           "lora_amd_split16_transpose")
+    _check(lib.lora_amd_split16_transpose(dev.data_ptr(), len(stacks), tiles, dtype_code(dt), _stream()), "lora_amd_split16_transpose")
 
 
 def colreduce_workspace_floats(M: int, K: int, r: int) -> int:

@@ -184,32 +184,21 @@ def _flat_stacks(shapes, device):
 
 
 def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
-                    generator: Optional[torch.Generator] = None, pairs=None):
+                    generator: Optional[torch.Generator] = None):
     """``topr_svd_batched`` for a LIST of stacks of different shapes ([B_g, N_g, K_g] f32, contiguous) run in lock-step:
     every step of the iteration is ONE launch (pair) for the whole model — ``lora_amd_colreduce_ragged`` /
     ``lora_amd_rowdot_ragged`` over a descriptor table with one entry per shape group, ``chol_inverse_batched`` and the
     l x l core SVD over the concatenation of all groups.  SD1.5 extended (224 sites, 31 shapes): ~110 launches instead
-    of ~3100.  Returns per group (U [B,N,r], S [B,r], Vh [B,r,K]) with the deterministic sign rule of the batched path.
-
-    ``pairs`` (instead of ``deltas = None``): per group (tuned weights, base weights) — lists of same-shape, same-dtype
-    contiguous tensors whose residual tuned - base (flattened from dim 1, cli_svd.py:30-32, :57-60) is the matrix to
-    factor.  On the planes path the residuals are then never materialised in f32: the split launch forms them on the fly."""
+    of ~3100.  Returns per group (U [B,N,r], S [B,r], Vh [B,r,K]) with the deterministic sign rule of the batched path."""
     _C.require()
-    if deltas is None:
-        dev = pairs[0][0][0].device
-        dims = [(len(ts), ts[0].shape[0], ts[0].numel() // ts[0].shape[0]) for ts, _ in pairs]
-    else:
-        dev = deltas[0].device
-        dims = [tuple(d.shape) for d in deltas]
+    dev = deltas[0].device
+    dims = [tuple(d.shape) for d in deltas]
     l = _sketch_width(rank, oversample, dims[0][1], dims[0][2])
     for (B, N, K) in dims:
         if not group_supported(N, K, rank, oversample) or _sketch_width(rank, oversample, N, K) != l:
             raise ValueError(f"topr_svd_ragged: shape {N}x{K} rank {rank} is outside the batched device path")
     nb = sum(B for B, _, _ in dims)
     planes = PLANES and l == 16 and all(N % 32 == 0 and K % 32 == 0 for _, N, K in dims)
-    if deltas is None and not planes:   # the f32 passes want the residuals themselves: one launch forms them
-        _, deltas = _flat_stacks(dims, dev)
-        _C.sub_ragged([(t, b) for ts, bs in pairs for t, b in zip(ts, bs)], [d[i] for d, (ts, _) in zip(deltas, pairs) for i in range(len(ts))])
     # second resident layout of the residuals (f32 passes only: the planes of dW^T come out of the split launch)
     delta_t = None if planes else [d.transpose(1, 2).contiguous() for d in deltas]
     yshape = [(B, N, l) for B, N, K in dims]
@@ -247,15 +236,7 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
                     [torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes_])
         dh, dl = planes_of([(B, N, K) for B, N, K in dims])
         th, tl = planes_of([(B, K, N) for B, N, K in dims])
-        if deltas is not None:
-            _C.split16_transpose([d.contiguous() for d in deltas], dh, dl, th, tl)
-        else:   # one descriptor per site: tuned - base formed in f32 inside the launch, straight into the four planes
-            xs, bs_, hs, ls, ths, tls = [], [], [], [], [], []
-            for (ts, bs), (B, N, K), h_, l_, th_, tl_ in zip(pairs, dims, dh, dl, th, tl):
-                for i, (t, b) in enumerate(zip(ts, bs)):
-                    xs.append(t.reshape(1, N, K)); bs_.append(b.reshape(1, N, K))
-                    hs.append(h_[i:i + 1]); ls.append(l_[i:i + 1]); ths.append(th_[i:i + 1]); tls.append(tl_[i:i + 1])
-            _C.split16_transpose(xs, hs, ls, ths, tls, bases=bs_)
+        _C.split16_transpose([d.contiguous() for d in deltas], dh, dl, th, tl)
         pprog = _C.PlanesProgram(dev, l)
         p_sketch = pprog.table(list(zip(dh, dl, Zc, Ya)))     # Y = dW Omega
         p_fwd = pprog.table(list(zip(th, tl, Yb, Za)))        # Z = dW^T Q
@@ -331,9 +312,15 @@ def distill_model(groups, rank: int, clamp_quantile: float = 0.99, generator: Op
     for ent in fast:
         by_dtype.setdefault(groups[ent[0]][0][0].dtype, []).append(ent)
     for dt, ents in by_dtype.items():
-        # every residual W_tuned - W_base is formed inside topr_svd_ragged: by the split launch of the planes path (never
-        # written in f32) or by one lora_amd_sub_ragged launch for the f32 passes
-        trip = topr_svd_ragged(None, rank, generator=generator, pairs=[groups[gi] for gi, _, _, _ in ents], **svd_kw)
+        dev = groups[ents[0][0]][0][0].device
+        _, deltas = _flat_stacks([(B, N, K) for _, B, N, K in ents], dev)
+        pairs, outs = [], []
+        for (gi, B, N, K), d in zip(ents, deltas):
+            for i, (t, b) in enumerate(zip(*groups[gi])):
+                pairs.append((t, b))
+                outs.append(d[i])
+        _C.sub_ragged(pairs, outs)                                 # every residual W_tuned - W_base: one launch
+        trip = topr_svd_ragged(deltas, rank, generator=generator, **svd_kw)
         for (gi, _, _, _), (U, S, Vh) in zip(ents, trip):
             results[gi] = _clamp_pairs(U * S[:, None, :], Vh, clamp_quantile)
     return results

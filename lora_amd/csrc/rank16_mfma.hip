@@ -504,20 +504,7 @@ __global__ __launch_bounds__(256) void split16_ragged_kernel(const lora_amd_spli
 // the transposed planes through an LDS image of the tile (2-byte column gathers, 16-byte stores along n — the in-step merge's
 // way of writing W_eff^T).  Replaces a torch transpose copy per shape group plus a separate split.
 constexpr int kSpT = 64, kSpPitch = kSpT * 2 + 4;   // bytes per image row
-// EI = element type of the inputs: f32 stacks (src_b = NULL), or ANY of f32 / f16 / bf16 with src_b given — then the
-// residual src - src_b (cli_svd.py:30-32) is formed on the fly in f32 and never written.
-template <class EI>
-__device__ __forceinline__ void sp_load8(const void *p, int64_t i, float (&v)[8]) {
-  if constexpr (EI::kCode == LORA_AMD_F32) {
-    const float *f = reinterpret_cast<const float *>(p) + i;
-    const float4 a = gl_ld4(f), b = gl_ld4(f + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    load8<EI>(reinterpret_cast<const typename EI::storage *>(p) + i, v);
-  }
-}
-
-template <class E, class EI>
+template <class E>
 __global__ __launch_bounds__(256) void split16_transpose_kernel(const lora_amd_splitt_desc *__restrict__ descs, int n) {
   using S = typename E::storage;
   __shared__ __attribute__((aligned(16))) unsigned char s_hi[kSpT * kSpPitch], s_lo[kSpT * kSpPitch];
@@ -534,7 +521,7 @@ __global__ __launch_bounds__(256) void split16_transpose_kernel(const lora_amd_s
   const int tn = (int)(t / tiles_k), tk = (int)(t - (int64_t)tn * tiles_k);
   const int n0 = tn * kSpT, k0 = tk * kSpT;
   const int tid = threadIdx.x;
-  const int64_t moff = b * (int64_t)d.N * d.K;
+  const float *src = d.src + b * (int64_t)d.N * d.K;
   S *ph = reinterpret_cast<S *>(d.hi) + b * (int64_t)d.N * d.K, *pl = reinterpret_cast<S *>(d.lo) + b * (int64_t)d.N * d.K;
   S *th = reinterpret_cast<S *>(d.thi) + b * (int64_t)d.N * d.K, *tl = reinterpret_cast<S *>(d.tlo) + b * (int64_t)d.N * d.K;
   // rows of the tile: 8 chunks of 8 columns per row, 32 rows per sweep
@@ -544,14 +531,8 @@ __global__ __launch_bounds__(256) void split16_transpose_kernel(const lora_amd_s
     const int row = n0 + rl, col = k0 + c8 * 8;
     mu32x4 vh = r16_zero(), vl = r16_zero();
     if (row < d.N && col < d.K) {   // K % 8 == 0
-      float v[8];
-      sp_load8<EI>(d.src, moff + (int64_t)row * d.K + col, v);
-      if (d.src_b != nullptr) {
-        float w[8];
-        sp_load8<EI>(d.src_b, moff + (int64_t)row * d.K + col, w);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] -= w[e];
-      }
+      const float4 a = gl_ld4(src + (int64_t)row * d.K + col), bq = gl_ld4(src + (int64_t)row * d.K + col + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
       split_hi_lo<E>(v, vh, vl);
       *gl(reinterpret_cast<mu32x4 *>(ph + (int64_t)row * d.K + col)) = vh;
       *gl(reinterpret_cast<mu32x4 *>(pl + (int64_t)row * d.K + col)) = vl;
@@ -705,14 +686,12 @@ extern "C" int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int
   return check_launch("lora_amd_split16_ragged");
 }
 
-extern "C" int lora_amd_split16_transpose(const lora_amd_splitt_desc *descs_dev, int32_t n, int64_t tiles, int32_t in_dtype,
-                                          int32_t plane_dtype, void *stream) {
+extern "C" int lora_amd_split16_transpose(const lora_amd_splitt_desc *descs_dev, int32_t n, int64_t tiles, int32_t plane_dtype,
+                                          void *stream) {
   LORA_AMD_CHECK(descs_dev && n >= 1 && tiles >= 1 && tiles < (1ll << 31), LORA_AMD_EINVAL, "split16_transpose: bad argument");
-  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL, "split16_transpose: bf16 planes only");
-  LORA_AMD_CHECK(dtype_ok(in_dtype), LORA_AMD_EINVAL, "split16_transpose: bad input dtype %d", in_dtype);
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "split16_transpose: 16-bit planes only");
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == LORA_AMD_F32) hipLaunchKernelGGL((split16_transpose_kernel<bf16_t, f32_t>), dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
-  else if (in_dtype == LORA_AMD_F16) hipLaunchKernelGGL((split16_transpose_kernel<bf16_t, f16_t>), dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
-  else hipLaunchKernelGGL((split16_transpose_kernel<bf16_t, bf16_t>), dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(split16_transpose_kernel<f16_t>, dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
+  else hipLaunchKernelGGL(split16_transpose_kernel<bf16_t>, dim3((unsigned)tiles), dim3(256), 0, st, descs_dev, n);
   return check_launch("lora_amd_split16_transpose");
 }

@@ -2,7 +2,7 @@
 # Round 4, last GPU call: cli_svd's big products on the matrix cores over (hi, lo) planes — parity and configs[4] timing
 set -u
 OUT=gpurun_out
-TAG=r04zz
+TAG=r04z
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/../.."
