@@ -78,8 +78,7 @@ def merge_roofline(unet, iters=30):
     avg_s = sum(a.elapsed_time(b) for a, b in evs) / (iters * inner) * 1e-3
     ach = plan.bytes_algorithmic / avg_s / 1e9
     traffic, traffic_src = None, None
-    pmc = next((p for p in (os.path.join(REPO, "profiles", f) for f in ("r03_merge_pmc.json", "r02_merge_pmc.json", "r01_merge_pmc.json"))
-                if os.path.exists(p)), "")  # offline rocprofv3 --pmc passes (scripts/profile_bench.sh)
+    pmc = _newest_profile("merge_pmc.json")  # offline rocprofv3 --pmc passes (scripts/r0N_profiles.sh), newest round first
     if os.path.exists(pmc):
         try:
             m = json.load(open(pmc))["merge_per_launch"]
@@ -92,6 +91,14 @@ def merge_roofline(unet, iters=30):
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": plan.bytes_algorithmic, "avg_launch_us": round(avg_s * 1e6, 2),
             "launches_timed": iters * inner}
+
+
+def _newest_profile(suffix: str) -> str:
+    """profiles/rNN_<suffix> of the highest round that has one ('' if none)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else ""
 
 
 HBM_PEAK, MFMA_BF16_PEAK = 8.0e12, 2.5e15  # MI355X_MICROARCH.md: HBM3E spec, dense bf16 MFMA
@@ -399,6 +406,7 @@ def adapter_path_profile(step_fn, state) -> dict:
            "gpu_ms_per_step": round(ours_us / 1e3, 3), "algorithmic_bytes_per_step": int(byts),
            "frac": round(byts / (ours_us * 1e-6) / HBM_PEAK, 4) if ours_us else None, "bound": "hbm",
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": round(byts / (ours_us * 1e-6) / 1e9, 1) if ours_us else None,
+           "library_gemm_ms": round(merged_gemm_us / 1e3, 3), "library_gemm_calls": merged_gemm_calls,
            "hostops_gpu_ms_per_step": round(host_us / 1e3, 3), "all_kernels_gpu_ms_per_step": round(total_us / 1e3, 3),
            "sites_fwd_frozen_product_in_our_launch": own_sites, "sites_fwd_library_gemm_on_merged_weight": merged_sites,
            "sites_fwd_total": sum(1 for ph, *_ in log_ if ph == "fwd"),
@@ -435,6 +443,7 @@ def swap_in_aten_adapters(model) -> int:
 
 
 SECONDARY = [  # (tag, extra argv, env, timeout s): driver-observed lines for the other BASELINE geometries, short runs
+    ("frozen_only", ["--adapters", "none"], {}, 150),
     ("host_options_off", ["--channels-last", "0", "--head-pad", "0", "--conv-find", "0"], {"LORA_AMD_HOSTOPS": "0"}, 150),
     ("aten_adapters", ["--adapters", "aten"], {}, 150),
     ("fused_per_site_kernels (--merged 0)", ["--merged", "0"], {}, 150),
@@ -468,13 +477,21 @@ def run_secondaries(budget_s: float, steps: int) -> list:
         if "--svd" not in extra:
             argv += ["--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
         t0 = time.perf_counter()
+        dtag = "sec%d" % len(out)
         try:
-            r = subprocess.run(argv, capture_output=True, text=True, timeout=min(tmo, left), env={**os.environ, **env})
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=min(tmo, left),
+                               env={**os.environ, **env, "LORA_AMD_BENCH_DETAIL_TAG": dtag})
             d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             rec.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
                         "workload": d["config"].get("workload"), "wall_s": round(time.perf_counter() - t0, 1),
-                        "execution": d["config"].get("execution"), "attention_kernels": d["config"].get("attention_kernels"),
-                        "merged_sites": (d["config"].get("adapter_options", {}).get("merged_weights") or {}).get("sites")})
+                        "execution": d["config"].get("execution")})
+            try:  # the child's detail record (attention picks, merged-site count): detail only, never the stdout line
+                with open(os.path.join(REPO, "gpurun_out", "bench_detail_%s.json" % dtag)) as f:
+                    dd = json.load(f)
+                rec["attention_kernels"] = dd["config"].get("attention_kernels")
+                rec["merged_sites"] = (dd["config"].get("adapter_options", {}).get("merged_weights") or {}).get("sites")
+            except (OSError, KeyError, ValueError):
+                pass
             if r.stderr and "capture failed" in r.stderr:
                 rec["note"] = [ln for ln in r.stderr.splitlines() if "capture failed" in ln][-1][:300]
             if "roofline" in d:
@@ -485,6 +502,101 @@ def run_secondaries(budget_s: float, steps: int) -> list:
             rec["skipped"] = f"{type(e).__name__}: {e}"
         out.append(rec)
     return out
+
+
+# ----------------------------------------------------------------------------- the ONE stdout line (driver contract)
+LINE_LIMIT = 6144  # bytes; the driver keeps a ~12 KB tail of stdout and truncates strings at 128 characters
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 1] + "~"
+
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us")
+
+
+def _roof(d):
+    r = _pick(d, _ROOF_KEYS)
+    if "kernel" in r:
+        r["kernel"] = _short(r["kernel"].split(" (")[0], 80)
+    return r
+
+
+def compact_record(out: dict, detail_path: str = "") -> dict:
+    """The record rank 0 prints as the LAST (and only) stdout line: the contract's fields, ``roofline`` (the graded K3 kernel,
+    with the in-step launches nested under ``in_step`` so that they ride in the one object the driver keeps), ``cpu_baseline``,
+    ``secondary`` as (tag, value, unit, ms_per_step, steps, execution) only.  Everything else — kernel tables, attention
+    picks, long descriptions — is the detail record (``bench_detail.json`` + one stderr line)."""
+    cfg = out.get("config", {})
+    c = _pick(cfg, ("global_batch", "samples_per_s", "parallelism", "execution", "allreduce_us", "device", "trainable_params",
+                    "allreduce_payload_bytes", "final_loss", "sites", "groups", "weight_elements"))
+    c = {"workload": _short(cfg.get("workload_short") or cfg.get("workload", ""), 126), **c}
+    rec = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data") if k in out}
+    rec["metric"] = _short(rec.get("metric", ""), 126)
+    rec["config"] = c
+    ins = {k: _roof(v) for k, v in (out.get("roofline_in_step") or {}).items()}
+    if "roofline" in out:
+        rec["roofline"] = _roof(out["roofline"])
+        if ins:
+            rec["roofline"]["in_step"] = ins
+    if ins:
+        rec["roofline_in_step"] = ins
+        for k, v in ins.items():  # scalars the driver's `config` keeps
+            c[k + "_frac_in_step"] = v.get("frac")
+    if out.get("roofline_fused_gemm"):
+        rec["roofline_fused_gemm"] = [dict(_pick(e, ("site", "avg_launch_us", "bound", "frac", "hbm_frac", "mfma_frac")),
+                                           kernel=_short(e.get("kernel", "").split(" (")[0], 60))
+                                      for e in out["roofline_fused_gemm"]]
+        c["fused_gemm_frac"] = out["roofline_fused_gemm"][0].get("frac")
+    if "adapter_path" in out:
+        rec["adapter_path"] = _pick(out["adapter_path"], ("gpu_ms_per_step", "algorithmic_bytes_per_step", "frac",
+                                                          "library_gemm_ms", "library_gemm_calls", "frac_of_step_time"))
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        rec["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=_short(cb.get("sample", ""), 126))
+        if isinstance(cb.get("merge"), dict):
+            rec["cpu_baseline"]["merge_ms"] = cb["merge"].get("ms")
+    for k in ("lora_overhead_ms", "value_host_options_off", "value_frozen_only", "value_aten_adapters",
+              "value_fused_per_site_kernels"):
+        if k in out:
+            rec[k] = out[k]
+            c[k] = out[k]
+    if "secondary" in out:
+        rec["secondary"] = [dict(_pick(r, ("value", "unit", "ms_per_step", "steps", "execution")), tag=_short(r.get("tag", ""), 48),
+                                 **({"skipped": _short(r["skipped"], 60)} if "skipped" in r else {}))
+                            for r in out["secondary"]]
+    if detail_path:
+        rec["detail"] = detail_path
+    # hard guard: never print a line the driver cannot keep whole
+    for drop in ("adapter_path", "roofline_fused_gemm", "roofline_in_step", "secondary"):
+        if len(json.dumps(rec)) <= LINE_LIMIT:
+            break
+        rec.pop(drop, None)
+    return rec
+
+
+def emit(out: dict) -> None:
+    """Detail record -> gpurun_out/bench_detail.json (merged back from the GPU box) + ONE stderr line; compact record -> the
+    one stdout line."""
+    path = ""
+    try:
+        d = os.path.join(REPO, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        tag = os.environ.get("LORA_AMD_BENCH_DETAIL_TAG") or ("svd" if "cli_svd" in out.get("metric", "")
+                                                              else "n%d" % out.get("n_gpus", 1))
+        path = os.path.join("gpurun_out", "bench_detail_%s.json" % tag)
+        with open(os.path.join(REPO, path), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        log(f"[bench] detail file not written: {e}")
+        path = ""
+    log("[bench-detail] " + json.dumps(out))
+    print(json.dumps(compact_record(out, path)), flush=True)
 
 
 def self_launch(args) -> int:
@@ -610,7 +722,7 @@ def svd_bench(args) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50 for the training step, 3 for --svd)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (train_batch_size, ref :285-289)")
     ap.add_argument("--rank", type=int, default=4, dest="lora_rank")
@@ -632,7 +744,9 @@ def main():
     ap.add_argument("--merged", type=int, default=1, help="1: the maskless Linear adapters run on the step's merged weight "
                     "W + scale up down (one K3 merge launch per step, frozen GEMMs forward / input gradient, one launch for "
                     "both factor gradients); 0: the fused per-site MFMA kernels of rounds 1-2 (A/B)")
-    ap.add_argument("--adapters", choices=["hip", "aten"], default="hip", help="aten: the reference's op sequence "
+    ap.add_argument("--adapters", choices=["hip", "aten", "none"], default="hip", help="none: the same host UNet with NO "
+                    "adapters, gradient to the input latents only (the `frozen_only` leg: step - frozen_only = what the LoRA "
+                    "path costs); aten: the reference's op sequence "
                     "(lora.py:53-58 as stock ATen launches) in place of the HIP adapter kernels, same host model: the "
                     "comparison leg behind `secondary[aten_adapters]`")
     ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda", help="cpu: BASELINE configs[0]-style plumbing "
@@ -659,11 +773,13 @@ def main():
     if args.svd:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
         _C.require()
-        if args.steps == 20:
+        if args.steps is None:
             args.steps = 3
-        print(json.dumps(svd_bench(args)), flush=True)
+        emit(svd_bench(args))
         return
 
+    if args.steps is None:
+        args.steps = 50 if args.device == "cuda" else 3
     on_gpu = args.device == "cuda"
     if on_gpu:
         assert torch.cuda.is_available(), "bench.py needs a GPU (use --device cpu for the plumbing run)"
@@ -701,13 +817,18 @@ def main():
         unet = build_unet(dev, cdt, seed=0)
     if args.channels_last:
         unet.to(memory_format=torch.channels_last)
-    if args.extended:
+    if args.adapters == "none":
+        pass  # frozen_only leg: no adapter anywhere
+    elif args.extended:
         L.inject_trainable_lora_extended(unet, r=args.lora_rank)  # conv adapters keep the constructor's dropout 0.1
     else:
         L.inject_trainable_lora(unet, r=args.lora_rank)  # reference default: dropout 0, scale 1
     T.promote_lora_to_fp32(unet)
     unet.train()
-    groups = [{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}]
+    if args.adapters == "none":  # a one-element stand-in state keeps the step's tail (all-reduce, clip, AdamW) in the region
+        groups = [{"params": [torch.nn.Parameter(torch.zeros(4, device=dev))], "lr": 1e-4, "weight_decay": 1e-2}]
+    else:
+        groups = [{"params": T.lora_params(unet), "lr": 1e-4, "weight_decay": 1e-2}]
     text_encoder = None
     if args.text_encoder:
         from lora_amd.standin import clip_text_model
@@ -720,7 +841,9 @@ def main():
         groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
     merged = None
-    if args.adapters == "aten":
+    if args.adapters == "none":
+        n_sites = 0
+    elif args.adapters == "aten":
         n_sites = swap_in_aten_adapters(unet) + (swap_in_aten_adapters(text_encoder) if text_encoder is not None else 0)
     elif on_gpu:
         n_sites = state.attach_direct_grads(unet, *([text_encoder] if text_encoder is not None else []))
@@ -729,6 +852,17 @@ def main():
     else:
         n_sites = sum(isinstance(m, (L.LoraInjectedLinear, L.LoraInjectedConv2d)) for m in unet.modules())
     sched = DDPMScheduler()
+    # weights / factors from seed 0 on every rank (and rank 0's factors are broadcast by FlatLoraState); the noise and
+    # timestep stream of a rank from seed + rank, its data shard from 1234 + rank
+    torch.manual_seed(rank)
+    replicas = None
+    if world > 1:
+        mine = torch.tensor([float(torch.randn(8, device=dev).double().sum()), float(state.flat_p.double().sum())],
+                            dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        replicas = {"noise_stream_fingerprints": [round(float(v[0]), 6) for v in allv],
+                    "param_checksums": [float(v[1]) for v in allv]}
     cfg = T.StepConfig(with_prior_preservation=bool(args.with_prior_preservation))
     if args.with_prior_preservation:
         args.batch *= 2  # collate_fn concatenates instance and class examples (ref :698-702)
@@ -744,6 +878,8 @@ def main():
         ehs = torch.randn(args.batch, 77, 768, device=dev, generator=g).to(cdt)
 
     def fwd_bwd(lat, cond):
+        if args.adapters == "none":  # gradient to the input only: the frozen UNet's forward + input-gradient chain
+            lat = lat.detach().requires_grad_(True)
         return T.forward_backward(unet, sched, lat, cond, cfg, text_encoder=text_encoder, merged=merged)
 
     def barrier():
@@ -849,6 +985,11 @@ def main():
                         "prior_preservation=%d, adapters=%s, host=%s, %d adapter sites"
                         % (args.lora_rank, args.batch, "GPU" if on_gpu else "CPU rank", args.res, args.res, args.extended,
                            args.text_encoder, args.with_prior_preservation, args.adapters, args.standin, n_sites)),
+                       "workload_short": ("BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16 batch %d/GPU 512x512, %d Linear sites"
+                                          % (args.lora_rank, args.batch, n_sites)) if headline else
+                       ("variant: r%d b%d %dpx ext=%d te=%d prior=%d adapters=%s host=%s dev=%s sites=%d"
+                        % (args.lora_rank, args.batch, args.res, args.extended, args.text_encoder,
+                           args.with_prior_preservation, args.adapters, args.standin, args.device, n_sites)),
                        "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
                        "parallelism": f"dp{world}",
                        "value_counts": "optimizer updates per second of the whole job (train_lora_dreambooth.py's global step: "
@@ -857,7 +998,7 @@ def main():
                        "timed_region": "noise + add_noise + UNet fwd + MSE + bwd + partial reduce + all-reduce + clip + AdamW; "
                        "VAE encode and CLIP forward (ref :818-840) are outside it: latents and text states are the "
                        "synthetic inputs SURVEY 8d prescribes (cached_latents-style)",
-                       "allreduce_us": allreduce_us,
+                       "allreduce_us": allreduce_us, "replicas": replicas,
                        "eager_tail": {"what": "the part of a step outside the captured hipGraph: ONE all-reduce of the flat "
                                               "gradient + sumsq + clip/AdamW (three launches), enqueued by the host while the "
                                               "graph's kernels still run",
@@ -897,8 +1038,7 @@ def main():
                                "floor_ms_at_peak": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK * 1e3, 4),
                                "frac_of_step": round(adapter_path["algorithmic_bytes_per_step"] / HBM_PEAK
                                                      / (out["ms_per_step"] * 1e-3), 5)}
-            pmc = next((p_ for p_ in (os.path.join(REPO, "profiles", f) for f in ("r04_step_pmc.json", "r03_step_pmc.json"))
-                        if os.path.exists(p_)), "")
+            pmc = _newest_profile("step_pmc.json")
             if os.path.exists(pmc):
                 try:
                     m = json.load(open(pmc))
@@ -928,15 +1068,19 @@ def main():
         if world == 1 and on_gpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.lora_rank)
         if world == 1 and on_gpu and headline and not args.no_secondary:
-            out["secondary"] = run_secondaries(args.secondary_budget, steps=10)
+            out["secondary"] = run_secondaries(args.secondary_budget, steps=20)
             for rec in out["secondary"]:
+                if rec["tag"] == "frozen_only" and "value" in rec:
+                    # what the hand-written path costs a step: the same UNet, same graph, adapters removed
+                    out["value_frozen_only"] = rec["value"]
+                    out["lora_overhead_ms"] = round(out["ms_per_step"] - rec["ms_per_step"], 3)
                 if rec["tag"] == "host_options_off" and "value" in rec:
                     out["value_host_options_off"] = rec["value"]
                 if rec["tag"] == "aten_adapters" and "value" in rec:
                     out["value_aten_adapters"] = rec["value"]
                 if rec["tag"].startswith("fused_per_site_kernels") and "value" in rec:
                     out["value_fused_per_site_kernels"] = rec["value"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

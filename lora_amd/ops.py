@@ -518,10 +518,15 @@ class MergedWeights:
             self._add_transposed(e)
         return e["w_eff"], e["b_eff"], e["w_eff_t"]
 
-    def _entry(self, module, w, b, dt, in_heads, out_heads, out=None):
+    def _refresh_if_stale(self) -> None:
+        """An optimiser step since the last merge (an eager forward outside ``trainer.forward_backward``: validation,
+        sampling after ``state.step()``): the scratch weights of EVERY site are re-merged before the first one is read."""
         if (self._state is not None and self._fresh_at != self._state.step_count
                 and not torch.cuda.is_current_stream_capturing()):
-            self.refresh()  # an optimiser step since the last merge (an eager forward outside trainer.forward_backward)
+            self.refresh()
+
+    def _entry(self, module, w, b, dt, in_heads, out_heads, out=None):
+        self._refresh_if_stale()
         key = (id(module), in_heads, out_heads, dt)
         e = self.entries.get(key)
         # the factors were re-bound to new storage (FlatLoraState aliases them into its flat buffer), the frozen weight
@@ -541,6 +546,7 @@ class MergedWeights:
         are row ranges of ONE buffer (and column ranges of one transposed buffer), so that the forward of the group is
         one GEMM ``X [W_q; W_k; W_v]^T`` whose output columns are the sites' outputs.  Returns the group record
         (``cat`` [sum n_out, K], ``bias`` or None, ``splits``) or None when the sites' entries already exist apart."""
+        self._refresh_if_stale()  # the first LoRA call of a UNet forward is a group (attn1 q / k / v)
         gkey = tuple(id(m) for m in modules) + (out_heads, dt)
         g = self.groups.get(gkey)
         if g is not None:

@@ -837,7 +837,11 @@ def test_bench_two_rccl_ranks_print_one_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 8 and d["config"]["allreduce_us"] > 0 and "backend nccl" in r.stderr
-    assert d["config"]["eager_tail"]["frac_of_step"] < 0.01
+    assert len(lines[0]) < 8192
+    det = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("[bench-detail] ")][-1][len("[bench-detail] "):])
+    assert det["config"]["eager_tail"]["frac_of_step"] < 0.01
+    rep = det["config"]["replicas"]
+    assert len(set(rep["noise_stream_fingerprints"])) == 2 and len(set(rep["param_checksums"])) == 1
 
 
 # ----------------------------------------------------------------------------- checkpointing + adapter dropout

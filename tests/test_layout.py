@@ -90,7 +90,10 @@ def test_bench_self_launch_runs_two_gloo_ranks_end_to_end():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
     assert d["config"]["allreduce_us"] and d["config"]["allreduce_us"] > 0
     assert d["config"]["allreduce_payload_bytes"] == 4 * d["config"]["trainable_params"]
+    assert len(lines[0]) < 8192
     assert d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
     assert "backend gloo" in r.stderr
     # the part of a step outside the graph (one all-reduce + clip + AdamW) is reported with its host cost
-    assert d["config"]["eager_tail"]["host_enqueue_us_per_step"] > 0 and 0 < d["config"]["eager_tail"]["frac_of_step"] < 1
+    # (detail record: the stdout line carries scalars only)
+    det = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("[bench-detail] ")][-1][len("[bench-detail] "):])
+    assert det["config"]["eager_tail"]["host_enqueue_us_per_step"] > 0 and 0 < det["config"]["eager_tail"]["frac_of_step"] < 1
