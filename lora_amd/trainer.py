@@ -52,7 +52,7 @@ class FlatLoraState:
             raise ValueError("FlatLoraState: no parameters")
         self.params = params
         self.n = pos
-        self.device = device or params[0].device
+        self.device = torch.device(device) if device is not None else params[0].device
         self.betas, self.eps, self.max_grad_norm = betas, float(eps), float(max_grad_norm)
         self.flat_p = torch.empty(self.n, dtype=torch.float32, device=self.device)
         self.flat_g = torch.zeros_like(self.flat_p)
