@@ -533,7 +533,7 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
     picks, long descriptions — is the detail record (``bench_detail.json`` + one stderr line)."""
     cfg = out.get("config", {})
     c = _pick(cfg, ("global_batch", "samples_per_s", "parallelism", "execution", "allreduce_us", "device", "trainable_params",
-                    "allreduce_payload_bytes", "final_loss", "sites", "groups", "weight_elements"))
+                    "allreduce_payload_bytes", "final_loss", "sites", "groups", "weight_elements", "power_iterations"))
     c = {"workload": _short(cfg.get("workload_short") or cfg.get("workload", ""), 126), **c}
     rec = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                "scaling", "vs_baseline", "dtype", "data") if k in out}
@@ -652,7 +652,7 @@ def svd_bench(args) -> dict:
     from lora_amd.standin import sd15_lora_site_shapes
 
     dev = torch.device("cuda", 0)
-    rank, n_iter = 8, 4
+    rank, n_iter = 8, (int(os.environ["LORA_AMD_SVD_ITERS"]) if os.environ.get("LORA_AMD_SVD_ITERS") else None)  # None = adaptive
     shapes = Counter(sd15_lora_site_shapes(extended=True))
     g = torch.Generator(device=dev).manual_seed(0)
     groups = []
@@ -679,18 +679,21 @@ def svd_bench(args) -> dict:
         up, down = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    passes = 2 * n_iter + 2
+    iters = n_iter if n_iter is not None else (S.LAST_ITERATIONS or 4)
+    passes = 2 * iters + 2
     byts = passes * elems * 4 + 2 * elems * 4  # the residual passes + reading W_tuned and W_base once
     out = {"metric": "cli_svd distillation, SD1.5 UNet -> rank-8 LoRA (224 sites, extended injection)",
            "value": round(n_sites / dt, 2), "unit": "sites/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 "
-                                  "sites (31 shape groups, 730 M weight elements), randomized subspace iteration n_iter=4, "
+                                  "sites (31 shape groups, 730 M weight elements), randomized subspace iteration, "
                                   "every step ONE ragged launch over all shape groups; the products with dW / dW^T on the "
                                   "matrix cores over (hi, lo) bf16 planes of the residuals (lora_amd_split16_transpose + "
                                   "lora_amd_rowdot16_planes), on-device CholeskyQR3",
-                      "sites": n_sites, "groups": len(groups), "weight_elements": elems},
+                      "workload_short": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 sites",
+                      "sites": n_sites, "groups": len(groups), "weight_elements": elems, "power_iterations": iters,
+                      "iteration_count": "adaptive (Ritz energy settled)" if n_iter is None else "fixed"},
            "roofline": {"kernel": "lora_amd::rowdot16_planes_kernel<bf16> (the ten passes over the residuals: 812 us each = 3.6 TB/s "
                                   "= 0.45 of the roof in the kernel trace, profiles/r04_svd_kernel_trace_summary_planes_first.txt) "
                                   "+ everything else of the step",

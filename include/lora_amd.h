@@ -284,6 +284,73 @@ typedef struct lora_amd_sub_desc {
   int64_t n, begin;       /* elements; begin: running count of 4096-element blocks (filled by the caller) */
 } lora_amd_sub_desc;
 int lora_amd_sub_ragged(const lora_amd_sub_desc *descs_dev, int32_t n, int64_t blocks, int32_t in_dtype, void *stream);
+/* The small dense steps of the same subspace iteration, fused (csrc/svd_small.hip): every site of a model in ONE launch, the
+ * reduction behind a launch finished inside it by the last-arriving workgroup of each site.  A THIN matrix is [rows][16] f32,
+ * row-major, at element offset `off` of a flat buffer (`off` % 16 == 0); the same site table serves every buffer of that
+ * layout.  `blockmap` [total_blocks] int32 = the site of every 256-row block; counters [nsites] uint32, zero before the first
+ * launch (the last arriver of a site resets its word).
+ * replaces (cli_svd.py:24-92 as restated in lora_amd/cli_svd.py): colreduce_ragged (Gram) + chol_inverse_batched +
+ * rowdot_ragged per CholeskyQR pass, torch.linalg.svd of the 16 x 16 cores (rocSOLVER, one call per site), the per-group sign
+ * fixes, torch.quantile's sort and the clamp. */
+typedef struct lora_amd_thin_site {
+  int64_t off, rows;
+  int64_t block_begin;    /* running count of ceil(rows / 256) */
+  int32_t blocks, reserved;
+} lora_amd_thin_site;
+typedef struct lora_amd_thin_finish {
+  float *part;            /* [total_blocks][256] f32 workspace */
+  uint32_t *counters;     /* [nsites] */
+  int32_t mode;           /* 1: out = L^{-1} of (sum + shift_rel tr(sum)/16 I) = L L^T; 2: SVD of the sum */
+  float shift_rel;
+  float *linv_out;        /* mode 1: [nsites][16][16] */
+  float *ritz_out;        /* mode 1, or NULL: [nsites][2] = (sum of the `rank` largest eigenvalues of the un-shifted sum,
+                           * sum of the other 16 - rank) */
+  float *ubt, *vb;        /* mode 2: [nsites][rank][16] = U[:, :rank]^T and V[:, :rank]^T of sum = U S V^T */
+  float *s_out;           /* mode 2: [nsites][16], descending */
+  int32_t rank, reserved;
+} lora_amd_thin_finish;
+/* sum = A^T B over the rows of every site (b = NULL: B = A, the Gram matrix), then `fin`. */
+int lora_amd_thin_gram(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                       const float *a, const float *b, const lora_amd_thin_finish *fin, void *stream);
+/* dst = src M^T per site (mats [nsites][16][16]: the L^{-1} of a finish); fin != NULL: the Gram matrix of dst, then `fin`. */
+int lora_amd_thin_apply(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                        const float *src, const float *mats, float *dst, const lora_amd_thin_finish *fin, void *stream);
+/* dst [rows][rank] (at element offset off / 16 * rank) = (src M^T)[:, :rank] * scale_a * scale_b, mats [nsites][rank][16],
+ * scales [nsites][16] or NULL.  sign_out != NULL: also sign_out [nsites][16] = the sign of the largest-magnitude entry of
+ * every output column BEFORE scaling (first row on ties; cli_svd's deterministic sign rule), through sign_part
+ * [total_blocks][32] f32 and sign_rows [total_blocks][16] int32. */
+int lora_amd_thin_rotate(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                         const float *src, const float *mats, int32_t rank, const float *scale_a, const float *scale_b,
+                         float *dst, float *sign_part, int32_t *sign_rows, uint32_t *counters, float *sign_out, void *stream);
+/* Order statistics of a site's joint values {u [n_u], v [n_v] * sign[j % rank]} (the distribution cli_svd.py:39-47 takes its
+ * quantile of): three launches, pass = 0, 1, 2 (radix 11 + 11 + 10 bits of the order-preserving key); state [nsites][8]
+ * uint32 = {0, k, 0, 0xffffffff, 0, 0, 0, 0} before pass 0 with k = the 0-based ascending index wanted; after pass 2
+ * out2 [nsites][2] = (statistic k, statistic min(k + 1, n - 1)), both NaN if the site holds a NaN (torch.quantile's rule).
+ * hist [nsites][2048] uint32, zero before pass 0.  Blocks of 8192 values. */
+typedef struct lora_amd_thin_qsite {
+  int64_t off_u, off_v, n_u, n_v;
+  int64_t block_begin;    /* running count of ceil((n_u + n_v) / 8192) */
+  int32_t blocks, reserved;
+} lora_amd_thin_qsite;
+int lora_amd_thin_select(const lora_amd_thin_qsite *qsites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                         const float *u, const float *v, const float *sign, int32_t rank, int32_t pass, uint32_t *hist,
+                         uint32_t *counters, void *state, float *out2, void *stream);
+/* u <- clamp(u, -hi, hi) in place ([N][rank] = `up`); down [rank][K] (at off_v) = clamp(v [K][rank] * sign, -hi, hi);
+ * hi [nsites]; NaN in a value or in hi propagates (torch.minimum / maximum). */
+int lora_amd_thin_clamp(const lora_amd_thin_qsite *qsites_dev, const int32_t *blockmap_dev, int64_t total_blocks, float *u,
+                        const float *v, const float *sign, const float *hi, float *down, int32_t rank, void *stream);
+/* dW = (f32) tuned - (f32) base of ONE site [N][K] (cli_svd.py:30-32; N % 8 == 0, K % 8 == 0) -> the (hi, lo) planes of dW
+ * ([N][K]) and of dW^T ([K][N]) from one read of the two weights, and norm_part[tile] = the sum of squares of every 64 x 64
+ * tile (tile_begin = running count of ceil(N / 64) * ceil(K / 64), filled by the caller; the tiles of a site are consecutive).
+ * replaces: lora_amd_sub_ragged + lora_amd_split16_transpose (the f32 residual is never written). */
+typedef struct lora_amd_resid_desc {
+  const void *tuned, *base;
+  void *hi, *lo, *thi, *tlo;
+  int32_t N, K;
+  int64_t tile_begin;
+} lora_amd_resid_desc;
+int lora_amd_split16_residual(const lora_amd_resid_desc *descs_dev, int32_t n, int64_t tiles, int32_t in_dtype,
+                              int32_t plane_dtype, float *norm_part, void *stream);
 /* ------------------------------------------------------------------------
  * K1/K2 fused: one launch forward, two backward, one batched reduction per step.
  * These are what LoraInjectedLinear runs for 16-byte-friendly shapes (K%8==0, N%8==0,

@@ -34,6 +34,7 @@ SYMBOLS = (
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
     "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_split16_ragged", "lora_amd_split16_transpose",
+    "lora_amd_split16_residual", "lora_amd_thin_gram", "lora_amd_thin_apply", "lora_amd_thin_rotate", "lora_amd_thin_select", "lora_amd_thin_clamp",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
@@ -137,6 +138,27 @@ class PlanesDesc(C.Structure):
 class SplitTDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("thi", C.c_void_p), ("tlo", C.c_void_p),
                 ("batch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32), ("tile_begin", C.c_int64)]
+
+
+class ResidDesc(C.Structure):
+    _fields_ = [("tuned", C.c_void_p), ("base", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("thi", C.c_void_p),
+                ("tlo", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("tile_begin", C.c_int64)]
+
+
+class ThinSite(C.Structure):
+    _fields_ = [("off", C.c_int64), ("rows", C.c_int64), ("block_begin", C.c_int64), ("blocks", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class ThinQSite(C.Structure):
+    _fields_ = [("off_u", C.c_int64), ("off_v", C.c_int64), ("n_u", C.c_int64), ("n_v", C.c_int64),
+                ("block_begin", C.c_int64), ("blocks", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ThinFinishDesc(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("counters", C.c_void_p), ("mode", C.c_int32), ("shift_rel", C.c_float),
+                ("linv_out", C.c_void_p), ("ritz_out", C.c_void_p), ("ubt", C.c_void_p), ("vb", C.c_void_p),
+                ("s_out", C.c_void_p), ("rank", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SplitDesc(C.Structure):
@@ -254,6 +276,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_split16_ragged.restype = C.c_int
     lib.lora_amd_split16_transpose.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_split16_transpose.restype = C.c_int
+    lib.lora_amd_split16_residual.argtypes = [vp, i32, i64, i32, i32, vp, vp]
+    lib.lora_amd_split16_residual.restype = C.c_int
+    lib.lora_amd_thin_gram.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    lib.lora_amd_thin_apply.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
+    lib.lora_amd_thin_rotate.argtypes = [vp, vp, i64, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.lora_amd_thin_select.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.lora_amd_thin_clamp.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i32, vp]
+    lib.lora_amd_thin_gram.restype = lib.lora_amd_thin_apply.restype = lib.lora_amd_thin_rotate.restype = C.c_int
+    lib.lora_amd_thin_select.restype = lib.lora_amd_thin_clamp.restype = C.c_int
     lib.lora_amd_ragged_plan.restype = lib.lora_amd_rowdot_ragged.restype = C.c_int
     lib.lora_amd_colreduce_ragged.restype = lib.lora_amd_sub_ragged.restype = C.c_int
     lib.lora_amd_sumsq_workspace.argtypes = [i64]
@@ -769,6 +800,134 @@ class PlanesProgram:
         n, off, grid = self._meta[handle]
         _check(require().lora_amd_rowdot16_planes(self._dev.data_ptr() + off, n, grid, self.r, dtype_code(self.dt), _stream()),
                "lora_amd_rowdot16_planes")
+
+
+THIN_ROWS_PER_BLOCK, THIN_Q_ELEMS = 256, 8192
+
+
+def split16_residual(groups, dims, dh, dl, th, tl) -> torch.Tensor:
+    """Per site of every shape group: dW = tuned - base -> the (hi, lo) bf16 planes of dW (``dh[g][b]``, ``dl``) and of dW^T
+    (``th``, ``tl``) from ONE read of the two weights (``lora_amd_split16_residual``; the f32 residual is never written).
+    ``groups`` = [(tuned list, base list)], ``dims`` = [(B, N, K)].  Returns |dW|_F^2 per site [sum B] (f32, deterministic:
+    per-tile partials of the launch summed in tile order)."""
+    import numpy as np
+
+    lib = require()
+    nsites = sum(B for B, _, _ in dims)
+    arr = (ResidDesc * nsites)()
+    i, tiles, ends = 0, 0, []
+    in_dt = groups[0][0][0].dtype
+    for (tuned, base), (B, N, K), h, l, t_h, t_l in zip(groups, dims, dh, dl, th, tl):
+        if N % 8 or K % 8:
+            raise ValueError("split16_residual: N and K must be multiples of 8")
+        hp, lp, thp, tlp = h.data_ptr(), l.data_ptr(), t_h.data_ptr(), t_l.data_ptr()
+        nt = -(-N // 64) * -(-K // 64)
+        for b in range(B):
+            t_, b_ = tuned[b], base[b]
+            if t_.dtype != in_dt or b_.dtype != in_dt or not (t_.is_contiguous() and b_.is_contiguous()) or t_.numel() != N * K:
+                raise ValueError("split16_residual: contiguous weights of one dtype and of the group's size expected")
+            d = arr[i]
+            d.tuned, d.base = t_.data_ptr(), b_.data_ptr()
+            o = b * N * K * 2
+            d.hi, d.lo, d.thi, d.tlo, d.N, d.K, d.tile_begin = hp + o, lp + o, thp + o, tlp + o, N, K, tiles
+            tiles += nt
+            ends.append(tiles)
+            i += 1
+    dev = dh[0].device
+    table = table_to_device(arr, dev)
+    part = torch.empty(tiles, dtype=torch.float32, device=dev)
+    _check(lib.lora_amd_split16_residual(table.data_ptr(), nsites, tiles, dtype_code(in_dt), dtype_code(dh[0].dtype),
+                                         part.data_ptr(), _stream()), "lora_amd_split16_residual")
+    c = torch.cumsum(part.double(), 0)
+    e = torch.from_numpy(np.asarray(ends, dtype=np.int64) - 1).to(dev)
+    tot = c[e]
+    return torch.diff(tot, prepend=tot.new_zeros(1)).float()
+
+
+class ThinTable:
+    """Site table of the fused small steps of the subspace iteration (csrc/svd_small.hip): one entry per thin matrix
+    [rows][16] f32 at element offset ``off`` of any flat buffer of that layout, 256-row blocks, a block -> site map."""
+
+    def __init__(self, sites, device):
+        """sites: [(off, rows)]."""
+        import numpy as np
+
+        arr = (ThinSite * len(sites))()
+        blk, bm = 0, []
+        for i, (d, (off, rows)) in enumerate(zip(arr, sites)):
+            if off % 16:
+                raise ValueError("ThinTable: site offsets must be multiples of 16 elements")
+            nb = -(-int(rows) // THIN_ROWS_PER_BLOCK)
+            d.off, d.rows, d.block_begin, d.blocks = int(off), int(rows), blk, nb
+            bm += [i] * nb
+            blk += nb
+        self.n, self.total_blocks, self.device = len(sites), blk, device
+        self.sites = table_to_device(arr, device)
+        self.blockmap = torch.from_numpy(np.asarray(bm, dtype=np.int32)).to(device)
+        self.part = torch.empty(blk * 256, dtype=torch.float32, device=device)
+        self.counters = torch.zeros(len(sites), dtype=torch.int32, device=device)
+
+
+class ThinQTable:
+    """Per-site joint value ranges for the quantile selection / clamp: (off_u, n_u) in the `up` buffer, (off_v, n_v) in the
+    `down` buffer; blocks of 8192 values."""
+
+    def __init__(self, sites, device):
+        import numpy as np
+
+        arr = (ThinQSite * len(sites))()
+        blk, bm = 0, []
+        for i, (d, (off_u, n_u, off_v, n_v)) in enumerate(zip(arr, sites)):
+            nb = -(-(int(n_u) + int(n_v)) // THIN_Q_ELEMS)
+            d.off_u, d.off_v, d.n_u, d.n_v, d.block_begin, d.blocks = int(off_u), int(off_v), int(n_u), int(n_v), blk, nb
+            bm += [i] * nb
+            blk += nb
+        self.n, self.total_blocks, self.device = len(sites), blk, device
+        self.sites = table_to_device(arr, device)
+        self.blockmap = torch.from_numpy(np.asarray(bm, dtype=np.int32)).to(device)
+        self.hist = torch.zeros(len(sites) * 2048, dtype=torch.int32, device=device)
+        self.counters = torch.zeros(len(sites), dtype=torch.int32, device=device)
+
+
+def thin_finish(table: ThinTable, mode: int, rank: int, shift_rel: float = 0.0, linv_out=None, ritz_out=None, ubt=None,
+                vb=None, s_out=None) -> ThinFinishDesc:
+    f = ThinFinishDesc()
+    f.part, f.counters, f.mode, f.shift_rel, f.rank = table.part.data_ptr(), table.counters.data_ptr(), mode, shift_rel, rank
+    for name, t in (("linv_out", linv_out), ("ritz_out", ritz_out), ("ubt", ubt), ("vb", vb), ("s_out", s_out)):
+        setattr(f, name, t.data_ptr() if t is not None else None)
+    return f
+
+
+def thin_gram(table: ThinTable, a: torch.Tensor, b, fin: ThinFinishDesc) -> None:
+    _check(require().lora_amd_thin_gram(table.sites.data_ptr(), table.blockmap.data_ptr(), table.total_blocks, a.data_ptr(),
+                                        b.data_ptr() if b is not None else None, C.byref(fin), _stream()), "lora_amd_thin_gram")
+
+
+def thin_apply(table: ThinTable, src: torch.Tensor, mats: torch.Tensor, dst: torch.Tensor, fin=None) -> None:
+    _check(require().lora_amd_thin_apply(table.sites.data_ptr(), table.blockmap.data_ptr(), table.total_blocks, src.data_ptr(),
+                                         mats.data_ptr(), dst.data_ptr(), C.byref(fin) if fin is not None else None, _stream()),
+           "lora_amd_thin_apply")
+
+
+def thin_rotate(table: ThinTable, src, mats, rank: int, dst, scale_a=None, scale_b=None, sign_ws=None, sign_out=None) -> None:
+    """sign_ws = (part [total_blocks * 32] f32, rows [total_blocks * 16] int32) when ``sign_out`` is wanted."""
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    _check(require().lora_amd_thin_rotate(table.sites.data_ptr(), table.blockmap.data_ptr(), table.total_blocks, src.data_ptr(),
+                                          mats.data_ptr(), rank, p(scale_a), p(scale_b), dst.data_ptr(),
+                                          p(sign_ws[0]) if sign_ws else None, p(sign_ws[1]) if sign_ws else None,
+                                          table.counters.data_ptr() if sign_out is not None else None, p(sign_out), _stream()),
+           "lora_amd_thin_rotate")
+
+
+def thin_select(q: ThinQTable, u, v, sign, rank: int, pass_: int, state, out2) -> None:
+    _check(require().lora_amd_thin_select(q.sites.data_ptr(), q.blockmap.data_ptr(), q.total_blocks, u.data_ptr(), v.data_ptr(),
+                                          sign.data_ptr(), rank, pass_, q.hist.data_ptr(), q.counters.data_ptr(),
+                                          state.data_ptr(), out2.data_ptr(), _stream()), "lora_amd_thin_select")
+
+
+def thin_clamp(q: ThinQTable, u, v, sign, hi, down, rank: int) -> None:
+    _check(require().lora_amd_thin_clamp(q.sites.data_ptr(), q.blockmap.data_ptr(), q.total_blocks, u.data_ptr(), v.data_ptr(),
+                                         sign.data_ptr(), hi.data_ptr(), down.data_ptr(), rank, _stream()), "lora_amd_thin_clamp")
 
 
 def split16_ragged(srcs, his, los) -> None:

@@ -46,6 +46,17 @@ from .lora import (LoraInjectedConv2d, LoraInjectedLinear, inject_trainable_lora
 # (csrc/rank16_mfma.hip: lora_amd_split16_ragged + lora_amd_rowdot16_planes) when the sketch is 16 wide and every shape is a
 # multiple of 32 both ways; False = the f32 column-reduction passes of rounds 2-3 (tests run both).
 PLANES = True
+# The small dense steps between the passes (Gram / Cholesky / apply, the 16 x 16 core SVDs, sign rule, quantile, clamp) as
+# fused launches over a per-site table (csrc/svd_small.hip) when the sketch is 16 wide; False = rounds 2-4's ragged launches +
+# torch.linalg.svd / torch.topk per shape group (tests run both).
+THIN = True
+# adaptive iteration count (``n_iter=None``): the squared error of the rank-r product is |dW|_F^2 - E_r with E_r the top-r Ritz
+# energy (sum of the r largest eigenvalues of the Gram matrix of dW Qz), which only grows with the iterations.  Iterate until,
+# for EVERY site, one more power iteration improved that squared error by less than RES_TOL of itself (floor: 1e-6 |dW|^2, the
+# resolution of the f32 sums; an exactly low-rank residual).  |dW|_F^2 comes out of the launch that forms the residual.  At
+# least 2, at most MAX_ITER iterations.
+RES_TOL, MAX_ITER = 1e-3, 12
+LAST_ITERATIONS = None  # power iterations the last fused distillation ran (evidence for bench.py)
 
 
 def _iter_lora(model):  # ref :16-21
@@ -85,11 +96,12 @@ def group_supported(N: int, K: int, rank: int, oversample: int = 8) -> bool:
     return K % 8 == 0 and rank <= l <= min(N, K)
 
 
-def topr_svd_batched(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 4,
+def topr_svd_batched(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: Optional[int] = 4,
                      generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Top-``rank`` singular triplets (U [B,N,r], S [B,r], Vh [B,r,K]) of a stack of f32 matrices [B, N, K] on the
     device; every step is one launch for the whole stack (see module docstring)."""
     _C.require()
+    n_iter = 4 if n_iter is None else n_iter
     B, N, K = delta.shape
     l = _sketch_width(rank, oversample, N, K)
     if not group_supported(N, K, rank, oversample):
@@ -119,7 +131,7 @@ def topr_svd_batched(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter
     return u * sgn[:, None, :], s, vh * sgn[:, :, None]
 
 
-def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: int = 4,
+def topr_svd(delta: torch.Tensor, rank: int, oversample: int = 8, n_iter: Optional[int] = 4,
              generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Top-``rank`` singular triplets (U [N,r], S [r], Vh [r,K]) of a 2-D f32 matrix.
 
@@ -183,7 +195,181 @@ def _flat_stacks(shapes, device):
     return flat, [flat[o:o + B * R * Cc].view(B, R, Cc) for o, (B, R, Cc) in zip(offs, shapes)]
 
 
-def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
+def _elem_off(view: torch.Tensor, flat: torch.Tensor) -> int:
+    return (view.data_ptr() - flat.data_ptr()) // 4
+
+
+class _ThinState:
+    """Buffers and tables of one fused subspace iteration over a list of stacks (``_subspace_thin``)."""
+
+
+def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
+    """The subspace iteration of ``topr_svd_ragged`` with a 16-wide sketch on the matrix cores end to end: the products with
+    dW / dW^T over (hi, lo) bf16 planes (``lora_amd_rowdot16_planes``), every CholeskyQR3 as 4 fused launches over a per-site
+    table (``lora_amd_thin_gram`` / ``lora_amd_thin_apply``: the Gram matrix of a pass's output is accumulated by the pass and
+    inverted by its last-arriving workgroup), the 16 x 16 core SVDs by a one-sided Jacobi inside the launch that sums the cores.
+    ``n_iter=None``: power iterations until the top-r Ritz energy of every site (eigenvalues of the Gram matrix of dW Qz, from
+    the same launch) settles to RITZ_TOL — a flat spectrum needs more than the 4 iterations a decaying one does.
+    ``pairs`` = [(tuned list, base list)] per group instead of ``deltas`` = [B, N, K] f32 stacks: the residuals are formed
+    inside the launch that writes the planes (``lora_amd_split16_residual``), never in f32.
+    Leaves Q in ``st.yb``, Qb in ``st.za``, the core factors in ``st.ubt / st.vb / st.s``."""
+    if pairs is not None:
+        dev = pairs[0][0][0].device
+        dims = [(len(t), t[0].shape[0], t[0].numel() // t[0].shape[0]) for t, _ in pairs]
+    else:
+        dev = deltas[0].device
+        dims = [tuple(d.shape) for d in deltas]
+    l = 16
+    yshape = [(B, N, l) for B, N, K in dims]
+    zshape = [(B, K, l) for B, N, K in dims]
+    st = _ThinState()
+    st.dims, st.rank = dims, rank
+    st.ya, Ya = _flat_stacks(yshape, dev)
+    st.yb, Yb = _flat_stacks(yshape, dev)
+    st.za, Za = _flat_stacks(zshape, dev)
+    st.zb, Zb = _flat_stacks(zshape, dev)
+    st.zc, Zc = _flat_stacks(zshape, dev)
+    ysites, zsites = [], []
+    for (B, N, K), y, z in zip(dims, Ya, Za):
+        oy, oz = _elem_off(y, st.ya), _elem_off(z, st.za)
+        ysites += [(oy + b * N * l, N) for b in range(B)]
+        zsites += [(oz + b * K * l, K) for b in range(B)]
+    st.ysites, st.zsites = ysites, zsites
+    st.ty, st.tz = _C.ThinTable(ysites, dev), _C.ThinTable(zsites, dev)
+    nb = len(ysites)
+    st.nb = nb
+    lin = [torch.empty(nb * 256, dtype=torch.float32, device=dev) for _ in range(2)]
+    st.ritz = torch.zeros(nb, 2, dtype=torch.float32, device=dev)
+    st.ubt = torch.empty(nb * rank * l, dtype=torch.float32, device=dev)
+    st.vb = torch.empty(nb * rank * l, dtype=torch.float32, device=dev)
+    st.s = torch.empty(nb, l, dtype=torch.float32, device=dev)
+
+    def planes_of(shapes_):
+        return ([torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes_],
+                [torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes_])
+    dh, dl = planes_of([(B, N, K) for B, N, K in dims])
+    th, tl = planes_of([(B, K, N) for B, N, K in dims])
+    if pairs is not None:
+        norm2 = _C.split16_residual(pairs, dims, dh, dl, th, tl)
+    else:
+        _C.split16_transpose([d.contiguous() for d in deltas], dh, dl, th, tl)
+        norm2 = torch.cat([d.square().sum((1, 2)) for d in deltas]) if n_iter is None else None
+    pprog = _C.PlanesProgram(dev, l)
+    p_sketch = pprog.table(list(zip(dh, dl, Zc, Ya)))     # Y = dW Omega
+    p_fwd = pprog.table(list(zip(th, tl, Yb, Za)))        # Z = dW^T Q
+    p_back = pprog.table(list(zip(dh, dl, Zb, Ya)))       # Y = dW Qz
+    p_b = pprog.table(list(zip(th, tl, Yb, Zc)))          # b^T = dW^T Q
+    pprog.upload()
+
+    def orth(tab, a, b, ritz=None):
+        """CholeskyQR3 a -> b -> a -> b (result in ``b``): shifted first pass, two clean ones; 4 launches."""
+        fin = lambda shift, out, rz=None: _C.thin_finish(tab, 1, rank, shift, linv_out=out, ritz_out=rz)  # noqa: E731
+        _C.thin_gram(tab, a, None, fin(1e-4, lin[0], ritz))
+        _C.thin_apply(tab, a, lin[0], b, fin(0.0, lin[1]))
+        _C.thin_apply(tab, b, lin[1], a, fin(0.0, lin[0]))
+        _C.thin_apply(tab, a, lin[0], b)
+
+    st.zc.normal_(generator=generator)                            # Omega, every site at once
+    pprog.run(p_sketch)
+    orth(st.ty, st.ya, st.yb)                                     # q in yb
+    it, prev = 0, None
+    while True:
+        pprog.run(p_fwd)
+        orth(st.tz, st.za, st.zb)                                 # qz in zb
+        pprog.run(p_back)
+        orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
+        it += 1
+        if n_iter is not None:
+            if it >= n_iter:
+                break
+            continue
+        if it >= MAX_ITER:
+            break
+        if prev is not None:
+            gained = (st.ritz[:, 0] - prev).abs()
+            err2 = (norm2 - st.ritz[:, 0]).clamp_min(0.0)
+            if bool((gained <= torch.maximum(RES_TOL * err2, 1e-6 * norm2)).all()):  # one host sync per iteration
+                break
+        prev = st.ritz[:, 0].clone()
+    st.iterations = it
+    global LAST_ITERATIONS
+    LAST_ITERATIONS = it
+    pprog.run(p_b)                                                # b^T [K, l] in zc
+    _C.thin_gram(st.tz, st.zc, None, _C.thin_finish(st.tz, 1, rank, 1e-4, linv_out=lin[0]))
+    _C.thin_apply(st.tz, st.zc, lin[0], st.za, _C.thin_finish(st.tz, 1, rank, 0.0, linv_out=lin[1]))
+    _C.thin_apply(st.tz, st.za, lin[1], st.zb, _C.thin_finish(st.tz, 1, rank, 0.0, linv_out=lin[0]))
+    _C.thin_apply(st.tz, st.zb, lin[0], st.za)                    # qb in za
+    # core = b Qb = zc^T za, its SVD inside the same launch
+    _C.thin_gram(st.tz, st.zc, st.za, _C.thin_finish(st.tz, 2, rank, ubt=st.ubt, vb=st.vb, s_out=st.s))
+    st.sign = torch.empty(nb, l, dtype=torch.float32, device=dev)
+    st.sign_ws = (torch.empty(st.tz.total_blocks * 32, dtype=torch.float32, device=dev),
+                  torch.empty(st.tz.total_blocks * 16, dtype=torch.int32, device=dev))
+    st.uo = torch.empty(st.ya.numel() // l * rank, dtype=torch.float32, device=dev)
+    st.vo = torch.empty(st.za.numel() // l * rank, dtype=torch.float32, device=dev)
+    # V = Qb Vb[:r]^T [K, r] and the sign rule (largest-|.| entry of every down row positive) in one launch
+    _C.thin_rotate(st.tz, st.za, st.vb, rank, st.vo, sign_ws=st.sign_ws, sign_out=st.sign)
+    return st
+
+
+def _group_views(st, flat, rows_of, cols: int):
+    """Per shape group the [B, rows, cols] view of a flat per-site buffer laid out like the iteration's stacks."""
+    out, i = [], 0
+    sites = st.ysites if rows_of == "N" else st.zsites
+    for (B, N, K) in st.dims:
+        rows = N if rows_of == "N" else K
+        o = sites[i][0] // 16 * cols
+        out.append(flat[o:o + B * rows * cols].view(B, rows, cols))
+        i += B
+    return out
+
+
+_QTABLES = {}
+
+
+def _distill_thin(pairs, rank: int, clamp_quantile: float, n_iter, generator):
+    """``topr_svd_ragged`` + ``_clamp_pairs`` with the small steps fused, from (tuned, base) weight lists per shape group:
+    returns per group (up [B, N, r], down [B, r, K])."""
+    st = _subspace_thin(None, rank, n_iter, generator, pairs=pairs)
+    dev = st.ya.device
+    # up = Q Ub[:, :r] diag(S) diag(sign)
+    _C.thin_rotate(st.ty, st.yb, st.ubt, rank, st.uo, scale_a=st.s, scale_b=st.sign)
+    key = (tuple(st.ysites), tuple(st.zsites), rank, clamp_quantile, str(dev))
+    ent = _QTABLES.get(key)
+    if ent is None:
+        qs, ks, ws = [], [], []
+        q32 = torch.tensor(clamp_quantile, dtype=torch.float32)
+        for (oy, N), (oz, K) in zip(st.ysites, st.zsites):
+            n = (N + K) * rank
+            qs.append((oy // 16 * rank, N * rank, oz // 16 * rank, K * rank))
+            ranks = q32 * (n - 1)          # ATen's quantile: ranks and weights in the input dtype
+            lo = ranks.floor()
+            ks.append(int(lo.item()))
+            ws.append(float((ranks - lo).item()))
+        tmpl = torch.zeros(len(qs), 8, dtype=torch.int32)
+        tmpl[:, 1] = torch.tensor(ks, dtype=torch.int32)
+        tmpl[:, 3] = -1
+        if len(_QTABLES) > 8:
+            _QTABLES.clear()
+        ent = _QTABLES[key] = (_C.ThinQTable(qs, dev), tmpl.to(dev), torch.tensor(ws, dtype=torch.float32, device=dev))
+    qt, tmpl, w = ent
+    state = tmpl.clone()
+    out2 = torch.empty(st.nb, 2, dtype=torch.float32, device=dev)
+    for p in range(3):
+        _C.thin_select(qt, st.uo, st.vo, st.sign, rank, p, state, out2)
+    hi = torch.lerp(out2[:, 0], out2[:, 1], w)      # torch.quantile's interpolation, bit for bit
+    down = torch.empty_like(st.vo)
+    _C.thin_clamp(qt, st.uo, st.vo, st.sign, hi, down, rank)
+    ups = _group_views(st, st.uo, "N", rank)
+    downs = [d.view(B, rank, K) for d, (B, N, K) in zip(_group_views(st, down, "K", rank), st.dims)]
+    return list(zip(ups, downs)), st
+
+
+def _thin_ok(dims, rank: int, oversample: int) -> bool:
+    return (THIN and PLANES and all(_sketch_width(rank, oversample, N, K) == 16 and N % 32 == 0 and K % 32 == 0
+                                    for _, N, K in dims))
+
+
+def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: Optional[int] = 4,
                     generator: Optional[torch.Generator] = None):
     """``topr_svd_batched`` for a LIST of stacks of different shapes ([B_g, N_g, K_g] f32, contiguous) run in lock-step:
     every step of the iteration is ONE launch (pair) for the whole model — ``lora_amd_colreduce_ragged`` /
@@ -199,6 +385,19 @@ def topr_svd_ragged(deltas, rank: int, oversample: int = 8, n_iter: int = 4,
             raise ValueError(f"topr_svd_ragged: shape {N}x{K} rank {rank} is outside the batched device path")
     nb = sum(B for B, _, _ in dims)
     planes = PLANES and l == 16 and all(N % 32 == 0 and K % 32 == 0 for _, N, K in dims)
+    if planes and THIN:
+        st = _subspace_thin([d.contiguous() for d in deltas], rank, n_iter, generator)
+        _C.thin_rotate(st.ty, st.yb, st.ubt, rank, st.uo, scale_a=st.sign)        # U = Q Ub[:, :r] diag(sign)
+        vt = torch.empty_like(st.vo)
+        _C.thin_rotate(st.tz, st.za, st.vb, rank, vt, scale_a=st.sign)            # Vh^T = Qb Vb[:r]^T diag(sign)
+        Us, Vs, o = _group_views(st, st.uo, "N", rank), _group_views(st, vt, "K", rank), 0
+        out = []
+        for (B, N, K), u, v in zip(dims, Us, Vs):
+            out.append((u, st.s[o:o + B, :rank], v.transpose(1, 2).contiguous()))
+            o += B
+        return out
+    if n_iter is None:
+        n_iter = 4
     # second resident layout of the residuals (f32 passes only: the planes of dW^T come out of the split launch)
     delta_t = None if planes else [d.transpose(1, 2).contiguous() for d in deltas]
     yshape = [(B, N, l) for B, N, K in dims]
@@ -313,6 +512,15 @@ def distill_model(groups, rank: int, clamp_quantile: float = 0.99, generator: Op
         by_dtype.setdefault(groups[ent[0]][0][0].dtype, []).append(ent)
     for dt, ents in by_dtype.items():
         dev = groups[ents[0][0]][0][0].device
+        if _thin_ok([(B, N, K) for _, B, N, K in ents], rank, over):
+            # residuals, planes and |dW|^2 in one launch; the small steps fused; adaptive iteration count unless the caller
+            # fixes one (``n_iter=``)
+            flat2 = [([t.reshape(t.shape[0], -1) for t in groups[gi][0]], [b.reshape(b.shape[0], -1) for b in groups[gi][1]])
+                     for gi, _, _, _ in ents]
+            res, _ = _distill_thin(flat2, rank, clamp_quantile, svd_kw.get("n_iter"), generator)
+            for (gi, _, _, _), ud in zip(ents, res):
+                results[gi] = ud
+            continue
         _, deltas = _flat_stacks([(B, N, K) for _, B, N, K in ents], dev)
         pairs, outs = [], []
         for (gi, B, N, K), d in zip(ents, deltas):
