@@ -461,10 +461,19 @@ typedef struct lora_amd_ws_site {
 } lora_amd_ws_site;
 
 int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);
+/* K1/K2 input-stationary form (csrc/gemm_xs.hip): the same contract as lora_amd_linear_ws for ONE site — same packed weight
+ * (lora_amd_ws_pack), same site struct (flayout 0: forward; 3: input gradient; bit 2: accumulate into y), same dropout mask
+ * indexing — with the roles turned round: a wave keeps its 32 input rows in registers (a lane's 16-byte piece IS the MFMA
+ * operand), the weight panel goes through LDS.  For the short-contraction / many-row sites: K = 320 or 640
+ * (lora_amd_xs_config returns 0 otherwise).  site->down == NULL: plain Y = X B^T + bias (a merged-weight site).
+ * replaces: lora_diffusion/lora.py:53-58 and its input gradient at those sites. */
+int lora_amd_xs_config(int32_t K, int32_t *panel_cols, int32_t *block_rows);
 int64_t lora_amd_ws_packed_elems(int32_t N, int32_t K);
 /* Pack B (element (n, k) at w[n * stride_n + k * stride_k], n < N, k < K) into fragment order (zero-padded panels). */
 int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, int32_t dtype, void *out,
                      void *stream);
+int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
+                       const lora_amd_ws_site *site, void *stream);
 int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
                        const lora_amd_ws_site *sites /* host array */, int32_t nsites, int32_t row_groups, void *stream);
 

@@ -214,12 +214,12 @@ __device__ void arrive_and_finish(const Finish &f, int site, int64_t block_begin
   __shared__ double dsum[4][256];
   const int t = threadIdx.x;
   if (nblocks > 1) {
-    *gl(f.part + (block_begin + local_block) * 256 + t) = mine;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the slab goes out WRITE-THROUGH (agent-scope relaxed store = sc1): no release fence — a buffer_wbl2 per block, ~1500
+    // blocks per launch, was most of this kernel's time in the round's first form (68 us against 10 without the hand-off)
+    __hip_atomic_store(f.part + (block_begin + local_block) * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the arrival
     __syncthreads();
     if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned prev = __hip_atomic_fetch_add(f.counters + site, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = prev == (unsigned)(nblocks - 1);
       if (last) {
@@ -448,15 +448,13 @@ __global__ __launch_bounds__(256) void thin_rotate_kernel(const Site *__restrict
     int br = s_row[0][t];
     for (int w = 1; w < 4; ++w)
       if (s_abs[w][t] > ba || (s_abs[w][t] == ba && s_row[w][t] < br)) { ba = s_abs[w][t]; bv = s_val[w][t]; br = s_row[w][t]; }
-    *gl(so.part + blk * 32 + t) = ba;
-    *gl(so.part + blk * 32 + 16 + t) = bv;
-    *gl(so.rowpart + blk * 16 + t) = br;
+    __hip_atomic_store(so.part + blk * 32 + t, ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through, as above
+    __hip_atomic_store(so.part + blk * 32 + 16 + t, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(so.rowpart + blk * 16 + t, br, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned prev = __hip_atomic_fetch_add(so.counters + site, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = prev == (unsigned)(st.blocks - 1);
     if (last) {
@@ -551,9 +549,9 @@ __global__ __launch_bounds__(256) void thin_select_kernel(const QSite *__restric
     if (pass == 2) {
       const unsigned m4 = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
       if (m4 != 0xffffffffu) __hip_atomic_fetch_min(&state[site].next_key, m4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (everything this block published went through device-scope atomics: nothing to write back, no release fence)
     const unsigned prev = __hip_atomic_fetch_add(counters + site, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = prev == (unsigned)(st.blocks - 1);
     if (last) {

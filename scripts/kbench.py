@@ -192,6 +192,46 @@ def bench_linear(args):
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
 
 
+def bench_xs(args):
+    """K1/K2 input-stationary kernel (gemm_xs.hip) per site shape: forward with the LoRA branch, with dropout, the plain
+    product on a packed weight (what a merged-weight site would run), the input gradient — next to the weight-stationary
+    kernel, the library GEMM alone and the library GEMM + one branch launch."""
+    r = args.rank
+    HBM = 8.0e12
+    shapes = ((16384, 320, 320), (16384, 320, 960), (16384, 320, 2560), (4096, 640, 640), (4096, 640, 1920), (4096, 640, 5120),
+              (9216, 320, 320), (9216, 320, 2560), (2304, 640, 640), (2304, 640, 5120))
+    for (M, K, N) in shapes:
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV).to(torch.bfloat16)
+        A = torch.randn(r, K, device=DEV) * 0.25
+        B = torch.randn(N, r, device=DEV) * 0.05
+        byts = (M * K + N * K + M * N) * 2 + (N + K) * r * 4 + M * r * 4
+        res = dict(M=M, K=K, N=N, r=r, MB=round(byts / 1e6, 2), floor_us_8TBs=round(byts / HBM * 1e6, 2))
+        wp = _C.ws_pack(W)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        site = dict(wp=wp, N=N, bias=bias, down=A, up=B, scale=1e-3, y=y)
+        res["xs_us"] = timeit(lambda: _C.linear_xs(x, site), args.iters)[0] * 1e6
+        res["xs_frac8"] = byts / (res["xs_us"] * 1e-6) / HBM
+        res["xs_drop_us"] = timeit(lambda: _C.linear_xs(x, dict(site, p=0.1, seed=7, off=11)), args.iters)[0] * 1e6
+        res["xs_plain_us"] = timeit(lambda: _C.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6
+        res["ws_us"] = timeit(lambda: _C.linear_ws(x, [site]), args.iters)[0] * 1e6
+        res["ws_drop_us"] = timeit(lambda: _C.linear_ws(x, [dict(site, p=0.1, seed=7, off=11)]), args.iters)[0] * 1e6
+        res["lib_gemm_us"] = timeit(lambda: torch.nn.functional.linear(x, W, bias), args.iters)[0] * 1e6
+        if _C.fused_ok(x, N, r):
+            res["lib_gemm_plus_lora_us"] = timeit(lambda: _C.linear_fwd_(x, torch.nn.functional.linear(x, W, bias), A, B, 1e-3,
+                                                                         None, 0.0, 0, 0), args.iters)[0] * 1e6
+        if N in (320, 640):
+            g = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+            wpt = _C.ws_pack(W, True)
+            dx = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+            st = dict(wp=wpt, N=K, down=B, up=A, scale=1.0, t_scale=1.0, flayout=3, y=dx)
+            res["xs_dx_us"] = timeit(lambda: _C.linear_xs(g, st), args.iters)[0] * 1e6
+            res["ws_dx_us"] = timeit(lambda: _C.linear_ws(g, [st]), args.iters)[0] * 1e6
+            res["lib_dx_us"] = timeit(lambda: g @ W, args.iters)[0] * 1e6
+        print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+
+
 def bench_ws(args):
     """K1/K2 weight-stationary fused GEMM (gemm_ws.hip) vs the LDS-ring kernel and the library GEMM + linear_fwd."""
     r = 4
@@ -556,7 +596,9 @@ if __name__ == "__main__":
         bench_mstep(a)
     if "linear" in a.what:
         bench_linear(a)
-    if "ws" in a.what:
+    if "xs" in a.what.split(","):
+        bench_xs(a)
+    if "ws" in a.what.split(","):
         bench_ws(a)
     if "conv" in a.what:
         bench_conv(a)

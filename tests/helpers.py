@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import importlib.util
+import contextlib
 import os
 import sys
 
@@ -225,3 +226,27 @@ def philox_dropout_mask(numel: int, p: float, seed: int, offset: int, device="cp
     words = torch.stack([c0, c1, c2, c3], dim=1)                          # [n/8, 4]
     u16 = torch.stack([words & 0xFFFF, words >> 16], dim=2).reshape(-1)   # element 2i = low half, 2i+1 = high half
     return (u16 >= thr).to(torch.float32) * keep
+
+
+@contextlib.contextmanager
+def oracle_on_device():
+    """Evaluate the oracle's plain-torch op sequence (oracle/torch_ref.py) ON the GPU in f32 instead of on the host: the
+    SD1.5-size whole steps take the host a minute each and the GPU suite has a time limit.  Inside this context the stand-in
+    host model runs library kernels only — the fused host passes of csrc/hostops.hip, head padding and grouped projections are
+    switched off — so the oracle stays independent of every hand-written kernel; f32 GEMMs / convolutions on ROCm are true f32
+    (no TF32 on gfx950).  Kernel-level parity tests keep the host (numpy / f64) oracle."""
+    from lora_amd.standin import fused
+
+    prev = fused._ENABLED
+    env = {k: os.environ.get(k) for k in ("LORA_AMD_HEAD_PAD", "LORA_AMD_GROUP_QKV")}
+    fused._ENABLED = False
+    os.environ["LORA_AMD_HEAD_PAD"] = os.environ["LORA_AMD_GROUP_QKV"] = "0"
+    try:
+        yield
+    finally:
+        fused._ENABLED = prev
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -165,7 +165,18 @@ def test_distill_largest_conv_site_on_device_vs_reference_recipe():
     K = Ci * 9
     tuned, base = _planted(N, K, r + 4, 2e-3 / (N ** 0.5 + K ** 0.5), 2, "cpu")
     res = (tuned - base).float()
-    up_ref, down_ref, hi_ref, U_ref, Vh_ref = _reference_recipe(res, r, 0.99)
+    # the reference's recipe (cli_svd.py:57-74: exact SVD, top r, signed-quantile clamp).  LAPACK's thin SVD of this 1280 x
+    # 23040 matrix takes the host 40 s; the SAME top-r triplets come from the f64 eigen-decomposition of the 1280 x 1280 Gram
+    # matrix dW dW^T (exact to ~1e-13 here: sigma_8 / sigma_1 = 0.03), evaluated with library f64 kernels
+    A = res.double().to(DEV)
+    ev, Q = torch.linalg.eigh(A @ A.T)
+    Sg = ev.flip(0)[:r].sqrt()
+    Ur = Q.flip(1)[:, :r]
+    U_ref = (Ur * Sg).float().cpu()
+    Vh_ref = ((Ur.T @ A) / Sg[:, None]).float().cpu()
+    hi_ref = float(torch.quantile(torch.cat([U_ref.flatten(), Vh_ref.flatten()]), 0.99))
+    up_ref, down_ref = U_ref.clamp(-hi_ref, hi_ref), Vh_ref.clamp(-hi_ref, hi_ref)
+    del A, Q
     t4, b4 = tuned.view(N, Ci, 3, 3).to(DEV), base.view(N, Ci, 3, 3).to(DEV)
     up, down = S.distill_pair(t4, b4, r, 0.99, generator=torch.Generator(device=DEV).manual_seed(0))
     assert up.shape == (N, r) and down.shape == (r, K) and up.is_cuda
@@ -428,23 +439,25 @@ def test_ragged_svd_of_several_shape_groups_vs_exact_svd():
 
 
 # ----------------------------------------------------------------------------- the benchmarked configuration vs the oracle
-def _sd15_twins(r=4):
-    """SD1.5-size UNet twice: bf16 on the device exactly as bench.py builds it, f32 on the host with the same
-    (bf16-representable) frozen values and the reference-algorithm adapters; same factor values (up != 0)."""
+def _sd15_twins(r=4, ref_device=DEV):
+    """SD1.5-size UNet twice: bf16 on the device exactly as bench.py builds it, and the f32 oracle twin with the same
+    (bf16-representable) frozen values and the reference-algorithm adapters; same factor values (up != 0).  The oracle twin
+    lives on ``ref_device``: the GPU by default (its steps are then evaluated inside ``H.oracle_on_device()``: library
+    kernels only, f32 — the host needs a minute per SD1.5-size step)."""
     sys.path.insert(0, H.REPO)
     from bench import build_unet
 
     dev_unet = build_unet(torch.device(DEV), torch.bfloat16, seed=0)
     with torch.device("meta"):
         ref = sd15_unet()
-    ref.to_empty(device="cpu")
-    ref.load_state_dict({k: v.float().cpu() for k, v in dev_unet.state_dict().items()})
+    ref.to_empty(device=ref_device)
+    ref.load_state_dict({k: v.float().to(ref_device) for k, v in dev_unet.state_dict().items()})
     ref.requires_grad_(False)
     ref_params = TR.inject(ref, L.UNET_DEFAULT_TARGET_REPLACE, r=r)
     g = torch.Generator().manual_seed(11)
     for s_ in TR.sites_of(ref):
-        s_.up.data.copy_(torch.randn(s_.up.shape, generator=g) * 0.02)
-        s_.down.data.copy_(torch.randn(s_.down.shape, generator=g) / r)
+        s_.up.data.copy_((torch.randn(s_.up.shape, generator=g) * 0.02).to(ref_device))
+        s_.down.data.copy_((torch.randn(s_.down.shape, generator=g) / r).to(ref_device))
     L.inject_trainable_lora(dev_unet, r=r)
     T.promote_lora_to_fp32(dev_unet)
     ours = [m for m in dev_unet.modules() if isinstance(m, L.LoraInjectedLinear)]
@@ -459,7 +472,8 @@ def _sd15_twins(r=4):
 
 @pytest.fixture(scope="module")
 def sd15_reference_step():
-    """One batch-1 512^2 step of the oracle (f32, host): loss and every LoRA gradient, computed once per module."""
+    """One batch-1 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
+    every LoRA gradient, computed once per module."""
     ref, ref_params, dev_unet = _sd15_twins()
     g = torch.Generator().manual_seed(123)
     lat = torch.randn(1, 4, 64, 64, generator=g) * 0.18215
@@ -471,12 +485,14 @@ def sd15_reference_step():
     grads = {}
     hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(ref_params)]
     opt = torch.optim.SGD(ref_params, lr=0.0)
-    loss = TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat, noise, ts, ehs,
-                              DDPMScheduler().alphas_cumprod, max_grad_norm=1e30)
+    with H.oracle_on_device():
+        loss = TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat.to(DEV), noise.to(DEV), ts.to(DEV),
+                                  ehs.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV), max_grad_norm=1e30)
     for h in hooks:
         h.remove()
-    g_ref = [grads[i].reshape(-1).numpy() for i in range(len(ref_params))]
+    g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))]
     del ref
+    torch.cuda.empty_cache()
     return dict(loss=float(loss), grads=g_ref, dev_unet=dev_unet, lat=lat, ehs=ehs, noise=noise, ts=ts)
 
 

@@ -342,7 +342,7 @@ LR_STEPS = 1e-2  # large enough that ONE AdamW update (+-lr per element at step 
 
 @pytest.fixture(scope="module")
 def sd15_three_reference_steps():
-    """Three dreambooth steps of the oracle (f32, host) on ONE fixed batch-1 512^2 batch: per step the loss, every LoRA
+    """Three dreambooth steps of the oracle (f32; its plain torch ops on the GPU, ``H.oracle_on_device``) on ONE fixed batch-1 512^2 batch: per step the loss, every LoRA
     gradient and the parameters / Adam moments after the update.  The batch is the same every step, so whatever changes
     from step to step comes from the optimiser update alone."""
     ref, ref_params, dev_unet = _sd15_twins()
@@ -352,20 +352,23 @@ def sd15_three_reference_steps():
     noise = torch.randn(1, 4, 64, 64, generator=g).to(torch.bfloat16).float()
     ts = torch.randint(0, 1000, (1,), generator=g)
     opt = torch.optim.AdamW(ref_params, lr=LR_STEPS, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
-    start = torch.cat([p.detach().reshape(-1) for p in ref_params]).clone()
+    start = torch.cat([p.detach().reshape(-1) for p in ref_params]).cpu().clone()
     steps = []
-    for _ in range(3):
-        grads = {}
-        hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(ref_params)]
-        loss = TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat, noise, ts, ehs,
-                                  DDPMScheduler().alphas_cumprod, max_grad_norm=1.0)
-        for h in hooks:
-            h.remove()
-        steps.append(dict(loss=float(loss), grads=[grads[i].reshape(-1).numpy() for i in range(len(ref_params))],
-                          after=torch.cat([p.detach().reshape(-1) for p in ref_params]).clone(),
-                          m=torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref_params]).clone(),
-                          v=torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref_params]).clone()))
-    del ref
+    acp = DDPMScheduler().alphas_cumprod.to(DEV)
+    with H.oracle_on_device():  # the oracle's plain torch ops, f32, evaluated on the GPU (library kernels only)
+        for _ in range(3):
+            grads = {}
+            hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(ref_params)]
+            loss = TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat.to(DEV), noise.to(DEV),
+                                      ts.to(DEV), ehs.to(DEV), acp, max_grad_norm=1.0)
+            for h in hooks:
+                h.remove()
+            steps.append(dict(loss=float(loss), grads=[grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))],
+                              after=torch.cat([p.detach().reshape(-1) for p in ref_params]).cpu().clone(),
+                              m=torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ref_params]).cpu().clone(),
+                              v=torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ref_params]).cpu().clone()))
+    del ref, opt
+    torch.cuda.empty_cache()
     return dict(steps=steps, start=start, dev_unet=dev_unet, lat=lat, ehs=ehs, noise=noise, ts=ts)
 
 
@@ -600,17 +603,17 @@ def test_sd15_unet_plus_clip_rank8_step_matches_oracle(monkeypatch):
     dev_te.requires_grad_(False)
     with torch.device("meta"):
         ref_unet = sd15_unet()
-    ref_unet.to_empty(device="cpu")
-    ref_unet.load_state_dict({k: v.float().cpu() for k, v in dev_unet.state_dict().items()})
-    ref_te = clip_text_model()
-    ref_te.load_state_dict({k: v.float().cpu() for k, v in dev_te.state_dict().items()})
+    ref_unet.to_empty(device=DEV)   # the oracle twins live on the GPU too: evaluated under H.oracle_on_device() below
+    ref_unet.load_state_dict({k: v.float() for k, v in dev_unet.state_dict().items()})
+    ref_te = clip_text_model().to(DEV)
+    ref_te.load_state_dict({k: v.float() for k, v in dev_te.state_dict().items()})
     ref_unet.requires_grad_(False), ref_te.requires_grad_(False)
     p_unet = TR.inject(ref_unet, L.UNET_DEFAULT_TARGET_REPLACE, r=r)
     p_te = TR.inject(ref_te, ["CLIPAttention"], r=r)
     g = torch.Generator().manual_seed(11)
     for s_ in TR.sites_of(ref_unet) + TR.sites_of(ref_te):
-        s_.up.data.copy_(torch.randn(s_.up.shape, generator=g) * 0.02)
-        s_.down.data.copy_(torch.randn(s_.down.shape, generator=g) / r)
+        s_.up.data.copy_((torch.randn(s_.up.shape, generator=g) * 0.02).to(DEV))
+        s_.down.data.copy_((torch.randn(s_.down.shape, generator=g) / r).to(DEV))
     L.inject_trainable_lora(dev_unet, r=r)
     L.inject_trainable_lora(dev_te, target_replace_module=["CLIPAttention"], r=r)
     T.promote_lora_to_fp32(dev_unet), T.promote_lora_to_fp32(dev_te)
@@ -631,12 +634,15 @@ def test_sd15_unet_plus_clip_rank8_step_matches_oracle(monkeypatch):
     grads = {}
     hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(params)]
     opt = torch.optim.SGD(params, lr=0.0)
-    loss_ref = float(TR.dreambooth_step(lambda x, tt, c: ref_unet(x, tt, ref_te(c)[0]).sample, params, opt, lat, noise, ts,
-                                        ids, DDPMScheduler().alphas_cumprod, max_grad_norm=1e30))
+    with H.oracle_on_device():
+        loss_ref = float(TR.dreambooth_step(lambda x, tt, c: ref_unet(x, tt, ref_te(c)[0]).sample, params, opt, lat.to(DEV),
+                                            noise.to(DEV), ts.to(DEV), ids.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV),
+                                            max_grad_norm=1e30))
     for h in hooks:
         h.remove()
-    g_ref = [grads[i].reshape(-1).numpy() for i in range(len(params))]
+    g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(params))]
     del ref_unet, ref_te
+    torch.cuda.empty_cache()
 
     monkeypatch.setenv("LORA_AMD_HEAD_PAD", "1")
     monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1")
@@ -695,14 +701,14 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
     dev_unet = build_unet(torch.device(DEV), torch.bfloat16, seed=0)
     with torch.device("meta"):
         ref = sd15_unet()
-    ref.to_empty(device="cpu")
-    ref.load_state_dict({k: v.float().cpu() for k, v in dev_unet.state_dict().items()})
+    ref.to_empty(device=DEV)   # the oracle twin on the GPU too: evaluated under H.oracle_on_device() below
+    ref.load_state_dict({k: v.float() for k, v in dev_unet.state_dict().items()})
     ref.requires_grad_(False)
     ref_params = TR.inject(ref, L.UNET_EXTENDED_TARGET_REPLACE, r=r, dropout_p=p_drop, conv=True)
     g = torch.Generator().manual_seed(11)
     for s_ in TR.sites_of(ref):
-        s_.up.data.copy_(torch.randn(s_.up.shape, generator=g) * 0.02)
-        s_.down.data.copy_(torch.randn(s_.down.shape, generator=g) / r)
+        s_.up.data.copy_((torch.randn(s_.up.shape, generator=g) * 0.02).to(DEV))
+        s_.down.data.copy_((torch.randn(s_.down.shape, generator=g) / r).to(DEV))
     monkeypatch.setenv("LORA_AMD_HEAD_PAD", "1")
     monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1")
     monkeypatch.setattr(fused, "_ENABLED", True)
@@ -790,14 +796,14 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
             if kind == "linear":
                 rows = x.numel() // x.shape[-1]
                 N = mod.up.shape[0]
-                mod.mask = H.philox_dropout_mask(rows * N, p_drop, seed, off).view(*x.shape[:-1], N)
+                mod.mask = H.philox_dropout_mask(rows * N, p_drop, seed, off, DEV).view(*x.shape[:-1], N)
             else:
                 B, _, Hh, Ww = x.shape
                 f = mod.frozen
                 Ho = (Hh + 2 * f.padding[0] - f.dilation[0] * (f.kernel_size[0] - 1) - 1) // f.stride[0] + 1
                 Wo = (Ww + 2 * f.padding[1] - f.dilation[1] * (f.kernel_size[1] - 1) - 1) // f.stride[1] + 1
                 Co = mod.up.shape[0]
-                flatm = H.philox_dropout_mask(B * Co * Ho * Wo, p_drop, seed, off)
+                flatm = H.philox_dropout_mask(B * Co * Ho * Wo, p_drop, seed, off, DEV)
                 mod.mask = flatm.view(B, Ho, Wo, Co).permute(0, 3, 1, 2) if nhwc else flatm.view(B, Co, Ho, Wo)
         return site.register_forward_pre_hook(pre_hook)
 
@@ -805,11 +811,12 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
     grads = {}
     ghooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(ref_params)]
     opt = torch.optim.SGD(ref_params, lr=0.0)
-    loss_ref = float(TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat, noise, ts, ehs,
-                                        DDPMScheduler().alphas_cumprod, max_grad_norm=1e30))
+    with H.oracle_on_device():
+        loss_ref = float(TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat.to(DEV), noise.to(DEV),
+                                            ts.to(DEV), ehs.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV), max_grad_norm=1e30))
     for h in hooks + ghooks:
         h.remove()
-    g_ref = [grads[i].reshape(-1).numpy() for i in range(len(ref_params))]
+    g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))]
     assert abs(loss - loss_ref) <= 0.01 * abs(loss_ref), (loss, loss_ref)
     cos = _grad_cos(flat, g_ref)
     assert cos >= 0.99, cos
