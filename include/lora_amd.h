@@ -466,8 +466,11 @@ int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);
  * indexing — with the roles turned round: a wave keeps its 32 input rows in registers (a lane's 16-byte piece IS the MFMA
  * operand), the weight panel goes through LDS.  For the short-contraction / many-row sites: K = 320 or 640
  * (lora_amd_xs_config returns 0 otherwise).  site->down == NULL: plain Y = X B^T + bias (a merged-weight site).
+ * site->reserved = 1: site->wp is the row-major weight [N][K] itself (no packed copy).
  * replaces: lora_diffusion/lora.py:53-58 and its input gradient at those sites. */
 int lora_amd_xs_config(int32_t K, int32_t *panel_cols, int32_t *block_rows);
+/* measurement override (scripts/kbench.py): 16-row slabs per wave (1, 2, 4) and panels per workgroup; 0 = choose */
+void lora_amd_xs_set_tuning(int32_t slabs, int32_t panels_per_group);
 int64_t lora_amd_ws_packed_elems(int32_t N, int32_t K);
 /* Pack B (element (n, k) at w[n * stride_n + k * stride_k], n < N, k < K) into fragment order (zero-padded panels). */
 int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, int32_t dtype, void *out,

@@ -44,7 +44,7 @@ SYMBOLS = (
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
-    "lora_amd_xs_config", "lora_amd_linear_xs",
+    "lora_amd_xs_config", "lora_amd_xs_set_tuning", "lora_amd_linear_xs",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd", "lora_amd_conv3_nhwc_bwd_dx",
     "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
@@ -347,6 +347,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_xs_config.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     lib.lora_amd_linear_xs.argtypes = [vp, i64, i64, i32, i32, C.POINTER(WsSite), vp]
     lib.lora_amd_xs_config.restype = lib.lora_amd_linear_xs.restype = C.c_int
+    lib.lora_amd_xs_set_tuning.argtypes = [i32, i32]
+    lib.lora_amd_xs_set_tuning.restype = None
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
@@ -1815,12 +1817,17 @@ def linear_xs(x: torch.Tensor, s: dict):
     bias = s.get("bias")
     d.wp, d.bias, d.y, d.down, d.up, d.t_out = s["wp"].data_ptr(), _ptr(bias), y.data_ptr(), _ptr(down), _ptr(up), _ptr(t)
     d.ldy, d.N, d.r, d.panel_begin, d.flayout = y.stride(0), N, r, 0, fl
+    d.reserved = 1 if s.get("rowmajor") else 0   # ``wp`` = the [N, K] weight itself (contiguous rows) instead of its pack
     d.scale, d.t_scale = float(s.get("scale", 1.0)), float(s.get("t_scale", 1.0))
     off_s, off_p = _off(s.get("off", 0))
     d.dropout_p, d.seed, d.offset, d.offset_dev = float(s.get("p", 0.0)), int(s.get("seed", 0)), off_s, off_p
     _check(lib.lora_amd_linear_xs(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), C.byref(d), _stream()),
            "lora_amd_linear_xs")
     return y, t
+
+
+def xs_set_tuning(slabs: int = 0, panels_per_group: int = 0) -> None:
+    require().lora_amd_xs_set_tuning(int(slabs), int(panels_per_group))
 
 
 def linear_xs_fwd(x, weight, bias, down, up, scale, p: float = 0.0, seed: int = 0, off=0):

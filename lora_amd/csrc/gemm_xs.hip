@@ -19,9 +19,17 @@
 //   * the low-rank branch never leaves the matrix pipe: T^T = down X^T (down as hi + lo 16-bit fragments, built once per
 //     workgroup into LDS) lands as lane (row, g) -> T[row][4g .. 4g+3], which IS the B operand of the rank product against
 //     the up fragment {up_hi[4g..], up_hi[4g..]} x {T_hi[4g..], T_lo[4g..]} (+ one MFMA for up_lo T_hi): f32-grade factors;
-//   * blocks that share rows are 8 apart in the grid (same XCD by the observed b % 8 placement): the second panel's input
-//     comes out of that XCD's L2.
-// Same entry contract as lora_amd_linear_ws (one site), same packed weight: the two kernels are routed per shape.
+//   * a workgroup walks PG consecutive panels with its rows RESIDENT (the input is read from HBM once per column group, not
+//     once per panel): two LDS buffers, panel p + 1 arrives by LDS-DMA while panel p is multiplied; one barrier per panel and a
+//     COUNTED vmcnt wait (the only younger operations are the NCT x SL output stores of the previous panel, always issued —
+//     rows / columns out of range store to a trash line — so the next panel's DMA is never drained behind them);
+//   * blocks that share rows are 8 apart in the grid (same XCD by the observed b % 8 placement): the other column groups'
+//     input comes out of that XCD's L2.
+// Same entry contract as lora_amd_linear_ws (one site), same packed weight (or the row-major weight itself: site.reserved = 1);
+// the two kernels are routed per shape.
+// Measured (profiles/r05_kbench_xs.log): at (16384, 320, 320) the library GEMM, the weight-stationary kernel and this one all
+// take 12-13 us for 21 MB — launch, load, multiply and store phases of ONE wave of workgroups do not overlap, the problem is
+// two bandwidth-delay products small; the wide sites (N >= 4 K) are where the input-resident loop pays.
 #include <algorithm>
 
 #include "common.hpp"
@@ -70,47 +78,75 @@ __device__ __forceinline__ void xs_split4(const float (&v)[4], xu32x2 &hi, xu32x
 struct XsArgs {
   const void *x;
   int64_t ldx, M;
-  int32_t npanels, nrb;
+  int32_t npanels, nrb, pg, ncg;   // panels of the site, row blocks, panels per workgroup, column groups
+  int32_t nct_total, reserved;     // 16-column tiles the packed operand holds (its zero padding included)
   lora_amd_ws_site site;
 };
+
+// Stores of rows / columns out of range go here: a store that is always issued keeps the per-panel VMEM operation count exact,
+// which the counted s_waitcnt of the panel loop relies on; every lane may write the same 8 bytes.
+__device__ char g_xs_trash[64];
 
 // KF = K / 32; NCT = 16-column tiles per panel; SL = 16-row slabs per wave; FL = factor layout (0: down [r, K], up [N, r];
 // 3: down [K, r], up [r, N]: the input-gradient call); DROP as in csrc/gemm_ws.hip: forward — the rank term keeps its own
 // accumulator and is multiplied by the lane's mask values; backward — the input fragments that feed T are ANDed with the
 // forward's mask, 1 / (1 - p) goes into T.  LORA = false: plain Y = X B^T + bias (the merged-weight sites).
 template <class E, int KF, int NCT, int SL, int FL, bool DROP, bool LORA>
-__global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 1) void linear_xs_kernel(const XsArgs a) {
+__global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
   using S = typename E::storage;
   constexpr int K = KF * 32;
-  constexpr int PANEL = NCT * KF * 1024;             // bytes
+  constexpr int PANEL = NCT * KF * 1024;             // bytes of one panel image
   constexpr int TF = (KF + 3) / 4;                   // k-steps of `down` one wave converts
-  __shared__ __attribute__((aligned(1024))) char smem[PANEL + (LORA ? 2 * KF * 1024 : 0)];
-  char *sdown = smem + PANEL;                        // [KF][hi 1 KB | lo 1 KB]
+  constexpr int NDMA = (NCT * KF + 3) / 4;           // 1 KB pieces of a panel per wave
+  constexpr int NST = NCT * SL;                      // output stores per wave and panel (always issued)
+  static_assert(2 * PANEL + 2 * KF * 1024 <= 160 * 1024, "LDS budget");
+  static_assert(NST <= 63, "vmcnt field");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * PANEL + (LORA ? 2 * KF * 1024 : 0)];
+  char *sdown = smem + 2 * PANEL;                    // [KF][hi 1 KB | lo 1 KB]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  // blocks b and b + 8 share their rows (same XCD): b = (rb / 8) * 8 np + pn * 8 + rb % 8
-  const int np = a.npanels;
-  const int grp = blockIdx.x / (8 * np), rem = blockIdx.x - grp * 8 * np;
-  const int pn = rem >> 3, rb = grp * 8 + (rem & 7);
+  // blocks b and b + 8 share their rows (same XCD): b = (rb / 8) * 8 ncg + cg * 8 + rb % 8
+  const int ncg = a.ncg;
+  const int grp = blockIdx.x / (8 * ncg), rem = blockIdx.x - grp * 8 * ncg;
+  const int cg = rem >> 3, rb = grp * 8 + (rem & 7);
   if (rb >= a.nrb) return;
   const lora_amd_ws_site &st = a.site;
   const int N = st.N, r = st.r;
   const int64_t M = a.M, ldx = a.ldx;
   const S *x = reinterpret_cast<const S *>(a.x);
-  const int n0 = pn * NCT * 16;
+  const int p_begin = cg * a.pg, p_end = min(p_begin + a.pg, a.npanels);
   const int64_t row0 = ((int64_t)rb * 4 + wave) * (16 * SL);
+  const bool rowmajor = st.reserved == 1;            // the weight itself ([N, K] rows) instead of the packed operand
 
-  // ---- the weight panel: global -> LDS, 1 KB pieces dealt to the waves (oldest operations)
-  {
-    const S *wp = reinterpret_cast<const S *>(st.wp) + (int64_t)pn * NCT * KF * 512 + lane * 8;
+  // panel pn -> LDS buffer `buf`: 1 KB fragment images dealt to the waves
+  const S *wbase = reinterpret_cast<const S *>(st.wp);
+  auto issue_panel = [&](int pn, int buf) {
+    char *dst = smem + buf * PANEL;
+    if (!rowmajor) {
 #pragma unroll
-    for (int q = 0; q < (NCT * KF + 3) / 4; ++q) {
-      const int piece = wave + 4 * q;
-      if (piece < NCT * KF) xs_glds16(wp + (int64_t)piece * 512, smem + piece * 1024);
+      for (int q = 0; q < NDMA; ++q) {
+        const int piece = wave + 4 * q;                // = ct * KF + s
+        if (piece < NCT * KF) {
+          const int ct = piece / KF, s = piece - ct * KF;
+          const int ctg = min(pn * NCT + ct, a.nct_total - 1);   // a tile past the packed operand: its columns are >= N
+          xs_glds16(wbase + ((int64_t)ctg * KF + s) * 512 + lane * 8, dst + piece * 1024);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NDMA; ++q) {
+        const int piece = wave + 4 * q;                // = ct * KF + s
+        if (piece < NCT * KF) {
+          const int ct = piece / KF, s = piece - ct * KF;
+          const int n = pn * NCT * 16 + ct * 16 + l15;
+          xs_glds16(wbase + (int64_t)(n < N ? n : N - 1) * K + s * 32 + lg * 8, dst + piece * 1024);
+        }
+      }
     }
-  }
+  };
+  issue_panel(p_begin, 0);
   // ---- this wave's rows: every 16-byte piece of its SL slabs, all in flight at once
   xu32x4 xr[SL][KF];
   bool rok[SL];
@@ -128,11 +164,30 @@ __global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 
   const uint64_t doff = DROP ? dropout_offset(st.offset, st.offset_dev) : 0;
   const uint32_t dthr = (uint32_t)(st.dropout_p * 65536.0f + 0.5f);
   const float dkeep = DROP ? 1.0f / (1.0f - st.dropout_p) : 1.0f;
+  const float *upp = st.up;
+  const S *biasp = reinterpret_cast<const S *>(st.bias);
   float draw[LORA ? TF : 1][8];
-  float uraw[LORA ? NCT : 1][4];
-  xu32x2 braw[NCT];
+  float uraw[LORA ? NCT : 1][4], unext[LORA ? NCT : 1][4];
+  xu32x2 braw[NCT], bnext[NCT];
+  // the factor / bias pieces of one panel: unconditional loads from clamped addresses (exact operation count), zeroed later
+  auto load_small = [&](int pn, float (&u)[LORA ? NCT : 1][4], xu32x2 (&b)[NCT]) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (LORA) {
+        const int n = pn * NCT * 16 + ct * 16 + l15, nc = n < N ? n : N - 1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int rk = 4 * lg + v, rc = rk < r ? rk : r - 1;
+          u[ct][v] = up_rk ? *gl(upp + (int64_t)rc * N + nc) : *gl(upp + (int64_t)nc * r + rc);
+        }
+      }
+      const int nb = pn * NCT * 16 + ct * 16 + lg * 4;  // 4 consecutive columns: all in range or all out (N % 4 == 0)
+      b[ct] = xu32x2{0u, 0u};
+      if (biasp != nullptr) b[ct] = *gl(reinterpret_cast<const xu32x2 *>(biasp + (nb < N ? nb : N - 4)));
+    }
+  };
   if (LORA) {
-    const float *downp = st.down, *upp = st.up;
+    const float *downp = st.down;
     const int rank = l15 < r ? l15 : r - 1;
 #pragma unroll
     for (int q = 0; q < TF; ++q) {
@@ -146,24 +201,8 @@ __global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 
         draw[q][4] = p1.x; draw[q][5] = p1.y; draw[q][6] = p1.z; draw[q][7] = p1.w;
       }
     }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const int n = n0 + ct * 16 + l15, nc = n < N ? n : N - 1;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int rk = 4 * lg + v, rc = rk < r ? rk : r - 1;
-        const float u = up_rk ? *gl(upp + (int64_t)rc * N + nc) : *gl(upp + (int64_t)nc * r + rc);
-        uraw[ct][v] = (rk < r && n < N) ? u * scale : 0.f;
-      }
-    }
   }
-  const S *biasp = reinterpret_cast<const S *>(st.bias);
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int nb = n0 + ct * 16 + lg * 4;  // 4 consecutive columns: all in range or all out (N % 4 == 0)
-    braw[ct] = xu32x2{0u, 0u};
-    if (biasp != nullptr) braw[ct] = *gl(reinterpret_cast<const xu32x2 *>(biasp + (nb < N ? nb : N - 4)));
-  }
+  load_small(p_begin, unext, bnext);
   // ---- `down` -> hi / lo fragments in LDS (each wave its share of the k-steps)
   if (LORA) {
 #pragma unroll
@@ -182,7 +221,7 @@ __global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of this wave have landed (and its rows are here)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first panel's pieces of this wave have landed, its rows are here
   __syncthreads();
 
   // ---- T^T = down X^T: lane (row, g) ends with T[row][4g .. 4g+3]
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 
       float tv[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) tv[v] = tacc[sl][v] * tm;
-      if (pn == 0 && st.t_out != nullptr && rok[sl]) {
+      if (cg == 0 && st.t_out != nullptr && rok[sl]) {
         float *tp = st.t_out + (row0 + sl * 16 + l15) * r + 4 * lg;
         if ((r & 3) == 0) {
           if (4 * lg < r) gl_st4(tp, tv[0] * t_scale, tv[1] * t_scale, tv[2] * t_scale, tv[3] * t_scale);
@@ -233,72 +272,99 @@ __global__ __launch_bounds__(256, (NCT * KF + 2 * KF) * 1024 <= 80 * 1024 ? 2 : 
     }
   }
 
-  // ---- the panel's column tiles
+  // ---- the column group's panels
   S *y = reinterpret_cast<S *>(st.y);
   const int64_t ldy = st.ldy;
   const bool accumulate = (st.flayout & 4) != 0;
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int ncol = n0 + ct * 16 + 4 * lg;  // this lane's 4 output columns
-    xf32x4 acc[SL];
-#pragma unroll
-    for (int sl = 0; sl < SL; ++sl) acc[sl] = xf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KF; ++s) {
-      const xu32x4 wf = *reinterpret_cast<const xu32x4 *>(smem + (ct * KF + s) * 1024 + lane * 16);
-#pragma unroll
-      for (int sl = 0; sl < SL; ++sl) acc[sl] = XsMfma<E>::mma(xs_frag<E>(wf), xs_frag<E>(xr[sl][s]), acc[sl]);
+  for (int pn = p_begin; pn < p_end; ++pn) {
+    const int buf = (pn - p_begin) & 1;
+    if (pn > p_begin) {
+      // the loads issued one iteration ago (this panel's image, its factor / bias pieces) are OLDER than the NST stores that
+      // followed them: a counted wait leaves the stores in flight.  The accumulate form reads y between its stores: drain.
+      if (accumulate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      __syncthreads();   // every wave's pieces are in, and every wave is done with the buffer the next DMA overwrites
     }
-    xu32x4 ua1 = xu32x4{0u, 0u, 0u, 0u}, ua2 = ua1;
-    if (LORA) {
-      xu32x2 hi, lo;
-      xs_split4<E>(uraw[ct], hi, lo);
-      ua1 = xu32x4{hi[0], hi[1], hi[0], hi[1]};
-      ua2 = xu32x4{lo[0], lo[1], 0u, 0u};
-    }
-    union { S s[4]; xu32x2 v; } bb;
-    bb.v = braw[ct];
 #pragma unroll
-    for (int sl = 0; sl < SL; ++sl) {
-      const int64_t row = row0 + sl * 16 + l15;
-      xf32x4 val = acc[sl];
+    for (int ct = 0; ct < NCT; ++ct) {
+      braw[ct] = bnext[ct];
       if (LORA) {
-        if (DROP && FL == 0) {
-          xf32x4 br = XsMfma<E>::mma(xs_frag<E>(ua1), xs_frag<E>(bt1[sl]), xf32x4{0.f, 0.f, 0.f, 0.f});
-          br = XsMfma<E>::mma(xs_frag<E>(ua2), xs_frag<E>(bt2[sl]), br);
-          uint32_t rr[4];
-          Philox ph(st.seed);
-          ph((uint64_t)((row * (int64_t)N + ncol) >> 3), doff, rr);   // chunk = 8 consecutive columns of a row of [M, N]
-          const int h4 = (ncol >> 2) & 1;                              // which half of the chunk
-          const uint32_t w0 = rr[2 * h4], w1 = rr[2 * h4 + 1];
-          val[0] += ((w0 & 0xFFFFu) >= dthr) ? br[0] * dkeep : 0.f;
-          val[1] += ((w0 >> 16) >= dthr) ? br[1] * dkeep : 0.f;
-          val[2] += ((w1 & 0xFFFFu) >= dthr) ? br[2] * dkeep : 0.f;
-          val[3] += ((w1 >> 16) >= dthr) ? br[3] * dkeep : 0.f;
-        } else {
-          val = XsMfma<E>::mma(xs_frag<E>(ua1), xs_frag<E>(bt1[sl]), val);
-          val = XsMfma<E>::mma(xs_frag<E>(ua2), xs_frag<E>(bt2[sl]), val);
-        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uraw[ct][v] = unext[ct][v];
       }
-      if (rok[sl] && ncol < N) {
-        S *yp = y + row * ldy + ncol;
+    }
+    if (pn + 1 < p_end) {
+      issue_panel(pn + 1, buf ^ 1);
+      load_small(pn + 1, unext, bnext);
+    }
+    asm volatile("" ::: "memory");
+    const char *pan = smem + buf * PANEL;
+    const int n0 = pn * NCT * 16;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int ncol = n0 + ct * 16 + 4 * lg;  // this lane's 4 output columns
+      xf32x4 acc[SL];
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) acc[sl] = xf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KF; ++s) {
+        const xu32x4 wf = *reinterpret_cast<const xu32x4 *>(pan + (ct * KF + s) * 1024 + lane * 16);
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) acc[sl] = XsMfma<E>::mma(xs_frag<E>(wf), xs_frag<E>(xr[sl][s]), acc[sl]);
+      }
+      xu32x4 ua1 = xu32x4{0u, 0u, 0u, 0u}, ua2 = ua1;
+      if (LORA) {
+        float uv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uv[v] = (4 * lg + v < r && n0 + ct * 16 + l15 < N) ? uraw[ct][v] * scale : 0.f;
+        xu32x2 hi, lo;
+        xs_split4<E>(uv, hi, lo);
+        ua1 = xu32x4{hi[0], hi[1], hi[0], hi[1]};
+        ua2 = xu32x4{lo[0], lo[1], 0u, 0u};
+      }
+      union { S s[4]; xu32x2 v; } bb;
+      bb.v = braw[ct];
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int64_t row = row0 + sl * 16 + l15;
+        xf32x4 val = acc[sl];
+        if (LORA) {
+          if (DROP && FL == 0) {
+            xf32x4 br = XsMfma<E>::mma(xs_frag<E>(ua1), xs_frag<E>(bt1[sl]), xf32x4{0.f, 0.f, 0.f, 0.f});
+            br = XsMfma<E>::mma(xs_frag<E>(ua2), xs_frag<E>(bt2[sl]), br);
+            uint32_t rr[4];
+            Philox ph(st.seed);
+            ph((uint64_t)((row * (int64_t)N + ncol) >> 3), doff, rr);   // chunk = 8 consecutive columns of a row of [M, N]
+            const int h4 = (ncol >> 2) & 1;                              // which half of the chunk
+            const uint32_t w0 = h4 ? rr[2] : rr[0], w1 = h4 ? rr[3] : rr[1];
+            val[0] += ((w0 & 0xFFFFu) >= dthr) ? br[0] * dkeep : 0.f;
+            val[1] += ((w0 >> 16) >= dthr) ? br[1] * dkeep : 0.f;
+            val[2] += ((w1 & 0xFFFFu) >= dthr) ? br[2] * dkeep : 0.f;
+            val[3] += ((w1 >> 16) >= dthr) ? br[3] * dkeep : 0.f;
+          } else {
+            val = XsMfma<E>::mma(xs_frag<E>(ua1), xs_frag<E>(bt1[sl]), val);
+            val = XsMfma<E>::mma(xs_frag<E>(ua2), xs_frag<E>(bt2[sl]), val);
+          }
+        }
+        const bool ok = rok[sl] && ncol < N;
+        S *yp = ok ? y + row * ldy + ncol : reinterpret_cast<S *>(g_xs_trash);
         union { S s[4]; xu32x2 v; } o, old;
         old.v = xu32x2{0u, 0u};
         if (accumulate) old.v = *gl(reinterpret_cast<const xu32x2 *>(yp));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o.s[e] = E::from_f(val[e] + E::to_f(bb.s[e]) + (accumulate ? E::to_f(old.s[e]) : 0.f));
-        *gl(reinterpret_cast<xu32x2 *>(yp)) = o.v;
+        *gl(reinterpret_cast<xu32x2 *>(yp)) = o.v;   // always issued: exactly NST stores per wave and panel
       }
     }
   }
 }
 
-struct XsCfg { int KF, NCT, SL; };
+struct XsCfg { int KF, NCT; };
 inline bool xs_cfg(int K, XsCfg *c) {
   switch (K) {
-    case 320: *c = {10, 5, 2}; return true;   // 50 KB panel + 20 KB down: 2 workgroups per CU
-    case 640: *c = {20, 2, 2}; return true;   // 40 KB + 40 KB
+    case 320: *c = {10, 5}; return true;   // 2 x 50 KB panel images + 20 KB of down fragments
+    case 640: *c = {20, 3}; return true;   // 2 x 60 KB + 40 KB
     default: return false;
   }
 }
@@ -317,11 +383,18 @@ void xs_launch(const XsArgs &a, int fl, bool drop, bool lora, dim3 grid, hipStre
 
 using namespace lora_amd;
 
+static int g_xs_sl = 0, g_xs_pg = 0;   // kbench overrides (0 = choose): slabs per wave, panels per workgroup
+
+extern "C" void lora_amd_xs_set_tuning(int32_t slabs, int32_t panels_per_group) {
+  g_xs_sl = slabs;
+  g_xs_pg = panels_per_group;
+}
+
 extern "C" int lora_amd_xs_config(int32_t K, int32_t *panel_cols, int32_t *block_rows) {
   XsCfg c;
   if (!xs_cfg(K, &c)) return 0;
   if (panel_cols) *panel_cols = c.NCT * 16;
-  if (block_rows) *block_rows = 64 * c.SL;
+  if (block_rows) *block_rows = 64 * 2;
   return 1;
 }
 
@@ -342,26 +415,51 @@ extern "C" int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t
                      (!lora || (((uintptr_t)q.down % 16) == 0 && ((uintptr_t)q.up % 16) == 0)),
                  LORA_AMD_EINVAL, "linear_xs: N, ldy must be multiples of 4, pointers aligned");
   LORA_AMD_CHECK(q.dropout_p >= 0.f && q.dropout_p < 1.f, LORA_AMD_EINVAL, "linear_xs: dropout p=%f", q.dropout_p);
+  LORA_AMD_CHECK(q.reserved == 0 || q.reserved == 1, LORA_AMD_EINVAL, "linear_xs: reserved = 0 (packed weight) or 1 (row-major)");
   const int fl = q.flayout & 3;
   LORA_AMD_CHECK(fl == 0 || fl == 3, LORA_AMD_EINVAL, "linear_xs: factor layout 0 (forward) or 3 (input gradient)");
   const bool drop = lora && q.dropout_p > 0.f;
   LORA_AMD_CHECK(!drop || fl == 3 || q.N % 8 == 0, LORA_AMD_EINVAL, "linear_xs: dropout needs N %% 8 == 0");
-  // the packed weight is padded to lora_amd_ws_packed_elems' panel (a multiple of this kernel's)
-  int bn = 0;
-  lora_amd_ws_config(K, &bn, nullptr);
-  const int npad = (q.N + bn - 1) / bn * bn;
   XsArgs a;
   a.x = x; a.ldx = ldx; a.M = M; a.site = q;
-  a.npanels = npad / (c.NCT * 16);
-  a.nrb = (int)((M + 64 * c.SL - 1) / (64 * c.SL));
-  const dim3 grid((unsigned)(((a.nrb + 7) / 8) * 8 * a.npanels));
-  hipStream_t st = (hipStream_t)stream;
-  if (K == 320) {
-    if (act_dtype == LORA_AMD_BF16) xs_launch<bf16_t, 10, 5, 2>(a, fl, drop, lora, grid, st);
-    else xs_launch<f16_t, 10, 5, 2>(a, fl, drop, lora, grid, st);
-  } else {
-    if (act_dtype == LORA_AMD_BF16) xs_launch<bf16_t, 20, 2, 2>(a, fl, drop, lora, grid, st);
-    else xs_launch<f16_t, 20, 2, 2>(a, fl, drop, lora, grid, st);
+  const int pcols = c.NCT * 16;
+  a.npanels = (q.N + pcols - 1) / pcols;
+  {
+    // the packed operand is padded to lora_amd_ws_packed_elems' panel (the kernel clamps the tiles of its last panel to it)
+    int bn = 0;
+    lora_amd_ws_config(K, &bn, nullptr);
+    a.nct_total = (int)((int64_t)(q.N + bn - 1) / bn * bn / 16);
+    a.reserved = 0;
   }
+  // slabs per wave and panels per workgroup: about one workgroup per CU, the input read as few times as that allows
+  const int sl_max = K == 320 ? 4 : 2;
+  int sl = g_xs_sl > 0 ? g_xs_sl : sl_max;
+  if (g_xs_sl == 0) while (sl > 1 && (M + 64 * sl - 1) / (64 * sl) * 1 < 48) sl >>= 1;   // few rows: smaller blocks
+  if (sl > sl_max) sl = sl_max;
+  if (sl != 1 && sl != 2 && sl != 4) sl = 2;
+  a.nrb = (int)((M + 64 * sl - 1) / (64 * sl));
+  int pg = g_xs_pg;
+  if (pg <= 0) {
+    const int want_groups = std::max(1, (int)((288 + a.nrb - 1) / a.nrb));   // column groups for ~288 workgroups
+    pg = std::max(1, a.npanels / want_groups);
+  }
+  if (pg > a.npanels) pg = a.npanels;
+  a.pg = pg;
+  a.ncg = (a.npanels + pg - 1) / pg;
+  const dim3 grid((unsigned)(((a.nrb + 7) / 8) * 8 * a.ncg));
+  hipStream_t st = (hipStream_t)stream;
+#define XS_DISPATCH(E)                                                                         \
+  do {                                                                                         \
+    if (K == 320) {                                                                            \
+      if (sl == 4) xs_launch<E, 10, 5, 4>(a, fl, drop, lora, grid, st);                        \
+      else if (sl == 2) xs_launch<E, 10, 5, 2>(a, fl, drop, lora, grid, st);                   \
+      else xs_launch<E, 10, 5, 1>(a, fl, drop, lora, grid, st);                                \
+    } else {                                                                                   \
+      if (sl >= 2) xs_launch<E, 20, 3, 2>(a, fl, drop, lora, grid, st);                        \
+      else xs_launch<E, 20, 3, 1>(a, fl, drop, lora, grid, st);                                \
+    }                                                                                          \
+  } while (0)
+  if (act_dtype == LORA_AMD_BF16) XS_DISPATCH(bf16_t); else XS_DISPATCH(f16_t);
+#undef XS_DISPATCH
   return check_launch("lora_amd_linear_xs");
 }

@@ -213,6 +213,15 @@ def bench_xs(args):
         site = dict(wp=wp, N=N, bias=bias, down=A, up=B, scale=1e-3, y=y)
         res["xs_us"] = timeit(lambda: _C.linear_xs(x, site), args.iters)[0] * 1e6
         res["xs_frac8"] = byts / (res["xs_us"] * 1e-6) / HBM
+        sweep = {}
+        for sl in ((1, 2, 4) if K == 320 else (1, 2)):
+            for pg in (1, 2, 4, 8, 64):
+                _C.xs_set_tuning(sl, pg)
+                sweep[f"sl{sl}_pg{pg}"] = round(timeit(lambda: _C.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6, 2)
+        _C.xs_set_tuning(0, 0)
+        res["xs_plain_sweep"] = sweep
+        res["xs_plain_best"] = min(sweep.items(), key=lambda kv: kv[1])
+        res["xs_plain_rowmajor_us"] = timeit(lambda: _C.linear_xs(x, dict(wp=W, N=N, bias=bias, y=y, rowmajor=True)), args.iters)[0] * 1e6
         res["xs_drop_us"] = timeit(lambda: _C.linear_xs(x, dict(site, p=0.1, seed=7, off=11)), args.iters)[0] * 1e6
         res["xs_plain_us"] = timeit(lambda: _C.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6
         res["ws_us"] = timeit(lambda: _C.linear_ws(x, [site]), args.iters)[0] * 1e6

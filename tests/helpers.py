@@ -234,10 +234,14 @@ def oracle_on_device():
     SD1.5-size whole steps take the host a minute each and the GPU suite has a time limit.  Inside this context the stand-in
     host model runs library kernels only — the fused host passes of csrc/hostops.hip, head padding and grouped projections are
     switched off — so the oracle stays independent of every hand-written kernel; f32 GEMMs / convolutions on ROCm are true f32
-    (no TF32 on gfx950).  Kernel-level parity tests keep the host (numpy / f64) oracle."""
+    (no TF32 on gfx950).  Convolutions take ATen's native im2col + rocBLAS path (MIOpen off): exact f32, and no run-time
+    compilation of MIOpen kernels for the oracle's odd shapes (3x3 convs onto 16 channels: a minute of JIT on a fresh box).
+    Kernel-level parity tests keep the host (numpy / f64) oracle."""
     from lora_amd.standin import fused
 
     prev = fused._ENABLED
+    prev_cudnn = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False
     env = {k: os.environ.get(k) for k in ("LORA_AMD_HEAD_PAD", "LORA_AMD_GROUP_QKV")}
     fused._ENABLED = False
     os.environ["LORA_AMD_HEAD_PAD"] = os.environ["LORA_AMD_GROUP_QKV"] = "0"
@@ -245,6 +249,7 @@ def oracle_on_device():
         yield
     finally:
         fused._ENABLED = prev
+        torch.backends.cudnn.enabled = prev_cudnn
         for k, v in env.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -36,9 +36,10 @@ def test_xs_forward_matches_oracle(M, K, N, r, dt):
     close(n(y), yo, absref, dt, k=3e-5, msg="Y")   # f32-grade accumulation + ONE rounding of the output
 
 
-@pytest.mark.parametrize("M,K,N", [(16384, 320, 960), (4096, 640, 640), (300, 320, 100)])
+@pytest.mark.parametrize("M,K,N", [(16384, 320, 960), (4096, 640, 640), (300, 320, 100), (2304, 640, 5120)])
 def test_xs_plain_product_on_a_packed_weight(M, K, N):
-    """site.down == NULL: Y = X W^T + b (what a merged-weight site runs), and the accumulate form Y += X W^T."""
+    """site.down == NULL: Y = X W^T + b (what a merged-weight site runs) from the packed operand AND from the row-major
+    weight itself (site.reserved = 1), and the accumulate form Y += X W^T."""
     dt = "bf16"
     x, w, b = rnd((M, K), dt, 1.0, seed=1), rnd((N, K), dt, 0.05, seed=2), rnd((N,), dt, 0.5, seed=3)
     y, t = _C.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, bias=b))
@@ -47,6 +48,8 @@ def test_xs_plain_product_on_a_packed_weight(M, K, N):
     ref = X @ W.T + Bv
     absref = np.abs(X) @ np.abs(W).T + np.abs(Bv)
     close(n(y), ref, absref, dt, k=3e-5, msg="Y")
+    y_rm, _ = _C.linear_xs(x, dict(wp=w, N=N, bias=b, rowmajor=True))
+    assert torch.equal(y_rm, y)
     y0 = rnd((M, N), dt, 1.0, seed=7)
     y1 = y0.clone()
     _C.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, y=y1, flayout=4))
@@ -104,6 +107,22 @@ def test_xs_dropout_input_gradient_vs_oracle_with_extracted_mask(M, K, N, r, p):
     dx, gt = _C.linear_xs_dx(g, w, down, up, s, p, seed, off)
     close(n(gt), gt_o, s * ((np.abs(G) * mask) @ np.abs(U)), "f32", k=3e-5, msg="Gt")
     close(n(dx), dxo, np.abs(G) @ np.abs(W) + np.abs(gt_o) @ np.abs(A), dt, k=3e-5, msg="dX")
+
+
+@pytest.mark.parametrize("sl,pg", [(1, 1), (2, 3), (4, 2), (4, 64), (2, 1)])
+def test_xs_block_geometries_agree(sl, pg):
+    """Slabs per wave / panels per workgroup are launch geometry only: every choice gives the same bits (one accumulation
+    order per output element), through the panel loop's double-buffered LDS images and counted waits."""
+    M, K, N, r, s = 5000, 320, 2560, 8, 0.7
+    x, w, b = rnd((M, K), "bf16", seed=1), rnd((N, K), "bf16", 0.05, seed=2), rnd((N,), "bf16", seed=3)
+    down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
+    y0, t0 = _C.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
+    try:
+        _C.xs_set_tuning(sl, pg)
+        y1, t1 = _C.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
+    finally:
+        _C.xs_set_tuning(0, 0)
+    assert torch.equal(y0, y1) and torch.equal(t0, t1)
 
 
 def test_xs_and_ws_kernels_agree_on_the_same_site():
