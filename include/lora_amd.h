@@ -262,6 +262,10 @@ typedef struct lora_amd_planes_desc {
 int lora_amd_rowdot16_planes_plan(lora_amd_planes_desc *descs_host, int32_t n, int64_t *grid);
 int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t r, int32_t plane_dtype,
                              void *stream);
+/* The same with the factor given as PACKED fragments (lora_amd_thin_pack): desc.f points at 16-bit elements
+ * [batch][C / 32][hi 512 | lo 512] (the bytes of the f32 [C][16] factor), 16 output columns. */
+int lora_amd_rowdot16_planes_packed(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t plane_dtype,
+                                    void *stream);
 typedef struct lora_amd_split_desc {
   const float *src;
   void *hi, *lo;
@@ -322,6 +326,10 @@ int lora_amd_thin_apply(const lora_amd_thin_site *sites_dev, const int32_t *bloc
 int lora_amd_thin_rotate(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
                          const float *src, const float *mats, int32_t rank, const float *scale_a, const float *scale_b,
                          float *dst, float *sign_part, int32_t *sign_rows, uint32_t *counters, float *sign_out, void *stream);
+/* src [rows][16] f32 of every site -> the (hi, lo) MFMA fragments lora_amd_rowdot16_planes_packed reads, at 16-bit element
+ * offset 2 * off of dst: [rows / 32][hi 512 | lo 512], lane l = (j = l & 15, kq = l >> 4) holds src[32 ks + 8 kq + e][j]. */
+int lora_amd_thin_pack(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                       const float *src, void *dst, int32_t plane_dtype, void *stream);
 /* Order statistics of a site's joint values {u [n_u], v [n_v] * sign[j % rank]} (the distribution cli_svd.py:39-47 takes its
  * quantile of): three launches, pass = 0, 1, 2 (radix 11 + 11 + 10 bits of the order-preserving key); state [nsites][8]
  * uint32 = {0, k, 0, 0xffffffff, 0, 0, 0, 0} before pass 0 with k = the 0-based ascending index wanted; after pass 2
@@ -462,7 +470,7 @@ typedef struct lora_amd_ws_site {
 
 int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);
 /* K1/K2 input-stationary form (csrc/gemm_xs.hip): the same contract as lora_amd_linear_ws for ONE site — same packed weight
- * (lora_amd_ws_pack), same site struct (flayout 0: forward; 3: input gradient; bit 2: accumulate into y), same dropout mask
+ * (lora_amd_ws_pack), same site struct (flayout 0: forward; 3: input gradient; no accumulate form), same dropout mask
  * indexing — with the roles turned round: a wave keeps its 32 input rows in registers (a lane's 16-byte piece IS the MFMA
  * operand), the weight panel goes through LDS.  For the short-contraction / many-row sites: K = 320 or 640
  * (lora_amd_xs_config returns 0 otherwise).  site->down == NULL: plain Y = X B^T + bias (a merged-weight site).

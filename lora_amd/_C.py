@@ -33,7 +33,8 @@ SYMBOLS = (
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
     "lora_amd_rowdot_batched", "lora_amd_colreduce_batched", "lora_amd_chol_inverse_batched",
     "lora_amd_ragged_plan", "lora_amd_rowdot_ragged", "lora_amd_colreduce_ragged", "lora_amd_sub_ragged",
-    "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_split16_ragged", "lora_amd_split16_transpose",
+    "lora_amd_rowdot16_planes_plan", "lora_amd_rowdot16_planes", "lora_amd_rowdot16_planes_packed", "lora_amd_thin_pack",
+    "lora_amd_split16_ragged", "lora_amd_split16_transpose",
     "lora_amd_split16_residual", "lora_amd_thin_gram", "lora_amd_thin_apply", "lora_amd_thin_rotate", "lora_amd_thin_select", "lora_amd_thin_clamp",
     "lora_amd_linear_plan", "lora_amd_linear_fwd", "lora_amd_linear_bwd_g", "lora_amd_linear_bwd_x",
     "lora_amd_linear_bwd_factors", "lora_amd_linear_bwd_factors_drop", "lora_amd_linear_bwd_factors_heads",
@@ -274,6 +275,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_rowdot16_planes.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_split16_ragged.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_rowdot16_planes_plan.restype = lib.lora_amd_rowdot16_planes.restype = C.c_int
+    lib.lora_amd_rowdot16_planes_packed.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_thin_pack.argtypes = [vp, vp, i64, vp, vp, i32, vp]
+    lib.lora_amd_rowdot16_planes_packed.restype = lib.lora_amd_thin_pack.restype = C.c_int
     lib.lora_amd_split16_ragged.restype = C.c_int
     lib.lora_amd_split16_transpose.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_split16_transpose.restype = C.c_int
@@ -774,8 +778,12 @@ class PlanesProgram:
     declared once (``table``), uploaded in one copy, each run one C call.  rows: per shape group (hi [B, M, C], lo, f [B, C, r]
     f32, out [B, M, r] f32)."""
 
-    def __init__(self, device, r: int, plane_dtype: torch.dtype = torch.bfloat16):
-        self.device, self.r, self.dt = device, int(r), plane_dtype
+    def __init__(self, device, r: int, plane_dtype: torch.dtype = torch.bfloat16, packed: bool = False):
+        """``packed``: the factor of every row is given as fragments (``thin_pack``): a 16-bit tensor [B, C * 32] (hi / lo
+        1 KB blocks per 32 rows of the [C, 16] factor) instead of f32 [B, C, r]; r = 16."""
+        self.device, self.r, self.dt, self.packed = device, int(r), plane_dtype, bool(packed)
+        if packed and self.r != 16:
+            raise ValueError("PlanesProgram: packed factors are 16 columns wide")
         self._blobs, self._meta, self._size, self._dev = [], [], 0, None
 
     def table(self, rows) -> int:
@@ -783,9 +791,10 @@ class PlanesProgram:
         arr = (PlanesDesc * len(rows))()
         for d, (hi, lo, f, out) in zip(arr, rows):
             B, M, Cc = hi.shape
-            if hi.dtype != self.dt or lo.dtype != self.dt or f.dtype != torch.float32 or out.dtype != torch.float32:
-                raise TypeError("PlanesProgram: 16-bit planes, f32 factor and output expected")
-            if tuple(lo.shape) != (B, M, Cc) or tuple(f.shape) != (B, Cc, self.r) or tuple(out.shape) != (B, M, self.r):
+            fdt, fshape = (self.dt, (B, Cc * 32)) if self.packed else (torch.float32, (B, Cc, self.r))
+            if hi.dtype != self.dt or lo.dtype != self.dt or f.dtype != fdt or out.dtype != torch.float32:
+                raise TypeError("PlanesProgram: 16-bit planes, f32 (or packed 16-bit) factor and f32 output expected")
+            if tuple(lo.shape) != (B, M, Cc) or tuple(f.shape) != fshape or tuple(out.shape) != (B, M, self.r):
                 raise ValueError(f"PlanesProgram: shape mismatch {tuple(hi.shape)} {tuple(f.shape)} {tuple(out.shape)}")
             if not (hi.is_contiguous() and lo.is_contiguous() and f.is_contiguous() and out.is_contiguous()):
                 raise ValueError("PlanesProgram: contiguous stacks expected")
@@ -804,6 +813,10 @@ class PlanesProgram:
 
     def run(self, handle: int) -> None:
         n, off, grid = self._meta[handle]
+        if self.packed:
+            _check(require().lora_amd_rowdot16_planes_packed(self._dev.data_ptr() + off, n, grid, dtype_code(self.dt), _stream()),
+                   "lora_amd_rowdot16_planes_packed")
+            return
         _check(require().lora_amd_rowdot16_planes(self._dev.data_ptr() + off, n, grid, self.r, dtype_code(self.dt), _stream()),
                "lora_amd_rowdot16_planes")
 
@@ -923,6 +936,12 @@ def thin_rotate(table: ThinTable, src, mats, rank: int, dst, scale_a=None, scale
                                           p(sign_ws[0]) if sign_ws else None, p(sign_ws[1]) if sign_ws else None,
                                           table.counters.data_ptr() if sign_out is not None else None, p(sign_out), _stream()),
            "lora_amd_thin_rotate")
+
+
+def thin_pack(table: ThinTable, src: torch.Tensor, dst: torch.Tensor) -> None:
+    """src [rows][16] f32 per site -> dst: the (hi, lo) fragments of every site at 16-bit element offset 2 * off."""
+    _check(require().lora_amd_thin_pack(table.sites.data_ptr(), table.blockmap.data_ptr(), table.total_blocks, src.data_ptr(),
+                                        dst.data_ptr(), dtype_code(dst.dtype), _stream()), "lora_amd_thin_pack")
 
 
 def thin_select(q: ThinQTable, u, v, sign, rank: int, pass_: int, state, out2) -> None:
@@ -1878,7 +1897,7 @@ def gemm_choice_bwd(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, t: t
         return c
     if torch.cuda.is_current_stream_capturing():
         return static_bwd_choice(M, K, N, ws_ok)
-    gt_part, up_part, down_part = bufs
+    gt_part, up_part, down_part = bufs() if callable(bufs) else bufs
     plan = linear_plan(M, K, N, r)
     ring_ok = gemm_supported(g, weight_t(weight), K, r)
 

@@ -155,12 +155,14 @@ def _quantile_rows(x: torch.Tensor, q: float) -> torch.Tensor:
     n = x.shape[1]
     if not x.is_cuda or not (0.5 <= q <= 1.0) or n < 64:
         return torch.quantile(x, q, dim=1)
+    bad = torch.isnan(x).any(dim=1)   # torch.quantile: a row holding a NaN gives NaN (top-k would sort it as the largest value)
     ranks = torch.tensor(q, dtype=x.dtype) * (n - 1)
     below = ranks.floor()
     lo = int(below.item())
     hi = min(lo + 1, n - 1)
     vals = torch.topk(x, n - lo, dim=1, largest=True, sorted=True).values   # descending: column j = order statistic n - 1 - j
-    return torch.lerp(vals[:, n - 1 - lo], vals[:, n - 1 - hi], float((ranks - below).item()))   # an exact f32 value
+    out = torch.lerp(vals[:, n - 1 - lo], vals[:, n - 1 - hi], float((ranks - below).item()))   # an exact f32 value
+    return torch.where(bad, torch.full_like(out, float("nan")), out)
 
 
 def _clamp_pairs(U: torch.Tensor, Vh: torch.Tensor, clamp_quantile: float):
@@ -254,11 +256,16 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
     else:
         _C.split16_transpose([d.contiguous() for d in deltas], dh, dl, th, tl)
         norm2 = torch.cat([d.square().sum((1, 2)) for d in deltas]) if n_iter is None else None
-    pprog = _C.PlanesProgram(dev, l)
-    p_sketch = pprog.table(list(zip(dh, dl, Zc, Ya)))     # Y = dW Omega
-    p_fwd = pprog.table(list(zip(th, tl, Yb, Za)))        # Z = dW^T Q
-    p_back = pprog.table(list(zip(dh, dl, Zb, Ya)))       # Y = dW Qz
-    p_b = pprog.table(list(zip(th, tl, Yb, Zc)))          # b^T = dW^T Q
+    # the factor of a pass enters the matrix pipe as (hi, lo) 16-bit fragments, packed ONCE per pass (lora_amd_thin_pack) instead
+    # of split per 16-row slab inside it: two coalesced 16-byte loads per k-step in place of eight strided ones + the split
+    st.pky = torch.empty(st.yb.numel() * 2, dtype=torch.bfloat16, device=dev)
+    st.pkz = torch.empty(st.zb.numel() * 2, dtype=torch.bfloat16, device=dev)
+    PY = [st.pky[2 * _elem_off(y, st.ya): 2 * _elem_off(y, st.ya) + B * N * 32].view(B, N * 32) for (B, N, K), y in zip(dims, Ya)]
+    PZ = [st.pkz[2 * _elem_off(z, st.za): 2 * _elem_off(z, st.za) + B * K * 32].view(B, K * 32) for (B, N, K), z in zip(dims, Za)]
+    pprog = _C.PlanesProgram(dev, l, packed=True)
+    p_y = pprog.table(list(zip(dh, dl, PZ, Ya)))          # Y = dW F, F [K, 16] packed in pkz (Omega, then Qz)
+    p_z = pprog.table(list(zip(th, tl, PY, Za)))          # Z = dW^T Q, Q [N, 16] packed in pky
+    p_b = pprog.table(list(zip(th, tl, PY, Zc)))          # b^T = dW^T Q
     pprog.upload()
 
     def orth(tab, a, b, ritz=None):
@@ -270,13 +277,16 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
         _C.thin_apply(tab, a, lin[0], b)
 
     st.zc.normal_(generator=generator)                            # Omega, every site at once
-    pprog.run(p_sketch)
+    _C.thin_pack(st.tz, st.zc, st.pkz)
+    pprog.run(p_y)
     orth(st.ty, st.ya, st.yb)                                     # q in yb
     it, prev = 0, None
     while True:
-        pprog.run(p_fwd)
+        _C.thin_pack(st.ty, st.yb, st.pky)
+        pprog.run(p_z)
         orth(st.tz, st.za, st.zb)                                 # qz in zb
-        pprog.run(p_back)
+        _C.thin_pack(st.tz, st.zb, st.pkz)
+        pprog.run(p_y)
         orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
         it += 1
         if n_iter is not None:
@@ -294,6 +304,7 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
     st.iterations = it
     global LAST_ITERATIONS
     LAST_ITERATIONS = it
+    _C.thin_pack(st.ty, st.yb, st.pky)
     pprog.run(p_b)                                                # b^T [K, l] in zc
     _C.thin_gram(st.tz, st.zc, None, _C.thin_finish(st.tz, 1, rank, 1e-4, linv_out=lin[0]))
     _C.thin_apply(st.tz, st.zc, lin[0], st.za, _C.thin_finish(st.tz, 1, rank, 0.0, linv_out=lin[1]))

@@ -75,6 +75,11 @@ __device__ __forceinline__ void xs_split4(const float (&v)[4], xu32x2 &hi, xu32x
   lo = l.u;
 }
 
+// the factor / bias values of a workgroup's columns live in LDS for the whole kernel (no global load inside the panel loop: a
+// value loaded there and carried to the next iteration made the compiler drain vmcnt to 0 at the loop's back edge)
+constexpr int kXsUpFloats = 8192;   // columns x r4 (r4 = rank rounded up to 4) per workgroup
+constexpr int kXsBiasCols = 2048;
+
 struct XsArgs {
   const void *x;
   int64_t ldx, M;
@@ -99,10 +104,14 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
   constexpr int TF = (KF + 3) / 4;                   // k-steps of `down` one wave converts
   constexpr int NDMA = (NCT * KF + 3) / 4;           // 1 KB pieces of a panel per wave
   constexpr int NST = NCT * SL;                      // output stores per wave and panel (always issued)
-  static_assert(2 * PANEL + 2 * KF * 1024 <= 160 * 1024, "LDS budget");
+  static_assert(2 * PANEL + 2 * KF * 1024 + kXsUpFloats * 4 + kXsBiasCols * 2 <= 160 * 1024, "LDS budget");
   static_assert(NST <= 63, "vmcnt field");
-  __shared__ __attribute__((aligned(1024))) char smem[2 * PANEL + (LORA ? 2 * KF * 1024 : 0)];
-  char *sdown = smem + 2 * PANEL;                    // [KF][hi 1 KB | lo 1 KB]
+  // separate objects: the LDS-DMA writes `smem` only, and the compiler puts an s_waitcnt vmcnt(0) in front of every LDS read
+  // it cannot prove disjoint from a DMA destination
+  __shared__ __attribute__((aligned(1024))) char smem[2 * PANEL];                     // the two panel images
+  __shared__ __attribute__((aligned(16))) char sdown[LORA ? 2 * KF * 1024 : 16];      // [KF][hi 1 KB | lo 1 KB]
+  __shared__ __attribute__((aligned(16))) float sup[LORA ? kXsUpFloats : 4];          // [columns of this workgroup][r4]: scale * up
+  __shared__ __attribute__((aligned(16))) S sbias[kXsBiasCols];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,25 +176,8 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
   const float *upp = st.up;
   const S *biasp = reinterpret_cast<const S *>(st.bias);
   float draw[LORA ? TF : 1][8];
-  float uraw[LORA ? NCT : 1][4], unext[LORA ? NCT : 1][4];
-  xu32x2 braw[NCT], bnext[NCT];
-  // the factor / bias pieces of one panel: unconditional loads from clamped addresses (exact operation count), zeroed later
-  auto load_small = [&](int pn, float (&u)[LORA ? NCT : 1][4], xu32x2 (&b)[NCT]) {
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      if (LORA) {
-        const int n = pn * NCT * 16 + ct * 16 + l15, nc = n < N ? n : N - 1;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int rk = 4 * lg + v, rc = rk < r ? rk : r - 1;
-          u[ct][v] = up_rk ? *gl(upp + (int64_t)rc * N + nc) : *gl(upp + (int64_t)nc * r + rc);
-        }
-      }
-      const int nb = pn * NCT * 16 + ct * 16 + lg * 4;  // 4 consecutive columns: all in range or all out (N % 4 == 0)
-      b[ct] = xu32x2{0u, 0u};
-      if (biasp != nullptr) b[ct] = *gl(reinterpret_cast<const xu32x2 *>(biasp + (nb < N ? nb : N - 4)));
-    }
-  };
+  const int r4 = (r + 3) & ~3;
+  const int c_begin = p_begin * NCT * 16, ncols = (p_end - p_begin) * NCT * 16;   // this workgroup's columns
   if (LORA) {
     const float *downp = st.down;
     const int rank = l15 < r ? l15 : r - 1;
@@ -202,7 +194,19 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
       }
     }
   }
-  load_small(p_begin, unext, bnext);
+  // ---- scale * up and the bias of this workgroup's columns -> LDS
+  if (LORA) {
+    for (int i = tid; i < ncols * r4; i += 256) {
+      const int c = i / r4, rk = i - c * r4, nn = c_begin + c;
+      float u = 0.f;
+      if (rk < r && nn < N) u = (up_rk ? *gl(upp + (int64_t)rk * N + nn) : *gl(upp + (int64_t)nn * r + rk)) * scale;
+      sup[i] = u;
+    }
+  }
+  for (int i = tid; i < ncols; i += 256) {
+    const int nn = c_begin + i;
+    sbias[i] = (biasp != nullptr && nn < N) ? *gl(biasp + nn) : E::from_f(0.f);
+  }
   // ---- `down` -> hi / lo fragments in LDS (each wave its share of the k-steps)
   if (LORA) {
 #pragma unroll
@@ -275,28 +279,20 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
   // ---- the column group's panels
   S *y = reinterpret_cast<S *>(st.y);
   const int64_t ldy = st.ldy;
-  const bool accumulate = (st.flayout & 4) != 0;
   for (int pn = p_begin; pn < p_end; ++pn) {
     const int buf = (pn - p_begin) & 1;
     if (pn > p_begin) {
       // the loads issued one iteration ago (this panel's image, its factor / bias pieces) are OLDER than the NST stores that
-      // followed them: a counted wait leaves the stores in flight.  The accumulate form reads y between its stores: drain.
-      if (accumulate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-      __syncthreads();   // every wave's pieces are in, and every wave is done with the buffer the next DMA overwrites
+      // followed them: a counted wait leaves the stores in flight.  (No accumulate form here: a load of y between the stores —
+      // even one under a branch that is never taken — put an s_waitcnt vmcnt(0) in front of EVERY store: 63 us instead of
+      // ~25 for 96 MB, profiles/r05_kbench_xs_first.log.  Grouped input gradients stay on lora_amd_linear_ws.)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      // every wave's pieces are in, and every wave is done with the buffer the next DMA overwrites.  An LDS-only barrier:
+      // __syncthreads() drains vmcnt to 0 — the previous panel's stores, a memory round trip per panel (measured: 63 us for
+      // 96 MB with it, profiles/r05_kbench_xs_first.log)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      braw[ct] = bnext[ct];
-      if (LORA) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) uraw[ct][v] = unext[ct][v];
-      }
-    }
-    if (pn + 1 < p_end) {
-      issue_panel(pn + 1, buf ^ 1);
-      load_small(pn + 1, unext, bnext);
-    }
+    if (pn + 1 < p_end) issue_panel(pn + 1, buf ^ 1);
     asm volatile("" ::: "memory");
     const char *pan = smem + buf * PANEL;
     const int n0 = pn * NCT * 16;
@@ -313,17 +309,20 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
         for (int sl = 0; sl < SL; ++sl) acc[sl] = XsMfma<E>::mma(xs_frag<E>(wf), xs_frag<E>(xr[sl][s]), acc[sl]);
       }
       xu32x4 ua1 = xu32x4{0u, 0u, 0u, 0u}, ua2 = ua1;
+      const int cl = n0 - c_begin + ct * 16;   // column of this tile inside the workgroup's range
       if (LORA) {
-        float uv[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) uv[v] = (4 * lg + v < r && n0 + ct * 16 + l15 < N) ? uraw[ct][v] * scale : 0.f;
+        float uv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * lg < r4) {
+          const float4 u4 = *reinterpret_cast<const float4 *>(sup + (cl + l15) * r4 + 4 * lg);
+          uv[0] = u4.x; uv[1] = u4.y; uv[2] = u4.z; uv[3] = u4.w;
+        }
         xu32x2 hi, lo;
         xs_split4<E>(uv, hi, lo);
         ua1 = xu32x4{hi[0], hi[1], hi[0], hi[1]};
         ua2 = xu32x4{lo[0], lo[1], 0u, 0u};
       }
       union { S s[4]; xu32x2 v; } bb;
-      bb.v = braw[ct];
+      bb.v = *reinterpret_cast<const xu32x2 *>(sbias + cl + 4 * lg);
 #pragma unroll
       for (int sl = 0; sl < SL; ++sl) {
         const int64_t row = row0 + sl * 16 + l15;
@@ -348,12 +347,9 @@ __global__ __launch_bounds__(256, 1) void linear_xs_kernel(const XsArgs a) {
         }
         const bool ok = rok[sl] && ncol < N;
         S *yp = ok ? y + row * ldy + ncol : reinterpret_cast<S *>(g_xs_trash);
-        union { S s[4]; xu32x2 v; } o, old;
-        old.v = xu32x2{0u, 0u};
-        if (accumulate) old.v = *gl(reinterpret_cast<const xu32x2 *>(yp));
+        union { S s[4]; xu32x2 v; } o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o.s[e] = E::from_f(val[e] + E::to_f(bb.s[e]) + (accumulate ? E::to_f(old.s[e]) : 0.f));
+        for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(val[e] + E::to_f(bb.s[e]));
         *gl(reinterpret_cast<xu32x2 *>(yp)) = o.v;   // always issued: exactly NST stores per wave and panel
       }
     }
@@ -364,7 +360,7 @@ struct XsCfg { int KF, NCT; };
 inline bool xs_cfg(int K, XsCfg *c) {
   switch (K) {
     case 320: *c = {10, 5}; return true;   // 2 x 50 KB panel images + 20 KB of down fragments
-    case 640: *c = {20, 3}; return true;   // 2 x 60 KB + 40 KB
+    case 640: *c = {20, 2}; return true;   // 2 x 40 KB + 40 KB
     default: return false;
   }
 }
@@ -416,8 +412,9 @@ extern "C" int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t
                  LORA_AMD_EINVAL, "linear_xs: N, ldy must be multiples of 4, pointers aligned");
   LORA_AMD_CHECK(q.dropout_p >= 0.f && q.dropout_p < 1.f, LORA_AMD_EINVAL, "linear_xs: dropout p=%f", q.dropout_p);
   LORA_AMD_CHECK(q.reserved == 0 || q.reserved == 1, LORA_AMD_EINVAL, "linear_xs: reserved = 0 (packed weight) or 1 (row-major)");
-  const int fl = q.flayout & 3;
-  LORA_AMD_CHECK(fl == 0 || fl == 3, LORA_AMD_EINVAL, "linear_xs: factor layout 0 (forward) or 3 (input gradient)");
+  const int fl = q.flayout;
+  LORA_AMD_CHECK(fl == 0 || fl == 3, LORA_AMD_EINVAL,
+                 "linear_xs: factor layout 0 (forward) or 3 (input gradient); no accumulate form (use lora_amd_linear_ws)");
   const bool drop = lora && q.dropout_p > 0.f;
   LORA_AMD_CHECK(!drop || fl == 3 || q.N % 8 == 0, LORA_AMD_EINVAL, "linear_xs: dropout needs N %% 8 == 0");
   XsArgs a;
@@ -443,7 +440,13 @@ extern "C" int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t
     const int want_groups = std::max(1, (int)((288 + a.nrb - 1) / a.nrb));   // column groups for ~288 workgroups
     pg = std::max(1, a.npanels / want_groups);
   }
+  {  // the workgroup's factor / bias columns must fit their LDS arrays
+    const int r4 = lora ? (q.r + 3) & ~3 : 4;
+    const int cap = std::min(kXsUpFloats / (pcols * r4), kXsBiasCols / pcols);
+    if (pg > cap) pg = cap;
+  }
   if (pg > a.npanels) pg = a.npanels;
+  if (pg < 1) pg = 1;
   a.pg = pg;
   a.ncg = (a.npanels + pg - 1) / pg;
   const dim3 grid((unsigned)(((a.nrb + 7) / 8) * 8 * a.ncg));
@@ -455,8 +458,8 @@ extern "C" int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t
       else if (sl == 2) xs_launch<E, 10, 5, 2>(a, fl, drop, lora, grid, st);                   \
       else xs_launch<E, 10, 5, 1>(a, fl, drop, lora, grid, st);                                \
     } else {                                                                                   \
-      if (sl >= 2) xs_launch<E, 20, 3, 2>(a, fl, drop, lora, grid, st);                        \
-      else xs_launch<E, 20, 3, 1>(a, fl, drop, lora, grid, st);                                \
+      if (sl >= 2) xs_launch<E, 20, 2, 2>(a, fl, drop, lora, grid, st);                        \
+      else xs_launch<E, 20, 2, 1>(a, fl, drop, lora, grid, st);                                \
     }                                                                                          \
   } while (0)
   if (act_dtype == LORA_AMD_BF16) XS_DISPATCH(bf16_t); else XS_DISPATCH(f16_t);

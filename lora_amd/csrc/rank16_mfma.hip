@@ -399,7 +399,11 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
 // bits; same bytes as f32): the skinny products of the randomized subspace iteration (cli_svd.py:24-92 restated in
 // lora_amd/cli_svd.py) on the matrix cores — hi F_hi + hi F_lo + lo F_hi per k-step.  One launch for every shape group of
 // a model (descriptor table); a workgroup = 16 waves = 16 / wps slabs of 16 rows, wps waves per slab dealing the k-steps.
-template <class E>
+// PK: the factor arrives as PACKED hi / lo fragments (lora_amd_thin_pack: [k step][hi 1 KB | lo 1 KB], lane l's 16 bytes at
+// 16 l) instead of f32 [C][r]: two coalesced 16-byte loads per k-step where the f32 form needs eight strided scalar loads and
+// ~50 VALU instructions of hi / lo splitting — per 16-row slab, i.e. once per three MFMAs (round 5: the pass was issue-bound,
+// not byte-bound, at 3.6 TB/s).
+template <class E, bool PK>
 __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_planes_desc *__restrict__ descs, int n, int r) {
   using S = typename E::storage;
   __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
@@ -434,25 +438,45 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
   const int64_t base = (b * d.M + (rok ? row : 0)) * (int64_t)C + 8 * q;
   const S *xh = reinterpret_cast<const S *>(d.hi) + base, *xl = reinterpret_cast<const S *>(d.lo) + base;
   const float *f = d.f + b * (int64_t)C * r;
+  const S *pk = reinterpret_cast<const S *>(d.f) + b * (int64_t)C * 32 + lane * 8;   // PK: [C / 32][hi 512 | lo 512] elements
   mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     auto piece = [&](const S *p, int ks) -> mu32x4 {
       return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(p + (int64_t)ks * 32)) : r16_zero();
     };
     mu32x4 h0 = piece(xh, cw), l0 = piece(xl, cw), h1 = piece(xh, cw + wps), l1 = piece(xl, cw + wps);
-    R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
+    if constexpr (PK) {
+      auto frag = [&](int ks, int part) -> mu32x4 {
+        return *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)(ks < nks ? ks : 0) * 1024 + part * 512));
+      };
+      mu32x4 fh = frag(cw, 0), fl = frag(cw, 1);
 #pragma unroll 1
-    for (int ks = cw; ks < nks; ks += wps) {
-      const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
-      mu32x4 fh, fl;
-      r16_factor_split<E>(fr, 1.0f, fh, fl);
-      if (ks + wps < nks) fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (ks + wps) * 32);
-      mu32x4 ch = h0, cl = l0;
-      if (!rok) { ch = r16_zero(); cl = r16_zero(); }
-      acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
-      acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
-      acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
-      h0 = h1; l0 = l1; h1 = h2; l1 = l2;
+      for (int ks = cw; ks < nks; ks += wps) {
+        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
+        const mu32x4 nfh = frag(ks + wps, 0), nfl = frag(ks + wps, 1);
+        mu32x4 ch = h0, cl = l0;
+        if (!rok) { ch = r16_zero(); cl = r16_zero(); }
+        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
+        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
+        acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+        h0 = h1; l0 = l1; h1 = h2; l1 = l2;
+        fh = nfh; fl = nfl;
+      }
+    } else {
+      R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
+#pragma unroll 1
+      for (int ks = cw; ks < nks; ks += wps) {
+        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
+        mu32x4 fh, fl;
+        r16_factor_split<E>(fr, 1.0f, fh, fl);
+        if (ks + wps < nks) fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (ks + wps) * 32);
+        mu32x4 ch = h0, cl = l0;
+        if (!rok) { ch = r16_zero(); cl = r16_zero(); }
+        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
+        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
+        acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+        h0 = h1; l0 = l1; h1 = h2; l1 = l2;
+      }
     }
   }
   if (wps > 1) {
@@ -671,9 +695,19 @@ extern "C" int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, i
   LORA_AMD_CHECK(r >= 1 && r <= 16, LORA_AMD_ERANK, "rowdot16_planes: %d output columns outside [1,16]", r);
   LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "rowdot16_planes: 16-bit planes only");
   hipStream_t st = (hipStream_t)stream;
-  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL(rowdot16_planes_kernel<f16_t>, dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
-  else hipLaunchKernelGGL(rowdot16_planes_kernel<bf16_t>, dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL((rowdot16_planes_kernel<f16_t, false>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
+  else hipLaunchKernelGGL((rowdot16_planes_kernel<bf16_t, false>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, r);
   return check_launch("lora_amd_rowdot16_planes");
+}
+
+extern "C" int lora_amd_rowdot16_planes_packed(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid,
+                                               int32_t plane_dtype, void *stream) {
+  LORA_AMD_CHECK(descs_dev && n >= 1 && grid >= 1 && grid < (1ll << 31), LORA_AMD_EINVAL, "rowdot16_planes_packed: bad argument");
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "rowdot16_planes_packed: 16-bit planes only");
+  hipStream_t st = (hipStream_t)stream;
+  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL((rowdot16_planes_kernel<f16_t, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);
+  else hipLaunchKernelGGL((rowdot16_planes_kernel<bf16_t, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);
+  return check_launch("lora_amd_rowdot16_planes_packed");
 }
 
 extern "C" int lora_amd_split16_ragged(const lora_amd_split_desc *descs_dev, int32_t n, int64_t blocks, int32_t plane_dtype,

@@ -645,6 +645,36 @@ __global__ __launch_bounds__(256) void thin_clamp_kernel(const QSite *__restrict
   }
 }
 
+// ---- a thin matrix F [rows][16] f32 -> the (hi, lo) 16-bit MFMA fragments the planes product reads ----------------------------
+// dst (16-bit elements, at element offset 2 off): [k step = 32 rows][hi 512 | lo 512], lane l = (j = l & 15, kq = l >> 4) holds
+// F[32 ks + 8 kq + e][j], e = 0..7 (rows past the site: zero).  One workgroup = 256 rows = 8 k-steps, two pieces per thread.
+template <class E>
+__global__ __launch_bounds__(256) void thin_pack_kernel(const Site *__restrict__ sites, const int32_t *__restrict__ blockmap,
+                                                        const float *__restrict__ src, typename E::storage *__restrict__ dst) {
+  using S = typename E::storage;
+  const int site = gl(blockmap)[blockIdx.x];
+  const Site st = ld_site(sites + site);
+  const int lb = (int)(blockIdx.x - st.block_begin);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int id = u * 256 + threadIdx.x, ksl = id >> 6, lane = id & 63;
+    const int64_t ks = (int64_t)lb * 8 + ksl;
+    if (ks * 32 >= st.rows) continue;
+    const int j = lane & 15, kq = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t row = ks * 32 + 8 * kq + e;
+      v[e] = row < st.rows ? *gl(src + st.off + row * 16 + j) : 0.f;
+    }
+    mu32x4 hi, lo;
+    split_hi_lo<E>(v, hi, lo);
+    S *o = dst + 2 * st.off + ks * 1024 + lane * 8;
+    *gl(reinterpret_cast<mu32x4 *>(o)) = hi;
+    *gl(reinterpret_cast<mu32x4 *>(o + 512)) = lo;
+  }
+}
+
 // ---- dW = W_tuned - W_base (cli_svd.py:30-32) -> the (hi, lo) 16-bit planes of dW AND of dW^T, and |dW|_F^2 ----------------
 // One read of the two weights, no f32 residual in memory (rounds 2-4: sub_ragged wrote it, split16_transpose read it back:
 // 2 x 2.9 GB of the distillation's traffic).  One 64 x 64 tile per workgroup; the transposed planes through an LDS image of the
@@ -826,4 +856,18 @@ extern "C" int lora_amd_split16_residual(const lora_amd_resid_desc *descs_dev, i
   else
     hipLaunchKernelGGL((split16_residual_kernel<bf16_t, bf16_t>), grid, block, 0, (hipStream_t)stream, d, (int)n, norm_part);
   return check_launch("lora_amd_split16_residual");
+}
+
+extern "C" int lora_amd_thin_pack(const lora_amd_thin_site *sites_dev, const int32_t *blockmap_dev, int64_t total_blocks,
+                                  const float *src, void *dst, int32_t plane_dtype, void *stream) {
+  LORA_AMD_CHECK(sites_dev && blockmap_dev && src && dst && total_blocks >= 1, LORA_AMD_EINVAL, "thin_pack: null argument");
+  LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "thin_pack: 16-bit fragments only");
+  const dim3 grid((unsigned)total_blocks), block(256);
+  if (plane_dtype == LORA_AMD_BF16)
+    hipLaunchKernelGGL(thin_pack_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const Site *)sites_dev, blockmap_dev, src,
+                       reinterpret_cast<__bf16 *>(dst));
+  else
+    hipLaunchKernelGGL(thin_pack_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const Site *)sites_dev, blockmap_dev, src,
+                       reinterpret_cast<_Float16 *>(dst));
+  return check_launch("lora_amd_thin_pack");
 }

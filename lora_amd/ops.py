@@ -338,17 +338,24 @@ class LoraLinearFunction(torch.autograd.Function):
                 sink.pending = key
                 db = g2.sum(0) if (ctx.has_bias and need_b) else None
                 return None, None, db, None, None, None, None, None, None
-            if sink is not None:
-                gt_part, up_part, down_part = sink.workspace(key, plan, g2.device)
-            else:
-                gt_part, up_part, down_part = (torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
-                                               for n in (plan.gt_part_floats, plan.up_part_floats,
-                                                         plan.down_part_floats))
+            # the per-site partial slabs (Gt column tiles, dUp / dDown row blocks) exist only on the paths that write them: a
+            # site whose factor gradients go to the step's deferred matrix-core pass registers nothing here (the
+            # dead slabs of every dropout site, and a reset of the trainer's reduce table per site)
+            key0, _bufs = key, []
+
+            def bufs():
+                if not _bufs:
+                    if sink is not None:
+                        _bufs.append(sink.workspace(key0, plan, g2.device))
+                    else:
+                        _bufs.append(tuple(torch.empty(max(int(n), 1), dtype=torch.float32, device=g2.device)
+                                           for n in (plan.gt_part_floats, plan.up_part_floats, plan.down_part_floats)))
+                return _bufs[0]
             tile = 0
             if (need_x and sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
                     and weight.is_contiguous() and g2.dtype in (torch.bfloat16, torch.float16)
                     and weight.dtype == g2.dtype):
-                tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, (gt_part, up_part, down_part))
+                tile = _C.gemm_choice_bwd(g2, x2, weight, t, down_c, up_c, s, bufs)
                 if (p > 0.0 and WS_DROPOUT_WIDE_BWD and tile != _C.WS_TILE and M >= 256
                         and _C.ws_supported(g2, N, K, r) and K % 8 == 0):
                     tile = _C.WS_TILE
@@ -370,6 +377,7 @@ class LoraLinearFunction(torch.autograd.Function):
                     mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, None, None, "mfma", plan_m, (p, seed, off))
                     _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors_deferred_mfma", M, K, N, r)
                 else:
+                    gt_part, up_part, down_part = bufs()
                     _C.linear_bwd_factors(g2, t, up_part, x2, gt, down_part, r, s, dropout=(p, seed, off))
                     _log("bwd", ("ws" if tile == _C.WS_TILE else f"ring{tile}") + "_dx+factors", M, K, N, r)
             elif plan_m is not None and need_x and r > 8 and not need_w:
@@ -386,6 +394,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 _log("bwd", "rowdot+lib+rank_update+factors_deferred_mfma", M, K, N, r)
             else:
                 _log("bwd", "g+lib+x", M, K, N, r)
+                gt_part, up_part, down_part = bufs()
                 _C.linear_bwd_g(g2, t, up_c, gt_part, up_part, s, p, seed, off)
                 dx2 = (g2 @ weight) if need_x else None  # frozen dense GEMM
                 if dx2 is not None and not _C._rows_ok(dx2):
@@ -396,6 +405,7 @@ class LoraLinearFunction(torch.autograd.Function):
             if sink is not None:
                 sink.pending = key  # summed into the flat grad buffer by the trainer's batched reduce
             else:
+                gt_part, up_part, down_part = bufs()
                 d_up = torch.empty((N, r), dtype=torch.float32, device=g2.device)
                 d_down = torch.empty((r, K), dtype=torch.float32, device=g2.device)
                 rows = [(up_part, d_up, plan.nparts_up, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
@@ -506,6 +516,7 @@ class MergedWeights:
         self._pack_tables = {}
         self._graph_keep = []
         self.groups = {}     # (ids of the adapters of one input, out_heads, dtype) -> concatenated scratch weights
+        self._keys = {}      # id(adapter) -> dither key (see _dither_key)
 
     def lookup(self, module, w, b, dt, in_heads, out_heads, need_dx: bool = True):
         """(w_eff, bias_eff, w_eff_t) for this adapter and layout; creates (and fills) the entry on first use.
@@ -607,7 +618,7 @@ class MergedWeights:
         step = w.dtype in (torch.bfloat16, torch.float16)  # the in-step merge kernel (csrc/merge_step.hip)
         e = dict(module=module, w=w.detach(), w_eff=w_eff, b_eff=b_eff, w_eff_t=None, w_t=None, scale=float(module.scale),
                  ptrs=(up.data_ptr(), down.data_ptr(), w.data_ptr()), in_heads=in_heads, out_heads=out_heads, step=step,
-                 key=len(self.entries) + 1, group=None)
+                 key=self._dither_key(module), group=None)
         if not step:  # f32 weights: the collapse kernel's sites (round 3's form; head sub-ranges, separate transposed site)
             heads_in = (in_heads[1], in_heads[2]) if in_heads else None
             sites = []
@@ -622,6 +633,13 @@ class MergedWeights:
         self._launch_one(e)  # this forward's values; the step plan is rebuilt
         self._plans = None
         return e
+
+    def _dither_key(self, module) -> int:
+        """The site key the dithered rounding hashes (csrc/merge_step.hip): one per ADAPTER, handed out in the order the
+        adapters first run — the host model's execution order, the same whether sites are grouped or not — and kept when an
+        entry is rebuilt (new layout, new scale, re-bound factors), so that the same run gives the same bits (ADVICE r4:
+        ``len(entries) + 1`` could collide after a rebuild and depended on the registration order of LAYOUTS)."""
+        return self._keys.setdefault(id(module), len(self._keys) + 1)
 
     def _msite(self, e) -> dict:
         m = e["module"]

@@ -284,3 +284,35 @@ def test_residual_planes_and_norms_in_one_launch_equal_sub_then_split(dt):
             assert torch.equal(x, y)
     want = torch.cat([d.double().square().sum((1, 2)) for d in deltas])
     assert (norm2.double() - want).abs().max() <= 2e-6 * want.max()
+
+
+def test_packed_factor_fragments_give_the_same_product_as_the_f32_factor():
+    """lora_amd_thin_pack + lora_amd_rowdot16_planes_packed vs lora_amd_rowdot16_planes on the f32 factor: the same hi / lo
+    fragments reach the matrix cores either way — bit-equal outputs."""
+    g = torch.Generator().manual_seed(12)
+    dims = [(2, 320, 640), (1, 64, 2880), (3, 640, 96)]     # (B, M, C): X [B, M, C] planes, F [B, C, 16]
+    X = [torch.randn(B, M, Cc, generator=g).to(DEV) for B, M, Cc in dims]
+    hi = [x.to(torch.bfloat16) for x in X]
+    lo = [(x - h.float()).to(torch.bfloat16) for x, h in zip(X, hi)]
+    offs, tot = [], 0
+    for B, M, Cc in dims:
+        offs.append(tot)
+        tot += B * Cc * 16
+    flat = torch.randn(tot, generator=g).to(DEV)
+    F = [flat[o:o + B * Cc * 16].view(B, Cc, 16) for o, (B, M, Cc) in zip(offs, dims)]
+    out_a = [torch.empty(B, M, 16, device=DEV) for B, M, Cc in dims]
+    out_b = [torch.empty(B, M, 16, device=DEV) for B, M, Cc in dims]
+    pa = _C.PlanesProgram(DEV, 16)
+    ha = pa.table(list(zip(hi, lo, F, out_a)))
+    pa.upload()
+    pa.run(ha)
+    tab = _C.ThinTable([(o + b * Cc * 16, Cc) for o, (B, M, Cc) in zip(offs, dims) for b in range(B)], DEV)
+    pk = torch.full((tot * 2,), 7.0, dtype=torch.bfloat16, device=DEV)
+    _C.thin_pack(tab, flat, pk)
+    PK = [pk[2 * o: 2 * o + B * Cc * 32].view(B, Cc * 32) for o, (B, M, Cc) in zip(offs, dims)]
+    pb = _C.PlanesProgram(DEV, 16, packed=True)
+    hb = pb.table(list(zip(hi, lo, PK, out_b)))
+    pb.upload()
+    pb.run(hb)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
