@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 4
+#define LORA_AMD_ABI_VERSION 5
 
 /* status codes */
 #define LORA_AMD_OK 0

@@ -20,7 +20,7 @@ F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
 ROUND_REFERENCE, ROUND_ONCE, ROUND_DITHER = 0, 1, 2
 MAX_RANK = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 

@@ -428,17 +428,18 @@ extern "C" int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t
     a.nct_total = (int)((int64_t)(q.N + bn - 1) / bn * bn / 16);
     a.reserved = 0;
   }
-  // slabs per wave and panels per workgroup: about one workgroup per CU, the input read as few times as that allows
+  // slabs per wave and panels per workgroup (profiles/r05_kbench_xs.log): ONE round of workgroups (LDS holds one per CU), the
+  // input read as few times as that allows; 64-row waves only where the site is wide enough to amortise their registers
   const int sl_max = K == 320 ? 4 : 2;
-  int sl = g_xs_sl > 0 ? g_xs_sl : sl_max;
-  if (g_xs_sl == 0) while (sl > 1 && (M + 64 * sl - 1) / (64 * sl) * 1 < 48) sl >>= 1;   // few rows: smaller blocks
+  int sl = g_xs_sl > 0 ? g_xs_sl : (K == 320 ? (q.N >= 2048 && M >= 12288 ? 4 : 2) : 2);
+  if (g_xs_sl == 0) while (sl > 1 && (M + 64 * sl - 1) / (64 * sl) < 32) sl >>= 1;   // few rows: smaller blocks
   if (sl > sl_max) sl = sl_max;
   if (sl != 1 && sl != 2 && sl != 4) sl = 2;
   a.nrb = (int)((M + 64 * sl - 1) / (64 * sl));
   int pg = g_xs_pg;
   if (pg <= 0) {
-    const int want_groups = std::max(1, (int)((288 + a.nrb - 1) / a.nrb));   // column groups for ~288 workgroups
-    pg = std::max(1, a.npanels / want_groups);
+    const int groups = std::max(1, 256 / std::max(1, a.nrb));   // column groups that keep the grid within one round
+    pg = (a.npanels + groups - 1) / groups;
   }
   {  // the workgroup's factor / bias columns must fit their LDS arrays
     const int r4 = lora ? (q.r + 3) & ~3 : 4;

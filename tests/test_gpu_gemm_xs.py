@@ -50,7 +50,7 @@ def test_xs_plain_product_on_a_packed_weight(M, K, N):
     close(n(y), ref, absref, dt, k=3e-5, msg="Y")
     y_rm, _ = _C.linear_xs(x, dict(wp=w, N=N, bias=b, rowmajor=True))
     assert torch.equal(y_rm, y)
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="no accumulate form"):
         _C.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, y=y.clone(), flayout=4))
 
 
