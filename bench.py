@@ -141,33 +141,42 @@ def in_step_rooflines(state, fwd_bwd, latents, ehs) -> dict:
     fwd_bwd(latents, ehs)
     owed = list(mw._owed)
     if owed:
-        gx = sum((st[0].numel() + st[1].numel()) * st[0].element_size() for st in owed)
+        gx_rows = sum((st[0].numel() + st[1].numel()) * st[0].element_size() for st in owed)   # rows as laid out (head padding)
+        dense = lambda t, hd: t.shape[0] * (hd[0] * hd[1] if hd else t.shape[1])  # noqa: E731
+        gx = sum((dense(st[0], st[7]) + dense(st[1], st[8])) * st[0].element_size() for st in owed)   # M (N + K) e
 
         # record the launches of ONE flush (tables built and uploaded once), then time re-issuing exactly those launches:
         # the host's table building must not sit between the timed launches
-        names = ("factor_pack", "linear_bwd_factors_mfma_ragged", "linear_bwd_factors_self_ragged")
+        names = ("factor_pack", "linear_bwd_factors_mfma_ragged", "linear_bwd_factors_self_ragged", "reduce_batched")
         orig, calls = {nm: getattr(_C, nm) for nm in names}, []
         try:
             for nm in names:
                 setattr(_C, nm, (lambda *a, _n=nm: (calls.append((_n, a)), orig[_n](*a))[1]))
             mw._owed = list(owed)
-            mw.flush_factors()
+            state.reduce_pending()   # flush (pack + pass per class) AND the fold of every site's partial slabs into flat_g
         finally:
             for nm in names:
                 setattr(_C, nm, orig[nm])
         torch.cuda.synchronize()
         sec = _time_launch(lambda: [orig[nm](*a) for nm, a in calls], iters=10, inner=2)
+        nofold = [(nm, a) for nm, a in calls if nm != "reduce_batched"]
+        sec_nofold = _time_launch(lambda: [orig[nm](*a) for nm, a in nofold], iters=10, inner=2)
         kinds = sorted({st[9] for st in owed})
         launched = sorted({nm for nm, _ in calls})
-        kern = ("lora_amd::factors_reg_kernel<bf16> (register-resident matrix-core pass) + factor_pack"
-                if _C.factors_mfma_set_form(-1) == 1 else "lora_amd::factors_mfma_kernel<bf16> (LDS-resident) + factor_pack") \
-            if "linear_bwd_factors_mfma_ragged" in launched else "lora_amd::linear_bwd_factors_self_ragged_kernel<bf16> (VALU pass)"
+        kern = ("lora_amd::factors_reg_kernel<bf16> (register-resident matrix-core pass) + factor_pack + reduce_batched"
+                if _C.factors_mfma_set_form(-1) == 1 else "lora_amd::factors_mfma_kernel<bf16> (LDS-resident) + factor_pack + fold") \
+            if "linear_bwd_factors_mfma_ragged" in launched else "lora_amd::linear_bwd_factors_self_ragged_kernel<bf16> (VALU pass) + fold"
         out["factor_pass"] = {"kernel": "%s: G and X of %d sites; passes: %s" % (kern, len(owed), "+".join(kinds)),
                               "bound": "hbm", "algorithmic_bytes_per_launch": int(gx), "avg_launch_us": round(sec * 1e6, 2),
                               "achieved": round(gx / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(gx / sec / HBM_PEAK, 4),
                               "launches": [nm for nm, _ in calls],
-                              "includes": "the pack launch and one pass launch per LDS class; the fold (reduce_batched) is not in it"}
+                              "without_fold_us": round(sec_nofold * 1e6, 2),
+                              "frac_without_fold": round(gx / sec_nofold / HBM_PEAK, 4),
+                              "bytes_of_rows_as_laid_out": int(gx_rows),
+                              "includes": "the pack launch, one pass launch per LDS class AND the fold (reduce_batched) of the "
+                                          "partial slabs; bytes = SURVEY 8d's M (N + K) e of the dense sites (the head-padded "
+                                          "rows the kernel walks are bytes_of_rows_as_laid_out)"}
     state.reduce_pending()
     state.zero_grad()
     return out
@@ -216,18 +225,52 @@ def gemm_roofline(iters=20):
             name = "lora_amd::linear_gemm_fwd_kernel<bf16> (K1 fused, LDS ring, tile %d)" % tile
         else:
             continue
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            run()
-        e.record()
-        torch.cuda.synchronize()
-        sec = a.elapsed_time(e) / iters * 1e-3
         flops, byts = 2.0 * M * K * N + 2.0 * M * 4 * (K + N), (M * K + N * K + M * N) * 2 + (N + K) * 4 * 4 + M * 4 * 4
-        out.append({"kernel": name, "site": [M, K, N, 4], **roofline_entry(flops, byts, sec)})
+
+        def timed(fn, inner=10):
+            """Seconds per call: `inner` back-to-back calls captured into a hipGraph, the replay bracketed by HIP events on
+            the launch stream (the host's ctypes / launch cost per call exceeds these kernels' 10-13 us)."""
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(inner):
+                    fn()
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(iters):
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                graph.replay()
+                e.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(e) / inner * 1e-3)
+            ts.sort()
+            return ts[len(ts) // 2]
+
+        out.append({"kernel": name, "site": [M, K, N, 4], **roofline_entry(flops, byts, timed(run))})
+        # the input-stationary kernel of round 5 (csrc/gemm_xs.hip) on the same site: fused with the branch, and as the plain
+        # product next to the library GEMM (the kernel is not routed in the step: it wins the plain product only)
+        if _C.xs_supported(x, K, N, 4):
+            wp = _C.ws_pack(w)
+            y2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            fused = dict(wp=wp, N=N, bias=b, down=down, up=up, scale=1.0, y=y2)
+            out.append({"kernel": "lora_amd::linear_xs_kernel<bf16> (K1 fused, input-stationary)", "site": [M, K, N, 4],
+                        **roofline_entry(flops, byts, timed(lambda: _C.linear_xs(x, fused)))})
+            pb = (M * K + N * K + M * N) * 2
+            plain = dict(wp=wp, N=N, bias=b, y=y2)
+            out.append({"kernel": "lora_amd::linear_xs_kernel<bf16> (plain X W^T + b)", "site": [M, K, N, 0],
+                        **roofline_entry(2.0 * M * K * N, pb, timed(lambda: _C.linear_xs(x, plain)))})
+            out.append({"kernel": "library GEMM (hipBLASLt via torch, X W^T + b)", "site": [M, K, N, 0],
+                        **roofline_entry(2.0 * M * K * N, pb, timed(lambda: torch.nn.functional.linear(x, w, b)))})
     return out
 
 
@@ -549,8 +592,7 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
         for k, v in ins.items():  # scalars the driver's `config` keeps
             c[k + "_frac_in_step"] = v.get("frac")
     if out.get("roofline_fused_gemm"):
-        rec["roofline_fused_gemm"] = [dict(_pick(e, ("site", "avg_launch_us", "bound", "frac", "hbm_frac", "mfma_frac")),
-                                           kernel=_short(e.get("kernel", "").split(" (")[0], 60))
+        rec["roofline_fused_gemm"] = [dict(_pick(e, ("site", "avg_launch_us", "frac")), kernel=_short(e.get("kernel", ""), 64))
                                       for e in out["roofline_fused_gemm"]]
         c["fused_gemm_frac"] = out["roofline_fused_gemm"][0].get("frac")
     if "adapter_path" in out:

@@ -472,14 +472,15 @@ def _sd15_twins(r=4, ref_device=DEV):
 
 @pytest.fixture(scope="module")
 def sd15_reference_step():
-    """One batch-1 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
+    """One batch-4 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
     every LoRA gradient, computed once per module."""
     ref, ref_params, dev_unet = _sd15_twins()
     g = torch.Generator().manual_seed(123)
-    lat = torch.randn(1, 4, 64, 64, generator=g) * 0.18215
-    ehs = torch.randn(1, 77, 768, generator=g)
-    noise = torch.randn(1, 4, 64, 64, generator=g)
-    ts = torch.randint(0, 1000, (1,), generator=g)
+    B = 4   # BASELINE configs[1]'s batch (round 4 ran these at batch 1)
+    lat = torch.randn(B, 4, 64, 64, generator=g) * 0.18215
+    ehs = torch.randn(B, 77, 768, generator=g)
+    noise = torch.randn(B, 4, 64, 64, generator=g)
+    ts = torch.randint(0, 1000, (B,), generator=g)
     # the device step sees bf16 inputs: give the oracle the same (bf16-representable) values
     lat, ehs, noise = (v.to(torch.bfloat16).float() for v in (lat, ehs, noise))
     grads = {}
