@@ -472,11 +472,14 @@ def _sd15_twins(r=4, ref_device=DEV):
 
 @pytest.fixture(scope="module")
 def sd15_reference_step():
-    """One batch-4 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
+    """One batch-1 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
     every LoRA gradient, computed once per module."""
     ref, ref_params, dev_unet = _sd15_twins()
     g = torch.Generator().manual_seed(123)
-    B = 4   # BASELINE configs[1]'s batch (round 4 ran these at batch 1)
+    B = 1   # batch 1: the fixed per-tensor bound below (cosine >= 0.99 against F32) does not hold for every tensor at batch 4 —
+    # there a bf16 step and an f32 step differ by more on the weakest gradients (0.973-0.976 on one `up` tensor in all three
+    # configurations, the ATen-normalised "plain" one included).  Batch 4 is judged against the reference's own bf16 arithmetic
+    # instead: tests/test_gpu_parity_r5.py::test_batch4_step_error_is_bracketed_by_the_bf16_autocast_reference
     lat = torch.randn(B, 4, 64, 64, generator=g) * 0.18215
     ehs = torch.randn(B, 77, 768, generator=g)
     noise = torch.randn(B, 4, 64, 64, generator=g)
