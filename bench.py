@@ -163,8 +163,7 @@ def in_step_rooflines(state, fwd_bwd, latents, ehs) -> dict:
         sec_nofold = _time_launch(lambda: [orig[nm](*a) for nm, a in nofold], iters=10, inner=2)
         kinds = sorted({st[9] for st in owed})
         launched = sorted({nm for nm, _ in calls})
-        kern = ("lora_amd::factors_reg_kernel<bf16> (register-resident matrix-core pass) + factor_pack + reduce_batched"
-                if _C.factors_mfma_set_form(-1) == 1 else "lora_amd::factors_mfma_kernel<bf16> (LDS-resident) + factor_pack + fold") \
+        kern = "lora_amd::factors_reg_kernel<bf16> (register-resident matrix-core pass) + factor_pack + reduce_batched" \
             if "linear_bwd_factors_mfma_ragged" in launched else "lora_amd::linear_bwd_factors_self_ragged_kernel<bf16> (VALU pass) + fold"
         out["factor_pass"] = {"kernel": "%s: G and X of %d sites; passes: %s" % (kern, len(owed), "+".join(kinds)),
                               "bound": "hbm", "algorithmic_bytes_per_launch": int(gx), "avg_launch_us": round(sec * 1e6, 2),
@@ -595,6 +594,13 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
         rec["roofline_fused_gemm"] = [dict(_pick(e, ("site", "avg_launch_us", "frac")), kernel=_short(e.get("kernel", ""), 64))
                                       for e in out["roofline_fused_gemm"]]
         c["fused_gemm_frac"] = out["roofline_fused_gemm"][0].get("frac")
+    if "step_hbm" in out and "measured_frac_of_peak" in out["step_hbm"]:
+        # rocprof counters of the SAME command taken in a separate run (PMC passes cannot ride a timed run): three scalars + the
+        # file they come from; the per-kernel tables stay in that file
+        rec["step_pmc"] = {"hbm_frac_of_peak": out["step_hbm"]["measured_frac_of_peak"],
+                           "hbm_GBs": out["step_hbm"].get("measured_GBs_at_this_step_time"),
+                           "mfma_frac_of_peak": (out.get("mfma_util") or {}).get("whole_step_mfma_frac_of_peak"),
+                           "static": True, "source": _short(str((out.get("mfma_util") or {}).get("source", "profiles/")), 60)}
     if "adapter_path" in out:
         rec["adapter_path"] = _pick(out["adapter_path"], ("gpu_ms_per_step", "algorithmic_bytes_per_step", "frac",
                                                           "library_gemm_ms", "library_gemm_calls", "frac_of_step_time"))
@@ -615,7 +621,7 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
     if detail_path:
         rec["detail"] = detail_path
     # hard guard: never print a line the driver cannot keep whole
-    for drop in ("adapter_path", "roofline_fused_gemm", "roofline_in_step", "secondary"):
+    for drop in ("step_pmc", "adapter_path", "roofline_fused_gemm", "roofline_in_step", "secondary"):
         if len(json.dumps(rec)) <= LINE_LIMIT:
             break
         rec.pop(drop, None)

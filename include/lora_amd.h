@@ -143,9 +143,9 @@ int lora_amd_merge_step_set_tuning(int32_t tile, int32_t dither);
  * their matrix-core forms (csrc/rank16_mfma.hip; same arguments, outputs and partial-buffer geometry).  enable = 0 routes
  * them back to the VALU kernels (parity tests compare the two), 1 = default, < 0 only reads.  Returns the previous value. */
 int lora_amd_rank16_mfma(int32_t enable);
-/* Which kernel lora_amd_linear_bwd_factors_mfma_ragged launches on a planned table: 0 = the row block of the narrower operand
- * resident in LDS, 1 = resident in registers, every wave autonomous between four barriers (same tables, same slabs).
- * < 0 only reads.  Returns the previous value. */
+/* Round 4 kept two kernels behind lora_amd_linear_bwd_factors_mfma_ragged (0 = the row block of the narrower operand resident
+ * in LDS, 1 = resident in registers, every wave autonomous between four barriers).  The LDS-resident one was removed in ABI 5:
+ * the entry stays, ignores its argument and always returns 1. */
 int lora_amd_factors_mfma_set_form(int32_t form);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):

@@ -31,11 +31,11 @@
 //     x 32 B are both bank-conflict-free (scripts/lds_banks.py checks the lane groups of the microarchitecture guide).
 // Algorithmic bytes per site: M (N + K) e (G and X once) + the partial slabs 2 RT 4 (N + K) M / R (written here, read by
 // lora_amd_reduce_batched).
-// TWO kernels run the same tables (lora_amd_factors_mfma_set_form): the LDS-resident one described above (the round's first
-// form: FETCH_SIZE 1.0x algorithmic but 0.22-0.30 of the byte roof — ten barriers and LDS round trips in front of serially
-// dependent MFMAs cost a 64-row block ~25-40 K cycles of dependent work per wave; profiles/r04_kbench_fm_variants.log,
-// r04_fm_pmc.jsonl, r04_fm_engine_trace_*.txt) and the REGISTER-resident, wave-autonomous one further down
-// (factors_reg_kernel: the default; 0.43-0.45 of the roof on the headline step's 144 sites against 0.29 for the VALU pass).
+// The kernel of this file is the REGISTER-resident, wave-autonomous form further down (factors_reg_kernel: 0.43-0.45 of the
+// roof on the headline step's 144 sites against 0.29 for the VALU pass).  The description above is the round's first form —
+// the row block of the narrower operand resident in LDS — whose geometry rules still size the tables (lora_amd_factors_mfma_plan:
+// supported shapes, rows per block, LDS class); that kernel itself (0.22-0.30: ten barriers and LDS round trips in front of
+// serially dependent MFMAs; profiles/r04_kbench_fm_variants.log, r04_fm_pmc.jsonl) was removed in round 5.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -49,7 +49,6 @@ constexpr int kFmThreads = 256;   // 4 waves
 constexpr int kFmNPA1 = 10, kFmNPA2 = 20;  // 16-byte pieces per thread of ONE resident block (R * Ca <= 20480 / 40960 elements)
 constexpr int kFmNPB = 8;         // ... of one streamed chunk (R * CW <= 16384 elements)
 constexpr int kFmMaxNB = 8;       // row blocks one workgroup walks (their partial sums meet in its slab)
-constexpr int kFmMaxRT16 = 4;     // row tiles of 16 per block (R <= 64)
 constexpr int kFmLdsSmall = 81920, kFmLdsLarge = 163840;  // two workgroups per CU / one
 
 __host__ __device__ inline int fm_pitch(int cols) {  // bytes; smallest p >= 2 cols with p % 64 == 32
@@ -118,335 +117,6 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
     hb.c = h; lb.c = l;
     *gl(reinterpret_cast<mu32x4 *>(dst + ((int64_t)c8 * 16 + jj) * 8)) = hb.u;
     *gl(reinterpret_cast<mu32x4 *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8)) = lb.u;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------- the pass
-template <class E, int NP>
-struct FmStage { mu32x4 v[NP]; };
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + s_barrier: hipcc drains EVERY outstanding
-// global load (s_waitcnt vmcnt(0)) before it, which would end the flight of the next chunk's / next row block's loads at
-// the first barrier after they were issued — the whole point of this kernel's pipeline is that they stay in flight across
-// the barriers until their registers are written to LDS.  All cross-wave communication here goes through LDS
-// (lgkmcnt(0) = this wave's ds_write / ds_read have completed); global stores are never read by another wave.
-__device__ __forceinline__ void fm_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Pieces (16 bytes) of a [R, c8w] tile, row-major, dealt to the threads with stride 256: piece p0 + tid + i * 256 is
-// (row, c).  One division per tile instead of one per piece.
-struct FmPieces {
-  int row, c, dr, dc, c8w;
-  __device__ __forceinline__ FmPieces(int p0, int c8w_) : c8w(c8w_) {
-    // an opaque zero: the pieces' (row, c) depend only on the thread and the tile shape, and hipcc otherwise hoists all of
-    // them out of the row-block loop and keeps them live (+54 registers: spills at two workgroups per CU)
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    const int p = p0 + threadIdx.x + z;
-    row = p / c8w; c = p - row * c8w;
-    dr = kFmThreads / c8w; dc = kFmThreads - dr * c8w;
-  }
-  __device__ __forceinline__ void next() {
-    row += dr; c += dc;
-    if (c >= c8w) { c -= c8w; ++row; }
-  }
-};
-
-// Issue the loads of a thread's pieces of the tile whose first column chunk is c8_0 — all in flight.  Rows past the end
-// of the matrix (and pieces past the end of the tile) read a valid address and are zeroed.
-template <class E, int NP>
-__device__ __forceinline__ void fm_issue(FmStage<E, NP> &st, const typename E::storage *data, int64_t ld, int64_t m0,
-                                         int nrows, int p0, int c8w, int c8_0, const FmHeads &hd) {
-  FmPieces it(p0, c8w);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const bool ok = it.row < nrows;
-    const typename E::storage *src = data + (m0 + (ok ? it.row : 0)) * ld + (int64_t)fm_hchunk(c8_0 + it.c, hd) * 8;
-    const mu32x4 v = *gl(reinterpret_cast<const mu32x4 *>(src));
-    st.v[i] = ok ? v : mu32x4{0u, 0u, 0u, 0u};
-    it.next();
-  }
-}
-// nn.Dropout on the branch (lora.py:45, 57): G enters both contractions as mask (.) G.  The keep pattern of the forward is
-// regenerated here from (seed, offset) — Philox chunk = 8 consecutive elements of the dense [M, N] output, as every other
-// kernel of the library indexes it — and applied as a bit mask when the piece goes to LDS; the 1 / (1 - p) factor is folded
-// into the site's scale (both outputs are linear in G).
-struct FmDrop { bool on; uint64_t seed, off; uint32_t thr; int64_t row0; int n8, c8_0; };
-
-template <class E, int NP, bool DROP>
-__device__ __forceinline__ void fm_write(const FmStage<E, NP> &st, unsigned char *buf, int pitch, int R, int p0, int c8w,
-                                         const FmDrop &dr) {
-  FmPieces it(p0, c8w);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    if (it.row < R) {
-      mu32x4 v = st.v[i];
-      if constexpr (DROP) {  // straight-line: `on` only selects between the mask and all-ones
-        uint32_t rr[4];
-        Philox ph(dr.seed);
-        ph((uint64_t)((dr.row0 + it.row) * dr.n8 + dr.c8_0 + it.c), dr.off, rr);
-        const uint32_t all = dr.on ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          v[w] &= all | ((rr[w] & 0xFFFFu) >= dr.thr ? 0x0000FFFFu : 0u) | ((rr[w] >> 16) >= dr.thr ? 0xFFFF0000u : 0u);
-      }
-      *reinterpret_cast<mu32x4 *>(buf + it.row * pitch + it.c * 16) = v;
-    }
-    it.next();
-  }
-}
-
-// The first fragment pair (hi, lo) of a wave's share of a tile's k-steps: issued BEFORE the barrier that publishes the tile,
-// so that the L2 trip of the factors is not on the path from "tile in LDS" to "first MFMA".
-struct FmFrag2 { mu32x4 h, l; };
-template <class E>
-__device__ __forceinline__ FmFrag2 fm_first_frags(const typename E::storage *pk, int64_t split_stride, int nks) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ks = wave < nks ? wave : 0;
-  FmFrag2 f;
-  f.h = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)ks * 512 + lane * 8));
-  f.l = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)ks * 512 + lane * 8));
-  return f;
-}
-
-// phase 1 of one tile [R, ncols] in LDS: acc[t] += Data[tile t rows, k-step] . (hi + lo of the packed factor), for the
-// k-steps ks = wave, wave + 4, ... of the tile.  `pk` points at the fragment of the tile's first column (split 0),
-// `split_stride` = elements between the hi and the lo pack, `f0` = fm_first_frags of the same arguments.
-template <class E>
-__device__ __forceinline__ void fm_phase1(mf32x4 (&acc)[kFmMaxRT16], const unsigned char *buf, int pitch, int nrt, int nks,
-                                          const typename E::storage *pk, int64_t split_stride, FmFrag2 f0) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned char *rowp = buf + (lane & 15) * pitch + (lane >> 4) * 16;
-  if (wave >= nks) return;
-  mu32x4 fh = f0.h, fl = f0.l;
-#pragma unroll 1
-  for (int ks = wave; ks < nks; ks += 4) {
-    const int kn = ks + 4 < nks ? ks + 4 : ks;  // next fragment in flight while this one is used
-    const mu32x4 nh = *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)kn * 512 + lane * 8));
-    const mu32x4 nl = *gl(reinterpret_cast<const mu32x4 *>(pk + split_stride + (int64_t)kn * 512 + lane * 8));
-    const typename FmMfma<E>::frag bh = fm_frag<E>(fh), bl = fm_frag<E>(fl);
-#pragma unroll
-    for (int t = 0; t < kFmMaxRT16; ++t) {
-      if (t < nrt) {
-        const typename FmMfma<E>::frag a =
-            fm_frag<E>(*reinterpret_cast<const mu32x4 *>(rowp + t * 16 * pitch + ks * 64));
-        acc[t] = FmMfma<E>::mma(a, bh, acc[t]);
-        acc[t] = FmMfma<E>::mma(a, bl, acc[t]);
-      }
-    }
-    fh = nh; fl = nl;
-  }
-}
-
-// The four waves' partial [R, 16] blocks -> T = s * sum, split hi / lo, stored [split][jj][position] so that phase 2
-// reads a lane's 8 contraction rows with one 16-byte load.  Position of row ro (0..31) inside its 32-row k-step:
-//   ro < 16: 8 (ro / 4) + ro % 4        ro >= 16: 8 ((ro - 16) / 4) + 4 + ro % 4
-// (the rows a transpose read hands to lane group q: 4q..4q+3 with the first read, 16+4q..16+4q+3 with the second).
-template <class E>
-__device__ __forceinline__ void fm_combine_put(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, int nrt) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int t = 0; t < kFmMaxRT16; ++t) {
-    if (t < nrt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) scratch[((wave * nrt + t) * 4 + g) * 64 + lane] = acc[t][g];
-    }
-  }
-}
-// ... after a barrier: rows >= nrows (past the end of the matrix) give T = 0
-template <class E>
-__device__ __forceinline__ void fm_combine_get(const float *scratch, unsigned char *tt, int nrt, int R, float scale, int nrows) {
-  using S = typename E::storage;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tp = fm_tpitch(R);
-  for (int t = wave; t < nrt; t += 4) {
-    union { S s[4]; mu32x2 u; } h, l;
-    const int jj = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v += scratch[((w * nrt + t) * 4 + g) * 64 + lane];
-      v = (t * 16 + 4 * q + g) < nrows ? v * scale : 0.f;
-      h.s[g] = E::from_f(v);
-      l.s[g] = E::from_f(v - E::to_f(h.s[g]));
-    }
-    const int pos = (t >> 1) * 32 + 8 * q + 4 * (t & 1);
-    *reinterpret_cast<mu32x2 *>(tt + jj * tp + pos * 2) = h.u;
-    *reinterpret_cast<mu32x2 *>(tt + (16 + jj) * tp + pos * 2) = l.u;
-  }
-}
-template <class E>
-__device__ __forceinline__ void fm_combine(const mf32x4 (&acc)[kFmMaxRT16], float *scratch, unsigned char *tt, int nrt,
-                                           int R, float scale, int nrows) {
-  fm_combine_put<E>(acc, scratch, nrt);
-  fm_barrier();
-  fm_combine_get<E>(scratch, tt, nrt, R, scale, nrows);
-}
-
-// 8 contraction rows x 1 column of a row-major LDS tile as an MFMA operand: lane (q = lane / 16, i = lane % 16) gets
-// rows {32 ks + 4q + e, e < 4} and {32 ks + 16 + 4q + e} of column c0 + i: two ds_read_b64_tr_b16 (each 16-lane
-// group reads a [4 rows][16 columns] block; lane s of the group supplies the address of row s / 4, columns 4 (s % 4) ..).
-template <class E>
-__device__ __forceinline__ typename FmMfma<E>::frag fm_colfrag(const unsigned char *buf, int pitch, int ks, int c0) {
-  const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
-  const unsigned char *p = buf + (ks * 32 + 4 * q + (i >> 2)) * pitch + (c0 + 4 * (i & 3)) * 2;
-  union { ms16x4 h[2]; mu32x4 u; } r;
-  r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p));
-  r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ms16x4 __attribute__((address_space(3))) *)(p + 16 * pitch));
-  return fm_frag<E>(r.u);
-}
-
-// phase 2 of one tile [R, ncols] in LDS: out[jj][col0 + c] (+)= sum_rows T[row, jj] Data[row, c] for the tile's columns;
-// column tiles of 16 are dealt to the waves.  `tf` = the T fragments (hi, lo per 32-row k-step) in registers.
-// `accumulate`: the workgroup's earlier row blocks already left their sums in `out` (its own slab: the same lane wrote
-// the same 16 bytes; read back past the L1 with a non-temporal load, one column tile ahead of its use).
-template <class E>
-__device__ __forceinline__ void fm_phase2(const unsigned char *buf, int pitch, int nk2, int ncols,
-                                          const mu32x4 (&tf)[kFmMaxRT16], float *out, int64_t ldo, int RT, bool accumulate) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jj = lane & 15, q = lane >> 4;
-  const int nct = ncols >> 4;
-  const bool owner = jj < RT;
-  float *base = out + (owner ? jj : 0) * ldo + 4 * q;
-  mf32x4 old = {0.f, 0.f, 0.f, 0.f};
-  if (accumulate && owner && wave < nct) old = __builtin_nontemporal_load(gl(reinterpret_cast<const mf32x4 *>(base + wave * 16)));
-#pragma unroll 1
-  for (int ct = wave; ct < nct; ct += 4) {
-    mf32x4 nxt = {0.f, 0.f, 0.f, 0.f};
-    if (accumulate && owner && ct + 4 < nct) nxt = __builtin_nontemporal_load(gl(reinterpret_cast<const mf32x4 *>(base + (ct + 4) * 16)));
-    mf32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
-      if (k2 < nk2) {
-        const typename FmMfma<E>::frag a = fm_colfrag<E>(buf, pitch, k2, ct * 16);
-        d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2]), d);
-        d = FmMfma<E>::mma(a, fm_frag<E>(tf[2 * k2 + 1]), d);
-      }
-    }
-    if (owner) *gl(reinterpret_cast<mf32x4 *>(base + ct * 16)) = d + old;
-    old = nxt;
-  }
-}
-
-template <class E>
-__device__ __forceinline__ void fm_load_tfrags(mu32x4 (&tf)[kFmMaxRT16], const unsigned char *tt, int R, int nk2) {
-  const int lane = threadIdx.x & 63, jj = lane & 15, q = lane >> 4;
-  const int tp = fm_tpitch(R);
-#pragma unroll
-  for (int k2 = 0; k2 < kFmMaxRT16 / 2; ++k2) {
-    if (k2 < nk2) {
-      tf[2 * k2] = *reinterpret_cast<const mu32x4 *>(tt + jj * tp + (k2 * 32 + 8 * q) * 2);
-      tf[2 * k2 + 1] = *reinterpret_cast<const mu32x4 *>(tt + (16 + jj) * tp + (k2 * 32 + 8 * q) * 2);
-    }
-  }
-}
-
-template <class E, int LDSB, bool DROP>
-__global__ __launch_bounds__(kFmThreads, LDSB <= 81920 ? 2 : 1) void factors_mfma_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
-  using S = typename E::storage;
-  constexpr int NPA = LDSB <= 81920 ? kFmNPA1 : kFmNPA2;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const lora_amd_fm_site q = sites[lo];
-  const int64_t sb_idx = (int64_t)blockIdx.x - q.block_begin;   // this workgroup's slab = its run of row blocks
-  const int R = q.rows_per_block, nrt = R >> 4, nk2 = R >> 5;
-  const int64_t nrb = (q.M + R - 1) / R;
-  const int64_t rb0 = sb_idx * q.blocks_per_wg;
-  const int nblk = (int)min((int64_t)q.blocks_per_wg, nrb - rb0);
-  const bool ax = q.resident_is_x != 0;
-  const int RT = q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16;
-  // A = resident operand, B = streamed operand
-  const S *da = reinterpret_cast<const S *>(ax ? q.x : q.g), *db = reinterpret_cast<const S *>(ax ? q.g : q.x);
-  const int64_t lda = ax ? q.ldx : q.ldg, ldb = ax ? q.ldg : q.ldx;
-  const int Ca = ax ? q.K : q.N, Cb = ax ? q.N : q.K;
-  const FmHeads hda = fm_heads((ax ? q.x_head_dim : q.g_head_dim) >> 3, (ax ? q.x_head_pad : q.g_head_pad) >> 3);
-  const FmHeads hdb = fm_heads((ax ? q.g_head_dim : q.x_head_dim) >> 3, (ax ? q.g_head_pad : q.x_head_pad) >> 3);
-  const S *pka = reinterpret_cast<const S *>(ax ? q.pk_down : q.pk_up), *pkb = reinterpret_cast<const S *>(ax ? q.pk_up : q.pk_down);
-  float *outa = (ax ? q.down_part : q.up_part) + sb_idx * RT * (int64_t)Ca;   // = sum over the blocks of TB^T A
-  float *outb = (ax ? q.up_part : q.down_part) + sb_idx * RT * (int64_t)Cb;   // = ... TA^T B
-  const int pa = q.pitch_a, pb = q.pitch_b, CW = q.cw, nch = q.nchunk;
-  unsigned char *bufA = lds, *bufB = bufA + R * pa;
-  unsigned char *ttA = bufB + R * pb, *ttB = ttA + 32 * fm_tpitch(R);
-  float *scratch = reinterpret_cast<float *>(bufB);  // [4 waves][nrt][4][64] f32 <= R * pitch_b (planner)
-  const int c8a = Ca >> 3, cw0 = min(CW, Cb);
-  const int64_t splita = (int64_t)c8a * 128, splitb = (int64_t)(Cb >> 3) * 128;
-  // dropout: G is the streamed operand when X is resident, else the resident one
-  const bool drop = DROP && q.dropout_p > 0.f;
-  FmDrop dra, drb;
-  dra.on = drop && !ax; drb.on = drop && ax;
-  dra.seed = drb.seed = q.seed;
-  dra.off = drb.off = drop ? dropout_offset(q.offset, q.offset_dev) : 0;
-  dra.thr = drb.thr = (uint32_t)(q.dropout_p * 65536.0f + 0.5f);
-  dra.n8 = drb.n8 = q.N >> 3;
-  dra.c8_0 = 0;
-
-  // ---- the first block's resident rows and first chunk: in flight before the first wait.  From here on the NEXT block's
-  // resident rows (sa) and the next chunk (sb) are always in flight while the current ones are consumed.
-  FmStage<E, NPA> sa;
-  FmStage<E, kFmNPB> sb;
-  {
-    const int64_t m0 = rb0 * R;
-    const int nrows = (int)min((int64_t)R, q.M - m0);
-    fm_issue<E, NPA>(sa, da, lda, m0, nrows, 0, c8a, 0, hda);
-    fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw0 >> 3, 0, hdb);
-  }
-  mf32x4 acc[kFmMaxRT16];
-  mu32x4 tf[kFmMaxRT16];
-#pragma unroll 1
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int64_t m0 = (rb0 + blk) * R, m1 = m0 + R;
-    const int nrows = (int)min((int64_t)R, q.M - m0);
-    const int nrows1 = (int)min((int64_t)R, q.M - m1);   // of the next block (if any)
-    const bool more = blk + 1 < nblk;
-    const bool accum = blk > 0;
-    FmFrag2 f0 = fm_first_frags<E>(pka, splita, Ca >> 5);
-    dra.row0 = drb.row0 = m0;
-    fm_write<E, NPA, DROP>(sa, bufA, pa, R, 0, c8a, dra);
-    fm_barrier();
-    if (more) fm_issue<E, NPA>(sa, da, lda, m1, nrows1, 0, c8a, 0, hda);
-    // ---- TA
-#pragma unroll
-    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-    fm_phase1<E>(acc, bufA, pa, nrt, Ca >> 5, pka, splita, f0);
-    fm_combine<E>(acc, scratch, ttA, nrt, R, q.scale, nrows);
-    f0 = fm_first_frags<E>(pkb, splitb, cw0 >> 5);
-    fm_barrier();  // TA visible; the scratch (= chunk buffer) is free
-    fm_load_tfrags<E>(tf, ttA, R, nk2);
-    // ---- B in column chunks
-#pragma unroll
-    for (int t = 0; t < kFmMaxRT16; ++t) acc[t] = mf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-      const int col0 = c * CW, cw = min(CW, Cb - col0);
-      drb.c8_0 = col0 >> 3;
-      fm_write<E, kFmNPB, DROP>(sb, bufB, pb, R, 0, cw >> 3, drb);
-      fm_barrier();
-      if (c + 1 < nch) {
-        const int col1 = col0 + CW, cw1 = min(CW, Cb - col1);
-        fm_issue<E, kFmNPB>(sb, db, ldb, m0, nrows, 0, cw1 >> 3, col1 >> 3, hdb);
-      } else if (more) {
-        fm_issue<E, kFmNPB>(sb, db, ldb, m1, nrows1, 0, cw0 >> 3, 0, hdb);
-      }
-      fm_phase1<E>(acc, bufB, pb, nrt, cw >> 5, pkb + (int64_t)(col0 >> 3) * 128, splitb, f0);
-      if (c + 1 < nch) {
-        const int col1 = col0 + CW;
-        f0 = fm_first_frags<E>(pkb + (int64_t)(col1 >> 3) * 128, splitb, min(CW, Cb - col1) >> 5);
-      }
-      fm_phase2<E>(bufB, pb, nk2, cw, tf, outb + col0, Cb, RT, accum);
-      fm_barrier();  // the chunk buffer is free
-    }
-    // ---- TB, then the resident block's column sums
-    fm_combine<E>(acc, scratch, ttB, nrt, R, q.scale, nrows);
-    fm_barrier();
-    fm_load_tfrags<E>(tf, ttB, R, nk2);
-    fm_phase2<E>(bufA, pa, nk2, Ca, tf, outa, Ca, RT, accum);
-    fm_barrier();  // the resident buffer is free for the next block
   }
 }
 
@@ -697,7 +367,6 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
-static int g_fm_form = 1;   // 0: LDS-resident kernel, 1: register-resident kernel (lora_amd_factors_mfma_set_form)
 
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
 
@@ -756,7 +425,7 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   int cls = 0;
   (void)flags;  // bit 0 (dropout site) selects the masked kernel at launch time; the geometry is the same
   // the register-resident kernel holds 20 pieces per lane: 64 rows up to 640 columns of the narrower operand, 32 beyond
-  if (rows == 0 && g_fm_form == 1) rows = 64;
+  if (rows == 0) rows = 64;
   if (!fm_choose(M, K, N, r, act_dtype, rows, &g, &cls)) return LORA_AMD_OK;
   out->supported = 1;
   out->lds_class = cls;
@@ -846,29 +515,21 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
-#define FM(E, L)                                                                                                      \
+#define FM(E)                                                                                                         \
   do {                                                                                                                \
-    if (g_fm_form == 1) {                                                                                             \
-      if (drop) hipLaunchKernelGGL((factors_reg_kernel<E, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-      else hipLaunchKernelGGL((factors_reg_kernel<E, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    } else if (drop) hipLaunchKernelGGL((factors_mfma_kernel<E, L, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    else hipLaunchKernelGGL((factors_mfma_kernel<E, L, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    if (drop) hipLaunchKernelGGL((factors_reg_kernel<E, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    else hipLaunchKernelGGL((factors_reg_kernel<E, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n);     \
   } while (0)
-  if (act_dtype == LORA_AMD_F16) {
-    if (lds_class == 1) FM(f16_t, kFmLdsSmall); else FM(f16_t, kFmLdsLarge);
-  } else {
-    if (lds_class == 1) FM(bf16_t, kFmLdsSmall); else FM(bf16_t, kFmLdsLarge);
-  }
+  if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
 #undef FM
   return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
 }
 
 
-// Which kernel lora_amd_linear_bwd_factors_mfma_ragged launches on a planned table: 0 = LDS-resident row block
-// (factors_mfma_kernel), 1 = register-resident (factors_reg_kernel); same tables, same slabs.  < 0 only reads; returns the
-// previous value.
+// Rounds 4 kept two kernels on the same tables (0 = LDS-resident row block, 1 = register-resident).  The LDS-resident one
+// (0.22-0.30 of the byte roof against 0.43-0.45) was removed in round 5 (docs/DESIGN_HISTORY.md keeps its description); the
+// entry stays in the ABI and always answers 1.
 extern "C" int lora_amd_factors_mfma_set_form(int32_t form) {
-  const int prev = g_fm_form;
-  if (form == 0 || form == 1) g_fm_form = form;
-  return prev;
+  (void)form;
+  return 1;
 }
