@@ -19,8 +19,12 @@ each step of the iteration is ONE launch for the whole stack —
 — all HBM-streaming passes over dW with a skinny factor (``csrc/linear.hip``), plus one batched l x l SVD (torch) of
 the triangular-factor-sized core at the end.  Model-level entry (``distill_model`` / ``topr_svd_ragged``): every step is ONE
 launch over all shape groups, and with a 16-wide sketch the products with dW / dW^T run on the matrix cores over (hi, lo)
-bf16 planes of the residuals (``PLANES``; ``csrc/rank16_mfma.hip``: ``lora_amd_split16_transpose`` +
-``lora_amd_rowdot16_planes``, 3.6 TB/s per pass).  With ``n_iter`` power iterations the captured subspace error decays like
+bf16 planes of the residuals (``PLANES``; ``csrc/rank16_mfma.hip``: ``lora_amd_rowdot16_planes[_packed]``, 4.1 TB/s per pass).
+Round 5 (``THIN``, ``csrc/svd_small.hip``): the residuals, their planes and |dW|^2 come out of ONE launch
+(``lora_amd_split16_residual``); every small dense step between two passes — Gram / Cholesky / apply (CholeskyQR3 = 4 launches),
+the 16 x 16 core SVDs (one-sided Jacobi inside the launch that sums the cores), the sign rule, the quantile (exact radix
+selection, bit-equal to ``torch.quantile``) and the clamp — is a launch over a per-site table whose reduction is finished by the
+last-arriving workgroup of each site; the iteration count adapts to the spectrum (``n_iter=None``): 224 sites in ~13 ms.  With ``n_iter`` power iterations the captured subspace error decays like
 (s_{l+1}/s_r)^(2 n_iter + 1); the defaults reproduce ``up @ down`` of the reference to ~1e-4 relative on
 distillation-like spectra.  The signs of singular vectors are arbitrary (LAPACK's are too, and the reference's clamp
 threshold - a quantile of SIGNED entries - inherits that arbitrariness); the device path fixes them by making the
@@ -363,6 +367,8 @@ def _distill_thin(pairs, rank: int, clamp_quantile: float, n_iter, generator):
             _QTABLES.clear()
         ent = _QTABLES[key] = (_C.ThinQTable(qs, dev), tmpl.to(dev), torch.tensor(ws, dtype=torch.float32, device=dev))
     qt, tmpl, w = ent
+    qt.counters.zero_()   # the table is cached across calls: a launch that died half-way must not poison the next one
+    qt.hist.zero_()
     state = tmpl.clone()
     out2 = torch.empty(st.nb, 2, dtype=torch.float32, device=dev)
     for p in range(3):
