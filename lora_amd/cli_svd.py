@@ -527,16 +527,21 @@ def distill_model(groups, rank: int, clamp_quantile: float = 0.99, generator: Op
     by_dtype = {}
     for ent in fast:
         by_dtype.setdefault(groups[ent[0]][0][0].dtype, []).append(ent)
-    for dt, ents in by_dtype.items():
-        dev = groups[ents[0][0]][0][0].device
-        if _thin_ok([(B, N, K) for _, B, N, K in ents], rank, over):
+    for dt, all_ents in by_dtype.items():
+        dev = groups[all_ents[0][0]][0][0].device
+        # the groups the fused path takes (16-wide sketch, shapes multiples of 32) go through it together; the rest (if any)
+        # through the ragged launches of rounds 2-4
+        thin = [e for e in all_ents if _thin_ok([e[1:]], rank, over)]
+        ents = [e for e in all_ents if e not in thin]
+        if thin:
             # residuals, planes and |dW|^2 in one launch; the small steps fused; adaptive iteration count unless the caller
             # fixes one (``n_iter=``)
             flat2 = [([t.reshape(t.shape[0], -1) for t in groups[gi][0]], [b.reshape(b.shape[0], -1) for b in groups[gi][1]])
-                     for gi, _, _, _ in ents]
+                     for gi, _, _, _ in thin]
             res, _ = _distill_thin(flat2, rank, clamp_quantile, svd_kw.get("n_iter"), generator)
-            for (gi, _, _, _), ud in zip(ents, res):
+            for (gi, _, _, _), ud in zip(thin, res):
                 results[gi] = ud
+        if not ents:
             continue
         _, deltas = _flat_stacks([(B, N, K) for _, B, N, K in ents], dev)
         pairs, outs = [], []

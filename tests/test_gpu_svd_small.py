@@ -316,3 +316,27 @@ def test_packed_factor_fragments_give_the_same_product_as_the_f32_factor():
     pb.run(hb)
     for a, b in zip(out_a, out_b):
         assert torch.equal(a, b)
+
+
+def test_a_model_with_shapes_outside_the_fused_path_is_split_between_the_two_paths():
+    """``distill_model``: the groups the fused path takes (multiples of 32) and the ones it does not (40 x 72) in ONE call:
+    every group vs the exact truncation, clamp off."""
+    from tests.test_cli_svd import _planted
+
+    r = 8
+    shapes = [(2, 320, 320), (1, 40, 72), (1, 640, 2880), (2, 72, 40)]
+    tuned, base = [], []
+    for gi, (B, N, K) in enumerate(shapes):
+        tb = [_planted(N, K, r + 4, 2e-3 / (N ** 0.5 + K ** 0.5), 10 * gi + i, "cpu") for i in range(B)]
+        tuned.append([t.to(DEV) for t, _ in tb])
+        base.append([b.to(DEV) for _, b in tb])
+    res = S.distill_model(list(zip(tuned, base)), r, 1.0, torch.Generator(device=DEV).manual_seed(3))
+    assert all(x is not None for x in res)
+    for (B, N, K), ts, bs, (up, down) in zip(shapes, tuned, base, res):
+        assert up.shape == (B, N, r) and down.shape == (B, r, K)
+        for i in range(B):
+            dd = (ts[i] - bs[i]).double().cpu()
+            U, Sg, Vh = torch.linalg.svd(dd, full_matrices=False)
+            ref = (U[:, :r] * Sg[:r]) @ Vh[:r]
+            got = up[i].double().cpu() @ down[i].double().cpu()
+            assert (got - ref).norm() <= 5e-4 * ref.norm(), ((N, K, i), float((got - ref).norm() / ref.norm()))
