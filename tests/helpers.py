@@ -19,6 +19,23 @@ if REPO not in sys.path:
 _class_cache = {}
 
 
+_LAP = [None]
+
+
+def lap(label: str) -> None:
+    """Phase timing of the long whole-step tests (``LORA_AMD_TEST_LAPS=1 pytest -s``): device-synchronised seconds since
+    the previous lap, to stderr.  Off by default: no synchronisation is added to a normal run."""
+    if os.environ.get("LORA_AMD_TEST_LAPS") != "1":
+        return
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    now = time.perf_counter()
+    if _LAP[0] is not None:
+        print(f"[lap] {label}: {now - _LAP[0]:.2f} s", file=sys.stderr, flush=True)
+    _LAP[0] = now
+
+
 def named_class(name: str):
     """An nn.Module subclass whose __name__ is ``name`` (the finder matches class-name strings)."""
     if name not in _class_cache:

@@ -474,7 +474,9 @@ def _sd15_twins(r=4, ref_device=DEV):
 def sd15_reference_step():
     """One batch-1 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
     every LoRA gradient, computed once per module."""
+    H.lap("fixture start")
     ref, ref_params, dev_unet = _sd15_twins()
+    H.lap("fixture: twins built")
     g = torch.Generator().manual_seed(123)
     B = 1   # batch 1: the fixed per-tensor bound below (cosine >= 0.99 against F32) does not hold for every tensor at batch 4 —
     # there a bf16 step and an f32 step differ by more on some tensors (measured, call c10 of round 5: cosine 0.973-0.976 on one
@@ -495,6 +497,7 @@ def sd15_reference_step():
                                   ehs.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV), max_grad_norm=1e30)
     for h in hooks:
         h.remove()
+    H.lap("fixture: oracle step")
     g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))]
     del ref
     torch.cuda.empty_cache()
@@ -556,17 +559,22 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
         return T.forward_backward(unet, sched, l_, c_, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
 
     try:
-        for _ in range(2):  # attention choices are timed on first use; the padded layout applies from the second call
+        H.lap(f"{config}: state ready")
+        for i in range(2):  # attention choices are timed on first use; the padded layout applies from the second call
             fwd_bwd(lat, ehs)
             st.zero_grad()
+            H.lap(f"{config}: warm-up step {i}")
         if bench_like:
             graphed = T.GraphedForwardBackward(fwd_bwd, lat, ehs, st)
             st.zero_grad()
+            H.lap(f"{config}: captured")
             loss = float(graphed(lat, ehs))
         else:
             loss = float(fwd_bwd(lat, ehs))
             st.reduce_pending()
+        H.lap(f"{config}: measured step")
         _compare_step(ref, loss, st)
+        H.lap(f"{config}: compared")
         if merged is not None:  # every one of the 144 sites took the merged path, in the layouts the host model uses
             assert len({id(e["module"]) for e in merged.entries.values()}) == 144 and merged.refreshes >= 3
     finally:

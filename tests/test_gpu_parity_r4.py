@@ -700,8 +700,10 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
     sys.path.insert(0, H.REPO)
     from bench import build_unet
 
+    H.lap("start")
     torch.manual_seed(1234)
     dev_unet = build_unet(torch.device(DEV), torch.bfloat16, seed=0)
+    H.lap("device UNet built")
     with torch.device("meta"):
         ref = sd15_unet()
     ref.to_empty(device=DEV)   # the oracle twin on the GPU too: evaluated under H.oracle_on_device() below
@@ -729,6 +731,7 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
     st = T.FlatLoraState([{"params": T.lora_params(dev_unet), "lr": 1e-4, "weight_decay": 1e-2}], max_grad_norm=1.0,
                          device=torch.device(DEV))
     st.attach_direct_grads(dev_unet)
+    H.lap("twins injected")
     g = torch.Generator().manual_seed(123)
     hw = 96
     lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.18215).to(torch.bfloat16).float()
@@ -775,12 +778,14 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
         return T.forward_backward(dev_unet, sched, lat_d, ehs_d, T.StepConfig(t_multiplier=0.8), noise=noise_d,
                                   timesteps=ts_d)
 
-    for _ in range(2):  # attention / MIOpen choices settle; the padded layout applies from the second call
+    for i in range(2):  # attention / MIOpen choices settle; the padded layout applies from the second call
         fwd_bwd()
         st.zero_grad()
+        H.lap(f"device warm-up step {i}")
     draws.clear()
     loss = float(fwd_bwd())
     st.reduce_pending()
+    H.lap("device recorded step")
     flat = n(st.flat_g)
     for m in ours:
         m.__dict__.pop("_forward_device", None)
@@ -819,10 +824,12 @@ def test_extended_rank16_768_step_with_dropout_matches_oracle(monkeypatch):
                                             ts.to(DEV), ehs.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV), max_grad_norm=1e30))
     for h in hooks + ghooks:
         h.remove()
+    H.lap("oracle step with the device's masks")
     g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))]
     assert abs(loss - loss_ref) <= 0.01 * abs(loss_ref), (loss, loss_ref)
     cos = _grad_cos(flat, g_ref)
     assert cos >= 0.99, cos
+    H.lap("compare")
     na, nb = float(np.linalg.norm(flat)), float(np.sqrt(sum(float(g_ @ g_) for g_ in g_ref)))
     assert abs(na - nb) <= 0.1 * nb, (na, nb)
 
