@@ -471,6 +471,9 @@ if not RANK16_MFMA and _C.available():
 
 # Rounding of the in-step merge of 16-bit weights (csrc/merge_step.hip): "dither" (default) = nearest with a fixed
 # per-element dither, so that a delta below half an ulp of the frozen weight survives in the row sums; "once" = nearest even
+# (one of the two documented USER options that are environment variables read once at import — the other is
+# LORA_AMD_FACTORS_MFMA in _C.py; they choose numerics / a pass, not a measurement variant, so they are not
+# part of LORA_AMD_AB; tests flip the module attribute)
 MERGE_ROUNDING = _C.ROUND_ONCE if os.environ.get("LORA_AMD_MERGE_ROUNDING", "dither") == "once" else _C.ROUND_DITHER
 
 
