@@ -256,18 +256,10 @@ def gemm_roofline(iters=20):
             return ts[len(ts) // 2]
 
         out.append({"kernel": name, "site": [M, K, N, 4], **roofline_entry(flops, byts, timed(run))})
-        # the input-stationary kernel of round 5 (csrc/gemm_xs.hip) on the same site: fused with the branch, and as the plain
-        # product next to the library GEMM (the kernel is not routed in the step: it wins the plain product only)
-        if _C.xs_supported(x, K, N, 4):
-            wp = _C.ws_pack(w)
-            y2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            fused = dict(wp=wp, N=N, bias=b, down=down, up=up, scale=1.0, y=y2)
-            out.append({"kernel": "lora_amd::linear_xs_kernel<bf16> (K1 fused, input-stationary)", "site": [M, K, N, 4],
-                        **roofline_entry(flops, byts, timed(lambda: _C.linear_xs(x, fused)))})
+        # the library GEMM alone on the same site (round 5's input-stationary experiment left the product library in round
+        # 6: scripts/gemm_xs/, `scripts/kbench.py --what xs`)
+        if True:
             pb = (M * K + N * K + M * N) * 2
-            plain = dict(wp=wp, N=N, bias=b, y=y2)
-            out.append({"kernel": "lora_amd::linear_xs_kernel<bf16> (plain X W^T + b)", "site": [M, K, N, 0],
-                        **roofline_entry(2.0 * M * K * N, pb, timed(lambda: _C.linear_xs(x, plain)))})
             out.append({"kernel": "library GEMM (hipBLASLt via torch, X W^T + b)", "site": [M, K, N, 0],
                         **roofline_entry(2.0 * M * K * N, pb, timed(lambda: torch.nn.functional.linear(x, w, b)))})
     return out

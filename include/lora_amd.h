@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 5
+#define LORA_AMD_ABI_VERSION 6
 
 /* status codes */
 #define LORA_AMD_OK 0
@@ -143,10 +143,6 @@ int lora_amd_merge_step_set_tuning(int32_t tile, int32_t dither);
  * their matrix-core forms (csrc/rank16_mfma.hip; same arguments, outputs and partial-buffer geometry).  enable = 0 routes
  * them back to the VALU kernels (parity tests compare the two), 1 = default, < 0 only reads.  Returns the previous value. */
 int lora_amd_rank16_mfma(int32_t enable);
-/* Round 4 kept two kernels behind lora_amd_linear_bwd_factors_mfma_ragged (0 = the row block of the narrower operand resident
- * in LDS, 1 = resident in registers, every wave autonomous between four barriers).  The LDS-resident one was removed in ABI 5:
- * the entry stays, ignores its argument and always returns 1. */
-int lora_amd_factors_mfma_set_form(int32_t form);
 
 /* Tuning knobs of the planner/launcher (<= 0 keeps the current value):
  * target elements per tile and resident workgroups per CU (the LDS-slab kernel's grid cap).  blocks_per_cu >= 100
@@ -469,22 +465,10 @@ typedef struct lora_amd_ws_site {
 } lora_amd_ws_site;
 
 int lora_amd_ws_config(int32_t K, int32_t *panel_cols, int32_t *tile_rows);
-/* K1/K2 input-stationary form (csrc/gemm_xs.hip): the same contract as lora_amd_linear_ws for ONE site — same packed weight
- * (lora_amd_ws_pack), same site struct (flayout 0: forward; 3: input gradient; no accumulate form), same dropout mask
- * indexing — with the roles turned round: a wave keeps its 32 input rows in registers (a lane's 16-byte piece IS the MFMA
- * operand), the weight panel goes through LDS.  For the short-contraction / many-row sites: K = 320 or 640
- * (lora_amd_xs_config returns 0 otherwise).  site->down == NULL: plain Y = X B^T + bias (a merged-weight site).
- * site->reserved = 1: site->wp is the row-major weight [N][K] itself (no packed copy).
- * replaces: lora_diffusion/lora.py:53-58 and its input gradient at those sites. */
-int lora_amd_xs_config(int32_t K, int32_t *panel_cols, int32_t *block_rows);
-/* measurement override (scripts/kbench.py): 16-row slabs per wave (1, 2, 4) and panels per workgroup; 0 = choose */
-void lora_amd_xs_set_tuning(int32_t slabs, int32_t panels_per_group);
 int64_t lora_amd_ws_packed_elems(int32_t N, int32_t K);
 /* Pack B (element (n, k) at w[n * stride_n + k * stride_k], n < N, k < K) into fragment order (zero-padded panels). */
 int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, int32_t dtype, void *out,
                      void *stream);
-int lora_amd_linear_xs(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
-                       const lora_amd_ws_site *site, void *stream);
 int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
                        const lora_amd_ws_site *sites /* host array */, int32_t nsites, int32_t row_groups, void *stream);
 

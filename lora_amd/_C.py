@@ -20,14 +20,14 @@ F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
 ROUND_REFERENCE, ROUND_ONCE, ROUND_DITHER = 0, 1, 2
 MAX_RANK = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 # every symbol include/lora_amd.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
-    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma", "lora_amd_factors_mfma_set_form",
+    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma",
     "lora_amd_merge_step_plan", "lora_amd_merge_step",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
@@ -45,7 +45,6 @@ SYMBOLS = (
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
-    "lora_amd_xs_config", "lora_amd_xs_set_tuning", "lora_amd_linear_xs",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd", "lora_amd_conv3_nhwc_bwd_dx",
     "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
@@ -252,8 +251,6 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_merge_step_set_tuning.argtypes = [i32, i32]
     lib.lora_amd_rank16_mfma.argtypes = [i32]
     lib.lora_amd_rank16_mfma.restype = C.c_int
-    lib.lora_amd_factors_mfma_set_form.argtypes = [i32]
-    lib.lora_amd_factors_mfma_set_form.restype = C.c_int
     lib.lora_amd_rowdot.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     lib.lora_amd_rowdot_masked.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32,
                                            f32, u64, u64, vp, vp]
@@ -348,11 +345,6 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_ws_pack.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp]
     lib.lora_amd_linear_ws.argtypes = [vp, i64, i64, i32, i32, C.POINTER(WsSite), i32, i32, vp]
     lib.lora_amd_ws_config.restype = lib.lora_amd_ws_pack.restype = lib.lora_amd_linear_ws.restype = C.c_int
-    lib.lora_amd_xs_config.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
-    lib.lora_amd_linear_xs.argtypes = [vp, i64, i64, i32, i32, C.POINTER(WsSite), vp]
-    lib.lora_amd_xs_config.restype = lib.lora_amd_linear_xs.restype = C.c_int
-    lib.lora_amd_xs_set_tuning.argtypes = [i32, i32]
-    lib.lora_amd_xs_set_tuning.restype = None
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
@@ -578,11 +570,6 @@ class MergeStepPlan:
 
 def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
     require().lora_amd_merge_set_tuning(int(tile_elems), int(blocks_per_cu))
-
-
-def factors_mfma_set_form(form: int = -1) -> int:
-    """Kernel of the matrix-core factor pass: 0 = LDS-resident row block, 1 = register-resident; returns the previous one."""
-    return int(require().lora_amd_factors_mfma_set_form(int(form)))
 
 
 def rank16_mfma(enable: int = -1) -> int:
@@ -1805,60 +1792,6 @@ def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
     _check(lib.lora_amd_linear_ws(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), arr, len(sites), int(row_groups),
                                   _stream()), "lora_amd_linear_ws")
     return outs
-
-
-_XS_K = (320, 640)
-
-
-def xs_supported(x: torch.Tensor, K: int, N: int, r: int) -> bool:
-    """Can the input-stationary kernel (csrc/gemm_xs.hip) run a site of contraction length K, width N, rank r on rows ``x``?"""
-    return (K in _XS_K and x.dtype in (torch.bfloat16, torch.float16) and r <= 16 and N % 4 == 0 and x.dim() == 2
-            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
-
-
-def linear_xs(x: torch.Tensor, s: dict):
-    """ONE site through the input-stationary kernel: the site dict of :func:`linear_ws` (``down`` / ``up`` None: the plain
-    product on the packed weight).  Returns (y, t)."""
-    lib = require()
-    M, K = x.shape
-    d = WsSite()
-    N, fl = int(s["N"]), int(s.get("flayout", 0))
-    down, up = s.get("down"), s.get("up")
-    r = 0
-    if down is not None:
-        r = down.shape[1] if fl & 1 else down.shape[0]
-        if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
-            raise ValueError("linear_xs: contiguous f32 factors expected")
-    y = s.get("y")
-    if y is None:
-        y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    t = torch.empty((M, r), dtype=torch.float32, device=x.device) if (r and s.get("want_t", True)) else None
-    bias = s.get("bias")
-    d.wp, d.bias, d.y, d.down, d.up, d.t_out = s["wp"].data_ptr(), _ptr(bias), y.data_ptr(), _ptr(down), _ptr(up), _ptr(t)
-    d.ldy, d.N, d.r, d.panel_begin, d.flayout = y.stride(0), N, r, 0, fl
-    d.reserved = 1 if s.get("rowmajor") else 0   # ``wp`` = the [N, K] weight itself (contiguous rows) instead of its pack
-    d.scale, d.t_scale = float(s.get("scale", 1.0)), float(s.get("t_scale", 1.0))
-    off_s, off_p = _off(s.get("off", 0))
-    d.dropout_p, d.seed, d.offset, d.offset_dev = float(s.get("p", 0.0)), int(s.get("seed", 0)), off_s, off_p
-    _check(lib.lora_amd_linear_xs(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), C.byref(d), _stream()),
-           "lora_amd_linear_xs")
-    return y, t
-
-
-def xs_set_tuning(slabs: int = 0, panels_per_group: int = 0) -> None:
-    require().lora_amd_xs_set_tuning(int(slabs), int(panels_per_group))
-
-
-def linear_xs_fwd(x, weight, bias, down, up, scale, p: float = 0.0, seed: int = 0, off=0):
-    """(y, t) of one site through the input-stationary kernel (same contract as :func:`linear_ws_fwd`)."""
-    return linear_xs(x, dict(wp=ws_pack(weight), N=weight.shape[0], bias=bias, down=down, up=up, scale=scale, p=p, seed=seed,
-                             off=off))
-
-
-def linear_xs_dx(g, weight, down, up, scale, p: float = 0.0, seed: int = 0, off=0):
-    """(dX, Gt) of one site through the input-stationary kernel (same contract as :func:`linear_ws_dx`)."""
-    return linear_xs(g, dict(wp=ws_pack(weight, True), N=weight.shape[1], down=up, up=down, scale=scale, t_scale=scale,
-                             flayout=3, p=p, seed=seed, off=off))
 
 
 def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0):

@@ -5,37 +5,37 @@
 //           (dUp = s G^T (X down^T), dDown = (s G up)^T X) when the forward ran on W + s up down (ops.MergedWeights),
 //           and csrc/linear_fused.hip's linear_bwd_factors_self_ragged_kernel for 16-bit activations: that VALU pass
 //           reads every row block twice (row-dot phase, column-sum phase; the second read misses the L2: FETCH_SIZE
-//           2.0x algorithmic, 0.25 of the byte roof).
+//           2.0x algorithmic, 0.29 of the byte roof).
 //
-// One workgroup (4 waves) owns R rows of one site.  With A = the narrower of (X, G) and B = the wider one, fa / fb the
-// factor contracted against A's / B's columns (A = X: fa = down, fb = up):
+// One workgroup (4 waves) owns R = 64 (32) rows of one site.  With A = the narrower of (X, G) and B = the wider one, fa / fb
+// the factor contracted against A's / B's columns (A = X: fa = down, fb = up):
 //
 //     TA = s A fa^T [R, r]        outB[j, c] = sum_m TA[m, j] B[m, c]       (A = X: T,  outB = dUp partial)
 //     TB = s B fb^T [R, r]        outA[j, c] = sum_m TB[m, j] A[m, c]       (        Gt, outA = dDown partial)
 //
-//   * A's row block [R, Ca] stays RESIDENT in LDS (160 KiB per CU on gfx950: 64 rows x 320 columns = 42 KB, two
-//     workgroups per CU; the 1280-wide sites take one workgroup per CU), B streams through a second LDS buffer in column
-//     chunks [R, CW]: chunk c + 1 is in flight (registers) while chunk c is consumed.  Per chunk: TB accumulates
-//     (phase 1) and outB's columns of the chunk are finished and stored (phase 2, TA is complete by then); after the
-//     last chunk TB is complete and outA is computed from the resident block.  Nothing is read twice.
-//   * both phases are v_mfma_f32_16x16x32 (the rank padded to the 16 of the tile):
-//       phase 1  D[row, j]  += Data[row, 32 cols] . F[j, 32 cols]^T      A-operand = ds_read_b128 of a row, B-operand = a
-//                packed factor fragment (lora_amd_factor_pack: 1 KB coalesced per wave, L2-resident);
-//       phase 2  D[col, j]  += Data^T[col, 32 rows] . T[32 rows, j]      A-operand = two ds_read_b64_tr_b16 (the LDS
-//                transpose read of gfx950: the row-major tile delivered column-major), B-operand = T from LDS.
-//     f32 precision is kept by splitting every 16-bit operand that is not data: factor = hi + lo, T = hi + lo (two MFMAs
+//   * A's row block stays RESIDENT IN REGISTERS (<= 20 16-byte pieces per lane: 64 rows x 640 columns or 32 x 1280 over the
+//     four waves), B streams through a 4-deep register ring of 32 x 32 units; a wave owns the 32-column groups
+//     wave, wave + 4, ... of both operands and is autonomous between four barriers (factors_reg_kernel below).
+//   * both contractions are v_mfma_f32_16x16x32 (the rank padded to the 16 of the tile):
+//       phase 1  D[row, j]  += Data[row, 32 cols] . F[j, 32 cols]^T      A operand = the 16-byte piece a lane loaded from a
+//                row-major row, B operand = a packed factor fragment (lora_amd_factor_pack: 1 KB per wave, L2-resident);
+//       phase 2  D[col, j]  += Data^T[col, 32 rows] . T[32 rows, j]      A operand = two ds_read_b64_tr_b16 of the wave's
+//                own 32 x 32 staging tile (the LDS transpose read of gfx950), B operand = T fragments from LDS.
+//   * f32 precision is kept by splitting every 16-bit operand that is not data: factor = hi + lo, T = hi + lo (two MFMAs
 //     into the same accumulator) — the matrix pipe is < 20 % busy at the HBM rate, so the split is free.
-//   * phase 1 is split over the waves by k-step (each packed fragment is fetched by ONE wave and reused for all R / 16
-//     row tiles); the four partial [R, 16] blocks meet once in LDS.
-//   * LDS rows are padded to pitch = 32 (mod 64) bytes: the ds_read_b128 of 16 rows and the transpose reads of 8 rows
-//     x 32 B are both bank-conflict-free (scripts/lds_banks.py checks the lane groups of the microarchitecture guide).
+//   * f16 (round 6): f16 has 5 exponent bits — `up` starts at 0 (lora.py:50-51) and sits at ~1e-4 for hundreds of steps,
+//     Gt = s G up at ~1e-8 .. 1e-3: their hi parts land near or in f16's subnormals and the lo parts vanish.  Every split
+//     operand is therefore PRE-SCALED BY A POWER OF TWO and the scale folded back into the f32 result (exact):
+//       factors  per (site, side): factor_absmax_kernel puts 2^e, e = 11 - floor(log2 max|f|), into the 16-byte tail of
+//                the pack; the pack kernel multiplies before the split, the pass multiplies T by 2^-e;
+//       T / Gt   per row block: every wave leaves the largest |partial| of its share in LDS; the sum of the four is an
+//                upper bound of max|T|, 2^e' brings it into [2^14, 2^15), the slab values leave multiplied by 2^-e'.
+//     bf16 has f32's exponent range: its instantiation carries none of this.
 // Algorithmic bytes per site: M (N + K) e (G and X once) + the partial slabs 2 RT 4 (N + K) M / R (written here, read by
 // lora_amd_reduce_batched).
-// The kernel of this file is the REGISTER-resident, wave-autonomous form further down (factors_reg_kernel: 0.43-0.45 of the
-// roof on the headline step's 144 sites against 0.29 for the VALU pass).  The description above is the round's first form —
-// the row block of the narrower operand resident in LDS — whose geometry rules still size the tables (lora_amd_factors_mfma_plan:
-// supported shapes, rows per block, LDS class); that kernel itself (0.22-0.30: ten barriers and LDS round trips in front of
-// serially dependent MFMAs; profiles/r04_kbench_fm_variants.log, r04_fm_pmc.jsonl) was removed in round 5.
+// History: round 4's first form kept the row block of the narrower operand resident in LDS (0.22-0.30 of the roof: ten
+// barriers and LDS round trips in front of serially dependent MFMAs; profiles/r04_kbench_fm_variants.log); it was removed
+// in round 5, its geometry rules (fm_fit: supported shapes, rows per block) still size the tables.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -76,9 +76,47 @@ __device__ __forceinline__ int fm_hchunk(int c, const FmHeads &h) {
 //   pk[split][c8][jj][e] = part_split(factor(jj, c8 * 8 + e))   jj < r, else 0;   16 x 8 elements = 256 B per c8
 // factor(jj, c) = down[jj, c] (FACTOR_RK) or up[c, jj] (FACTOR_KR).  A k-step's fragment (4 consecutive c8) is 1 KB
 // contiguous and lane l reads its 16 bytes at l * 16.
+// f16 only: the power of two that brings the largest |factor| of a (site, side) into [2^11, 2^12) and its inverse, as two
+// floats in the 16-byte tail of the pack ([2][C/8][16][8] elements, then the tail).  One workgroup per (site, side).
+__device__ __forceinline__ float fm_wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+// 2^e with max * 2^e in [2^top, 2^(top + 1)) (max > 0, finite, inside the clamp), as (scale, 1 / scale); (1, 1) for 0
+__device__ __forceinline__ void fm_pow2_scale(float mx, int top, float &scale, float &inv) {
+  int ex = (int)((__float_as_uint(mx) >> 23) & 0xffu);   // mx in [2^(ex - 127), 2^(ex - 126))
+  if (!(mx > 0.f)) ex = 127 + top;                        // zero (or NaN): no scaling
+  ex = min(max(ex, 40 + top), 210 + top);                 // both powers stay normal f32 numbers
+  scale = __uint_as_float((uint32_t)(254 + top - ex) << 23);
+  inv = __uint_as_float((uint32_t)(ex - top) << 23);
+}
+constexpr int kFmFactorTop = 11, kFmTTop = 14;
+__global__ __launch_bounds__(256) void factor_absmax_kernel(const lora_amd_pack_site *__restrict__ sites, int n) {
+  __shared__ float s_m[4];
+  const lora_amd_pack_site q = sites[blockIdx.x >> 1];
+  const bool is_up = blockIdx.x & 1;
+  const int C = is_up ? q.N : q.K;
+  const float *src = is_up ? q.up : q.down;
+  const int64_t cnt = (int64_t)C * q.r;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < cnt; i += 256) m = fmaxf(m, fabsf(gl(src)[i]));
+  m = fm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    float sc, inv;
+    fm_pow2_scale(m, kFmFactorTop, sc, inv);
+    float *tail = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(is_up ? q.pk_up : q.pk_down) + (int64_t)C * 32);
+    gl(tail)[0] = sc; gl(tail)[1] = inv; gl(tail)[2] = 0.f; gl(tail)[3] = 0.f;
+  }
+}
+
 template <class E>
 __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_site *__restrict__ sites, int n, int64_t total) {
   using S = typename E::storage;
+  constexpr bool kScaled = E::kCode == LORA_AMD_F16;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -105,13 +143,18 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
         for (int e = 0; e < 8; ++e) v[e] = gl(src)[e];
       }
     }
+    S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
+    if constexpr (kScaled) {   // the tail factor_absmax_kernel wrote in the launch before this one
+      const float fs = gl(reinterpret_cast<const float *>(dst + (int64_t)C * 32))[0];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= fs;
+    }
     Chunk8<E> h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       h.v[e] = E::from_f(v[e]);
       l.v[e] = E::from_f(v[e] - E::to_f(h.v[e]));
     }
-    S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
     const int64_t split_stride = (int64_t)(C >> 3) * 128;  // elements per split
     union { Chunk8<E> c; mu32x4 u; } hb, lb;
     hb.c = h; lb.c = l;
@@ -141,10 +184,12 @@ constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS 
 template <class E, bool DROP>
 __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   using S = typename E::storage;
+  constexpr bool kScaled = E::kCode == LORA_AMD_F16;   // power-of-two pre-scaling of the split operands (file header)
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
   __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
   __shared__ int64_t s_begin[kFrSitesLds];
+  __shared__ float s_pmax[4];                                          // f16: largest |partial| of each wave's share
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
   // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
   // memory is eight DEPENDENT trips to L2 in front of the block's first load)
@@ -177,6 +222,11 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   const FmHeads hdb = fm_heads((ax ? sd.g_head_dim : sd.x_head_dim) >> 3, (ax ? sd.g_head_pad : sd.x_head_pad) >> 3);
   const S *pka = reinterpret_cast<const S *>(ax ? sd.pk_down : sd.pk_up), *pkb = reinterpret_cast<const S *>(ax ? sd.pk_up : sd.pk_down);
   const int64_t splita = (int64_t)(Ca >> 3) * 128, splitb = (int64_t)(Cb >> 3) * 128;
+  float finv_a = 1.f, finv_b = 1.f;   // f16: 1 / (the power of two the pack multiplied the factor by)
+  if constexpr (kScaled) {
+    finv_a = gl(reinterpret_cast<const float *>(pka + 2 * splita))[1];
+    finv_b = gl(reinterpret_cast<const float *>(pkb + 2 * splitb))[1];
+  }
   float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
   float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
   const int nga = Ca >> 5, ngb = Cb >> 5;
@@ -216,9 +266,11 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
     }
     asm volatile("" ::: "memory");
   };
+  float tinv = 1.f;   // f16: 1 / (the power of two the T fragments in use were multiplied by)
   auto store_group = [&](float *out, int C, int cg, mf32x4 (&acc)[2]) {
     float *o = out + (int64_t)(jj < RT ? jj : 0) * C + cg * 32 + 4 * q;
     if (jj < RT) {
+      if constexpr (kScaled) { acc[0] *= tinv; acc[1] *= tinv; }
       *gl(reinterpret_cast<mf32x4 *>(o)) = acc[0];
       *gl(reinterpret_cast<mf32x4 *>(o + 16)) = acc[1];
     }
@@ -229,15 +281,32 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
     for (int x = 0; x < 4; ++x)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) s_part[(wave * 64 + (x >> 1) * 32 + (x & 1) * 16 + 4 * q + reg) * 16 + jj] = d[x][reg];
+    if constexpr (kScaled) {
+      float m = 0.f;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) m = fmaxf(m, fabsf(d[x][reg]));
+      m = fm_wave_max(m);
+      if (lane == 0) s_pmax[wave] = m;
+    }
   };
-  auto build_tf = [&]() {   // k slot 8 q + e <-> row 4 q + e (e < 4) / 16 + 4 q + e - 4: the order of the transposed reads
+  // T = tscale * (sum of the four waves' shares) -> (hi, lo) fragments.  f16: tscale carries 1 / (factor scale) and the
+  // block's own power of two, chosen from the bound |T| <= |tscale| * sum_w max|share_w|; every wave keeps its inverse
+  auto build_tf = [&](float tscale) {   // k slot 8 q + e <-> row 4 q + e (e < 4) / 16 + 4 q + e - 4: the order of the transposed reads
+    if constexpr (kScaled) {
+      float up2, dn2;
+      fm_pow2_scale(fabsf(tscale) * (s_pmax[0] + s_pmax[1] + s_pmax[2] + s_pmax[3]), kFmTTop, up2, dn2);
+      tscale *= up2;
+      tinv = dn2;
+    }
     if (wave < (rs2 ? 2 : 1)) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int row = wave * 32 + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
-        v[e] = sd.scale * (s_part[(0 * 64 + row) * 16 + jj] + s_part[(1 * 64 + row) * 16 + jj] +
-                           s_part[(2 * 64 + row) * 16 + jj] + s_part[(3 * 64 + row) * 16 + jj]);
+        v[e] = tscale * (s_part[(0 * 64 + row) * 16 + jj] + s_part[(1 * 64 + row) * 16 + jj] +
+                         s_part[(2 * 64 + row) * 16 + jj] + s_part[(3 * 64 + row) * 16 + jj]);
       }
       mu32x4 h, l;
       split_hi_lo<E>(v, h, l);
@@ -305,7 +374,7 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   for (int sl = 0; sl < 4; ++sl) load_unit(sl, b0[sl], b1[sl]);
   store_parts(d1);
   __syncthreads();
-  build_tf();
+  build_tf(sd.scale * finv_a);
   __syncthreads();
   mu32x4 tfh[2], tfl[2];
   tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
@@ -350,7 +419,7 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   // ---- 4. TB -> fragments
   store_parts(d1);
   __syncthreads();
-  build_tf();
+  build_tf(sd.scale * finv_b);
   __syncthreads();
   tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
   tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
@@ -437,8 +506,8 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
-  out->pack_up_elems = (int64_t)N * 32;    // [2][N/8][16][8]
-  out->pack_down_elems = (int64_t)K * 32;
+  out->pack_up_elems = (int64_t)N * 32 + 8;    // [2][N/8][16][8] + the 16-byte tail (f16: the pack's power-of-two scale)
+  out->pack_down_elems = (int64_t)K * 32 + 8;
   return LORA_AMD_OK;
 }
 
@@ -466,8 +535,12 @@ extern "C" int lora_amd_factor_pack(const lora_amd_pack_site *sites_dev, int32_t
                  "factor_pack: the matrix-core factor pass takes f16 / bf16 activations");
   const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
   hipStream_t st = (hipStream_t)stream;
-  if (act_dtype == LORA_AMD_F16) hipLaunchKernelGGL(factor_pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
-  else hipLaunchKernelGGL(factor_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
+  if (act_dtype == LORA_AMD_F16) {
+    hipLaunchKernelGGL(factor_absmax_kernel, dim3(2u * (unsigned)n), dim3(256), 0, st, sites_dev, n);
+    hipLaunchKernelGGL(factor_pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
+  } else {
+    hipLaunchKernelGGL(factor_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, sites_dev, n, total);
+  }
   return check_launch("lora_amd_factor_pack");
 }
 
@@ -523,13 +596,4 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
 #undef FM
   return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
-}
-
-
-// Rounds 4 kept two kernels on the same tables (0 = LDS-resident row block, 1 = register-resident).  The LDS-resident one
-// (0.22-0.30 of the byte roof against 0.43-0.45) was removed in round 5 (docs/DESIGN_HISTORY.md keeps its description); the
-// entry stays in the ABI and always answers 1.
-extern "C" int lora_amd_factors_mfma_set_form(int32_t form) {
-  (void)form;
-  return 1;
 }

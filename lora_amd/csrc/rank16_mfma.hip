@@ -1,4 +1,4 @@
-// Rank-tile-16 forms of the adapter's streaming kernels on the matrix cores (ranks 9..16, 16-bit activations, f32 factors).
+// Rank-tile-16 forms of the adapter's streaming kernels on the matrix cores (ranks 9..16, bf16 activations, f32 factors).
 //
 // replaces: csrc/linear.hip's rowdot / rank_update kernels and csrc/linear_fused.hip's linear_bwd_g_kernel<E, 16> for
 //           lora_diffusion/lora.py:53-58 (Linear) and lora.py:130-135 (Conv2d, channels-last rows) at rank 16 — BASELINE
@@ -588,8 +588,11 @@ __global__ __launch_bounds__(256) void split16_transpose_kernel(const lora_amd_s
   }
 }
 
+// bf16 activations only (round 6): the (hi, lo) split of `up` ~ 1e-4 (lora.py:50-51 starts it at 0) and of Gt = s G up
+// ~ 1e-8 .. 1e-3 needs f32's exponent range, which bf16 has and f16 has not — f16 activations at ranks 9..16 take the VALU
+// kernels (exact f32 arithmetic on the converted data); the one-launch factor pass (factor_mfma.hip) pre-scales instead.
 static bool r16_common_ok(int act_dtype, int fdt, int r) {
-  return g_r16_mfma && (act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16) && fdt == LORA_AMD_F32 && r > 8 && r <= 16;
+  return g_r16_mfma && act_dtype == LORA_AMD_BF16 && fdt == LORA_AMD_F32 && r > 8 && r <= 16;
 }
 
 bool r16_rowdot(const void *x, int64_t ldx, const void *f, int fdt, int layout, float *t_out, int64_t M, int C, int r,
@@ -608,8 +611,7 @@ bool r16_rowdot(const void *x, int64_t ldx, const void *f, int fdt, int layout, 
 #define RD(E, D)                                                                                                      \
   hipLaunchKernelGGL((rowdot16_mfma_kernel<E, D>), dim3(grid), dim3(block), 0, st,                                    \
                      reinterpret_cast<const typename E::storage *>(x), ldx, ff, layout, t_out, M, C, r, wps, scale, p, seed, offset, offset_dev)
-  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RD(f16_t, true); else RD(f16_t, false); }
-  else { if (p > 0.f) RD(bf16_t, true); else RD(bf16_t, false); }
+  if (p > 0.f) RD(bf16_t, true); else RD(bf16_t, false);
 #undef RD
   return true;
 }
@@ -629,8 +631,7 @@ bool r16_rank_update(void *y, int64_t ldy, const float *t, int nparts, int64_t p
   hipLaunchKernelGGL((rank_update16_mfma_kernel<E, D>), dim3((unsigned)gx, (unsigned)ny), dim3(kR16Threads), 0, st,   \
                      reinterpret_cast<typename E::storage *>(y), ldy, t, nparts, part_stride, ff, layout, M, N, r,    \
                      rows, scale, p, seed, offset, offset_dev)
-  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) RU(f16_t, true); else RU(f16_t, false); }
-  else { if (p > 0.f) RU(bf16_t, true); else RU(bf16_t, false); }
+  if (p > 0.f) RU(bf16_t, true); else RU(bf16_t, false);
 #undef RU
   return true;
 }
@@ -648,8 +649,7 @@ bool r16_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, int f
   hipLaunchKernelGGL((bwd_g16_mfma_kernel<E, D>), dim3(grid), dim3(kR16Threads), 0, st,                               \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, uf, gt_part, up_part, M, N, r, log_ct8, nct, \
                      rows_per_block, scale, p, seed, offset, offset_dev)
-  if (act_dtype == LORA_AMD_F16) { if (p > 0.f) BG(f16_t, true); else BG(f16_t, false); }
-  else { if (p > 0.f) BG(bf16_t, true); else BG(bf16_t, false); }
+  if (p > 0.f) BG(bf16_t, true); else BG(bf16_t, false);
 #undef BG
   return true;
 }

@@ -766,7 +766,7 @@ class MergedWeights:
         groups = {}
         # the register-resident kernel needs no LDS class: every site of a (dtype, rank tile, masked) group in ONE launch
         # (the table is planned against the large class, which every supported site fits)
-        one_class = _C.factors_mfma_set_form(-1) == 1 if any(st[9] == "mfma" for st in owed) else False
+        one_class = True
         for st in owed:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16

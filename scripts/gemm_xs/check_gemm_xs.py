@@ -1,12 +1,14 @@
-"""K1/K2 input-stationary kernel (csrc/gemm_xs.hip, round 5): lora.py:53-58 and its input gradient at the short-contraction /
+"""K1/K2 input-stationary kernel (scripts/gemm_xs/gemm_xs.hip, round 5; an experiment outside the product library since round 6 —
+run with ``python -m pytest scripts/gemm_xs/check_gemm_xs.py -m gpu``): lora.py:53-58 and its input gradient at the short-contraction /
 many-row sites, against the numpy oracle — plain product, LoRA branch, dropout with the kernels' own mask extracted, the
 accumulate form, ragged M / N tails, f16.  The factors enter as hi + lo fragments (f32-grade), so the tolerance on the branch
-is the output rounding alone.  Everything goes through the C-ABI (``lora_amd/_C.py``)."""
+is the output rounding alone.  Goes through ``scripts/gemm_xs/xs.py`` (ctypes)."""
 import numpy as np
 import pytest
 import torch
 
 from lora_amd import _C
+from scripts.gemm_xs import xs as XS
 from oracle import lora_numpy as O
 from tests.test_gpu_kernels import close, n, rnd
 from tests.test_gpu_parity_r3 import _mask
@@ -27,8 +29,8 @@ def test_xs_forward_matches_oracle(M, K, N, r, dt):
     x, w = rnd((M, K), dt, 1.0, seed=1), rnd((N, K), dt, 0.05, seed=2)
     b = rnd((N,), dt, 0.5, seed=3)
     down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
-    assert _C.xs_supported(x, K, N, r)
-    y, t = _C.linear_xs_fwd(x, w, b, down, up, s)
+    assert XS.xs_supported(x, K, N, r)
+    y, t = XS.linear_xs_fwd(x, w, b, down, up, s)
     X, W, Bv, A, U = n(x), n(w), n(b), n(down), n(up)
     yo, to = O.lora_linear_forward(X, W, Bv, A, U, s)
     close(n(t), to, np.abs(X) @ np.abs(A).T, "f32", k=3e-5, msg="T")
@@ -42,16 +44,16 @@ def test_xs_plain_product_on_a_packed_weight(M, K, N):
     weight itself (site.reserved = 1); the accumulate flag of lora_amd_linear_ws is refused."""
     dt = "bf16"
     x, w, b = rnd((M, K), dt, 1.0, seed=1), rnd((N, K), dt, 0.05, seed=2), rnd((N,), dt, 0.5, seed=3)
-    y, t = _C.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, bias=b))
+    y, t = XS.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, bias=b))
     assert t is None
     X, W, Bv = n(x), n(w), n(b)
     ref = X @ W.T + Bv
     absref = np.abs(X) @ np.abs(W).T + np.abs(Bv)
     close(n(y), ref, absref, dt, k=3e-5, msg="Y")
-    y_rm, _ = _C.linear_xs(x, dict(wp=w, N=N, bias=b, rowmajor=True))
+    y_rm, _ = XS.linear_xs(x, dict(wp=w, N=N, bias=b, rowmajor=True))
     assert torch.equal(y_rm, y)
     with pytest.raises(RuntimeError, match="no accumulate form"):
-        _C.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, y=y.clone(), flayout=4))
+        XS.linear_xs(x, dict(wp=_C.ws_pack(w), N=N, y=y.clone(), flayout=4))
 
 
 @pytest.mark.parametrize("M,K,N,r", [(4096, 640, 640, 4), (9216, 2560, 320, 16), (1000, 1280, 640, 8), (130, 768, 320, 3),
@@ -62,8 +64,8 @@ def test_xs_input_gradient(M, K, N, r):
     dt, s = "bf16", 0.6
     g, w = rnd((M, N), dt, 1.0, seed=2), rnd((N, K), dt, 0.05, seed=3)
     down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
-    assert _C.xs_supported(g, N, K, r)
-    dx, gt = _C.linear_xs_dx(g, w, down, up, s)
+    assert XS.xs_supported(g, N, K, r)
+    dx, gt = XS.linear_xs_dx(g, w, down, up, s)
     G, W, A, U = n(g), n(w), n(down), n(up)
     dxo, _, _, _, _ = O.lora_linear_backward(G, np.zeros((M, K), np.float32), W, A, U, s)
     gt_ref = s * (G @ U)
@@ -81,7 +83,7 @@ def test_xs_dropout_forward_vs_oracle_with_extracted_mask(M, K, N, r, p):
     down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.5, seed=5)
     off = torch.tensor([977], dtype=torch.int64, device=DEV)
     mask = _mask(M, N, p, seed, off)
-    y, t = _C.linear_xs_fwd(x, w, b, down, up, s, p, seed, off)
+    y, t = XS.linear_xs_fwd(x, w, b, down, up, s, p, seed, off)
     X, W, Bv, A, U = n(x), n(w), n(b), n(down), n(up)
     yo, to = O.lora_linear_forward(X, W, Bv, A, U, s, None, mask)
     close(n(t), to, np.abs(X) @ np.abs(A).T, "f32", k=3e-5, msg="T")
@@ -102,7 +104,7 @@ def test_xs_dropout_input_gradient_vs_oracle_with_extracted_mask(M, K, N, r, p):
     G, W, A, U = n(g), n(w), n(down), n(up)
     dxo, _, _, _, _ = O.lora_linear_backward(G, np.zeros((M, K), np.float32), W, A, U, s, None, mask)
     gt_o = s * ((G * mask) @ U)
-    dx, gt = _C.linear_xs_dx(g, w, down, up, s, p, seed, off)
+    dx, gt = XS.linear_xs_dx(g, w, down, up, s, p, seed, off)
     close(n(gt), gt_o, s * ((np.abs(G) * mask) @ np.abs(U)), "f32", k=3e-5, msg="Gt")
     close(n(dx), dxo, np.abs(G) @ np.abs(W) + np.abs(gt_o) @ np.abs(A), dt, k=3e-5, msg="dX")
 
@@ -114,12 +116,12 @@ def test_xs_block_geometries_agree(sl, pg):
     M, K, N, r, s = 5000, 320, 2560, 8, 0.7
     x, w, b = rnd((M, K), "bf16", seed=1), rnd((N, K), "bf16", 0.05, seed=2), rnd((N,), "bf16", seed=3)
     down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
-    y0, t0 = _C.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
+    y0, t0 = XS.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
     try:
-        _C.xs_set_tuning(sl, pg)
-        y1, t1 = _C.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
+        XS.xs_set_tuning(sl, pg)
+        y1, t1 = XS.linear_xs_fwd(x, w, b, down, up, s, 0.1, 5, 9)
     finally:
-        _C.xs_set_tuning(0, 0)
+        XS.xs_set_tuning(0, 0)
     assert torch.equal(y0, y1) and torch.equal(t0, t1)
 
 
@@ -129,7 +131,7 @@ def test_xs_and_ws_kernels_agree_on_the_same_site():
     M, K, N, r, s = 4096, 320, 640, 4, 0.9
     x, w, b = rnd((M, K), "bf16", seed=1), rnd((N, K), "bf16", 0.05, seed=2), rnd((N,), "bf16", seed=3)
     down, up = rnd((r, K), "f32", 0.2, seed=4), rnd((N, r), "f32", 0.3, seed=5)
-    y1, t1 = _C.linear_xs_fwd(x, w, b, down, up, s)
+    y1, t1 = XS.linear_xs_fwd(x, w, b, down, up, s)
     y2, t2 = _C.linear_ws_fwd(x, w, b, down, up, s)
     assert (t1 - t2).abs().max() <= 1e-4 * t2.abs().max()
     assert (y1.float() - y2.float()).abs().max() <= 2.0 ** -6 * y2.float().abs().max()

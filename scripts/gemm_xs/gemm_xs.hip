@@ -33,6 +33,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "gemm_xs.h"
 
 namespace lora_amd {
 namespace {

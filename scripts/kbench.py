@@ -193,9 +193,10 @@ def bench_linear(args):
 
 
 def bench_xs(args):
-    """K1/K2 input-stationary kernel (gemm_xs.hip) per site shape: forward with the LoRA branch, with dropout, the plain
+    """K1/K2 input-stationary kernel (scripts/gemm_xs/gemm_xs.hip, an experiment outside the product library) per site shape: forward with the LoRA branch, with dropout, the plain
     product on a packed weight (what a merged-weight site would run), the input gradient — next to the weight-stationary
     kernel, the library GEMM alone and the library GEMM + one branch launch."""
+    from scripts.gemm_xs import xs as XS
     r = args.rank
     HBM = 8.0e12
     shapes = ((16384, 320, 320), (16384, 320, 960), (16384, 320, 2560), (4096, 640, 640), (4096, 640, 1920), (4096, 640, 5120),
@@ -211,19 +212,19 @@ def bench_xs(args):
         wp = _C.ws_pack(W)
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         site = dict(wp=wp, N=N, bias=bias, down=A, up=B, scale=1e-3, y=y)
-        res["xs_us"] = timeit(lambda: _C.linear_xs(x, site), args.iters)[0] * 1e6
+        res["xs_us"] = timeit(lambda: XS.linear_xs(x, site), args.iters)[0] * 1e6
         res["xs_frac8"] = byts / (res["xs_us"] * 1e-6) / HBM
         sweep = {}
         for sl in ((1, 2, 4) if K == 320 else (1, 2)):
             for pg in (1, 2, 4, 8, 64):
-                _C.xs_set_tuning(sl, pg)
-                sweep[f"sl{sl}_pg{pg}"] = round(timeit(lambda: _C.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6, 2)
-        _C.xs_set_tuning(0, 0)
+                XS.xs_set_tuning(sl, pg)
+                sweep[f"sl{sl}_pg{pg}"] = round(timeit(lambda: XS.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6, 2)
+        XS.xs_set_tuning(0, 0)
         res["xs_plain_sweep"] = sweep
         res["xs_plain_best"] = min(sweep.items(), key=lambda kv: kv[1])
-        res["xs_plain_rowmajor_us"] = timeit(lambda: _C.linear_xs(x, dict(wp=W, N=N, bias=bias, y=y, rowmajor=True)), args.iters)[0] * 1e6
-        res["xs_drop_us"] = timeit(lambda: _C.linear_xs(x, dict(site, p=0.1, seed=7, off=11)), args.iters)[0] * 1e6
-        res["xs_plain_us"] = timeit(lambda: _C.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6
+        res["xs_plain_rowmajor_us"] = timeit(lambda: XS.linear_xs(x, dict(wp=W, N=N, bias=bias, y=y, rowmajor=True)), args.iters)[0] * 1e6
+        res["xs_drop_us"] = timeit(lambda: XS.linear_xs(x, dict(site, p=0.1, seed=7, off=11)), args.iters)[0] * 1e6
+        res["xs_plain_us"] = timeit(lambda: XS.linear_xs(x, dict(wp=wp, N=N, bias=bias, y=y)), args.iters)[0] * 1e6
         res["ws_us"] = timeit(lambda: _C.linear_ws(x, [site]), args.iters)[0] * 1e6
         res["ws_drop_us"] = timeit(lambda: _C.linear_ws(x, [dict(site, p=0.1, seed=7, off=11)]), args.iters)[0] * 1e6
         res["lib_gemm_us"] = timeit(lambda: torch.nn.functional.linear(x, W, bias), args.iters)[0] * 1e6
@@ -235,7 +236,7 @@ def bench_xs(args):
             wpt = _C.ws_pack(W, True)
             dx = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
             st = dict(wp=wpt, N=K, down=B, up=A, scale=1.0, t_scale=1.0, flayout=3, y=dx)
-            res["xs_dx_us"] = timeit(lambda: _C.linear_xs(g, st), args.iters)[0] * 1e6
+            res["xs_dx_us"] = timeit(lambda: XS.linear_xs(g, st), args.iters)[0] * 1e6
             res["ws_dx_us"] = timeit(lambda: _C.linear_ws(g, [st]), args.iters)[0] * 1e6
             res["lib_dx_us"] = timeit(lambda: g @ W, args.iters)[0] * 1e6
         print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
@@ -418,22 +419,18 @@ def bench_fm(args):
                                    "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
         tot += t
     # the register-resident kernel on the same tables
-    prev = _C.factors_mfma_set_form(1)
-    try:
-        tot_r = 0.0
-        for tab, ns, grid, cls in tabs:
-            t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
-            rec[f"reg_class{cls}_us"] = round(t * 1e6, 1)
-            tot_r += t
-        rec["reg_pass_us"], rec["reg_frac8"] = round(tot_r * 1e6, 1), round(byts / 8e12 / tot_r, 3)
-        # ... and as ONE launch over every site (what ops.MergedWeights.flush_factors issues for this kernel)
-        every = [s_ for _, ss in sorted(by_cls.items()) for s_ in ss]
-        arr, grid = _C.factors_mfma_table(every, dt, 2)
-        tab1 = _C.table_to_device(arr, DEV)
-        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab1, len(every), grid, 2, dt), inner=5)
-        rec["reg_one_launch_us"], rec["reg_one_launch_frac8"] = round(t * 1e6, 1), round(byts / 8e12 / t, 3)
-    finally:
-        _C.factors_mfma_set_form(prev)
+    tot_r = 0.0
+    for tab, ns, grid, cls in tabs:
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
+        rec[f"reg_class{cls}_us"] = round(t * 1e6, 1)
+        tot_r += t
+    rec["reg_pass_us"], rec["reg_frac8"] = round(tot_r * 1e6, 1), round(byts / 8e12 / tot_r, 3)
+    # ... and as ONE launch over every site (what ops.MergedWeights.flush_factors issues for this kernel)
+    every = [s_ for _, ss in sorted(by_cls.items()) for s_ in ss]
+    arr, grid = _C.factors_mfma_table(every, dt, 2)
+    tab1 = _C.table_to_device(arr, DEV)
+    t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab1, len(every), grid, 2, dt), inner=5)
+    rec["reg_one_launch_us"], rec["reg_one_launch_frac8"] = round(t * 1e6, 1), round(byts / 8e12 / t, 3)
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
     rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)

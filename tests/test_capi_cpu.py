@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"declared in include/lora_amd.h but not exported: {missing}"
     assert sorted(_C.SYMBOLS) == declared, "lora_amd/_C.py SYMBOLS out of sync with the header"
-    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 5 and lib.lora_amd_target_arch() == b"gfx950"
+    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 6 and lib.lora_amd_target_arch() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
@@ -215,8 +215,10 @@ def test_round4_hooks_and_plan_values_are_host_state():
     its range, and the in-step merge's plan value carries the tile geometry it was planned for."""
     lib = _C.require()
     assert _C.rank16_mfma(-1) == 1 and _C.rank16_mfma(0) == 1 and _C.rank16_mfma(-1) == 0 and _C.rank16_mfma(1) == 0
-    # round 5 removed the LDS-resident kernel: the entry stays in the ABI and always answers "register-resident"
-    assert _C.factors_mfma_set_form(-1) == 1 and _C.factors_mfma_set_form(0) == 1 and _C.factors_mfma_set_form(7) == 1
+    # ABI 6 dropped the dead lora_amd_factors_mfma_set_form entry (round 5 had removed the kernel it switched to) and the
+    # unrouted input-stationary GEMM's three entries (scripts/gemm_xs/ now)
+    for gone in ("lora_amd_factors_mfma_set_form", "lora_amd_linear_xs", "lora_amd_xs_config", "lora_amd_xs_set_tuning"):
+        assert not hasattr(lib, gone), gone
     assert lib.lora_amd_merge_step_set_tuning(9, -1) != 0 and b"tile 9" in lib.lora_amd_last_error()
     sites = (_C.MstepSite * 2)()
     for s, (N, K, r) in zip(sites, [(320, 320, 4), (2560, 328, 16)]):

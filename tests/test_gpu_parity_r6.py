@@ -1,0 +1,243 @@
+"""Round-6 device parity: ``--mixed_precision fp16`` (ref train_lora_dreambooth.py:489-494) at the
+magnitudes the reference's own initial state produces.
+
+``lora_up`` starts at 0 (lora.py:50-51) and sits at ~1e-4 for the first hundreds of steps at lr 1e-4; ``Gt = s G up`` is
+then ~1e-8 (unscaled G ~ 1e-5) .. ~1e-3 (loss-scaled by 65536).  f16 has 5 exponent bits: an operand of that size split
+hi + lo for the matrix cores lands in f16's subnormals and loses its lo part.  Round 6: the one-launch factor pass
+(csrc/factor_mfma.hip) pre-scales every split operand by a power of two (per site for the factors, per row block for
+T / Gt) and folds the scale back into the f32 result; the rank-9..16 streaming kernels take their VALU forms for f16.
+
+* the factor pass vs ``oracle/lora_numpy.lora_linear_backward`` with ``up ~ N(0, 1e-4)``, G loss-scaled (x 65536) and
+  unscaled, f16 activations, dropout, ranks 4 / 8 / 16, ``up = 0`` exactly: 1e-4 of the absolute bound, the bf16 tolerance;
+* the per-site kernels (rowdot / rank_update / bwd_g at rank 16, f16) at the same magnitudes;
+* a whole fp16 run from the reference's init with dynamic loss scaling against the f32 restatement of the reference's step.
+Everything goes through the C-ABI (``lora_amd/_C.py``)."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import lora_amd as L
+from lora_amd import _C
+from lora_amd import trainer as T
+from lora_amd.standin import DDPMScheduler, sd15_unet
+from oracle import lora_numpy as O
+from oracle import torch_ref as TR
+from tests import helpers as H
+from tests.test_gpu_kernels import close, n, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOSS_SCALE = 65536.0
+
+
+def _factor_pass(x, g, down, up, s_, r, dt, drop=None):
+    """pack + one-launch pass + fold for ONE site -> (d_up [N, r], d_down [r, K]) as numpy."""
+    M, K = x.shape
+    N = g.shape[1]
+    plan = _C.factors_mfma_plan(M, K, N, r, dt)
+    assert plan.supported
+    up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
+    down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
+    pk_down = torch.full((int(plan.pack_down_elems),), float("nan"), dtype=dt, device=DEV)
+    pk_up = torch.full((int(plan.pack_up_elems),), float("nan"), dtype=dt, device=DEV)
+    arr, total = _C.factor_pack_table([(down, up, pk_down, pk_up)])
+    _C.factor_pack(_C.table_to_device(arr, DEV), 1, total, dt)
+    row = (g, x, pk_down, pk_up, up_part, down_part, s_, None, None, r, plan) + ((drop,) if drop else ())
+    arr, grid = _C.factors_mfma_table([row], dt, int(plan.lds_class))
+    _C.linear_bwd_factors_mfma_ragged(_C.table_to_device(arr, DEV), 1, grid, int(plan.lds_class), dt, bool(drop))
+    d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
+    table, cnt, total = _C.make_reduce_table(
+        [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
+         (down_part, d_down, plan.nparts, plan.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)], DEV)
+    _C.reduce_batched(table, cnt, total)
+    return n(d_up), n(d_down)
+
+
+@pytest.mark.parametrize("M,K,N,r", [(16384, 320, 320, 4), (1024, 1280, 1280, 16), (4096, 640, 5120, 8), (308, 768, 320, 4)])
+@pytest.mark.parametrize("g_std,up_std", [(1e-5 * LOSS_SCALE, 1e-4), (1e-5, 1e-4), (3e-4, 3e-6), (1e-5 * LOSS_SCALE, 0.0)],
+                         ids=["loss_scaled", "unscaled", "tiny_up", "up_zero"])
+def test_factor_pass_f16_at_the_magnitudes_of_the_reference_init(M, K, N, r, g_std, up_std):
+    """autograd of lora.py:53-58 for the factors under fp16 (ref train_lora_dreambooth.py:489-494), ``up`` as small as the
+    reference's zero init leaves it: dUp = s G^T (X down^T), dDown = (s G up)^T X within 1e-4 of the absolute bound — the
+    bf16 tolerance of test_factors_mfma_pass_vs_oracle — although up ~ 1e-4 and Gt ~ 1e-8 .. 1e-3 are below or near f16's
+    smallest normal number (6.1e-5).  The oracle sees the same f16-rounded G and X."""
+    dt, s_ = torch.float16, 0.7
+    x, g = rnd((M, K), "f16", seed=1), rnd((M, N), "f16", g_std, seed=2)
+    down = rnd((r, K), "f32", 1.0 / r, seed=3)
+    up = rnd((N, r), "f32", up_std, seed=4) if up_std else torch.zeros(N, r, device=DEV)
+    X, G, A, U = n(x), n(g), n(down), n(up)
+    _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s_)
+    d_up, d_down = _factor_pass(x, g, down, up, s_, r, dt)
+    close(d_up, duo, s_ * (np.abs(G).T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
+    close(d_down, ddo, (s_ * np.abs(G) @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
+    if up_std == 0.0:
+        assert not d_down.any()  # Gt = 0 exactly: the reference's first step
+    else:   # not vacuous: the result is well above f32 noise
+        assert np.abs(ddo).max() > 0 and np.isfinite(d_down).all() and np.isfinite(d_up).all()
+
+
+@pytest.mark.parametrize("M,K,N,r,p", [(4096, 320, 320, 16, 0.1), (2000, 640, 320, 4, 0.25)])
+def test_factor_pass_f16_with_dropout_at_training_magnitudes(M, K, N, r, p):
+    """The same with nn.Dropout on the branch (lora.py:45, 57; the extended injection's p = 0.1): the mask regenerated from
+    (seed, offset_dev) inside the f16 instantiation of the kernel."""
+    dt, s_, seed = torch.float16, 0.8, 0x5EED1234
+    off = torch.tensor([(1 << 33) + 777], dtype=torch.int64, device=DEV)
+    x, g = rnd((M, K), "f16", seed=1), rnd((M, N), "f16", 1e-5 * LOSS_SCALE, seed=2)
+    down, up = rnd((r, K), "f32", 1.0 / r, seed=3), rnd((N, r), "f32", 1e-4, seed=4)
+    mask = H.philox_dropout_mask(M * N, p, seed, int(off.item())).view(M, N).numpy()
+    X, G, A, U = n(x), n(g), n(down), n(up)
+    _, ddo, duo, _, _ = O.lora_linear_backward(G, X, np.zeros((N, K), np.float32), A, U, s_, None, mask)
+    d_up, d_down = _factor_pass(x, g, down, up, s_, r, dt, drop=(p, seed, off))
+    Gm = np.abs(G) * mask
+    close(d_up, duo, s_ * (Gm.T @ (np.abs(X) @ np.abs(A).T)), "f32", k=1e-4, msg="dUp")
+    close(d_down, ddo, (s_ * Gm @ np.abs(U)).T @ np.abs(X), "f32", k=1e-4, msg="dDown")
+
+
+def test_factor_pass_f16_propagates_an_overflowed_gradient():
+    """GradScaler's skip logic (ref :489-494 through accelerate) keys on non-finite gradients: an inf in G must reach the
+    folded gradients through the pre-scaled operands (the power of two is chosen from a clamped bound, never NaN-ed away)."""
+    M, K, N, r = 1024, 320, 320, 4
+    x, g = rnd((M, K), "f16", seed=1), rnd((M, N), "f16", 0.5, seed=2)
+    g[100, 7] = float("inf")
+    down, up = rnd((r, K), "f32", 0.25, seed=3), rnd((N, r), "f32", 1e-4, seed=4)
+    d_up, d_down = _factor_pass(x, g, down, up, 1.0, r, torch.float16)
+    assert not np.isfinite(d_up).all() and not np.isfinite(d_down).all()
+
+
+@pytest.mark.parametrize("r", [16, 12])
+def test_rank16_streaming_kernels_f16_at_training_magnitudes(r):
+    """The per-site kernels of the dropout sites at ranks 9..16 (BASELINE configs[3]'s rank) with f16 activations: Gt = s G up
+    (rowdot, factor [N, r] ~ 1e-4), dX += Gt down (rank_update, Gt ~ 1e-3 .. 1e-8) — f32-grade against float64, for a
+    loss-scaled and an unscaled G.  (f16 takes the VALU kernels since round 6: csrc/rank16_mfma.hip's split needs bf16's
+    exponent range.)"""
+    M, N, K, s_ = 2304, 640, 320, 0.9
+    up, down = rnd((N, r), "f32", 1e-4, seed=1), rnd((r, K), "f32", 1.0 / r, seed=2)
+    for g_std in (1e-5 * LOSS_SCALE, 1e-5):
+        g = rnd((M, N), "f16", g_std, seed=3)
+        gt = _C.rowdot(g, up, _C.FACTOR_KR, s_)
+        want = s_ * (n(g).astype(np.float64) @ n(up).astype(np.float64))
+        close(n(gt), want, s_ * (np.abs(n(g)) @ np.abs(n(up))), msg=f"Gt g_std={g_std}")
+        dx = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+        _C.rank_update_(dx, gt, down, _C.FACTOR_RK, 1.0)
+        wdx = n(gt).astype(np.float64) @ n(down).astype(np.float64)
+        # one f16 rounding of the result (subnormal results: absolute 2^-25)
+        assert np.abs(n(dx) - wdx).max() <= 2.0 ** -11 * np.abs(wdx).max() + 2.0 ** -24
+
+
+# ----------------------------------------------------------------------------- the whole fp16 step from the reference's init
+def test_fp16_loss_scaled_run_from_the_reference_initial_state(monkeypatch):
+    """ref train_lora_dreambooth.py:489-494 (``--mixed_precision fp16``: accelerate's GradScaler around the step) and
+    lora.py:50-51 (``up = 0``): 6 steps at lr 1e-4 of the SD1.5-size UNet on the bench's path (f16-resident weights,
+    channels-last, head-padded + grouped projections, merged weights, dynamic loss scaling 65536) against the reference's
+    op sequence in f32 (``oracle/torch_ref``, evaluated on the device by ``H.oracle_on_device``).  ``up`` is 0, then
+    ~1e-4 .. 6e-4: exactly the regime where the f16 split used to lose its low parts.  Checked per step: the loss; no step
+    skipped for overflow; after the run: ||up||, the direction of ``up``, and the last step's factor gradients per tensor."""
+    from lora_amd.standin import fused
+
+    steps, lr = 6, 1e-4
+    sys.path.insert(0, H.REPO)
+    from bench import build_unet
+
+    g = torch.Generator().manual_seed(78)
+    data = [((torch.randn(4, 4, 64, 64, generator=g) * 0.18215), torch.randn(4, 77, 768, generator=g),
+             torch.randn(4, 4, 64, 64, generator=g), torch.randint(0, 1000, (4,), generator=g)) for _ in range(2)]
+    sched = DDPMScheduler()
+
+    def init_down(mods):
+        gg = torch.Generator().manual_seed(5)
+        return [torch.randn(m.lora_down.weight.shape if hasattr(m, "lora_down") else m.down.shape, generator=gg) / 4
+                for m in mods]
+
+    monkeypatch.setenv("LORA_AMD_HEAD_PAD", "1")
+    monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1")
+    monkeypatch.setattr(fused, "_ENABLED", True)
+
+    # ---- device, fp16
+    unet = build_unet(torch.device(DEV), torch.float16, seed=0)
+    state = {k_: v.float() for k_, v in unet.state_dict().items()}   # the f16-rounded frozen weights, for the f32 reference
+    unet.to(memory_format=torch.channels_last)
+    L.inject_trainable_lora(unet, r=4)
+    T.promote_lora_to_fp32(unet)
+    mods = [m for m in unet.modules() if isinstance(m, L.LoraInjectedLinear)]
+    for m, d in zip(mods, init_down(mods)):
+        m.lora_down.weight.data.copy_(d.to(DEV))
+        assert float(m.lora_up.weight.abs().max()) == 0.0  # the reference's init
+    unet.train()
+    st = T.FlatLoraState([{"params": T.lora_params(unet), "lr": lr, "weight_decay": 1e-2}], max_grad_norm=1.0,
+                         device=torch.device(DEV))
+    st.attach_direct_grads(unet)
+    scaler = st.enable_loss_scaling(LOSS_SCALE)
+    mw = st.enable_merged_weights(unet)
+    fmt = torch.channels_last
+    dev_losses, last_grads = [], None
+    for k in range(steps):
+        lat, ehs, noise, ts = data[k % 2]
+        loss = T.forward_backward(unet, sched, lat.to(DEV).half().contiguous(memory_format=fmt), ehs.to(DEV).half(),
+                                  T.StepConfig(), noise=noise.to(DEV).half().contiguous(memory_format=fmt),
+                                  timesteps=ts.to(DEV), merged=mw, loss_scale=st.loss_scale)
+        st.reduce_pending()
+        last_grads = (st.flat_g / float(scaler[0])).cpu().numpy().copy()
+        st.step(st.all_reduce())
+        dev_losses.append(float(loss))
+        assert float(scaler[0]) == LOSS_SCALE and float(scaler[3]) == 1.0, (k, scaler.tolist())  # no overflow, no skip
+    ups_dev = torch.cat([m.lora_up.weight.detach().reshape(-1) for m in mods]).float().cpu().numpy()
+    sizes = [p.numel() for p in T.lora_params(unet)]
+    del unet, st, mw
+    torch.cuda.empty_cache()
+
+    # ---- the reference's op sequence, f32, same f16-rounded frozen weights and inputs
+    with torch.device("meta"):
+        ref = sd15_unet()
+    ref.to_empty(device=DEV)
+    ref.load_state_dict(state)
+    del state
+    ref.requires_grad_(False)
+    params = TR.inject(ref, L.UNET_DEFAULT_TARGET_REPLACE, r=4)
+    sites = TR.sites_of(ref)
+    for s_, d in zip(sites, init_down(sites)):
+        s_.down.data.copy_(d.to(DEV))
+    ref.train()
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    ac = sched.alphas_cumprod.to(DEV)
+    ref_losses, ref_grads = [], None
+    with H.oracle_on_device():
+        for k in range(steps):
+            lat, ehs, noise, ts = (t.to(DEV) for t in data[k % 2])
+            lat, ehs, noise = (v.half().float() for v in (lat, ehs, noise))
+            grads = {}
+            hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(params)]
+            ref_losses.append(float(TR.dreambooth_step(lambda x_, tt, c: ref(x_, tt, c).sample, params, opt, lat, noise, ts, ehs, ac)))
+            for h in hooks:
+                h.remove()
+            ref_grads = [grads[i].reshape(-1).cpu().numpy() for i in range(len(params))]
+    ups_ref = torch.cat([s_.up.detach().reshape(-1) for s_ in sites]).float().cpu().numpy()
+    del ref
+    torch.cuda.empty_cache()
+
+    dev_losses, ref_losses = np.array(dev_losses), np.array(ref_losses)
+    cos_up = float(ups_dev @ ups_ref / (np.linalg.norm(ups_dev) * np.linalg.norm(ups_ref) + 1e-30))
+    rep = dict(dev_losses=dev_losses.round(5).tolist(), ref_losses=ref_losses.round(5).tolist(),
+               up_norm=(float(np.linalg.norm(ups_dev)), float(np.linalg.norm(ups_ref))), cos_up=cos_up)
+    # per-tensor cosine of the LAST step's factor gradients (up ~ 5e-4 there: dDown = (s G up)^T X is the operand at risk)
+    pos, worst_up, worst_down = 0, 2.0, 2.0
+    gmax = [max(float(np.linalg.norm(gr)) for gr in ref_grads[kind::2]) for kind in (0, 1)]   # per kind: |dDown| ~ |up| |dUp|
+    assert [gr.size for gr in ref_grads] == sizes
+    for i, gr in enumerate(ref_grads):   # order [up0, down0, up1, ...] = itertools.chain(*unet_lora_params), ref :610-616
+        gd = last_grads[pos:pos + gr.size]
+        pos += gr.size
+        nr = float(np.linalg.norm(gr))
+        if nr < 1e-3 * gmax[i % 2]:
+            continue
+        c = float(gr @ gd) / (nr * float(np.linalg.norm(gd)) + 1e-30)
+        if i % 2 == 0:
+            worst_up = min(worst_up, c)
+        else:
+            worst_down = min(worst_down, c)
+    rep.update(worst_cos_d_up=worst_up, worst_cos_d_down=worst_down)
+    print("\n[fp16 run from up = 0]", rep)
+    assert np.abs(dev_losses - ref_losses).max() <= 0.01 * np.abs(ref_losses).max(), rep
+    nr = rep["up_norm"][1]
+    assert abs(rep["up_norm"][0] - nr) <= 0.05 * nr and cos_up >= 0.9, rep
+    assert worst_up >= 0.98 and worst_down >= 0.98, rep
