@@ -478,6 +478,8 @@ def swap_in_aten_adapters(model) -> int:
 
 SECONDARY = [  # (tag, extra argv, env, timeout s): driver-observed lines for the other BASELINE geometries, short runs
     ("frozen_only", ["--adapters", "none"], {}, 150),
+    ("frozen_only configs[2]", ["--adapters", "none", "--text-encoder", "1", "--rank", "8"], {}, 150),
+    ("frozen_only configs[3]", ["--adapters", "none", "--extended", "1", "--rank", "16", "--res", "768", "--batch", "1"], {}, 240),
     ("host_options_off", ["--channels-last", "0", "--head-pad", "0", "--conv-find", "0"], {"LORA_AMD_HOSTOPS": "0"}, 150),
     ("aten_adapters", ["--adapters", "aten"], {}, 150),
     ("fused_per_site_kernels (--merged 0)", ["--merged", "0"], {}, 150),
@@ -566,7 +568,7 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
     ``secondary`` as (tag, value, unit, ms_per_step, steps, execution) only.  Everything else — kernel tables, attention
     picks, long descriptions — is the detail record (``bench_detail.json`` + one stderr line)."""
     cfg = out.get("config", {})
-    c = _pick(cfg, ("global_batch", "samples_per_s", "parallelism", "execution", "allreduce_us", "device", "trainable_params",
+    c = _pick(cfg, ("global_batch", "samples_per_s", "global_steps_per_s", "parallelism", "execution", "allreduce_us", "device", "trainable_params",
                     "allreduce_payload_bytes", "final_loss", "sites", "groups", "weight_elements", "power_iterations"))
     c = {"workload": _short(cfg.get("workload_short") or cfg.get("workload", ""), 126), **c}
     rec = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -601,7 +603,8 @@ def compact_record(out: dict, detail_path: str = "") -> dict:
         rec["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=_short(cb.get("sample", ""), 126))
         if isinstance(cb.get("merge"), dict):
             rec["cpu_baseline"]["merge_ms"] = cb["merge"].get("ms")
-    for k in ("lora_overhead_ms", "value_host_options_off", "value_frozen_only", "value_aten_adapters",
+    for k in ("lora_overhead_ms", "lora_overhead_ms_cfg2", "lora_overhead_ms_cfg3", "value_frozen_only_cfg2",
+              "value_frozen_only_cfg3", "value_host_options_off", "value_frozen_only", "value_aten_adapters",
               "value_fused_per_site_kernels"):
         if k in out:
             rec[k] = out[k]
@@ -799,6 +802,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--path-log", default=None, help="write the adapter-path profile's per-site records (phase, kernel path, "
                     "M, K, N, r) of one eager step to this JSON file")
+    ap.add_argument("--frozen-twins", type=int, default=1, help="--adapters none: 1 = every adapter site runs its frozen twin "
+                    "(the merged path's GEMM launches on frozen weights, standin/frozen.py: like for like with the adapter "
+                    "step); 0 = plain nn.Linear modules (round 5's form of the leg)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary lines (other BASELINE "
                     "geometries, host options off, ATen adapters) the default 1-GPU run appends under `secondary`")
     ap.add_argument("--secondary-budget", type=float, default=420.0, help="seconds all secondary lines may take together")
@@ -861,7 +867,14 @@ def main():
     if args.channels_last:
         unet.to(memory_format=torch.channels_last)
     if args.adapters == "none":
-        pass  # frozen_only leg: no adapter anywhere
+        # frozen_only leg: no adapter anywhere.  On the device every site an adapter would occupy gets its FROZEN TWIN
+        # (standin/frozen.py): the merged path's own GEMM launches on frozen weights in the same layouts (grouped q / k / v,
+        # head-padded rows / columns, transposed copy for the input gradient), so that step - frozen_only isolates the LoRA
+        # launches (the plain-Linear form of this leg ran 3 GEMMs where the adapter step runs 1)
+        if on_gpu and args.frozen_twins:
+            from lora_amd.standin.frozen import install_frozen_twins
+
+            install_frozen_twins(unet, L.UNET_EXTENDED_TARGET_REPLACE if args.extended else L.UNET_DEFAULT_TARGET_REPLACE)
     elif args.extended:
         L.inject_trainable_lora_extended(unet, r=args.lora_rank)  # conv adapters keep the constructor's dropout 0.1
     else:
@@ -878,10 +891,20 @@ def main():
 
         text_encoder = clip_text_model().to(dev).to(cdt)
         text_encoder.requires_grad_(False)
-        L.inject_trainable_lora(text_encoder, target_replace_module=["CLIPAttention"], r=args.lora_rank)
-        T.promote_lora_to_fp32(text_encoder)
-        text_encoder.train()
-        groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
+        if args.adapters == "none":
+            # frozen twin of configs[2]: the text encoder's backward must still run (in the adapter step it reaches the
+            # encoder's LoRA factors): the embedding output becomes a gradient leaf
+            if on_gpu and args.frozen_twins:
+                from lora_amd.standin.frozen import install_frozen_twins
+
+                install_frozen_twins(text_encoder, ["CLIPAttention"])
+            text_encoder.text_model.embeddings.register_forward_hook(lambda m, i, o: o.detach().requires_grad_(True))
+            text_encoder.train()
+        else:
+            L.inject_trainable_lora(text_encoder, target_replace_module=["CLIPAttention"], r=args.lora_rank)
+            T.promote_lora_to_fp32(text_encoder)
+            text_encoder.train()
+            groups.append({"params": T.lora_params(text_encoder), "lr": 5e-6, "weight_decay": 1e-2})
     state = T.FlatLoraState(groups, max_grad_norm=1.0, device=dev)
     merged = None
     if args.adapters == "none":
@@ -1017,7 +1040,10 @@ def main():
                       else "tiny stand-in UNet (plumbing)")
         out = {
             "metric": "train steps/sec SD1.5 rank-4 512^2 (train_lora_dreambooth.py step)",
-            "value": round(args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            # whole-job aggregate (driver contract): every rank's step consumes its own batch, so N ranks complete N x K
+            # batch-steps in the timed region; at N = 1 this is train_lora_dreambooth.py's global step rate, at N > 1 the
+            # global (optimiser-update) rate is config.global_steps_per_s = value / N
+            "value": round(args.steps * world / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if on_gpu else "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: SD1.5 UNet LoRA rank-%d bf16, batch %d/GPU, 512x512 (64x64x4 "
@@ -1035,9 +1061,11 @@ def main():
                            args.with_prior_preservation, args.adapters, args.standin, args.device, n_sites)),
                        "global_batch": args.batch * world, "samples_per_s": round(args.steps * args.batch * world / dt, 3),
                        "parallelism": f"dp{world}",
-                       "value_counts": "optimizer updates per second of the whole job (train_lora_dreambooth.py's global step: "
-                       "one update consumes batch x n_gpus samples; weak scaling, so aggregate throughput is samples_per_s)",
+                       "value_counts": "batch-steps per second summed over the ranks (a rank's step = one pass of the hot path "
+                       "over its own batch; weak scaling): value = samples_per_s / batch = n_gpus x global_steps_per_s, where "
+                       "global_steps_per_s counts train_lora_dreambooth.py's optimiser updates (one consumes batch x n_gpus samples)",
                        "rank_steps_per_s": round(args.steps * world / dt, 4),
+                       "global_steps_per_s": round(args.steps / dt, 4),
                        "timed_region": "noise + add_noise + UNet fwd + MSE + bwd + partial reduce + all-reduce + clip + AdamW; "
                        "VAE encode and CLIP forward (ref :818-840) are outside it: latents and text states are the "
                        "synthetic inputs SURVEY 8d prescribes (cached_latents-style)",
@@ -1123,6 +1151,13 @@ def main():
                     out["value_aten_adapters"] = rec["value"]
                 if rec["tag"].startswith("fused_per_site_kernels") and "value" in rec:
                     out["value_fused_per_site_kernels"] = rec["value"]
+            # the same difference for the other two training geometries: adapter step - its frozen twin, same child-run length
+            by_tag = {rec["tag"]: rec for rec in out["secondary"] if "ms_per_step" in rec and rec.get("ms_per_step")}
+            for cfg, full in (("cfg2", "configs[2] UNet+CLIP rank 8"), ("cfg3", "configs[3] extended rank 16 768^2 batch 1")):
+                twin = "frozen_only configs[%s]" % cfg[-1]
+                if full in by_tag and twin in by_tag:
+                    out["lora_overhead_ms_" + cfg] = round(by_tag[full]["ms_per_step"] - by_tag[twin]["ms_per_step"], 3)
+                    out["value_frozen_only_" + cfg] = by_tag[twin]["value"]
         emit(out)
     if world > 1:
         dist.barrier()

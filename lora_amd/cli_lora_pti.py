@@ -334,7 +334,8 @@ def train(instance_data_dir: str, pretrained_model_name_or_path: str, output_dir
     unet_lr, text_encoder_lr, ti_lr = learning_rate_unet * mult, learning_rate_text * mult, learning_rate_ti * mult
 
     dataset = SIO.PivotalTuningDataset(instance_data_dir, tokenizer, token_map, use_template, resolution,
-                                       use_mask_captioned_data=use_mask_captioned_data, seed=seed * 1000 + rank)
+                                       use_mask_captioned_data=use_mask_captioned_data, seed=seed * 1000 + rank,
+                                       content_seed=seed * 1000)
     if color_jitter and is_main:
         print("PTI : color_jitter needs torchvision (not installed); ignored")
     dataloader = text2img_dataloader(dataset, train_batch_size, tokenizer, vae, cached_latents, dev, rank, world, seed)

@@ -862,7 +862,9 @@ class LoraLinearMergedFunction(torch.autograd.Function):
             y = F.linear(x2, w_eff, b_eff)  # frozen dense GEMM (MFMA, hipBLASLt) on W + scale up down
         K = in_heads[0] * in_heads[1] if in_heads else w_eff.shape[1]
         N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
-        _log("fwd", "merged" + ("_heads" if (in_heads or out_heads) else ""), x2.shape[0], K, N, down.shape[0])
+        # down / up None: a FROZEN site in the merged path's layout (standin/frozen.py, bench.py's `frozen_only` leg)
+        _log("fwd", "merged" + ("_heads" if (in_heads or out_heads) else ""), x2.shape[0], K, N,
+             down.shape[0] if down is not None else 0)
         ctx.save_for_backward(x2, w_eff, down, up)
         ctx.w_eff_t = w_eff_t  # frozen for the step (never an autograd input)
         ctx.scale, ctx.sink, ctx.x_shape = float(scale), sink, x.shape
@@ -874,7 +876,6 @@ class LoraLinearMergedFunction(torch.autograd.Function):
     def backward(ctx, g):
         x2, w_eff, down, up = ctx.saved_tensors
         K, N = ctx.dims
-        r, M = down.shape[0], x2.shape[0]
         g2 = _rows2d(g, w_eff.shape[0])
         need_x, _, need_b, need_down, need_up = ctx.needs_input_grad[:5]
         sink = ctx.sink
@@ -921,7 +922,7 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                 outs.append(y.view(*x.shape[:-1], y.shape[1]))
                 N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
                 _log("fwd", "merged_group" + ("_cat" if cat is not None else "") + ("_heads" if out_heads else ""),
-                     x2.shape[0], K, N, down.shape[0])
+                     x2.shape[0], K, N, down.shape[0] if down is not None else 0)
         ctx.save_for_backward(x2, *[t for st in sites for t in (st[0], st[2], st[3])])
         ctx.meta = [(float(st[4]), st[5], st[6], st[7]) for st in sites]
         ctx.n, ctx.x_shape = n, x.shape
@@ -940,7 +941,6 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
             w_eff, down, up = saved[1 + 3 * i:4 + 3 * i]
             scale, sink, out_heads, w_eff_t = ctx.meta[i]
             g = gs[i]
-            r = down.shape[0]
             N = out_heads[0] * out_heads[1] if out_heads else w_eff.shape[0]
             d_down = d_up = None
             if g is not None:
@@ -949,7 +949,8 @@ class LoraLinearMergedGroupFunction(torch.autograd.Function):
                     with _gemm_range():
                         wb = w_eff_t.t() if w_eff_t is not None else w_eff  # [N', K] operand; transposed storage: TN GEMM
                         dx = (g2 @ wb) if dx is None else dx.addmm_(g2, wb)
-                d_down, d_up = _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, None, K, N, "merged_group")
+                if down is not None:   # None: a frozen site (standin/frozen.py)
+                    d_down, d_up = _merged_factor_grads(g2, x2, down, up, scale, sink, out_heads, None, K, N, "merged_group")
             grads += [None, None, d_down, d_up, None, None, None, None]
         grads[0] = dx.view(ctx.x_shape) if dx is not None else None
         return tuple(grads)

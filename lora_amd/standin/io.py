@@ -164,9 +164,13 @@ class DreamBoothDataset(torch.utils.data.Dataset):
 
     def __init__(self, instance_data_root: str, instance_prompt: str, tokenizer, class_data_root: Optional[str] = None,
                  class_prompt: Optional[str] = None, size: int = 512, center_crop: bool = False, resize: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, content_seed: Optional[int] = None):
+        """``seed``: this process's augmentation stream (random crops; per rank).  ``content_seed``: what ``synthetic:N``
+        images are generated from — the SAME on every rank of a data-parallel run, so that a DistributedSampler partitions
+        one dataset (default: ``seed``)."""
         self.size, self.center_crop, self.resize, self.tokenizer = size, center_crop, resize, tokenizer
         self.rng = np.random.default_rng(seed)
+        seed = seed if content_seed is None else content_seed
         self.instance = self._source(instance_data_root, seed)
         if len(self.instance) == 0:
             raise ValueError("Instance images root doesn't exists.")
@@ -292,7 +296,8 @@ class PivotalTuningDataset(torch.utils.data.Dataset):
 
     def __init__(self, instance_data_root: str, tokenizer, token_map: Optional[dict] = None,
                  use_template: Optional[str] = None, size: int = 512, h_flip: bool = True, resize: bool = True,
-                 use_mask_captioned_data: bool = False, seed: int = 0):
+                 use_mask_captioned_data: bool = False, seed: int = 0, content_seed: Optional[int] = None):
+        # seed: this process's augmentation stream (flips; per rank); content_seed: the synthetic images (same on every rank)
         assert not (use_mask_captioned_data and use_template), "Can't use both mask caption data and template."
         self.size, self.tokenizer, self.resize, self.h_flip = size, tokenizer, resize, h_flip
         self.token_map, self.use_template = token_map or {}, use_template
@@ -300,7 +305,7 @@ class PivotalTuningDataset(torch.utils.data.Dataset):
         self.masks: List[Optional[str]] = []
         if instance_data_root.startswith("synthetic:"):
             n = int(instance_data_root.split(":", 1)[1])
-            self.items = synthetic_images(n, size, seed)
+            self.items = synthetic_images(n, size, seed if content_seed is None else content_seed)
             self.captions = [f"synthetic image {i} of DUMMY" for i in range(n)]
             self.masks = [None] * n
         else:

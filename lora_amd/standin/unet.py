@@ -59,13 +59,24 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(self.act(self.linear_1(x)))
 
 
+def _linear_group(mods, x, out_heads=None):
+    """Several projections on one tensor in one launch: LoRA adapters (``lora.lora_linear_group``) or their frozen twins
+    (``standin/frozen.py``, the `frozen_only` measurement leg); None: call the modules one by one."""
+    from ..lora import lora_linear_group
+    from .frozen import FrozenSite, frozen_linear_group
+
+    if isinstance(mods[0], FrozenSite):
+        return frozen_linear_group(mods, x, out_heads)
+    return lora_linear_group(mods, x, out_heads) if out_heads is not None else lora_linear_group(mods, x)
+
+
 def project_qkv(attn, x, context=None):
     """to_q / to_k / to_v of an attention block.  When the projections are LoRA adapters that read the same tensor
     (self-attention: all three; cross-attention: to_k and to_v on the text states) they go out as ONE launch of the
     weight-stationary kernel (``lora.lora_linear_group``); otherwise module by module, as diffusers does."""
     ctx = x if context is None else context
     if x.is_cuda and os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0":
-        from ..lora import lora_linear_group
+        lora_linear_group = _linear_group
 
         if context is None:
             out = lora_linear_group([attn.to_q, attn.to_k, attn.to_v], x)
@@ -107,8 +118,7 @@ class CrossAttention(nn.Module):
             lay = (h, d, D)
             q = k = v = None
             if x.is_cuda and os.environ.get("LORA_AMD_GROUP_QKV", "1") != "0":
-                from ..lora import lora_linear_group
-
+                lora_linear_group = _linear_group
                 if context is None:
                     out = lora_linear_group([self.to_q, self.to_k, self.to_v], x, out_heads=lay)
                     if out is not None:

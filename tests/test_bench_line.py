@@ -124,3 +124,50 @@ def test_eight_gloo_ranks_print_one_short_line_with_distinct_noise_streams_and_e
     os.remove(detail)
     assert len(set(rep["noise_stream_fingerprints"])) == 8, rep
     assert len(set(rep["param_checksums"])) == 1, rep
+
+
+def _bench_line(n_ranks: int, tag: str):
+    env = {**os.environ, "OMP_NUM_THREADS": "1", "LORA_AMD_BENCH_DETAIL_TAG": tag}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, "bench.py"), "--gpus", str(n_ranks), "--device", "cpu", "--standin",
+                        "tiny", "--steps", "2", "--warmup", "1", "--res", "64", "--batch", "2", "--no-cpu-baseline",
+                        "--no-secondary"], capture_output=True, text=True, timeout=900, env=env, cwd=H.REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    detail = os.path.join(H.REPO, "gpurun_out", "bench_detail_%s.json" % tag)
+    with open(detail) as f:
+        det = json.load(f)
+    os.remove(detail)
+    return json.loads(lines[0]), det
+
+
+def test_lines_at_one_and_two_ranks_are_the_same_metric_and_scale_weakly():
+    """what the driver's SCALE run compares across N.  The N = 1 and N = 2 lines (gloo on the CPU, tiny
+    stand-in UNet) name the same metric / unit / dtype / workload, differ in n_gpus / parallelism / global batch exactly as
+    weak scaling says (per-rank batch fixed), and report the WHOLE-JOB aggregate the driver divides by N x value(1):
+    value = batch-steps per second summed over the ranks = rank_steps_per_s = n_gpus x global_steps_per_s (optimiser updates
+    per second) = samples_per_s / per-rank batch; the N = 2 line carries the timed all-reduce and its payload (the flat LoRA
+    gradient: 4 bytes x trainable parameters)."""
+    one, det1 = _bench_line(1, "cpuscale1")
+    two, det2 = _bench_line(2, "cpuscale2")
+    for k in ("metric", "unit", "dtype", "higher_is_better", "scaling", "data", "steps", "warmup"):
+        assert one[k] == two[k], k
+    assert one["scaling"] == "weak" and one["vs_baseline"] is None and two["vs_baseline"] is None
+    assert (one["n_gpus"], two["n_gpus"]) == (1, 2)
+    c1, c2 = one["config"], two["config"]
+    assert c1["workload"] == c2["workload"]
+    assert (c1["parallelism"], c2["parallelism"]) == ("dp1", "dp2") and (c1["global_batch"], c2["global_batch"]) == (2, 4)
+    assert c1["allreduce_us"] is None and c2["allreduce_us"] > 0
+    assert c1["allreduce_payload_bytes"] == c2["allreduce_payload_bytes"] == 4 * c1["trainable_params"]
+    for line, det in ((one, det1), (two, det2)):
+        c = line["config"]
+        per_rank_batch = c["global_batch"] // line["n_gpus"]
+        assert per_rank_batch == 2
+        assert abs(c["samples_per_s"] - line["value"] * per_rank_batch) <= 1e-2 * c["samples_per_s"] + 1e-3
+        assert abs(det["config"]["rank_steps_per_s"] - line["value"]) <= 1e-6 + 1e-3 * line["value"]
+        assert abs(c["global_steps_per_s"] * line["n_gpus"] - line["value"]) <= 1e-3 * line["value"] + 1e-3
+        assert abs(line["ms_per_step"] * c["global_steps_per_s"] - 1e3) <= 1.0   # ms_per_step: wall time of one global step
+    rep = det2["config"]["replicas"]
+    assert len(set(rep["noise_stream_fingerprints"])) == 2 and len(set(rep["param_checksums"])) == 1

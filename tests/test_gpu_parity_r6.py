@@ -237,7 +237,46 @@ def test_fp16_loss_scaled_run_from_the_reference_initial_state(monkeypatch):
             worst_down = min(worst_down, c)
     rep.update(worst_cos_d_up=worst_up, worst_cos_d_down=worst_down)
     print("\n[fp16 run from up = 0]", rep)
-    assert np.abs(dev_losses - ref_losses).max() <= 0.01 * np.abs(ref_losses).max(), rep
+    # measured (profiles/r06_fp16_run.log): loss gap 3e-4, ||up|| 0.43368 / 0.43368, cos(up) 0.99989, worst per-tensor gradient
+    # cosine 0.99998 (dUp) / 0.99996 (dDown)
+    assert np.abs(dev_losses - ref_losses).max() <= 0.002 * np.abs(ref_losses).max(), rep
     nr = rep["up_norm"][1]
-    assert abs(rep["up_norm"][0] - nr) <= 0.05 * nr and cos_up >= 0.9, rep
-    assert worst_up >= 0.98 and worst_down >= 0.98, rep
+    assert abs(rep["up_norm"][0] - nr) <= 0.01 * nr and cos_up >= 0.999, rep
+    assert worst_up >= 0.999 and worst_down >= 0.999, rep
+
+
+# ----------------------------------------------------------------------------- the `frozen_only` leg of bench.py
+def test_frozen_twins_compute_the_plain_frozen_model_on_device(monkeypatch):
+    """standin/frozen.py: the frozen twins (merged path's GEMM launches on frozen weights: grouped q / k / v, head-padded
+    rows / columns, transposed copies for the input gradient) compute what the plain ``nn.Linear`` model computes — output
+    and the gradient to the input latents — so ``step - frozen_only`` in the bench line differs by the LoRA launches only."""
+    from lora_amd.standin import attention, tiny_unet
+    from lora_amd.standin.frozen import install_frozen_twins
+
+    torch.manual_seed(0)
+    unet = tiny_unet(cross_attention_dim=64).to(DEV).to(torch.bfloat16)
+    unet.requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16()
+    t = torch.tensor([10, 700], device=DEV)
+    c = torch.randn(2, 77, 64, generator=g).to(DEV).bfloat16()
+    gy = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16()
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        y = unet(xi, t, c).sample
+        (y.float() * gy.float()).sum().backward()
+        return y.float(), xi.grad.float()
+
+    monkeypatch.setenv("LORA_AMD_GROUP_QKV", "0")
+    monkeypatch.setenv("LORA_AMD_HEAD_PAD", "0")
+    y0, dx0 = run()
+    assert install_frozen_twins(unet) > 0
+    for pad in ("0", "1"):
+        monkeypatch.setenv("LORA_AMD_GROUP_QKV", "1")
+        monkeypatch.setenv("LORA_AMD_HEAD_PAD", pad)
+        monkeypatch.setattr(attention, "FORCE_PAD", 64 if pad == "1" else None)
+        y1, dx1 = run()
+        # bf16 GEMMs in a different grouping: a few ulps of the activations
+        assert (y1 - y0).abs().max() <= 0.03 * y0.abs().max(), pad
+        assert float((dx1 * dx0).sum() / (dx1.norm() * dx0.norm())) >= 0.999, pad

@@ -229,3 +229,26 @@ def test_unet_channels_last_equals_nchw():
     torch.testing.assert_close(y1.contiguous(), y0, rtol=1e-4, atol=1e-5)
     for a, b in zip(g1, g0):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-6)
+
+
+def test_frozen_twins_sit_on_the_adapter_sites_and_change_nothing_on_cpu():
+    """standin/frozen.py (bench.py's `frozen_only` leg): a FrozenSite on exactly the modules inject_trainable_lora adapts
+    (144 on the SD1.5 shape, 48 on CLIP), same parameter objects, and on CPU the model computes what it computed before."""
+    from lora_amd.standin.frozen import FrozenSite, install_frozen_twins
+
+    with torch.device("meta"):
+        big = sd15_unet()
+    assert install_frozen_twins(big) == 144
+    assert install_frozen_twins(big) == 0   # idempotent: children of a twin are not sites
+    torch.manual_seed(0)
+    unet = tiny_unet()
+    x, t, c = torch.randn(2, 4, 16, 16), torch.tensor([3, 500]), torch.randn(2, 7, 32)
+    want = unet(x, t, c).sample
+    w0 = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.weight
+    n_sites = install_frozen_twins(unet)
+    twin = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q
+    assert isinstance(twin, FrozenSite) and twin.linear.weight is w0
+    ref = tiny_unet()
+    assert n_sites == len(L.inject_trainable_lora(ref)[1]) // 2 or n_sites == sum(
+        isinstance(m, L.LoraInjectedLinear) for m in ref.modules())
+    torch.testing.assert_close(unet(x, t, c).sample, want)

@@ -202,7 +202,7 @@ def main(args):
     dataset = SIO.DreamBoothDataset(args.instance_data_dir, args.instance_prompt, tokenizer,
                                     args.class_data_dir if args.with_prior_preservation else None, args.class_prompt,
                                     args.resolution, args.center_crop, args.resize,
-                                    seed=(args.seed or 0) * 1000 + rank)
+                                    seed=(args.seed or 0) * 1000 + rank, content_seed=(args.seed or 0) * 1000)
     if args.color_jitter and is_main:
         print("warning: --color_jitter needs torchvision (not installed); ignored")
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True,
