@@ -898,7 +898,8 @@ def main():
                 from lora_amd.standin.frozen import install_frozen_twins
 
                 install_frozen_twins(text_encoder, ["CLIPAttention"])
-            text_encoder.text_model.embeddings.register_forward_hook(lambda m, i, o: o.detach().requires_grad_(True))
+            emb = next(m for n_, m in text_encoder.named_modules() if n_.endswith("embeddings"))  # transformers 4 / 5 paths
+            emb.register_forward_hook(lambda m, i, o: o.detach().requires_grad_(True))
             text_encoder.train()
         else:
             L.inject_trainable_lora(text_encoder, target_replace_module=["CLIPAttention"], r=args.lora_rank)

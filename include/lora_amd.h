@@ -543,8 +543,11 @@ int lora_amd_reduce_batched(const lora_amd_reduce_desc *descs_dev, int32_t n, in
  * The factors arrive packed in MFMA fragment order (lora_amd_factor_pack, one launch per step for all sites).
  * A workgroup walks blocks_per_wg consecutive row blocks (the next block's loads in flight while the current one is
  * consumed) and leaves ONE partial slab for them.
- * lds_class: 1 = <= 80 KiB per workgroup (two per CU), 2 = <= 160 KiB (one per CU: the 1280-wide sites); one launch per
- * class.  Shapes: N, K multiples of 32, rank <= 16; anything else: supported = 0, use the _self_ragged pass. */
+ * lds_class (a REGISTER class since the register-resident kernel of round 4; the name is the ABI's): 1 = the block's rows of
+ * the narrower operand fit 6 resident (row step, column group) pairs per wave (rows x columns <= 64 x 320 or 32 x 640) — the
+ * kernel that runs three workgroups per CU; 2 = up to 10 pairs (64 x 640, 32 x 1280), two per CU.  One launch per class; a
+ * table planned for class 2 may hold class-1 sites (they then run the two-per-CU kernel).
+ * Shapes: N, K multiples of 32, rank <= 16; anything else: supported = 0, use the _self_ragged pass. */
 typedef struct lora_amd_factors_mfma_plan_t {
   int32_t supported, lds_class, rank_tile, rows_per_block, nparts, lds_bytes;
   int32_t blocks_per_wg, reserved;          /* row blocks one workgroup walks: nparts = ceil(ceil(M / rows) / blocks_per_wg) */
@@ -590,6 +593,10 @@ int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_
  * dropout_p = 0 in such a table run unmasked) */
 int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid, int32_t lds_class,
                                             int32_t act_dtype, int32_t masked, void *stream);
+/* Tuning / test hook: which kernel a table of class 1 runs — 0 = the 10-pair kernel every class can take (two workgroups per
+ * CU), 1 (default) = the 6-pair kernel with a 2-unit ring, 2 = with a 4-unit ring (three workgroups per CU); < 0 only reads.
+ * Returns the previous value. */
+int lora_amd_factors_mfma_set_tuning(int32_t narrow);
 
 
 /* ------------------------------------------------------------------------

@@ -27,7 +27,7 @@ _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 # every symbol include/lora_amd.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "lora_amd_abi_version", "lora_amd_last_error", "lora_amd_target_arch",
-    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma",
+    "lora_amd_merge_plan", "lora_amd_merge_batched", "lora_amd_merge_set_tuning", "lora_amd_merge_step_set_tuning", "lora_amd_rank16_mfma", "lora_amd_factors_mfma_set_tuning",
     "lora_amd_merge_step_plan", "lora_amd_merge_step",
     "lora_amd_rowdot", "lora_amd_rowdot_masked", "lora_amd_rank_update",
     "lora_amd_colreduce_workspace", "lora_amd_colreduce",
@@ -570,6 +570,14 @@ class MergeStepPlan:
 
 def merge_set_tuning(tile_elems: int = 0, blocks_per_cu: int = 0) -> None:
     require().lora_amd_merge_set_tuning(int(tile_elems), int(blocks_per_cu))
+
+
+def factors_mfma_set_tuning(narrow: int = -1) -> int:
+    """Kernel of class-1 tables of the matrix-core factor pass (0 wide, 1 narrow / ring 2, 2 narrow / ring 4); returns the previous."""
+    lib = require()
+    lib.lora_amd_factors_mfma_set_tuning.argtypes = [C.c_int32]
+    lib.lora_amd_factors_mfma_set_tuning.restype = C.c_int
+    return int(lib.lora_amd_factors_mfma_set_tuning(int(narrow)))
 
 
 def rank16_mfma(enable: int = -1) -> int:

@@ -177,12 +177,17 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
 //   5. outA += A^T TB from the resident pieces the same way.
 // No wave waits for another inside a step, the LDS queue of a wave is in order (write -> transpose read needs no wait),
 // and the only loads on the critical path of a block are its first ones.
-constexpr int kFrPairs = 10;   // resident (row step, group) units per wave
+// resident (row step, group) units per wave: PAIRS = 10 serves every supported site (64 rows x 640 columns or 32 x 1280 of the
+// narrower operand: 80 registers of pieces, 244 in all, two workgroups per CU); PAIRS = 6 serves the sites of register class 1
+// (R x Ca <= 64 x 320 or 32 x 640 — every M = 16384 site of SD1.5 and the cross-attention k / v: 56 % of the step's bytes) in
+// <= 168 registers, THREE workgroups per CU: a block's life is load latency + ~1.5 us of dependent MFMA / LDS work with no
+// load in flight, and only other workgroups on the CU fill that gap (round 6)
+constexpr int kFrPairsWide = 10, kFrPairsNarrow = 6;
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
 constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
 
-template <class E, bool DROP>
-__global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+template <class E, bool DROP, int kFrPairs, int MINB, int RING>
+__global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   using S = typename E::storage;
   constexpr bool kScaled = E::kCode == LORA_AMD_F16;   // power-of-two pre-scaling of the split operands (file header)
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
@@ -251,10 +256,17 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   };
   unsigned char *stage = s_stage + wave * 32 * kFrPitch;
   // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
-  auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, mf32x4 (&acc)[2]) {
+  // kTfLds (the three-per-CU kernel): the T fragments of a row step are read from LDS at every use instead of living in 16
+  // registers for the whole stream (two more ds_read_b128 per unit buy the third workgroup)
+  constexpr bool kTfLds = MINB >= 3;
+  auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, int rs, mf32x4 (&acc)[2]) {
     *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
     *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
     asm volatile("" ::: "memory");
+    if constexpr (kTfLds) {
+      th = s_tf[(rs * 2 + 0) * 64 + lane];
+      tl = s_tf[(rs * 2 + 1) * 64 + lane];
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const unsigned char *pp = stage + (4 * q + (jj >> 2)) * kFrPitch + (16 * nt + 4 * (jj & 3)) * 2;
@@ -360,9 +372,9 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   // ---- 3. B: the first ring slots go out before the barrier
   const int ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;
   const int nunits = ngb_w * (rs2 ? 2 : 1);
-  mu32x4 b0[4], b1[4];
+  mu32x4 b0[RING], b1[RING];   // RING units (32 rows x 32 columns = two pieces) of B in flight per wave
 #pragma unroll
-  for (int sl = 0; sl < 4; ++sl) b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
+  for (int sl = 0; sl < RING; ++sl) b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
   auto load_unit = [&](int u, mu32x4 &x0, mu32x4 &x1) {
     const int rs = rs2 ? (u & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
     if (u < nunits) {   // wave-uniform
@@ -371,14 +383,17 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
     }
   };
 #pragma unroll
-  for (int sl = 0; sl < 4; ++sl) load_unit(sl, b0[sl], b1[sl]);
+  for (int sl = 0; sl < RING; ++sl) load_unit(sl, b0[sl], b1[sl]);
   store_parts(d1);
   __syncthreads();
   build_tf(sd.scale * finv_a);
   __syncthreads();
   mu32x4 tfh[2], tfl[2];
-  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
-  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  tfh[0] = tfl[0] = tfh[1] = tfl[1] = mu32x4{0u, 0u, 0u, 0u};
+  if constexpr (!kTfLds) {
+    tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+    tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  }
 #pragma unroll
   for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
   mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
@@ -386,9 +401,9 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
     mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
     if (wave < ngb) { nfh = frag(pkb, splitb, wave, false); nfl = frag(pkb, splitb, wave, true); }
 #pragma unroll 1
-    for (int u0 = 0; u0 < nunits; u0 += 4) {
+    for (int u0 = 0; u0 < nunits; u0 += RING) {
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
+      for (int sl = 0; sl < RING; ++sl) {
         const int u = u0 + sl;
         if (u < nunits) {   // wave-uniform
           const int rs = rs2 ? (sl & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
@@ -397,19 +412,19 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
             if (cg + 4 < ngb) { nfh = frag(pkb, splitb, cg + 4, false); nfl = frag(pkb, splitb, cg + 4, true); }
           }
           const mu32x4 p0 = finish(b0[sl], cg, rs * 32 + jj, mask_b), p1 = finish(b1[sl], cg, rs * 32 + 16 + jj, mask_b);
-          load_unit(u + 4, b0[sl], b1[sl]);
+          load_unit(u + RING, b0[sl], b1[sl]);
           if (rs2 && (sl & 1)) {
             d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[2]);
             d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[2]);
             d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[3]);
             d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[3]);
-            phase2(p0, p1, tfh[1], tfl[1], acc);
+            phase2(p0, p1, tfh[1], tfl[1], 1, acc);
           } else {
             d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[0]);
             d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[0]);
             d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[1]);
             d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[1]);
-            phase2(p0, p1, tfh[0], tfl[0], acc);
+            phase2(p0, p1, tfh[0], tfl[0], 0, acc);
           }
           if (!rs2 || (sl & 1)) store_group(outb, Cb, cg, acc);
         }
@@ -421,15 +436,17 @@ __global__ __launch_bounds__(kFmThreads, 2) void factors_reg_kernel(const lora_a
   __syncthreads();
   build_tf(sd.scale * finv_b);
   __syncthreads();
-  tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
-  tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  if constexpr (!kTfLds) {
+    tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
+    tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+  }
   // ---- 5. outA = A^T TB from the resident pieces
 #pragma unroll
   for (int pp = 0; pp < kFrPairs; ++pp) {
     const int cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
     if (cg < nga) {
-      if (rs2 && (pp & 1)) phase2(pa[2 * pp], pa[2 * pp + 1], tfh[1], tfl[1], acc);
-      else phase2(pa[2 * pp], pa[2 * pp + 1], tfh[0], tfl[0], acc);
+      if (rs2 && (pp & 1)) phase2(pa[2 * pp], pa[2 * pp + 1], tfh[1], tfl[1], 1, acc);
+      else phase2(pa[2 * pp], pa[2 * pp + 1], tfh[0], tfl[0], 0, acc);
       if (!rs2 || (pp & 1)) store_group(outa, Ca, cg, acc);
     }
   }
@@ -482,9 +499,20 @@ static int fm_blocks_per_wg(int64_t nrb) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(v, 1), kFmMaxNB), nrb));
 }
 
+static int g_fm_narrow = 1;   // 0: class-1 tables run the wide kernel too (A/B hook, lora_amd_factors_mfma_set_tuning)
+
 }  // namespace lora_amd
 
 using namespace lora_amd;
+
+// Tuning / test hook: tables of register class 1 run 0 = the 10-pair kernel (two workgroups per CU, rounds 4-5), 1 (default) =
+// the 6-pair kernel with a 2-unit ring, 2 = the 6-pair kernel with a 4-unit ring (three per CU both); < 0 only reads.  Returns
+// the previous value.
+extern "C" int lora_amd_factors_mfma_set_tuning(int32_t narrow) {
+  const int prev = g_fm_narrow;
+  if (narrow >= 0 && narrow <= 2) g_fm_narrow = narrow;
+  return prev;
+}
 
 extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows,
                                           int32_t flags, lora_amd_factors_mfma_plan_t *out) {
@@ -588,12 +616,17 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
-#define FM(E)                                                                                                         \
+  // register class 1 (every site of the table planned with lds_class 1: <= 6 resident pairs per wave): three workgroups per CU
+  const int narrow = lds_class == 1 ? g_fm_narrow : 0;
+#define FM2(E, D)                                                                                                     \
   do {                                                                                                                \
-    if (drop) hipLaunchKernelGGL((factors_reg_kernel<E, true>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    else hipLaunchKernelGGL((factors_reg_kernel<E, false>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n);     \
+    if (narrow == 1) hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsNarrow, 3, 2>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    else if (narrow == 2) hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsNarrow, 3, 4>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+    else hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsWide, 2, 4>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
   } while (0)
+#define FM(E) do { if (drop) FM2(E, true); else FM2(E, false); } while (0)
   if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
+#undef FM2
 #undef FM
   return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
 }

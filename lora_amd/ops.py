@@ -449,12 +449,15 @@ CONCAT_GROUPS = True
 # ranks 9..16 on 16-bit activations: matrix-core forms of rowdot / rank_update / linear_fwd / linear_bwd_g
 # (csrc/rank16_mfma.hip; 0 = the VALU kernels, through the library's lora_amd_rank16_mfma hook)
 RANK16_MFMA = True
+# the one-launch factor pass as one launch per REGISTER class (class 1 = the M = 16384 sites: three workgroups per CU,
+# csrc/factor_mfma.hip) instead of one launch of the two-per-CU kernel over every site (rounds 4-5)
+FM_TWO_CLASSES = True
 
 
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "WS_DROPOUT", "WS_DROPOUT_WIDE",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "WS_DROPOUT", "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
     for item in filter(None, (s.strip() for s in spec.split(","))):
@@ -764,9 +767,9 @@ class MergedWeights:
             return
         owed, self._owed = self._owed, []
         groups = {}
-        # the register-resident kernel needs no LDS class: every site of a (dtype, rank tile, masked) group in ONE launch
-        # (the table is planned against the large class, which every supported site fits)
-        one_class = True
+        # one launch per register class of a (dtype, rank tile, masked) group: class 1 (the narrower operand's block fits 6
+        # resident pairs per wave: every M = 16384 site) runs three workgroups per CU, class 2 two (csrc/factor_mfma.hip)
+        one_class = not FM_TWO_CLASSES
         for st in owed:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16

@@ -367,19 +367,24 @@ def bench_fm(args):
     sites = sd15_site_list()
     byts = sum((M * K + M * N) * 2 for M, K, N in sites)
     gs, xs, downs, ups = {}, {}, [], []
-    for i, (M, K, N) in enumerate(sites):  # activations shared per shape (memory), factors per site
-        if (M, K, N) not in gs:
-            gs[(M, K, N)] = torch.randn(M, N, device=DEV).to(dt)
-            xs[(M, K, N)] = torch.randn(M, K, device=DEV).to(dt)
+    shapes = list(sites)
+    shared = os.environ.get("LORA_AMD_FM_SHARED", "0") == "1"   # rounds 4-5: one (G, X) per SHAPE — L2 / MALL hits flattered the pass
+    sites = [(M, K, N) if shared else (M, K, N, i) for i, (M, K, N) in enumerate(sites)]
+    for i, key in enumerate(sites):  # activations per site (1.97 GB; round 6) or per shape, factors per site
+        M, K, N = key[:3]
+        if key not in gs:
+            gs[key] = torch.randn(M, N, device=DEV).to(dt)
+            xs[key] = torch.randn(M, K, device=DEV).to(dt)
         downs.append(torch.randn(r, K, device=DEV) * 0.25)
         ups.append(torch.randn(N, r, device=DEV) * 0.05)
-    rec = {"sites": len(sites), "GX_GB": round(byts / 1e9, 4), "floor_us_8TBs": round(byts / 8e12 * 1e6, 1)}
+    rec = {"sites": len(sites), "activations": "per shape (shared)" if shared else "per site", "GX_GB": round(byts / 1e9, 4), "floor_us_8TBs": round(byts / 8e12 * 1e6, 1)}
     # ---- VALU pass
     vs, rows_v = [], []
-    for (M, K, N), down, up in zip(sites, downs, ups):
+    for key, down, up in zip(sites, downs, ups):
+        M, K, N = key[:3]
         pl = _C.factors_self_plan(M, K, N, r, _C.SELF_ROWS_DEFERRED)
         up_part, down_part = torch.empty(int(pl.up_part_floats), device=DEV), torch.empty(int(pl.down_part_floats), device=DEV)
-        vs.append((gs[(M, K, N)], xs[(M, K, N)], down, up, up_part, down_part, 1.0, None, None))
+        vs.append((gs[key], xs[key], down, up, up_part, down_part, 1.0, None, None))
         rows_v += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
                    (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
     arr, grid = _C.factors_self_ragged_table(vs, dt)
@@ -391,14 +396,15 @@ def bench_fm(args):
     rec["valu_fold_us"] = round(t * 1e6, 1)
     # ---- matrix-core pass
     by_cls, packs, rows_m, part_bytes = {}, [], [], 0
-    for (M, K, N), down, up in zip(sites, downs, ups):
+    for key, down, up in zip(sites, downs, ups):
+        M, K, N = key[:3]
         pl = _C.factors_mfma_plan(M, K, N, r, dt)
         assert pl.supported, (M, K, N)
         up_part, down_part = torch.empty(int(pl.up_part_floats), device=DEV), torch.empty(int(pl.down_part_floats), device=DEV)
         part_bytes += (int(pl.up_part_floats) + int(pl.down_part_floats)) * 4
         pk_down, pk_up = torch.empty(int(pl.pack_down_elems), dtype=dt, device=DEV), torch.empty(int(pl.pack_up_elems), dtype=dt, device=DEV)
         packs.append((down, up, pk_down, pk_up))
-        by_cls.setdefault(int(pl.lds_class), []).append((gs[(M, K, N)], xs[(M, K, N)], pk_down, pk_up, up_part, down_part, 1.0,
+        by_cls.setdefault(int(pl.lds_class), []).append((gs[key], xs[key], pk_down, pk_up, up_part, down_part, 1.0,
                                                         None, None, r, pl))
         rows_m += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
                    (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
@@ -418,6 +424,17 @@ def bench_fm(args):
                                    "frac8": round(b / 8e12 / t, 3), "rows": sorted({int(s_[10].rows_per_block) for s_ in ss}),
                                    "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
         tot += t
+    # class 1 on each of its kernels (lora_amd_factors_mfma_set_tuning): 0 = 10 pairs, two workgroups per CU (rounds 4-5);
+    # 1 = 6 pairs, 2-unit ring, three per CU; 2 = 6 pairs, 4-unit ring
+    for tab, ns, grid, cls in tabs:
+        if cls != 1:
+            continue
+        prev = _C.factors_mfma_set_tuning(-1)
+        for mode in (0, 1, 2):
+            _C.factors_mfma_set_tuning(mode)
+            t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
+            rec[f"class1_kernel{mode}_us"] = round(t * 1e6, 1)
+        _C.factors_mfma_set_tuning(prev)
     # the register-resident kernel on the same tables
     tot_r = 0.0
     for tab, ns, grid, cls in tabs:
