@@ -34,6 +34,7 @@ extern "C" {
 #define LORA_AMD_ERANK (-2)    /* rank r outside [1, LORA_AMD_MAX_RANK] */
 #define LORA_AMD_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
 #define LORA_AMD_EWORKSPACE (-4) /* workspace too small */
+#define LORA_AMD_EUNSUPPORTED (-5) /* this entry has no kernel for the (dtype, rank, shape): the caller takes the documented other path */
 
 #define LORA_AMD_MAX_RANK 64
 
@@ -388,6 +389,16 @@ int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t, const void
                           int32_t factor_dtype, float scale, float dropout_p, uint64_t seed,
                           uint64_t offset, const uint64_t *offset_dev, void *stream);
 
+/* The same with the fold of the nct_g column-tile partials INSIDE the launch: gt_out [M, r] is complete when the launch ends
+ * (the last-arriving column workgroup of a row block sums the tiles in order and resets the block's counter), no
+ * lora_amd_sum_parts behind it.  counters: lora_amd_linear_bwd_g_blocks(M, N, r) uint32, zeroed ONCE.  Matrix-core form
+ * only: bf16 rows, f32 factors, rank 9..16 — anything else returns LORA_AMD_EUNSUPPORTED. */
+int lora_amd_linear_bwd_g_blocks(int64_t M, int32_t N, int32_t r, int64_t *row_blocks);
+int lora_amd_linear_bwd_g_folded(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part, float *gt_out,
+                                 uint32_t *counters, float *up_part, int64_t M, int32_t N, int32_t r, int32_t act_dtype,
+                                 int32_t factor_dtype, float scale, float dropout_p, uint64_t seed, uint64_t offset,
+                                 const uint64_t *offset_dev, void *stream);
+
 /* One pass over X[M,K] (and dX, in place, holding G @ W; may be NULL): with Gt' = (sum gt_part) @ S,
  * down_part[nparts_down][RT][K] = Gt'^T @ X (per row block) and dX += Gt' @ down. */
 int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, const float *gt_part,
@@ -681,6 +692,8 @@ typedef struct lora_amd_conv3_nhwc_plan_t {
   int32_t pr;       /* factor gradient: image rows per LDS-staged strip */
   int32_t nsplit;   /* factor gradient: workgroups per 64-channel chunk = number of dDown partials */
   int32_t rank_pad; /* rows of one dDown partial (r rounded up to 4 / 8 / 16) */
+  int32_t fwd_tiles; /* forward pixel tiles = arrival counters (uint32, zeroed once) of lora_amd_conv3_nhwc_fwd_fused */
+  int32_t reserved;
   int64_t pf_elems, pd_elems; /* packed factor sizes in activation-dtype elements */
   int64_t t_part_floats;      /* ksplit > 1: ksplit * B*H*W * r, else 0 */
   int64_t down_part_floats;   /* nsplit * rank_pad * C_in * 9 */
@@ -700,6 +713,30 @@ int lora_amd_conv3_nhwc_bwd_dx(void *dx, const float *gt, const void *pd, int32_
 /* down_part [nsplit][rank_pad][C_in * 9] f32: per-workgroup partial sums of dDown (rows >= r are not written). */
 int lora_amd_conv3_nhwc_bwd_down(const void *x, const float *gt, float *down_part, int32_t B, int32_t C_in,
                                  int32_t H, int32_t W, int32_t r, int32_t act_dtype, void *stream);
+/* Round 6 — launch fusion of the 3x3 site.
+ * (1) The fragment packs of EVERY conv site in ONE launch per optimiser step (the factors change once per step, not per
+ *     forward): pf / pd as lora_amd_conv3_nhwc_pack writes them plus pu, `up` [C_out, r] as the matrix-core operand of the
+ *     up-projection (C_out * 32 elements: per 32-column group two interleaved tiles of (hi | lo) fragments).  The caller
+ *     fills the first block of every site, lora_amd_conv3_nhwc_pack_plan (host) KS and `begin`, and returns the piece total. */
+typedef struct lora_amd_conv3_pack_site {
+  const float *down, *up;   /* f32 [r, C_in, 3, 3], [C_out, r] */
+  void *pf, *pd, *pu;       /* plan.pf_elems, plan.pd_elems, C_out * 32 elements of the activation dtype */
+  int32_t r, C_in, C_out, KS;
+  int64_t begin;
+} lora_amd_conv3_pack_site;
+int lora_amd_conv3_nhwc_pack_plan(lora_amd_conv3_pack_site *sites, int32_t n, int64_t *total);
+int lora_amd_conv3_nhwc_pack_batched(const lora_amd_conv3_pack_site *sites_dev, int32_t n, int64_t total, int32_t act_dtype,
+                                     void *stream);
+/* (2) lora.py:130-135's low-rank branch in ONE launch: T = conv3x3(X; down) -> t_out [B*H*W, r] f32 (saved for the backward)
+ *     and Y += scale * mask o (T up^T) in place on the frozen convolution's output Y [B, H, W, C_out]; dropout as
+ *     lora_amd_rank_update draws it (chunk = 8 consecutive columns of a row of [B*H*W, C_out]).  Geometries with
+ *     plan.ksplit > 1 (small maps: the channel loop is split over several workgroups per pixel tile) need t_part
+ *     (plan.t_part_floats) and `counters` (plan.fwd_tiles uint32, zeroed ONCE: the last-arriving workgroup of a tile folds
+ *     the shares, runs the up-projection and resets its counter).  bf16 activations, C_out % 32 == 0. */
+int lora_amd_conv3_nhwc_fwd_fused(const void *x, const void *pf, const void *pu, void *y, float *t_out, float *t_part,
+                                  uint32_t *counters, int32_t B, int32_t C_in, int32_t C_out, int32_t H, int32_t W,
+                                  int32_t r, int32_t act_dtype, float scale, float dropout_p, uint64_t seed, uint64_t offset,
+                                  const uint64_t *offset_dev, void *stream);
 /* out[n] = sum_p part[p * stride + i]: folds the column-tile partials of lora_amd_linear_bwd_g into one Gt. */
 int lora_amd_sum_parts(const float *part, int32_t nparts, int64_t stride, float *out, int64_t n, void *stream);
 

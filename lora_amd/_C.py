@@ -48,6 +48,8 @@ SYMBOLS = (
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd", "lora_amd_conv3_nhwc_bwd_dx",
     "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
+    "lora_amd_conv3_nhwc_pack_plan", "lora_amd_conv3_nhwc_pack_batched", "lora_amd_conv3_nhwc_fwd_fused",
+    "lora_amd_linear_bwd_g_blocks", "lora_amd_linear_bwd_g_folded",
     "lora_amd_sumsq_workspace", "lora_amd_sumsq", "lora_amd_clip_adamw", "lora_amd_clip_adamw_dev",
     "lora_amd_step_advance", "lora_amd_loss_scale_update", "lora_amd_ti_rows_step",
     "lora_amd_groupnorm_workspace", "lora_amd_groupnorm_supported", "lora_amd_groupnorm_fwd", "lora_amd_groupnorm_bwd",
@@ -212,8 +214,14 @@ class ConvPlan(C.Structure):
 class Conv3NhwcPlan(C.Structure):
     _fields_ = [("native", C.c_int32), ("pt", C.c_int32), ("ksplit", C.c_int32), ("csplit", C.c_int32),
                 ("ks", C.c_int32), ("pr", C.c_int32), ("nsplit", C.c_int32), ("rank_pad", C.c_int32),
+                ("fwd_tiles", C.c_int32), ("reserved", C.c_int32),
                 ("pf_elems", C.c_int64), ("pd_elems", C.c_int64), ("t_part_floats", C.c_int64),
                 ("down_part_floats", C.c_int64)]
+
+
+class Conv3PackSite(C.Structure):
+    _fields_ = [("down", C.c_void_p), ("up", C.c_void_p), ("pf", C.c_void_p), ("pd", C.c_void_p), ("pu", C.c_void_p),
+                ("r", C.c_int32), ("C_in", C.c_int32), ("C_out", C.c_int32), ("KS", C.c_int32), ("begin", C.c_int64)]
 
 
 WS_MAX_SITES = 4
@@ -357,8 +365,17 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_conv3_nhwc_bwd_dx.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv3_nhwc_bwd_down.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_sum_parts.argtypes = [vp, i32, i64, vp, i64, vp]
+    lib.lora_amd_conv3_nhwc_pack_plan.argtypes = [C.POINTER(Conv3PackSite), i32, C.POINTER(i64)]
+    lib.lora_amd_conv3_nhwc_pack_batched.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_conv3_nhwc_fwd_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32,
+                                                  u64, u64, vp, vp]
+    lib.lora_amd_linear_bwd_g_blocks.argtypes = [i64, i32, i32, C.POINTER(i64)]
+    lib.lora_amd_linear_bwd_g_folded.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, u64,
+                                                 u64, vp, vp]
     for name in ("lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd",
-                 "lora_amd_conv3_nhwc_bwd_dx", "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts"):
+                 "lora_amd_conv3_nhwc_bwd_dx", "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
+                 "lora_amd_conv3_nhwc_pack_plan", "lora_amd_conv3_nhwc_pack_batched", "lora_amd_conv3_nhwc_fwd_fused",
+                 "lora_amd_linear_bwd_g_blocks", "lora_amd_linear_bwd_g_folded"):
         getattr(lib, name).restype = C.c_int
     lib.lora_amd_groupnorm_workspace.argtypes = [i32, i32, i32, i32]
     lib.lora_amd_groupnorm_workspace.restype = sz
@@ -1435,6 +1452,68 @@ def conv3_nhwc_down_fwd(x: torch.Tensor, pf: torch.Tensor, r: int, t_part: Optio
                                                   t.data_ptr(), B, Ci, H, W, r, dtype_code(x.dtype), _stream()),
            "lora_amd_conv3_nhwc_down_fwd")
     return t
+
+
+def conv3_nhwc_pack_table(sites):
+    """``sites`` = [(down f32 [r, C_in, 3, 3], up f32 [C_out, r], pf, pd, pu)] -> (planned ctypes table, total pieces): the
+    fragment packs of every conv site of a model in ONE launch (round 6; once per optimiser step)."""
+    arr = (Conv3PackSite * len(sites))()
+    for q, (down, up, pf, pd, pu) in zip(arr, sites):
+        if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
+            raise ValueError("conv3_nhwc_pack_table: contiguous f32 factors expected")
+        q.down, q.up, q.pf, q.pd, q.pu = down.data_ptr(), up.data_ptr(), pf.data_ptr(), pd.data_ptr(), pu.data_ptr()
+        q.r, q.C_in, q.C_out = down.shape[0], down.shape[1], up.shape[0]
+    total = C.c_int64(0)
+    _check(require().lora_amd_conv3_nhwc_pack_plan(arr, len(sites), C.byref(total)), "lora_amd_conv3_nhwc_pack_plan")
+    return arr, total.value
+
+
+def conv3_nhwc_pack_batched(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dtype) -> None:
+    _check(require().lora_amd_conv3_nhwc_pack_batched(table_dev.data_ptr(), n, total, dtype_code(act_dtype), _stream()),
+           "lora_amd_conv3_nhwc_pack_batched")
+
+
+def conv3_nhwc_fused_ok(x: torch.Tensor, C_out: int, r: int) -> bool:
+    """Does ``lora_amd_conv3_nhwc_fwd_fused`` take this site?  (bf16 rows, C_out a multiple of 32, a native geometry.)"""
+    B, Ci, H, W = x.shape
+    return x.dtype == torch.bfloat16 and C_out % 32 == 0 and bool(conv3_nhwc_plan(B, Ci, H, W, r).native)
+
+
+def conv3_nhwc_fwd_fused_(x: torch.Tensor, pf: torch.Tensor, pu: torch.Tensor, y: torch.Tensor, r: int, scale: float,
+                          t_part: Optional[torch.Tensor], counters: Optional[torch.Tensor], dropout_p: float = 0.0,
+                          seed: int = 0, offset=0) -> torch.Tensor:
+    """y (channels_last, in place) += scale * mask o (conv3x3(x; down) up^T) in ONE launch; returns T [B*H*W, r] f32."""
+    B, Ci, H, W = _nhwc_dims(x)
+    Co = y.shape[1]
+    _nhwc_dims(y)
+    t = torch.empty((B * H * W, r), dtype=torch.float32, device=x.device)
+    _check(require().lora_amd_conv3_nhwc_fwd_fused(x.data_ptr(), pf.data_ptr(), pu.data_ptr(), y.data_ptr(), t.data_ptr(),
+                                                   _ptr(t_part), _ptr(counters), B, Ci, Co, H, W, r, dtype_code(x.dtype),
+                                                   float(scale), float(dropout_p), int(seed), *_off(offset), _stream()),
+           "lora_amd_conv3_nhwc_fwd_fused")
+    return t
+
+
+def linear_bwd_g_blocks(M: int, N: int, r: int) -> int:
+    nb = C.c_int64(0)
+    _check(require().lora_amd_linear_bwd_g_blocks(int(M), int(N), int(r), C.byref(nb)), "lora_amd_linear_bwd_g_blocks")
+    return int(nb.value)
+
+
+def linear_bwd_g_folded_ok(g: torch.Tensor, up: torch.Tensor, r: int) -> bool:
+    return g.dtype == torch.bfloat16 and up.dtype == torch.float32 and 8 < r <= 16
+
+
+def linear_bwd_g_folded(g: torch.Tensor, t: torch.Tensor, up: torch.Tensor, gt_part: torch.Tensor, gt_out: torch.Tensor,
+                        counters: torch.Tensor, up_part: torch.Tensor, scale: float, dropout_p: float, seed: int,
+                        offset) -> None:
+    """:func:`linear_bwd_g` with the fold of the Gt column-tile partials inside the launch (``gt_out`` [M, r] complete)."""
+    M, N = g.shape
+    _check(require().lora_amd_linear_bwd_g_folded(g.data_ptr(), g.stride(0), t.data_ptr(), up.data_ptr(), gt_part.data_ptr(),
+                                                  gt_out.data_ptr(), counters.data_ptr(), up_part.data_ptr(), M, N,
+                                                  t.shape[1], dtype_code(g.dtype), dtype_code(up.dtype), float(scale),
+                                                  float(dropout_p), int(seed), *_off(offset), _stream()),
+           "lora_amd_linear_bwd_g_folded")
 
 
 def conv3_nhwc_bwd_dx_(dx: torch.Tensor, gt: torch.Tensor, pd: torch.Tensor) -> torch.Tensor:

@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "mfma16.hpp"
 
 namespace lora_amd {
 
@@ -225,6 +226,290 @@ __global__ __launch_bounds__(kNhThreads) void conv3_down_nhwc_kernel(const typen
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (lg * 4 + e < r) dst[e] = v[e];
+      }
+    }
+  }
+}
+
+// ============================================================================ round 6: one launch per forward
+// VERDICT r2..r5 "K4 launch fusion": a 3x3 site's forward was pack + down-conv (+ fold of its channel-share partials on small
+// maps) + up-projection = 3-4 launches of 5-10 us each on maps that hold a few hundred KB — launch-bound, 44 sites a step.
+//   * conv3_site_pack_kernel: the fragment packs of EVERY conv site of a model in one launch, once per optimiser step
+//     (the factors change once per step, not per forward): pf, pd as conv3_pack_kernel writes them, plus pu — `up` [C_out, r]
+//     as the A operand of the up-projection's transposed product (csrc/rank16_mfma.hip's rank_update16 builds the same
+//     fragment from f32 per workgroup): per 32-column group and interleaved tile t, lane (i, kq) holds (kq < 2 ? hi : lo) of
+//     up[n(i, t)][8 (kq & 1) + e], n(i, t) = 32 cg + 8 (i / 4) + 4 t + i % 4.
+//   * conv3_fwd_fused_kernel: T = conv3x3(X; down) for the workgroup's pixel tile exactly as conv3_down_nhwc_kernel, then —
+//     in the SAME launch — Y[tile pixels, :] += scale * mask o (T up^T) on the matrix cores, dropout regenerated from
+//     Philox(seed, offset) with rank_update16's chunk indexing.  Small maps split the channel loop over `ksplit`
+//     workgroups per tile: each writes its partial T write-through and arrives at the tile's counter; the LAST arriver sums
+//     the partials in share order (deterministic), and runs the up-projection for the tile (the hand-off of
+//     csrc/svd_small.hip: sc1 stores + vmcnt(0) + relaxed agent-scope arrival, one acquire fence in the last arriver, the
+//     counter reset by it — nothing to clear between launches, hipGraph-replayable).
+struct NhPackSite {   // mirrors lora_amd_conv3_pack_site
+  const float *down, *up;
+  void *pf, *pd, *pu;
+  int32_t r, C_in, C_out, KS;
+  int64_t begin;
+};
+
+template <class E>
+__global__ __launch_bounds__(256) void conv3_site_pack_kernel(const NhPackSite *__restrict__ sites, int n, int64_t total) {
+  using S = typename E::storage;
+  for (int64_t id0 = (int64_t)blockIdx.x * 256 + threadIdx.x; id0 < total; id0 += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sites[mid].begin <= id0) lo = mid; else hi = mid - 1;
+    }
+    const NhPackSite q = sites[lo];
+    const int r = q.r, C = q.C_in, KS = q.KS, KC = C >> 5;
+    const int64_t npf = (int64_t)9 * KC * 64, npd = (int64_t)(C >> 4) * KS * 64;
+    int64_t id = id0 - q.begin;
+    Chunk8<E> c;
+    S *dst;
+    if (id < npf) {
+      const int lane = (int)(id & 63), f = (int)(id >> 6);
+      const int kc = f % KC, tap = f / KC;
+      const int row = lane & 15, c0 = kc * 32 + (lane >> 4) * 8;
+      const bool lo_rows = r <= 8, lop = lo_rows && row >= 8;
+      const int j = lop ? row - 8 : row;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = j < r ? gl(q.down)[((int64_t)j * C + c0 + e) * 9 + tap] : 0.f;
+        c.v[e] = E::from_f(lop ? v - E::to_f(E::from_f(v)) : v);
+      }
+      dst = reinterpret_cast<S *>(q.pf) + id * 8;
+    } else if (id < npf + npd) {
+      id -= npf;
+      const int lane = (int)(id & 63), f = (int)(id >> 6);
+      const int ks = f % KS, ct = f / KS;
+      const int ch = ct * 16 + (lane & 15), s0 = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int sl = s0 + e;
+        const int tap = sl / r, j = sl - tap * r;
+        c.v[e] = E::from_f(sl < 9 * r ? gl(q.down)[((int64_t)j * C + ch) * 9 + tap] : 0.f);
+      }
+      dst = reinterpret_cast<S *>(q.pd) + id * 8;
+    } else {
+      id -= npf + npd;   // piece = (column group, tile, lane)
+      const int lane = (int)(id & 63), tile = (int)((id >> 6) & 1), cg = (int)(id >> 7);
+      const int i = lane & 15, kq = lane >> 4;
+      const int nn = cg * 32 + 8 * (i >> 2) + 4 * tile + (i & 3), j0 = 8 * (kq & 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (nn < q.C_out && j0 + e < r) ? gl(q.up)[(int64_t)nn * r + j0 + e] : 0.f;
+        const S h = E::from_f(v);
+        c.v[e] = kq < 2 ? h : E::from_f(v - E::to_f(h));
+      }
+      dst = reinterpret_cast<S *>(q.pu) + id * 8;
+    }
+    union { Chunk8<E> c; nu32x4 u; } o;
+    o.c = c;
+    *gl(reinterpret_cast<nu32x4 *>(dst)) = o.u;
+  }
+}
+
+template <class E, int PT, bool DROP>
+__global__ __launch_bounds__(kNhThreads) void conv3_fwd_fused_kernel(
+    const typename E::storage *__restrict__ x, const typename E::storage *__restrict__ pf,
+    const typename E::storage *__restrict__ pu, typename E::storage *__restrict__ y, float *__restrict__ t_out,
+    float *__restrict__ t_part, unsigned *__restrict__ counters, const NhGeom g, int Co, float scale, float p, uint64_t seed,
+    uint64_t offset, const uint64_t *offset_dev) {
+  using S = typename E::storage;
+  using F = typename NhMfma<E>::frag;
+  __shared__ __attribute__((aligned(16))) float red[4 * PT * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float s_T[PT * 16 * 16];       // [tile row][pixel][rank] of the finished tile
+  __shared__ __attribute__((aligned(16))) nu32x4 s_tf[PT * 2 * 64];      // [tile row][hi, lo][lane]: B operands of the update
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int tile_id = (int)xcd_remap(blockIdx.x, gridDim.x);
+  int bid = tile_id;
+  const int tc = bid % g.ntc;
+  bid /= g.ntc;
+  const int rgi = bid % g.nrg, b = bid / g.nrg;
+  const int H = g.H, W = g.W, C = g.C, KC = C >> 5, r = g.r;
+  const int y0 = rgi * PT, xx = tc * 16 + l15;
+
+  int rowoff[PT + 2], coloff[3];
+  unsigned rowmask[PT + 2], colmask[3];
+#pragma unroll
+  for (int q = 0; q < PT + 2; ++q) {
+    const int yy = y0 + q - 1;
+    rowoff[q] = ((b * H + nh_clamp(yy, H - 1)) * W) * C;
+    rowmask[q] = (yy >= 0 && yy < H) ? 0xFFFFFFFFu : 0u;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int xs = xx + d - 1;
+    coloff[d] = nh_clamp(xs, W - 1) * C + lg * 8;
+    colmask[d] = (xs >= 0 && xs < W) ? 0xFFFFFFFFu : 0u;
+  }
+  nf32x4 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[t] = (nf32x4){0.f, 0.f, 0.f, 0.f};
+  const int ksplit = gridDim.y;
+  for (int kc = blockIdx.y * 4 + wave; kc < KC; kc += 4 * ksplit) {   // conv3_down_nhwc_kernel's k loop
+    const S *xk = x + kc * 32;
+    const S *pk = pf + ((int64_t)kc * 64 + lane) * 8;
+    nu32x4 praw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) praw[tap] = *gl(reinterpret_cast<const nu32x4 *>(pk + (int64_t)(tap * KC) * 512));
+    nu32x4 xr[3][PT + 2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < PT + 2; ++q) xr[d][q] = *gl(reinterpret_cast<const nu32x4 *>(xk + rowoff[q] + coloff[d]));
+    F pa[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("" : "+v"(praw[tap]));
+      pa[tap] = nh_frag_bits<E>(praw[tap]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < PT + 2; ++q) asm volatile("" : "+v"(xr[d][q]));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+      for (int q = 0; q < PT + 2; ++q) {
+        const unsigned m = rowmask[q] & colmask[d];
+        xr[d][q] = xr[d][q] & (nu32x4){m, m, m, m};
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) acc[t] = NhMfma<E>::mma(pa[dy * 3 + d], nh_frag_bits<E>(xr[d][t + dy]), acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < PT; ++t) *reinterpret_cast<nf32x4 *>(red + ((wave * PT + t) * 64 + lane) * 4) = acc[t];
+  __syncthreads();
+  // wave w finishes tile rows t = w, w + 4, ...: v[e] = (this workgroup's share of) T[pixel l15 of row t][rank 4 lg + e]
+  const bool rank_live = lg * 4 < r;
+  const int64_t Mr = (int64_t)g.B * H * W * r;
+  for (int t = wave; t < PT; t += 4) {
+    nf32x4 v = (nf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const nf32x4 *>(red + ((w * PT + t) * 64 + lane) * 4);
+    if (r <= 8 && lg < 2) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const nf32x4 *>(red + ((w * PT + t) * 64 + lane + 32) * 4);
+    }
+    const int yy = y0 + t;
+    const bool live = yy < H && xx < W && rank_live;
+    const int64_t pix = ((int64_t)b * H + nh_clamp(yy, H - 1)) * W + nh_clamp(xx, W - 1);
+    if (ksplit > 1) {   // write-through partial of this channel share
+      float *dst = t_part + (int64_t)blockIdx.y * Mr + pix * r + lg * 4;
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_T[(t * 16 + l15) * 16 + lg * 4 + e] = (live && lg * 4 + e < r) ? v[e] : 0.f;
+    }
+  }
+  if (ksplit > 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)(ksplit - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int t = wave; t < PT; t += 4) {   // the shares in order: the same sum whichever workgroup arrives last
+      const int yy = y0 + t;
+      const bool live = yy < H && xx < W && rank_live;
+      const int64_t pix = ((int64_t)b * H + nh_clamp(yy, H - 1)) * W + nh_clamp(xx, W - 1);
+      nf32x4 v = (nf32x4){0.f, 0.f, 0.f, 0.f};
+      if (live)
+        for (int kz = 0; kz < ksplit; ++kz) v += *gl(reinterpret_cast<const nf32x4 *>(t_part + (int64_t)kz * Mr + pix * r + lg * 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_T[(t * 16 + l15) * 16 + lg * 4 + e] = (live && lg * 4 + e < r) ? v[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  // T of the tile: to memory (the backward's dUp = (mask o G)^T T reads it) and into B-operand fragments (hi | hi, lo | lo)
+  for (int i = tid; i < PT * 16 * (r >> 2); i += kNhThreads) {
+    const int q4 = i % (r >> 2), px = (i / (r >> 2)) & 15, t = i / ((r >> 2) * 16);
+    const int yy = y0 + t, xq = tc * 16 + px;
+    if (yy < H && xq < W)
+      *gl(reinterpret_cast<nf32x4 *>(t_out + (((int64_t)b * H + yy) * W + xq) * r + q4 * 4)) =
+          *reinterpret_cast<const nf32x4 *>(s_T + (t * 16 + px) * 16 + q4 * 4);
+  }
+  for (int t = wave; t < PT; t += 4) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = s_T[(t * 16 + l15) * 16 + 8 * (lg & 1) + e];
+    mu32x4 hi, lo;
+    split_hi_lo<E>(v, hi, lo);
+    s_tf[(t * 2 + 0) * 64 + lane] = hi;
+    s_tf[(t * 2 + 1) * 64 + lane] = lo;
+  }
+  __syncthreads();
+  // Y[tile pixels, :] += scale mask o (T up^T): rank_update16's transposed product, a wave = the 32-column groups wave, wave + 4, ..
+  uint64_t off = 0;
+  if constexpr (DROP) off = dropout_offset(offset, offset_dev);
+  const int ncg = Co >> 5;
+  bool pok[PT];
+  int64_t prow[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int yy = y0 + t;
+    pok[t] = yy < H && xx < W;
+    prow[t] = ((int64_t)b * H + nh_clamp(yy, H - 1)) * W + nh_clamp(xx, W - 1);
+  }
+  auto ufrag = [&](int cg, int tile) -> mu32x4 {
+    return *gl(reinterpret_cast<const mu32x4 *>(pu + (((int64_t)(cg < ncg ? cg : 0) * 2 + tile) * 64 + lane) * 8));
+  };
+  auto yload = [&](int cg, int t) -> mu32x4 {
+    return *gl(reinterpret_cast<const mu32x4 *>(y + prow[t] * Co + (cg < ncg ? cg : 0) * 32 + 8 * lg));
+  };
+  mu32x4 ua0 = ufrag(wave, 0), ua1 = ufrag(wave, 1);
+  mu32x4 yv[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) yv[t] = yload(wave, t);
+  for (int cg = wave; cg < ncg; cg += 4) {
+    const mu32x4 c0 = ua0, c1 = ua1;
+    mu32x4 yc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) yc[t] = yv[t];
+    ua0 = ufrag(cg + 4, 0); ua1 = ufrag(cg + 4, 1);   // the next group's operands are in flight while this one is multiplied
+#pragma unroll
+    for (int t = 0; t < PT; ++t) yv[t] = yload(cg + 4, t);
+    const int col = cg * 32 + 8 * lg;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const mu32x4 th = s_tf[(t * 2 + 0) * 64 + lane], tl = s_tf[(t * 2 + 1) * 64 + lane];
+      mf32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      d0 = FmMfma<E>::mma(fm_frag<E>(c0), fm_frag<E>(th), d0);
+      d0 = FmMfma<E>::mma(fm_frag<E>(c0), fm_frag<E>(tl), d0);
+      d1 = FmMfma<E>::mma(fm_frag<E>(c1), fm_frag<E>(th), d1);
+      d1 = FmMfma<E>::mma(fm_frag<E>(c1), fm_frag<E>(tl), d1);
+      float pr[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      if constexpr (DROP) {
+        float mk[8];
+        dropout_mult8(seed, off, (uint64_t)((prow[t] * (int64_t)Co + col) >> 3), p, mk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pr[e] *= mk[e];
+      }
+      if (pok[t]) {
+        union { mu32x4 u; Chunk8<E> c; } in, out;
+        in.u = yc[t];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out.c.v[e] = E::from_f(fmaf(scale, pr[e], E::to_f(in.c.v[e])));
+        *gl(reinterpret_cast<mu32x4 *>(y + prow[t] * Co + col)) = out.u;
       }
     }
   }
@@ -629,6 +914,7 @@ extern "C" int lora_amd_conv3_nhwc_plan(int32_t B, int32_t C_in, int32_t H, int3
   out->pf_elems = (int64_t)9 * C_in * 16;
   out->pd_elems = (int64_t)C_in * out->ks * 32;
   out->t_part_floats = q.ksplit > 1 ? q.ksplit * M * r : 0;
+  out->fwd_tiles = (int32_t)((int64_t)B * nh_cdiv(H, q.pt) * ((W + 15) / 16));
   out->down_part_floats = (int64_t)q.nsplit * out->rank_pad * C_in * 9;
   return LORA_AMD_OK;
 }
@@ -698,6 +984,79 @@ extern "C" int lora_amd_conv3_nhwc_down_fwd(const void *x, const void *pf, float
   const int rc = check_launch("lora_amd_conv3_nhwc_down_fwd");
   if (rc != LORA_AMD_OK || q.ksplit == 1) return rc;
   return nh_launch_sum(t_part, q.ksplit, (int64_t)B * H * W * r, t_out, stream);
+}
+
+// ---------------------------------------------------------------------------- round 6: batched pack, fused forward
+static inline int64_t nh_pack_pieces(int r, int C_in, int C_out) {
+  const int KS = (9 * r + 31) / 32;
+  return (int64_t)9 * (C_in / 32) * 64 + (int64_t)(C_in / 16) * KS * 64 + (int64_t)(C_out / 32) * 2 * 64;
+}
+
+extern "C" int lora_amd_conv3_nhwc_pack_plan(lora_amd_conv3_pack_site *sites, int32_t n, int64_t *total) {
+  LORA_AMD_CHECK(sites && n >= 1 && total, LORA_AMD_EINVAL, "conv3_nhwc_pack_plan: bad argument");
+  static_assert(sizeof(lora_amd_conv3_pack_site) == sizeof(NhPackSite), "site table layout");
+  int64_t begin = 0;
+  for (int i = 0; i < n; ++i) {
+    lora_amd_conv3_pack_site &q = sites[i];
+    LORA_AMD_CHECK(q.down && q.up && q.pf && q.pd && q.pu, LORA_AMD_EINVAL, "conv3_nhwc_pack_plan: site %d: null pointer", i);
+    LORA_AMD_CHECK(q.r >= 4 && q.r <= 16 && q.r % 4 == 0, LORA_AMD_ERANK, "conv3_nhwc_pack_plan: site %d: rank %d not in {4, 8, 12, 16}", i, q.r);
+    LORA_AMD_CHECK(q.C_in >= 64 && q.C_in % 64 == 0 && q.C_out >= 32 && q.C_out % 32 == 0, LORA_AMD_EINVAL,
+                   "conv3_nhwc_pack_plan: site %d: C_in %% 64 == 0 and C_out %% 32 == 0 required", i);
+    LORA_AMD_CHECK((((uintptr_t)q.pf | (uintptr_t)q.pd | (uintptr_t)q.pu) & 15u) == 0, LORA_AMD_EINVAL,
+                   "conv3_nhwc_pack_plan: site %d: packs must be 16-byte aligned", i);
+    q.KS = (9 * q.r + 31) / 32;
+    q.begin = begin;
+    begin += nh_pack_pieces(q.r, q.C_in, q.C_out);
+  }
+  *total = begin;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_conv3_nhwc_pack_batched(const lora_amd_conv3_pack_site *sites_dev, int32_t n, int64_t total,
+                                                int32_t act_dtype, void *stream) {
+  LORA_AMD_CHECK(sites_dev && n >= 1 && total >= 1, LORA_AMD_EINVAL, "conv3_nhwc_pack_batched: bad argument");
+  LORA_AMD_CHECK(act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16, LORA_AMD_EINVAL,
+                 "conv3_nhwc_pack_batched: activations must be bf16 or f16");
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+  const NhPackSite *sd = reinterpret_cast<const NhPackSite *>(sites_dev);
+  if (act_dtype == LORA_AMD_BF16)
+    hipLaunchKernelGGL(conv3_site_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sd, n, total);
+  else
+    hipLaunchKernelGGL(conv3_site_pack_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sd, n, total);
+  return check_launch("lora_amd_conv3_nhwc_pack_batched");
+}
+
+extern "C" int lora_amd_conv3_nhwc_fwd_fused(const void *x, const void *pf, const void *pu, void *y, float *t_out,
+                                             float *t_part, uint32_t *counters, int32_t B, int32_t C_in, int32_t C_out,
+                                             int32_t H, int32_t W, int32_t r, int32_t act_dtype, float scale,
+                                             float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                                             void *stream) {
+  NH_COMMON("conv3_nhwc_fwd_fused");
+  LORA_AMD_CHECK(act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
+                 "conv3_nhwc_fwd_fused: bf16 activations (the (hi, lo) split of `up` ~ 1e-4 needs bf16's exponent range; "
+                 "f16 runs conv3_nhwc_down_fwd + rank_update)");
+  LORA_AMD_CHECK(x && pf && pu && y && t_out, LORA_AMD_EINVAL, "conv3_nhwc_fwd_fused: null pointer");
+  LORA_AMD_CHECK(C_out >= 32 && C_out % 32 == 0, LORA_AMD_EINVAL, "conv3_nhwc_fwd_fused: C_out %% 32 == 0 required");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "conv3_nhwc_fwd_fused: dropout p=%f", dropout_p);
+  LORA_AMD_CHECK((((uintptr_t)x | (uintptr_t)pf | (uintptr_t)pu | (uintptr_t)y | (uintptr_t)t_out | (uintptr_t)t_part) & 15u) == 0,
+                 LORA_AMD_EINVAL, "conv3_nhwc_fwd_fused: 16-byte aligned buffers");
+  const NhCuts q = nh_cuts(B, C_in, H, W, r);
+  LORA_AMD_CHECK(q.ksplit == 1 || (t_part != nullptr && counters != nullptr), LORA_AMD_EWORKSPACE,
+                 "conv3_nhwc_fwd_fused: this geometry splits the channels over %d workgroups per tile and needs t_part "
+                 "(plan.t_part_floats) and one zeroed counter per tile (plan.fwd_tiles)", q.ksplit);
+  const NhGeom g = nh_geom(B, C_in, H, W, r, q.pt);
+  const dim3 grid((unsigned)((int64_t)B * g.nrg * g.ntc), (unsigned)q.ksplit);
+  using S = bf16_t::storage;
+  const bool drop = dropout_p > 0.f;
+#define NH_FUSED(PT_, D_)                                                                                              \
+  hipLaunchKernelGGL((conv3_fwd_fused_kernel<bf16_t, PT_, D_>), grid, dim3(kNhThreads), 0, (hipStream_t)stream,        \
+                     (const S *)x, (const S *)pf, (const S *)pu, (S *)y, t_out, t_part, counters, g, C_out, scale,      \
+                     dropout_p, seed, offset, offset_dev)
+  if (q.pt == 4) { if (drop) NH_FUSED(4, true); else NH_FUSED(4, false); }
+  else if (q.pt == 2) { if (drop) NH_FUSED(2, true); else NH_FUSED(2, false); }
+  else { if (drop) NH_FUSED(1, true); else NH_FUSED(1, false); }
+#undef NH_FUSED
+  return check_launch("lora_amd_conv3_nhwc_fwd_fused");
 }
 
 extern "C" int lora_amd_conv3_nhwc_bwd_dx(void *dx, const float *gt, const void *pd, int32_t B, int32_t C_in,

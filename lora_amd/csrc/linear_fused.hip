@@ -1255,6 +1255,34 @@ extern "C" int lora_amd_linear_bwd_g(const void *g, int64_t ldg, const float *t,
   return check_launch("lora_amd_linear_bwd_g");
 }
 
+// lora_amd_linear_bwd_g with the fold of its Gt column-tile partials inside the launch (round 6): gt_out [M, r] complete when
+// the launch ends, no lora_amd_sum_parts behind it.  Only the matrix-core form has the in-launch hand-off: bf16 rows, f32
+// factors, ranks 9..16; anything else returns LORA_AMD_EUNSUPPORTED and the caller runs lora_amd_linear_bwd_g +
+// lora_amd_sum_parts.  `counters`: one uint32 per row block (lora_amd_linear_bwd_g_blocks), zeroed ONCE.
+extern "C" int lora_amd_linear_bwd_g_blocks(int64_t M, int32_t N, int32_t r, int64_t *row_blocks) {
+  LORA_AMD_CHECK(row_blocks && M >= 0 && N > 0 && r >= 1 && r <= 16, LORA_AMD_EINVAL, "linear_bwd_g_blocks: bad argument");
+  *row_blocks = bwd_geom(M, N, frank_tile(r), 64).nrb;
+  return LORA_AMD_OK;
+}
+
+extern "C" int lora_amd_linear_bwd_g_folded(const void *g, int64_t ldg, const float *t, const void *up, float *gt_part,
+                                            float *gt_out, uint32_t *counters, float *up_part, int64_t M, int32_t N,
+                                            int32_t r, int32_t act_dtype, int32_t factor_dtype, float scale,
+                                            float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                                            void *stream) {
+  FUSED_COMMON("linear_bwd_g_folded", act_dtype, factor_dtype);
+  LORA_AMD_CHECK(g && t && up && up_part && gt_part && gt_out && counters, LORA_AMD_EINVAL, "linear_bwd_g_folded: null pointer");
+  LORA_AMD_CHECK(aligned_ok(g, ldg, N, act_dtype) && pow2_divisor(N / 8, 64) >= 4, LORA_AMD_EINVAL,
+                 "linear_bwd_g_folded: shape/alignment not supported by the fused path (see lora_amd_linear_plan)");
+  LORA_AMD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, LORA_AMD_EINVAL, "linear_bwd_g_folded: dropout p=%f", dropout_p);
+  const int RT = frank_tile(r);
+  const BwdGeom q = bwd_geom(M, N, RT, 64);
+  if (RT == 16 && r16_bwd_g(g, ldg, t, up, factor_dtype, gt_part, up_part, M, N, r, q.log_ct8, q.nct, q.rows_per_block, q.nrb,
+                            act_dtype, scale, dropout_p, seed, offset, offset_dev, (hipStream_t)stream, gt_out, counters))
+    return check_launch("lora_amd_linear_bwd_g_folded");
+  LORA_AMD_CHECK(false, LORA_AMD_EUNSUPPORTED, "linear_bwd_g_folded: the in-launch fold needs bf16 rows, f32 factors and a rank in 9..16");
+}
+
 extern "C" int lora_amd_linear_bwd_x(const void *x, int64_t ldx, void *dx, int64_t lddx, const float *gt_part,
                                      int32_t nct_g, const void *down, const float *sel, float *down_part,
                                      int64_t M, int32_t K, int32_t r, int32_t act_dtype, int32_t factor_dtype,

@@ -248,8 +248,10 @@ template <class E, bool DROP>
 __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
     const typename E::storage *__restrict__ g, int64_t ldg, const float *__restrict__ t, const float *__restrict__ up,
     float *__restrict__ gt_part, float *__restrict__ up_part, int64_t M, int N, int r, int log_ct8, int nct,
-    int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev) {
+    int rows_per_block, float scale, float p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+    float *__restrict__ gt_out, unsigned *__restrict__ counters) {
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kR16Pitch];  // a 32 x 32 tile per wave (12 KB)
+  __shared__ int s_last;
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[4 * 2 * 64];                     // T fragments [row step][hi, lo][lane]
   __shared__ __attribute__((aligned(16))) float s_gtw[4 * 128 * 16];                   // Gt partial of each column wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
@@ -356,12 +358,41 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
   }
   __syncthreads();
   if (gt_part != nullptr) {
-    float *gtp = gt_part + (int64_t)ct * M * r + m0 * r;
+    // gt_out (round 6): the column-tile partials of a row block are folded INSIDE the launch by the block's last-arriving
+    // column workgroup (csrc/svd_small.hip's hand-off: write-through partials, vmcnt(0), relaxed agent-scope arrival, one
+    // acquire fence in the last arriver, which also resets the counter) — the separate lora_amd_sum_parts launch of every
+    // conv / Linear dropout site's backward is gone
+    const bool fold = gt_out != nullptr;
+    float *gtp = (fold && nct == 1 ? gt_out : gt_part + (int64_t)ct * M * r) + m0 * r;
     for (int i = tid; i < nrows * r; i += kR16Threads) {
       const int row = i / r, j = i - row * r;
       float sum = 0.f;
       for (int w = 0; w < GW; ++w) sum += s_gtw[(w * 128 + row) * 16 + j];
-      gtp[i] = sum;
+      if (fold && nct > 1) __hip_atomic_store(gtp + i, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else gtp[i] = sum;
+    }
+    if (fold && nct > 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(counters + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)(nct - 1);
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(counters + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {   // the tiles in order: the same sum whichever workgroup arrives last
+        const float *src = gt_part + m0 * r;
+        float *dst = gt_out + m0 * r;
+        for (int i = tid; i < nrows * r; i += kR16Threads) {
+          float sum = 0.f;
+          for (int c = 0; c < nct; ++c) sum += gl(src)[(int64_t)c * M * r + i];
+          dst[i] = sum;
+        }
+      }
     }
   }
   if (RW > 1) {  // ncg == 1: the row waves of a column group meet in LDS (the staging tiles are free now)
@@ -638,7 +669,7 @@ bool r16_rank_update(void *y, int64_t ldy, const float *t, int nparts, int64_t p
 
 bool r16_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, int fdt, float *gt_part, float *up_part, int64_t M,
                int N, int r, int log_ct8, int nct, int rows_per_block, int64_t nrb, int act_dtype, float scale, float p,
-               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st, float *gt_out, unsigned *counters) {
   const int cw = 8 << log_ct8;
   if (!r16_common_ok(act_dtype, fdt, r) || cw < 32 || cw > 512 || rows_per_block > 128 || N % 8 || ldg % 8 ||
       ((uintptr_t)g & 15u) || M <= 0 || !up_part || ((uintptr_t)up_part & 15u) || nrb * nct > 0x7fffffff)
@@ -648,7 +679,7 @@ bool r16_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, int f
 #define BG(E, D)                                                                                                      \
   hipLaunchKernelGGL((bwd_g16_mfma_kernel<E, D>), dim3(grid), dim3(kR16Threads), 0, st,                               \
                      reinterpret_cast<const typename E::storage *>(g), ldg, t, uf, gt_part, up_part, M, N, r, log_ct8, nct, \
-                     rows_per_block, scale, p, seed, offset, offset_dev)
+                     rows_per_block, scale, p, seed, offset, offset_dev, gt_out, counters)
   if (p > 0.f) BG(bf16_t, true); else BG(bf16_t, false);
 #undef BG
   return true;

@@ -17,6 +17,7 @@ bool r16_rank_update(void *y, int64_t ldy, const float *t, int nparts, int64_t p
                      const uint64_t *offset_dev, hipStream_t st);
 bool r16_bwd_g(const void *g, int64_t ldg, const float *t, const void *up, int fdt, float *gt_part, float *up_part, int64_t M,
                int N, int r, int log_ct8, int nct, int rows_per_block, int64_t nrb, int act_dtype, float scale, float p,
-               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st);
+               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st, float *gt_out = nullptr,
+               unsigned *counters = nullptr);
 
 }  // namespace lora_amd

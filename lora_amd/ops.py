@@ -452,12 +452,17 @@ RANK16_MFMA = True
 # the one-launch factor pass as one launch per REGISTER class (class 1 = the M = 16384 sites: three workgroups per CU,
 # csrc/factor_mfma.hip) instead of one launch of the two-per-CU kernel over every site (rounds 4-5)
 FM_TWO_CLASSES = True
+# the channels-last 3x3 site as ONE forward launch (csrc/conv_nhwc.hip, round 6: batched pack once per optimiser step + the
+# fused down-conv / fold / up-projection / dropout / add kernel) and its G pass with the Gt fold inside the launch; False =
+# the launch sequence of rounds 3-5 (pack + down [+ sum_parts] + rank_update; bwd_g + sum_parts): the A/B and the parity twin
+CONV3_FUSED = True
 
 
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "WS_DROPOUT", "WS_DROPOUT_WIDE",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONV3_FUSED", "WS_DROPOUT",
+               "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
     for item in filter(None, (s.strip() for s in spec.split(","))):
@@ -1345,6 +1350,111 @@ class LoraConvFunction(torch.autograd.Function):
         return dx, dw, db, d_down, d_up, None, None, None, None, None
 
 
+class ConvSitePacks:
+    """Fragment packs (pf, pd, pu) and arrival counters of every channels-last 3x3 adapter site, refreshed by ONE
+    ``lora_amd_conv3_nhwc_pack_batched`` launch per optimiser step — the factors change once per step, not per forward
+    (rounds 3-5 re-packed ``down`` in every forward of every site: 44 launches a step at configs[3]).
+
+    A site registers on its first forward (packed alone, on the spot).  From then on the first conv forward after an
+    optimiser step (``owner.step_count`` moved: ``FlatLoraState``'s kernels write the factors through raw pointers, so
+    tensor versions do not see them) launches the table of ALL registered sites; without an owner a site is re-packed
+    alone when one of its factors' ``_version`` changed.  Tables and packs are persistent: hipGraph-replayable."""
+
+    def __init__(self, owner=None):
+        self.owner = owner
+        self.sites = {}      # (down ptr, up ptr, dtype) -> record
+        self._table = None   # (device table, n, total) per activation dtype
+        self._fresh_at = None
+
+    def _pack(self, recs, dt):
+        arr, total = _C.conv3_nhwc_pack_table([(q["down"], q["up"], q["pf"], q["pd"], q["pu"]) for q in recs])
+        return _C.table_to_device(arr, recs[0]["pf"].device), len(recs), total
+
+    def refresh(self) -> None:
+        if not self.sites:
+            return
+        if self._table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ConvSitePacks: the site table must exist before hipGraph capture (run the step eagerly first)")
+            by_dt = {}
+            for q in self.sites.values():
+                by_dt.setdefault(q["dt"], []).append(q)
+            self._table = {dt: self._pack(recs, dt) for dt, recs in by_dt.items()}
+        for dt, (tab, n, total) in self._table.items():
+            _C.conv3_nhwc_pack_batched(tab, n, total, dt)
+        self._fresh_at = self._stamp()
+
+    def _stamp(self):
+        return getattr(self.owner, "step_count", None)
+
+    def get(self, down: torch.Tensor, up2: torch.Tensor, dt, plan, lplan_blocks: int):
+        """(pf, pd, pu, fwd counters, bwd counters) of the site whose f32 factors are ``down`` [r, C_in, 3, 3], ``up2`` [C_out, r]."""
+        key = (down.data_ptr(), up2.data_ptr(), dt)
+        q = self.sites.get(key)
+        if q is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ConvSitePacks: a new conv site appeared during hipGraph capture (run the step eagerly first)")
+            dev = down.device
+            q = self.sites[key] = dict(down=down, up=up2, dt=dt, ver=(down._version, up2._version),
+                                       pf=torch.empty(int(plan.pf_elems), dtype=dt, device=dev),
+                                       pd=torch.empty(int(plan.pd_elems), dtype=dt, device=dev),
+                                       pu=torch.empty(up2.shape[0] * 32, dtype=dt, device=dev), cnt={})
+            self._table = None
+            tab, n, total = self._pack([q], dt)
+            _C.conv3_nhwc_pack_batched(tab, n, total, dt)
+        elif self.owner is not None:
+            if self._fresh_at != self._stamp():
+                self.refresh()
+        elif q["ver"] != (down._version, up2._version):   # no trainer state: torch's own optimisers bump the version
+            tab, n, total = self._pack([q], dt)
+            _C.conv3_nhwc_pack_batched(tab, n, total, dt)
+            q["ver"] = (down._version, up2._version)
+        ck = (int(plan.fwd_tiles), int(lplan_blocks))
+        cnt = q["cnt"].get(ck)
+        if cnt is None:   # zeroed once: the last arriver of a tile / row block resets its counter
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ConvSitePacks: a site's counters must exist before hipGraph capture")
+            cnt = q["cnt"][ck] = (torch.zeros(max(ck[0], 1), dtype=torch.int32, device=down.device),
+                                  torch.zeros(max(ck[1], 1), dtype=torch.int32, device=down.device))
+        return q["pf"], q["pd"], q["pu"], cnt[0], cnt[1]
+
+
+def conv_pack_registries(*models):
+    """The ConvSitePacks of the trainer states that own ``models``' conv adapters (found through the adapters' gradient
+    sinks; cached on the first model once non-empty): ``trainer.forward_backward`` refreshes them at the top of a step, so
+    that the ONE pack launch is the step's (and a captured graph's) first conv-adapter node."""
+    if not models or models[0] is None:
+        return ()
+    cached = models[0].__dict__.get("_conv_pack_regs")
+    if cached:
+        return cached
+    regs = []
+    for m in models:
+        if m is None:
+            continue
+        for mod in m.modules():
+            sink = mod.__dict__.get("_grad_sink")
+            reg = getattr(getattr(sink, "owner", None), "__dict__", {}).get("_conv_packs") if sink is not None else None
+            if reg is not None and reg not in regs:
+                regs.append(reg)
+    if regs:
+        models[0].__dict__["_conv_pack_regs"] = tuple(regs)
+    return tuple(regs)
+
+
+_CONV_PACKS_DEFAULT = ConvSitePacks()   # sites without a trainer state (inference through monkeypatch_*, plain torch optimisers)
+
+
+def conv_site_packs(sink) -> ConvSitePacks:
+    owner = getattr(sink, "owner", None)
+    if owner is None:
+        return _CONV_PACKS_DEFAULT
+    reg = owner.__dict__.get("_conv_packs")
+    if reg is None:
+        reg = owner.__dict__["_conv_packs"] = ConvSitePacks(owner)
+    return reg
+
+
 class LoraConv3NhwcFunction(torch.autograd.Function):
     """The same site (lora.py:130-135, 3x3 / padding 1 / stride 1) for channels_last activations: csrc/conv_nhwc.hip.
 
@@ -1365,16 +1475,37 @@ class LoraConv3NhwcFunction(torch.autograd.Function):
         plan = _C.conv3_nhwc_plan(B, Ci, H, W, r)
         down_c = down.float().contiguous()  # f32 masters: no-ops in training
         up2 = up.reshape(Co, r).float().contiguous()
-        pf, pd = _C.conv3_nhwc_pack(down_c, x.dtype, plan)
-        t = _C.conv3_nhwc_down_fwd(x, pf, r)
         sel_c = sel.to(torch.float32).contiguous() if sel is not None else None
-        if sel_c is not None:  # rare (set_lora_diag): T' = T S^T on the [M, r] rows
-            t = (t @ sel_c.t()).contiguous()
         seed = off = 0
         if dropout_p > 0.0:
             seed, off = next_dropout_stream(x.device)
-        _C.rank_update_(y.permute(0, 2, 3, 1).view(M, Co), t, up2, _C.FACTOR_KR, scale, dropout_p, seed, off)
+        # ONE launch (round 6): packs from the per-step table, T, the fold of its channel shares, the up-projection, dropout
+        # and the add; the selector form (set_lora_diag: T' = T S^T between the two products) keeps the launch sequence
+        fused = (CONV3_FUSED and sel_c is None and _C.conv3_nhwc_fused_ok(x, Co, r) and down_c is down
+                 and up2.data_ptr() == up.data_ptr())
+        cnt_bwd = None
+        if fused:
+            packs = conv_site_packs(sink)
+            pf, pd, pu, cnt_fwd, cnt_bwd = packs.get(down_c, up2, x.dtype, plan, _C.linear_bwd_g_blocks(M, Co, r))
+            t_part = None
+            if plan.ksplit > 1:
+                t_part = packs.__dict__.setdefault("_t_part", {}).get((x.device, int(plan.t_part_floats)))
+                if t_part is None:   # scratch of ONE launch (complete before the next conv site's forward starts)
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("ConvSitePacks: the T workspace must exist before hipGraph capture")
+                    t_part = packs._t_part[(x.device, int(plan.t_part_floats))] = torch.empty(
+                        int(plan.t_part_floats), dtype=torch.float32, device=x.device)
+            t = _C.conv3_nhwc_fwd_fused_(x, pf, pu, y, r, scale, t_part, cnt_fwd, dropout_p, seed, off)
+            _log("fwd", "conv3_nhwc_fused", M, Ci * 9, Co, r)
+        else:
+            pf, pd = _C.conv3_nhwc_pack(down_c, x.dtype, plan)
+            t = _C.conv3_nhwc_down_fwd(x, pf, r)
+            if sel_c is not None:  # rare (set_lora_diag): T' = T S^T on the [M, r] rows
+                t = (t @ sel_c.t()).contiguous()
+            _C.rank_update_(y.permute(0, 2, 3, 1).view(M, Co), t, up2, _C.FACTOR_KR, scale, dropout_p, seed, off)
+            _log("fwd", "conv3_nhwc_pack+down+update", M, Ci * 9, Co, r)
         ctx.save_for_backward(x, weight, down, up, t, sel_c, pd)
+        ctx.cnt_bwd = cnt_bwd
         ctx.scale, ctx.p, ctx.seed, ctx.off, ctx.sink = float(scale), float(dropout_p), seed, off, sink
         ctx.has_bias = bias is not None
         return y
@@ -1405,7 +1536,11 @@ class LoraConv3NhwcFunction(torch.autograd.Function):
         s, p, seed, off = ctx.scale, ctx.p, ctx.seed, ctx.off
         fused_g = bool(lplan.fused) and _C._rows_ok(g2)
         d_up_direct = None
-        if fused_g:
+        if fused_g and ctx.cnt_bwd is not None and _C.linear_bwd_g_folded_ok(g2, up2, r):
+            # one pass over G AND the fold of the Gt column-tile partials in the same launch (round 6)
+            gt = gt_buf[:M * r].view(M, r)
+            _C.linear_bwd_g_folded(g2, t, up2, gt_part, gt, ctx.cnt_bwd, up_part, s, p, seed, off)
+        elif fused_g:
             # one pass over G: Gt column-tile partials + dUp row-block partials; the partials of Gt are then folded
             _C.linear_bwd_g(g2, t, up2, gt_part, up_part, s, p, seed, off)
             gt = _C.sum_parts(gt_part, lplan.nct_g, M * r, out=gt_buf[:M * r]).view(M, r)

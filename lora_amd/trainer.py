@@ -312,6 +312,8 @@ def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConf
     the returned loss is the un-scaled one."""
     if merged is not None:
         merged.refresh()
+    for reg in ops.conv_pack_registries(unet, text_encoder):   # conv adapters: ONE fragment-pack launch per step
+        reg.refresh()
     if noise is None:
         noise = torch.randn_like(latents)
     if timesteps is None:

@@ -112,9 +112,10 @@ def test_host_pass_geometry_is_pure_host_arithmetic():
 
 def test_conv3_nhwc_plan_is_pure_host_arithmetic():
     """Geometry of the channels-last 3x3 kernels (csrc/conv_nhwc.hip): which sites qualify and how they are cut."""
-    assert C.sizeof(_C.Conv3NhwcPlan) == 64 and _C.Conv3NhwcPlan.pf_elems.offset == 32
+    assert C.sizeof(_C.Conv3NhwcPlan) == 72 and _C.Conv3NhwcPlan.pf_elems.offset == 40   # ABI 6: + fwd_tiles
     pl = _C.conv3_nhwc_plan(4, 320, 64, 64, 16)  # SD1.5 ResnetBlock2D conv at 512^2, batch 4, extended LoRA rank 16
     assert pl.native == 1 and pl.pt == 4 and pl.ks == 5 and pl.rank_pad == 16
+    assert pl.fwd_tiles == 4 * (64 // 4) * (64 // 16)   # 16-column x pt-row pixel tiles: the fused forward's counters
     assert pl.ksplit == 1 and pl.csplit == 1 and pl.t_part_floats == 0  # 256 / 512 pixel tiles fill the chip
     assert pl.pf_elems == 9 * 320 * 16 and pl.pd_elems == 320 * 5 * 32
     assert pl.pr == 4 and (pl.pr + 2) * 64 * 8 <= 12 * 256  # strip of 4 rows (+2 halo rows) = 12 chunks per thread
@@ -124,12 +125,27 @@ def test_conv3_nhwc_plan_is_pure_host_arithmetic():
     pl = _C.conv3_nhwc_plan(1, 1280, 12, 12, 4)  # the 12x12 maps of 768^2 images: native here (masked tile edges)
     assert pl.native == 1 and pl.pt == 1 and pl.ks == 2 and pl.rank_pad == 4 and pl.pr == 12 and pl.nsplit == 1
     assert pl.ksplit == 10 and pl.t_part_floats == 10 * 144 * 4  # 12 pixel tiles: the channels are split as well
+    assert pl.fwd_tiles == 12
     assert 1 < pl.csplit <= 1280 // 64
     for bad in [(4, 320, 64, 64, 3), (4, 320, 64, 64, 20), (4, 100, 64, 64, 4), (64, 2560, 256, 256, 4),
                 (1, 64, 8, 200, 4)]:
         assert _C.conv3_nhwc_plan(*bad).native == 0
     lib = _C.require()
     assert lib.lora_amd_conv3_nhwc_plan(1, 64, 8, 8, 65, C.byref(_C.Conv3NhwcPlan())) == -2
+    # round 6: the batched pack's table is planned on the host (piece counts per site: pf + pd + pu), bad sites refused
+    sites = (_C.Conv3PackSite * 2)()
+    for q, (r, ci, co) in zip(sites, [(16, 320, 640), (4, 1280, 1280)]):
+        q.down = q.up = q.pf = q.pd = q.pu = 4096
+        q.r, q.C_in, q.C_out = r, ci, co
+    total = C.c_int64(0)
+    assert lib.lora_amd_conv3_nhwc_pack_plan(sites, 2, C.byref(total)) == 0
+    n0 = 9 * (320 // 32) * 64 + (320 // 16) * 5 * 64 + (640 // 32) * 128
+    assert (sites[0].KS, sites[1].KS, sites[0].begin, sites[1].begin) == (5, 2, 0, n0)
+    assert total.value == n0 + 9 * (1280 // 32) * 64 + (1280 // 16) * 2 * 64 + (1280 // 32) * 128
+    sites[1].C_out = 1290
+    assert lib.lora_amd_conv3_nhwc_pack_plan(sites, 2, C.byref(total)) == -1 and b"C_out" in lib.lora_amd_last_error()
+    nb = C.c_int64(0)
+    assert lib.lora_amd_linear_bwd_g_blocks(9216, 320, 16, C.byref(nb)) == 0 and nb.value >= 9216 // 128
 
 
 def test_round3_planners_are_pure_host_arithmetic():
