@@ -260,9 +260,11 @@ int lora_amd_rowdot16_planes_plan(lora_amd_planes_desc *descs_host, int32_t n, i
 int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t r, int32_t plane_dtype,
                              void *stream);
 /* The same with the factor given as PACKED fragments (lora_amd_thin_pack): desc.f points at 16-bit elements
- * [batch][C / 32][hi 512 | lo 512] (the bytes of the f32 [C][16] factor), 16 output columns. */
+ * [batch][C / 32][hi 512 | lo 512] (the bytes of the f32 [C][16] factor), 16 output columns.  hi_only != 0 (ABI 6): the hi
+ * plane alone (X to 8 mantissa bits, half the bytes) — the power iterations of cli_svd's subspace iteration, which only steer a
+ * subspace; the pass that forms the returned factors reads both planes. */
 int lora_amd_rowdot16_planes_packed(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid, int32_t plane_dtype,
-                                    void *stream);
+                                    int32_t hi_only, void *stream);
 typedef struct lora_amd_split_desc {
   const float *src;
   void *hi, *lo;

@@ -280,7 +280,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_rowdot16_planes.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_split16_ragged.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_rowdot16_planes_plan.restype = lib.lora_amd_rowdot16_planes.restype = C.c_int
-    lib.lora_amd_rowdot16_planes_packed.argtypes = [vp, i32, i64, i32, vp]
+    lib.lora_amd_rowdot16_planes_packed.argtypes = [vp, i32, i64, i32, i32, vp]
     lib.lora_amd_thin_pack.argtypes = [vp, vp, i64, vp, vp, i32, vp]
     lib.lora_amd_rowdot16_planes_packed.restype = lib.lora_amd_thin_pack.restype = C.c_int
     lib.lora_amd_split16_ragged.restype = C.c_int
@@ -823,10 +823,11 @@ class PlanesProgram:
     def upload(self):
         self._dev = torch.frombuffer(bytearray(b"".join(self._blobs)), dtype=torch.uint8).to(self.device)
 
-    def run(self, handle: int) -> None:
+    def run(self, handle: int, hi_only: bool = False) -> None:
         n, off, grid = self._meta[handle]
         if self.packed:
-            _check(require().lora_amd_rowdot16_planes_packed(self._dev.data_ptr() + off, n, grid, dtype_code(self.dt), _stream()),
+            _check(require().lora_amd_rowdot16_planes_packed(self._dev.data_ptr() + off, n, grid, dtype_code(self.dt),
+                                                             1 if hi_only else 0, _stream()),
                    "lora_amd_rowdot16_planes_packed")
             return
         _check(require().lora_amd_rowdot16_planes(self._dev.data_ptr() + off, n, grid, self.r, dtype_code(self.dt), _stream()),

@@ -60,6 +60,10 @@ THIN = True
 # resolution of the f32 sums; an exactly low-rank residual).  |dW|_F^2 comes out of the launch that forms the residual.  At
 # least 2, at most MAX_ITER iterations.
 RES_TOL, MAX_ITER = 1e-3, 12
+# the passes that only steer the subspace (the sketch and every power iteration) read the hi plane of the residuals alone: half
+# the bytes; an O(2^-9) perturbation of range(Q) costs the rank-r Frobenius error to second order, and the pass that forms the
+# returned factors (b = Q^T dW) reads both planes.  False: every pass on both planes (rounds 4-5).
+HI_ONLY_ITERATIONS = True
 LAST_ITERATIONS = None  # power iterations the last fused distillation ran (evidence for bench.py)
 
 
@@ -281,16 +285,17 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
         _C.thin_apply(tab, a, lin[0], b)
 
     st.zc.normal_(generator=generator)                            # Omega, every site at once
+    hi = HI_ONLY_ITERATIONS
     _C.thin_pack(st.tz, st.zc, st.pkz)
-    pprog.run(p_y)
+    pprog.run(p_y, hi)
     orth(st.ty, st.ya, st.yb)                                     # q in yb
     it, prev = 0, None
     while True:
         _C.thin_pack(st.ty, st.yb, st.pky)
-        pprog.run(p_z)
+        pprog.run(p_z, hi)
         orth(st.tz, st.za, st.zb)                                 # qz in zb
         _C.thin_pack(st.tz, st.zb, st.pkz)
-        pprog.run(p_y)
+        pprog.run(p_y, hi)
         orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
         it += 1
         if n_iter is not None:

@@ -434,7 +434,10 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
 // 16 l) instead of f32 [C][r]: two coalesced 16-byte loads per k-step where the f32 form needs eight strided scalar loads and
 // ~50 VALU instructions of hi / lo splitting — per 16-row slab, i.e. once per three MFMAs (round 5: the pass was issue-bound,
 // not byte-bound, at 3.6 TB/s).
-template <class E, bool PK>
+// LO = false (round 6): the hi plane alone (X ~ hi to 8 mantissa bits) at half the bytes — the power iterations of the
+// subspace iteration only steer a subspace (an O(2^-9) perturbation of it costs the rank-r Frobenius error to second order);
+// the pass that forms the returned factors (b = Q^T dW) reads both planes.
+template <class E, bool PK, bool LO = true>
 __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_planes_desc *__restrict__ descs, int n, int r) {
   using S = typename E::storage;
   __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
@@ -475,7 +478,11 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
     auto piece = [&](const S *p, int ks) -> mu32x4 {
       return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(p + (int64_t)ks * 32)) : r16_zero();
     };
-    mu32x4 h0 = piece(xh, cw), l0 = piece(xl, cw), h1 = piece(xh, cw + wps), l1 = piece(xl, cw + wps);
+    auto piece_lo = [&](int ks) -> mu32x4 {
+      if constexpr (LO) return piece(xl, ks);
+      else return r16_zero();
+    };
+    mu32x4 h0 = piece(xh, cw), l0 = piece_lo(cw), h1 = piece(xh, cw + wps), l1 = piece_lo(cw + wps);
     if constexpr (PK) {
       auto frag = [&](int ks, int part) -> mu32x4 {
         return *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)(ks < nks ? ks : 0) * 1024 + part * 512));
@@ -483,13 +490,13 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
       mu32x4 fh = frag(cw, 0), fl = frag(cw, 1);
 #pragma unroll 1
       for (int ks = cw; ks < nks; ks += wps) {
-        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
+        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece_lo(ks + 2 * wps);
         const mu32x4 nfh = frag(ks + wps, 0), nfl = frag(ks + wps, 1);
         mu32x4 ch = h0, cl = l0;
         if (!rok) { ch = r16_zero(); cl = r16_zero(); }
         acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
         acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
-        acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+        if constexpr (LO) acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
         h0 = h1; l0 = l1; h1 = h2; l1 = l2;
         fh = nfh; fl = nfl;
       }
@@ -732,12 +739,17 @@ extern "C" int lora_amd_rowdot16_planes(const lora_amd_planes_desc *descs_dev, i
 }
 
 extern "C" int lora_amd_rowdot16_planes_packed(const lora_amd_planes_desc *descs_dev, int32_t n, int64_t grid,
-                                               int32_t plane_dtype, void *stream) {
+                                               int32_t plane_dtype, int32_t hi_only, void *stream) {
   LORA_AMD_CHECK(descs_dev && n >= 1 && grid >= 1 && grid < (1ll << 31), LORA_AMD_EINVAL, "rowdot16_planes_packed: bad argument");
   LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "rowdot16_planes_packed: 16-bit planes only");
   hipStream_t st = (hipStream_t)stream;
-  if (plane_dtype == LORA_AMD_F16) hipLaunchKernelGGL((rowdot16_planes_kernel<f16_t, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);
-  else hipLaunchKernelGGL((rowdot16_planes_kernel<bf16_t, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);
+#define RP(E)                                                                                                          \
+  do {                                                                                                                 \
+    if (hi_only) hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, false>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16); \
+    else hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);          \
+  } while (0)
+  if (plane_dtype == LORA_AMD_F16) RP(f16_t); else RP(bf16_t);
+#undef RP
   return check_launch("lora_amd_rowdot16_planes_packed");
 }
 

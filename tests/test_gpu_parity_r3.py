@@ -472,58 +472,42 @@ def _sd15_twins(r=4, ref_device=DEV):
 
 @pytest.fixture(scope="module")
 def sd15_reference_step():
-    """One batch-1 512^2 step of the oracle (f32, its plain torch ops evaluated on the GPU, ``H.oracle_on_device``): loss and
-    every LoRA gradient, computed once per module."""
+    """One BATCH-4 512^2 step (BASELINE configs[1]'s batch) of the oracle's op sequence, twice on the same values: in f32, and
+    under torch.autocast(bf16) — the reference's own arithmetic (ref train_lora_dreambooth.py:489-494) — both as plain torch ops
+    on the GPU (``H.oracle_on_device``); loss and every LoRA gradient of each, computed once per module.  (Rounds 2-5 held the
+    device step to cosine >= 0.99 against F32 per tensor, which a bf16 step of batch 4 does not meet on every tensor whoever
+    computes it — 0.973-0.976 on one `up` tensor in all three configurations, the ATen-normalised one included — so that
+    fixture had gone back to batch 1; round 6 judges batch 4 by the bracket rule instead, tests/helpers.bracket.)"""
     H.lap("fixture start")
     ref, ref_params, dev_unet = _sd15_twins()
     H.lap("fixture: twins built")
     g = torch.Generator().manual_seed(123)
-    B = 1   # batch 1: the fixed per-tensor bound below (cosine >= 0.99 against F32) does not hold for every tensor at batch 4 —
-    # there a bf16 step and an f32 step differ by more on some tensors (measured, call c10 of round 5: cosine 0.973-0.976 on one
-    # `up` tensor at 1.9 % of the largest norm, 0.984-0.989 on four more, the SAME in all three configurations, the
-    # ATen-normalised "plain" one included: the host model's bf16 arithmetic, not a kernel).  Batch 4 is judged against the reference's own bf16 arithmetic
-    # instead: tests/test_gpu_parity_r5.py::test_batch4_step_error_is_bracketed_by_the_bf16_autocast_reference
+    B = 4
     lat = torch.randn(B, 4, 64, 64, generator=g) * 0.18215
     ehs = torch.randn(B, 77, 768, generator=g)
     noise = torch.randn(B, 4, 64, 64, generator=g)
     ts = torch.randint(0, 1000, (B,), generator=g)
     # the device step sees bf16 inputs: give the oracle the same (bf16-representable) values
     lat, ehs, noise = (v.to(torch.bfloat16).float() for v in (lat, ehs, noise))
-    grads = {}
-    hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.clone())) for i, p in enumerate(ref_params)]
-    opt = torch.optim.SGD(ref_params, lr=0.0)
     with H.oracle_on_device():
-        loss = TR.dreambooth_step(lambda x, tt, c: ref(x, tt, c).sample, ref_params, opt, lat.to(DEV), noise.to(DEV), ts.to(DEV),
-                                  ehs.to(DEV), DDPMScheduler().alphas_cumprod.to(DEV), max_grad_norm=1e30)
-    for h in hooks:
-        h.remove()
-    H.lap("fixture: oracle step")
-    g_ref = [grads[i].reshape(-1).cpu().numpy() for i in range(len(ref_params))]
+        _, l32, g32 = H.oracle_step_on_device(ref, ref_params, lat.to(DEV), noise.to(DEV), ts.to(DEV), ehs.to(DEV), False)
+        _, lbf, gbf = H.oracle_step_on_device(ref, ref_params, lat.to(DEV), noise.to(DEV), ts.to(DEV), ehs.to(DEV), True)
+    H.lap("fixture: oracle steps (f32, bf16 autocast)")
     del ref
     torch.cuda.empty_cache()
-    return dict(loss=float(loss), grads=g_ref, dev_unet=dev_unet, lat=lat, ehs=ehs, noise=noise, ts=ts)
+    return dict(loss=l32, loss_bf=lbf, g32=g32, gbf=gbf, dev_unet=dev_unet, lat=lat, ehs=ehs, noise=noise, ts=ts)
 
 
-def _compare_step(ref, loss_dev, st):
-    assert abs(loss_dev - ref["loss"]) <= 0.01 * abs(ref["loss"]), (loss_dev, ref["loss"])
-    flat = n(st.flat_g)
-    pos, worst, norms = 0, (2.0, -1), []
-    gmax = max(float(np.linalg.norm(g)) for g in ref["grads"])
-    for i, gr in enumerate(ref["grads"]):
-        gd = flat[pos:pos + gr.size]
-        pos += gr.size
-        nr, nd = float(np.linalg.norm(gr)), float(np.linalg.norm(gd))
-        if nr < 1e-4 * gmax:  # a tensor whose gradient is numerically nothing next to the others
-            continue
-        cos = float(gr @ gd) / (nr * nd + 1e-30)
-        norms.append(nd / nr)
-        if cos < worst[0]:
-            worst = (cos, i)
-    assert pos == flat.size
-    assert worst[0] >= 0.99, f"LoRA gradient tensor {worst[1]} (up/down alternate): cosine {worst[0]:.4f}"
-    assert 0.9 <= min(norms) and max(norms) <= 1.1, (min(norms), max(norms))
-    tot_r = float(np.sqrt(sum(float(g @ g) for g in ref["grads"])))
-    assert abs(float(np.linalg.norm(flat)) - tot_r) <= 0.02 * tot_r
+def _compare_step(ref, loss_dev, st, label):
+    """The bracket rule (tests/helpers.bracket / assert_bracket): the device step may be as far from the f32 step as the
+    reference's own bf16 step is — loss within 1.5 x (+ 0.05 % of the loss: the reference's own loss error moves between 2e-5
+    and 2e-4 with the library's attention picks), LoRA gradients in aggregate and for the median tensor within the measured
+    ratio + 10 %, no tensor both 4 x the reference's error and 3 % off, none 5 % off; total gradient norm within 2 %."""
+    l32, lbf = ref["loss"], ref["loss_bf"]
+    assert abs(loss_dev - l32) <= 1.5 * abs(lbf - l32) + 5e-4 * abs(l32), (loss_dev, lbf, l32)
+    H.assert_bracket(H.bracket(ref["g32"], ref["gbf"], st.flat_g, label))
+    tot_r = float(torch.cat(ref["g32"]).norm())
+    assert abs(float(st.flat_g.norm()) - tot_r) <= 0.02 * tot_r
 
 
 @pytest.mark.parametrize("config", ["bench", "bench_fused_sites", "plain"])
@@ -532,9 +516,9 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
     q/k/v/out projections, grouped q/k/v, the hostops passes, the step replayed from a hipGraph); "plain": NCHW, no head
     padding, one launch per projection, ATen normalisations, eager; "bench" additionally runs the adapters on the step's
     merged weight (``--merged 1``, bench.py's default since round 3), "bench_fused_sites" on the per-site fused MFMA
-    kernels (``--merged 0``).  All vs oracle/torch_ref.dreambooth_step (f32 on
-    the host): loss within 1 %, every LoRA gradient tensor's cosine >= 0.99, norms within 10 %, total norm within 2 %.
-    (bf16 compute against f32: the tolerance is the north star's stated fp16-class tolerance on whole-step quantities.)"""
+    kernels (``--merged 0``).  All at BATCH 4 against oracle/torch_ref.dreambooth_step by the bracket rule (``_compare_step``:
+    as close to the f32 step as the reference's own bf16-autocast step is; the north star's "stated fp16 tolerance" made
+    concrete as the reference's own mixed-precision error)."""
     from lora_amd.standin import fused
 
     ref = sd15_reference_step
@@ -573,7 +557,7 @@ def test_sd15_size_step_in_bench_configuration_matches_oracle(sd15_reference_ste
             loss = float(fwd_bwd(lat, ehs))
             st.reduce_pending()
         H.lap(f"{config}: measured step")
-        _compare_step(ref, loss, st)
+        _compare_step(ref, loss, st, config)
         H.lap(f"{config}: compared")
         if merged is not None:  # every one of the 144 sites took the merged path, in the layouts the host model uses
             assert len({id(e["module"]) for e in merged.entries.values()}) == 144 and merged.refreshes >= 3

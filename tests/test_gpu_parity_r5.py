@@ -56,28 +56,9 @@ def test_group_forward_after_an_optimizer_step_runs_on_this_steps_weights():
 
 # ----------------------------------------------------------------------------- whole step vs the reference's OWN precision
 def _oracle_step_on_device(ref, ref_params, lat, noise, ts, ehs, autocast):
-    """One step of oracle/torch_ref.dreambooth_step (plain ATen ops) on the GPU: f32, or under torch.autocast(bf16) — the
-    arithmetic the reference itself runs (accelerate mixed_precision="bf16", train_lora_dreambooth.py:489-494, 744-770).
-    Returns (UNet output, loss, [gradient per LoRA tensor])."""
-    from lora_amd.standin import DDPMScheduler
-    from oracle import torch_ref as TR
+    from tests import helpers as H
 
-    out = {}
-
-    def unet_fn(x, tt, c):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            y = ref(x, tt, c).sample
-        out["pred"] = y.detach().float()
-        return y
-
-    grads = {}
-    hooks = [p.register_hook(lambda gr, i=i: grads.__setitem__(i, gr.detach().clone())) for i, p in enumerate(ref_params)]
-    opt = torch.optim.SGD(ref_params, lr=0.0)
-    loss = TR.dreambooth_step(unet_fn, ref_params, opt, lat, noise, ts, ehs, DDPMScheduler().alphas_cumprod.to(lat.device),
-                              max_grad_norm=1e30)
-    for h in hooks:
-        h.remove()
-    return out["pred"], float(loss), [grads[i].reshape(-1).float() for i in range(len(ref_params))]
+    return H.oracle_step_on_device(ref, ref_params, lat, noise, ts, ehs, autocast)
 
 
 def test_batch4_step_error_is_bracketed_by_the_bf16_autocast_reference(monkeypatch):
@@ -144,36 +125,13 @@ def test_batch4_step_error_is_bracketed_by_the_bf16_autocast_reference(monkeypat
     # (the bf16 reference's own loss error moves between 2e-5 and 2e-4 with the library's attention kernel picks: a floor of
     # 0.05 % of the loss keeps the bracket meaningful when it happens to be tiny)
     assert abs(loss_dev - l32) <= 1.5 * abs(lbf - l32) + 5e-4 * abs(l32), (loss_dev, lbf, l32)
-    pos, rows = 0, []
-    gmax = max(float(x.norm()) for x in g32)
-    tot_dev = tot_bf = 0.0
-    for i, (a32, abf) in enumerate(zip(g32, gbf)):
-        gd = gdev[pos:pos + a32.numel()]
-        pos += a32.numel()
-        ed, eb = float((gd - a32).norm()), float((abf - a32).norm())
-        tot_dev += ed * ed
-        tot_bf += eb * eb
-        if float(a32.norm()) < 1e-3 * gmax:
-            continue  # a tensor whose gradient is numerically nothing next to the others
-        rows.append((ed / max(eb, 1e-30), i, ed / float(a32.norm()), eb / float(a32.norm()), a32.numel()))
-    assert pos == gdev.numel()
-    rows.sort(reverse=True)
-    ratios = [r_[0] for r_ in rows]
-    print(f"LoRA gradients: aggregate ratio {(tot_dev / tot_bf) ** 0.5:.3f}; per tensor median {ratios[len(ratios) // 2]:.3f}, "
-          f"90th pct {ratios[len(ratios) // 10]:.3f}, max {ratios[0]:.3f}, {len(ratios)} tensors")
-    for r_ in rows[:8]:
-        print("   tensor %d (%s of site %d, %d elements): ratio %.2f, rel err dev %.3e, bf16 ref %.3e"
-              % (r_[1], "down" if r_[1] % 2 else "up", r_[1] // 2, r_[4], r_[0], r_[2], r_[3]))
-    assert (tot_dev / tot_bf) ** 0.5 <= 1.6   # measured 1.27-1.41 over five boxes
-    assert ratios[len(ratios) // 2] <= 1.5    # measured 1.20-1.30
-    # single tensors: the device step rounds differently from autocast in places that are the HOST model's policy, not the
-    # adapters' (bf16-resident weights and residual stream against f32 weights + per-op casts): a tensor may land at a few
-    # times the bf16 reference's error where that error happens to be small (the worst ratio moves between 2.5 and 4.2 from box
-    # to box, always on a `down` gradient whose own relative error is 0.6-2 %); none may be BOTH more than 4x the reference's
-    # and more than 3 % off
-    bad = [r_ for r_ in rows if r_[0] > 4.0 and r_[2] > 0.03]
-    assert not bad, bad[:4]
-    assert max(r_[2] for r_ in rows) <= 0.05, max(rows, key=lambda r_: r_[2])
+    # aggregate 1.27-1.41 and median 1.20-1.30 over five boxes: asserted at + 10 % (round 6; round 5: 1.6 / 1.5).  Single
+    # tensors: the device step rounds differently from autocast in places that are the HOST model's policy, not the adapters'
+    # (bf16-resident weights and residual stream against f32 weights + per-op casts — measured in round 6 by running the SAME
+    # adapters under the reference's policy, test_gpu_parity_r6.py::test_bracket_under_the_reference_precision_policy): a tensor
+    # may land at a few times the bf16 reference's error where that error happens to be small (worst ratio 2.5-4.2 from box
+    # to box, always a `down` gradient at 0.6-2 % relative error); none may be BOTH > 4 x the reference's and > 3 % off
+    H.assert_bracket(H.bracket(g32, gbf, gdev, "bench configuration, batch 4"))
 
 
 # ----------------------------------------------------------------------------- the dithered rounding of the in-step merge
