@@ -724,7 +724,11 @@ def svd_bench(args) -> dict:
     dt = (time.perf_counter() - t0) / args.steps
     iters = n_iter if n_iter is not None else (S.LAST_ITERATIONS or 4)
     passes = 2 * iters + 2
-    byts = passes * elems * 4 + 2 * elems * 4  # the residual passes + reading W_tuned and W_base once
+    # the subspace-steering passes (sketch + power iterations) read the hi plane only (2 bytes / element), the pass that forms
+    # the factors both planes (4); + forming the planes: read W_tuned and W_base (f32), write four 16-bit planes
+    hi_only = bool(getattr(S, "HI_ONLY_ITERATIONS", False))
+    pass_bytes = ((passes - 1) * 2 + 4) * elems if hi_only else passes * elems * 4
+    byts = pass_bytes + 2 * elems * 4 + 4 * elems * 2
     out = {"metric": "cli_svd distillation, SD1.5 UNet -> rank-8 LoRA (224 sites, extended injection)",
            "value": round(n_sites / dt, 2), "unit": "sites/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -737,14 +741,15 @@ def svd_bench(args) -> dict:
                       "workload_short": "BASELINE configs[4]: cli_svd distillation of a fine-tuned SD1.5 UNet to rank-8 LoRA, 224 sites",
                       "sites": n_sites, "groups": len(groups), "weight_elements": elems, "power_iterations": iters,
                       "iteration_count": "adaptive (Ritz energy settled)" if n_iter is None else "fixed"},
-           "roofline": {"kernel": "lora_amd::rowdot16_planes_kernel<bf16> (the ten passes over the residuals: 812 us each = 3.6 TB/s "
-                                  "= 0.45 of the roof in the kernel trace, profiles/r04_svd_kernel_trace_summary_planes_first.txt) "
-                                  "+ everything else of the step",
+           "roofline": {"kernel": "lora_amd::rowdot16_planes_kernel<bf16> (%d passes over the residuals, %s) + split16_residual + "
+                                  "everything else of the step" % (passes, "all but the last on the hi plane only" if hi_only
+                                                                   else "both planes"),
                         "bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes,
-                        "note": "WHOLE-STEP figure: the ~2000 small launches of a step (Gram, Cholesky, the 16 x 16 SVDs, quantile "
-                                "sorts, sign fixes) cost twice what the ten passes over the residuals do"}}
+                        "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes, "hi_plane_only_passes": passes - 1 if hi_only else 0,
+                        "note": "WHOLE-STEP figure (passes + forming the planes + ~70 small launches + one host sync per adaptive "
+                                "iteration from the 4th on); per-kernel shares: profiles/r06_svd_kernel_trace_summary.txt.  "
+                                "LORA_AMD_SVD_ITERS=4 fixes the iteration count (rounds 2-4's iso-work figure)"}}
     if not args.no_cpu_baseline:
         import subprocess
 

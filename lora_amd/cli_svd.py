@@ -58,8 +58,9 @@ THIN = True
 # energy (sum of the r largest eigenvalues of the Gram matrix of dW Qz), which only grows with the iterations.  Iterate until,
 # for EVERY site, one more power iteration improved that squared error by less than RES_TOL of itself (floor: 1e-6 |dW|^2, the
 # resolution of the f32 sums; an exactly low-rank residual).  |dW|_F^2 comes out of the launch that forms the residual.  At
-# least 2, at most MAX_ITER iterations.
-RES_TOL, MAX_ITER = 1e-3, 12
+# least MIN_ITER = 4 (the fixed count of rounds 2-4), at most MAX_ITER iterations; "improved by" = the geometric-tail estimate
+# gain rho / (1 - rho) from the ratio rho of two successive gains.
+RES_TOL, MIN_ITER, MAX_ITER = 1e-3, 4, 12   # MIN_ITER = the fixed count of rounds 2-4: the adaptive rule only ever ADDS iterations
 # the passes that only steer the subspace (the sketch and every power iteration) read the hi plane of the residuals alone: half
 # the bytes; an O(2^-9) perturbation of range(Q) costs the rank-r Frobenius error to second order, and the pass that forms the
 # returned factors (b = Q^T dW) reads both planes.  False: every pass on both planes (rounds 4-5).
@@ -289,7 +290,7 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
     _C.thin_pack(st.tz, st.zc, st.pkz)
     pprog.run(p_y, hi)
     orth(st.ty, st.ya, st.yb)                                     # q in yb
-    it, prev = 0, None
+    it, prev, prev_gain = 0, None, None
     while True:
         _C.thin_pack(st.ty, st.yb, st.pky)
         pprog.run(p_z, hi)
@@ -304,11 +305,16 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
             continue
         if it >= MAX_ITER:
             break
-        if prev is not None:
-            gained = (st.ritz[:, 0] - prev).abs()
+        gained = (st.ritz[:, 0] - prev).abs() if prev is not None else None
+        if it >= MIN_ITER and prev_gain is not None:
+            # what is still to come, from the convergence ratio of two successive gains (a geometric tail gain rho / (1 - rho),
+            # rho capped at 0.95): a small gain alone does not stop a site whose gains are not shrinking
+            rho = (gained / prev_gain.clamp_min(1e-30)).clamp(0.0, 0.95)
+            remaining = gained * rho / (1.0 - rho)
             err2 = (norm2 - st.ritz[:, 0]).clamp_min(0.0)
-            if bool((gained <= torch.maximum(RES_TOL * err2, 1e-6 * norm2)).all()):  # one host sync per iteration
+            if bool((remaining <= torch.maximum(RES_TOL * err2, 1e-6 * norm2)).all()):  # one host sync per iteration >= MIN_ITER
                 break
+        prev_gain = gained
         prev = st.ritz[:, 0].clone()
     st.iterations = it
     global LAST_ITERATIONS

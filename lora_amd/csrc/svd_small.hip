@@ -215,7 +215,13 @@ __device__ void arrive_and_finish(const Finish &f, int site, int64_t block_begin
   const int t = threadIdx.x;
   if (nblocks > 1) {
     // the slab goes out WRITE-THROUGH (agent-scope relaxed store = sc1): no release fence — a buffer_wbl2 per block, ~1500
-    // blocks per launch, was most of this kernel's time in the round's first form (68 us against 10 without the hand-off)
+    // blocks per launch, was most of this kernel's time in the round's first form (68 us against 10 without the hand-off).
+    // This is the hand-off cdna_hip_programming.md gives for in-launch reductions on gfx950 ("equally valid ...: sc1
+    // (write-through) slab stores -> every wave s_waitcnt vmcnt(0) -> __syncthreads() -> lane 0 relaxed agent fetch_add; the
+    // reducer then reads the slabs ... with an acquire fence + plain loads": the fence's buffer_inv sc1 drops the L1 of the CU
+    // all waves of the last block share).  It is NOT a release/acquire pair of the HIP memory model on other targets (ADVICE
+    // r5): the library builds for gfx950 only (csrc/Makefile's ARCH is a cross-compile knob of the same family, and
+    // lora_amd_target_arch() answers "gfx950"); tests/test_gpu_svd_small.py repeats the hand-off thousands of times.
     __hip_atomic_store(f.part + (block_begin + local_block) * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the arrival
     __syncthreads();
@@ -716,7 +722,9 @@ __global__ __launch_bounds__(256) void split16_residual_kernel(const RDesc *__re
       load8<EIN>(pa + (int64_t)row * K + col, a);
       load8<EIN>(pb + (int64_t)row * K + col, b);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] = a[e] - b[e]; sq = fmaf(v[e], v[e], sq); }
+      // the reference subtracts in the weights' own dtype and only then calls .float() (cli_svd.py:30-33, 57-60: fp16
+      // pipelines): a 16-bit input pair gives the difference ROUNDED to that dtype; f32 inputs subtract in f32
+      for (int e = 0; e < 8; ++e) { v[e] = round_to<EIN>(a[e] - b[e]); sq = fmaf(v[e], v[e], sq); }
       split_hi_lo<E>(v, vh, vl);
       *gl(reinterpret_cast<mu32x4 *>(ph + (int64_t)row * K + col)) = vh;
       *gl(reinterpret_cast<mu32x4 *>(pl + (int64_t)row * K + col)) = vl;
