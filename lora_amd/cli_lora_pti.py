@@ -116,14 +116,15 @@ def loss_step(batch, unet, vae, text_encoder, scheduler, train_inpainting=False,
     noise = torch.randn_like(latents)
     timesteps = torch.randint(0, int(scheduler.config.num_train_timesteps * t_mutliplier), (latents.shape[0],),
                               device=dev).long()
-    noisy = scheduler.add_noise(latents, noise, timesteps)
+    # formed in f32, rounded once (trainer.forward_backward says why: a 16-bit alpha_bar_t rounds to 1 at t = 0)
+    noisy = scheduler.add_noise(latents.float(), noise.float(), timesteps).to(dt)
     ehs = text_encoder(batch["input_ids"].to(dev))[0]
     pred = unet(noisy, timesteps, ehs.to(dt)).sample
     ptype = getattr(scheduler.config, "prediction_type", "epsilon")
     if ptype == "epsilon":
         target = noise
     elif ptype == "v_prediction":
-        target = scheduler.get_velocity(latents, noise, timesteps)
+        target = scheduler.get_velocity(latents.float(), noise.float(), timesteps)
     else:
         raise ValueError(f"Unknown prediction type {ptype}")
     if batch.get("mask", None) is not None:

@@ -309,10 +309,12 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
         if it >= MIN_ITER and prev_gain is not None:
             # what is still to come, from the convergence ratio of two successive gains (a geometric tail gain rho / (1 - rho),
             # rho capped at 0.95): a small gain alone does not stop a site whose gains are not shrinking
-            rho = (gained / prev_gain.clamp_min(1e-30)).clamp(0.0, 0.95)
+            # (a previous gain already inside the rounding noise of the Ritz energies, 1e-6 |dW|^2, says nothing about a ratio)
+            floor = 1e-6 * norm2
+            rho = torch.where(prev_gain > floor, gained / prev_gain.clamp_min(1e-30), torch.zeros_like(gained)).clamp(0.0, 0.95)
             remaining = gained * rho / (1.0 - rho)
             err2 = (norm2 - st.ritz[:, 0]).clamp_min(0.0)
-            if bool((remaining <= torch.maximum(RES_TOL * err2, 1e-6 * norm2)).all()):  # one host sync per iteration >= MIN_ITER
+            if bool((remaining <= torch.maximum(RES_TOL * err2, floor)).all()):  # one host sync per iteration >= MIN_ITER
                 break
         prev_gain = gained
         prev = st.ritz[:, 0].clone()

@@ -319,7 +319,15 @@ def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConf
     if timesteps is None:
         timesteps = torch.randint(0, int(cfg.num_train_timesteps * cfg.t_multiplier), (latents.shape[0],),
                                   device=latents.device).long()
-    noisy = scheduler.add_noise(latents, noise, timesteps)
+    # the noisy latents are formed in f32 and rounded ONCE to the compute dtype.  diffusers' DDPMScheduler.add_noise (ref
+    # train_lora_dreambooth.py:837) works in the latents' dtype: under mixed precision it rounds alpha_bar_t itself to 16 bits
+    # first — bf16(0.99915) = 1, so a t = 0 sample gets NO noise and small t a badly quantised one — and then rounds three more
+    # times.  Measured on a batch holding t = 0 (profiles/r06_bracket_t0.log): the step's LoRA gradients sit 6.4 x as far from
+    # the f32 step as the bf16-autocast reference's; formed in f32: 1.29 x.  16 K elements per sample: free.
+    if latents.dtype in (torch.bfloat16, torch.float16):
+        noisy = scheduler.add_noise(latents.float(), noise.float(), timesteps).to(latents.dtype)
+    else:
+        noisy = scheduler.add_noise(latents, noise, timesteps)
     ctx = torch.autocast(latents.device.type, dtype=cfg.autocast_dtype) if cfg.autocast_dtype is not None \
         else torch.autocast(latents.device.type, enabled=False)
     with ctx, _dropout_pool(unet, text_encoder, latents.device):
@@ -328,7 +336,7 @@ def forward_backward(unet, scheduler, latents: torch.Tensor, cond, cfg: StepConf
     if cfg.prediction_type == "epsilon":
         target = noise
     elif cfg.prediction_type == "v_prediction":
-        target = scheduler.get_velocity(latents, noise, timesteps)
+        target = scheduler.get_velocity(latents.float(), noise.float(), timesteps)
     else:
         raise ValueError(f"Unknown prediction type {cfg.prediction_type}")
     loss = dreambooth_loss(pred, target, cfg)

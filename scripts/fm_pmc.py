@@ -11,8 +11,10 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = ("factors_mfma_engine_kernel", "factors_mfma_kernel", "linear_bwd_factors_self_ragged_kernel", "factor_pack_kernel",
-            "reduce_batched_kernel", "merge_step_kernel", "merge_co_kernel")
+FAMILIES = ("factors_reg_kernel<lora_amd::bf16_t, false, 6, 3, 2>", "factors_reg_kernel<lora_amd::bf16_t, false, 6, 3, 4>",
+            "factors_reg_kernel<lora_amd::bf16_t, false, 10, 2, 4>", "factors_mfma_engine_kernel", "factors_mfma_kernel",
+            "linear_bwd_factors_self_ragged_kernel", "factor_pack_kernel", "reduce_batched_kernel", "merge_step_kernel",
+            "merge_co_kernel")
 
 
 def main(dirs):

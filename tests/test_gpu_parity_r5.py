@@ -112,7 +112,7 @@ def test_batch4_step_error_is_bracketed_by_the_bf16_autocast_reference(monkeypat
         gdev = st.flat_g.clone()
         with torch.no_grad():
             merged.refresh()
-            pdev = unet(sched.add_noise(latd, noised, ts), ts, ehsd).sample.float()
+            pdev = unet(sched.add_noise(latd.float(), noised.float(), ts).to(latd.dtype), ts, ehsd).sample.float()
     finally:
         for m in unet.modules():
             m.__dict__.pop("_grad_sink", None)
