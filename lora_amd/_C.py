@@ -1295,6 +1295,9 @@ def factor_pack(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dt
            "lora_amd_factor_pack")
 
 
+FM_DEBUG = 0
+
+
 def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
     """Host half of the matrix-core pass: ``sites`` = [(g, x, pk_down, pk_up, up_part, down_part, scale, g_heads,
     x_heads, r, plan[, (p, seed, offset)])] of one LDS class and rank tile (``plan`` = the site's ``factors_mfma_plan``;
@@ -1319,6 +1322,7 @@ def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
         q.K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
         q.r, q.scale = int(r), float(scale)
         q.rows_per_block, q.blocks_per_wg = int(plan.rows_per_block), int(plan.blocks_per_wg)
+        q.reserved = FM_DEBUG   # 0; scripts/kbench.py's measurement switches of the pass (csrc/factor_mfma.hip)
         q.g_head_dim, q.g_head_pad = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
         q.x_head_dim, q.x_head_pad = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
     grid = C.c_int64(0)

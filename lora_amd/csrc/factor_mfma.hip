@@ -183,6 +183,11 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
 // <= 168 registers, THREE workgroups per CU: a block's life is load latency + ~1.5 us of dependent MFMA / LDS work with no
 // load in flight, and only other workgroups on the CU fill that gap (round 6)
 constexpr int kFrPairsWide = 10, kFrPairsNarrow = 6;
+__device__ __forceinline__ mf32x4 fm_asf(mu32x4 v) {   // bit pattern as four floats (keeps a skipped phase's operands alive)
+  union { mu32x4 u; mf32x4 f; } c;
+  c.u = v;
+  return c.f;
+}
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
 constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
 
@@ -235,6 +240,9 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
   float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
   const int nga = Ca >> 5, ngb = Cb >> 5;
+  // measurement switches (scripts/kbench.py, LORA_AMD_FM_DEBUG; 0 in every product table): 1 = no slab stores, 2 = no phase 2
+  // (no LDS staging / transpose reads / second MFMAs), 4 = the factor fragments are not fetched
+  const int dbg = sd.reserved;
   const bool drop = DROP && sd.dropout_p > 0.f;
   const bool mask_a = drop && !ax, mask_b = drop && ax;   // G is the masked operand
   const uint64_t seed = sd.seed, off = drop ? dropout_offset(sd.offset, sd.offset_dev) : 0;
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
     return v;
   };
   auto frag = [&](const S *pk, int64_t split, int cg, bool lo_part) -> mu32x4 {
+    if (dbg & 4) return mu32x4{0x3f803f80u, 0u, 0u, 0u};
     return *gl(reinterpret_cast<const mu32x4 *>(pk + (lo_part ? split : 0) + (int64_t)cg * 512 + lane * 8));
   };
   unsigned char *stage = s_stage + wave * 32 * kFrPitch;
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   // registers for the whole stream (two more ds_read_b128 per unit buy the third workgroup)
   constexpr bool kTfLds = MINB >= 3;
   auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, int rs, mf32x4 (&acc)[2]) {
+    if (dbg & 2) { acc[0] += fm_asf(p0); acc[1] += fm_asf(p1); return; }
     *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
     *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
     asm volatile("" ::: "memory");
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   float tinv = 1.f;   // f16: 1 / (the power of two the T fragments in use were multiplied by)
   auto store_group = [&](float *out, int C, int cg, mf32x4 (&acc)[2]) {
     float *o = out + (int64_t)(jj < RT ? jj : 0) * C + cg * 32 + 4 * q;
-    if (jj < RT) {
+    if (jj < RT && (!(dbg & 1) || acc[0][0] == 12345.678f)) {
       if constexpr (kScaled) { acc[0] *= tinv; acc[1] *= tinv; }
       *gl(reinterpret_cast<mf32x4 *>(o)) = acc[0];
       *gl(reinterpret_cast<mf32x4 *>(o + 16)) = acc[1];

@@ -424,6 +424,17 @@ def bench_fm(args):
                                    "frac8": round(b / 8e12 / t, 3), "rows": sorted({int(s_[10].rows_per_block) for s_ in ss}),
                                    "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
         tot += t
+    # where the pass's time goes: the same tables with parts of the kernel switched off (results are then wrong; timing only):
+    # 1 = no slab stores, 2 = no phase 2 (LDS staging, transpose reads, second MFMAs), 4 = no factor-fragment loads
+    if os.environ.get("LORA_AMD_FM_ATTRIB", "0") == "1":
+        for dbg in (0, 1, 2, 4, 7):
+            _C.FM_DEBUG = dbg
+            for cls, ss in sorted(by_cls.items()):
+                arr_d, grid_d = _C.factors_mfma_table(ss, dt, cls)
+                tab_d = _C.table_to_device(arr_d, DEV)
+                t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab_d, len(ss), grid_d, cls, dt), inner=5)
+                rec[f"attrib_class{cls}_off{dbg}_us"] = round(t * 1e6, 1)
+        _C.FM_DEBUG = 0
     # class 1 on each of its kernels (lora_amd_factors_mfma_set_tuning): 0 = 10 pairs, two workgroups per CU (rounds 4-5);
     # 1 = 6 pairs, 2-unit ring, three per CU; 2 = 6 pairs, 4-unit ring
     for tab, ns, grid, cls in tabs:
