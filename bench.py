@@ -871,6 +871,8 @@ def main():
         unet = build_unet(dev, cdt, seed=0)
     if args.channels_last:
         unet.to(memory_format=torch.channels_last)
+    if on_gpu and os.environ.get("LORA_AMD_FM_NARROW"):   # same-box A/B of the factor pass's class-1 kernels (measurement only)
+        _C.factors_mfma_set_tuning(int(os.environ["LORA_AMD_FM_NARROW"]))
     if args.adapters == "none":
         # frozen_only leg: no adapter anywhere.  On the device every site an adapter would occupy gets its FROZEN TWIN
         # (standin/frozen.py): the merged path's own GEMM launches on frozen weights in the same layouts (grouped q / k / v,

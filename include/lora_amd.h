@@ -604,11 +604,14 @@ int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_
                                       int64_t *grid);
 /* masked: 0 = no site of the table has dropout_p > 0; 1 = the kernel that regenerates the dropout mask on G (sites with
  * dropout_p = 0 in such a table run unmasked) */
+/* rows_per_block (ABI 6): the block height (32 / 64) every site of the table was planned with — one per table
+ * (lora_amd_factors_mfma_ragged_plan refuses a mixed one): a compile-time constant of the kernel. */
 int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid, int32_t lds_class,
-                                            int32_t act_dtype, int32_t masked, void *stream);
-/* Tuning / test hook: which kernel a table of class 1 runs — 0 = the 10-pair kernel every class can take (two workgroups per
- * CU), 1 (default) = the 6-pair kernel with a 2-unit ring, 2 = with a 4-unit ring (three workgroups per CU); < 0 only reads.
- * Returns the previous value. */
+                                            int32_t rows_per_block, int32_t act_dtype, int32_t masked, void *stream);
+/* Tuning / test hook: which kernel a table of class 1 (64-row blocks) runs — 0 = the 10-pair kernel every class can take (two
+ * workgroups per CU, two column groups in flight per wave), 1 / 2 = the 6-pair kernel at three workgroups per CU with 1 / 2
+ * groups in flight, 3 / 4 / 5 = the 6-pair kernel at two per CU with 2 / 3 / 4 groups in flight; < 0 only reads.  Returns the
+ * previous value. */
 int lora_amd_factors_mfma_set_tuning(int32_t narrow);
 
 

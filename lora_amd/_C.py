@@ -335,7 +335,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_factor_pack_plan.argtypes = [C.POINTER(PackSite), i32, C.POINTER(i64)]
     lib.lora_amd_factor_pack.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_factors_mfma_ragged_plan.argtypes = [C.POINTER(FmSite), i32, i32, i32, C.POINTER(i64)]
-    lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, i32, vp]
+    lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, i32, i32, vp]
     for name in ("lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
                  "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged"):
         getattr(lib, name).restype = C.c_int
@@ -1295,9 +1295,6 @@ def factor_pack(table_dev: torch.Tensor, n: int, total: int, act_dtype: torch.dt
            "lora_amd_factor_pack")
 
 
-FM_DEBUG = 0
-
-
 def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
     """Host half of the matrix-core pass: ``sites`` = [(g, x, pk_down, pk_up, up_part, down_part, scale, g_heads,
     x_heads, r, plan[, (p, seed, offset)])] of one LDS class and rank tile (``plan`` = the site's ``factors_mfma_plan``;
@@ -1322,7 +1319,6 @@ def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
         q.K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
         q.r, q.scale = int(r), float(scale)
         q.rows_per_block, q.blocks_per_wg = int(plan.rows_per_block), int(plan.blocks_per_wg)
-        q.reserved = FM_DEBUG   # 0; scripts/kbench.py's measurement switches of the pass (csrc/factor_mfma.hip)
         q.g_head_dim, q.g_head_pad = (g_heads[1], g_heads[2]) if g_heads else (0, 0)
         q.x_head_dim, q.x_head_pad = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
     grid = C.c_int64(0)
@@ -1332,8 +1328,9 @@ def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
 
 
 def linear_bwd_factors_mfma_ragged(table_dev: torch.Tensor, n: int, grid: int, lds_class: int,
-                                   act_dtype: torch.dtype, masked: bool = False) -> None:
-    _check(require().lora_amd_linear_bwd_factors_mfma_ragged(table_dev.data_ptr(), n, grid, lds_class,
+                                   act_dtype: torch.dtype, masked: bool = False, rows: int = 64) -> None:
+    """``rows``: the block height (``plan.rows_per_block``) of EVERY site of the table (one per table, ABI 6)."""
+    _check(require().lora_amd_linear_bwd_factors_mfma_ragged(table_dev.data_ptr(), n, grid, lds_class, int(rows),
                                                              dtype_code(act_dtype), int(bool(masked)), _stream()),
            "lora_amd_linear_bwd_factors_mfma_ragged")
 

@@ -183,18 +183,26 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
 // <= 168 registers, THREE workgroups per CU: a block's life is load latency + ~1.5 us of dependent MFMA / LDS work with no
 // load in flight, and only other workgroups on the CU fill that gap (round 6)
 constexpr int kFrPairsWide = 10, kFrPairsNarrow = 6;
-__device__ __forceinline__ mf32x4 fm_asf(mu32x4 v) {   // bit pattern as four floats (keeps a skipped phase's operands alive)
-  union { mu32x4 u; mf32x4 f; } c;
-  c.u = v;
-  return c.f;
-}
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
 constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
 
-template <class E, bool DROP, int kFrPairs, int MINB, int RING>
+// Round 6: NO register copy of a value a load is still writing.  The round-4/5 loop rotated its ring by assignment (slot k <-
+// slot k + 1, `fh = nfh` for the prefetched factor fragments): every such v_mov of an in-flight destination made hipcc put
+// `s_waitcnt vmcnt(0)` in front of it — the youngest load — so the "ring" drained completely once per unit and once more per
+// column group, whatever its depth (rings of 2 / 4 / 6 / 8 / 12 units all ran within 3 % of each other,
+// profiles/r06_kbench_fm_ring_depths.log; with the stores, phase 2 AND the fragment loads switched off the skeleton still took
+// 85 % of the time, r06_kbench_fm_attribution.log).  Now a ring SLOT is a whole column group — its 2 or 4 pieces and its two
+// factor fragments, loaded together — the slots are indexed statically in a loop unrolled over them, a slot is refilled in
+// place right after its last use, and every load is unconditional (clamped address, value discarded) so that no load sits
+// behind a branch: the waits are counted ones and RG groups stay in flight per wave.
+//   RS2: two 32-row steps per block (R = 64) / one (R = 32) — compile-time, so that the resident pieces' (row step, group)
+//   order is static too.
+template <class E, bool DROP, int kFrPairs, int MINB, int RG, bool RS2>
 __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
   using S = typename E::storage;
   constexpr bool kScaled = E::kCode == LORA_AMD_F16;   // power-of-two pre-scaling of the split operands (file header)
+  constexpr int NRS = RS2 ? 2 : 1;                     // row steps per block
+  constexpr int kGroupsA = kFrPairs / NRS;             // resident column groups per wave
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
   __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
@@ -218,8 +226,7 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
     }
   }
   const lora_amd_fm_site sd = sites[lo];
-  const int R = sd.rows_per_block;
-  const bool rs2 = R == 64;            // two 32-row steps per block, else one
+  constexpr int R = 32 * NRS;          // == sd.rows_per_block (the launcher sorts the sites of a table by it)
   const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;
   const int64_t m0 = rb * R;
   const int nrows = (int)min((int64_t)R, sd.M - m0);
@@ -240,36 +247,33 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
   float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
   const int nga = Ca >> 5, ngb = Cb >> 5;
-  // measurement switches (scripts/kbench.py, LORA_AMD_FM_DEBUG; 0 in every product table): 1 = no slab stores, 2 = no phase 2
-  // (no LDS staging / transpose reads / second MFMAs), 4 = the factor fragments are not fetched
-  const int dbg = sd.reserved;
+  const int nga_w = wave < nga ? (nga - wave + 3) >> 2 : 0, ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;   // this wave's groups
   const bool drop = DROP && sd.dropout_p > 0.f;
   const bool mask_a = drop && !ax, mask_b = drop && ax;   // G is the masked operand
   const uint64_t seed = sd.seed, off = drop ? dropout_offset(sd.offset, sd.offset_dev) : 0;
   const uint32_t thr = (uint32_t)(sd.dropout_p * 65536.0f + 0.5f);
   const int n8 = sd.N >> 3;
 
+  // every load is issued whatever the indices: out-of-range ones read element (row 0, group 0) and are zeroed by finish()
   auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int cg, int row, bool ok) -> mu32x4 {
     const int ph = fm_hchunk(ok ? cg * 4 + q : 0, h);
     // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
     return *gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8));
   };
-  auto finish = [&](mu32x4 v, int cg, int row, bool masked) -> mu32x4 {
-    if (row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
+  auto finish = [&](mu32x4 v, int cg, int row, bool live, bool masked) -> mu32x4 {
+    if (!live || row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
     if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + q), thr);
     return v;
   };
   auto frag = [&](const S *pk, int64_t split, int cg, bool lo_part) -> mu32x4 {
-    if (dbg & 4) return mu32x4{0x3f803f80u, 0u, 0u, 0u};
     return *gl(reinterpret_cast<const mu32x4 *>(pk + (lo_part ? split : 0) + (int64_t)cg * 512 + lane * 8));
   };
   unsigned char *stage = s_stage + wave * 32 * kFrPitch;
-  // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
   // kTfLds (the three-per-CU kernel): the T fragments of a row step are read from LDS at every use instead of living in 16
   // registers for the whole stream (two more ds_read_b128 per unit buy the third workgroup)
   constexpr bool kTfLds = MINB >= 3;
+  // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
   auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, int rs, mf32x4 (&acc)[2]) {
-    if (dbg & 2) { acc[0] += fm_asf(p0); acc[1] += fm_asf(p1); return; }
     *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
     *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
     asm volatile("" ::: "memory");
@@ -289,24 +293,24 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
     asm volatile("" ::: "memory");
   };
   float tinv = 1.f;   // f16: 1 / (the power of two the T fragments in use were multiplied by)
-  auto store_group = [&](float *out, int C, int cg, mf32x4 (&acc)[2]) {
-    float *o = out + (int64_t)(jj < RT ? jj : 0) * C + cg * 32 + 4 * q;
-    if (jj < RT && (!(dbg & 1) || acc[0][0] == 12345.678f)) {
+  auto store_group = [&](float *out, int C, int cg, bool live, mf32x4 (&acc)[2]) {
+    float *o = out + (int64_t)(jj < RT ? jj : 0) * C + (live ? cg : 0) * 32 + 4 * q;
+    if (live && jj < RT) {
       if constexpr (kScaled) { acc[0] *= tinv; acc[1] *= tinv; }
       *gl(reinterpret_cast<mf32x4 *>(o)) = acc[0];
       *gl(reinterpret_cast<mf32x4 *>(o + 16)) = acc[1];
     }
     acc[0] = acc[1] = mf32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto store_parts = [&](const mf32x4 (&d)[4]) {   // D1 lane (j = jj, rows 4 q + reg) of (row step, 16-row group)
+  auto store_parts = [&](const mf32x4 (&d)[2 * NRS]) {   // D1 lane (j = jj, rows 4 q + reg) of (row step, 16-row group)
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 2 * NRS; ++x)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) s_part[(wave * 64 + (x >> 1) * 32 + (x & 1) * 16 + 4 * q + reg) * 16 + jj] = d[x][reg];
     if constexpr (kScaled) {
       float m = 0.f;
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+      for (int x = 0; x < 2 * NRS; ++x)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) m = fmaxf(m, fabsf(d[x][reg]));
       m = fm_wave_max(m);
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
       tscale *= up2;
       tinv = dn2;
     }
-    if (wave < (rs2 ? 2 : 1)) {
+    if (wave < NRS) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -337,63 +341,58 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
     }
   };
 
-  // ---- 1. the resident pieces: pair pp = (row step rs, group index gi), pieces 2 pp (rows rs 32 + jj) and 2 pp + 1 (+ 16)
-  mu32x4 pa[2 * kFrPairs];
+  // ---- 1. the resident pieces of A: group gi of this wave = column group wave + 4 gi, pieces [gi][row step][row half]
+  mu32x4 pa[kGroupsA][NRS][2];
 #pragma unroll
-  for (int pp = 0; pp < kFrPairs; ++pp) {
-    const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-    pa[2 * pp] = pa[2 * pp + 1] = mu32x4{0u, 0u, 0u, 0u};
-    if (cg < nga) {   // wave-uniform
-      pa[2 * pp] = load_piece(da, lda, hda, cg, rs * 32 + jj, rs * 32 + jj < nrows);
-      pa[2 * pp + 1] = load_piece(da, lda, hda, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
-    }
+  for (int gi = 0; gi < kGroupsA; ++gi) {
+    const bool live = gi < nga_w;
+    const int cg = live ? wave + 4 * gi : 0;
+#pragma unroll
+    for (int rs = 0; rs < NRS; ++rs)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) pa[gi][rs][h] = load_piece(da, lda, hda, cg, rs * 32 + h * 16 + jj, live && rs * 32 + h * 16 + jj < nrows);
   }
-  // ---- 2. TA = A fa^T
-  mf32x4 d1[4];
+  // ---- 3 (issued here): the first RG column groups of B and their factor fragments
+  mu32x4 pb[RG][NRS][2], fb[RG][2];
+  auto load_group = [&](int gi, mu32x4 (&p)[NRS][2], mu32x4 (&f)[2]) {
+    const bool live = gi < ngb_w;
+    const int cg = live ? wave + 4 * gi : 0;
+    f[0] = frag(pkb, splitb, cg, false);
+    f[1] = frag(pkb, splitb, cg, true);
 #pragma unroll
-  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
-    if (wave < nga) { nfh = frag(pka, splita, wave, false); nfl = frag(pka, splita, wave, true); }
+    for (int rs = 0; rs < NRS; ++rs)
 #pragma unroll
-    for (int pp = 0; pp < kFrPairs; ++pp) {
-      const int rs = rs2 ? (pp & 1) : 0, cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-      if (!rs2 || !(pp & 1)) {  // first pair of a group
-        fh = nfh; fl = nfl;
-        if (cg + 4 < nga) { nfh = frag(pka, splita, cg + 4, false); nfl = frag(pka, splita, cg + 4, true); }
-      }
-      if (cg < nga) {
-        pa[2 * pp] = finish(pa[2 * pp], cg, rs * 32 + jj, mask_a);
-        pa[2 * pp + 1] = finish(pa[2 * pp + 1], cg, rs * 32 + 16 + jj, mask_a);
-        if (rs2 && (pp & 1)) {
-          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[2]);
-          d1[2] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[2]);
-          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[3]);
-          d1[3] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[3]);
-        } else {
-          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fh), d1[0]);
-          d1[0] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp]), fm_frag<E>(fl), d1[0]);
-          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fh), d1[1]);
-          d1[1] = FmMfma<E>::mma(fm_frag<E>(pa[2 * pp + 1]), fm_frag<E>(fl), d1[1]);
-        }
-      }
-    }
-  }
-  // ---- 3. B: the first ring slots go out before the barrier
-  const int ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;
-  const int nunits = ngb_w * (rs2 ? 2 : 1);
-  mu32x4 b0[RING], b1[RING];   // RING units (32 rows x 32 columns = two pieces) of B in flight per wave
-#pragma unroll
-  for (int sl = 0; sl < RING; ++sl) b0[sl] = b1[sl] = mu32x4{0u, 0u, 0u, 0u};
-  auto load_unit = [&](int u, mu32x4 &x0, mu32x4 &x1) {
-    const int rs = rs2 ? (u & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
-    if (u < nunits) {   // wave-uniform
-      x0 = load_piece(db, ldb, hdb, cg, rs * 32 + jj, rs * 32 + jj < nrows);
-      x1 = load_piece(db, ldb, hdb, cg, rs * 32 + 16 + jj, rs * 32 + 16 + jj < nrows);
-    }
+      for (int h = 0; h < 2; ++h) p[rs][h] = load_piece(db, ldb, hdb, cg, rs * 32 + h * 16 + jj, live && rs * 32 + h * 16 + jj < nrows);
   };
+  // ---- 2. TA = A fa^T: the fragments of A's groups in a two-deep buffer indexed by the (static) parity of the group
+  mf32x4 d1[2 * NRS];
 #pragma unroll
-  for (int sl = 0; sl < RING; ++sl) load_unit(sl, b0[sl], b1[sl]);
+  for (int x = 0; x < 2 * NRS; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    mu32x4 fa[2][2];
+    fa[0][0] = frag(pka, splita, nga_w > 0 ? wave : 0, false);
+    fa[0][1] = frag(pka, splita, nga_w > 0 ? wave : 0, true);
+#pragma unroll
+    for (int s = 0; s < RG; ++s) load_group(s, pb[s], fb[s]);
+#pragma unroll
+    for (int gi = 0; gi < kGroupsA; ++gi) {
+      const bool live = gi < nga_w;
+      const int cg = wave + 4 * gi;
+      if (gi + 1 < kGroupsA) {
+        const int cn = gi + 1 < nga_w ? cg + 4 : 0;
+        fa[(gi + 1) & 1][0] = frag(pka, splita, cn, false);
+        fa[(gi + 1) & 1][1] = frag(pka, splita, cn, true);
+      }
+#pragma unroll
+      for (int rs = 0; rs < NRS; ++rs)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          pa[gi][rs][h] = finish(pa[gi][rs][h], cg, rs * 32 + h * 16 + jj, live, mask_a);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(pa[gi][rs][h]), fm_frag<E>(fa[gi & 1][0]), d1[rs * 2 + h]);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(pa[gi][rs][h]), fm_frag<E>(fa[gi & 1][1]), d1[rs * 2 + h]);
+        }
+    }
+  }
   store_parts(d1);
   __syncthreads();
   build_tf(sd.scale * finv_a);
@@ -402,43 +401,36 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   tfh[0] = tfl[0] = tfh[1] = tfl[1] = mu32x4{0u, 0u, 0u, 0u};
   if constexpr (!kTfLds) {
     tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
-    tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+    if constexpr (RS2) { tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane]; }
   }
 #pragma unroll
-  for (int x = 0; x < 4; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  for (int x = 0; x < 2 * NRS; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
   mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
-  {
-    mu32x4 fh = mu32x4{0u, 0u, 0u, 0u}, fl = fh, nfh = fh, nfl = fh;
-    if (wave < ngb) { nfh = frag(pkb, splitb, wave, false); nfl = frag(pkb, splitb, wave, true); }
+  // ---- 3. B: slot s holds group g0 + s; consumed, then refilled in place with group g0 + s + RG
 #pragma unroll 1
-    for (int u0 = 0; u0 < nunits; u0 += RING) {
+  for (int g0 = 0; g0 < ngb_w; g0 += RG) {
 #pragma unroll
-      for (int sl = 0; sl < RING; ++sl) {
-        const int u = u0 + sl;
-        if (u < nunits) {   // wave-uniform
-          const int rs = rs2 ? (sl & 1) : 0, cg = wave + 4 * (rs2 ? (u >> 1) : u);
-          if (!rs2 || !(sl & 1)) {
-            fh = nfh; fl = nfl;
-            if (cg + 4 < ngb) { nfh = frag(pkb, splitb, cg + 4, false); nfl = frag(pkb, splitb, cg + 4, true); }
-          }
-          const mu32x4 p0 = finish(b0[sl], cg, rs * 32 + jj, mask_b), p1 = finish(b1[sl], cg, rs * 32 + 16 + jj, mask_b);
-          load_unit(u + RING, b0[sl], b1[sl]);
-          if (rs2 && (sl & 1)) {
-            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[2]);
-            d1[2] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[2]);
-            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[3]);
-            d1[3] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[3]);
-            phase2(p0, p1, tfh[1], tfl[1], 1, acc);
-          } else {
-            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fh), d1[0]);
-            d1[0] = FmMfma<E>::mma(fm_frag<E>(p0), fm_frag<E>(fl), d1[0]);
-            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fh), d1[1]);
-            d1[1] = FmMfma<E>::mma(fm_frag<E>(p1), fm_frag<E>(fl), d1[1]);
-            phase2(p0, p1, tfh[0], tfl[0], 0, acc);
-          }
-          if (!rs2 || (sl & 1)) store_group(outb, Cb, cg, acc);
+    for (int s = 0; s < RG; ++s) {
+      const int gi = g0 + s;
+      const bool live = gi < ngb_w;
+      const int cg = wave + 4 * gi;
+      mu32x4 qv[NRS][2];
+#pragma unroll
+      for (int rs = 0; rs < NRS; ++rs)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) qv[rs][h] = finish(pb[s][rs][h], cg, rs * 32 + h * 16 + jj, live, mask_b);
+      const mu32x4 fh = fb[s][0], fl = fb[s][1];
+#pragma unroll
+      for (int rs = 0; rs < NRS; ++rs)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(qv[rs][h]), fm_frag<E>(fh), d1[rs * 2 + h]);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(qv[rs][h]), fm_frag<E>(fl), d1[rs * 2 + h]);
         }
-      }
+      load_group(gi + RG, pb[s], fb[s]);   // the slot's registers are free: its next group goes out before the LDS work
+#pragma unroll
+      for (int rs = 0; rs < NRS; ++rs) phase2(qv[rs][0], qv[rs][1], tfh[rs], tfl[rs], rs, acc);
+      store_group(outb, Cb, cg, live, acc);
     }
   }
   // ---- 4. TB -> fragments
@@ -448,17 +440,15 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   __syncthreads();
   if constexpr (!kTfLds) {
     tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
-    tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane];
+    if constexpr (RS2) { tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane]; }
   }
   // ---- 5. outA = A^T TB from the resident pieces
 #pragma unroll
-  for (int pp = 0; pp < kFrPairs; ++pp) {
-    const int cg = wave + 4 * (rs2 ? (pp >> 1) : pp);
-    if (cg < nga) {
-      if (rs2 && (pp & 1)) phase2(pa[2 * pp], pa[2 * pp + 1], tfh[1], tfl[1], 1, acc);
-      else phase2(pa[2 * pp], pa[2 * pp + 1], tfh[0], tfl[0], 0, acc);
-      if (!rs2 || (pp & 1)) store_group(outa, Ca, cg, acc);
-    }
+  for (int gi = 0; gi < kGroupsA; ++gi) {
+    const bool live = gi < nga_w;
+#pragma unroll
+    for (int rs = 0; rs < NRS; ++rs) phase2(pa[gi][rs][0], pa[gi][rs][1], tfh[rs], tfl[rs], rs, acc);
+    store_group(outa, Ca, wave + 4 * gi, live, acc);
   }
 }
 
@@ -515,12 +505,12 @@ static int g_fm_narrow = 1;   // 0: class-1 tables run the wide kernel too (A/B 
 
 using namespace lora_amd;
 
-// Tuning / test hook: tables of register class 1 run 0 = the 10-pair kernel (two workgroups per CU, rounds 4-5), 1 (default) =
-// the 6-pair kernel with a 2-unit ring, 2 = the 6-pair kernel with a 4-unit ring (three per CU both); < 0 only reads.  Returns
-// the previous value.
+// Tuning / test hook: tables of register class 1 (64-row blocks) run 0 = the 10-pair kernel (two workgroups per CU, two column
+// groups in flight per wave: rounds 4-5's geometry), 1 / 2 = the 6-pair kernel at three workgroups per CU with 1 / 2 groups in
+// flight, 3 / 4 / 5 = the 6-pair kernel at two per CU with 2 / 3 / 4 groups in flight; < 0 only reads.  Returns the previous value.
 extern "C" int lora_amd_factors_mfma_set_tuning(int32_t narrow) {
   const int prev = g_fm_narrow;
-  if (narrow >= 0 && narrow <= 2) g_fm_narrow = narrow;
+  if (narrow >= 0 && narrow <= 5) g_fm_narrow = narrow;
   return prev;
 }
 
@@ -596,6 +586,9 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
   for (int i = 0; i < n; ++i) {
     lora_amd_fm_site &q = sites[i];
     FmGeom g;
+    LORA_AMD_CHECK(q.rows_per_block == sites[0].rows_per_block, LORA_AMD_EINVAL,
+                   "factors_mfma_ragged_plan: site %d: %d rows per block, site 0: %d (one block height per table: it is a "
+                   "compile-time constant of the kernel)", i, q.rows_per_block, sites[0].rows_per_block);
     LORA_AMD_CHECK(q.r >= 1 && q.r <= 16 && (q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16) == rt0, LORA_AMD_ERANK,
                    "factors_mfma_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
     LORA_AMD_CHECK(q.g && q.x && q.pk_up && q.pk_down && q.up_part && q.down_part, LORA_AMD_EINVAL,
@@ -619,24 +612,34 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
 }
 
 extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
-                                                       int32_t lds_class, int32_t act_dtype, int32_t masked, void *stream) {
+                                                       int32_t lds_class, int32_t rows_per_block, int32_t act_dtype,
+                                                       int32_t masked, void *stream) {
   LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
                  LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
+  LORA_AMD_CHECK(rows_per_block == 32 || rows_per_block == 64, LORA_AMD_EINVAL,
+                 "linear_bwd_factors_mfma_ragged: rows_per_block = the 32 or 64 every site of the table was planned with");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
   const bool drop = masked != 0;  // a table of dropout sites: the kernel with the Philox mask on G (straight-line, no per-site branch)
-  // register class 1 (every site of the table planned with lds_class 1: <= 6 resident pairs per wave): three workgroups per CU
-  const int narrow = lds_class == 1 ? g_fm_narrow : 0;
-#define FM2(E, D)                                                                                                     \
-  do {                                                                                                                \
-    if (narrow == 1) hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsNarrow, 3, 2>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    else if (narrow == 2) hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsNarrow, 3, 4>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
-    else hipLaunchKernelGGL((factors_reg_kernel<E, D, kFrPairsWide, 2, 4>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n); \
+  // register class 1 with 64-row blocks (<= 3 resident column groups per wave): the 6-pair kernels, chosen by
+  // lora_amd_factors_mfma_set_tuning; everything else: the 10-pair kernel of its block height
+  const int narrow = (lds_class == 1 && rows_per_block == 64) ? g_fm_narrow : 0;
+#define FML(E, D, P, B, G, S2) hipLaunchKernelGGL((factors_reg_kernel<E, D, P, B, G, S2>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n)
+#define FM2(E, D)                                                          \
+  do {                                                                     \
+    if (narrow == 1) FML(E, D, kFrPairsNarrow, 3, 1, true);                \
+    else if (narrow == 2) FML(E, D, kFrPairsNarrow, 3, 2, true);           \
+    else if (narrow == 3) FML(E, D, kFrPairsNarrow, 2, 2, true);           \
+    else if (narrow == 4) FML(E, D, kFrPairsNarrow, 2, 3, true);           \
+    else if (narrow == 5) FML(E, D, kFrPairsNarrow, 2, 4, true);           \
+    else if (rows_per_block == 64) FML(E, D, kFrPairsWide, 2, 2, true);    \
+    else FML(E, D, kFrPairsWide, 2, 4, false);                             \
   } while (0)
 #define FM(E) do { if (drop) FM2(E, true); else FM2(E, false); } while (0)
   if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
 #undef FM2
+#undef FML
 #undef FM
   return check_launch("lora_amd_linear_bwd_factors_mfma_ragged");
 }

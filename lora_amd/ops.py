@@ -779,7 +779,8 @@ class MergedWeights:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16
             masked = kind == "mfma" and st[11] is not None and st[11][0] > 0.0
-            cls = (2 if one_class else int(plan.lds_class), masked) if kind == "mfma" else 0
+            # (register class, block height, masked): the block height is a compile-time constant of the kernel
+            cls = (2 if one_class else int(plan.lds_class), masked, int(plan.rows_per_block)) if kind == "mfma" else 0
             groups.setdefault((kind, st[0].dtype, rt, cls), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
         packed = {}  # activation dtype -> packs of this flush's sites, each adapter once
@@ -800,7 +801,7 @@ class MergedWeights:
                                  plan, drop))
                 arr, grid = _C.factors_mfma_table(rows, dt, cls[0])
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
-                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls[0], dt, cls[1])
+                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls[0], dt, cls[1], cls[2])
             else:
                 arr, grid = _C.factors_self_ragged_table([st[:9] for st in sites], dt)
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)

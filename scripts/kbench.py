@@ -404,7 +404,7 @@ def bench_fm(args):
         part_bytes += (int(pl.up_part_floats) + int(pl.down_part_floats)) * 4
         pk_down, pk_up = torch.empty(int(pl.pack_down_elems), dtype=dt, device=DEV), torch.empty(int(pl.pack_up_elems), dtype=dt, device=DEV)
         packs.append((down, up, pk_down, pk_up))
-        by_cls.setdefault(int(pl.lds_class), []).append((gs[key], xs[key], pk_down, pk_up, up_part, down_part, 1.0,
+        by_cls.setdefault((int(pl.lds_class), int(pl.rows_per_block)), []).append((gs[key], xs[key], pk_down, pk_up, up_part, down_part, 1.0,
                                                         None, None, r, pl))
         rows_m += [(up_part, torch.empty(N, r, device=DEV), pl.nparts, pl.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
                    (down_part, torch.empty(r, K, device=DEV), pl.nparts, pl.rank_tile, K, r, _C.FACTOR_RK, 1.0, 0.0)]
@@ -414,51 +414,26 @@ def bench_fm(args):
     rec["pack_us"] = round(t * 1e6, 1)
     tot = 0.0
     tabs = []
-    for cls, ss in sorted(by_cls.items()):
+    for (cls, rpb), ss in sorted(by_cls.items()):   # one launch per (register class, block height)
         arr, grid = _C.factors_mfma_table(ss, dt, cls)
         tab = _C.table_to_device(arr, DEV)
-        tabs.append((tab, len(ss), grid, cls))
+        tabs.append((tab, len(ss), grid, cls, rpb))
         b = sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)
-        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt), inner=5)
-        rec[f"mfma_class{cls}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
-                                   "frac8": round(b / 8e12 / t, 3), "rows": sorted({int(s_[10].rows_per_block) for s_ in ss}),
-                                   "blocks_per_wg": sorted({int(s_[10].blocks_per_wg) for s_ in ss})}
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt, False, rpb), inner=5)
+        rec[f"mfma_class{cls}_rows{rpb}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
+                                             "frac8": round(b / 8e12 / t, 3)}
         tot += t
-    # where the pass's time goes: the same tables with parts of the kernel switched off (results are then wrong; timing only):
-    # 1 = no slab stores, 2 = no phase 2 (LDS staging, transpose reads, second MFMAs), 4 = no factor-fragment loads
-    if os.environ.get("LORA_AMD_FM_ATTRIB", "0") == "1":
-        for dbg in (0, 1, 2, 4, 7):
-            _C.FM_DEBUG = dbg
-            for cls, ss in sorted(by_cls.items()):
-                arr_d, grid_d = _C.factors_mfma_table(ss, dt, cls)
-                tab_d = _C.table_to_device(arr_d, DEV)
-                t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab_d, len(ss), grid_d, cls, dt), inner=5)
-                rec[f"attrib_class{cls}_off{dbg}_us"] = round(t * 1e6, 1)
-        _C.FM_DEBUG = 0
-    # class 1 on each of its kernels (lora_amd_factors_mfma_set_tuning): 0 = 10 pairs, two workgroups per CU (rounds 4-5);
-    # 1 = 6 pairs, 2-unit ring, three per CU; 2 = 6 pairs, 4-unit ring
-    for tab, ns, grid, cls in tabs:
-        if cls != 1:
+    # class 1 on each of its kernels (lora_amd_factors_mfma_set_tuning): 0 = 10 pairs, two workgroups per CU, 2 groups in flight;
+    # 1 / 2 = 6 pairs, three per CU, 1 / 2 groups in flight; 3 / 4 / 5 = 6 pairs, two per CU, 2 / 3 / 4 groups in flight
+    for tab, ns, grid, cls, rpb in tabs:
+        if (cls, rpb) != (1, 64):
             continue
         prev = _C.factors_mfma_set_tuning(-1)
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3, 4, 5):
             _C.factors_mfma_set_tuning(mode)
-            t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
+            t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
             rec[f"class1_kernel{mode}_us"] = round(t * 1e6, 1)
         _C.factors_mfma_set_tuning(prev)
-    # the register-resident kernel on the same tables
-    tot_r = 0.0
-    for tab, ns, grid, cls in tabs:
-        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt), inner=5)
-        rec[f"reg_class{cls}_us"] = round(t * 1e6, 1)
-        tot_r += t
-    rec["reg_pass_us"], rec["reg_frac8"] = round(tot_r * 1e6, 1), round(byts / 8e12 / tot_r, 3)
-    # ... and as ONE launch over every site (what ops.MergedWeights.flush_factors issues for this kernel)
-    every = [s_ for _, ss in sorted(by_cls.items()) for s_ in ss]
-    arr, grid = _C.factors_mfma_table(every, dt, 2)
-    tab1 = _C.table_to_device(arr, DEV)
-    t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab1, len(every), grid, 2, dt), inner=5)
-    rec["reg_one_launch_us"], rec["reg_one_launch_frac8"] = round(t * 1e6, 1), round(byts / 8e12 / t, 3)
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
     rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)

@@ -46,7 +46,8 @@ def _factor_pass(x, g, down, up, s_, r, dt, drop=None):
     _C.factor_pack(_C.table_to_device(arr, DEV), 1, total, dt)
     row = (g, x, pk_down, pk_up, up_part, down_part, s_, None, None, r, plan) + ((drop,) if drop else ())
     arr, grid = _C.factors_mfma_table([row], dt, int(plan.lds_class))
-    _C.linear_bwd_factors_mfma_ragged(_C.table_to_device(arr, DEV), 1, grid, int(plan.lds_class), dt, bool(drop))
+    _C.linear_bwd_factors_mfma_ragged(_C.table_to_device(arr, DEV), 1, grid, int(plan.lds_class), dt, bool(drop),
+                                      int(plan.rows_per_block))
     d_up, d_down = torch.empty(N, r, device=DEV), torch.empty(r, K, device=DEV)
     table, cnt, total = _C.make_reduce_table(
         [(up_part, d_up, plan.nparts, plan.rank_tile, N, r, _C.FACTOR_KR, 1.0, 0.0),
