@@ -63,6 +63,13 @@ cfg3twin)
   python scripts/prof_summary.py $(find $OUT/r06_cfg3twin_trace -name "*kernel_trace.csv" | head -1) 70 > $OUT/r06_cfg3twin_kernel_trace_summary.txt
   rm -rf $OUT/r06_cfg3twin_trace
   head -12 $OUT/r06_cfg3twin_kernel_trace_summary.txt | cut -c1-150 ;;
+svdtrace)
+  python bench.py --svd --warmup 1 --steps 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r06_svd_trace -o svd -- python bench.py --svd --warmup 1 --steps 3 --no-cpu-baseline > $OUT/r06_bench_svd.json 2> $OUT/r06_svd_traced.err
+  python scripts/prof_summary.py $(find $OUT/r06_svd_trace -name "*kernel_trace.csv" | head -1) 30 > $OUT/r06_svd_kernel_trace_summary.txt
+  rm -rf $OUT/r06_svd_trace
+  LORA_AMD_SVD_ITERS=4 python bench.py --svd --warmup 2 --steps 5 --no-cpu-baseline > $OUT/r06_bench_svd_iters4.json 2> /dev/null
+  head -8 $OUT/r06_svd_kernel_trace_summary.txt | cut -c1-150; cut -c1-250 $OUT/r06_bench_svd_iters4.json ;;
 kbench)
   timeout 200 python scripts/kbench.py --what ${KBENCH_WHAT:-ws} > $OUT/r06_kbench_${KBENCH_WHAT:-ws}.log 2>&1
   tail -40 $OUT/r06_kbench_${KBENCH_WHAT:-ws}.log ;;
