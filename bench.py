@@ -727,7 +727,8 @@ def svd_bench(args) -> dict:
     # the subspace-steering passes (sketch + power iterations) read the hi plane only (2 bytes / element), the pass that forms
     # the factors both planes (4); + forming the planes: read W_tuned and W_base (f32), write four 16-bit planes
     hi_only = bool(getattr(S, "HI_ONLY_ITERATIONS", False))
-    pass_bytes = ((passes - 1) * 2 + 4) * elems if hi_only else passes * elems * 4
+    full = 1 + max(1, iters - 3) if hi_only else passes   # b = Q^T dW, and dW Qz from the 4th iteration on
+    pass_bytes = ((passes - full) * 2 + full * 4) * elems
     byts = pass_bytes + 2 * elems * 4 + 4 * elems * 2
     out = {"metric": "cli_svd distillation, SD1.5 UNet -> rank-8 LoRA (224 sites, extended injection)",
            "value": round(n_sites / dt, 2), "unit": "sites/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -742,11 +743,10 @@ def svd_bench(args) -> dict:
                       "sites": n_sites, "groups": len(groups), "weight_elements": elems, "power_iterations": iters,
                       "iteration_count": "adaptive (Ritz energy settled)" if n_iter is None else "fixed"},
            "roofline": {"kernel": "lora_amd::rowdot16_planes_kernel<bf16> (%d passes over the residuals, %s) + split16_residual + "
-                                  "everything else of the step" % (passes, "all but the last on the hi plane only" if hi_only
-                                                                   else "both planes"),
+                                  "everything else of the step" % (passes, "%d of them on the hi plane only" % (passes - full)),
                         "bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes, "hi_plane_only_passes": passes - 1 if hi_only else 0,
+                        "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes, "hi_plane_only_passes": passes - full,
                         "note": "WHOLE-STEP figure (passes + forming the planes + ~70 small launches + one host sync per adaptive "
                                 "iteration from the 4th on); per-kernel shares: profiles/r06_svd_kernel_trace_summary.txt.  "
                                 "LORA_AMD_SVD_ITERS=4 fixes the iteration count (rounds 2-4's iso-work figure)"}}

@@ -61,9 +61,9 @@ THIN = True
 # least MIN_ITER = 4 (the fixed count of rounds 2-4), at most MAX_ITER iterations; "improved by" = the geometric-tail estimate
 # gain rho / (1 - rho) from the ratio rho of two successive gains.
 RES_TOL, MIN_ITER, MAX_ITER = 1e-3, 4, 12   # MIN_ITER = the fixed count of rounds 2-4: the adaptive rule only ever ADDS iterations
-# the passes that only steer the subspace (the sketch and every power iteration) read the hi plane of the residuals alone: half
-# the bytes; an O(2^-9) perturbation of range(Q) costs the rank-r Frobenius error to second order, and the pass that forms the
-# returned factors (b = Q^T dW) reads both planes.  False: every pass on both planes (rounds 4-5).
+# the passes that only steer the subspace (the sketch, every `dW^T Q`, and `dW Qz` of the iterations before the one that may be
+# the last) read the hi plane of the residuals alone: half the bytes; the products the returned factors are formed from (the last
+# iterations' `dW Qz` and b = Q^T dW) read both planes.  False: every pass on both planes (rounds 4-5).
 HI_ONLY_ITERATIONS = True
 LAST_ITERATIONS = None  # power iterations the last fused distillation ran (evidence for bench.py)
 
@@ -296,7 +296,10 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
         pprog.run(p_z, hi)
         orth(st.tz, st.za, st.zb)                                 # qz in zb
         _C.thin_pack(st.tz, st.zb, st.pkz)
-        pprog.run(p_y, hi)
+        # the Q that is RETURNED must come from a product with dW itself: from the iteration that may be the last one on
+        # (MIN_ITER, or the caller's fixed count) `dW Qz` reads both planes — one multiplication by the exact matrix contracts
+        # the hi-plane iterations' O(2^-9) subspace error by the spectral gap (exactly low-rank deltas: to nothing)
+        pprog.run(p_y, hi and it + 1 < (n_iter if n_iter is not None else MIN_ITER))
         orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
         it += 1
         if n_iter is not None:

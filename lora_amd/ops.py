@@ -452,6 +452,8 @@ RANK16_MFMA = True
 # the one-launch factor pass as one launch per REGISTER class (class 1 = the M = 16384 sites: three workgroups per CU,
 # csrc/factor_mfma.hip) instead of one launch of the two-per-CU kernel over every site (rounds 4-5)
 FM_TWO_CLASSES = True
+# the factor-pass launches of one flush on forked streams (their tails overlap) instead of back to back on the launch stream
+CONCURRENT_FACTOR_LAUNCHES = True
 # the channels-last 3x3 site as ONE forward launch (csrc/conv_nhwc.hip, round 6: batched pack once per optimiser step + the
 # fused down-conv / fold / up-projection / dropout / add kernel) and its G pass with the Gt fold inside the launch; False =
 # the launch sequence of rounds 3-5 (pack + down [+ sum_parts] + rank_update; bwd_g + sum_parts): the A/B and the parity twin
@@ -461,7 +463,7 @@ CONV3_FUSED = True
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONV3_FUSED", "WS_DROPOUT",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "CONV3_FUSED", "WS_DROPOUT",
                "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
@@ -791,6 +793,7 @@ class MergedWeights:
                     packed.setdefault(dt, {})[id(pk[0])] = pk
         for dt, pks in packed.items():
             self._pack_factors(dt, list(pks.values()))
+        launches = []   # (workgroups, closure): the tables go up on the launch stream first, the kernels may then run side by side
         for (kind, dt, rt, cls), sites in groups.items():
             dev0 = sites[0][0].device
             if kind == "mfma":
@@ -801,11 +804,34 @@ class MergedWeights:
                                  plan, drop))
                 arr, grid = _C.factors_mfma_table(rows, dt, cls[0])
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
-                _C.linear_bwd_factors_mfma_ragged(dev, len(sites), grid, cls[0], dt, cls[1], cls[2])
+                launches.append((grid, lambda dev=dev, n=len(sites), grid=grid, cls=cls, dt=dt:
+                                 _C.linear_bwd_factors_mfma_ragged(dev, n, grid, cls[0], dt, cls[1], cls[2])))
             else:
                 arr, grid = _C.factors_self_ragged_table([st[:9] for st in sites], dt)
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
-                _C.linear_bwd_factors_self_ragged(dev, len(sites), grid, sites[0][2].shape[0], dt)
+                launches.append((grid, lambda dev=dev, n=len(sites), grid=grid, r=sites[0][2].shape[0], dt=dt:
+                                 _C.linear_bwd_factors_self_ragged(dev, n, grid, r, dt)))
+        # The launches of one flush are independent (disjoint slabs): the largest goes out on the launch stream, the others on
+        # side streams forked from it and joined behind it, so that the tail of one launch fills with the workgroups of the next
+        # instead of three tails in a row (round 6: one launch per register class and block height = three launches in the
+        # headline step).  Capturable: the fork / join become edges of the hipGraph.
+        launches.sort(key=lambda t: -t[0])
+        if len(launches) == 1 or not CONCURRENT_FACTOR_LAUNCHES:
+            for _, fn in launches:
+                fn()
+            return
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_side_streams", [])
+        while len(side) < len(launches) - 1:
+            side.append(torch.cuda.Stream(device=main.device))
+        for st_ in side[:len(launches) - 1]:
+            st_.wait_stream(main)
+        launches[0][1]()
+        for (_, fn), st_ in zip(launches[1:], side):
+            with torch.cuda.stream(st_):
+                fn()
+        for st_ in side[:len(launches) - 1]:
+            main.wait_stream(st_)
 
     def invalidate(self) -> None:
         """Factor tensors were re-bound (new storage) or a scale changed: rebuild the entries on their next use."""
