@@ -727,7 +727,10 @@ def svd_bench(args) -> dict:
     # the subspace-steering passes (sketch + power iterations) read the hi plane only (2 bytes / element), the pass that forms
     # the factors both planes (4); + forming the planes: read W_tuned and W_base (f32), write four 16-bit planes
     hi_only = bool(getattr(S, "HI_ONLY_ITERATIONS", False))
-    full = 1 + max(1, iters - 3) if hi_only else passes   # b = Q^T dW, and dW Qz from the 4th iteration on
+    # both planes: b = Q^T dW and the last dW Qz (a fixed count's last pass; the adaptive loop repeats it: one pass more)
+    if hi_only and n_iter is None:
+        passes += 1
+    full = 2 if hi_only else passes
     pass_bytes = ((passes - full) * 2 + full * 4) * elems
     byts = pass_bytes + 2 * elems * 4 + 4 * elems * 2
     out = {"metric": "cli_svd distillation, SD1.5 UNet -> rank-8 LoRA (224 sites, extended injection)",

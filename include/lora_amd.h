@@ -604,8 +604,9 @@ int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_
                                       int64_t *grid);
 /* masked: 0 = no site of the table has dropout_p > 0; 1 = the kernel that regenerates the dropout mask on G (sites with
  * dropout_p = 0 in such a table run unmasked) */
-/* rows_per_block (ABI 6): the block height (32 / 64) every site of the table was planned with — one per table
- * (lora_amd_factors_mfma_ragged_plan refuses a mixed one): a compile-time constant of the kernel. */
+/* rows_per_block (ABI 6): the block height (32 / 64) every site of the table was planned with — a compile-time constant of
+ * the kernel — or 0 for a class-2 table that holds sites of both heights (one launch, the workgroup enters its site's
+ * instantiation); a class-1 table has one height (lora_amd_factors_mfma_ragged_plan refuses a mixed one). */
 int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid, int32_t lds_class,
                                             int32_t rows_per_block, int32_t act_dtype, int32_t masked, void *stream);
 /* Tuning / test hook: which kernel a table of class 1 (64-row blocks) runs — 0 = the 10-pair kernel every class can take (two

@@ -296,10 +296,11 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
         pprog.run(p_z, hi)
         orth(st.tz, st.za, st.zb)                                 # qz in zb
         _C.thin_pack(st.tz, st.zb, st.pkz)
-        # the Q that is RETURNED must come from a product with dW itself: from the iteration that may be the last one on
-        # (MIN_ITER, or the caller's fixed count) `dW Qz` reads both planes — one multiplication by the exact matrix contracts
-        # the hi-plane iterations' O(2^-9) subspace error by the spectral gap (exactly low-rank deltas: to nothing)
-        pprog.run(p_y, hi and it + 1 < (n_iter if n_iter is not None else MIN_ITER))
+        # the Q that is RETURNED must come from a product with dW itself — one multiplication by the exact matrix contracts the
+        # hi-plane iterations' O(2^-9) subspace error by the spectral gap (exactly low-rank deltas: to nothing): a fixed count's
+        # LAST `dW Qz` reads both planes; the adaptive loop (whose stopping rule compares like with like: hi-plane Ritz energies)
+        # repeats its last `dW Qz` on both planes after it has stopped
+        pprog.run(p_y, hi and not (n_iter is not None and it + 1 >= n_iter))
         orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
         it += 1
         if n_iter is not None:
@@ -321,6 +322,9 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
                 break
         prev_gain = gained
         prev = st.ritz[:, 0].clone()
+    if n_iter is None and hi:
+        pprog.run(p_y, False)          # pkz still holds the last Qz
+        orth(st.ty, st.ya, st.yb)
     st.iterations = it
     global LAST_ITERATIONS
     LAST_ITERATIONS = it

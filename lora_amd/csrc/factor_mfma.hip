@@ -197,36 +197,26 @@ constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS 
 // behind a branch: the waits are counted ones and RG groups stay in flight per wave.
 //   RS2: two 32-row steps per block (R = 64) / one (R = 32) — compile-time, so that the resident pieces' (row step, group)
 //   order is static too.
+//   The block's work is a device function (fm_block) so that ONE launch can hold sites of both block heights: the kernel looks
+//   its site up and enters the instantiation of the site's height (a table of one height compiles to that one alone).
+struct FmSmem {
+  unsigned char *stage;   // [4 waves][32 rows][kFrPitch]
+  float *part;            // [4 waves][64 rows][16]
+  mu32x4 *tf;             // [2 row steps][hi, lo][64 lanes]
+  float *pmax;            // [4]
+};
+
 template <class E, bool DROP, int kFrPairs, int MINB, int RG, bool RS2>
-__global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+__device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSmem &sm) {
   using S = typename E::storage;
   constexpr bool kScaled = E::kCode == LORA_AMD_F16;   // power-of-two pre-scaling of the split operands (file header)
   constexpr int NRS = RS2 ? 2 : 1;                     // row steps per block
   constexpr int kGroupsA = kFrPairs / NRS;             // resident column groups per wave
-  __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
-  __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
-  __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
-  __shared__ int64_t s_begin[kFrSitesLds];
-  __shared__ float s_pmax[4];                                          // f16: largest |partial| of each wave's share
+  unsigned char *s_stage = sm.stage;
+  float *s_part = sm.part, *s_pmax = sm.pmax;
+  mu32x4 *s_tf = sm.tf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
-  // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
-  // memory is eight DEPENDENT trips to L2 in front of the block's first load)
-  int lo = 0, hi = n - 1;
-  if (n <= kFrSitesLds) {
-    for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
-    __syncthreads();
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (s_begin[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-  } else {
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-  }
-  const lora_amd_fm_site sd = sites[lo];
-  constexpr int R = 32 * NRS;          // == sd.rows_per_block (the launcher sorts the sites of a table by it)
+  constexpr int R = 32 * NRS;          // == sd.rows_per_block
   const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;
   const int64_t m0 = rb * R;
   const int nrows = (int)min((int64_t)R, sd.M - m0);
@@ -452,6 +442,41 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   }
 }
 
+// HEIGHTS: 1 = every site of the table has 64-row blocks, 0 = 32-row blocks, 2 = both (dispatch per workgroup)
+template <class E, bool DROP, int kFrPairs, int MINB, int RG64, int RG32, int HEIGHTS>
+__global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
+  __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
+  __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
+  __shared__ int64_t s_begin[kFrSitesLds];
+  __shared__ float s_pmax[4];                                          // f16: largest |partial| of each wave's share
+  const int tid = threadIdx.x;
+  // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
+  // memory is eight DEPENDENT trips to L2 in front of the block's first load)
+  int lo = 0, hi = n - 1;
+  if (n <= kFrSitesLds) {
+    for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
+    __syncthreads();
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_begin[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+  }
+  const lora_amd_fm_site sd = sites[lo];
+  const FmSmem sm{s_stage, s_part, s_tf, s_pmax};
+  if constexpr (HEIGHTS == 1) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm);
+  else if constexpr (HEIGHTS == 0) fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm);
+  else {
+    if (sd.rows_per_block == 64) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm);   // block-uniform
+    else fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- host side
 
 struct FmGeom { int R, resident_is_x, cw, nchunk, pitch_a, pitch_b, lds; };
@@ -586,9 +611,9 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
   for (int i = 0; i < n; ++i) {
     lora_amd_fm_site &q = sites[i];
     FmGeom g;
-    LORA_AMD_CHECK(q.rows_per_block == sites[0].rows_per_block, LORA_AMD_EINVAL,
-                   "factors_mfma_ragged_plan: site %d: %d rows per block, site 0: %d (one block height per table: it is a "
-                   "compile-time constant of the kernel)", i, q.rows_per_block, sites[0].rows_per_block);
+    LORA_AMD_CHECK(lds_class == 2 || q.rows_per_block == sites[0].rows_per_block, LORA_AMD_EINVAL,
+                   "factors_mfma_ragged_plan: site %d: %d rows per block, site 0: %d (a class-1 table has one block height)", i,
+                   q.rows_per_block, sites[0].rows_per_block);
     LORA_AMD_CHECK(q.r >= 1 && q.r <= 16 && (q.r <= 4 ? 4 : q.r <= 8 ? 8 : 16) == rt0, LORA_AMD_ERANK,
                    "factors_mfma_ragged_plan: site %d: rank %d (one rank tile per table)", i, q.r);
     LORA_AMD_CHECK(q.g && q.x && q.pk_up && q.pk_down && q.up_part && q.down_part, LORA_AMD_EINVAL,
@@ -616,8 +641,11 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
                                                        int32_t masked, void *stream) {
   LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
                  LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
-  LORA_AMD_CHECK(rows_per_block == 32 || rows_per_block == 64, LORA_AMD_EINVAL,
-                 "linear_bwd_factors_mfma_ragged: rows_per_block = the 32 or 64 every site of the table was planned with");
+  LORA_AMD_CHECK(rows_per_block == 32 || rows_per_block == 64 || rows_per_block == 0, LORA_AMD_EINVAL,
+                 "linear_bwd_factors_mfma_ragged: rows_per_block = the 32 or 64 every site of the table was planned with, or 0 "
+                 "for a table that holds both (class 2 only)");
+  LORA_AMD_CHECK(rows_per_block != 0 || lds_class == 2, LORA_AMD_EINVAL,
+                 "linear_bwd_factors_mfma_ragged: a class-1 table has one block height");
   LORA_AMD_CHECK(act_dtype == LORA_AMD_F16 || act_dtype == LORA_AMD_BF16, LORA_AMD_EINVAL,
                  "linear_bwd_factors_mfma_ragged: f16 / bf16 activations only");
   hipStream_t st = (hipStream_t)stream;
@@ -625,16 +653,18 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   // register class 1 with 64-row blocks (<= 3 resident column groups per wave): the 6-pair kernels, chosen by
   // lora_amd_factors_mfma_set_tuning; everything else: the 10-pair kernel of its block height
   const int narrow = (lds_class == 1 && rows_per_block == 64) ? g_fm_narrow : 0;
-#define FML(E, D, P, B, G, S2) hipLaunchKernelGGL((factors_reg_kernel<E, D, P, B, G, S2>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n)
-#define FM2(E, D)                                                          \
-  do {                                                                     \
-    if (narrow == 1) FML(E, D, kFrPairsNarrow, 3, 1, true);                \
-    else if (narrow == 2) FML(E, D, kFrPairsNarrow, 3, 2, true);           \
-    else if (narrow == 3) FML(E, D, kFrPairsNarrow, 2, 2, true);           \
-    else if (narrow == 4) FML(E, D, kFrPairsNarrow, 2, 3, true);           \
-    else if (narrow == 5) FML(E, D, kFrPairsNarrow, 2, 4, true);           \
-    else if (rows_per_block == 64) FML(E, D, kFrPairsWide, 2, 2, true);    \
-    else FML(E, D, kFrPairsWide, 2, 4, false);                             \
+  if (lds_class == 1 && rows_per_block != 64 && rows_per_block != 32) rows_per_block = 64;
+#define FML(E, D, P, B, G64, G32, H) hipLaunchKernelGGL((factors_reg_kernel<E, D, P, B, G64, G32, H>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n)
+#define FM2(E, D)                                                            \
+  do {                                                                       \
+    if (narrow == 1) FML(E, D, kFrPairsNarrow, 3, 1, 1, 1);                  \
+    else if (narrow == 2) FML(E, D, kFrPairsNarrow, 3, 2, 2, 1);             \
+    else if (narrow == 3) FML(E, D, kFrPairsNarrow, 2, 2, 2, 1);             \
+    else if (narrow == 4) FML(E, D, kFrPairsNarrow, 2, 3, 3, 1);             \
+    else if (narrow == 5) FML(E, D, kFrPairsNarrow, 2, 4, 4, 1);             \
+    else if (rows_per_block == 64) FML(E, D, kFrPairsWide, 2, 2, 4, 1);      \
+    else if (rows_per_block == 32) FML(E, D, kFrPairsWide, 2, 2, 4, 0);      \
+    else FML(E, D, kFrPairsWide, 2, 2, 4, 2);                                \
   } while (0)
 #define FM(E) do { if (drop) FM2(E, true); else FM2(E, false); } while (0)
   if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);

@@ -452,8 +452,10 @@ RANK16_MFMA = True
 # the one-launch factor pass as one launch per REGISTER class (class 1 = the M = 16384 sites: three workgroups per CU,
 # csrc/factor_mfma.hip) instead of one launch of the two-per-CU kernel over every site (rounds 4-5)
 FM_TWO_CLASSES = True
-# the factor-pass launches of one flush on forked streams (their tails overlap) instead of back to back on the launch stream
-CONCURRENT_FACTOR_LAUNCHES = True
+# the factor-pass launches of one flush on forked streams (their tails could overlap) instead of back to back on the launch
+# stream.  OFF: measured, same box, the captured step with the fork / join edges runs 31.3 steps/s against 35.6 without
+# (profiles/r06_concurrent_factor_launches_ab.txt: a multi-stream hipGraph costs the whole step 3.9 ms, far more than three tails)
+CONCURRENT_FACTOR_LAUNCHES = False
 # the channels-last 3x3 site as ONE forward launch (csrc/conv_nhwc.hip, round 6: batched pack once per optimiser step + the
 # fused down-conv / fold / up-projection / dropout / add kernel) and its G pass with the Gt fold inside the launch; False =
 # the launch sequence of rounds 3-5 (pack + down [+ sum_parts] + rank_update; bwd_g + sum_parts): the A/B and the parity twin
@@ -781,8 +783,10 @@ class MergedWeights:
             r, kind, plan = st[2].shape[0], st[9], st[10]
             rt = 4 if r <= 4 else 8 if r <= 8 else 16
             masked = kind == "mfma" and st[11] is not None and st[11][0] > 0.0
-            # (register class, block height, masked): the block height is a compile-time constant of the kernel
-            cls = (2 if one_class else int(plan.lds_class), masked, int(plan.rows_per_block)) if kind == "mfma" else 0
+            # (register class, masked, block height): class 1 = one height per table (64), class 2 = one launch for both
+            # heights (0: the workgroup enters its site's instantiation)
+            c_ = 2 if one_class else int(plan.lds_class)
+            cls = (c_, masked, int(plan.rows_per_block) if c_ == 1 else 0) if kind == "mfma" else 0
             groups.setdefault((kind, st[0].dtype, rt, cls), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
         packed = {}  # activation dtype -> packs of this flush's sites, each adapter once

@@ -184,22 +184,33 @@ def test_factor_pass_selection_modes_agree(monkeypatch):
     lat, ehs = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16(), torch.randn(2, 77, 64, generator=g).to(DEV).bfloat16()
     noise, ts = torch.randn(2, 4, 32, 32, generator=g).to(DEV).bfloat16(), torch.randint(0, 1000, (2,), generator=g).to(DEV)
     sched = DDPMScheduler()
-    for _ in range(2):   # the attention kernels of a shape are timed and chosen on its first uses: settle before comparing steps
-        T.forward_backward(unet, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
-        st.reduce_pending()
-    grads, kinds = {}, {}
-    for mode in ("masked", "all", "none"):
-        monkeypatch.setattr(_C, "FACTORS_MFMA_MODE", mode)
-        monkeypatch.setattr(_C, "FACTORS_MFMA", mode != "none")
+    def one_step():
         st.zero_grad()
         ops.PATH_LOG = []
         try:
-            T.forward_backward(unet, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
+            loss = T.forward_backward(unet, sched, lat, ehs, T.StepConfig(), noise=noise, timesteps=ts, merged=merged)
             st.reduce_pending()
         finally:
             log_, ops.PATH_LOG = ops.PATH_LOG, None
-        grads[mode] = st.flat_g.clone()
-        kinds[mode] = {path for ph, path, *_ in log_ if ph == "bwd"}
+        return float(loss), st.flat_g.clone(), {path for ph, path, *_ in log_ if ph == "bwd"}
+
+    # The host model's FORWARD is two-valued from call to call (measured, scripts/r06_calls/c14_probe.py: the loss alternates
+    # between 1.0787293 and 1.0787890 whatever the factor-pass mode — the library GEMMs' kernel picks follow the addresses the
+    # caching allocator hands out): the three modes are compared on steps whose LOSS is bit-equal to the first mode's.
+    for _ in range(2):
+        one_step()
+    grads, kinds, target = {}, {}, None
+    for mode in ("masked", "all", "none"):
+        monkeypatch.setattr(_C, "FACTORS_MFMA_MODE", mode)
+        monkeypatch.setattr(_C, "FACTORS_MFMA", mode != "none")
+        for _ in range(12):
+            loss, g_, k_ = one_step()
+            if target is None or loss == target:
+                break
+        else:
+            pytest.skip("the forward did not reproduce the first mode's loss in 12 tries")
+        target = loss
+        grads[mode], kinds[mode] = g_, k_
     assert any("deferred_mfma" in k for k in kinds["all"]) and not any("deferred_mfma" in k for k in kinds["masked"])
     assert any("deferred_self" in k for k in kinds["masked"]) and any("deferred_self" in k for k in kinds["none"])
     ref = grads["masked"]
