@@ -785,8 +785,10 @@ class MergedWeights:
             masked = kind == "mfma" and st[11] is not None and st[11][0] > 0.0
             # (register class, masked, block height): class 1 = one height per table (64), class 2 = one launch for both
             # heights (0: the workgroup enters its site's instantiation)
-            c_ = 2 if one_class else int(plan.lds_class)
-            cls = (c_, masked, int(plan.rows_per_block) if c_ == 1 else 0) if kind == "mfma" else 0
+            cls = 0
+            if kind == "mfma":
+                c_ = 2 if one_class else int(plan.lds_class)
+                cls = (c_, masked, int(plan.rows_per_block) if c_ == 1 else 0)
             groups.setdefault((kind, st[0].dtype, rt, cls), []).append(st)
         capturing = torch.cuda.is_current_stream_capturing()
         packed = {}  # activation dtype -> packs of this flush's sites, each adapter once
