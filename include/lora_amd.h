@@ -591,7 +591,10 @@ typedef struct lora_amd_fm_site {
   int32_t rows_per_block;         /* caller: lora_amd_factors_mfma_plan's rows_per_block and ... */
   int32_t blocks_per_wg;          /* ... blocks_per_wg for this site */
   /* filled by lora_amd_factors_mfma_ragged_plan */
-  int32_t resident_is_x, cw, nchunk, pitch_a, pitch_b, lds_bytes;
+  int32_t resident_is_x, cw, nchunk;
+  int32_t x_head_magic, g_head_magic; /* ceil(2^32 / (head_dim / 8)) as a bit pattern, 0 = dense rows (the kernel's division-free
+                                       * column -> padded-column map) */
+  int32_t lds_bytes;
   int64_t block_begin;
   /* nn.Dropout(p) on the branch (lora.py:45, 57): p > 0 makes G enter as mask (.) G with the forward's mask regenerated from
    * (seed, offset + *offset_dev) — the caller folds 1 / (1 - p) into `scale`; T = X down^T is unaffected */

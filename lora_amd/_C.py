@@ -108,8 +108,8 @@ class FmSite(C.Structure):
         ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("scale", C.c_float),
         ("g_head_dim", C.c_int32), ("g_head_pad", C.c_int32), ("x_head_dim", C.c_int32), ("x_head_pad", C.c_int32),
         ("rows_per_block", C.c_int32), ("blocks_per_wg", C.c_int32),
-        ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("pitch_a", C.c_int32),
-        ("pitch_b", C.c_int32), ("lds_bytes", C.c_int32),
+        ("resident_is_x", C.c_int32), ("cw", C.c_int32), ("nchunk", C.c_int32), ("x_head_magic", C.c_int32),
+        ("g_head_magic", C.c_int32), ("lds_bytes", C.c_int32),
         ("block_begin", C.c_int64),
         ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
         ("offset_dev", C.c_void_p),

@@ -60,11 +60,8 @@ __host__ __device__ inline int fm_tpitch(int R) { return R * 2 + 16; }
 // chunk index of a head-padded row, branch-free (a branch around the address of a load costs its own s_waitcnt): q = c / hc by
 // a 32-bit magic multiply (exact for c < 2^16), hc = 0 (dense) has magic 0 and gives c back
 struct FmHeads { uint32_t magic; int hc, hp; };
-__device__ __forceinline__ FmHeads fm_heads(int hc, int hp) {
-  FmHeads h;
-  h.magic = hc ? (uint32_t)((0x100000000ull + hc - 1) / (uint32_t)hc) : 0u;
-  h.hc = hc; h.hp = hp;
-  return h;
+__host__ __device__ inline uint32_t fm_head_magic(int hc) {   // ceil(2^32 / hc); the plan computes it (a 64-bit division)
+  return hc ? (uint32_t)((0x100000000ull + hc - 1) / (uint32_t)hc) : 0u;
 }
 __device__ __forceinline__ int fm_hchunk(int c, const FmHeads &h) {
   const int q = (int)__umulhi((uint32_t)c, h.magic);
@@ -186,6 +183,18 @@ constexpr int kFrPairsWide = 10, kFrPairsNarrow = 6;
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
 constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
 
+// -DFM_TRACE (scripts/fm_trace/: a second library, never the product's): every wave leaves 100 MHz wall-clock stamps of its
+// block's stages in a buffer — [block][wave][16]: 0 kernel entry, 1 block prefix in LDS, 2 site index known, 3 site record in
+// SGPRs and row offsets computed, 4 A's loads issued, 5 every first load issued, 6 A multiplied (its data landed), 7 T ready (two
+// barriers), 8 B streamed, 9 Gt ready (two barriers), 10 block done
+#ifdef FM_TRACE
+__device__ unsigned long long *g_fm_trace = nullptr;
+__device__ long long g_fm_trace_cap = 0;
+#define FM_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); fm_ts[k] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FM_STAMP(k) do { } while (0)
+#endif
+
 // Round 6: NO register copy of a value a load is still writing.  The round-4/5 loop rotated its ring by assignment (slot k <-
 // slot k + 1, `fh = nfh` for the prefetched factor fragments): every such v_mov of an in-flight destination made hipcc put
 // `s_waitcnt vmcnt(0)` in front of it — the youngest load — so the "ring" drained completely once per unit and once more per
@@ -207,8 +216,13 @@ struct FmSmem {
 };
 
 template <class E, bool DROP, int kFrPairs, int MINB, int RG, bool RS2>
-__device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSmem &sm) {
+__device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSmem &sm, int64_t blk, unsigned long long t_entry = 0,
+                                         unsigned long long t_prefix = 0) {
   using S = typename E::storage;
+#ifdef FM_TRACE
+  unsigned long long fm_ts[16] = {t_entry, t_prefix, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  FM_STAMP(2);
+#endif
   constexpr bool kScaled = E::kCode == LORA_AMD_F16;   // power-of-two pre-scaling of the split operands (file header)
   constexpr int NRS = RS2 ? 2 : 1;                     // row steps per block
   constexpr int kGroupsA = kFrPairs / NRS;             // resident column groups per wave
@@ -217,7 +231,7 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   mu32x4 *s_tf = sm.tf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
   constexpr int R = 32 * NRS;          // == sd.rows_per_block
-  const int64_t rb = (int64_t)blockIdx.x - sd.block_begin;
+  const int64_t rb = blk - sd.block_begin;
   const int64_t m0 = rb * R;
   const int nrows = (int)min((int64_t)R, sd.M - m0);
   const bool ax = sd.resident_is_x != 0;
@@ -225,8 +239,10 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   const S *da = reinterpret_cast<const S *>(ax ? sd.x : sd.g), *db = reinterpret_cast<const S *>(ax ? sd.g : sd.x);
   const int64_t lda = ax ? sd.ldx : sd.ldg, ldb = ax ? sd.ldg : sd.ldx;
   const int Ca = ax ? sd.K : sd.N, Cb = ax ? sd.N : sd.K;
-  const FmHeads hda = fm_heads((ax ? sd.x_head_dim : sd.g_head_dim) >> 3, (ax ? sd.x_head_pad : sd.g_head_pad) >> 3);
-  const FmHeads hdb = fm_heads((ax ? sd.g_head_dim : sd.x_head_dim) >> 3, (ax ? sd.g_head_pad : sd.x_head_pad) >> 3);
+  const FmHeads hda{(uint32_t)(ax ? sd.x_head_magic : sd.g_head_magic), (ax ? sd.x_head_dim : sd.g_head_dim) >> 3,
+                    (ax ? sd.x_head_pad : sd.g_head_pad) >> 3};
+  const FmHeads hdb{(uint32_t)(ax ? sd.g_head_magic : sd.x_head_magic), (ax ? sd.g_head_dim : sd.x_head_dim) >> 3,
+                    (ax ? sd.g_head_pad : sd.x_head_pad) >> 3};
   const S *pka = reinterpret_cast<const S *>(ax ? sd.pk_down : sd.pk_up), *pkb = reinterpret_cast<const S *>(ax ? sd.pk_up : sd.pk_down);
   const int64_t splita = (int64_t)(Ca >> 3) * 128, splitb = (int64_t)(Cb >> 3) * 128;
   float finv_a = 1.f, finv_b = 1.f;   // f16: 1 / (the power of two the pack multiplied the factor by)
@@ -234,8 +250,6 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
     finv_a = gl(reinterpret_cast<const float *>(pka + 2 * splita))[1];
     finv_b = gl(reinterpret_cast<const float *>(pkb + 2 * splitb))[1];
   }
-  float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
-  float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
   const int nga = Ca >> 5, ngb = Cb >> 5;
   const int nga_w = wave < nga ? (nga - wave + 3) >> 2 : 0, ngb_w = wave < ngb ? (ngb - wave + 3) >> 2 : 0;   // this wave's groups
   const bool drop = DROP && sd.dropout_p > 0.f;
@@ -244,20 +258,46 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   const uint32_t thr = (uint32_t)(sd.dropout_p * 65536.0f + 0.5f);
   const int n8 = sd.N >> 3;
 
-  // every load is issued whatever the indices: out-of-range ones read element (row 0, group 0) and are zeroed by finish()
-  auto load_piece = [&](const S *d, int64_t ld, const FmHeads &h, int cg, int row, bool ok) -> mu32x4 {
-    const int ph = fm_hchunk(ok ? cg * 4 + q : 0, h);
-    // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
-    return *gl(reinterpret_cast<const mu32x4 *>(d + (m0 + (ok ? row : 0)) * ld + (int64_t)ph * 8));
+  // Addresses (round 6, after the stage stamps of scripts/fm_trace showed 4-9 us of a 15-23 us block going by BEFORE its first
+  // load left: ~650 instructions of per-piece 64-bit multiplies, a 64-bit division for the head layout and the site lookup):
+  // everything wave-uniform — the block's first row, the factor packs, the slabs — is a scalar base; a lane keeps ONE 32-bit byte
+  // offset per (row step, row half) and operand (row clamped into the block: every load is issued whatever the indices, the
+  // values of rows >= nrows and of dead groups are zeroed by finish()) and adds a group's column offset to it: one VALU add per
+  // piece, and the load takes the base + 32-bit offset form.  A row block spans < 2^31 bytes (the plan checks ld < 2^23).
+  const unsigned char *basea = reinterpret_cast<const unsigned char *>(da + m0 * lda);
+  const unsigned char *baseb = reinterpret_cast<const unsigned char *>(db + m0 * ldb);
+  const uint32_t ldab = (uint32_t)lda * 2u, ldbb = (uint32_t)ldb * 2u;
+  uint32_t rowa[NRS][2], rowb[NRS][2];
+#pragma unroll
+  for (int rs = 0; rs < NRS; ++rs)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t rc = (uint32_t)min(rs * 32 + h * 16 + jj, nrows - 1);
+      rowa[rs][h] = __umul24(rc, ldab);
+      rowb[rs][h] = __umul24(rc, ldbb);
+    }
+  FM_STAMP(3);
+  auto coff = [&](const FmHeads &h, int cg) -> uint32_t { return (uint32_t)fm_hchunk(cg * 4 + q, h) * 16u; };
+  // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
+  auto load_piece = [&](const unsigned char *base, uint32_t ro, uint32_t co) -> mu32x4 {
+    return *gl(reinterpret_cast<const mu32x4 *>(base + (ro + co)));
   };
   auto finish = [&](mu32x4 v, int cg, int row, bool live, bool masked) -> mu32x4 {
     if (!live || row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
     if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + q), thr);
     return v;
   };
-  auto frag = [&](const S *pk, int64_t split, int cg, bool lo_part) -> mu32x4 {
-    return *gl(reinterpret_cast<const mu32x4 *>(pk + (lo_part ? split : 0) + (int64_t)cg * 512 + lane * 8));
+  const unsigned char *pkbh = reinterpret_cast<const unsigned char *>(pkb), *pkbl = reinterpret_cast<const unsigned char *>(pkb + splitb);
+  const unsigned char *pkah = reinterpret_cast<const unsigned char *>(pka), *pkal = reinterpret_cast<const unsigned char *>(pka + splita);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto frag = [&](const unsigned char *pk, int cg) -> mu32x4 {   // a k-step's fragment: 1 KB, lane l its 16 bytes at 16 l
+    return *gl(reinterpret_cast<const mu32x4 *>(pk + ((uint32_t)cg * 1024u + lane16)));
   };
+  // slabs: [RT][C] floats per block and operand; lane (j = jj, columns 4 q ..) of a group's two 16-column tiles
+  float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
+  float *outb = (ax ? sd.up_part : sd.down_part) + rb * RT * (int64_t)Cb;
+  const uint32_t jrow = jj < RT ? (uint32_t)jj : 0u;
+  const uint32_t slaba = (jrow * (uint32_t)Ca + 4u * q) * 4u, slabb = (jrow * (uint32_t)Cb + 4u * q) * 4u;
   unsigned char *stage = s_stage + wave * 32 * kFrPitch;
   // kTfLds (the three-per-CU kernel): the T fragments of a row step are read from LDS at every use instead of living in 16
   // registers for the whole stream (two more ds_read_b128 per unit buy the third workgroup)
@@ -283,12 +323,12 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
     asm volatile("" ::: "memory");
   };
   float tinv = 1.f;   // f16: 1 / (the power of two the T fragments in use were multiplied by)
-  auto store_group = [&](float *out, int C, int cg, bool live, mf32x4 (&acc)[2]) {
-    float *o = out + (int64_t)(jj < RT ? jj : 0) * C + (live ? cg : 0) * 32 + 4 * q;
+  auto store_group = [&](float *out, uint32_t slab, int cg, bool live, mf32x4 (&acc)[2]) {
+    unsigned char *o = reinterpret_cast<unsigned char *>(out) + (slab + (uint32_t)(live ? cg : 0) * 128u);
     if (live && jj < RT) {
       if constexpr (kScaled) { acc[0] *= tinv; acc[1] *= tinv; }
       *gl(reinterpret_cast<mf32x4 *>(o)) = acc[0];
-      *gl(reinterpret_cast<mf32x4 *>(o + 16)) = acc[1];
+      *gl(reinterpret_cast<mf32x4 *>(o + 64)) = acc[1];
     }
     acc[0] = acc[1] = mf32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -335,24 +375,24 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   mu32x4 pa[kGroupsA][NRS][2];
 #pragma unroll
   for (int gi = 0; gi < kGroupsA; ++gi) {
-    const bool live = gi < nga_w;
-    const int cg = live ? wave + 4 * gi : 0;
+    const uint32_t co = coff(hda, gi < nga_w ? wave + 4 * gi : 0);
 #pragma unroll
     for (int rs = 0; rs < NRS; ++rs)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) pa[gi][rs][h] = load_piece(da, lda, hda, cg, rs * 32 + h * 16 + jj, live && rs * 32 + h * 16 + jj < nrows);
+      for (int h = 0; h < 2; ++h) pa[gi][rs][h] = load_piece(basea, rowa[rs][h], co);
   }
+  FM_STAMP(4);
   // ---- 3 (issued here): the first RG column groups of B and their factor fragments
   mu32x4 pb[RG][NRS][2], fb[RG][2];
   auto load_group = [&](int gi, mu32x4 (&p)[NRS][2], mu32x4 (&f)[2]) {
-    const bool live = gi < ngb_w;
-    const int cg = live ? wave + 4 * gi : 0;
-    f[0] = frag(pkb, splitb, cg, false);
-    f[1] = frag(pkb, splitb, cg, true);
+    const int cg = gi < ngb_w ? wave + 4 * gi : 0;
+    f[0] = frag(pkbh, cg);
+    f[1] = frag(pkbl, cg);
+    const uint32_t co = coff(hdb, cg);
 #pragma unroll
     for (int rs = 0; rs < NRS; ++rs)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) p[rs][h] = load_piece(db, ldb, hdb, cg, rs * 32 + h * 16 + jj, live && rs * 32 + h * 16 + jj < nrows);
+      for (int h = 0; h < 2; ++h) p[rs][h] = load_piece(baseb, rowb[rs][h], co);
   };
   // ---- 2. TA = A fa^T: the fragments of A's groups in a two-deep buffer indexed by the (static) parity of the group
   mf32x4 d1[2 * NRS];
@@ -360,18 +400,22 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   for (int x = 0; x < 2 * NRS; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
   {
     mu32x4 fa[2][2];
-    fa[0][0] = frag(pka, splita, nga_w > 0 ? wave : 0, false);
-    fa[0][1] = frag(pka, splita, nga_w > 0 ? wave : 0, true);
+    fa[0][0] = frag(pkah, nga_w > 0 ? wave : 0);
+    fa[0][1] = frag(pkal, nga_w > 0 ? wave : 0);
 #pragma unroll
     for (int s = 0; s < RG; ++s) load_group(s, pb[s], fb[s]);
+    // every load above leaves before the first wait: with cheap addresses hipcc otherwise sinks half of them behind the
+    // first MFMAs (shorter live ranges), i.e. behind an s_waitcnt for the block's first piece
+    __builtin_amdgcn_sched_barrier(0);
+    FM_STAMP(5);
 #pragma unroll
     for (int gi = 0; gi < kGroupsA; ++gi) {
       const bool live = gi < nga_w;
       const int cg = wave + 4 * gi;
       if (gi + 1 < kGroupsA) {
         const int cn = gi + 1 < nga_w ? cg + 4 : 0;
-        fa[(gi + 1) & 1][0] = frag(pka, splita, cn, false);
-        fa[(gi + 1) & 1][1] = frag(pka, splita, cn, true);
+        fa[(gi + 1) & 1][0] = frag(pkah, cn);
+        fa[(gi + 1) & 1][1] = frag(pkal, cn);
       }
 #pragma unroll
       for (int rs = 0; rs < NRS; ++rs)
@@ -383,10 +427,12 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
         }
     }
   }
+  FM_STAMP(6);
   store_parts(d1);
   __syncthreads();
   build_tf(sd.scale * finv_a);
   __syncthreads();
+  FM_STAMP(7);
   mu32x4 tfh[2], tfl[2];
   tfh[0] = tfl[0] = tfh[1] = tfl[1] = mu32x4{0u, 0u, 0u, 0u};
   if constexpr (!kTfLds) {
@@ -396,7 +442,9 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
 #pragma unroll
   for (int x = 0; x < 2 * NRS; ++x) d1[x] = mf32x4{0.f, 0.f, 0.f, 0.f};
   mf32x4 acc[2] = {mf32x4{0.f, 0.f, 0.f, 0.f}, mf32x4{0.f, 0.f, 0.f, 0.f}};
-  // ---- 3. B: slot s holds group g0 + s; consumed, then refilled in place with group g0 + s + RG
+  // ---- 3. B: slot s holds group g0 + s; consumed, then refilled in place with group g0 + s + RG.  Branch-free on purpose: a
+  // wave-uniform `if (live)` around the work of a dead slot (call c20's build) brought the register copies of in-flight slots
+  // and their s_waitcnt vmcnt(0) back (the compiler rotates the slots through the join)
 #pragma unroll 1
   for (int g0 = 0; g0 < ngb_w; g0 += RG) {
 #pragma unroll
@@ -420,14 +468,16 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
       load_group(gi + RG, pb[s], fb[s]);   // the slot's registers are free: its next group goes out before the LDS work
 #pragma unroll
       for (int rs = 0; rs < NRS; ++rs) phase2(qv[rs][0], qv[rs][1], tfh[rs], tfl[rs], rs, acc);
-      store_group(outb, Cb, cg, live, acc);
+      store_group(outb, slabb, cg, live, acc);
     }
   }
   // ---- 4. TB -> fragments
+  FM_STAMP(8);
   store_parts(d1);
   __syncthreads();
   build_tf(sd.scale * finv_b);
   __syncthreads();
+  FM_STAMP(9);
   if constexpr (!kTfLds) {
     tfh[0] = s_tf[0 * 64 + lane]; tfl[0] = s_tf[1 * 64 + lane];
     if constexpr (RS2) { tfh[1] = s_tf[2 * 64 + lane]; tfl[1] = s_tf[3 * 64 + lane]; }
@@ -438,8 +488,17 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
     const bool live = gi < nga_w;
 #pragma unroll
     for (int rs = 0; rs < NRS; ++rs) phase2(pa[gi][rs][0], pa[gi][rs][1], tfh[rs], tfl[rs], rs, acc);
-    store_group(outa, Ca, wave + 4 * gi, live, acc);
+    store_group(outa, slaba, wave + 4 * gi, live, acc);
   }
+#ifdef FM_TRACE
+  FM_STAMP(10);
+  if (g_fm_trace && lane < 16 && (blk * 4 + wave + 1) * 16 <= g_fm_trace_cap) {
+    unsigned long long v = fm_ts[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v = lane == k ? fm_ts[k] : v;
+    g_fm_trace[(blk * 4 + wave) * 16 + lane] = v;
+  }
+#endif
 }
 
 // HEIGHTS: 1 = every site of the table has 64-row blocks, 0 = 32-row blocks, 2 = both (dispatch per workgroup)
@@ -451,12 +510,23 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   __shared__ int64_t s_begin[kFrSitesLds];
   __shared__ float s_pmax[4];                                          // f16: largest |partial| of each wave's share
   const int tid = threadIdx.x;
+#ifdef FM_TRACE
+  const unsigned long long t_entry = wall_clock64();
+#else
+  const unsigned long long t_entry = 0;
+#endif
+  unsigned long long t_prefix = t_entry;
   // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
-  // memory is eight DEPENDENT trips to L2 in front of the block's first load)
+  // memory is eight DEPENDENT trips to L2 in front of the block's first load).  A workgroup per row block: walking runs of
+  // 2 / 4 / 8 consecutive blocks per workgroup (launch and lookup paid once per run) measured 2-60 % SLOWER
+  // (profiles/r06_kbench_fm_span.log).
   int lo = 0, hi = n - 1;
   if (n <= kFrSitesLds) {
     for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
     __syncthreads();
+#ifdef FM_TRACE
+    t_prefix = wall_clock64();
+#endif
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
       if (s_begin[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
@@ -467,13 +537,15 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
       if (sites[mid].block_begin <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
     }
   }
+  lo = __builtin_amdgcn_readfirstlane(lo);   // wave-uniform: the site record arrives by scalar loads and lives in SGPRs
   const lora_amd_fm_site sd = sites[lo];
   const FmSmem sm{s_stage, s_part, s_tf, s_pmax};
-  if constexpr (HEIGHTS == 1) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm);
-  else if constexpr (HEIGHTS == 0) fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm);
+  const int64_t blk = blockIdx.x;
+  if constexpr (HEIGHTS == 1) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm, blk, t_entry, t_prefix);
+  else if constexpr (HEIGHTS == 0) fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm, blk, t_entry, t_prefix);
   else {
-    if (sd.rows_per_block == 64) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm);   // block-uniform
-    else fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm);
+    if (sd.rows_per_block == 64) fm_block<E, DROP, kFrPairs, MINB, RG64, true>(sd, sm, blk, t_entry, t_prefix);   // block-uniform
+    else fm_block<E, DROP, kFrPairs, MINB, RG32, false>(sd, sm, blk, t_entry, t_prefix);
   }
 }
 
@@ -529,6 +601,16 @@ static int g_fm_narrow = 1;   // 0: class-1 tables run the wide kernel too (A/B 
 }  // namespace lora_amd
 
 using namespace lora_amd;
+
+#ifdef FM_TRACE
+extern "C" int lora_amd_fm_trace_set(void *buf, int64_t cap_words) {
+  unsigned long long *p = (unsigned long long *)buf;
+  long long c = cap_words;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fm_trace), &p, sizeof(p)) != hipSuccess) return LORA_AMD_EINVAL;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fm_trace_cap), &c, sizeof(c)) != hipSuccess) return LORA_AMD_EINVAL;
+  return LORA_AMD_OK;
+}
+#endif
 
 // Tuning / test hook: tables of register class 1 (64-row blocks) run 0 = the 10-pair kernel (two workgroups per CU, two column
 // groups in flight per wave: rounds 4-5's geometry), 1 / 2 = the 6-pair kernel at three workgroups per CU with 1 / 2 groups in
@@ -624,7 +706,12 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
                        heads_ok(q.g_head_dim, q.g_head_pad, q.N, q.ldg) && heads_ok(q.x_head_dim, q.x_head_pad, q.K, q.ldx),
                    LORA_AMD_EINVAL, "factors_mfma_ragged_plan: site %d: shape / alignment / head layout / LDS class not supported", i);
     q.rows_per_block = g.R; q.resident_is_x = g.resident_is_x; q.cw = g.cw; q.nchunk = g.nchunk;
-    q.pitch_a = g.pitch_a; q.pitch_b = g.pitch_b; q.lds_bytes = g.lds;
+    q.lds_bytes = g.lds;
+    LORA_AMD_CHECK(q.ldg < (1ll << 23) && q.ldx < (1ll << 23) && (q.g_head_dim == 0 || q.g_head_dim >= 16) &&
+                       (q.x_head_dim == 0 || q.x_head_dim >= 16),
+                   LORA_AMD_EINVAL, "factors_mfma_ragged_plan: site %d: row pitch >= 2^23 elements or head_dim 8", i);
+    q.g_head_magic = (int32_t)fm_head_magic(q.g_head_dim >> 3);
+    q.x_head_magic = (int32_t)fm_head_magic(q.x_head_dim >> 3);
     const int64_t nrb = (q.M + g.R - 1) / g.R;
     LORA_AMD_CHECK(q.blocks_per_wg >= 1 && q.blocks_per_wg <= kFmMaxNB, LORA_AMD_EINVAL,
                    "factors_mfma_ragged_plan: site %d: blocks_per_wg %d outside [1, %d]", i, q.blocks_per_wg, kFmMaxNB);

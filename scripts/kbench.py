@@ -9,6 +9,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lora_amd import _C  # noqa: E402
+
+if os.environ.get("LORA_AMD_LIB"):   # a measurement build of the same ABI (scripts/fm_trace/); kbench only
+    _C.LIB_PATH = os.path.abspath(os.environ["LORA_AMD_LIB"])
 from lora_amd.standin import sd15_lora_site_shapes  # noqa: E402
 
 DEV = "cuda:0"
@@ -434,6 +437,34 @@ def bench_fm(args):
             t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
             rec[f"class1_kernel{mode}_us"] = round(t * 1e6, 1)
         _C.factors_mfma_set_tuning(prev)
+    # class 1 by site type and the step's own class-2 table (both block heights in one launch).  (Call c16 also swept runs of
+    # 2 / 4 / 8 consecutive row blocks per workgroup with a kernel that has since been removed: profiles/r06_kbench_fm_span.log)
+    prev = _C.factors_mfma_set_tuning(-1)
+    extra = []
+    c1 = by_cls.get((1, 64), [])
+    for name, pick in (("c1_square", lambda s_: s_[0].shape[0] > 1024 and s_[0].shape[1] == s_[1].shape[1]),
+                       ("c1_geglu", lambda s_: s_[0].shape[1] == 8 * s_[1].shape[1]),
+                       ("c1_text_kv", lambda s_: s_[0].shape[0] <= 1024)):
+        ss = [s_ for s_ in c1 if pick(s_)]
+        if ss:
+            arr, grid = _C.factors_mfma_table(ss, dt, 1)
+            extra.append((name, _C.table_to_device(arr, DEV), len(ss), grid, 1, 64, sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)))
+    c2 = [s_ for (cls, rpb), ss in sorted(by_cls.items()) if cls == 2 for s_ in ss]
+    if c2:
+        arr, grid = _C.factors_mfma_table(c2, dt, 2)
+        extra.append(("c2_mixed", _C.table_to_device(arr, DEV), len(c2), grid, 2, 0, sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in c2)))
+    for tab, ns, grid, cls, rpb in tabs:
+        extra.append((f"class{cls}_rows{rpb}", tab, ns, grid, cls, rpb, 0))
+    # longest blocks first (bytes per row block, descending): the table order ops.flush_factors uses since call c20
+    cost = lambda s_: -int(s_[10].rows_per_block) * (s_[0].shape[1] + s_[1].shape[1])  # noqa: E731
+    for name, ss, cls, rpb in (("c1_longest_first", sorted(c1, key=cost), 1, 64), ("c2_mixed_longest_first", sorted(c2, key=cost), 2, 0)):
+        if ss:
+            arr, grid = _C.factors_mfma_table(ss, dt, cls)
+            extra.append((name, _C.table_to_device(arr, DEV), len(ss), grid, cls, rpb, sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)))
+    for name, tab, ns, grid, cls, rpb, b in extra:
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
+        rec["part_" + name] = {"blocks": grid, "GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
+                               **({"frac8": round(b / 8e12 / t, 3)} if b else {})}
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
     rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)
@@ -444,6 +475,69 @@ def bench_fm(args):
         worst = max(worst, float((a[1] - b[1]).abs().max() / (a[1].abs().max() + 1e-30)))
     rec["max_rel_diff_valu_vs_matrix_core_last_run"] = worst   # the slabs hold the register form's result (it ran last)
     print(json.dumps(rec), flush=True)
+
+
+def bench_fmtrace(args):
+    """Where a block of the factor pass spends its life: the pass from scripts/fm_trace/liblora_amd_trace.so (the same source
+    under -DFM_TRACE), every wave's 100 MHz wall-clock stamps averaged per stage, per site type.  LORA_AMD_LIB must point at
+    that library BEFORE lora_amd._C loads (kbench does it below when --what fmtrace)."""
+    import ctypes as C
+
+    import numpy as np
+    lib = _C.require()
+    lib.lora_amd_fm_trace_set.argtypes = [C.c_void_p, C.c_int64]
+    r, dt = args.rank, torch.bfloat16
+    sites = sd15_site_list()
+    groups = {"c1_square": [s_ for s_ in sites if s_[0] == 16384 and s_[1] == s_[2]],
+              "c1_geglu": [s_ for s_ in sites if s_[0] == 16384 and s_[2] == 8 * s_[1]],
+              "c2_square_640": [s_ for s_ in sites if s_[0] == 4096 and s_[1] == s_[2]],
+              "c2_geglu_640": [s_ for s_ in sites if s_[0] == 4096 and s_[2] == 8 * s_[1]],
+              "c2_1280": [s_ for s_ in sites if s_[0] <= 1024 and s_[1] == 1280]}
+    names = ["prefix_to_LDS", "search", "site_record+row_offsets", "issue_A", "issue_B0", "A_landed+phase1", "T_handoff", "B_stream",
+             "Gt_handoff", "phase2_A+stores"]
+    NS = len(names) + 1
+    for name, shp in groups.items():
+        ss, packs = [], []
+        cls = rpb = None
+        for (M, K, N) in shp:
+            pl = _C.factors_mfma_plan(M, K, N, r, dt)
+            g, x = torch.randn(M, N, device=DEV).to(dt), torch.randn(M, K, device=DEV).to(dt)
+            down, up = torch.randn(r, K, device=DEV) * 0.25, torch.randn(N, r, device=DEV) * 0.05
+            pk_down, pk_up = torch.empty(int(pl.pack_down_elems), dtype=dt, device=DEV), torch.empty(int(pl.pack_up_elems), dtype=dt, device=DEV)
+            packs.append((down, up, pk_down, pk_up))
+            ss.append((g, x, pk_down, pk_up, torch.empty(int(pl.up_part_floats), device=DEV), torch.empty(int(pl.down_part_floats), device=DEV),
+                       1.0, None, None, r, pl))
+            cls = int(pl.lds_class)
+            rpb = int(pl.rows_per_block) if rpb in (None, int(pl.rows_per_block)) else 0
+        arr, total = _C.factor_pack_table(packs)
+        _C.factor_pack(_C.table_to_device(arr, DEV), len(packs), total, dt)
+        arr, grid = _C.factors_mfma_table(ss, dt, cls)
+        tab = _C.table_to_device(arr, DEV)
+        buf = torch.zeros(grid * 4 * 16, dtype=torch.int64, device=DEV)
+        for _ in range(3):
+            _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt, False, rpb)
+        torch.cuda.synchronize()
+        lib.lora_amd_fm_trace_set(buf.data_ptr(), buf.numel())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _C.linear_bwd_factors_mfma_ragged(tab, len(ss), grid, cls, dt, False, rpb)
+        e1.record()
+        torch.cuda.synchronize()
+        lib.lora_amd_fm_trace_set(None, 0)
+        t = buf.view(grid, 4, 16).cpu().numpy().astype(np.float64)[:, :, :NS] * 0.01    # us (100 MHz)
+        d = np.diff(t, axis=2)                                                # [block][wave][stages]
+        life = t[:, :, NS - 1] - t[:, :, 0]
+        wg_life = t[:, :, NS - 1].max(axis=1) - t[:, :, 0].min(axis=1)
+        span = t[:, :, NS - 1].max() - t[:, :, 0].min()
+        byts = sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)
+        rec = {"group": name, "sites": len(ss), "blocks": grid, "class": cls, "rows": rpb, "GB": round(byts / 1e9, 4),
+               "launch_us_events": round(e0.elapsed_time(e1) * 1e3, 1), "first_to_last_stamp_us": round(float(span), 1),
+               "wave_life_us_mean": round(float(life.mean()), 2), "workgroup_life_us_mean": round(float(wg_life.mean()), 2),
+               "workgroup_life_us_p10_p50_p90": [round(float(v), 2) for v in np.percentile(wg_life, [10, 50, 90])],
+               "concurrent_workgroups_mean": round(float(wg_life.sum() / span), 1),
+               "stage_us_mean": {n_: round(float(d[:, :, i].mean()), 2) for i, n_ in enumerate(names)},
+               "stage_us_p90": {n_: round(float(np.percentile(d[:, :, i], 90)), 2) for i, n_ in enumerate(names)}}
+        print(json.dumps(rec), flush=True)
 
 
 def bench_gemm_layouts(args):
@@ -619,5 +713,7 @@ if __name__ == "__main__":
         bench_self(a)
     if "fm" in a.what.split(","):
         bench_fm(a)
+    if "fmtrace" in a.what.split(","):
+        bench_fmtrace(a)
     if "gemmlayout" in a.what:
         bench_gemm_layouts(a)
