@@ -229,7 +229,8 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   unsigned char *s_stage = sm.stage;
   float *s_part = sm.part, *s_pmax = sm.pmax;
   mu32x4 *s_tf = sm.tf;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, jj = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: group indices and their masks live in SGPRs
   constexpr int R = 32 * NRS;          // == sd.rows_per_block
   const int64_t rb = blk - sd.block_begin;
   const int64_t m0 = rb * R;

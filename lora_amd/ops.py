@@ -456,6 +456,11 @@ FM_TWO_CLASSES = True
 # stream.  OFF: measured, same box, the captured step with the fork / join edges runs 31.3 steps/s against 35.6 without
 # (profiles/r06_concurrent_factor_launches_ab.txt: a multi-stream hipGraph costs the whole step 3.9 ms, far more than three tails)
 CONCURRENT_FACTOR_LAUNCHES = False
+# the factor-pass tables ordered longest row blocks first (flush_factors) instead of in backward order; ..._CLASS1: also the
+# class-1 table.  Same box, kernel traces (profiles/r06_fm_table_order_ab.txt): class 2 278-285 -> 248-249 us, class 1
+# 319-321 -> 323 us (its blocks differ 5x, but the wide ones are a third of them and already interleaved): class 2 only
+FM_LONGEST_FIRST = True
+FM_LONGEST_FIRST_CLASS1 = False
 # the channels-last 3x3 site as ONE forward launch (csrc/conv_nhwc.hip, round 6: batched pack once per optimiser step + the
 # fused down-conv / fold / up-projection / dropout / add kernel) and its G pass with the Gt fold inside the launch; False =
 # the launch sequence of rounds 3-5 (pack + down [+ sum_parts] + rank_update; bwd_g + sum_parts): the A/B and the parity twin
@@ -465,7 +470,7 @@ CONV3_FUSED = True
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "CONV3_FUSED", "WS_DROPOUT",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "FM_LONGEST_FIRST", "FM_LONGEST_FIRST_CLASS1", "CONV3_FUSED", "WS_DROPOUT",
                "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
@@ -803,10 +808,11 @@ class MergedWeights:
         for (kind, dt, rt, cls), sites in groups.items():
             dev0 = sites[0][0].device
             if kind == "mfma":
-                # longest row blocks first: a block of the widest sites lives 5x longer than one of the square ones, and in
-                # backward order the widest come out last and run alone in the launch's tail (kbench, call c20: class 1
-                # 309 -> 296 us, class 2 287 -> 253 us).  Stable: equal blocks keep the backward order.
-                sites = sorted(sites, key=lambda st: -int(st[10].rows_per_block) * (st[0].shape[1] + st[1].shape[1]))
+                # longest row blocks first: a block of the widest sites lives 3-5x longer than one of the square ones; in backward
+                # order some of them start late and run alone in the launch's tail (FM_LONGEST_FIRST above).  Stable: equal
+                # blocks keep the backward order.
+                if FM_LONGEST_FIRST and (cls[0] != 1 or FM_LONGEST_FIRST_CLASS1):
+                    sites = sorted(sites, key=lambda st: -int(st[10].rows_per_block) * (st[0].shape[1] + st[1].shape[1]))
                 rows = []
                 for (g2, x2, down, up, up_part, down_part, scale, g_heads, x_heads, _, plan, drop) in sites:
                     pk = self._packs_of(down, up, dt, plan)

@@ -373,11 +373,18 @@ def bench_fm(args):
     shapes = list(sites)
     shared = os.environ.get("LORA_AMD_FM_SHARED", "0") == "1"   # rounds 4-5: one (G, X) per SHAPE — L2 / MALL hits flattered the pass
     sites = [(M, K, N) if shared else (M, K, N, i) for i, (M, K, N) in enumerate(sites)]
+    # as in the model: q / k / v of a self-attention block read ONE x, k / v of a cross-attention block the text states (9 sites
+    # per transformer block, sd15_site_list's order); LORA_AMD_FM_OWN_X=1 gives every site its own x
+    own_x = os.environ.get("LORA_AMD_FM_OWN_X", "0") == "1"
+    xkey = {}
+    for i, key in enumerate(sites):
+        j = i % 9
+        xkey[key] = key if (shared or own_x or j not in (1, 2, 6)) else sites[i - (j if j < 3 else 1)]
     for i, key in enumerate(sites):  # activations per site (1.97 GB; round 6) or per shape, factors per site
         M, K, N = key[:3]
         if key not in gs:
             gs[key] = torch.randn(M, N, device=DEV).to(dt)
-            xs[key] = torch.randn(M, K, device=DEV).to(dt)
+            xs[key] = xs[xkey[key]] if xkey[key] is not key else torch.randn(M, K, device=DEV).to(dt)
         downs.append(torch.randn(r, K, device=DEV) * 0.25)
         ups.append(torch.randn(N, r, device=DEV) * 0.05)
     rec = {"sites": len(sites), "activations": "per shape (shared)" if shared else "per site", "GX_GB": round(byts / 1e9, 4), "floor_us_8TBs": round(byts / 8e12 * 1e6, 1)}
