@@ -231,6 +231,14 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   mu32x4 *s_tf = sm.tf;
   const int tid = threadIdx.x, lane = tid & 63, jj = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: group indices and their masks live in SGPRs
+  // Load layout (round 6, call c25/c26): a piece (16 rows x 64 bytes) is FETCHED with four consecutive lanes on one row's 64
+  // bytes — lane l: row lr = l >> 2, 16-byte chunk lc = l & 3 — not in the MFMA operand order (row l & 15, chunk l >> 4), whose
+  // 64 lanes are 64 scattered 16-byte accesses: scripts/ld_shape_probe.hip measures what a CU's load path sustains from
+  // cache-resident data at 9.7 TB/s (chip) for the operand order — one lane per cycle through the L1's tag pipeline, 64 cycles
+  // per instruction — against 23-28 TB/s for this one and 31-34 TB/s for full 128-byte lines; the pass ran that path at 50-70 %
+  // (stage stamps: ~0.2 us to ISSUE one such load).  The registers hold a piece in the load layout; the MFMA operands come
+  // from the wave's LDS tile, which every piece crosses anyway for the transposed read of phase 2.
+  const int lr = lane >> 2, lc = lane & 3;
   constexpr int R = 32 * NRS;          // == sd.rows_per_block
   const int64_t rb = blk - sd.block_begin;
   const int64_t m0 = rb * R;
@@ -273,19 +281,19 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   for (int rs = 0; rs < NRS; ++rs)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t rc = (uint32_t)min(rs * 32 + h * 16 + jj, nrows - 1);
+      const uint32_t rc = (uint32_t)min(rs * 32 + h * 16 + lr, nrows - 1);
       rowa[rs][h] = __umul24(rc, ldab);
       rowb[rs][h] = __umul24(rc, ldbb);
     }
   FM_STAMP(3);
-  auto coff = [&](const FmHeads &h, int cg) -> uint32_t { return (uint32_t)fm_hchunk(cg * 4 + q, h) * 16u; };
+  auto coff = [&](const FmHeads &h, int cg) -> uint32_t { return (uint32_t)fm_hchunk(cg * 4 + lc, h) * 16u; };
   // plain loads: the non-temporal form measured 7 % slower in the step (profiles/r04_kbench_fm_register_form_nt.log)
   auto load_piece = [&](const unsigned char *base, uint32_t ro, uint32_t co) -> mu32x4 {
     return *gl(reinterpret_cast<const mu32x4 *>(base + (ro + co)));
   };
   auto finish = [&](mu32x4 v, int cg, int row, bool live, bool masked) -> mu32x4 {
     if (!live || row >= nrows) return mu32x4{0u, 0u, 0u, 0u};
-    if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + q), thr);
+    if (DROP && masked) v &= dropout_and8(seed, off, (uint64_t)((m0 + row) * (int64_t)n8 + cg * 4 + lc), thr);
     return v;
   };
   const unsigned char *pkbh = reinterpret_cast<const unsigned char *>(pkb), *pkbl = reinterpret_cast<const unsigned char *>(pkb + splitb);
@@ -303,11 +311,19 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   // kTfLds (the three-per-CU kernel): the T fragments of a row step are read from LDS at every use instead of living in 16
   // registers for the whole stream (two more ds_read_b128 per unit buy the third workgroup)
   constexpr bool kTfLds = MINB >= 3;
-  // out[j][cg * 32 + 16 nt + 4 q ..] += (pieces of one row step)^T T-fragment; the transposed read of the wave's tile
-  auto phase2 = [&](mu32x4 p0, mu32x4 p1, mu32x4 th, mu32x4 tl, int rs, mf32x4 (&acc)[2]) {
-    *reinterpret_cast<mu32x4 *>(stage + jj * kFrPitch + q * 16) = p0;
-    *reinterpret_cast<mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16) = p1;
+  // the wave's 32 x 32 tile: a row step's two pieces go in as they were loaded (row lr / 16 + lr, chunk lc) ...
+  auto tile_put = [&](mu32x4 p0, mu32x4 p1) {
+    *reinterpret_cast<mu32x4 *>(stage + lr * kFrPitch + lc * 16) = p0;
+    *reinterpret_cast<mu32x4 *>(stage + (16 + lr) * kFrPitch + lc * 16) = p1;
     asm volatile("" ::: "memory");
+  };
+  // ... come back as the A operands of phase 1 (row jj / 16 + jj, k chunk q: conflict-free at the 96-byte pitch) ...
+  auto tile_rows = [&](mu32x4 &f0, mu32x4 &f1) {
+    f0 = *reinterpret_cast<const mu32x4 *>(stage + jj * kFrPitch + q * 16);
+    f1 = *reinterpret_cast<const mu32x4 *>(stage + (16 + jj) * kFrPitch + q * 16);
+  };
+  // ... and column-major (ds_read_b64_tr_b16) for phase 2: out[j][cg * 32 + 16 nt + 4 q ..] += (the row step)^T T-fragment
+  auto tile_cols_mma = [&](mu32x4 th, mu32x4 tl, int rs, mf32x4 (&acc)[2]) {
     if constexpr (kTfLds) {
       th = s_tf[(rs * 2 + 0) * 64 + lane];
       tl = s_tf[(rs * 2 + 1) * 64 + lane];
@@ -419,13 +435,19 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
         fa[(gi + 1) & 1][1] = frag(pkal, cn);
       }
 #pragma unroll
-      for (int rs = 0; rs < NRS; ++rs)
+      for (int rs = 0; rs < NRS; ++rs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pa[gi][rs][h] = finish(pa[gi][rs][h], cg, rs * 32 + h * 16 + lr, live, mask_a);
+        tile_put(pa[gi][rs][0], pa[gi][rs][1]);
+        mu32x4 f[2];
+        tile_rows(f[0], f[1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          pa[gi][rs][h] = finish(pa[gi][rs][h], cg, rs * 32 + h * 16 + jj, live, mask_a);
-          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(pa[gi][rs][h]), fm_frag<E>(fa[gi & 1][0]), d1[rs * 2 + h]);
-          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(pa[gi][rs][h]), fm_frag<E>(fa[gi & 1][1]), d1[rs * 2 + h]);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(f[h]), fm_frag<E>(fa[gi & 1][0]), d1[rs * 2 + h]);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(f[h]), fm_frag<E>(fa[gi & 1][1]), d1[rs * 2 + h]);
         }
+        asm volatile("" ::: "memory");
+      }
     }
   }
   FM_STAMP(6);
@@ -457,18 +479,21 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
 #pragma unroll
       for (int rs = 0; rs < NRS; ++rs)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) qv[rs][h] = finish(pb[s][rs][h], cg, rs * 32 + h * 16 + jj, live, mask_b);
+        for (int h = 0; h < 2; ++h) qv[rs][h] = finish(pb[s][rs][h], cg, rs * 32 + h * 16 + lr, live, mask_b);
       const mu32x4 fh = fb[s][0], fl = fb[s][1];
-#pragma unroll
-      for (int rs = 0; rs < NRS; ++rs)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(qv[rs][h]), fm_frag<E>(fh), d1[rs * 2 + h]);
-          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(qv[rs][h]), fm_frag<E>(fl), d1[rs * 2 + h]);
-        }
       load_group(gi + RG, pb[s], fb[s]);   // the slot's registers are free: its next group goes out before the LDS work
 #pragma unroll
-      for (int rs = 0; rs < NRS; ++rs) phase2(qv[rs][0], qv[rs][1], tfh[rs], tfl[rs], rs, acc);
+      for (int rs = 0; rs < NRS; ++rs) {   // a row step through the tile: rows for TB (phase 1), columns for outB (phase 2)
+        tile_put(qv[rs][0], qv[rs][1]);
+        mu32x4 f[2];
+        tile_rows(f[0], f[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(f[h]), fm_frag<E>(fh), d1[rs * 2 + h]);
+          d1[rs * 2 + h] = FmMfma<E>::mma(fm_frag<E>(f[h]), fm_frag<E>(fl), d1[rs * 2 + h]);
+        }
+        tile_cols_mma(tfh[rs], tfl[rs], rs, acc);
+      }
       store_group(outb, slabb, cg, live, acc);
     }
   }
@@ -488,7 +513,10 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   for (int gi = 0; gi < kGroupsA; ++gi) {
     const bool live = gi < nga_w;
 #pragma unroll
-    for (int rs = 0; rs < NRS; ++rs) phase2(pa[gi][rs][0], pa[gi][rs][1], tfh[rs], tfl[rs], rs, acc);
+    for (int rs = 0; rs < NRS; ++rs) {
+      tile_put(pa[gi][rs][0], pa[gi][rs][1]);
+      tile_cols_mma(tfh[rs], tfl[rs], rs, acc);
+    }
     store_group(outa, slaba, wave + 4 * gi, live, acc);
   }
 #ifdef FM_TRACE
@@ -598,6 +626,7 @@ static int fm_blocks_per_wg(int64_t nrb) {
 }
 
 static int g_fm_narrow = 1;   // 0: class-1 tables run the wide kernel too (A/B hook, lora_amd_factors_mfma_set_tuning)
+static int g_fm_wide = 0;     // measurement variants of the 10-pair kernel's ring (same hook, bits 4..7; bf16, maskless, rows = 0)
 
 }  // namespace lora_amd
 
@@ -617,8 +646,11 @@ extern "C" int lora_amd_fm_trace_set(void *buf, int64_t cap_words) {
 // groups in flight per wave: rounds 4-5's geometry), 1 / 2 = the 6-pair kernel at three workgroups per CU with 1 / 2 groups in
 // flight, 3 / 4 / 5 = the 6-pair kernel at two per CU with 2 / 3 / 4 groups in flight; < 0 only reads.  Returns the previous value.
 extern "C" int lora_amd_factors_mfma_set_tuning(int32_t narrow) {
-  const int prev = g_fm_narrow;
-  if (narrow >= 0 && narrow <= 5) g_fm_narrow = narrow;
+  const int prev = g_fm_narrow | (g_fm_wide << 4);
+  if (narrow >= 0 && (narrow & 15) <= 5 && (narrow >> 4) <= 4) {
+    g_fm_narrow = narrow & 15;
+    g_fm_wide = narrow >> 4;
+  }
   return prev;
 }
 
@@ -755,7 +787,13 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
     else FML(E, D, kFrPairsWide, 2, 2, 4, 2);                                \
   } while (0)
 #define FM(E) do { if (drop) FM2(E, true); else FM2(E, false); } while (0)
-  if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
+  if (g_fm_wide != 0 && narrow == 0 && rows_per_block == 0 && !drop && act_dtype == LORA_AMD_BF16) {
+    // ring depths of the 10-pair kernel (64-row sites, 32-row sites): 1 = (3, 4), 2 = (4, 4), 3 = (2, 6), 4 = (3, 6); default (2, 4)
+    if (g_fm_wide == 1) FML(bf16_t, false, kFrPairsWide, 2, 3, 4, 2);
+    else if (g_fm_wide == 2) FML(bf16_t, false, kFrPairsWide, 2, 4, 4, 2);
+    else if (g_fm_wide == 3) FML(bf16_t, false, kFrPairsWide, 2, 2, 6, 2);
+    else FML(bf16_t, false, kFrPairsWide, 2, 3, 6, 2);
+  } else if (act_dtype == LORA_AMD_F16) FM(f16_t); else FM(bf16_t);
 #undef FM2
 #undef FML
 #undef FM

@@ -468,10 +468,32 @@ def bench_fm(args):
         if ss:
             arr, grid = _C.factors_mfma_table(ss, dt, cls)
             extra.append((name, _C.table_to_device(arr, DEV), len(ss), grid, cls, rpb, sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)))
+    # class 2 by site type too
+    for name, pick in (("c2_square_640", lambda s_: s_[0].shape[0] == 4096 and s_[0].shape[1] == s_[1].shape[1]),
+                       ("c2_geglu_640", lambda s_: s_[0].shape[0] == 4096 and s_[0].shape[1] == 8 * s_[1].shape[1]),
+                       ("c2_1280", lambda s_: s_[1].shape[1] == 1280), ("c2_text_kv", lambda s_: s_[1].shape[1] == 768)):
+        ss = [s_ for s_ in c2 if pick(s_)]
+        if ss:
+            arr, grid = _C.factors_mfma_table(ss, dt, 2)
+            extra.append((name, _C.table_to_device(arr, DEV), len(ss), grid, 2, 0, sum((s_[0].numel() + s_[1].numel()) * 2 for s_ in ss)))
     for name, tab, ns, grid, cls, rpb, b in extra:
         t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
-        rec["part_" + name] = {"blocks": grid, "GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
-                               **({"frac8": round(b / 8e12 / t, 3)} if b else {})}
+        row = {"blocks": grid, "GB": round(b / 1e9, 4), "us": round(t * 1e6, 1), **({"frac8": round(b / 8e12 / t, 3)} if b else {})}
+        # ring depths (lora_amd_factors_mfma_set_tuning): class 1 on its kernels 2 .. 5, class-2 mixed-height tables on the 10-pair
+        # kernel's ring variants 1 .. 4
+        if os.environ.get("LORA_AMD_FM_RINGS", "1") == "1" and b:
+            if cls == 1:
+                for mode in (2, 3, 4, 5):
+                    _C.factors_mfma_set_tuning(mode)
+                    t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
+                    row[f"kernel{mode}_us"] = round(t * 1e6, 1)
+            elif rpb == 0:
+                for w in (1, 2, 3, 4):
+                    _C.factors_mfma_set_tuning((prev & 15) | (w << 4))
+                    t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tab, ns, grid, cls, dt, False, rpb), inner=5)
+                    row[f"ring{w}_us"] = round(t * 1e6, 1)
+            _C.factors_mfma_set_tuning(prev & 15)
+        rec["part_" + name] = row
     red_m = _C.make_reduce_table(rows_m, DEV)
     t, _ = timeit(lambda: _C.reduce_batched(*red_m), inner=5)
     rec["mfma_fold_us"], rec["mfma_partial_MB"] = round(t * 1e6, 1), round(part_bytes / 1e6, 1)

@@ -8,8 +8,12 @@
 //   mode 0  fragment-shaped, 32-column groups dealt round-robin to the 4 waves (the round-4..6 kernel)
 //   mode 1  fragment-shaped, both halves of a line in the SAME wave, issued back to back
 //   mode 2  full lines: lane (row = l >> 3, chunk = l & 7), 8 rows x 128 B per instruction (not an MFMA operand: the ceiling)
+//   mode 3  the SAME 16 rows x 64 B per instruction as mode 0, but FOUR CONSECUTIVE LANES on one row's 64 bytes
+//           (row = l >> 2, chunk = l & 3): 16 contiguous runs per instruction instead of 64 scattered 16-byte accesses
 // A workgroup = 256 threads = 64 rows x C columns, every load issued before the first use (as the kernel's resident block).
-// usage: ld_shape_probe [M] [C] [lds_kb]   (lds_kb pads LDS to pin 2 or 3 workgroups per CU)
+// usage: ld_shape_probe [M] [C] [wrap]   wrap > 0: block b reads row block b % wrap — a footprint of wrap x 64 rows that stays in
+//        the L2 (wrap = 64: 2.6 MB at C = 320) or the MALL (wrap = 512): what the LOAD PATH of a CU (address coalescer, L1 tag
+//        pipeline) sustains for each shape when HBM is out of the picture (round 6, call c25)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -21,10 +25,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, int NG>   // NG = C / 32 column groups
 __global__ __launch_bounds__(256, 2) void probe(const unsigned short *__restrict__ x, int64_t ld, unsigned *__restrict__ out,
-                                                int lds_words) {
+                                                int lds_words, int wrap) {
   extern __shared__ unsigned pad[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int64_t m0 = (int64_t)(wrap > 0 ? blockIdx.x % wrap : blockIdx.x) * 64;
   const unsigned short *base = x + m0 * ld;
   u32x4 acc = {0u, 0u, 0u, 0u};
   if (MODE == 2) {
@@ -39,13 +43,13 @@ __global__ __launch_bounds__(256, 2) void probe(const unsigned short *__restrict
 #pragma unroll
     for (int i = 0; i < 2 * NL; ++i) acc ^= v[i];
   } else {
-    const int jj = lane & 15, q = lane >> 4;
+    const int jj = MODE == 3 ? lane >> 2 : lane & 15, q = MODE == 3 ? lane & 3 : lane >> 4;
     constexpr int GPW = (NG + 3) / 4;   // groups per wave (upper bound)
     u32x4 v[GPW * 4];
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
       int cg;
-      if (MODE == 0) {
+      if (MODE == 0 || MODE == 3) {
         cg = wave + 4 * i;
       } else {   // full rounds of 4 line pairs (8 groups), the remaining groups one per wave
         constexpr int NR = NG / 8;
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void probe(const unsigned short *__restrict
   if (r == 0x12345678u) out[blockIdx.x * 256 + tid] = r;   // never true for random data: keeps the loads alive
 }
 
+static int g_wrap = 0;
 template <int NG>
 static void run(int mode, const unsigned short *x, int64_t M, int64_t ld, unsigned *out, int lds_bytes, const char *tag) {
   const int blocks = (int)(M / 64);
@@ -73,9 +78,10 @@ static void run(int mode, const unsigned short *x, int64_t M, int64_t ld, unsign
   hipEventCreate(&a);
   hipEventCreate(&b);
   auto launch = [&]() {
-    if (mode == 0) hipLaunchKernelGGL((probe<0, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4);
-    else if (mode == 1) hipLaunchKernelGGL((probe<1, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4);
-    else hipLaunchKernelGGL((probe<2, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4);
+    if (mode == 0) hipLaunchKernelGGL((probe<0, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4, g_wrap);
+    else if (mode == 1) hipLaunchKernelGGL((probe<1, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4, g_wrap);
+    else if (mode == 3) hipLaunchKernelGGL((probe<3, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4, g_wrap);
+    else hipLaunchKernelGGL((probe<2, NG>), dim3(blocks), dim3(256), lds_bytes, 0, x, ld, out, lds_bytes / 4, g_wrap);
   };
   for (int i = 0; i < 3; ++i) launch();
   hipDeviceSynchronize();
@@ -96,6 +102,8 @@ static void run(int mode, const unsigned short *x, int64_t M, int64_t ld, unsign
 int main(int argc, char **argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 16384 * 96;   // ~1 GB at C = 320: far beyond L2 + MALL
   const int C = argc > 2 ? atoi(argv[2]) : 320;
+  g_wrap = argc > 3 ? atoi(argv[3]) : 0;
+  printf("# M %lld C %d wrap %d (footprint %.1f MB)\n", (long long)M, C, g_wrap, (g_wrap ? g_wrap * 64.0 : (double)M) * C * 2 / 1e6);
   const int64_t ld = C;
   std::vector<unsigned short> h((size_t)1 << 20);
   for (auto &v : h) v = (unsigned short)rand();
@@ -108,10 +116,10 @@ int main(int argc, char **argv) {
     if (off + n > (size_t)M * ld * 2) n = (size_t)M * ld * 2 - off;
     hipMemcpy((char *)x + off, h.data(), n, hipMemcpyHostToDevice);
   }
-  const char *tags[3] = {"mode 0 fragment-shaped, groups round-robin", "mode 1 fragment-shaped, line mates same wave",
-                         "mode 2 full 128-byte lines"};
+  const char *tags[4] = {"mode 0 fragment-shaped, groups round-robin", "mode 1 fragment-shaped, line mates same wave",
+                         "mode 2 full 128-byte lines", "mode 3 16 rows x 64 B, 4 lanes per row"};
   for (int lds_kb : {72, 48, 36}) {   // 2, 3, 4 workgroups per CU by LDS (160 KB)
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       if (C == 320) run<10>(mode, x, M, ld, out, lds_kb << 10, tags[mode]);
       else if (C == 640) run<20>(mode, x, M, ld, out, lds_kb << 10, tags[mode]);
       else if (C == 2560) run<80>(mode, x, M, ld, out, lds_kb << 10, tags[mode]);
