@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
 // LO = false (round 6): the hi plane alone (X ~ hi to 8 mantissa bits) at half the bytes — the power iterations of the
 // subspace iteration only steer a subspace (an O(2^-9) perturbation of it costs the rank-r Frobenius error to second order);
 // the pass that forms the returned factors (b = Q^T dW) reads both planes.
-template <class E, bool PK, bool LO = true>
+template <class E, bool PK, bool LO = true, bool ROWLD = false>
 __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_planes_desc *__restrict__ descs, int n, int r) {
   using S = typename E::storage;
   __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
@@ -482,25 +482,53 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
       if constexpr (LO) return piece(xl, ks);
       else return r16_zero();
     };
-    mu32x4 h0 = piece(xh, cw), l0 = piece_lo(cw), h1 = piece(xh, cw + wps), l1 = piece_lo(cw + wps);
     if constexpr (PK) {
+      // Round 6: a piece (16 rows x 64 bytes) is FETCHED four lanes per row (row l >> 2, chunk l & 3) and brought into the MFMA
+      // operand order (row l & 15, chunk l >> 4) by four ds_bpermute_b32: the operand order's 64 scattered 16-byte accesses go
+      // through the L1 tag pipeline one lane per cycle (scripts/ld_shape_probe.hip: 9.7 TB/s from cache against 23-28 for
+      // this order).  Same box: 557 -> 503 us for the hi-plane pass, 911 -> 806 us for both planes (call c28).
+      // (The factor pass's other finding — static slots instead of the rotating h0 = h1 = h2 — does NOT carry over: a wave
+      // here has two or three k-steps, an unrolled three-slot loop runs up to two dead ones; it measured 25 % slower.)
+      const int lr = ROWLD ? lane >> 2 : jj, lc = ROWLD ? lane & 3 : q;
+      const int64_t lrow = m0 + lr;
+      const bool lrok = active && lrow < d.M;
+      const int64_t lbase = (b * d.M + (lrok ? lrow : 0)) * (int64_t)C + 8 * lc;
+      const S *ph = reinterpret_cast<const S *>(d.hi) + lbase, *pl = reinterpret_cast<const S *>(d.lo) + lbase;
+      const int src = ((jj << 2) | q) << 2;   // byte address of the source lane for ds_bpermute: lane (row jj, chunk q) = 4 jj + q
+      auto to_operand = [&](mu32x4 v) -> mu32x4 {
+        if constexpr (!ROWLD) return v;
+        mu32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v[i]);
+        return o;
+      };
+      auto lpiece_lo = [&](int ks) -> mu32x4 {
+        if constexpr (LO) return piece(pl, ks);
+        else return r16_zero();
+      };
+      mu32x4 h0 = piece(ph, cw), l0 = lpiece_lo(cw), h1 = piece(ph, cw + wps), l1 = lpiece_lo(cw + wps);
       auto frag = [&](int ks, int part) -> mu32x4 {
         return *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)(ks < nks ? ks : 0) * 1024 + part * 512));
       };
       mu32x4 fh = frag(cw, 0), fl = frag(cw, 1);
 #pragma unroll 1
       for (int ks = cw; ks < nks; ks += wps) {
-        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece_lo(ks + 2 * wps);
+        const mu32x4 h2 = piece(ph, ks + 2 * wps), l2 = lpiece_lo(ks + 2 * wps);
         const mu32x4 nfh = frag(ks + wps, 0), nfl = frag(ks + wps, 1);
         mu32x4 ch = h0, cl = l0;
-        if (!rok) { ch = r16_zero(); cl = r16_zero(); }
+        if (!lrok) { ch = r16_zero(); cl = r16_zero(); }
+        ch = to_operand(ch);
         acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
         acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
-        if constexpr (LO) acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+        if constexpr (LO) {
+          cl = to_operand(cl);
+          acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+        }
         h0 = h1; l0 = l1; h1 = h2; l1 = l2;
         fh = nfh; fl = nfl;
       }
     } else {
+      mu32x4 h0 = piece(xh, cw), l0 = piece_lo(cw), h1 = piece(xh, cw + wps), l1 = piece_lo(cw + wps);
       R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
 #pragma unroll 1
       for (int ks = cw; ks < nks; ks += wps) {
@@ -744,9 +772,9 @@ extern "C" int lora_amd_rowdot16_planes_packed(const lora_amd_planes_desc *descs
   LORA_AMD_CHECK(plane_dtype == LORA_AMD_BF16 || plane_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "rowdot16_planes_packed: 16-bit planes only");
   hipStream_t st = (hipStream_t)stream;
 #define RP(E)                                                                                                          \
-  do {                                                                                                                 \
-    if (hi_only) hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, false>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16); \
-    else hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);          \
+  do {   /* ROWLD: pieces fetched four lanes per row (kernel comment) */                                               \
+    if (hi_only) hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, false, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16); \
+    else hipLaunchKernelGGL((rowdot16_planes_kernel<E, true, true, true>), dim3((unsigned)grid), dim3(1024), 0, st, descs_dev, n, 16);          \
   } while (0)
   if (plane_dtype == LORA_AMD_F16) RP(f16_t); else RP(bf16_t);
 #undef RP
