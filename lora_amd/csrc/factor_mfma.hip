@@ -14,13 +14,16 @@
 //     TB = s B fb^T [R, r]        outA[j, c] = sum_m TB[m, j] A[m, c]       (        Gt, outA = dDown partial)
 //
 //   * A's row block stays RESIDENT IN REGISTERS (<= 20 16-byte pieces per lane: 64 rows x 640 columns or 32 x 1280 over the
-//     four waves), B streams through a 4-deep register ring of 32 x 32 units; a wave owns the 32-column groups
-//     wave, wave + 4, ... of both operands and is autonomous between four barriers (factors_reg_kernel below).
+//     four waves), B streams through a ring of column-group slots; a wave owns the 32-column groups wave, wave + 4, ... of both
+//     operands and is autonomous between four barriers (factors_reg_kernel below).
+//   * a piece (16 rows x 64 bytes) is FETCHED with four consecutive lanes on one row (round 6: the MFMA operand order is 64
+//     scattered 16-byte accesses per instruction, one lane per cycle through the L1's tag pipeline) and held in that layout;
+//     every piece crosses the wave's own 32 x 32 LDS tile, which hands out both operand forms;
 //   * both contractions are v_mfma_f32_16x16x32 (the rank padded to the 16 of the tile):
-//       phase 1  D[row, j]  += Data[row, 32 cols] . F[j, 32 cols]^T      A operand = the 16-byte piece a lane loaded from a
-//                row-major row, B operand = a packed factor fragment (lora_amd_factor_pack: 1 KB per wave, L2-resident);
-//       phase 2  D[col, j]  += Data^T[col, 32 rows] . T[32 rows, j]      A operand = two ds_read_b64_tr_b16 of the wave's
-//                own 32 x 32 staging tile (the LDS transpose read of gfx950), B operand = T fragments from LDS.
+//       phase 1  D[row, j]  += Data[row, 32 cols] . F[j, 32 cols]^T      A operand = ds_read_b128 of the tile (row l & 15,
+//                chunk l >> 4), B operand = a packed factor fragment (lora_amd_factor_pack: 1 KB per wave, L2-resident);
+//       phase 2  D[col, j]  += Data^T[col, 32 rows] . T[32 rows, j]      A operand = two ds_read_b64_tr_b16 of the same tile
+//                (the LDS transpose read of gfx950), B operand = T fragments from LDS.
 //   * f32 precision is kept by splitting every 16-bit operand that is not data: factor = hi + lo, T = hi + lo (two MFMAs
 //     into the same accumulator) — the matrix pipe is < 20 % busy at the HBM rate, so the split is free.
 //   * f16 (round 6): f16 has 5 exponent bits — `up` starts at 0 (lora.py:50-51) and sits at ~1e-4 for hundreds of steps,
@@ -165,20 +168,20 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
 // csrc/rank16_mfma.hip's bwd_g16): a wave owns the 32-column groups cg = wave, wave + 4, ... of both operands.
 //   1. all of the block's A pieces are issued at once (<= 20 x 16 bytes per lane: 64 rows x 640 columns or 32 x 1280 over
 //      four waves) and stay in registers until step 5;
-//   2. phase 1 on them straight from the registers (A operand = the piece, B operand = the packed factor fragment):
-//      TA partials -> LDS, barrier, the four waves' partials are summed into T fragments (hi, lo), barrier;
-//   3. B streams through a 4-deep ring of units (32 rows x 32 columns = two pieces), each unit: phase 1 for TB from the
-//      registers, then through the wave's own 32 x 32 LDS tile and back column-major (ds_read_b64_tr_b16) for
-//      outB += B^T TA; a group's [16, 32] slab columns are complete after its row steps and stored at once;
+//   2. phase 1: a row step's two pieces -> the wave's own 32 x 32 LDS tile -> ds_read_b128 in operand order (B operand = the
+//      packed factor fragment): TA partials -> LDS, barrier, the four waves' partials are summed into T fragments (hi, lo),
+//      barrier;
+//   3. B streams through a ring of column-group slots; per row step the tile gives the rows (phase 1 for TB) and, column-major
+//      (ds_read_b64_tr_b16), the operand of outB += B^T TA; a group's [16, 32] slab columns are complete after its row steps
+//      and stored at once;
 //   4. TB partials -> LDS, barrier, T fragments, barrier;
-//   5. outA += A^T TB from the resident pieces the same way.
-// No wave waits for another inside a step, the LDS queue of a wave is in order (write -> transpose read needs no wait),
+//   5. outA += A^T TB from the resident pieces through the tile the same way.
+// No wave waits for another inside a step, the LDS queue of a wave is in order (write -> read -> transpose read needs no wait),
 // and the only loads on the critical path of a block are its first ones.
 // resident (row step, group) units per wave: PAIRS = 10 serves every supported site (64 rows x 640 columns or 32 x 1280 of the
-// narrower operand: 80 registers of pieces, 244 in all, two workgroups per CU); PAIRS = 6 serves the sites of register class 1
+// narrower operand: 80 registers of pieces, ~200 in all, two workgroups per CU); PAIRS = 6 serves the sites of register class 1
 // (R x Ca <= 64 x 320 or 32 x 640 — every M = 16384 site of SD1.5 and the cross-attention k / v: 56 % of the step's bytes) in
-// <= 168 registers, THREE workgroups per CU: a block's life is load latency + ~1.5 us of dependent MFMA / LDS work with no
-// load in flight, and only other workgroups on the CU fill that gap (round 6)
+// ~140 registers, THREE workgroups per CU (four, at 128 registers, measured no faster)
 constexpr int kFrPairsWide = 10, kFrPairsNarrow = 6;
 constexpr int kFrPitch = 96;   // bytes per row of a wave's 32 x 32 staging tile (conflict-free, scripts/lds_banks.py)
 constexpr int kFrSitesLds = 512;  // block prefix of the site table kept in LDS for the lookup
