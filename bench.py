@@ -727,9 +727,7 @@ def svd_bench(args) -> dict:
     # the subspace-steering passes (sketch + power iterations) read the hi plane only (2 bytes / element), the pass that forms
     # the factors both planes (4); + forming the planes: read W_tuned and W_base (f32), write four 16-bit planes
     hi_only = bool(getattr(S, "HI_ONLY_ITERATIONS", False))
-    # both planes: b = Q^T dW and the last dW Qz (a fixed count's last pass; the adaptive loop repeats it: one pass more)
-    if hi_only and n_iter is None:
-        passes += 1
+    # both planes: b = Q^T dW and the last dW Qz (the adaptive loop decides one iteration ahead and knows its last pass too)
     full = 2 if hi_only else passes
     pass_bytes = ((passes - full) * 2 + full * 4) * elems
     byts = pass_bytes + 2 * elems * 4 + 4 * elems * 2
@@ -751,7 +749,7 @@ def svd_bench(args) -> dict:
                         "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                         "algorithmic_bytes_per_step": byts, "passes_over_residuals": passes, "hi_plane_only_passes": passes - full,
                         "note": "WHOLE-STEP figure (passes + forming the planes + ~70 small launches + one host sync per adaptive "
-                                "iteration from the 4th on); per-kernel shares: profiles/r06_svd_kernel_trace_summary.txt.  "
+                                "iteration from the 3rd on); per-kernel shares: profiles/r06_svd_kernel_trace_summary.txt.  "
                                 "LORA_AMD_SVD_ITERS=4 fixes the iteration count (rounds 2-4's iso-work figure)"}}
     if not args.no_cpu_baseline:
         import subprocess

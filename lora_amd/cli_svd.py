@@ -59,7 +59,9 @@ THIN = True
 # for EVERY site, one more power iteration improved that squared error by less than RES_TOL of itself (floor: 1e-6 |dW|^2, the
 # resolution of the f32 sums; an exactly low-rank residual).  |dW|_F^2 comes out of the launch that forms the residual.  At
 # least MIN_ITER = 4 (the fixed count of rounds 2-4), at most MAX_ITER iterations; "improved by" = the geometric-tail estimate
-# gain rho / (1 - rho) from the ratio rho of two successive gains.
+# from the ratio rho of two successive gains, evaluated ONE ITERATION AHEAD (after iteration i: would everything after i + 1,
+# gain rho^2 / (1 - rho), be below the tolerance?) so that the loop knows its last iteration before it runs it — that one
+# reads both planes of the residuals (HI_ONLY_ITERATIONS below), all others the hi plane.
 RES_TOL, MIN_ITER, MAX_ITER = 1e-3, 4, 12   # MIN_ITER = the fixed count of rounds 2-4: the adaptive rule only ever ADDS iterations
 # the passes that only steer the subspace (the sketch, every `dW^T Q`, and `dW Qz` of the iterations before the one that may be
 # the last) read the hi plane of the residuals alone: half the bytes; the products the returned factors are formed from (the last
@@ -290,41 +292,40 @@ def _subspace_thin(deltas, rank: int, n_iter, generator, pairs=None):
     _C.thin_pack(st.tz, st.zc, st.pkz)
     pprog.run(p_y, hi)
     orth(st.ty, st.ya, st.yb)                                     # q in yb
-    it, prev, prev_gain = 0, None, None
+    it, prev, prev_gain, final_next = 0, None, None, False
     while True:
         _C.thin_pack(st.ty, st.yb, st.pky)
         pprog.run(p_z, hi)
         orth(st.tz, st.za, st.zb)                                 # qz in zb
         _C.thin_pack(st.tz, st.zb, st.pkz)
         # the Q that is RETURNED must come from a product with dW itself — one multiplication by the exact matrix contracts the
-        # hi-plane iterations' O(2^-9) subspace error by the spectral gap (exactly low-rank deltas: to nothing): a fixed count's
-        # LAST `dW Qz` reads both planes; the adaptive loop (whose stopping rule compares like with like: hi-plane Ritz energies)
-        # repeats its last `dW Qz` on both planes after it has stopped
-        pprog.run(p_y, hi and not (n_iter is not None and it + 1 >= n_iter))
-        orth(st.ty, st.ya, st.yb, st.ritz if n_iter is None else None)
+        # hi-plane iterations' O(2^-9) subspace error by the spectral gap (exactly low-rank deltas: to nothing): the LAST `dW Qz`
+        # reads both planes.  A fixed count knows its last iteration; the adaptive loop decides ONE ITERATION AHEAD (below), so
+        # it knows too — rounds 5-6a stopped after the fact and repeated the pass on both planes (one pass and one
+        # orthonormalisation more per distillation)
+        last = (it + 1 >= n_iter) if n_iter is not None else (final_next or it + 1 >= MAX_ITER)
+        pprog.run(p_y, hi and not last)
+        orth(st.ty, st.ya, st.yb, st.ritz if (n_iter is None and not last) else None)
         it += 1
-        if n_iter is not None:
-            if it >= n_iter:
-                break
-            continue
-        if it >= MAX_ITER:
+        if last:
             break
+        if n_iter is not None:
+            continue
         gained = (st.ritz[:, 0] - prev).abs() if prev is not None else None
-        if it >= MIN_ITER and prev_gain is not None:
-            # what is still to come, from the convergence ratio of two successive gains (a geometric tail gain rho / (1 - rho),
-            # rho capped at 0.95): a small gain alone does not stop a site whose gains are not shrinking
-            # (a previous gain already inside the rounding noise of the Ritz energies, 1e-6 |dW|^2, says nothing about a ratio)
+        if it >= MIN_ITER - 1 and prev_gain is not None:
+            # what will still be to come AFTER THE NEXT iteration, from the convergence ratio of two successive gains (a
+            # geometric tail: the next gain is gained * rho, everything after it gained * rho^2 / (1 - rho), rho capped at 0.95):
+            # a small gain alone does not stop a site whose gains are not shrinking.  (A previous gain already
+            # inside the rounding noise of the Ritz energies, 1e-6 |dW|^2, says nothing about a ratio.)  Compares like with
+            # like: every Ritz energy that enters comes from a hi-plane iteration.
             floor = 1e-6 * norm2
             rho = torch.where(prev_gain > floor, gained / prev_gain.clamp_min(1e-30), torch.zeros_like(gained)).clamp(0.0, 0.95)
-            remaining = gained * rho / (1.0 - rho)
-            err2 = (norm2 - st.ritz[:, 0]).clamp_min(0.0)
-            if bool((remaining <= torch.maximum(RES_TOL * err2, floor)).all()):  # one host sync per iteration >= MIN_ITER
-                break
+            remaining = gained * rho * rho / (1.0 - rho)
+            err2 = (norm2 - st.ritz[:, 0] - gained * rho).clamp_min(0.0)      # the squared error expected after the next one
+            if bool((remaining <= torch.maximum(RES_TOL * err2, floor)).all()):  # one host sync per iteration >= MIN_ITER - 1
+                final_next = True
         prev_gain = gained
         prev = st.ritz[:, 0].clone()
-    if n_iter is None and hi:
-        pprog.run(p_y, False)          # pkz still holds the last Qz
-        orth(st.ty, st.ya, st.yb)
     st.iterations = it
     global LAST_ITERATIONS
     LAST_ITERATIONS = it

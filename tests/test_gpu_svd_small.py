@@ -260,7 +260,8 @@ def test_fused_small_steps_equal_the_ragged_launches_of_rounds_2_to_4(monkeypatc
 def test_adaptive_iteration_stops_early_on_a_decaying_spectrum_and_runs_longer_on_a_flat_one(monkeypatch):
     """``n_iter=None``: never fewer than MIN_ITER = 4 (rounds 2-4's fixed count); a planted (decaying) spectrum stops there; a
     power-law one stops there too at the default tolerance (1e-3 of a LARGE tail energy) and runs on when the tolerance asks for
-    more — the geometric-tail estimate, not a single small gain, decides."""
+    more — the geometric-tail estimate, not a single small gain, decides (one iteration ahead: the loop's last pass is known
+    before it runs and reads both planes of the residuals)."""
     from tests.test_cli_svd import _planted
 
     t, b = _planted(640, 640, 12, 1e-5, 3, "cpu")
