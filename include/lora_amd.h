@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LORA_AMD_ABI_VERSION 6
+#define LORA_AMD_ABI_VERSION 7
 
 /* status codes */
 #define LORA_AMD_OK 0
@@ -472,7 +472,9 @@ typedef struct lora_amd_ws_site {
    * lora_amd_linear_bwd_g: element (m, n) of the site's [M, N] output (forward) resp. of G (input-gradient call, where
    * the launch's contraction length K is that N).  Needs N % 8 == 0. */
   float dropout_p;
-  int32_t reserved;
+  int32_t y_heads;   /* head-padded output: d | D << 16 (heads of d columns stored in slots of D, pad written as zeros; ldy >=
+                      * N / d * D); 0 = dense rows.  Needs N a multiple of the panel width (lora_amd_ws_config), no
+                      * accumulation, D - d <= d <= 2 (D - d) (40 in 64, 80 in 128, 160 in 256) */
   uint64_t seed, offset;
   const uint64_t *offset_dev; /* device int64 added to `offset` (graph replay / checkpoint recompute), or NULL */
 } lora_amd_ws_site;
@@ -484,6 +486,14 @@ int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_k, int32_t 
                      void *stream);
 int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
                        const lora_amd_ws_site *sites /* host array */, int32_t nsites, int32_t row_groups, void *stream);
+/* lora_amd_linear_ws on a head-padded INPUT (ABI 7; the dropout sites around the attention core, lora.py:53-58 called by
+ * CrossAttention.to_q / to_k / to_v / to_out): x rows hold K / x_head_dim heads of x_head_dim columns in slots of x_head_pad
+ * (multiples of 8; pad never read); 0, 0 = dense.  A site's y_heads does the same for its output.  With both, the pad /
+ * slice copies around the kernel disappear in either direction (forward: to_out reads the attention output as it is, q / k / v
+ * leave padded; input-gradient call: G of q / k / v arrives padded, dX of to_out leaves padded). */
+int lora_amd_linear_ws_heads(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t x_head_dim, int32_t x_head_pad,
+                             int32_t act_dtype, const lora_amd_ws_site *sites /* host array */, int32_t nsites,
+                             int32_t row_groups, void *stream);
 
 /* lora_amd_linear_gemm_fwd with head-padded activations: a row of `heads` runs of d elements stored with every run padded to D
  * (d, D multiples of 8; the layout attention kernels want for head sizes 40 / 80).  x_head_dim/x_head_pad describe

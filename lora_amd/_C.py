@@ -20,7 +20,7 @@ F32, F16, BF16 = 0, 1, 2
 FACTOR_RK, FACTOR_KR = 0, 1
 ROUND_REFERENCE, ROUND_ONCE, ROUND_DITHER = 0, 1, 2
 MAX_RANK = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -44,7 +44,7 @@ SYMBOLS = (
     "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
-    "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws",
+    "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws", "lora_amd_linear_ws_heads",
     "lora_amd_conv_plan", "lora_amd_conv_down_fwd", "lora_amd_conv_up_fwd", "lora_amd_conv_bwd_g", "lora_amd_conv_bwd_x",
     "lora_amd_conv3_nhwc_plan", "lora_amd_conv3_nhwc_pack", "lora_amd_conv3_nhwc_down_fwd", "lora_amd_conv3_nhwc_bwd_dx",
     "lora_amd_conv3_nhwc_bwd_down", "lora_amd_sum_parts",
@@ -231,7 +231,7 @@ class WsSite(C.Structure):
     _fields_ = [("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p),
                 ("t_out", C.c_void_p), ("ldy", C.c_int64), ("N", C.c_int32), ("r", C.c_int32),
                 ("panel_begin", C.c_int32), ("flayout", C.c_int32), ("scale", C.c_float), ("t_scale", C.c_float),
-                ("dropout_p", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("dropout_p", C.c_float), ("y_heads", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("offset_dev", C.c_void_p)]
 
 
@@ -352,7 +352,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_ws_packed_elems.restype = i64
     lib.lora_amd_ws_pack.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp]
     lib.lora_amd_linear_ws.argtypes = [vp, i64, i64, i32, i32, C.POINTER(WsSite), i32, i32, vp]
+    lib.lora_amd_linear_ws_heads.argtypes = [vp, i64, i64, i32, i32, i32, i32, C.POINTER(WsSite), i32, i32, vp]
     lib.lora_amd_ws_config.restype = lib.lora_amd_ws_pack.restype = lib.lora_amd_linear_ws.restype = C.c_int
+    lib.lora_amd_linear_ws_heads.restype = C.c_int
     lib.lora_amd_conv_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, C.POINTER(ConvPlan)]
     lib.lora_amd_conv_down_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.lora_amd_conv_up_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, vp]
@@ -1848,13 +1850,38 @@ def ws_pack(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     return hit[1]
 
 
-def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
+def ws_heads_ok(K: int, N: int, x_heads: Heads = None, y_heads: Heads = None) -> bool:
+    """Can ``linear_ws`` (dropout sites) read an input / write an output of contraction length ``K`` / width ``N`` in these head
+    layouts: input heads in 16-byte chunks; output pad no wider than the head and at least half of it (one zero group per live
+    group), whole panels, never both in one launch."""
+    if x_heads and y_heads:
+        return False
+    if x_heads:
+        h, d, D = x_heads
+        if d % 8 or D % 8 or D < d or h * d != K:
+            return False
+    if y_heads:
+        h, d, D = y_heads
+        bn = C.c_int32(0)
+        if not require().lora_amd_ws_config(int(K), C.byref(bn), None):
+            return False
+        if d % 4 or D % 4 or not (0 < D - d <= d <= 2 * (D - d)) or h * d != N or N % bn.value or D >= 65536:
+            return False
+    return True
+
+
+def linear_ws(x: torch.Tensor, sites, row_groups: int = 0, x_heads: Heads = None):
     """One launch for every site in ``sites`` (all reading ``x`` [M, K]); each site is a dict with ``wp`` (packed
     weight), ``N``, ``down``, ``up``, ``scale`` and optionally ``bias``, ``y`` (output buffer, allocated if absent),
     ``want_t`` (default True), ``t_scale``, ``flayout``, and ``p`` / ``seed`` / ``off`` for nn.Dropout on the branch (every
-    site of a launch or none; ``off`` an int or a 1-element int64 device tensor).  Returns [(y, t), ...]."""
+    site of a launch or none; ``off`` an int or a 1-element int64 device tensor).  Returns [(y, t), ...].
+    ``x_heads`` = (heads, d, D): the rows of x are head-padded (K = heads * d); a site's ``y_heads``: its output leaves
+    head-padded, pad zeroed (dropout sites only: ``ws_heads_ok``)."""
     lib = require()
-    M, K = x.shape
+    M = x.shape[0]
+    K = x_heads[0] * x_heads[1] if x_heads else x.shape[1]
+    if x.shape[1] != heads_width(K, x_heads):
+        raise ValueError(f"linear_ws: x has {x.shape[1]} columns, expected {heads_width(K, x_heads)}")
     if not 1 <= len(sites) <= WS_MAX_SITES:
         raise ValueError(f"linear_ws: 1..{WS_MAX_SITES} sites")
     arr = (WsSite * len(sites))()
@@ -1866,8 +1893,10 @@ def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
         if down.dtype != torch.float32 or up.dtype != torch.float32 or not down.is_contiguous() or not up.is_contiguous():
             raise ValueError("linear_ws: contiguous f32 factors expected")
         y = s.get("y")
+        yh = s.get("y_heads")
         if y is None:
-            y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+            y = torch.empty((M, heads_width(N, yh)), dtype=x.dtype, device=x.device)
+        d.y_heads = (int(yh[1]) | (int(yh[2]) << 16)) if yh else 0
         t = torch.empty((M, r), dtype=torch.float32, device=x.device) if s.get("want_t", True) else None
         bias = s.get("bias")
         d.wp, d.bias, d.y, d.down, d.up, d.t_out = (s["wp"].data_ptr(), _ptr(bias), y.data_ptr(), down.data_ptr(),
@@ -1878,23 +1907,28 @@ def linear_ws(x: torch.Tensor, sites, row_groups: int = 0):
         d.dropout_p, d.seed, d.offset, d.offset_dev = float(s.get("p", 0.0)), int(s.get("seed", 0)), off_s, off_p
         outs.append((y, t))
         keep.append((down, up, bias))
-    _check(lib.lora_amd_linear_ws(x.data_ptr(), x.stride(0), M, K, dtype_code(x.dtype), arr, len(sites), int(row_groups),
-                                  _stream()), "lora_amd_linear_ws")
+    xd, xD = (x_heads[1], x_heads[2]) if x_heads else (0, 0)
+    _check(lib.lora_amd_linear_ws_heads(x.data_ptr(), x.stride(0), M, K, xd, xD, dtype_code(x.dtype), arr, len(sites),
+                                        int(row_groups), _stream()), "lora_amd_linear_ws")
     return outs
 
 
-def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0):
+def linear_ws_fwd(x, weight, bias, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0,
+                  x_heads: Heads = None, y_heads: Heads = None):
     """(y, t) of ONE site through the weight-stationary kernel (same contract as :func:`linear_gemm_fwd`);
-    ``p`` > 0: nn.Dropout on the low-rank branch, mask indexed as :func:`linear_fwd_` does."""
+    ``p`` > 0: nn.Dropout on the low-rank branch, mask indexed as :func:`linear_fwd_` does (logical columns, whatever
+    the head layouts)."""
     return linear_ws(x, [dict(wp=ws_pack(weight), N=weight.shape[0], bias=bias, down=down, up=up, scale=scale, p=p,
-                              seed=seed, off=off)], row_groups)[0]
+                              seed=seed, off=off, y_heads=y_heads)], row_groups, x_heads)[0]
 
 
-def linear_ws_dx(g, weight, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0):
+def linear_ws_dx(g, weight, down, up, scale, row_groups: int = 0, p: float = 0.0, seed: int = 0, off=0,
+                 g_heads: Heads = None, dx_heads: Heads = None):
     """(dX [M,K], Gt [M,r] f32) = (G W + scale ((mask*G) up) down, scale (mask*G) up) of one site, weight-stationary on
-    W^T (mask = the forward's dropout mask when ``p`` > 0, all ones otherwise)."""
+    W^T (mask = the forward's dropout mask when ``p`` > 0, all ones otherwise).  ``g_heads``: G arrives head-padded (the
+    site's output was); ``dx_heads``: dX leaves head-padded (its input was)."""
     return linear_ws(g, [dict(wp=ws_pack(weight, True), N=weight.shape[1], down=up, up=down, scale=scale,
-                              t_scale=scale, flayout=3, p=p, seed=seed, off=off)], row_groups)[0]
+                              t_scale=scale, flayout=3, p=p, seed=seed, off=off, y_heads=dx_heads)], row_groups, g_heads)[0]
 
 
 _gemm_choice_bwd = _TuneCache("gemm_bwd")

@@ -22,6 +22,12 @@
 //   * sites that share the input (attn1 q/k/v, attn2 k/v) are panels of the same grid: grid = (panels of all sites) x
 //     (row groups); consecutive blocks of a row group land on the same XCD (b % 8), so the input tile is fetched from
 //     HBM once and re-read from that XCD's L2.
+// Head-padded activations (round 6; configs[3]'s dropout sites around the attention core): the input's 16-byte pieces are
+// fetched from their padded position (one magic multiply on the source address: the LDS tile is the dense one), the output's
+// 8-byte column groups go to their padded position and every live group of a head also writes one ZERO group into the head's
+// pad (D - d <= d: the first D - d live groups own one pad group each, the others repeat one of them — same value, and the
+// store count per tile stays exact for the counted waits).  Removes the pad / slice copies lora.forward_heads made around
+// this kernel (0.75 ms of a 35 ms configs[3] step).
 // The same entry point computes a site's input gradient dX = G W + scale (G up) down, Gt = scale G up when given the
 // weight packed in the transposed orientation (contraction over N) and the factors with their roles swapped.
 #include <algorithm>
@@ -70,6 +76,9 @@ struct WsArgs {
   const void *x;
   int64_t ldx, M;
   int32_t nsites, row_groups, ntiles, total_panels;
+  int32_t x_hc, x_hp;      // head-padded input: 16-byte chunks per head (live, padded); 0 = dense rows
+  uint32_t x_magic;        // ceil(2^32 / x_hc), 0 = dense
+  int32_t reserved;
   lora_amd_ws_site site[LORA_AMD_WS_MAX_SITES];
 };
 
@@ -97,7 +106,9 @@ __device__ inline float ws_pin(float v) { asm volatile("" : "+v"(v)); return v; 
 //   forward  — the rank-r term goes through its own MFMA, is multiplied by the lane's 4 mask values and added;
 //   backward — the G fragments that feed Gt = scale (mask*G) up are ANDed with the mask bits (one Philox call per
 //              fragment: its 8 k-slots are one chunk), 1/(1-p) is applied to T; the frozen product G W reads G unmasked.
-template <class E, int KF, int CS, int RS, int FL, int RM, bool DROP>
+// HD: head-padded activations — 0 none, 1 the input's rows, 2 the output's (own instantiations: the address arithmetic costs
+// ~28 registers, which the dense kernels at 500+ of 512 do not have; only the dropout sites are routed here with heads).
+template <class E, int KF, int CS, int RS, int FL, int RM, bool DROP, int HD = 0>
 __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a) {
   using S = typename E::storage;
   using F = typename WsMfma<E>::frag;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
   constexpr int NY = RS * CS;                   // output stores per wave and tile
   static_assert(K % 64 == 0 && (BM / 8) * NC % 4 == 0, "tile geometry");
   static_assert(kWsSlots * SLOT + 4 * BM * 16 * 4 <= 160 * 1024, "LDS budget");
-  static_assert(NY + NDMA <= 63, "vmcnt field");
+  static_assert((HD == 2 ? 2 : 1) * NY + NDMA <= 63, "vmcnt field (a head-padded output doubles the stores of a tile)");
   __shared__ __attribute__((aligned(1024))) char smem[kWsSlots * SLOT + 4 * BM * 16 * 4];
   float *tred = reinterpret_cast<float *>(smem + kWsSlots * SLOT);  // [4 waves][RS][64 lanes][4]: partial T^T
 
@@ -136,6 +147,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
   // the last valid row.  Addressing: one 64-bit tile base, 32-bit in-tile offsets.
   const int ldx32 = (int)ldx;
   const int lane_row = lane >> 3, lane_sw = lane & 7;
+  const uint32_t x_magic = a.x_magic;
+  const int x_hc = a.x_hc, x_hp = a.x_hp;
   auto issue_tile = [&](int tile, int slot) {
     const int64_t m0t = (int64_t)tile * BM;
     const S *tbase = x + m0t * ldx;
@@ -146,7 +159,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
       const int q = wave + 4 * u, c = q / (BM / 8), g = q - c * (BM / 8);  // wave-uniform
       const int rl = g * 8 + lane_row;
       const int rc = rl < rows_valid ? rl : rows_valid - 1;
-      ws_glds16(tbase + rc * ldx32 + c * 64 + ((lane_sw ^ (rl & 7)) << 3), sbase + (c * BM + g * 8) * 128);
+      // dense 16-byte chunk c * 8 + (swizzled slot) of the row -> its position in a head-padded row (x_magic = 0: unchanged)
+      if constexpr (HD == 1) {
+        const int cl = c * 8 + (lane_sw ^ (rl & 7));
+        const int qh = (int)__umulhi((uint32_t)cl, x_magic);
+        ws_glds16(tbase + rc * ldx32 + ((qh * x_hp + (cl - qh * x_hc)) << 3), sbase + (c * BM + g * 8) * 128);
+      } else {
+        ws_glds16(tbase + rc * ldx32 + c * 64 + ((lane_sw ^ (rl & 7)) << 3), sbase + (c * BM + g * 8) * 128);
+      }
     }
   };
 
@@ -222,6 +242,12 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
   const bool cols8 = n_wave + CS * 16 <= N;  // every column of this wave is in range: unconditional 8-byte stores
   const bool accum = st.flayout & 4;          // OUT += ... (input gradients of several sites meeting in one dX)
   const bool has_bias = st.bias != nullptr;
+  // head-padded output: 4-column groups per head, live (y_hd4) and padded (y_hp4); the launcher guarantees whole panels
+  // (cols8 everywhere), no accumulation, D - d <= d <= 2 (D - d)
+  const int y_hd4 = (st.y_heads & 0xffff) >> 2, y_hp4 = (int)((uint32_t)st.y_heads >> 16) >> 2;
+  constexpr bool yh = HD == 2;
+  const uint32_t y_magic = yh ? 0xFFFFFFFFu / (uint32_t)max(y_hd4, 1) + 1u : 0u;
+  const int y_pp = y_hp4 - y_hd4;
 
   // the small operands (oldest loads: hipcc's counted wait leaves the input pieces and the panel in flight): pin,
   // select, convert — before the k-loop, so that only fragments (64 registers), not raw values, live through it
@@ -266,7 +292,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
     } else {
       // tile `it` has landed for this wave: younger operations = previous tile's output stores + next tile's pieces
       const bool has_next = it + 1 < my_tiles;
-      if (cols8) { if (has_next) ws_wait_vmcnt<NY + NDMA>(); else ws_wait_vmcnt<NY>(); }
+      if constexpr (yh) { if (has_next) ws_wait_vmcnt<2 * NY + NDMA>(); else ws_wait_vmcnt<2 * NY>(); }
+      else if (cols8) { if (has_next) ws_wait_vmcnt<NY + NDMA>(); else ws_wait_vmcnt<NY>(); }
       else { if (has_next) ws_wait_vmcnt<NDMA>(); else ws_wait_vmcnt<0>(); }  // edge panel: store count not fixed
     }
     ws_barrier();  // ... and for every wave
@@ -378,7 +405,31 @@ __global__ __launch_bounds__(kWsThreads, 1) void linear_ws_kernel(const WsArgs a
       return o;
     };
     // ---- epilogue: lane holds OUT[m = i*16 + l15][n_wave + j*16 + lg*4 + 0..3]
-    if (cols8 && !accum) {  // the common case, branch-free: 8-byte stores, always issued (rows past M -> trash line)
+    if constexpr (yh) {
+      // head-padded rows: group g of the dense row -> head g / y_hd4, position g % y_hd4 of its y_hp4 slots; the same lane
+      // zeroes one pad group of that head (the first y_pp live groups own one each, the rest repeat one: 2 NY stores a tile)
+#pragma unroll
+      for (int i = 0; i < RS; ++i) {
+        const int64_t m = m0 + i * 16 + l15;
+        const bool row_ok = m < M;
+        S *yrow = y + (row_ok ? m : 0) * ldy;
+#pragma unroll
+        for (int j = 0; j < CS; ++j) {
+          union { u32x2 v; S s[4]; } o;
+          f32x4 val = acc[i][j];
+          if (DROP && FL == 0) val += dropped(i, j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.s[e] = E::from_f(val[e] + bv[j][e]);
+          const int g4 = (n_wave + j * 16 + lg * 4) >> 2;
+          const int qh = (int)__umulhi((uint32_t)g4, y_magic), u = g4 - qh * y_hd4;
+          const int hb = qh * y_hp4, v = u < y_pp ? u : u - y_pp;
+          u32x2 *live = row_ok ? reinterpret_cast<u32x2 *>(yrow + ((hb + u) << 2)) : reinterpret_cast<u32x2 *>(g_ws_trash);
+          u32x2 *pad = row_ok ? reinterpret_cast<u32x2 *>(yrow + ((hb + y_hd4 + v) << 2)) : reinterpret_cast<u32x2 *>(g_ws_trash);
+          *live = o.v;
+          *pad = (u32x2){0u, 0u};
+        }
+      }
+    } else if (cols8 && !accum) {  // the common case, branch-free: 8-byte stores, always issued (rows past M -> trash line)
 #pragma unroll
       for (int i = 0; i < RS; ++i) {
         const int64_t m = m0 + i * 16 + l15;
@@ -509,6 +560,16 @@ extern "C" int lora_amd_ws_pack(const void *w, int64_t stride_n, int64_t stride_
 
 extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t act_dtype,
                                   const lora_amd_ws_site *sites, int32_t nsites, int32_t row_groups, void *stream) {
+  return lora_amd_linear_ws_heads(x, ldx, M, K, 0, 0, act_dtype, sites, nsites, row_groups, stream);
+}
+
+// may a site's output (heads of d columns in slots of D) go through the padded epilogue: 8-byte groups, one pad group per live
+// group at most, at most two live groups per pad group
+static inline bool ws_y_heads_ok(int d, int D) { return d > 0 && d % 4 == 0 && D % 4 == 0 && D > d && D - d <= d && d <= 2 * (D - d) && D < 65536; }
+
+extern "C" int lora_amd_linear_ws_heads(const void *x, int64_t ldx, int64_t M, int32_t K, int32_t x_head_dim, int32_t x_head_pad,
+                                        int32_t act_dtype, const lora_amd_ws_site *sites, int32_t nsites, int32_t row_groups,
+                                        void *stream) {
   WsCfg c;
   LORA_AMD_CHECK(ws_cfg(K, &c), LORA_AMD_EINVAL, "linear_ws: contraction length %d has no weight-stationary kernel", K);
   LORA_AMD_CHECK(act_dtype == LORA_AMD_BF16 || act_dtype == LORA_AMD_F16, LORA_AMD_EINVAL, "linear_ws: bf16/f16 only");
@@ -516,6 +577,11 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
                  "linear_ws: bad argument (1..%d sites)", LORA_AMD_WS_MAX_SITES);
   LORA_AMD_CHECK(((uintptr_t)x % 16) == 0 && ldx % 8 == 0 && ldx >= K, LORA_AMD_EINVAL,
                  "linear_ws: input rows must be 16-byte aligned");
+  LORA_AMD_CHECK((x_head_dim == 0 && x_head_pad == 0) ||
+                     (x_head_dim >= 8 && x_head_dim % 8 == 0 && x_head_pad % 8 == 0 && x_head_pad >= x_head_dim &&
+                      K % x_head_dim == 0 && ldx >= (int64_t)(K / x_head_dim) * x_head_pad),
+                 LORA_AMD_EINVAL, "linear_ws: input head layout (%d in %d) does not fit K = %d, ldx = %lld", x_head_dim,
+                 x_head_pad, K, (long long)ldx);
   bool drop = false;
   for (int s = 0; s < nsites; ++s) {
     LORA_AMD_CHECK(sites[s].dropout_p >= 0.f && sites[s].dropout_p < 1.f, LORA_AMD_EINVAL,
@@ -524,11 +590,27 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
   }
   // forward with dropout at K = 320: the masked rank-r term keeps its own accumulators, which the 64-row tile has no
   // registers left for (495 of 512 in use) -> 32-row tiles
-  const bool half_rows = drop && (sites[0].flayout & 3) == 0 && K == 320;
+  // head-padded activations (own instantiations, dropout sites only): 1 = the input's rows, 2 = every site's output
+  int hd = x_head_dim ? 1 : 0;
+  for (int s = 0; s < nsites; ++s) {
+    LORA_AMD_CHECK((sites[s].y_heads != 0) == (sites[0].y_heads != 0), LORA_AMD_EINVAL,
+                   "linear_ws: site %d: head-padded outputs for every site of a launch or for none", s);
+    if (sites[s].y_heads != 0) {
+      LORA_AMD_CHECK(hd != 1, LORA_AMD_EINVAL, "linear_ws: head-padded input AND output in one launch is not built");
+      hd = 2;
+    }
+  }
+  LORA_AMD_CHECK(hd == 0 || drop, LORA_AMD_EINVAL,
+                 "linear_ws: head-padded activations are built for the dropout sites (p > 0) only; p = 0 sites with heads take "
+                 "lora_amd_linear_gemm_fwd_heads");
+  // ... and with head layouts in either direction (their address arithmetic costs ~28 registers)
+  const bool half_rows = drop && K == 320 && ((sites[0].flayout & 3) == 0 || hd != 0);
   if (half_rows) c.RS = 2;
   const int BN = c.CS * 64, BM = c.RS * 16;
   WsArgs a;
   a.x = x; a.ldx = ldx; a.M = M; a.nsites = nsites;
+  a.x_hc = x_head_dim >> 3; a.x_hp = x_head_pad >> 3; a.reserved = 0;
+  a.x_magic = x_head_dim ? (uint32_t)((0x100000000ull + (uint32_t)a.x_hc - 1) / (uint32_t)a.x_hc) : 0u;
   a.ntiles = (int)((M + BM - 1) / BM);
   int panels = 0;
   for (int s = 0; s < nsites; ++s) {
@@ -540,6 +622,14 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
                        ((uintptr_t)q.down % 16) == 0 && ((uintptr_t)q.up % 16) == 0 && ((uintptr_t)q.bias % 8) == 0 &&
                        ((uintptr_t)q.t_out % 16) == 0,
                    LORA_AMD_EINVAL, "linear_ws: site %d: N, ldy must be multiples of 4, pointers aligned", s);
+    if (q.y_heads != 0) {
+      const int d = q.y_heads & 0xffff, D = (int)((uint32_t)q.y_heads >> 16);
+      LORA_AMD_CHECK(ws_y_heads_ok(d, D) && q.N % d == 0 && q.N % BN == 0 && !(q.flayout & 4) &&
+                         q.ldy >= (int64_t)(q.N / d) * D,
+                     LORA_AMD_EINVAL,
+                     "linear_ws: site %d: head-padded output (%d in %d) needs whole %d-column panels, no accumulation, D - d <= d <= "
+                     "2 (D - d), ldy >= heads * D", s, d, D, BN);
+    }
     a.site[s].panel_begin = panels;
     panels += (q.N + BN - 1) / BN;
   }
@@ -572,30 +662,40 @@ extern "C" int lora_amd_linear_ws(const void *x, int64_t ldx, int64_t M, int32_t
   for (int s = 0; s < nsites; ++s)
     LORA_AMD_CHECK(!drop || sites[s].N % 8 == 0, LORA_AMD_EINVAL,
                    "linear_ws: site %d: dropout needs N %% 8 == 0 (mask chunks of 8 columns)", s);
-#define WS_D(E, KFV, CSV, RSV, DV)                                                                                 \
-  do {                                                                                                             \
-    if (fl == 3) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 3, 0, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else if (rm == 1) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 1, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else if (rm == 2) hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 2, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, 0, 0, DV>), dim3(grid), dim3(kWsThreads), 0, st, a); \
+#define WS_L(E, KFV, CSV, RSV, FLV, RMV, DV, HV) \
+  hipLaunchKernelGGL((linear_ws_kernel<E, KFV, CSV, RSV, FLV, RMV, DV, HV>), dim3(grid), dim3(kWsThreads), 0, st, a)
+#define WS_D(E, KFV, CSV, RSV, DV, HV)                          \
+  do {                                                          \
+    if (fl == 3) WS_L(E, KFV, CSV, RSV, 3, 0, DV, HV);          \
+    else if (rm == 1) WS_L(E, KFV, CSV, RSV, 0, 1, DV, HV);     \
+    else if (rm == 2) WS_L(E, KFV, CSV, RSV, 0, 2, DV, HV);     \
+    else WS_L(E, KFV, CSV, RSV, 0, 0, DV, HV);                  \
   } while (0)
-#define WS(E, KFV, CSV, RSV)                                  \
-  do {                                                        \
-    if (drop) WS_D(E, KFV, CSV, RSV, true);                   \
-    else WS_D(E, KFV, CSV, RSV, false);                       \
+#define WS_H(E, KFV, CSV, RSV) /* dropout sites: dense, head-padded input, head-padded output */ \
+  do {                                                          \
+    if (hd == 1) WS_D(E, KFV, CSV, RSV, true, 1);               \
+    else if (hd == 2) WS_D(E, KFV, CSV, RSV, true, 2);          \
+    else WS_D(E, KFV, CSV, RSV, true, 0);                       \
   } while (0)
-#define WS_K(E)                                  \
-  do {                                           \
-    if (K == 320 && half_rows) WS_D(E, 10, 5, 2, true); \
-    else if (K == 320 && drop) /* input gradient */ hipLaunchKernelGGL((linear_ws_kernel<E, 10, 5, 4, 3, 0, true>), dim3(grid), dim3(kWsThreads), 0, st, a); \
-    else if (K == 320) WS_D(E, 10, 5, 4, false); \
-    else if (K == 640) WS(E, 20, 2, 2);          \
-    else if (K == 768) WS(E, 24, 2, 2);          \
-    else WS(E, 40, 1, 1);                        \
+#define WS(E, KFV, CSV, RSV)                                    \
+  do {                                                          \
+    if (drop) WS_H(E, KFV, CSV, RSV);                           \
+    else WS_D(E, KFV, CSV, RSV, false, 0);                      \
+  } while (0)
+#define WS_K(E)                                                 \
+  do {                                                          \
+    if (K == 320 && half_rows) WS_H(E, 10, 5, 2);               \
+    else if (K == 320 && drop) /* input gradient, dense */ WS_L(E, 10, 5, 4, 3, 0, true, 0); \
+    else if (K == 320) WS_D(E, 10, 5, 4, false, 0);             \
+    else if (K == 640) WS(E, 20, 2, 2);                         \
+    else if (K == 768) WS(E, 24, 2, 2);                         \
+    else WS(E, 40, 1, 1);                                       \
   } while (0)
   if (act_dtype == LORA_AMD_BF16) WS_K(bf16_t); else WS_K(f16_t);
 #undef WS_K
 #undef WS
+#undef WS_H
 #undef WS_D
+#undef WS_L
   return check_launch("lora_amd_linear_ws");
 }

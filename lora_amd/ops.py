@@ -74,6 +74,9 @@ class dropout_pool:
 # choice is another kernel, forward and backward (the alternative there is the rank-16 VALU kernel on top of the library
 # GEMM; configs[3], same box: 21.26 -> 22.20 -> 22.44 steps/s, round 2).  Module constants (tests flip them), no switches.
 WS_DROPOUT = WS_DROPOUT_WIDE = WS_DROPOUT_WIDE_BWD = True
+# the dropout sites around the attention core in head-padded rows on the weight-stationary kernel (round 6; False = the
+# unpack -> kernel -> pack copies of rounds 3-5: the A/B and the parity twin)
+WS_HEADS = True
 
 
 # When a list: every adapter forward / backward appends (phase, kernel path, M, K, N, r) — what bench.py turns into
@@ -255,15 +258,26 @@ class LoraLinearFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, down, up, sel, scale, dropout_p, sink):
+    def forward(ctx, x, weight, bias, down, up, sel, scale, dropout_p, sink, in_heads=None, out_heads=None):
         _C.require()
         N, K = weight.shape
         r = down.shape[0]
-        x2 = _rows2d(x, K)
+        x2 = _rows2d(x, _C.heads_width(K, in_heads))
         seed = off = 0
         if dropout_p > 0.0:
             seed, off = next_dropout_stream(x.device)
         down_c, up_c = down.contiguous(), up.contiguous()
+        ctx.in_heads, ctx.out_heads = in_heads, out_heads
+        if in_heads is not None or out_heads is not None:
+            # a dropout site around the attention core (ws_heads_route_ok was the caller's check): the weight-stationary
+            # kernel reads / writes the head-padded rows itself — no pad / slice copy on either side
+            y, t = _C.linear_ws_fwd(x2, weight, bias, down_c, up_c, scale, 0, dropout_p, seed, off, x_heads=in_heads,
+                                    y_heads=out_heads)
+            _log("fwd", "ws_heads", x2.shape[0], K, N, r)
+            ctx.save_for_backward(x2, weight, down, up, t, sel)
+            ctx.scale, ctx.p, ctx.seed, ctx.off = float(scale), float(dropout_p), seed, off
+            ctx.has_bias, ctx.x_shape, ctx.sink, ctx.fused = bias is not None, x.shape, sink, True
+            return y.view(*x.shape[:-1], y.shape[1])
         tile = 0
         if (sel is None and down_c.dtype == torch.float32 and up_c.dtype == torch.float32
                 and x2.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x2.dtype):
@@ -301,8 +315,66 @@ class LoraLinearFunction(torch.autograd.Function):
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
+    def _backward_heads(ctx, g):
+        """Backward of a dropout site whose forward ran in head-padded rows: dX / Gt on the weight-stationary kernel in the
+        same layouts and both factor gradients in the step's deferred matrix-core pass (which takes the head layouts and
+        regenerates the mask); anything else — no trainer state, a shape the kernels refuse — detours through dense copies
+        and the regular backward."""
+        x2, weight, down, up, t, sel = ctx.saved_tensors
+        in_heads, out_heads = ctx.in_heads, ctx.out_heads
+        N, K = weight.shape
+        r, M = down.shape[0], x2.shape[0]
+        g2 = _rows2d(g, _C.heads_width(N, out_heads))
+        if not _C._rows_ok(g2):
+            g2 = g2.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        s, p, seed, off, sink = ctx.scale, ctx.p, ctx.seed, ctx.off, ctx.sink
+        down_c, up_c = down.contiguous(), up.contiguous()
+        mw = getattr(getattr(sink, "owner", None), "merged", None)
+        plan_m = None
+        if (mw is not None and mw.defer_factors and _C.FACTORS_MFMA and DEFER_MASKED_FACTORS and not need_w
+                and g2.dtype == x2.dtype):
+            plan_m = _C.factors_mfma_plan(M, K, N, r, g2.dtype)
+            if not plan_m.supported:
+                plan_m = None
+        dx_ok = (not need_x) or (WS_DROPOUT and _C.ws_supported(g2, N, K, r) and weight.is_contiguous()
+                                 and _C.ws_heads_ok(N, K, out_heads, in_heads))
+        if plan_m is None or not dx_ok:
+            from types import SimpleNamespace
+
+            x_log = unpack_heads(x2, in_heads) if in_heads else x2
+            g_log = unpack_heads(g2, out_heads) if out_heads else g2
+            fake = SimpleNamespace(saved_tensors=(x_log, weight, down, up, t, sel), in_heads=None, out_heads=None,
+                                   needs_input_grad=tuple(ctx.needs_input_grad[:5]) + (False,) * 6, scale=s, p=p,
+                                   seed=seed, off=off, sink=sink, fused=_C.fused_ok(x_log, N, r), has_bias=ctx.has_bias,
+                                   x_shape=x_log.shape)
+            dx, dw, db, d_down, d_up = LoraLinearFunction.backward(fake, g_log)[:5]
+            if dx is not None:
+                if in_heads:
+                    dx = pack_heads(dx, in_heads)
+                dx = dx.view(*ctx.x_shape[:-1], dx.shape[-1])
+            return dx, dw, db, d_down, d_up, None, None, None, None, None, None
+        if sink.pending is not None:
+            sink.flush()
+        dx = None
+        if need_x:
+            dx2, _gt = _C.linear_ws_dx(g2, weight, down_c, up_c, s, 0, p, seed, off, g_heads=out_heads, dx_heads=in_heads)
+            dx = dx2.view(*ctx.x_shape[:-1], dx2.shape[1])
+        key = ("mfma", M, K, N, r, int(plan_m.nparts))
+        up_part_m, down_part_m = sink.self_workspace(key, plan_m, g2.device)
+        mw.owe(g2, x2, down_c, up_c, up_part_m, down_part_m, s, out_heads, in_heads, "mfma", plan_m, (p, seed, off))
+        _log("bwd", ("ws_heads_dx+" if need_x else "") + "factors_deferred_mfma", M, K, N, r)
+        sink.pending = key
+        db = None
+        if ctx.has_bias and need_b:
+            db = (unpack_heads(g2, out_heads) if out_heads else g2).sum(0)
+        return dx, None, db, None, None, None, None, None, None, None, None
+
+    @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if getattr(ctx, "in_heads", None) is not None or getattr(ctx, "out_heads", None) is not None:
+            return LoraLinearFunction._backward_heads(ctx, g)
         x2, weight, down, up, t, sel = ctx.saved_tensors
         N, K = weight.shape
         r = down.shape[0]
@@ -337,7 +409,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 _log("bwd", "factors_deferred_mfma", M, K, N, r)
                 sink.pending = key
                 db = g2.sum(0) if (ctx.has_bias and need_b) else None
-                return None, None, db, None, None, None, None, None, None
+                return None, None, db, None, None, None, None, None, None, None, None
             # the per-site partial slabs (Gt column tiles, dUp / dDown row blocks) exist only on the paths that write them: a
             # site whose factor gradients go to the step's deferred matrix-core pass registers nothing here (the
             # dead slabs of every dropout site, and a reset of the trainer's reduce table per site)
@@ -434,7 +506,7 @@ class LoraLinearFunction(torch.autograd.Function):
                 dx = dx2.view(ctx.x_shape)
         dw = g2.t() @ x2 if need_w else None
         db = g2.sum(0) if (ctx.has_bias and need_b) else None
-        return dx, dw, db, d_down, d_up, None, None, None, None
+        return dx, dw, db, d_down, d_up, None, None, None, None, None, None
 
 
 # Module constants (tests and A/B scripts flip them; not environment switches):
@@ -470,7 +542,7 @@ CONV3_FUSED = True
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "FM_LONGEST_FIRST", "FM_LONGEST_FIRST_CLASS1", "CONV3_FUSED", "WS_DROPOUT",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "FM_LONGEST_FIRST", "FM_LONGEST_FIRST_CLASS1", "CONV3_FUSED", "WS_HEADS", "WS_DROPOUT",
                "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
@@ -1129,6 +1201,26 @@ class LoraLinearHeadsFunction(torch.autograd.Function):
         return dx, None, db, d_down, d_up, None, None, None, None, None
 
 
+def ws_heads_route_ok(x, weight, down, up, sel, dropout_p, in_heads, out_heads) -> bool:
+    """May a dropout site with head-padded input OR output run ``LoraLinearFunction`` in those layouts: the forward is the
+    weight-stationary kernel's (the route ``WS_DROPOUT_WIDE`` takes for dense rows too), contraction and panel widths fit
+    (``_C.ws_heads_ok``).  The backward decides for itself and can always detour through dense copies."""
+    if not (WS_HEADS and WS_DROPOUT and WS_DROPOUT_WIDE and x.is_cuda and dropout_p > 0.0 and sel is None):
+        return False
+    if (in_heads is None) == (out_heads is None):
+        return False
+    N, K = weight.shape
+    r = down.shape[0]
+    if not (down.dtype == torch.float32 and up.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16)
+            and weight.dtype == x.dtype and weight.is_contiguous() and N % 8 == 0 and not (K == 1280 and N >= 4 * K)):
+        return False
+    kw = _C.heads_width(K, in_heads)
+    if x.shape[-1] != kw or x.numel() == 0:
+        return False
+    x2 = x.reshape(-1, kw)
+    return bool(_C.ws_supported(x2, K, N, r) and _C.ws_heads_ok(K, N, in_heads, out_heads))
+
+
 def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], down: torch.Tensor,
                 up: torch.Tensor, sel: Optional[torch.Tensor], scale: float, dropout_p: float,
                 sink: Optional[GradSink] = None, in_heads=None, out_heads=None) -> torch.Tensor:
@@ -1145,6 +1237,10 @@ def lora_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         tile = _C.gemm_choice_cached(M, K, N, r, x.dtype, bias is not None) or 0
     if tile:
         return LoraLinearHeadsFunction.apply(x, weight, bias, down, up, float(scale), sink, in_heads, out_heads, tile)
+    if ws_heads_route_ok(x, weight, down, up, sel, dropout_p, in_heads, out_heads):
+        # nn.Dropout on the branch (configs[3]): the weight-stationary kernel in the padded layouts, both directions
+        return LoraLinearFunction.apply(x, weight, bias, down, up, None, float(scale), float(dropout_p), sink, in_heads,
+                                        out_heads)
     # dense detour (CPU tensors, shapes the fused kernel does not take, or a shape not timed yet: the regular function
     # times it, so the next call stays in the padded layout)
     y = LoraLinearFunction.apply(unpack_heads(x, in_heads) if in_heads else x, weight, bias, down, up, sel,

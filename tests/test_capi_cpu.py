@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"declared in include/lora_amd.h but not exported: {missing}"
     assert sorted(_C.SYMBOLS) == declared, "lora_amd/_C.py SYMBOLS out of sync with the header"
-    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 6 and lib.lora_amd_target_arch() == b"gfx950"
+    assert lib.lora_amd_abi_version() == _C.ABI_VERSION == 7 and lib.lora_amd_target_arch() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
