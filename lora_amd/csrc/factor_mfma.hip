@@ -551,7 +551,9 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   // which site: the table's block prefix is fetched once, in parallel, and searched in LDS (a search over the table in
   // memory is eight DEPENDENT trips to L2 in front of the block's first load).  A workgroup per row block: walking runs of
   // 2 / 4 / 8 consecutive blocks per workgroup (launch and lookup paid once per run) measured 2-60 % SLOWER
-  // (profiles/r06_kbench_fm_span.log).
+  // (profiles/r06_kbench_fm_span.log), and so did a persistent launch — one workgroup per resident slot drawing its next
+  // block from a counter behind the current block's loads: 5-28 % slower, parity-green (profiles/r06_kbench_fm_persistent.log,
+  // the patch beside it) — although the stage stamps show a slot empty for ~3.7 us between two workgroups.
   int lo = 0, hi = n - 1;
   if (n <= kFrSitesLds) {
     for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
