@@ -622,6 +622,14 @@ int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_t n, int32_
  * instantiation); a class-1 table has one height (lora_amd_factors_mfma_ragged_plan refuses a mixed one). */
 int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid, int32_t lds_class,
                                             int32_t rows_per_block, int32_t act_dtype, int32_t masked, void *stream);
+/* ABI 7: the same launch with the plan's block -> site map on the device (grid int32 entries, filled on the host by
+ * lora_amd_factors_mfma_block_map from a planned table): a workgroup finds its site with ONE scalar load instead of copying the
+ * table's block prefix to LDS and searching it (1.2 us of a 12.8 us block of the 320-wide sites).  block_map_dev = NULL is the
+ * entry above. */
+int lora_amd_factors_mfma_block_map(const lora_amd_fm_site *sites /* host, planned */, int32_t n, int64_t grid, int32_t *map);
+int lora_amd_linear_bwd_factors_mfma_ragged_mapped(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
+                                                   const int32_t *block_map_dev, int32_t lds_class, int32_t rows_per_block,
+                                                   int32_t act_dtype, int32_t masked, void *stream);
 /* Tuning / test hook: which kernel a table of class 1 (64-row blocks) runs — 0 = the 10-pair kernel every class can take (two
  * workgroups per CU, two column groups in flight per wave), 1 / 2 = the 6-pair kernel at three workgroups per CU with 1 / 2
  * groups in flight, 3 / 4 / 5 = the 6-pair kernel at two per CU with 2 / 3 / 4 groups in flight; < 0 only reads.  Returns the

@@ -41,7 +41,8 @@ SYMBOLS = (
     "lora_amd_linear_factors_self_plan", "lora_amd_linear_factors_self_plan_rows", "lora_amd_linear_bwd_factors_self",
     "lora_amd_linear_factors_self_ragged_plan", "lora_amd_linear_bwd_factors_self_ragged",
     "lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
-    "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged",
+    "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged", "lora_amd_factors_mfma_block_map",
+    "lora_amd_linear_bwd_factors_mfma_ragged_mapped",
     "lora_amd_linear_gemm_fwd_heads",
     "lora_amd_reduce_batched", "lora_amd_linear_gemm_supported", "lora_amd_linear_gemm_fwd",
     "lora_amd_ws_config", "lora_amd_ws_packed_elems", "lora_amd_ws_pack", "lora_amd_linear_ws", "lora_amd_linear_ws_heads",
@@ -336,6 +337,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.lora_amd_factor_pack.argtypes = [vp, i32, i64, i32, vp]
     lib.lora_amd_factors_mfma_ragged_plan.argtypes = [C.POINTER(FmSite), i32, i32, i32, C.POINTER(i64)]
     lib.lora_amd_linear_bwd_factors_mfma_ragged.argtypes = [vp, i32, i64, i32, i32, i32, i32, vp]
+    lib.lora_amd_factors_mfma_block_map.argtypes = [C.POINTER(FmSite), i32, i64, C.POINTER(i32)]
+    lib.lora_amd_linear_bwd_factors_mfma_ragged_mapped.argtypes = [vp, i32, i64, vp, i32, i32, i32, i32, vp]
+    lib.lora_amd_factors_mfma_block_map.restype = lib.lora_amd_linear_bwd_factors_mfma_ragged_mapped.restype = C.c_int
     for name in ("lora_amd_factors_mfma_plan", "lora_amd_factor_pack_plan", "lora_amd_factor_pack",
                  "lora_amd_factors_mfma_ragged_plan", "lora_amd_linear_bwd_factors_mfma_ragged"):
         getattr(lib, name).restype = C.c_int
@@ -1329,9 +1333,32 @@ def factors_mfma_table(sites, act_dtype: torch.dtype, lds_class: int):
     return arr, grid.value
 
 
+def factors_mfma_block_map(arr, grid: int):
+    """The block -> site map of a planned table (``factors_mfma_table``'s ``arr``): a ctypes int32 array of ``grid`` entries
+    for ``linear_bwd_factors_mfma_ragged(..., block_map=)`` (uploaded behind the table by ``factors_mfma_table_bytes``)."""
+    m = (C.c_int32 * int(grid))()
+    _check(require().lora_amd_factors_mfma_block_map(arr, len(arr), int(grid), m), "lora_amd_factors_mfma_block_map")
+    return m
+
+
+def factors_mfma_table_bytes(arr, grid: int) -> Tuple[bytes, int]:
+    """(table bytes + the block map behind them, byte offset of the map): one upload, one buffer."""
+    raw = bytes(arr)
+    pad = (-len(raw)) % 16
+    return raw + b"\0" * pad + bytes(factors_mfma_block_map(arr, grid)), len(raw) + pad
+
+
 def linear_bwd_factors_mfma_ragged(table_dev: torch.Tensor, n: int, grid: int, lds_class: int,
-                                   act_dtype: torch.dtype, masked: bool = False, rows: int = 64) -> None:
-    """``rows``: the block height (``plan.rows_per_block``) of EVERY site of the table (one per table, ABI 6)."""
+                                   act_dtype: torch.dtype, masked: bool = False, rows: int = 64, map_offset: int = 0) -> None:
+    """``rows``: the block height (``plan.rows_per_block``) of EVERY site of the table (one per table, ABI 6).
+    ``map_offset`` > 0: the table buffer holds the block -> site map at that byte offset (``factors_mfma_table_bytes``)."""
+    if map_offset:
+        _check(require().lora_amd_linear_bwd_factors_mfma_ragged_mapped(table_dev.data_ptr(), n, grid,
+                                                                        table_dev.data_ptr() + int(map_offset), lds_class,
+                                                                        int(rows), dtype_code(act_dtype), int(bool(masked)),
+                                                                        _stream()),
+               "lora_amd_linear_bwd_factors_mfma_ragged_mapped")
+        return
     _check(require().lora_amd_linear_bwd_factors_mfma_ragged(table_dev.data_ptr(), n, grid, lds_class, int(rows),
                                                              dtype_code(act_dtype), int(bool(masked)), _stream()),
            "lora_amd_linear_bwd_factors_mfma_ragged")

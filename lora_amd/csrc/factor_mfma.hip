@@ -535,7 +535,8 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
 
 // HEIGHTS: 1 = every site of the table has 64-row blocks, 0 = 32-row blocks, 2 = both (dispatch per workgroup)
 template <class E, bool DROP, int kFrPairs, int MINB, int RG64, int RG32, int HEIGHTS>
-__global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n) {
+__global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lora_amd_fm_site *__restrict__ sites, int n,
+                                                                              const int32_t *__restrict__ block_map) {
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4 * 32 * kFrPitch];
   __shared__ __attribute__((aligned(16))) float s_part[4 * 64 * 16];   // [wave][row][j]
   __shared__ __attribute__((aligned(16))) mu32x4 s_tf[2 * 2 * 64];     // [row step][hi, lo][lane]
@@ -554,8 +555,12 @@ __global__ __launch_bounds__(kFmThreads, MINB) void factors_reg_kernel(const lor
   // (profiles/r06_kbench_fm_span.log), and so did a persistent launch — one workgroup per resident slot drawing its next
   // block from a counter behind the current block's loads: 5-28 % slower, parity-green (profiles/r06_kbench_fm_persistent.log,
   // the patch beside it) — although the stage stamps show a slot empty for ~3.7 us between two workgroups.
+  // (round 6, third session) ... or not searched at all: the plan's block -> site map (lora_amd_factors_mfma_block_map) is ONE
+  // scalar load off blockIdx — the prefix copy, its barrier and nine dependent LDS reads were 1.2 us of a 12.8 us block
   int lo = 0, hi = n - 1;
-  if (n <= kFrSitesLds) {
+  if (block_map != nullptr) {
+    lo = block_map[blockIdx.x];
+  } else if (n <= kFrSitesLds) {
     for (int i = tid; i < n; i += kFmThreads) s_begin[i] = sites[i].block_begin;
     __syncthreads();
 #ifdef FM_TRACE
@@ -761,9 +766,33 @@ extern "C" int lora_amd_factors_mfma_ragged_plan(lora_amd_fm_site *sites, int32_
   return LORA_AMD_OK;
 }
 
+extern "C" int lora_amd_factors_mfma_block_map(const lora_amd_fm_site *sites, int32_t n, int64_t grid, int32_t *map) {
+  LORA_AMD_CHECK(sites && map && n >= 1 && grid >= 1, LORA_AMD_EINVAL, "factors_mfma_block_map: bad argument");
+  int64_t b = 0;
+  for (int i = 0; i < n; ++i) {
+    LORA_AMD_CHECK(sites[i].block_begin == b, LORA_AMD_EINVAL,
+                   "factors_mfma_block_map: site %d begins at block %lld, expected %lld (plan the table first)", i,
+                   (long long)sites[i].block_begin, (long long)b);
+    const int64_t end = i + 1 < n ? sites[i + 1].block_begin : grid;
+    LORA_AMD_CHECK(end > b && end <= grid, LORA_AMD_EINVAL, "factors_mfma_block_map: site %d: blocks [%lld, %lld) outside the grid", i,
+                   (long long)b, (long long)end);
+    for (; b < end; ++b) map[b] = i;
+  }
+  return LORA_AMD_OK;
+}
+
 extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
                                                        int32_t lds_class, int32_t rows_per_block, int32_t act_dtype,
                                                        int32_t masked, void *stream) {
+  return lora_amd_linear_bwd_factors_mfma_ragged_mapped(sites_dev, n, grid, nullptr, lds_class, rows_per_block, act_dtype, masked,
+                                                        stream);
+}
+
+extern "C" int lora_amd_linear_bwd_factors_mfma_ragged_mapped(const lora_amd_fm_site *sites_dev, int32_t n, int64_t grid,
+                                                              const int32_t *block_map_dev, int32_t lds_class,
+                                                              int32_t rows_per_block, int32_t act_dtype, int32_t masked,
+                                                              void *stream) {
+  LORA_AMD_CHECK(((uintptr_t)block_map_dev % 4) == 0, LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: block map not aligned");
   LORA_AMD_CHECK(sites_dev && n >= 1 && grid >= 1 && grid < (1ll << 31) && (lds_class == 1 || lds_class == 2),
                  LORA_AMD_EINVAL, "linear_bwd_factors_mfma_ragged: bad argument");
   LORA_AMD_CHECK(rows_per_block == 32 || rows_per_block == 64 || rows_per_block == 0, LORA_AMD_EINVAL,
@@ -779,7 +808,7 @@ extern "C" int lora_amd_linear_bwd_factors_mfma_ragged(const lora_amd_fm_site *s
   // lora_amd_factors_mfma_set_tuning; everything else: the 10-pair kernel of its block height
   const int narrow = (lds_class == 1 && rows_per_block == 64) ? g_fm_narrow : 0;
   if (lds_class == 1 && rows_per_block != 64 && rows_per_block != 32) rows_per_block = 64;
-#define FML(E, D, P, B, G64, G32, H) hipLaunchKernelGGL((factors_reg_kernel<E, D, P, B, G64, G32, H>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n)
+#define FML(E, D, P, B, G64, G32, H) hipLaunchKernelGGL((factors_reg_kernel<E, D, P, B, G64, G32, H>), dim3((unsigned)grid), dim3(kFmThreads), 0, st, sites_dev, n, block_map_dev)
 #define FM2(E, D)                                                            \
   do {                                                                       \
     if (narrow == 1) FML(E, D, kFrPairsNarrow, 3, 1, 1, 1);                  \

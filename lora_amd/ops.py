@@ -533,6 +533,9 @@ CONCURRENT_FACTOR_LAUNCHES = False
 # 319-321 -> 323 us (its blocks differ 5x, but the wide ones are a third of them and already interleaved): class 2 only
 FM_LONGEST_FIRST = True
 FM_LONGEST_FIRST_CLASS1 = False
+# the factor pass finds a workgroup's site through the plan's block -> site map (one scalar load) instead of copying the table's
+# block prefix to LDS and searching it (third session of round 6; False = the search: the A/B)
+FM_BLOCK_MAP = True
 # the channels-last 3x3 site as ONE forward launch (csrc/conv_nhwc.hip, round 6: batched pack once per optimiser step + the
 # fused down-conv / fold / up-projection / dropout / add kernel) and its G pass with the Gt fold inside the launch; False =
 # the launch sequence of rounds 3-5 (pack + down [+ sum_parts] + rank_update; bwd_g + sum_parts): the A/B and the parity twin
@@ -542,7 +545,7 @@ CONV3_FUSED = True
 def apply_ab_overrides(spec: str, namespace: dict) -> dict:
     """``LORA_AMD_AB="NAME=0,OTHER=1"``: the ONE measurement switch for same-box A/B runs — flips the module constants
     above (and only those) without a code edit; every A/B log under profiles/ names the spec it ran with."""
-    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "FM_LONGEST_FIRST", "FM_LONGEST_FIRST_CLASS1", "CONV3_FUSED", "WS_HEADS", "WS_DROPOUT",
+    allowed = ("TRANSPOSED_DX", "DEFER_MASKED_FACTORS", "CONCAT_GROUPS", "RANK16_MFMA", "FM_TWO_CLASSES", "CONCURRENT_FACTOR_LAUNCHES", "FM_LONGEST_FIRST", "FM_LONGEST_FIRST_CLASS1", "FM_BLOCK_MAP", "CONV3_FUSED", "WS_HEADS", "WS_DROPOUT",
                "WS_DROPOUT_WIDE",
                "WS_DROPOUT_WIDE_BWD")
     done = {}
@@ -891,9 +894,11 @@ class MergedWeights:
                     rows.append((g2, x2, pk[0], pk[1], up_part, down_part, scale, g_heads, x_heads, down.shape[0],
                                  plan, drop))
                 arr, grid = _C.factors_mfma_table(rows, dt, cls[0])
-                dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)
-                launches.append((grid, lambda dev=dev, n=len(sites), grid=grid, cls=cls, dt=dt:
-                                 _C.linear_bwd_factors_mfma_ragged(dev, n, grid, cls[0], dt, cls[1], cls[2])))
+                # the block -> site map rides behind the table (one upload): a workgroup finds its site with one scalar load
+                raw, moff = _C.factors_mfma_table_bytes(arr, grid) if FM_BLOCK_MAP else (bytes(arr), 0)
+                dev = self._upload((kind, dt, rt, cls), raw, dev0, capturing)
+                launches.append((grid, lambda dev=dev, n=len(sites), grid=grid, cls=cls, dt=dt, moff=moff:
+                                 _C.linear_bwd_factors_mfma_ragged(dev, n, grid, cls[0], dt, cls[1], cls[2], moff)))
             else:
                 arr, grid = _C.factors_self_ragged_table([st[:9] for st in sites], dt)
                 dev = self._upload((kind, dt, rt, cls), bytes(arr), dev0, capturing)

@@ -433,6 +433,15 @@ def bench_fm(args):
         rec[f"mfma_class{cls}_rows{rpb}"] = {"sites": len(ss), "blocks": grid, "GX_GB": round(b / 1e9, 4), "us": round(t * 1e6, 1),
                                              "frac8": round(b / 8e12 / t, 3)}
         tot += t
+    # the same launches with the block -> site map behind the table (ABI 7): one scalar load instead of the LDS prefix search
+    for (cls, rpb), ss in sorted(by_cls.items()):
+        arr, grid = _C.factors_mfma_table(ss, dt, cls)
+        raw, moff = _C.factors_mfma_table_bytes(arr, grid)
+        tabm = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tabm, len(ss), grid, cls, dt, False, rpb, moff), inner=5)
+        rec[f"mapped_class{cls}_rows{rpb}_us"] = round(t * 1e6, 1)
+        t, _ = timeit(lambda: _C.linear_bwd_factors_mfma_ragged(tabm, len(ss), grid, cls, dt, False, rpb), inner=5)
+        rec[f"search_class{cls}_rows{rpb}_us"] = round(t * 1e6, 1)
     # class 1 on each of its kernels (lora_amd_factors_mfma_set_tuning): 0 = 10 pairs, two workgroups per CU, 2 groups in flight;
     # 1 / 2 = 6 pairs, three per CU, 1 / 2 groups in flight; 3 / 4 / 5 = 6 pairs, two per CU, 2 / 3 / 4 groups in flight
     for tab, ns, grid, cls, rpb in tabs:

@@ -347,3 +347,43 @@ def test_bracket_under_the_reference_precision_policy(monkeypatch):
     assert ref_pol["aggregate"] <= 1.15 and ref_pol["median"] <= 1.15, ref_pol
     assert reps["reference policy (f32 host + autocast), merged weights"]["aggregate"] <= 1.25
     assert res["aggregate"] >= ref_pol["aggregate"]   # ... and the bf16-resident host is where the excess comes from
+
+
+def test_factor_pass_block_map_finds_the_same_sites_as_the_search():
+    """ABI 7: lora_amd_linear_bwd_factors_mfma_ragged_mapped (a workgroup reads its site index from the plan's block -> site map)
+    against the launch that searches the table's block prefix: a class-2 table of four sites with both block heights and a ragged
+    last block, and a class-1 table — the slabs are the same bits; a map that disagrees with the table is refused on the host."""
+    dt, r = torch.bfloat16, 4
+    for cls, shapes in ((2, [(300, 1280, 1280), (4096, 640, 640), (1000, 640, 5120), (77, 1280, 640)]),
+                        (1, [(2048, 320, 320), (1000, 320, 2560), (154, 768, 320)])):
+        rows, packs, slabs = [], [], []
+        for i, (M, K, N) in enumerate(shapes):
+            x, g = rnd((M, K), "bf16", seed=40 + i), rnd((M, N), "bf16", seed=60 + i)
+            down, up = rnd((r, K), "f32", 0.2, seed=80 + i), rnd((N, r), "f32", 0.3, seed=90 + i)
+            plan = _C.factors_mfma_plan(M, K, N, r, dt)
+            assert plan.supported and int(plan.lds_class) == cls, (M, K, N, plan.lds_class)
+            up_part = torch.full((int(plan.up_part_floats),), float("nan"), device=DEV)
+            down_part = torch.full((int(plan.down_part_floats),), float("nan"), device=DEV)
+            pk_down = torch.empty(int(plan.pack_down_elems), dtype=dt, device=DEV)
+            pk_up = torch.empty(int(plan.pack_up_elems), dtype=dt, device=DEV)
+            packs.append((down, up, pk_down, pk_up))
+            rows.append((g, x, pk_down, pk_up, up_part, down_part, 0.7, None, None, r, plan))
+            slabs += [up_part, down_part]
+        arr, total = _C.factor_pack_table(packs)
+        _C.factor_pack(_C.table_to_device(arr, DEV), len(packs), total, dt)
+        arr, grid = _C.factors_mfma_table(rows, dt, cls)
+        heights = {int(row[10].rows_per_block) for row in rows}
+        rpb = heights.pop() if len(heights) == 1 else 0
+        _C.linear_bwd_factors_mfma_ragged(_C.table_to_device(arr, DEV), len(rows), grid, cls, dt, False, rpb)
+        want = [s_.clone() for s_ in slabs]
+        for s_ in slabs:
+            s_.fill_(float("nan"))
+        raw, moff = _C.factors_mfma_table_bytes(arr, grid)
+        assert moff % 16 == 0 and len(raw) == moff + 4 * grid
+        tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
+        _C.linear_bwd_factors_mfma_ragged(tab, len(rows), grid, cls, dt, False, rpb, moff)
+        for a, b in zip(slabs, want):
+            assert not bool(torch.isnan(a).any()) and torch.equal(a, b)
+    unplanned = (_C.FmSite * 2)()   # block_begin = 0 twice: not a planned table
+    with pytest.raises(Exception):
+        _C.factors_mfma_block_map(unplanned, 8)
