@@ -580,8 +580,10 @@ typedef struct lora_amd_factors_mfma_plan_t {
 /* rows: 0 = the planner's choice (64, else 32), else 32 / 64 tried first.  flags: reserved (0). */
 int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32_t r, int32_t act_dtype, int32_t rows, int32_t flags,
                                lora_amd_factors_mfma_plan_t *out);
-/* f32 masters -> fragment packs: pk[split][c/8][16][8] in the activation dtype, split 0 = rounded value, split 1 = the
- * remainder, ranks >= r zero; pk_down from down [r, K], pk_up from up [N, r].  `begin` is filled by the plan (host). */
+/* f32 masters -> fragment packs: pk[split][c/8][RT][8] in the activation dtype (RT = the rank tile 4 / 8 / 16 of r; ABI 7 — it was
+ * [16] whatever the rank: a rank-4 pack is a quarter of the bytes now), split 0 = rounded value, split 1 = the remainder, ranks
+ * r .. RT - 1 zero; pk_down from down [r, K], pk_up from up [N, r]; sizes from lora_amd_factors_mfma_plan (pack_*_elems =
+ * 2 C RT + 8).  `begin` is filled by the plan (host). */
 typedef struct lora_amd_pack_site {
   const float *down, *up;
   void *pk_down, *pk_up;

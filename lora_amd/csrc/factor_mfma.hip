@@ -73,11 +73,15 @@ __device__ __forceinline__ int fm_hchunk(int c, const FmHeads &h) {
 
 // ---------------------------------------------------------------------------------------------------------- factor pack
 // f32 masters -> MFMA fragment order in the activation dtype, hi and lo parts:
-//   pk[split][c8][jj][e] = part_split(factor(jj, c8 * 8 + e))   jj < r, else 0;   16 x 8 elements = 256 B per c8
-// factor(jj, c) = down[jj, c] (FACTOR_RK) or up[c, jj] (FACTOR_KR).  A k-step's fragment (4 consecutive c8) is 1 KB
-// contiguous and lane l reads its 16 bytes at l * 16.
+//   pk[split][c8][jj][e] = part_split(factor(jj, c8 * 8 + e))   jj < RT (the rank tile 4 / 8 / 16; 0 for r <= jj < RT):
+//   RT x 8 elements = 16 RT bytes per c8
+// factor(jj, c) = down[jj, c] (FACTOR_RK) or up[c, jj] (FACTOR_KR).  A k-step's fragment (4 consecutive c8) is 64 RT bytes
+// contiguous; lane (jj = l & 15, q = l >> 4) reads its 16 bytes at (q RT + (jj & (RT - 1))) * 16: rank rows beyond the tile
+// REPEAT the tile's rows (third session of round 6: a rank-4 fragment is 256 B instead of 1 KB with three quarters of zeros —
+// the fragments were half as many L2 -> L1 bytes as the data).  The repeated rows give T columns j >= RT that copy live ones:
+// never stored (slabs hold RT rows), and of the same magnitude, which is what the f16 block scale looks at.
 // f16 only: the power of two that brings the largest |factor| of a (site, side) into [2^11, 2^12) and its inverse, as two
-// floats in the 16-byte tail of the pack ([2][C/8][16][8] elements, then the tail).  One workgroup per (site, side).
+// floats in the 16-byte tail of the pack ([2][C/8][RT][8] elements, then the tail).  One workgroup per (site, side).
 __device__ __forceinline__ float fm_wave_max(float m) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -92,6 +96,7 @@ __device__ __forceinline__ void fm_pow2_scale(float mx, int top, float &scale, f
   inv = __uint_as_float((uint32_t)(ex - top) << 23);
 }
 constexpr int kFmFactorTop = 11, kFmTTop = 14;
+__host__ __device__ inline int fm_rank_tile(int r) { return r <= 4 ? 4 : r <= 8 ? 8 : 16; }
 __global__ __launch_bounds__(256) void factor_absmax_kernel(const lora_amd_pack_site *__restrict__ sites, int n) {
   __shared__ float s_m[4];
   const lora_amd_pack_site q = sites[blockIdx.x >> 1];
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256) void factor_absmax_kernel(const lora_amd_pack_
     m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     float sc, inv;
     fm_pow2_scale(m, kFmFactorTop, sc, inv);
-    float *tail = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(is_up ? q.pk_up : q.pk_down) + (int64_t)C * 32);
+    const int RT = fm_rank_tile(q.r);
+    float *tail = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(is_up ? q.pk_up : q.pk_down) + (int64_t)C * 2 * RT);
     gl(tail)[0] = sc; gl(tail)[1] = inv; gl(tail)[2] = 0.f; gl(tail)[3] = 0.f;
   }
 }
@@ -124,11 +130,12 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
       if (sites[mid].begin <= i) lo = mid; else hi = mid - 1;
     }
     const lora_amd_pack_site q = sites[lo];
-    int64_t p = i - q.begin;                 // piece = (side, c8, jj): down side first
-    const int64_t nd = (int64_t)(q.K >> 3) * 16;
+    const int RT = fm_rank_tile(q.r), rts = RT == 4 ? 2 : RT == 8 ? 3 : 4;
+    int64_t p = i - q.begin;                 // piece = (side, c8, jj < RT): down side first
+    const int64_t nd = (int64_t)(q.K >> 3) * RT;
     const bool is_up = p >= nd;
     if (is_up) p -= nd;
-    const int c8 = (int)(p >> 4), jj = (int)(p & 15);
+    const int c8 = (int)(p >> rts), jj = (int)(p & (RT - 1));
     const int C = is_up ? q.N : q.K;
     float v[8];
 #pragma unroll
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
     }
     S *dst = reinterpret_cast<S *>(is_up ? q.pk_up : q.pk_down);
     if constexpr (kScaled) {   // the tail factor_absmax_kernel wrote in the launch before this one
-      const float fs = gl(reinterpret_cast<const float *>(dst + (int64_t)C * 32))[0];
+      const float fs = gl(reinterpret_cast<const float *>(dst + (int64_t)C * 2 * RT))[0];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= fs;
     }
@@ -155,11 +162,11 @@ __global__ __launch_bounds__(256) void factor_pack_kernel(const lora_amd_pack_si
       h.v[e] = E::from_f(v[e]);
       l.v[e] = E::from_f(v[e] - E::to_f(h.v[e]));
     }
-    const int64_t split_stride = (int64_t)(C >> 3) * 128;  // elements per split
+    const int64_t split_stride = (int64_t)(C >> 3) * RT * 8;  // elements per split
     union { Chunk8<E> c; mu32x4 u; } hb, lb;
     hb.c = h; lb.c = l;
-    *gl(reinterpret_cast<mu32x4 *>(dst + ((int64_t)c8 * 16 + jj) * 8)) = hb.u;
-    *gl(reinterpret_cast<mu32x4 *>(dst + split_stride + ((int64_t)c8 * 16 + jj) * 8)) = lb.u;
+    *gl(reinterpret_cast<mu32x4 *>(dst + ((int64_t)c8 * RT + jj) * 8)) = hb.u;
+    *gl(reinterpret_cast<mu32x4 *>(dst + split_stride + ((int64_t)c8 * RT + jj) * 8)) = lb.u;
   }
 }
 
@@ -247,7 +254,7 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   const int64_t m0 = rb * R;
   const int nrows = (int)min((int64_t)R, sd.M - m0);
   const bool ax = sd.resident_is_x != 0;
-  const int RT = sd.r <= 4 ? 4 : sd.r <= 8 ? 8 : 16;
+  const int RT = fm_rank_tile(sd.r);
   const S *da = reinterpret_cast<const S *>(ax ? sd.x : sd.g), *db = reinterpret_cast<const S *>(ax ? sd.g : sd.x);
   const int64_t lda = ax ? sd.ldx : sd.ldg, ldb = ax ? sd.ldg : sd.ldx;
   const int Ca = ax ? sd.K : sd.N, Cb = ax ? sd.N : sd.K;
@@ -256,7 +263,7 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   const FmHeads hdb{(uint32_t)(ax ? sd.g_head_magic : sd.x_head_magic), (ax ? sd.g_head_dim : sd.x_head_dim) >> 3,
                     (ax ? sd.g_head_pad : sd.x_head_pad) >> 3};
   const S *pka = reinterpret_cast<const S *>(ax ? sd.pk_down : sd.pk_up), *pkb = reinterpret_cast<const S *>(ax ? sd.pk_up : sd.pk_down);
-  const int64_t splita = (int64_t)(Ca >> 3) * 128, splitb = (int64_t)(Cb >> 3) * 128;
+  const int64_t splita = (int64_t)(Ca >> 3) * RT * 8, splitb = (int64_t)(Cb >> 3) * RT * 8;   // elements per split
   float finv_a = 1.f, finv_b = 1.f;   // f16: 1 / (the power of two the pack multiplied the factor by)
   if constexpr (kScaled) {
     finv_a = gl(reinterpret_cast<const float *>(pka + 2 * splita))[1];
@@ -301,9 +308,10 @@ __device__ __forceinline__ void fm_block(const lora_amd_fm_site &sd, const FmSme
   };
   const unsigned char *pkbh = reinterpret_cast<const unsigned char *>(pkb), *pkbl = reinterpret_cast<const unsigned char *>(pkb + splitb);
   const unsigned char *pkah = reinterpret_cast<const unsigned char *>(pka), *pkal = reinterpret_cast<const unsigned char *>(pka + splita);
-  const uint32_t lane16 = (uint32_t)lane * 16u;
-  auto frag = [&](const unsigned char *pk, int cg) -> mu32x4 {   // a k-step's fragment: 1 KB, lane l its 16 bytes at 16 l
-    return *gl(reinterpret_cast<const mu32x4 *>(pk + ((uint32_t)cg * 1024u + lane16)));
+  // a k-step's fragment: 64 RT bytes; lane (jj, q) its 16 bytes at (q RT + jj mod RT) * 16 (RT = 16: 16 l)
+  const uint32_t lane16 = (uint32_t)(q * RT + (jj & (RT - 1))) * 16u, fragb = (uint32_t)RT * 64u;
+  auto frag = [&](const unsigned char *pk, int cg) -> mu32x4 {
+    return *gl(reinterpret_cast<const mu32x4 *>(pk + ((uint32_t)cg * fragb + lane16)));
   };
   // slabs: [RT][C] floats per block and operand; lane (j = jj, columns 4 q ..) of a group's two 16-column tiles
   float *outa = (ax ? sd.down_part : sd.up_part) + rb * RT * (int64_t)Ca;
@@ -684,8 +692,8 @@ extern "C" int lora_amd_factors_mfma_plan(int64_t M, int32_t K, int32_t N, int32
   out->lds_bytes = g.lds;
   out->up_part_floats = (int64_t)out->nparts * out->rank_tile * N;
   out->down_part_floats = (int64_t)out->nparts * out->rank_tile * K;
-  out->pack_up_elems = (int64_t)N * 32 + 8;    // [2][N/8][16][8] + the 16-byte tail (f16: the pack's power-of-two scale)
-  out->pack_down_elems = (int64_t)K * 32 + 8;
+  out->pack_up_elems = (int64_t)N * 2 * out->rank_tile + 8;    // [2][N/8][RT][8] + the 16-byte tail (f16: the pack's power-of-two scale)
+  out->pack_down_elems = (int64_t)K * 2 * out->rank_tile + 8;
   return LORA_AMD_OK;
 }
 
@@ -700,7 +708,7 @@ extern "C" int lora_amd_factor_pack_plan(lora_amd_pack_site *sites, int32_t n, i
                        ((uintptr_t)q.pk_up % 16) == 0,
                    LORA_AMD_EINVAL, "factor_pack_plan: site %d: N, K must be multiples of 32, packs 16-byte aligned", i);
     q.begin = begin;
-    begin += (int64_t)((q.N + q.K) >> 3) * 16;
+    begin += (int64_t)((q.N + q.K) >> 3) * fm_rank_tile(q.r);
   }
   *total = begin;
   return LORA_AMD_OK;

@@ -34,7 +34,7 @@ def test_planner_geometry_fits_the_lds_and_matches_the_model(M, K, N, r):
     nrb = -(-M // pl.rows_per_block)
     assert 1 <= pl.blocks_per_wg <= min(8, nrb) and pl.nparts == -(-nrb // pl.blocks_per_wg)
     assert pl.up_part_floats == pl.nparts * pl.rank_tile * N and pl.down_part_floats == pl.nparts * pl.rank_tile * K
-    assert pl.pack_up_elems == 32 * N + 8 and pl.pack_down_elems == 32 * K + 8  # + the 16-byte scale tail (f16)
+    assert pl.pack_up_elems == 2 * pl.rank_tile * N + 8 and pl.pack_down_elems == 2 * pl.rank_tile * K + 8  # + the 16-byte scale tail (f16)
     assert pl.rows_per_block * min(K, N) <= (10 if pl.lds_class == 1 else 20) * 2048  # the next block waits in registers
     g = fm_model.geometry(M, K, N, pl.rows_per_block, cap)
     assert g is not None and g["lds"] == pl.lds_bytes
