@@ -437,10 +437,15 @@ __global__ __launch_bounds__(kR16Threads) void bwd_g16_mfma_kernel(
 // LO = false (round 6): the hi plane alone (X ~ hi to 8 mantissa bits) at half the bytes — the power iterations of the
 // subspace iteration only steer a subspace (an O(2^-9) perturbation of it costs the rank-r Frobenius error to second order);
 // the pass that forms the returned factors (b = Q^T dW) reads both planes.
+// Slabs per wave (third session of round 6): a k-step's packed factor fragments are 2 KB (hi | lo) against 1 KB of hi-plane data
+// per 16-row slab — two thirds of what a wave pulls through the CU's load path were fragments.  A wave now multiplies kPlNS
+// consecutive slabs against each fragment pair (the plan sizes the workgroups: slabs_per_wg = kPlNS * 16 / wps).
+constexpr int kPlNS = 2;
 template <class E, bool PK, bool LO = true, bool ROWLD = false>
 __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_planes_desc *__restrict__ descs, int n, int r) {
   using S = typename E::storage;
-  __shared__ __attribute__((aligned(16))) float s_red[16 * 4 * 64];
+  constexpr int NS = kPlNS;
+  __shared__ __attribute__((aligned(16))) float s_red[16 * NS * 4 * 64];
   __shared__ int64_t s_begin[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15, q = lane >> 4;
   int lo = 0, hi = n - 1;
@@ -458,31 +463,57 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
     }
   }
   const lora_amd_planes_desc d = descs[lo];
-  const int wps = d.wps, spw = 16 / wps;
+  const int wps = d.wps, spw = NS * (16 / wps);   // == d.slabs_per_wg (lora_amd_rowdot16_planes_plan)
   const int64_t nslabs = (d.M + 15) >> 4, wgs_per = (nslabs + spw - 1) / spw;
   const int64_t wg = (int64_t)blockIdx.x - d.wg_begin;
   const int64_t b = wg / wgs_per;
   const int sl = wave / wps, cw = wave - sl * wps;
-  const int64_t slab = (wg - b * wgs_per) * spw + sl;
-  const int64_t m0 = slab * 16;
-  const bool active = slab < nslabs;
+  const int64_t slab0 = (wg - b * wgs_per) * spw + (int64_t)sl * NS;   // this wave's NS consecutive slabs
   const int C = d.C, nks = C >> 5;
-  const int64_t row = m0 + jj;
-  const bool rok = active && row < d.M;
-  const int64_t base = (b * d.M + (rok ? row : 0)) * (int64_t)C + 8 * q;
-  const S *xh = reinterpret_cast<const S *>(d.hi) + base, *xl = reinterpret_cast<const S *>(d.lo) + base;
   const float *f = d.f + b * (int64_t)C * r;
   const S *pk = reinterpret_cast<const S *>(d.f) + b * (int64_t)C * 32 + lane * 8;   // PK: [C / 32][hi 512 | lo 512] elements
-  mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (active) {
+  mf32x4 accs[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) accs[s] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  const bool active = slab0 < nslabs;
+  if constexpr (!PK) {
+    // the f32-factor form (tests, the non-thin path): slab by slab
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int64_t m0 = (slab0 + s) * 16;
+      const int64_t row = m0 + jj;
+      const bool rok = slab0 + s < nslabs && row < d.M;
+      const int64_t base = (b * d.M + (rok ? row : 0)) * (int64_t)C + 8 * q;
+      const S *xh = reinterpret_cast<const S *>(d.hi) + base, *xl = reinterpret_cast<const S *>(d.lo) + base;
+      auto piece = [&](const S *p, int ks) -> mu32x4 {
+        return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(p + (int64_t)ks * 32)) : r16_zero();
+      };
+      mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (slab0 + s < nslabs) {
+        mu32x4 h0 = piece(xh, cw), l0 = piece(xl, cw), h1 = piece(xh, cw + wps), l1 = piece(xl, cw + wps);
+        R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
+#pragma unroll 1
+        for (int ks = cw; ks < nks; ks += wps) {
+          const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
+          mu32x4 fh, fl;
+          r16_factor_split<E>(fr, 1.0f, fh, fl);
+          if (ks + wps < nks) fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (ks + wps) * 32);
+          mu32x4 ch = h0, cl = l0;
+          if (!rok) { ch = r16_zero(); cl = r16_zero(); }
+          acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
+          acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
+          acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+          h0 = h1; l0 = l1; h1 = h2; l1 = l2;
+        }
+      }
+      accs[s] = acc;
+    }
+  }
+  if (PK && active) {
     auto piece = [&](const S *p, int ks) -> mu32x4 {
       return ks < nks ? *gl(reinterpret_cast<const mu32x4 *>(p + (int64_t)ks * 32)) : r16_zero();
     };
-    auto piece_lo = [&](int ks) -> mu32x4 {
-      if constexpr (LO) return piece(xl, ks);
-      else return r16_zero();
-    };
-    if constexpr (PK) {
+    {
       // Round 6: a piece (16 rows x 64 bytes) is FETCHED four lanes per row (row l >> 2, chunk l & 3) and brought into the MFMA
       // operand order (row l & 15, chunk l >> 4) by four ds_bpermute_b32: the operand order's 64 scattered 16-byte accesses go
       // through the L1 tag pipeline one lane per cycle (scripts/ld_shape_probe.hip: 9.7 TB/s from cache against 23-28 for
@@ -490,10 +521,16 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
       // (The factor pass's other finding — static slots instead of the rotating h0 = h1 = h2 — does NOT carry over: a wave
       // here has two or three k-steps, an unrolled three-slot loop runs up to two dead ones; it measured 25 % slower.)
       const int lr = ROWLD ? lane >> 2 : jj, lc = ROWLD ? lane & 3 : q;
-      const int64_t lrow = m0 + lr;
-      const bool lrok = active && lrow < d.M;
-      const int64_t lbase = (b * d.M + (lrok ? lrow : 0)) * (int64_t)C + 8 * lc;
-      const S *ph = reinterpret_cast<const S *>(d.hi) + lbase, *pl = reinterpret_cast<const S *>(d.lo) + lbase;
+      const S *ph[NS], *pl[NS];
+      bool lrok[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int64_t lrow = (slab0 + s) * 16 + lr;
+        lrok[s] = slab0 + s < nslabs && lrow < d.M;
+        const int64_t lbase = (b * d.M + (lrok[s] ? lrow : 0)) * (int64_t)C + 8 * lc;
+        ph[s] = reinterpret_cast<const S *>(d.hi) + lbase;
+        pl[s] = reinterpret_cast<const S *>(d.lo) + lbase;
+      }
       const int src = ((jj << 2) | q) << 2;   // byte address of the source lane for ds_bpermute: lane (row jj, chunk q) = 4 jj + q
       auto to_operand = [&](mu32x4 v) -> mu32x4 {
         if constexpr (!ROWLD) return v;
@@ -502,66 +539,68 @@ __global__ __launch_bounds__(1024) void rowdot16_planes_kernel(const lora_amd_pl
         for (int i = 0; i < 4; ++i) o[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v[i]);
         return o;
       };
-      auto lpiece_lo = [&](int ks) -> mu32x4 {
-        if constexpr (LO) return piece(pl, ks);
+      auto lpiece_lo = [&](int s, int ks) -> mu32x4 {
+        if constexpr (LO) return piece(pl[s], ks);
         else return r16_zero();
       };
-      mu32x4 h0 = piece(ph, cw), l0 = lpiece_lo(cw), h1 = piece(ph, cw + wps), l1 = lpiece_lo(cw + wps);
+      mu32x4 h0[NS], l0[NS], h1[NS], l1[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        h0[s] = piece(ph[s], cw); l0[s] = lpiece_lo(s, cw);
+        h1[s] = piece(ph[s], cw + wps); l1[s] = lpiece_lo(s, cw + wps);
+      }
       auto frag = [&](int ks, int part) -> mu32x4 {
         return *gl(reinterpret_cast<const mu32x4 *>(pk + (int64_t)(ks < nks ? ks : 0) * 1024 + part * 512));
       };
       mu32x4 fh = frag(cw, 0), fl = frag(cw, 1);
 #pragma unroll 1
       for (int ks = cw; ks < nks; ks += wps) {
-        const mu32x4 h2 = piece(ph, ks + 2 * wps), l2 = lpiece_lo(ks + 2 * wps);
+        mu32x4 h2[NS], l2[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { h2[s] = piece(ph[s], ks + 2 * wps); l2[s] = lpiece_lo(s, ks + 2 * wps); }
         const mu32x4 nfh = frag(ks + wps, 0), nfl = frag(ks + wps, 1);
-        mu32x4 ch = h0, cl = l0;
-        if (!lrok) { ch = r16_zero(); cl = r16_zero(); }
-        ch = to_operand(ch);
-        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
-        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
-        if constexpr (LO) {
-          cl = to_operand(cl);
-          acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          mu32x4 ch = h0[s], cl = l0[s];
+          if (!lrok[s]) { ch = r16_zero(); cl = r16_zero(); }
+          ch = to_operand(ch);
+          accs[s] = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), accs[s]);
+          accs[s] = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), accs[s]);
+          if constexpr (LO) {
+            cl = to_operand(cl);
+            accs[s] = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), accs[s]);
+          }
+          h0[s] = h1[s]; l0[s] = l1[s]; h1[s] = h2[s]; l1[s] = l2[s];
         }
-        h0 = h1; l0 = l1; h1 = h2; l1 = l2;
         fh = nfh; fl = nfl;
-      }
-    } else {
-      mu32x4 h0 = piece(xh, cw), l0 = piece_lo(cw), h1 = piece(xh, cw + wps), l1 = piece_lo(cw + wps);
-      R16Raw fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (cw < nks ? cw : 0) * 32);
-#pragma unroll 1
-      for (int ks = cw; ks < nks; ks += wps) {
-        const mu32x4 h2 = piece(xh, ks + 2 * wps), l2 = piece(xl, ks + 2 * wps);
-        mu32x4 fh, fl;
-        r16_factor_split<E>(fr, 1.0f, fh, fl);
-        if (ks + wps < nks) fr = r16_factor_load(f, LORA_AMD_FACTOR_KR, r, C, (ks + wps) * 32);
-        mu32x4 ch = h0, cl = l0;
-        if (!rok) { ch = r16_zero(); cl = r16_zero(); }
-        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fh), acc);
-        acc = FmMfma<E>::mma(fm_frag<E>(ch), fm_frag<E>(fl), acc);
-        acc = FmMfma<E>::mma(fm_frag<E>(cl), fm_frag<E>(fh), acc);
-        h0 = h1; l0 = l1; h1 = h2; l1 = l2;
       }
     }
   }
   if (wps > 1) {
     if (cw > 0) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) s_red[(wave * 4 + reg) * 64 + lane] = acc[reg];
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) s_red[((wave * NS + s) * 4 + reg) * 64 + lane] = accs[s][reg];
     }
     __syncthreads();
     if (cw > 0) return;
     for (int k = 1; k < wps; ++k)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) acc[reg] += s_red[((wave + k) * 4 + reg) * 64 + lane];
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) accs[s][reg] += s_red[(((wave + k) * NS + s) * 4 + reg) * 64 + lane];
   }
-  if (active && jj < r) {
+  if (jj < r) {
     float *o = d.out + b * d.M * r;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t rw = m0 + 4 * q + reg;
-      if (rw < d.M) o[rw * r + jj] = acc[reg];
+    for (int s = 0; s < NS; ++s) {
+      if (slab0 + s >= nslabs) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t rw = (slab0 + s) * 16 + 4 * q + reg;
+        if (rw < d.M) o[rw * r + jj] = accs[s][reg];
+      }
     }
   }
 }
@@ -745,7 +784,7 @@ extern "C" int lora_amd_rowdot16_planes_plan(lora_amd_planes_desc *descs, int32_
     int wps = 1;
     while (wps < 16 && nks / (2 * wps) >= 4) wps *= 2;
     d.wps = wps;
-    d.slabs_per_wg = 16 / wps;
+    d.slabs_per_wg = kPlNS * (16 / wps);   // a wave multiplies kPlNS consecutive slabs against each fragment pair
     const int64_t nslabs = (d.M + 15) / 16;
     d.wg_begin = begin;
     begin += d.batch * ((nslabs + d.slabs_per_wg - 1) / d.slabs_per_wg);
