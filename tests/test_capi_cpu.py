@@ -267,3 +267,42 @@ def test_matrix_core_factor_plan_prefers_64_row_blocks_for_the_register_kernel()
         assert pl.supported and pl.rows_per_block == rows and pl.blocks_per_wg == 1 and pl.nparts == -(-M // rows)
         # 20 resident 16-byte pieces per lane over four waves: rows x narrower width / (256 lanes x 8 elements)
         assert rows * min(K, N) <= 20 * 256 * 8
+
+
+def test_block_map_of_a_planned_factor_pass_table_is_host_arithmetic():
+    """ABI 7: lora_amd_factors_mfma_block_map fills block -> site for a table lora_amd_factors_mfma_ragged_plan planned (no GPU
+    involved); an unplanned table is refused; the bytes helper puts the map behind the table at a 16-byte boundary."""
+    import torch
+
+    shapes = [(300, 1280, 1280), (4096, 640, 640), (1000, 640, 5120)]
+    site = (_C.FmSite * len(shapes))()
+    for q, (M, K, N) in zip(site, shapes):
+        pl = _C.factors_mfma_plan(M, K, N, 4, torch.bfloat16)
+        assert pl.supported and pl.lds_class == 2
+        q.g = q.x = q.pk_up = q.pk_down = q.up_part = q.down_part = 4096
+        q.ldg, q.ldx, q.M, q.N, q.K, q.r, q.scale = N, K, M, N, K, 4, 1.0
+        q.rows_per_block, q.blocks_per_wg = pl.rows_per_block, pl.blocks_per_wg
+    grid = C.c_int64(0)
+    assert _C.require().lora_amd_factors_mfma_ragged_plan(site, len(shapes), _C.BF16, 2, C.byref(grid)) == 0
+    m = list(_C.factors_mfma_block_map(site, grid.value))
+    assert len(m) == grid.value and m == sorted(m) and set(m) == {0, 1, 2}
+    for i, q in enumerate(site):
+        assert m.index(i) == q.block_begin
+    raw, off = _C.factors_mfma_table_bytes(site, grid.value)
+    assert off % 16 == 0 and off >= C.sizeof(_C.FmSite) * len(shapes) and len(raw) == off + 4 * grid.value
+    with pytest.raises(Exception):
+        _C.factors_mfma_block_map((_C.FmSite * 2)(), 8)
+
+
+def test_ws_head_layout_rules():
+    """ABI 7: which head layouts the weight-stationary kernel's dropout instantiations take (lora_amd_linear_ws_heads /
+    lora_amd_ws_site.y_heads): input heads in 16-byte chunks, output pad no wider than the head and at least half of it, whole
+    panels, never both."""
+    assert _C.ws_heads_ok(320, 320, (8, 40, 64), None) and _C.ws_heads_ok(320, 320, None, (8, 40, 64))
+    assert _C.ws_heads_ok(640, 640, None, (8, 80, 128)) and _C.ws_heads_ok(1280, 1280, None, (8, 160, 256))
+    assert not _C.ws_heads_ok(320, 320, (8, 40, 64), (8, 40, 64))          # both in one launch
+    assert not _C.ws_heads_ok(768, 320, None, (8, 40, 64))                 # 320 columns are not whole 128-column panels at K = 768
+    assert not _C.ws_heads_ok(320, 320, None, (8, 40, 128))                # pad wider than the head
+    assert not _C.ws_heads_ok(320, 320, None, (10, 32, 40))                # head more than twice the pad
+    assert not _C.ws_heads_ok(320, 320, (8, 36, 64), None) and not _C.ws_heads_ok(320, 320, (4, 40, 64), None)
+    assert C.sizeof(_C.WsSite) == 112 and _C.WsSite.y_heads.offset == 84
