@@ -113,3 +113,43 @@ def test_upl_merges_lora_into_model(tmp_path):
     base = tiny_unet().state_dict()
     moved = [k for k in sd if k in base and not torch.equal(sd[k], base[k])]
     assert moved and all(k.endswith("weight") for k in moved)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_manager_composition_of_one_site_on_device_vs_the_oracle(tmp_path, dt):
+    """Multi-LoRA composition (lora_manager.py:13-71 ``lora_join`` + :122-131 ``tune`` -> lora.py:63-70 ``set_selector_from_diag``)
+    at ONE Linear site, against oracle/lora_numpy directly: two member LoRAs of ranks 2 and 3 joined to rank 5 (down rows / up
+    columns concatenated, as the join does), weights 0.5 and 2.0 repeated over the members' rank slices, the diagonal selector
+    applied INSIDE the device kernels — vs oracle.lora_linear_forward(selector = diag) and vs the weighted sum of the two members'
+    own branches (the statement the manager makes)."""
+    from oracle import lora_numpy as O
+    from tests.test_gpu_kernels import close, n, rnd
+
+    DEV = "cuda:0"
+    M, K, N, s = 300, 320, 640, 0.7
+    name = "f32" if dt == torch.float32 else "bf16"
+    x = rnd((M, K), name, seed=1)
+    w, b = rnd((N, K), name, 0.05, seed=2), rnd((N,), name, seed=3)
+    downs = [rnd((2, K), "f32", 0.3, seed=4), rnd((3, K), "f32", 0.3, seed=5)]
+    ups = [rnd((N, 2), "f32", 0.2, seed=6), rnd((N, 3), "f32", 0.2, seed=7)]
+    scales, ranklist = [0.5, 2.0], [2, 3]
+    m = L.LoraInjectedLinear(K, N, True, r=5, dropout_p=0.0, scale=s).to(DEV)
+    m.linear.weight.data.copy_(w.float()), m.linear.bias.data.copy_(b.float())
+    if dt != torch.float32:
+        m.linear.to(dt)
+    m.lora_down.weight.data.copy_(torch.cat(downs, 0))
+    m.lora_up.weight.data.copy_(torch.cat(ups, 1))
+    diag = torch.repeat_interleave(torch.tensor(scales), torch.tensor(ranklist))   # LoRAManager.tune
+    m.set_selector_from_diag(diag)
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+    X, W, Bv = n(x), n(w), n(b)
+    A_, U_ = np.concatenate([n(d) for d in downs], 0), np.concatenate([n(u) for u in ups], 1)
+    yo, _ = O.lora_linear_forward(X, W, Bv, A_, U_, s, selector=np.diag(n(diag)))
+    # ... which is the weighted sum of the members' branches on top of the frozen layer
+    y_sum = X @ W.T + Bv + s * sum(a * (X @ n(d).T) @ n(u).T for a, d, u in zip(scales, downs, ups))
+    np.testing.assert_allclose(yo, y_sum, rtol=2e-5, atol=2e-5 * np.abs(y_sum).max())
+    absy = np.abs(X) @ np.abs(W).T + np.abs(Bv) + s * (np.abs(X) @ np.abs(A_).T * np.abs(n(diag))) @ np.abs(U_).T
+    close(n(y), yo, absy, name, k=2.0 if dt != torch.float32 else 2e-5, msg="y")
